@@ -1,0 +1,331 @@
+"""Generate golden vectors by executing the REFERENCE's own source under import shims.
+
+Runs ONLY in the build container (needs /root/reference); never at test/bench time.  Third-party
+packages the reference imports (padertorch, paderbox, sed_scores_eval, torchvision, ...) are absent,
+so they are replaced by stub modules; the few third-party helpers the reference-owned maths calls
+(compute_mask, TakeLast/Mean/Sum/Max, Pad) are the oracle's restatements.  What is
+pinned is therefore the reference-OWNED code:  pb_sed/models/weak_label/crnn.py (review, losses,
+heads), pb_sed/models/strong_label/crnn.py (review), pb_sed/filters.py,
+pb_sed/models/base/inference.py (inference, filtering, boundariesfilt).
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py   ->  tests/golden/ref_*.npz
+No reference source is copied; only input/output arrays are stored.
+"""
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import numpy as np
+import scipy.signal  # noqa: F401  (import before aliasing np.bool, see SURVEY 8c gotchas)
+import torch
+
+np.int = int      # reference uses removed numpy aliases (inference.py:103-104, crnn.py:252)
+np.bool = bool
+
+from oracle import nn as onn                     # noqa: E402
+from oracle.frontend import compute_mask          # noqa: E402
+from tests.stubs import StubRNN, StubFeatures, StubCNN  # noqa: E402
+
+STUB_ROOTS = ('padertorch', 'paderbox', 'sed_scores_eval', 'torchvision', 'lazy_dataset', 'sacred',
+              'codecarbon', 'tensorboardX')
+
+
+class _Anything:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Anything()
+
+    def __getattr__(self, name):
+        return _Anything()
+
+
+class _StubModule(types.ModuleType):
+    __path__ = []
+
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return _Anything
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split('.')[0] in STUB_ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        return _StubModule(spec.name)
+
+    def exec_module(self, module):
+        pass
+
+
+sys.meta_path.insert(0, _Finder())
+import padertorch                                              # noqa: E402
+import padertorch.ops.sequence.mask as pt_mask                 # noqa: E402
+import padertorch.contrib.je.modules.reduce as pt_reduce       # noqa: E402
+import padertorch.contrib.je.modules.conv as pt_conv           # noqa: E402
+import paderbox.array as pb_array                              # noqa: E402
+import paderbox.array.segment as pb_segment                    # noqa: E402
+
+
+class _Model(torch.nn.Module):
+    def example_to_device(self, example, device=None):
+        return example
+
+
+def _segment_axis(x, length, shift, axis=-1, end='cut', pad_mode=None):
+    x = np.asarray(x)
+    axis %= x.ndim
+    xm = np.moveaxis(x, axis, 0)
+    n = (xm.shape[0] - length) // shift + 1
+    out = np.stack([xm[i * shift:i * shift + length] for i in range(n)])  # [n, length, ...]
+    return np.moveaxis(out, (0, 1), (axis, axis + 1))
+
+
+padertorch.Model = _Model
+pt_mask.compute_mask = compute_mask
+for _n in ('TakeLast', 'Mean', 'Sum', 'Max'):
+    setattr(pt_reduce, _n, getattr(onn, _n))
+pt_conv.Pad = onn.Pad
+pb_array.segment_axis = _segment_axis
+pb_segment.segment_axis = _segment_axis
+
+sys.path.insert(0, '/root/reference')
+from pb_sed.models.weak_label.crnn import CRNN as RefFBCRNN     # noqa: E402
+from pb_sed.models.strong_label.crnn import CRNN as RefBiCRNN   # noqa: E402
+from pb_sed import filters as ref_filters                       # noqa: E402
+import pb_sed.models.base                                      # noqa: E402
+ref_inf = sys.modules['pb_sed.models.base.inference']   # (the package re-exports a function of this name)
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+
+def make_targets(rng, b, k, t, seq_len, unlabeled_rows=(), weak_only_rows=()):
+    """Targets shaped like pb_sed/data_preparation/transform.py:56-124 (values in {0,.5,1})."""
+    weak = (rng.random((b, k)) < .3).astype(np.float32)
+    for i in range(b):
+        if weak[i].sum() == 0:
+            weak[i, rng.integers(k)] = 1
+    bnd = np.zeros((b, k, t), np.float32)
+    for i in range(b):
+        for c in range(k):
+            if weak[i, c] and i not in weak_only_rows:
+                on = rng.integers(0, max(seq_len[i] - 4, 1))
+                off = min(on + rng.integers(2, 12), seq_len[i])
+                bnd[i, c, on:off] = 1
+            elif weak[i, c]:
+                bnd[i, c, :seq_len[i]] = .5     # weakly labelled class: 0.5 over the clip
+    for i in unlabeled_rows:
+        weak[i] += (1 - weak[i]) * .5
+        bnd[i] += (1 - bnd[i]) * .5
+    return weak, bnd
+
+
+def gen_fbcrnn_loss():
+    rng = np.random.default_rng(11)
+    cases = {}
+    specs = [
+        dict(name='ragged_strong', b=6, k=10, t=50, ragged=True, bwd=True, kw={}),
+        dict(name='full_len', b=4, k=10, t=40, ragged=False, bwd=True, kw={}),
+        dict(name='no_bwd', b=5, k=10, t=30, ragged=True, bwd=False, kw={}),
+        dict(name='slat', b=5, k=10, t=30, ragged=True, bwd=True, kw=dict(slat=True)),
+        dict(name='weak_only', b=5, k=10, t=30, ragged=True, bwd=True,
+             kw=dict(strong_fwd_bwd_loss_weight=0.)),
+        dict(name='half_weight_smooth', b=5, k=7, t=33, ragged=True, bwd=True,
+             kw=dict(strong_fwd_bwd_loss_weight=.5, label_smoothing=.05)),
+        dict(name='class_weights', b=4, k=6, t=20, ragged=True, bwd=True,
+             kw=dict(class_weights=[1., 2., .5, 1., 3., 1.])),
+    ]
+    for s in specs:
+        b, k, t = s['b'], s['k'], s['t']
+        seq_len = np.sort(rng.integers(t // 2, t + 1, b))[::-1].copy() if s['ragged'] \
+            else np.full(b, t)
+        seq_len[0] = t
+        weak, bnd = make_targets(rng, b, k, t, seq_len, unlabeled_rows=(b - 1,),
+                                 weak_only_rows=(1,))
+        yf = torch.tensor(rng.uniform(1e-5, 1 - 1e-5, (b, k, t)).astype(np.float32),
+                          requires_grad=True)
+        yb = torch.tensor(rng.uniform(1e-5, 1 - 1e-5, (b, k, t)).astype(np.float32),
+                          requires_grad=True) if s['bwd'] else None
+        m = RefFBCRNN(None, None, None, None, **s['kw'])
+        m.train()
+        inputs = {'seq_len': seq_len.tolist()}
+        outputs = (yf, yb, seq_len, torch.zeros(b, 1, 4, t), seq_len,
+                   (torch.tensor(weak), torch.tensor(bnd)))
+        review = m.review(inputs, outputs)
+        review['loss'].backward()
+        n = s['name']
+        cases.update({
+            f'{n}/y_fwd': yf.detach().numpy(), f'{n}/seq_len': seq_len,
+            f'{n}/weak_targets': weak, f'{n}/boundary_targets': bnd,
+            f'{n}/loss': review['loss'].detach().numpy(),
+            f'{n}/grad_y_fwd': yf.grad.numpy(),
+            f'{n}/y_weak': review['buffers']['y_weak'],
+            f'{n}/targets_weak': review['buffers']['targets_weak'],
+            f'{n}/weak_label_rate': np.float64(review['scalars']['weak_label_rate']),
+            f'{n}/boundary_label_rate': np.float64(review['scalars']['boundary_label_rate']),
+            f'{n}/kw': np.array(repr(s['kw'])),
+        })
+        if yb is not None:
+            cases.update({f'{n}/y_bwd': yb.detach().numpy(), f'{n}/grad_y_bwd': yb.grad.numpy()})
+    np.savez_compressed(os.path.join(OUT, 'ref_fbcrnn_loss.npz'), **cases)
+    print('ref_fbcrnn_loss', {k: float(v) for k, v in cases.items() if k.endswith('/loss')})
+
+
+def gen_bicrnn_loss():
+    rng = np.random.default_rng(12)
+    cases = {}
+    for n, (b, k, t) in {'a': (4, 10, 50), 'b': (3, 5, 21)}.items():
+        seq_len = np.sort(rng.integers(t // 2, t + 1, b))[::-1].copy()
+        seq_len[0] = t
+        weak, st = make_targets(rng, b, k, t, seq_len, unlabeled_rows=(b - 1,))
+        y = torch.tensor(rng.uniform(.001, .999, (b, k, t)).astype(np.float32), requires_grad=True)
+        m = RefBiCRNN(None, None, None, tag_conditioning=True)
+        review = m.review({'seq_len': seq_len.tolist()},
+                          (y, seq_len, torch.zeros(b, 1, 4, t), seq_len,
+                           (torch.tensor(weak), torch.tensor(st))))
+        review['loss'].backward()
+        cases.update({f'{n}/y': y.detach().numpy(), f'{n}/seq_len': seq_len,
+                      f'{n}/strong_targets': st, f'{n}/loss': review['loss'].detach().numpy(),
+                      f'{n}/grad_y': y.grad.numpy(),
+                      f'{n}/y_strong': review['buffers']['y_strong'],
+                      f'{n}/targets_strong': review['buffers']['targets_strong']})
+    np.savez_compressed(os.path.join(OUT, 'ref_bicrnn_loss.npz'), **cases)
+    print('ref_bicrnn_loss', {k: float(v) for k, v in cases.items() if k.endswith('/loss')})
+
+
+def gen_fbcrnn_heads():
+    rng = np.random.default_rng(13)
+    b, c, t, k = 3, 6, 23, 4
+    h = rng.standard_normal((b, c, t)).astype(np.float32)
+    a_f = rng.standard_normal((k, c)).astype(np.float32)
+    a_b = rng.standard_normal((k, c)).astype(np.float32)
+    seq_len = np.array([23, 19, 12])
+    cases = dict(h=h, a_fwd=a_f, a_bwd=a_b, seq_len=seq_len)
+    for bwd in (True, False):
+        m = RefFBCRNN(StubFeatures(), StubCNN(), StubRNN(a_f, False),
+                      StubRNN(a_b, True) if bwd else None)
+        m.eval()
+        tag = 'fb' if bwd else 'f'
+        inputs = {'stft': torch.tensor(h), 'seq_len': seq_len.tolist()}
+        with torch.no_grad():
+            y, sl = m.tagging(dict(inputs))
+            cases[f'{tag}/tagging'], cases[f'{tag}/tagging_seq_len'] = y.numpy(), sl
+            if bwd:
+                y, sl = m.boundaries_detection(dict(inputs))
+                cases[f'{tag}/boundaries'] = y.numpy()
+            for wl, ws in ((5, 1), (4, 2), (1, 1), (7, 3)):
+                y, sl = m.sound_event_detection(dict(inputs), wl, ws)
+                cases[f'{tag}/sed_{wl}_{ws}'], cases[f'{tag}/sed_{wl}_{ws}_seq_len'] = y.numpy(), sl
+            wl1 = [3, 5, 3, 9]
+            y, sl = m.sound_event_detection(dict(inputs), wl1, 1)
+            cases[f'{tag}/sed_1d'], cases['wl_1d'] = y.numpy(), np.array(wl1)
+            wl2 = [[3, 5, 3, 9], [5, 5, 7, 3]]
+            y, sl = m.sound_event_detection(dict(inputs), wl2, 2)
+            cases[f'{tag}/sed_2d'], cases['wl_2d'] = y.numpy(), np.array(wl2)
+    np.savez_compressed(os.path.join(OUT, 'ref_fbcrnn_heads.npz'), **cases)
+    print('ref_fbcrnn_heads', sorted(cases))
+
+
+def gen_filters():
+    rng = np.random.default_rng(14)
+    x = rng.random((3, 5, 61)).astype(np.float32)
+    cases = dict(x=x)
+    for n in (1, 3, 5, 11, 41, 101):
+        cases[f'medfilt_{n}'] = ref_filters.medfilt(x.copy(), n, axis=-1)
+    cases['medfilt_axis1_3'] = ref_filters.medfilt(x.copy(), 3, axis=1)
+    for n in (2, 4, 10, 20):
+        cases[f'stepfilt_{n}'] = ref_filters.stepfilt(x.copy(), n, axis=-1)
+    for n in (0, 2, 6, 20):
+        cases[f'boundariesfilt_{n}'] = ref_inf.boundariesfilt(x.copy(), n, axis=-1)
+    l1 = np.array([1, 3, 5, 7, 11])
+    cases['len_1d'] = l1
+    cases['filtering_med_0d'] = ref_inf.filtering(x.copy(), ref_filters.medfilt, np.array(5))
+    cases['filtering_med_1d'] = ref_inf.filtering(x.copy(), ref_filters.medfilt, l1)
+    l2 = np.array([[1, 3, 5, 7, 11], [3, 3, 1, 21, 5]])
+    cases['len_2d'] = l2
+    cases['filtering_med_2d'] = ref_inf.filtering(x.copy(), ref_filters.medfilt, l2)
+    l2b = np.array([[3], [9]])
+    cases['len_2d_bcast'] = l2b
+    cases['filtering_med_2d_bcast'] = ref_inf.filtering(x.copy(), ref_filters.medfilt, l2b)
+    s1 = np.array([0, 2, 4, 10, 6])
+    cases['steplen_1d'] = s1
+    cases['filtering_bnd_1d'] = ref_inf.filtering(x.copy(), ref_inf.boundariesfilt, s1)
+    np.savez_compressed(os.path.join(OUT, 'ref_filters.npz'), **cases)
+    print('ref_filters', {k: (v.dtype.name, v.shape) for k, v in cases.items()})
+
+
+class _FakeModel:
+    def __init__(self, scores, seq_len):
+        self.scores, self.seq_len = scores, seq_len
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def example_to_device(self, ex, device=None):
+        return ex
+
+    def sound_event_detection(self, batch):
+        i = batch['batch_idx']
+        return torch.tensor(self.scores[i]), self.seq_len[i]
+
+    boundaries_detection = sound_event_detection
+    tagging = sound_event_detection
+
+
+def gen_inference():
+    rng = np.random.default_rng(15)
+    n_models, n_batches, b, k, t = 3, 2, 4, 5, 47
+    seq_len = [np.array([47, 40, 33, 20]), np.array([45, 44, 30, 9])]
+    scores = rng.random((n_models, n_batches, b, k, t)).astype(np.float32)
+    ids = [[f'clip{j}_{i}' for i in range(b)] for j in range(n_batches)]
+    tags = {aid: (rng.random(k) < .5).astype(np.float64) for batch in ids for aid in batch}
+    cases = dict(scores=scores, seq_len=np.stack(seq_len), ids=np.array(ids),
+                 tags=np.stack([tags[a] for batch in ids for a in batch]))
+
+    def dataset():
+        return [{'batch_idx': j, 'example_id': ids[j], 'seq_len': seq_len[j].tolist(),
+                 'weak_targets': 0} for j in range(n_batches)]
+    models = [_FakeModel(scores[i], seq_len) for i in range(n_models)]
+
+    def dump(name, out):
+        if isinstance(out, dict):
+            cases[name] = np.concatenate([out[a].reshape(-1) for batch in ids for a in batch])
+            cases[name + '_dtype'] = np.array(out[ids[0][0]].dtype.name)
+            cases[name + '_shape0'] = np.array(out[ids[0][0]].shape)
+
+    dump('sed_med_scalar', ref_inf.sound_event_detection(models, dataset(), None, medfilt_length=5))
+    ml = np.array([[1, 3, 5, 7, 11], [3, 3, 1, 21, 5]])
+    am = np.array([[True, False, True, True, False], [False, False, True, True, True]])
+    cases['medfilt_2d'], cases['apply_mask_2d'] = ml, am
+    dump('sed_med_2d_masked', ref_inf.sound_event_detection(
+        models, dataset(), None, medfilt_length=ml, apply_mask=am, masks=tags))
+    dump('bnd_step', ref_inf.boundaries_detection(
+        models, dataset(), None, stepfilt_length=np.array([0, 2, 4, 10, 6]),
+        apply_mask=True, masks=tags))
+    dump('tagging', ref_inf.tagging(models, dataset(), None))
+    np.savez_compressed(os.path.join(OUT, 'ref_inference.npz'), **cases)
+    print('ref_inference', {k: v.shape for k, v in cases.items()})
+
+
+if __name__ == '__main__':
+    gen_fbcrnn_loss()
+    gen_bicrnn_loss()
+    gen_fbcrnn_heads()
+    gen_filters()
+    gen_inference()
+    assert not os.path.exists('/root/reference/pb_sed/__pycache__'), 'bytecode written to reference'
