@@ -1,0 +1,109 @@
+/* pbsed.h - C-ABI of libpbsed_mi355.so: MI355X (gfx950) kernels for the pb_sed FBCRNN / BiCRNN hot path.
+ *
+ * The reference (fgnt/pb_sed) is pure Python and reaches its kernels through torch ops; it has no FFI of
+ * its own.  Each entry point below therefore replaces a *torch-level op site* of the reference and cites
+ * it (paths relative to the reference repo).  Conventions:
+ *   - all pointers are DEVICE pointers owned by the caller unless marked "host"; the library never frees or
+ *     retains them; `stream` is a hipStream_t (NULL = default stream); every call is asynchronous.
+ *   - activations use the reference layouts: 2-D [B, C, F, T], 1-D [B, C, T] (passed as F = 1);
+ *     GRU scan buffers are time-major [T, B, *].
+ *   - every function returns 0 on success or a negative PBSED_E_* code; pbsed_last_error() returns the
+ *     thread-local message.  No C++ exception crosses the boundary.
+ */
+#ifndef PBSED_H
+#define PBSED_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBSED_OK 0
+#define PBSED_E_ARG (-1)
+#define PBSED_E_HIP (-2)
+#define PBSED_E_UNSUPPORTED (-3)
+
+const char* pbsed_last_error(void);
+int pbsed_version(void);
+
+/* ---- fused front-end.  Replaces the CPU STFT (pb_sed/data_preparation/provider.py:315-323, called at
+ * pb_sed/data_preparation/transform.py:53) + NormalizedLogMelExtractor (pb_sed/models/weak_label/crnn.py:86-90).
+ * wav [B, n_samples] -> out [B, 1, F, T];  window[960], twiddle[1024][2], sparse mel filters
+ * (mel_start/mel_len/mel_off [F], mel_w flat), mean/inv_std [F]; seq_len_frames [B] or NULL. */
+int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, const int* seq_len_frames,
+                     const float* window, const float* twiddle, const int* mel_start, const int* mel_len,
+                     const int* mel_off, const float* mel_w, int F, const float* mean, const float* inv_std,
+                     float eps, float clampv, float* out, void* stream);
+
+/* ---- convolutions (CNN2d 3x3 / CNN1d k=1,3 / GRU input projections / heads): the `self.cnn(...)`,
+ * `self.rnn_*` op sites pb_sed/models/weak_label/crnn.py:93,61-67; layer list
+ * pb_sed/experiments/weak_label_crnn/training.py:159-169,218-260. */
+void pbsed_conv_pack_dims(int KH, int KW, int Cin, int Cout, int dgrad, int* in_padded /*host*/,
+                          int* out_padded /*host*/);
+/* w [Cout,Cin,KH,KW] -> packed [KH*KW][in_padded][out_padded]; dgrad=1 packs the flipped/transposed form. */
+int pbsed_pack_conv_weights(const float* w, float* w_packed, int Cout, int Cin, int KH, int KW, int dgrad,
+                            void* stream);
+/* y = conv(pad(mask(relu(x*scale+shift)))) + bias, optional (2,1) max-pool (pool_idx = argmax row) and
+ * per-channel (or per (channel,f)) masked sum / sum-of-squares of y accumulated into stats [C][2] (double). */
+int pbsed_conv_fwd(const float* x, const float* w_packed, const float* bias, const float* scale,
+                   const float* shift, int relu, const int* seq_len, float* y, unsigned char* pool_idx,
+                   double* stats, int stats_per_cf, int B, int Cin, int Cout, int F, int T, int KH, int KW,
+                   int pool, void* stream);
+int pbsed_conv_bwd_data(const float* g, const float* wd_packed, const unsigned char* unpool_idx,
+                        const int* seq_len, float* dz, const float* bx, const float* bmean,
+                        const float* binvstd, const float* bscale, const float* bshift, int relu,
+                        double* stats, int B, int Cin, int Cout, int F, int T, int KH, int KW, void* stream);
+int pbsed_conv_bwd_weight(const float* x, const float* scale, const float* shift, int relu,
+                          const int* seq_len, const float* g, const unsigned char* unpool_idx, float* dw,
+                          float* db, int B, int Cin, int Cout, int F, int T, int KH, int KW, void* stream);
+
+/* ---- Normalization ('batch', eps 1e-3; pb_sed/experiments/weak_label_crnn/training.py:223-225) */
+int pbsed_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
+                      float momentum, float* running_mean, float* running_power, float* mean, float* invstd,
+                      float* scale, float* shift, int C, void* stream);
+int pbsed_bn_eval_params(const float* gamma, const float* beta, float eps, const float* running_mean,
+                         const float* running_power, float* mean, float* invstd, float* scale, float* shift,
+                         int C, void* stream);
+int pbsed_bn_bwd_finalize(const double* sums, double count, float* dgamma, float* dbeta, float* m1, float* m2,
+                          int C, void* stream);
+int pbsed_bn_bwd_apply(float* dz, const float* x, const float* mean, const float* invstd, const float* scale,
+                       const float* m1, const float* m2, const int* seq_len, int B, int C, int S, int T,
+                       void* stream);
+
+/* ---- GRU recurrence (torch.nn.GRU inside padertorch's GRU wrapper; pb_sed/models/weak_label/crnn.py:61-67,
+ * pb_sed/models/strong_label/crnn.py:92).  Arrays of per-chain pointers are HOST arrays of device pointers. */
+int pbsed_gru_scan_fwd(int nchains, const float* const* gi, const float* const* w_hh, const float* const* b_hh,
+                       float* const* hs, float* const* save, const int* reverse /*host*/,
+                       const int* seq_len, int B, int H, int T, void* stream);
+int pbsed_gru_scan_bwd(int nchains, const float* const* w_hh_t, const float* const* hs,
+                       const float* const* save, const float* const* dy, float* const* dgi, float* const* dgh,
+                       float* const* dhz, const int* reverse /*host*/, const int* seq_len, int B, int H, int T,
+                       void* stream);
+int pbsed_bct_to_tbc(const float* src, float* dst, int B, int C, int T, void* stream);
+int pbsed_tbc_to_bct(const float* src, float* dst, int B, int C, int T, int shift, void* stream);
+int pbsed_transpose2d(const float* src, float* dst, int R, int C, void* stream);
+
+/* ---- heads' squash + losses (pb_sed/models/weak_label/crnn.py:58-59,107-206;
+ * pb_sed/models/strong_label/crnn.py:93,106-112) */
+int pbsed_squash_fwd(const float* x, float* y, size_t n, float eps, void* stream);
+int pbsed_squash_bwd(const float* y, const float* dy, float* dx, size_t n, float eps, void* stream);
+int pbsed_fbcrnn_loss(const float* logit_fwd, const float* logit_bwd, const float* weak_targets,
+                      const float* boundary_targets, const float* class_weights, const int* seq_len,
+                      float* y_fwd, float* y_bwd, float* dlogit_fwd, float* dlogit_bwd, float* loss, int B, int K,
+                      int T, float minimum_score, float strong_weight, int slat, float label_smoothing,
+                      int inputs_are_scores, void* stream);
+int pbsed_bicrnn_loss(const float* logit, const float* strong_targets, const int* seq_len, float* y,
+                      float* dlogit, float* loss, double* scratch, int B, int K, int T, int inputs_are_scores,
+                      void* stream);
+
+/* ---- optimiser (padertorch Adam(lr, gradient_clipping); pb_sed/experiments/weak_label_crnn/training.py:264-269) */
+int pbsed_grad_sumsq(const float* g, size_t n, double* out, void* stream);
+int pbsed_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                    float eps, int step, float grad_scale, float max_norm, const double* sumsq, float* norm_out,
+                    void* stream);
+int pbsed_memset_async(void* p, int value, size_t bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBSED_H */

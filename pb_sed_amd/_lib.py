@@ -1,0 +1,105 @@
+"""ctypes binding of ``libpbsed_mi355.so`` (the C-ABI declared in ``include/pbsed.h``).
+
+The product path has NO fallback: if the shared library is missing or an entry point fails the
+caller gets an exception - never a silent eager/CPU path.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpbsed_mi355.so')
+
+_f = C.POINTER(C.c_float)
+_d = C.POINTER(C.c_double)
+_i = C.POINTER(C.c_int)
+_u8 = C.POINTER(C.c_ubyte)
+_v = C.c_void_p
+_pp = C.POINTER(C.c_void_p)
+I, F32, F64, SZ = C.c_int, C.c_float, C.c_double, C.c_size_t
+
+# name -> argtypes (all return int status unless listed in _NON_STATUS)
+SIGNATURES = {
+    'pbsed_last_error': [],
+    'pbsed_version': [],
+    'pbsed_conv_pack_dims': [I, I, I, I, I, _i, _i],
+    'pbsed_pack_conv_weights': [_v, _v, I, I, I, I, I, _v],
+    'pbsed_conv_fwd': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, I, I, _v],
+    'pbsed_conv_bwd_data': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, _v, I, I, I, I, I, I, I, _v],
+    'pbsed_conv_bwd_weight': [_v, _v, _v, I, _v, _v, _v, _v, _v, I, I, I, I, I, I, I, _v],
+    'pbsed_bn_finalize': [_v, F64, _v, _v, F32, F32, _v, _v, _v, _v, _v, _v, I, _v],
+    'pbsed_bn_eval_params': [_v, _v, F32, _v, _v, _v, _v, _v, _v, I, _v],
+    'pbsed_bn_bwd_finalize': [_v, F64, _v, _v, _v, _v, I, _v],
+    'pbsed_bn_bwd_apply': [_v, _v, _v, _v, _v, _v, _v, _v, I, I, I, I, _v],
+    'pbsed_logmel_fwd': [_v, I, I, I, _v, _v, _v, _v, _v, _v, _v, I, _v, _v, F32, F32, _v, _v],
+    'pbsed_bct_to_tbc': [_v, _v, I, I, I, _v],
+    'pbsed_tbc_to_bct': [_v, _v, I, I, I, I, _v],
+    'pbsed_transpose2d': [_v, _v, I, I, _v],
+    'pbsed_gru_scan_fwd': [I, _pp, _pp, _pp, _pp, _pp, _i, _v, I, I, I, _v],
+    'pbsed_gru_scan_bwd': [I, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _i, _v, I, I, I, _v],
+    'pbsed_fbcrnn_loss': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, I, I, F32, F32, I, F32, I, _v],
+    'pbsed_bicrnn_loss': [_v, _v, _v, _v, _v, _v, _v, I, I, I, I, _v],
+    'pbsed_squash_fwd': [_v, _v, SZ, F32, _v],
+    'pbsed_squash_bwd': [_v, _v, _v, SZ, F32, _v],
+    'pbsed_grad_sumsq': [_v, SZ, _v, _v],
+    'pbsed_adam_step': [_v, _v, _v, _v, SZ, F32, F32, F32, F32, I, F32, F32, _v, _v, _v],
+    'pbsed_memset_async': [_v, I, SZ, _v],
+}
+_NON_STATUS = {'pbsed_last_error': C.c_char_p, 'pbsed_version': C.c_int, 'pbsed_conv_pack_dims': None}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} not found: build the HIP extension first '
+                f'(python -c "import __graft_entry__ as g; g.build()" or pb_sed_amd/csrc/build.sh). '
+                f'pb_sed_amd has no CPU/eager fallback.')
+        l = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if a declared symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = _NON_STATUS.get(name, C.c_int)
+        _lib = l
+    return _lib
+
+
+def ptr(t):
+    """Device (or host) pointer of a tensor, None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'pb_sed_amd kernels need contiguous tensors'
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = ptr(t)
+    return arr
+
+
+def int_array(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point; raise RuntimeError with the library's message."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f'{name} failed ({rc}): {lib().pbsed_last_error().decode()}')
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError('pb_sed_amd ops run on an MI355X (HIP) device only; got a CPU tensor. '
+                           'There is no CPU fallback - use the oracle/ package for CPU checks.')

@@ -1,0 +1,48 @@
+// Shared device helpers for the pb_sed MI355X (gfx950) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PBSED_OK 0
+#define PBSED_E_ARG (-1)
+#define PBSED_E_HIP (-2)
+#define PBSED_E_UNSUPPORTED (-3)
+
+namespace pbsed {
+
+// v_mfma_f32_16x16x4_f32: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+// D[row = (lane>>4)*4 + reg][col = lane&15].  Exact f32 (k-ordered fma chain).
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum16(float v) {
+    // sum over the 16 lanes sharing lane>>4 (xor 1,2,4,8 stays inside the 16-lane group)
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum64(float v) {
+    v = wave_sum16(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum64d(double v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+}  // namespace pbsed

@@ -1,0 +1,315 @@
+// Implicit-GEMM convolution forward on fp32 MFMA (v_mfma_f32_16x16x4_f32) for gfx950.
+//
+// One kernel family serves every contraction of the FBCRNN/BiCRNN forward path:
+//   CNN2d 3x3 (+BN/ReLU prologue, +bias, +(2,1) max-pool epilogue, +BN-statistics epilogue)
+//   CNN1d k=1 / k=3, GRU input projections (k=1), per-frame heads (k=1).
+// Reference op sites: pb_sed/models/weak_label/crnn.py:93 (self.cnn), :61-67 (rnn + output_net);
+// layer list pb_sed/experiments/weak_label_crnn/training.py:159-169,218-260.
+//
+// Mapping (DESIGN.md "conv_fwd"): GEMM M = Cout (MFMA A = weights), N = spatial (MFMA B = input
+// patch, 16 consecutive t per tile), K = (kh,kw,cin).  Spatial on N makes the D fragment
+// t-contiguous across lanes (coalesced stores in the reference's [B,C,F,T] layout) and puts the
+// two frequency rows of a (2,1) pool window into the same lane.  No im2col is materialised: the
+// input halo tile [CK][FT+KH-1][TT+KW-1] is staged once in LDS (prologue applied while staging).
+#include "common.h"
+#include "pbsed_internal.h"
+
+namespace pbsed {
+
+constexpr int pad16mod32(int n) { return ((n + 15) / 32) * 32 + 16; }
+
+template <int COUT_T, int FT, int TT, int KH, int KW, int CK, bool POOL>
+struct ConvFwdCfg {
+    static constexpr int WM = (COUT_T >= 32) ? 2 : 1;
+    static constexpr int WN = 4 / WM;
+    static constexpr int MTW = COUT_T / 16 / WM;
+    static constexpr int TT16 = TT / 16;
+    static constexpr int NTT = TT16 / WN;
+    static constexpr int NTW = FT * NTT;
+    static constexpr int KK = KH * KW;
+    static constexpr int ROWS = FT + KH - 1;
+    static constexpr int ROW = TT + KW - 1;
+    static constexpr int PLANE = pad16mod32(ROWS * ROW);
+    static constexpr int COUT_P = pad16mod32(COUT_T);
+    static constexpr int IN_ELEMS = CK * ROWS * ROW;
+    static constexpr int IN_PER_T = (IN_ELEMS + 255) / 256;
+    static constexpr int W_VEC = KK * CK * COUT_T / 4;
+    static constexpr int W_PER_T = (W_VEC + 255) / 256;
+    static constexpr int FO_T = POOL ? FT / 2 : FT;
+    static constexpr int LDS_FLOATS = CK * PLANE + KK * CK * COUT_P + COUT_T * FO_T * 2;
+    static_assert(TT16 % WN == 0, "t tiles must split over waves");
+    static_assert(!POOL || FT % 2 == 0, "pool needs row pairs");
+    static_assert(CK % 4 == 0 && COUT_T % 16 == 0, "tile granularity");
+};
+
+template <int COUT_T, int FT, int TT, int KH, int KW, int CK, bool POOL, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
+    using C = ConvFwdCfg<COUT_T, FT, TT, KH, KW, CK, POOL>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* in_s = smem;                               // [CK][PLANE]
+    float* w_s = smem + CK * C::PLANE;                // [KK][CK][COUT_P]
+    float* st_s = w_s + C::KK * CK * C::COUT_P;       // [COUT_T][FO_T][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int lq = lane >> 4, lr = lane & 15;
+
+    const int nTt = (a.T + TT - 1) / TT, nFt = (a.F + FT - 1) / FT;
+    int bx = blockIdx.x;
+    const int t0 = (bx % nTt) * TT; bx /= nTt;
+    const int f0 = (bx % nFt) * FT;
+    const int b = bx / nFt;
+    const int cout0 = blockIdx.y * COUT_T;
+    const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
+    const bool pro = a.scale != nullptr;
+    constexpr int PADH = (KH - 1) / 2, PADW = (KW - 1) / 2;
+
+    f32x4 acc[C::MTW][C::NTW];
+#pragma unroll
+    for (int m = 0; m < C::MTW; ++m)
+#pragma unroll
+        for (int n = 0; n < C::NTW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float rin[C::IN_PER_T];
+    float4 rw[C::W_PER_T];
+
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < C::IN_PER_T; ++i) {
+            const int idx = tid + i * 256;
+            float v = 0.f;
+            if (idx < C::IN_ELEMS) {
+                const int c = idx / (C::ROWS * C::ROW);
+                const int rem = idx - c * (C::ROWS * C::ROW);
+                const int r = rem / C::ROW, col = rem - r * C::ROW;
+                const int f = f0 - PADH + r, t = t0 - PADW + col, cin = c0 + c;
+                const int tlim = pro ? sl : a.T;   // Normalization re-masks its output (y*mask)
+                if (cin < a.Cin && f >= 0 && f < a.F && t >= 0 && t < tlim) {
+                    if (DGRAD && a.unpool_idx) {
+                        // input is the pooled gradient: route it to the argmax row of the (2,1) window
+                        const size_t o = ((size_t)(b * a.Cin + cin) * (a.F / 2) + (f >> 1)) * a.T + t;
+                        v = (a.unpool_idx[o] == (uint8_t)(f & 1)) ? a.x[o] : 0.f;
+                    } else {
+                        v = a.x[((size_t)(b * a.Cin + cin) * a.F + f) * a.T + t];
+                    }
+                    if (pro) {
+                        v = fmaf(v, a.scale[cin], a.shift[cin]);
+                        if (a.relu) v = fmaxf(v, 0.f);
+                    }
+                }
+            }
+            rin[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < C::W_PER_T; ++i) {
+            const int idx = tid + i * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < C::W_VEC) {
+                const int q = idx % (COUT_T / 4);
+                const int c = (idx / (COUT_T / 4)) % CK;
+                const int kk = idx / (COUT_T / 4) / CK;
+                v = *reinterpret_cast<const float4*>(
+                    a.wp + ((size_t)kk * a.CinP + c0 + c) * a.CoutP + cout0 + q * 4);
+            }
+            rw[i] = v;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < C::IN_PER_T; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < C::IN_ELEMS) {
+                const int c = idx / (C::ROWS * C::ROW);
+                const int rem = idx - c * (C::ROWS * C::ROW);
+                in_s[c * C::PLANE + rem] = rin[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::W_PER_T; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < C::W_VEC) {
+                const int q = idx % (COUT_T / 4);
+                const int ck = idx / (COUT_T / 4);   // kk*CK + c
+                *reinterpret_cast<float4*>(w_s + ck * C::COUT_P + q * 4) = rw[i];
+            }
+        }
+    };
+
+    if (tid < COUT_T * C::FO_T * 2) st_s[tid] = 0.f;
+    if (COUT_T * C::FO_T * 2 > 256)
+        for (int i = tid + 256; i < COUT_T * C::FO_T * 2; i += 256) st_s[i] = 0.f;
+
+    const int nChunks = a.CinP / CK;
+    load_chunk(0);
+    for (int ch = 0; ch < nChunks; ++ch) {
+        __syncthreads();            // previous chunk's MFMA reads are done
+        store_chunk();
+        __syncthreads();
+        if (ch + 1 < nChunks) load_chunk((ch + 1) * CK);   // in flight during the MFMAs below
+#pragma unroll 1
+        for (int kk = 0; kk < C::KK; ++kk) {
+            const int kh = kk / KW, kw = kk % KW;
+#pragma unroll
+            for (int cs = 0; cs < CK / 4; ++cs) {
+                float af[C::MTW], bf[C::NTW];
+#pragma unroll
+                for (int m = 0; m < C::MTW; ++m)
+                    af[m] = w_s[(kk * CK + cs * 4 + lq) * C::COUT_P + (wm * C::MTW + m) * 16 + lr];
+#pragma unroll
+                for (int n = 0; n < C::NTW; ++n) {
+                    const int fl = n / C::NTT, tt = wn * C::NTT + n % C::NTT;
+                    bf[n] = in_s[(cs * 4 + lq) * C::PLANE + (fl + kh) * C::ROW + tt * 16 + lr + kw];
+                }
+#pragma unroll
+                for (int m = 0; m < C::MTW; ++m)
+#pragma unroll
+                    for (int n = 0; n < C::NTW; ++n) acc[m][n] = mfma16(af[m], bf[n], acc[m][n]);
+            }
+        }
+    }
+
+    // ---- epilogue: bias, (2,1) max-pool, BN statistics of the produced tensor, store
+    const int Fo = POOL ? a.F / 2 : a.F;
+#pragma unroll
+    for (int m = 0; m < C::MTW; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cl = (wm * C::MTW + m) * 16 + lq * 4 + r;
+            const int cout = cout0 + cl;
+            const float bias = (a.bias && cout < a.Cout) ? a.bias[cout] : 0.f;
+#pragma unroll
+            for (int fo_l = 0; fo_l < C::FO_T; ++fo_l) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < C::NTT; ++j) {
+                    const int t = t0 + (wn * C::NTT + j) * 16 + lr;
+                    float v;
+                    int pidx = 0;
+                    if (POOL) {
+                        const float v0 = acc[m][(2 * fo_l) * C::NTT + j][r];
+                        const float v1 = acc[m][(2 * fo_l + 1) * C::NTT + j][r];
+                        pidx = v1 > v0;
+                        v = (pidx ? v1 : v0) + bias;
+                    } else {
+                        v = acc[m][fo_l * C::NTT + j][r] + bias;
+                    }
+                    const int fo = (POOL ? f0 / 2 : f0) + fo_l;
+                    if (cout < a.Cout && fo < Fo && t < a.T) {
+                        const size_t o = ((size_t)(b * a.Cout + cout) * Fo + fo) * a.T + t;
+                        if (DGRAD) {
+                            if (a.bx) {
+                                // backward through mask -> ReLU -> BN-apply of the layer's prologue:
+                                // dz = da * [z > 0] * [t < seq_len];  partial sums for BN backward
+                                const float xv = a.bx[o];
+                                const float z = fmaf(xv, a.bscale[cout], a.bshift[cout]);
+                                const bool keep = (t < sl) && (!a.relu || z > 0.f);
+                                v = keep ? v : 0.f;
+                                const float xhat = (xv - a.bmean[cout]) * a.binvstd[cout];
+                                s1 += v; s2 += v * xhat;
+                            }
+                            a.y[o] = v;
+                        } else {
+                            a.y[o] = v;
+                            if (POOL && a.pool_idx) a.pool_idx[o] = (uint8_t)pidx;
+                            if (t < sl) { s1 += v; s2 += v * v; }
+                        }
+                    }
+                }
+                if (a.stats) {
+                    s1 = wave_sum16(s1);
+                    s2 = wave_sum16(s2);
+                    if (lr == 0) {
+                        atomicAdd(&st_s[(cl * C::FO_T + fo_l) * 2 + 0], s1);
+                        atomicAdd(&st_s[(cl * C::FO_T + fo_l) * 2 + 1], s2);
+                    }
+                }
+            }
+        }
+    }
+    if (a.stats) {
+        __syncthreads();
+        for (int i = tid; i < COUT_T * C::FO_T * 2; i += 256) {
+            const int which = i & 1, fo_l = (i >> 1) % C::FO_T, cl = (i >> 1) / C::FO_T;
+            const int cout = cout0 + cl, fo = (POOL ? f0 / 2 : f0) + fo_l;
+            if (cout < a.Cout && fo < Fo) {
+                const int sidx = a.stats_cf ? cout * Fo + fo : cout;
+                atomicAdd(&a.stats[sidx * 2 + which], (double)st_s[i]);
+            }
+        }
+    }
+}
+
+template <int COUT_T, int FT, int TT, int KH, int KW, int CK, bool POOL, bool DGRAD>
+static int launch_cfg(const ConvFwdArgs& a, hipStream_t s) {
+    using C = ConvFwdCfg<COUT_T, FT, TT, KH, KW, CK, POOL>;
+    if (a.CinP % CK || a.CoutP % COUT_T) {
+        set_error("conv_fwd: packed dims CinP=%d CoutP=%d not multiples of tile (%d,%d)", a.CinP,
+                  a.CoutP, CK, COUT_T);
+        return PBSED_E_ARG;
+    }
+    const int nTt = (a.T + TT - 1) / TT, nFt = (a.F + FT - 1) / FT;
+    dim3 grid(nTt * nFt * a.B, a.CoutP / COUT_T);
+    const size_t lds = C::LDS_FLOATS * sizeof(float);
+    auto kern = conv_fwd_kernel<COUT_T, FT, TT, KH, KW, CK, POOL, DGRAD>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    return check_launch("conv_fwd");
+}
+
+// Tile selection.  cin/cout padding granularity used by pack_conv_weights must match
+// (conv_tile_dims below is the single source of truth for both).
+void conv_fwd_tile_dims(int KH, int KW, int Cin, int Cout, int* ck, int* cout_t) {
+    if (KH == 3) {
+        *ck = (Cin <= 4) ? 4 : 8;
+        *cout_t = Cout <= 16 ? 16 : Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;
+    } else {
+        *ck = (KW == 1) ? 16 : 8;
+        *cout_t = Cout <= 16 ? 16 : 128;
+    }
+}
+
+int conv_fwd_launch(const ConvFwdArgs& a, int KH, int KW, int pool, int dgrad, hipStream_t s) {
+    int ck, ct;
+    conv_fwd_tile_dims(KH, KW, a.Cin, a.Cout, &ck, &ct);
+    if (pool && (a.F % 2)) { set_error("conv_fwd: pool needs even F"); return PBSED_E_ARG; }
+    if (dgrad && pool) { set_error("conv dgrad: pool epilogue not valid"); return PBSED_E_ARG; }
+    if (dgrad && a.unpool_idx && (a.F % 2)) { set_error("conv dgrad: unpool needs even F"); return PBSED_E_ARG; }
+#define CFG(CT, FT_, TT_, KH_, KW_, CK_)                                          \
+    do {                                                                          \
+        if (dgrad) return launch_cfg<CT, FT_, TT_, KH_, KW_, CK_, false, true>(a, s);  \
+        if (pool) return launch_cfg<CT, FT_, TT_, KH_, KW_, CK_, true, false>(a, s);   \
+        return launch_cfg<CT, FT_, TT_, KH_, KW_, CK_, false, false>(a, s);            \
+    } while (0)
+    if (KH == 3 && KW == 3) {
+        if (ck == 4 && ct == 16) CFG(16, 4, 128, 3, 3, 4);
+        if (ct == 16) CFG(16, 4, 128, 3, 3, 8);
+        if (ct == 32) CFG(32, 4, 64, 3, 3, 8);
+        if (ct == 64) CFG(64, 4, 64, 3, 3, 8);
+        if (ct == 128) CFG(128, 4, 64, 3, 3, 8);
+    } else if (KH == 1 && !pool) {
+#define CFG1(CT, KW_, CK_)                                                            \
+    do {                                                                              \
+        if (dgrad) return launch_cfg<CT, 1, 64, 1, KW_, CK_, false, true>(a, s);      \
+        return launch_cfg<CT, 1, 64, 1, KW_, CK_, false, false>(a, s);                \
+    } while (0)
+        if (KW == 1) {
+            if (ct == 16) CFG1(16, 1, 16);
+            CFG1(128, 1, 16);
+        }
+        if (KW == 3) {
+            if (ct == 16) CFG1(16, 3, 8);
+            CFG1(128, 3, 8);
+        }
+#undef CFG1
+    }
+#undef CFG
+    set_error("conv_fwd: unsupported kernel %dx%d pool=%d", KH, KW, pool);
+    return PBSED_E_UNSUPPORTED;
+}
+
+}  // namespace pbsed

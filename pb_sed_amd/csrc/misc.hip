@@ -1,0 +1,442 @@
+// Small HBM-bound helper kernels: weight packing, BatchNorm finalise / backward, losses, Adam.
+// Reference op sites: padertorch Normalization ('batch', eps 1e-3; pb_sed/experiments/
+// weak_label_crnn/training.py:223-225), losses pb_sed/models/weak_label/crnn.py:107-206 and
+// pb_sed/models/strong_label/crnn.py:106-112, optimiser training.py:264-269 (Adam + grad-norm clip).
+#include "common.h"
+#include "pbsed_internal.h"
+
+namespace pbsed {
+
+// w [Cout][Cin][KH][KW] -> wp [KK][CinP][CoutP] (zero padded).  dgrad=1: roles swapped and taps
+// flipped: wp[kk'][co][ci] = w[co][ci][KH-1-kh'][KW-1-kw'] laid out as [KK][CoutP'(=in)][CinP'(=out)].
+__global__ void pack_conv_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
+                                         int Cin, int KH, int KW, int InP, int OutP, int dgrad) {
+    const int KK = KH * KW;
+    const size_t total = (size_t)KK * InP * OutP;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int o = i % OutP, ii = (i / OutP) % InP, kk = i / ((size_t)OutP * InP);
+        float v = 0.f;
+        if (!dgrad) {
+            if (o < Cout && ii < Cin) v = w[((size_t)o * Cin + ii) * KK + kk];
+        } else {
+            // kernel-input channel ii = layer cout, kernel-output channel o = layer cin
+            if (o < Cin && ii < Cout) v = w[((size_t)ii * Cin + o) * KK + (KK - 1 - kk)];
+        }
+        wp[i] = v;
+    }
+}
+
+// sums [C][2] (sum x, sum x^2 over masked positions) -> batch statistics + fused scale/shift.
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* running_mean,
+                                   float* running_power, float* mean, float* invstd, float* scale,
+                                   float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[2 * c] / count;
+    double var = sums[2 * c + 1] / count - m * m;
+    if (var < 0) var = 0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)m;
+    invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)m * sc;
+    if (running_mean) {
+        running_mean[c] = momentum * running_mean[c] + (1.f - momentum) * (float)m;
+        running_power[c] = momentum * running_power[c] + (1.f - momentum) * (float)(var + m * m);
+    }
+}
+
+__global__ void bn_eval_params_kernel(const float* gamma, const float* beta, float eps,
+                                      const float* running_mean, const float* running_power,
+                                      float* mean, float* invstd, float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float m = running_mean[c];
+    const float var = fmaxf(running_power[c] - m * m, 0.f);
+    const float is = rsqrtf(var + eps);
+    mean[c] = m; invstd[c] = is;
+    scale[c] = gamma[c] * is;
+    shift[c] = beta[c] - m * gamma[c] * is;
+}
+
+// sums [C][2] = (sum dz, sum dz*xhat) -> dgamma, dbeta (+=) and the two means used by bn_bwd_apply.
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double count, float* dgamma,
+                                       float* dbeta, float* m1, float* m2, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double s1 = sums[2 * c], s2 = sums[2 * c + 1];
+    if (dbeta) dbeta[c] += (float)s1;
+    if (dgamma) dgamma[c] += (float)s2;
+    m1[c] = (float)(s1 / count);
+    m2[c] = (float)(s2 / count);
+}
+
+// in place: dz -> dx = gamma*invstd * (dz - m1 - xhat*m2) on masked positions (0 elsewhere).
+// tensors [B, C, S, T] with S = inner rows per channel (F for 2-D, 1 for 1-D).
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ dz, const float* __restrict__ x,
+                                                           const float* mean, const float* invstd,
+                                                           const float* scale, const float* m1,
+                                                           const float* m2, const int* seq_len, int B,
+                                                           int C, int S, int T) {
+    const size_t total = (size_t)B * C * S * T;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int t = i % T;
+        const size_t row = i / T;
+        const int c = (row / S) % C, b = row / ((size_t)S * C);
+        const int sl = seq_len ? seq_len[b] : T;
+        float v = 0.f;
+        if (t < sl) {
+            const float xhat = (x[i] - mean[c]) * invstd[c];
+            v = scale[c] * (dz[i] - m1[c] - xhat * m2[c]);
+        }
+        dz[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------ FBCRNN loss
+// One block per (b, k) row.  Fused: squash (eps + (1-2eps) sigmoid), weak fwd/bwd BCE, strong
+// (boundary) fwd/bwd BCE with cummax targets, blend, seq-masked time mean, class-weighted
+// normalised sum, and the gradient wrt both heads' logits.
+struct FbLossArgs {
+    const float* lf;       // logits fwd [B,K,T]
+    const float* lb;       // logits bwd or null
+    const float* weak;     // [B,K]
+    const float* bnd;      // [B,K,T] boundary targets or null (slat / weight 0)
+    const float* cw;       // [K] class weights or null
+    const int* seq_len;    // [B]
+    float* yf; float* yb;  // squashed scores out (may be null)
+    float* dlf; float* dlb;  // grad wrt logits (may be null -> loss only)
+    float* loss;           // scalar accumulator (zeroed by caller)
+    int B, K, T, slat;
+    float eps, lambda, ls;
+    int prob_in;           // 1: lf/lb already hold squashed scores y, gradients are wrt y
+};
+
+__device__ __forceinline__ float bce_f(float p, float t) {
+    return -(t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(logf(1.f - p), -100.f));
+}
+__device__ __forceinline__ float dbce_f(float p, float t) { return -t / p + (1.f - t) / (1.f - p); }
+
+__global__ __launch_bounds__(256) void fbcrnn_loss_kernel(FbLossArgs a) {
+    extern __shared__ float sh[];           // tf[T], tb[T]
+    float* tf = sh; float* tb = sh + a.T;
+    __shared__ float red[8];
+    __shared__ float s_wsum, s_rowok;
+    const int row = blockIdx.x, b = row / a.K, k = row % a.K, tid = threadIdx.x;
+    const int T = a.T, L = min(a.seq_len[b], T);
+    // sum of weights over all (b,k)
+    float ws = 0.f;
+    for (int i = tid; i < a.B * a.K; i += blockDim.x) {
+        const float w = a.weak[i];
+        if (w < .01f || w > .99f) ws += a.cw ? a.cw[i % a.K] : 1.f;
+    }
+    ws = wave_sum64(ws);
+    if ((tid & 63) == 0) red[tid >> 6] = ws;
+    __syncthreads();
+    if (tid == 0) { float s = 0.f; for (int i = 0; i < (int)blockDim.x / 64; ++i) s += red[i]; s_wsum = s; }
+    __syncthreads();
+    const float wsum = s_wsum;
+    float w = a.weak[row];
+    const bool wm = (w < .01f) || (w > .99f);
+    w = wm ? w : 0.f;
+    const float wt = a.ls > 0.f ? fminf(fmaxf(w, a.ls), 1.f - a.ls) : w;
+    const float Wrow = wm ? (a.cw ? a.cw[k] : 1.f) : 0.f;
+    const float* lf = a.lf + (size_t)row * T;
+    const float* lb = a.lb ? a.lb + (size_t)row * T : nullptr;
+    const bool strong = a.lambda > 0.f && (a.slat || a.bnd);
+    // boundary mask row test over ALL T padded frames + cummax targets
+    float cnt = 0.f;
+    if (strong) {
+        for (int t = tid; t < T; t += blockDim.x) {
+            const float be = a.slat ? w : a.bnd[(size_t)row * T + t];
+            cnt += ((be > .99f) || (be < .01f)) ? 1.f : 0.f;
+            const float bt = a.ls > 0.f ? fminf(fmaxf(be, a.ls), 1.f - a.ls) : be;
+            tf[t] = bt; tb[t] = bt;
+        }
+    }
+    __syncthreads();
+    cnt = wave_sum64(cnt);
+    if ((tid & 63) == 0) red[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f; for (int i = 0; i < (int)blockDim.x / 64; ++i) s += red[i];
+        s_rowok = (strong && (s / (float)T > .999f) && (w > .99f)) ? 1.f : 0.f;
+        if (strong) for (int t = 1; t < T; ++t) tf[t] = fmaxf(tf[t], tf[t - 1]);
+    }
+    if (tid == 64 && strong) for (int t = T - 2; t >= 0; --t) tb[t] = fmaxf(tb[t], tb[t + 1]);
+    __syncthreads();
+    const bool rowok = s_rowok > 0.f;
+    const float sc = 1.f - 2.f * a.eps;
+    const float coef = (L > 0 && wsum > 0.f) ? Wrow / (wsum * (float)L) : 0.f;
+    float yl = 0.f;  // y_fwd at the last valid frame (no-bwd weak term)
+    if (!lb && L > 0) yl = a.prob_in ? lf[L - 1] : a.eps + sc / (1.f + expf(-lf[L - 1]));
+    float lsum = 0.f, glast = 0.f;
+    for (int t = tid; t < T; t += blockDim.x) {
+        float sf, yf, sb = 0.f, yb = 0.f;
+        if (a.prob_in) {
+            yf = lf[t]; sf = 0.f;
+            if (lb) yb = lb[t];
+        } else {
+            sf = 1.f / (1.f + expf(-lf[t]));
+            yf = a.eps + sc * sf;
+            if (lb) { sb = 1.f / (1.f + expf(-lb[t])); yb = a.eps + sc * sb; }
+        }
+        const float jf = a.prob_in ? 1.f : sc * sf * (1.f - sf);
+        const float jb = a.prob_in ? 1.f : sc * sb * (1.f - sb);
+        if (a.yf) a.yf[(size_t)row * T + t] = yf;
+        if (a.yb && lb) a.yb[(size_t)row * T + t] = yb;
+        float gf = 0.f, gb = 0.f;
+        if (t < L) {
+            float lam = 0.f;
+            if (strong) {
+                const float be = a.slat ? w : a.bnd[(size_t)row * T + t];
+                lam = (rowok && ((be > .99f) || (be < .01f))) ? a.lambda : 0.f;
+            }
+            float lw = 0.f;
+            if (wm) {
+                if (lb) {
+                    const float ym = fmaxf(yf, yb);
+                    lw = bce_f(ym, wt);
+                    const float d = dbce_f(ym, wt) * (1.f - lam);
+                    if (yf > yb) gf += d; else if (yb > yf) gb += d; else { gf += .5f * d; gb += .5f * d; }
+                } else {
+                    lw = bce_f(yl, wt);
+                    glast += dbce_f(yl, wt) * (1.f - lam);
+                }
+            }
+            float lsg = 0.f;
+            if (lam > 0.f) {
+                if (lb) {
+                    lsg = .5f * bce_f(yf, tf[t]) + .5f * bce_f(yb, tb[t]);
+                    gf += lam * .5f * dbce_f(yf, tf[t]);
+                    gb += lam * .5f * dbce_f(yb, tb[t]);
+                } else {
+                    lsg = bce_f(yf, tf[t]);
+                    gf += lam * dbce_f(yf, tf[t]);
+                }
+            }
+            lsum += lam * lsg + (1.f - lam) * lw;
+        }
+        if (a.dlf) a.dlf[(size_t)row * T + t] = coef * gf * jf;
+        if (a.dlb && lb) a.dlb[(size_t)row * T + t] = coef * gb * jb;
+    }
+    __syncthreads();
+    lsum = wave_sum64(lsum);
+    glast = wave_sum64(glast);
+    if ((tid & 63) == 0) { red[tid >> 6] = lsum; red[4 + (tid >> 6)] = glast; }
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f, g = 0.f;
+        for (int i = 0; i < (int)blockDim.x / 64; ++i) { s += red[i]; g += red[4 + i]; }
+        atomicAdd(a.loss, coef * s);
+        if (!lb && a.dlf && L > 0) {
+            const float sl_ = 1.f / (1.f + expf(-lf[L - 1]));
+            a.dlf[(size_t)row * T + L - 1] += coef * g * (a.prob_in ? 1.f : sc * sl_ * (1.f - sl_));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ BiCRNN loss
+struct BiLossArgs {
+    const float* logit; const float* st; const int* seq_len;
+    float* y; float* dlogit; float* loss; double* msum; int B, K, T; int prob_in;
+};
+__global__ void bicrnn_mask_count_kernel(BiLossArgs a) {
+    const size_t total = (size_t)a.B * a.K * a.T;
+    double c = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const float s = a.st[i];
+        c += ((s > .99f) || (s < .01f)) ? 1.0 : 0.0;
+    }
+    c = wave_sum64d(c);
+    if ((threadIdx.x & 63) == 0) atomicAdd(a.msum, c);
+}
+__global__ void bicrnn_loss_kernel(BiLossArgs a) {
+    const size_t total = (size_t)a.B * a.K * a.T;
+    const float inv = 1.f / (float)(*a.msum);
+    float ls = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = i % a.T, b = i / ((size_t)a.T * a.K);
+        const float s = a.prob_in ? a.logit[i] : 1.f / (1.f + expf(-a.logit[i]));
+        if (a.y) a.y[i] = s;
+        const float st = a.st[i];
+        float g = 0.f;
+        if (t < a.seq_len[b] && ((st > .99f) || (st < .01f))) {
+            ls += bce_f(s, st);
+            g = dbce_f(s, st) * (a.prob_in ? 1.f : s * (1.f - s)) * inv;
+        }
+        if (a.dlogit) a.dlogit[i] = g;
+    }
+    ls = wave_sum64(ls);
+    if ((threadIdx.x & 63) == 0) atomicAdd(a.loss, ls * inv);
+}
+
+// ------------------------------------------------------------------------------------ squash
+// y = eps + (1-2eps) sigmoid(x)  (pb_sed/models/weak_label/crnn.py:58-59; eps = 0 -> nn.Sigmoid)
+__global__ void squash_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float eps) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = eps + (1.f - 2.f * eps) / (1.f + expf(-x[i]));
+}
+__global__ void squash_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                  float* __restrict__ dx, size_t n, float eps) {
+    const float sc = 1.f - 2.f * eps;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float s = (y[i] - eps) / sc;
+        dx[i] = dy[i] * sc * s * (1.f - s);
+    }
+}
+
+// ------------------------------------------------------------------------------------ optimiser
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, double* out) {
+    double s = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double v = g[i];
+        s += v * v;
+    }
+    s = wave_sum64d(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+// torch.optim.Adam (no amsgrad / weight decay) preceded by clip_grad_norm_(max_norm):
+// clip_coef = min(1, max_norm / (norm + 1e-6)); also folds the data-parallel 1/world_size average.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                   float lr, float b1, float b2, float eps, float bc1,
+                                                   float bc2_sqrt, float gscale, float max_norm,
+                                                   const double* sumsq, float* norm_out) {
+    float coef = gscale;
+    if (sumsq) {
+        const float norm = (float)sqrt(*sumsq) * gscale;
+        coef *= fminf(1.f, max_norm / (norm + 1e-6f));
+        if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = norm;
+    }
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * coef;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+}  // namespace pbsed
+
+using namespace pbsed;
+
+static inline int nblocks(size_t n, int bs = 256, int cap = 2048) {
+    size_t b = (n + bs - 1) / bs;
+    return (int)(b > (size_t)cap ? cap : (b ? b : 1));
+}
+
+extern "C" {
+
+void pbsed_conv_pack_dims(int KH, int KW, int Cin, int Cout, int dgrad, int* InP, int* OutP) {
+    int ck, ct;
+    if (!dgrad) {
+        conv_fwd_tile_dims(KH, KW, Cin, Cout, &ck, &ct);
+        *InP = (Cin + ck - 1) / ck * ck; *OutP = (Cout + ct - 1) / ct * ct;
+    } else {
+        conv_fwd_tile_dims(KH, KW, Cout, Cin, &ck, &ct);
+        *InP = (Cout + ck - 1) / ck * ck; *OutP = (Cin + ct - 1) / ct * ct;
+    }
+}
+
+int pbsed_pack_conv_weights(const float* w, float* wp, int Cout, int Cin, int KH, int KW, int dgrad,
+                            void* stream) {
+    int InP, OutP;
+    pbsed_conv_pack_dims(KH, KW, Cin, Cout, dgrad, &InP, &OutP);
+    const size_t total = (size_t)KH * KW * InP * OutP;
+    hipLaunchKernelGGL(pack_conv_weights_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream,
+                       w, wp, Cout, Cin, KH, KW, InP, OutP, dgrad);
+    return check_launch("pack_conv_weights");
+}
+
+int pbsed_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
+                      float momentum, float* running_mean, float* running_power, float* mean,
+                      float* invstd, float* scale, float* shift, int C, void* stream) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums,
+                       count, gamma, beta, eps, momentum, running_mean, running_power, mean, invstd, scale,
+                       shift, C);
+    return check_launch("bn_finalize");
+}
+
+int pbsed_bn_eval_params(const float* gamma, const float* beta, float eps, const float* running_mean,
+                         const float* running_power, float* mean, float* invstd, float* scale,
+                         float* shift, int C, void* stream) {
+    hipLaunchKernelGGL(bn_eval_params_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma,
+                       beta, eps, running_mean, running_power, mean, invstd, scale, shift, C);
+    return check_launch("bn_eval_params");
+}
+
+int pbsed_bn_bwd_finalize(const double* sums, double count, float* dgamma, float* dbeta, float* m1,
+                          float* m2, int C, void* stream) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums,
+                       count, dgamma, dbeta, m1, m2, C);
+    return check_launch("bn_bwd_finalize");
+}
+
+int pbsed_bn_bwd_apply(float* dz, const float* x, const float* mean, const float* invstd, const float* scale,
+                       const float* m1, const float* m2, const int* seq_len, int B, int C, int S, int T,
+                       void* stream) {
+    const size_t total = (size_t)B * C * S * T;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       dz, x, mean, invstd, scale, m1, m2, seq_len, B, C, S, T);
+    return check_launch("bn_bwd_apply");
+}
+
+int pbsed_fbcrnn_loss(const float* logit_fwd, const float* logit_bwd, const float* weak_targets,
+                      const float* boundary_targets, const float* class_weights, const int* seq_len,
+                      float* y_fwd, float* y_bwd, float* dlogit_fwd, float* dlogit_bwd, float* loss,
+                      int B, int K, int T, float minimum_score, float strong_weight, int slat,
+                      float label_smoothing, int inputs_are_scores, void* stream) {
+    FbLossArgs a{logit_fwd, logit_bwd, weak_targets, boundary_targets, class_weights, seq_len, y_fwd, y_bwd,
+                 dlogit_fwd, dlogit_bwd, loss, B, K, T, slat, minimum_score, strong_weight, label_smoothing,
+                 inputs_are_scores};
+    hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream);
+    hipLaunchKernelGGL(fbcrnn_loss_kernel, dim3(B * K), dim3(256), 2 * T * sizeof(float), (hipStream_t)stream, a);
+    return check_launch("fbcrnn_loss");
+}
+
+int pbsed_bicrnn_loss(const float* logit, const float* strong_targets, const int* seq_len, float* y,
+                      float* dlogit, float* loss, double* scratch, int B, int K, int T,
+                      int inputs_are_scores, void* stream) {
+    BiLossArgs a{logit, strong_targets, seq_len, y, dlogit, loss, scratch, B, K, T, inputs_are_scores};
+    hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream);
+    hipMemsetAsync(scratch, 0, sizeof(double), (hipStream_t)stream);
+    const size_t total = (size_t)B * K * T;
+    hipLaunchKernelGGL(bicrnn_mask_count_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bicrnn_loss_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("bicrnn_loss");
+}
+
+int pbsed_squash_fwd(const float* x, float* y, size_t n, float eps, void* stream) {
+    hipLaunchKernelGGL(squash_fwd_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, eps);
+    return check_launch("squash_fwd");
+}
+
+int pbsed_squash_bwd(const float* y, const float* dy, float* dx, size_t n, float eps, void* stream) {
+    hipLaunchKernelGGL(squash_bwd_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, n, eps);
+    return check_launch("squash_bwd");
+}
+
+int pbsed_grad_sumsq(const float* g, size_t n, double* out, void* stream) {
+    hipMemsetAsync(out, 0, sizeof(double), (hipStream_t)stream);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    return check_launch("grad_sumsq");
+}
+
+int pbsed_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                    float beta2, float eps, int step, float grad_scale, float max_norm,
+                    const double* sumsq, float* norm_out, void* stream) {
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                       n, lr, beta1, beta2, eps, bc1, bc2s, grad_scale, max_norm, sumsq, norm_out);
+    return check_launch("adam_step");
+}
+
+}  // extern "C"

@@ -1,0 +1,256 @@
+"""Execution engine: drives the HIP kernels through the layer tables of ``pb_sed_amd.modules``.
+
+Forward and backward are explicit chains of C-ABI calls (no per-op autograd graph); the model
+classes wrap one whole network pass in a single ``torch.autograd.Function`` so that callers keep
+the reference contract ``loss = model.review(batch, model(batch))['loss']; loss.backward()``
+(reference pb_sed/models/weak_label/crnn.py:69-178, trainer loop SURVEY.md A.8).
+
+Parameter gradients are accumulated by the kernels straight into ``p.grad`` (aliases of one flat
+gradient buffer, see ``flatten_parameters``), which is what the fused Adam and the data-parallel
+all-reduce operate on.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .ops import PackedConv
+
+
+# ------------------------------------------------------------------------------------- parameters
+def flatten_parameters(module):
+    """Re-home every parameter (and its .grad) of ``module`` in one flat fp32 buffer each.
+
+    Returns (flat_param, flat_grad).  Idempotent; must be called after ``.to(device)``.
+    """
+    params = [p for p in module.parameters()]
+    flat = getattr(module, '_pbsed_flat', None)
+    if flat is not None and all(getattr(p, '_pbsed_flat_id', None) == id(flat[0]) and
+                                p.data_ptr() == flat[0].data_ptr() + 4 * p._pbsed_off
+                                for p in params):
+        for p in params:
+            if p.grad is None or p.grad.data_ptr() != flat[1].data_ptr() + 4 * p._pbsed_off:
+                p.grad = flat[1][p._pbsed_off:p._pbsed_off + p.numel()].view(p.shape)
+        return flat
+    device = params[0].device
+    n = sum(p.numel() for p in params)
+    fp = torch.empty(n, device=device, dtype=torch.float32)
+    fg = torch.zeros(n, device=device, dtype=torch.float32)
+    off = 0
+    for p in params:
+        k = p.numel()
+        fp[off:off + k].copy_(p.detach().reshape(-1))
+        p.data = fp[off:off + k].view(p.shape)
+        p.grad = fg[off:off + k].view(p.shape)
+        p._pbsed_off, p._pbsed_flat_id = off, id(fp)
+        off += k
+    module._pbsed_flat = (fp, fg)
+    return module._pbsed_flat
+
+
+def _grad(p):
+    """Accumulation target for a parameter's gradient (None if frozen)."""
+    if not p.requires_grad:
+        return None
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+# ------------------------------------------------------------------------------------- conv stacks
+class LayerDesc:
+    def __init__(self, conv, in_norm):
+        self.conv, self.in_norm = conv, in_norm
+
+
+def describe_stack(cnns):
+    """Flatten one or more _CNN modules into [conv + the norm applied (with ReLU) to its input]."""
+    convs = [c for cnn in cnns for c in cnn.convs]
+    layers = []
+    for j, c in enumerate(convs):
+        in_norm = c.norm if c.pre else (convs[j - 1].norm if j > 0 and convs[j - 1].post else None)
+        layers.append(LayerDesc(c, in_norm))
+    if convs[-1].post:
+        raise NotImplementedError('a trailing post-activation norm (output_layer=False without '
+                                  'pre_activation) has no consumer conv to fuse into')
+    if layers[0].in_norm is not None:
+        raise NotImplementedError('first layer with a pre-activation norm needs input statistics')
+    return layers
+
+
+def _count(seq_host, t, rows):
+    return float(np.minimum(np.asarray(seq_host), t).sum() * rows)
+
+
+def stack_forward(layers, x, seq_dev, seq_host, training):
+    """Run a conv stack.  Returns (y, ctx) - ctx is what stack_backward needs."""
+    ctx = []
+    st_in = None
+    for j, L in enumerate(layers):
+        c = L.conv
+        nxt = layers[j + 1] if j + 1 < len(layers) else None
+        next_norm = nxt.in_norm if nxt is not None else None
+        batch_stats = training and next_norm is not None and not next_norm.freeze_stats
+        if training and next_norm is not None and next_norm.freeze_stats:
+            raise NotImplementedError('training through frozen norm statistics')
+        per_cf = bool(batch_stats and c.ndim == 2 and nxt.conv.ndim == 1)
+        if c.ndim == 1 and x.dim() == 4:
+            x = x.flatten(1, 2)                       # 'b c f t -> b (c f) t' is a view in this layout
+        pc = PackedConv(c.conv.weight)
+        y, idx, stats = ops.conv_fwd(
+            x, pc, pc.fwd(), bias=c.conv.bias.detach(),
+            scale=None if st_in is None else st_in.scale, shift=None if st_in is None else st_in.shift,
+            relu=True, seq_len=seq_dev, pool=c.pool_f, want_stats=batch_stats, stats_per_cf=per_cf)
+        ctx.append((x, st_in, pc, idx))
+        if next_norm is None:
+            st_in = None
+        elif batch_stats:
+            rows = 1 if (per_cf or y.dim() == 3) else y.shape[2]
+            st_in = ops.bn_finalize(stats, _count(seq_host, y.shape[-1], rows), next_norm)
+        else:
+            st_in = ops.bn_eval_params(next_norm)
+        x = y
+    return x, ctx
+
+
+def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad):
+    """Backward of stack_forward; accumulates parameter grads, returns grad wrt the stack input."""
+    for j in reversed(range(len(layers))):
+        L, (x, st_in, pc, idx) = layers[j], ctx[j]
+        c = L.conv
+        g = g.contiguous()
+        dw, db = _grad(c.conv.weight), _grad(c.conv.bias)
+        if dw is not None:
+            ops.conv_bwd_weight(x, g, pc, dw, db,
+                                scale=None if st_in is None else st_in.scale,
+                                shift=None if st_in is None else st_in.shift,
+                                relu=True, seq_len=seq_dev, unpool_idx=idx)
+        if j == 0 and not need_input_grad:
+            return None
+        wd = pc.dgrad()
+        if st_in is not None:
+            dz, stats = ops.conv_bwd_data(g, pc, wd, x.shape, idx, seq_dev,
+                                          bn=(x, st_in.mean, st_in.invstd, st_in.scale, st_in.shift))
+            rows = 1 if x.dim() == 3 else x.shape[2]
+            norm = L.in_norm
+            g = ops.bn_backward(dz, x, st_in, stats, _count(seq_host, x.shape[-1], rows),
+                                _grad(norm.gamma), _grad(norm.beta), seq_dev)
+        else:
+            g, _ = ops.conv_bwd_data(g, pc, wd, x.shape, idx, None)
+    return g
+
+
+# ------------------------------------------------------------------------------------- recurrent part
+class _Chain:
+    """One GRU direction of one wrapper."""
+
+    def __init__(self, wrapper, widx, direction):
+        self.wrapper, self.widx, self.direction = wrapper, widx, direction
+        self.reverse = bool(wrapper.reverse) ^ bool(direction)
+        self.suffix = '_reverse' if direction else ''
+
+    def p(self, name, layer):
+        return getattr(self.wrapper.rnn, f'{name}_l{layer}{self.suffix}')
+
+
+def _chains(wrappers):
+    chains = []
+    for wi, w in enumerate(wrappers):
+        for d in range(2 if w.bidirectional else 1):
+            chains.append(_Chain(w, wi, d))
+    if len(chains) > 2:
+        raise NotImplementedError('at most two concurrent GRU chains (FBCRNN fwd+bwd or one BiGRU)')
+    return chains
+
+
+def rnn_forward(wrappers, h, seq_dev, seq_host, training):
+    """wrappers: list of modules.GRU sharing the input h [B,C,T].  Returns (logits per wrapper, ctx)."""
+    chains = _chains(wrappers)
+    num_layers = wrappers[0].num_layers
+    assert all(w.num_layers == num_layers for w in wrappers)
+    x_w = [h for _ in wrappers]                  # per-wrapper layer input [B, In, T]
+    layer_ctx = []
+    for l in range(num_layers):
+        gi, pcs = [], []
+        for ch in chains:
+            w_ih = ch.p('weight_ih', l)
+            pc = PackedConv(w_ih.unsqueeze(-1))
+            y, _, _ = ops.conv_fwd(x_w[ch.widx], pc, pc.fwd(), bias=ch.p('bias_ih', l).detach(),
+                                   seq_len=None)
+            gi.append(ops.bct_to_tbc(y))
+            pcs.append(pc)
+        hs, save = ops.gru_scan_fwd(gi, [ch.p('weight_hh', l).detach() for ch in chains],
+                                    [ch.p('bias_hh', l).detach() for ch in chains],
+                                    [ch.reverse for ch in chains], seq_dev, save=training)
+        hs_bct = [ops.tbc_to_bct(h_) for h_ in hs]
+        layer_ctx.append((list(x_w), pcs, hs, save))
+        x_w = []
+        for wi, w in enumerate(wrappers):
+            outs = [hs_bct[i] for i, ch in enumerate(chains) if ch.widx == wi]
+            x_w.append(outs[0] if len(outs) == 1 else torch.cat(outs, dim=1))
+    logits, head_ctx = [], []
+    for wi, w in enumerate(wrappers):
+        layers = describe_stack([w.output_net])
+        y, c = stack_forward(layers, x_w[wi], seq_dev, seq_host, training)
+        logits.append(y)
+        head_ctx.append((layers, c))
+    return logits, (chains, layer_ctx, head_ctx)
+
+
+def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
+    """Returns grad wrt the shared input h."""
+    chains, layer_ctx, head_ctx = ctx
+    num_layers = wrappers[0].num_layers
+    hid = wrappers[0].hidden_size
+    d_out = []                                   # per wrapper: grad wrt top-layer output [B, H*dirs, T]
+    for wi, w in enumerate(wrappers):
+        layers, c = head_ctx[wi]
+        d_out.append(stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True))
+    dh_in = None
+    for l in reversed(range(num_layers)):
+        x_w, pcs, hs, save = layer_ctx[l]
+        dy = []
+        for i, ch in enumerate(chains):
+            k = [j for j, c2 in enumerate(chains) if c2.widx == ch.widx].index(i)
+            dy.append(ops.bct_to_tbc(d_out[ch.widx][:, k * hid:(k + 1) * hid].contiguous()))
+        w_hh_t = [ops.transpose2d(ch.p('weight_hh', l).detach()) for ch in chains]
+        dgi, dgh = ops.gru_scan_bwd(w_hh_t, hs, save, dy, [ch.reverse for ch in chains], seq_dev)
+        dx_w = [None for _ in wrappers]
+        for i, ch in enumerate(chains):
+            dgi_b, dgh_b = ops.tbc_to_bct(dgi[i]), ops.tbc_to_bct(dgh[i])
+            hprev = ops.tbc_to_bct(hs[i], shift=1 if ch.reverse else -1)
+            w_hh, w_ih = ch.p('weight_hh', l), ch.p('weight_ih', l)
+            if w_hh.requires_grad:
+                ops.conv_bwd_weight(hprev, dgh_b, PackedConv(w_hh.unsqueeze(-1)),
+                                    _grad(w_hh), _grad(ch.p('bias_hh', l)))
+            if w_ih.requires_grad:
+                ops.conv_bwd_weight(x_w[ch.widx], dgi_b, pcs[i], _grad(w_ih), _grad(ch.p('bias_ih', l)))
+            dx, _ = ops.conv_bwd_data(dgi_b, pcs[i], pcs[i].dgrad(), x_w[ch.widx].shape)
+            dx_w[ch.widx] = dx if dx_w[ch.widx] is None else dx_w[ch.widx].add_(dx)
+        if l > 0:
+            d_out = dx_w
+        else:
+            dh_in = dx_w[0]
+            for d in dx_w[1:]:
+                dh_in = dh_in.add_(d)
+    return dh_in
+
+
+# ------------------------------------------------------------------------------------- front-end
+def features_from_audio(fe, audio, seq_dev, n_frames):
+    if fe._tables is None or fe._tables.window.device != audio.device:
+        fe._tables = ops.LogMelTables(fe.fbanks.detach().cpu().numpy(), audio.device)
+    return ops.logmel_fwd(audio, fe._tables, fe.mean, fe.inv_std, n_frames, seq_dev, eps=fe.eps,
+                          clamp=fe.clamp)
+
+
+def features_from_stft(fe, stft, seq_host):
+    """Compatibility path for callers that still hand over the reference's CPU STFT
+    ([B,1,T,bins,2], pb_sed/models/weak_label/crnn.py:80-83).  Plain tensor ops, not a hot path."""
+    power = (stft.to(torch.float32) ** 2).sum(-1)
+    logmel = torch.log(power @ fe.fbanks.T + fe.eps).transpose(-1, -2)
+    y = (logmel - fe.mean[:, None]) * fe.inv_std[:, None]
+    if fe.clamp is not None:
+        y = y.clamp(-fe.clamp, fe.clamp)
+    t = y.shape[-1]
+    m = torch.arange(t, device=y.device)[None] < torch.as_tensor(np.asarray(seq_host), device=y.device)[:, None]
+    return (y * m[:, None, None, :]).contiguous()

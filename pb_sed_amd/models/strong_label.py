@@ -1,0 +1,118 @@
+"""BiCRNN: drop-in counterpart of ``pb_sed.models.strong_label.CRNN``
+(reference pb_sed/models/strong_label/crnn.py:13-210), optionally tag-conditioned."""
+import numpy as np
+import torch
+
+from .. import engine, ops
+from ..modules import SHALLOW, NormalizedLogMelExtractor, build_cnn, build_rnn, num_frames
+from .base import SoundEventModel
+
+
+class _NetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, tag, seq_host, seq_dev, training, *params):
+        if tag is not None and model.cnn.conditional_dims:
+            b, _, f, t = x.shape
+            x = torch.cat([x, tag.reshape(b, -1, 1, 1).to(x.dtype).expand(b, tag.shape[1], f, t)], dim=1).contiguous()
+        layers = engine.describe_stack([model.cnn.cnn_2d, model.cnn.cnn_1d])
+        h, cnn_ctx = engine.stack_forward(layers, x, seq_dev, seq_host, training)
+        n_h = h.shape[1]
+        if tag is not None:
+            h = torch.cat([h, tag.reshape(h.shape[0], -1, 1).to(h.dtype).expand(-1, -1, h.shape[-1])], dim=1).contiguous()
+        logits, rnn_ctx = engine.rnn_forward([model.rnn], h, seq_dev, seq_host, training)
+        y = ops.squash_fwd(logits[0], 0.)
+        ctx.state = (model, layers, cnn_ctx, rnn_ctx, y, n_h, seq_host, seq_dev)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        model, layers, cnn_ctx, rnn_ctx, y, n_h, seq_host, seq_dev = ctx.state
+        ctx.state = None
+        engine.flatten_parameters(model)
+        dh = engine.rnn_backward([model.rnn], rnn_ctx, [ops.squash_bwd(y, dy, 0.)], seq_dev, seq_host)
+        engine.stack_backward(layers, cnn_ctx, dh[:, :n_h].contiguous(), seq_dev, seq_host, need_input_grad=False)
+        return (None,) * (6 + len(model._net_params))
+
+
+class _LossFunction(torch.autograd.Function):
+    """strong_label/crnn.py:106-112 fused (numerator seq-masked, denominator over all frames)."""
+
+    @staticmethod
+    def forward(ctx, y, strong_targets, seq_dev):
+        loss, _, d = ops.bicrnn_loss(y.contiguous(), strong_targets, seq_dev, inputs_are_scores=True)
+        ctx.d = d
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.d * g, None, None
+
+
+class CRNN(SoundEventModel):
+    def __init__(self, feature_extractor, cnn, rnn, *, tag_conditioning=False, labelwise_metrics=(),
+                 label_mapping=None, eval_segment_length=1):
+        super().__init__(labelwise_metrics=labelwise_metrics, label_mapping=label_mapping)
+        self.feature_extractor = feature_extractor
+        self.cnn = cnn
+        self.rnn = rnn
+        self.tag_conditioning = tag_conditioning
+        self.eval_segment_length = eval_segment_length
+
+    @classmethod
+    def build(cls, num_events=10, number_of_filters=128, stft_size=1024, sample_rate=16000,
+              hidden_size=256, num_layers=2, net=None, tag_conditioning=True, **kw):
+        """Reference factory (pb_sed/experiments/strong_label_crnn/training.py:159-263,
+        pb_sed/models/strong_label/crnn.py:155-197)."""
+        net = dict(SHALLOW if net is None else net)
+        fe = NormalizedLogMelExtractor(sample_rate, stft_size, number_of_filters)
+        cd = num_events if tag_conditioning else 0
+        cnn = build_cnn(1, input_height=number_of_filters, conditional_dims=cd, **net)
+        rnn = build_rnn(net['out_channels_1d'][-1] + cd, hidden_size, num_layers, num_events, hidden_size,
+                        bidirectional=True)
+        return cls(fe, cnn, rnn, tag_conditioning=tag_conditioning, **kw)
+
+    def forward(self, inputs):
+        key = 'audio_data' if 'audio_data' in inputs else 'stft'
+        x_in = inputs.pop(key) if self.training else inputs[key]
+        seq_host, seq_dev = self._seq(inputs, x_in.device)
+        if key == 'audio_data':
+            audio = x_in.reshape(x_in.shape[0], -1).to(torch.float32)
+            x = engine.features_from_audio(self.feature_extractor, audio, seq_dev, num_frames(audio.shape[1]))
+        else:
+            x = engine.features_from_stft(self.feature_extractor, x_in, seq_host)
+        targets = (inputs['weak_targets'], inputs['strong_targets']) if 'strong_targets' in inputs else None
+        tag = inputs['tag_condition'].to(torch.float32) if self.tag_conditioning else None
+        self._net_params = [p for p in self.parameters()]
+        engine.flatten_parameters(self)
+        training = self.training and torch.is_grad_enabled()
+        y = _NetFunction.apply(self, x, tag, seq_host, seq_dev, training, *self._net_params)
+        return y, seq_host, x, seq_host, targets
+
+    def review(self, inputs, outputs):
+        y, seq_len_y, x, _, targets = outputs
+        assert targets is not None
+        strong_targets = targets[1].to(torch.float32)
+        assert strong_targets.shape == y.shape, (strong_targets.shape, y.shape)
+        seq_dev = torch.as_tensor(np.asarray(seq_len_y), dtype=torch.int32).to(y.device)
+        loss = _LossFunction.apply(y, strong_targets, seq_dev)
+        mask = (strong_targets > .99) | (strong_targets < .01)
+        return dict(
+            loss=loss,
+            scalars=dict(seq_len=np.mean(inputs['seq_len']), strong_label_rate=mask.float().mean().item()),
+            images=dict(features=x[:3], strong_targets=strong_targets[:3]),
+            buffers=dict(),
+        )
+
+    def tagging(self, inputs):
+        y, seq_len_y, *_ = self.forward(inputs)
+        return y.max(-1, keepdim=True)[0], np.ones_like(seq_len_y)
+
+    def boundaries_detection(self, inputs):
+        return self.sound_event_detection(inputs)
+
+    def sound_event_detection(self, inputs):
+        y, seq_len_y, *_ = self.forward(inputs)
+        t = y.shape[-1]
+        m = (torch.arange(t, device=y.device)[None] <
+             torch.as_tensor(np.asarray(seq_len_y), device=y.device)[:, None])[:, None, :]
+        return y * m, seq_len_y

@@ -1,0 +1,237 @@
+"""FBCRNN: drop-in counterpart of ``pb_sed.models.weak_label.CRNN``
+(reference pb_sed/models/weak_label/crnn.py:14-340) running on the HIP kernels.
+
+Same constructor fields, same ``forward`` / ``review`` / ``tagging`` / ``boundaries_detection`` /
+``sound_event_detection`` contracts.  In addition to the reference's ``inputs['stft']`` the model
+accepts ``inputs['audio_data']`` ([B, N] waveform) so that the STFT runs on the GPU inside the fused
+log-mel kernel (BASELINE.json north_star).
+"""
+import numpy as np
+import torch
+
+from .. import engine, ops
+from ..modules import (SHALLOW, NormalizedLogMelExtractor, build_cnn, build_rnn, num_frames)
+from .base import SoundEventModel
+
+
+class _NetFunction(torch.autograd.Function):
+    """features -> CNN -> fwd/bwd GRUs -> heads -> squashed scores, as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, model, x, seq_host, seq_dev, training, *params):
+        layers = engine.describe_stack([model.cnn.cnn_2d, model.cnn.cnn_1d])
+        h, cnn_ctx = engine.stack_forward(layers, x, seq_dev, seq_host, training)
+        wrappers = [model.rnn_fwd] + ([model.rnn_bwd] if model.rnn_bwd is not None else [])
+        logits, rnn_ctx = engine.rnn_forward(wrappers, h, seq_dev, seq_host, training)
+        ys = [ops.squash_fwd(l, model.minimum_score) for l in logits]
+        ctx.state = (model, layers, cnn_ctx, wrappers, rnn_ctx, ys, seq_host, seq_dev)
+        ctx.mark_non_differentiable(h)
+        return (h, *ys)
+
+    @staticmethod
+    def backward(ctx, _dh, *dys):
+        model, layers, cnn_ctx, wrappers, rnn_ctx, ys, seq_host, seq_dev = ctx.state
+        ctx.state = None
+        engine.flatten_parameters(model)
+        dlogits = [ops.squash_bwd(y, dy, model.minimum_score) for y, dy in zip(ys, dys)]
+        dh = engine.rnn_backward(wrappers, rnn_ctx, dlogits, seq_dev, seq_host)
+        engine.stack_backward(layers, cnn_ctx, dh, seq_dev, seq_host, need_input_grad=False)
+        return (None,) * (5 + len(model._net_params))
+
+
+class _HeadsFunction(torch.autograd.Function):
+    """GRUs + heads only (windowed SED re-runs them on stacked windows of h; inference only)."""
+
+    @staticmethod
+    def forward(ctx, model, h, seq_host, seq_dev):
+        wrappers = [model.rnn_fwd] + ([model.rnn_bwd] if model.rnn_bwd is not None else [])
+        logits, _ = engine.rnn_forward(wrappers, h, seq_dev, seq_host, False)
+        return tuple(ops.squash_fwd(l, model.minimum_score) for l in logits)
+
+    @staticmethod
+    def backward(ctx, *g):
+        raise NotImplementedError('windowed SED is an inference method')
+
+
+class _LossFunction(torch.autograd.Function):
+    """Fused FBCRNN loss (pb_sed/models/weak_label/crnn.py:107-153,180-206) on squashed scores."""
+
+    @staticmethod
+    def forward(ctx, y_fwd, y_bwd, weak, bnd, seq_dev, cfg):
+        loss, _, _, d_f, d_b = ops.fbcrnn_loss(
+            y_fwd.contiguous(), None if y_bwd is None else y_bwd.contiguous(), weak, bnd, seq_dev,
+            minimum_score=cfg['minimum_score'], strong_weight=cfg['strong_weight'], slat=cfg['slat'],
+            label_smoothing=cfg['label_smoothing'], class_weights=cfg['class_weights'],
+            inputs_are_scores=True)
+        ctx.grads = (d_f, d_b)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d_f, d_b = ctx.grads
+        return d_f * g, (None if d_b is None else d_b * g), None, None, None, None
+
+
+class CRNN(SoundEventModel):
+    """
+    >>> crnn = CRNN.build(num_events=10)           # reference 'shallow' config
+    >>> outputs = crnn({'audio_data': wav, 'seq_len': [500] * 32, 'weak_targets': w, 'boundary_targets': b})
+    >>> review = crnn.review(inputs, outputs); review['loss'].backward()
+    """
+
+    def __init__(self, feature_extractor, cnn, rnn_fwd, rnn_bwd, *, minimum_score=1e-5,
+                 label_smoothing=0., labelwise_metrics=(), label_mapping=None, test_labels=None,
+                 slat=False, strong_fwd_bwd_loss_weight=1., class_weights=None):
+        super().__init__(labelwise_metrics=labelwise_metrics, label_mapping=label_mapping,
+                         test_labels=test_labels)
+        self.feature_extractor = feature_extractor
+        self.cnn = cnn
+        self.rnn_fwd = rnn_fwd
+        self.rnn_bwd = rnn_bwd
+        self.minimum_score = minimum_score
+        self.label_smoothing = label_smoothing
+        self.slat = slat
+        self.strong_fwd_bwd_loss_weight = strong_fwd_bwd_loss_weight
+        self.class_weights = None if class_weights is None else torch.Tensor(class_weights)
+
+    @classmethod
+    def build(cls, num_events=10, number_of_filters=128, stft_size=1024, sample_rate=16000,
+              hidden_size=256, num_layers=2, net=None, rnn_bwd=True, **kw):
+        """Reference model factory (pb_sed/experiments/weak_label_crnn/training.py:158-260)."""
+        net = dict(SHALLOW if net is None else net)
+        fe = NormalizedLogMelExtractor(sample_rate, stft_size, number_of_filters)
+        cnn = build_cnn(1, input_height=number_of_filters, **net)
+        c = net['out_channels_1d'][-1]
+        fwd = build_rnn(c, hidden_size, num_layers, num_events, hidden_size)
+        bwd = build_rnn(c, hidden_size, num_layers, num_events, hidden_size, reverse=True) if rnn_bwd else None
+        return cls(fe, cnn, fwd, bwd, **kw)
+
+    # ------------------------------------------------------------------ forward / review
+    def _features(self, inputs, seq_host, seq_dev):
+        if 'audio_data' in inputs:
+            audio = inputs['audio_data']
+            audio = audio.reshape(audio.shape[0], -1).to(torch.float32)
+            return engine.features_from_audio(self.feature_extractor, audio, seq_dev, num_frames(audio.shape[1]))
+        return engine.features_from_stft(self.feature_extractor, inputs['stft'], seq_host)
+
+    def _net(self, x, seq_host, seq_dev):
+        self._net_params = [p for p in self.parameters()]
+        engine.flatten_parameters(self)
+        training = self.training and torch.is_grad_enabled()   # batch statistics + saved context
+        return _NetFunction.apply(self, x, seq_host, seq_dev, training, *self._net_params)
+
+    def sigmoid(self, y):
+        return self.minimum_score + (1 - 2 * self.minimum_score) * torch.sigmoid(y)
+
+    def forward(self, inputs):
+        key = 'audio_data' if 'audio_data' in inputs else 'stft'
+        x_in = inputs.pop(key) if self.training else inputs[key]
+        seq_host, seq_dev = self._seq(inputs, x_in.device)
+        x = self._features({key: x_in}, seq_host, seq_dev)
+        targets = self.read_targets(inputs) if 'weak_targets' in inputs else None
+        h, y_fwd, *rest = self._net(x, seq_host, seq_dev)
+        y_bwd = rest[0] if rest else None
+        return y_fwd, y_bwd, seq_host, x, seq_host, targets
+
+    def read_targets(self, inputs, subsample_idx=None):
+        if 'boundary_targets' in inputs:
+            return inputs['weak_targets'], inputs['boundary_targets']
+        return inputs['weak_targets'],
+
+    def review(self, inputs, outputs):
+        y_fwd, y_bwd, seq_len, x, _, targets = outputs
+        assert targets is not None
+        weak_targets = targets[0].to(torch.float32)
+        seq_dev = torch.as_tensor(np.asarray(seq_len), dtype=torch.int32).to(y_fwd.device)
+        bnd = None
+        if self.strong_fwd_bwd_loss_weight > 0. and not self.slat:
+            assert len(targets) == 2, len(targets)
+            bnd = targets[1].to(torch.float32)
+        cfg = dict(minimum_score=self.minimum_score, strong_weight=self.strong_fwd_bwd_loss_weight,
+                   slat=self.slat, label_smoothing=self.label_smoothing,
+                   class_weights=None if self.class_weights is None else self.class_weights.to(y_fwd.device))
+        loss = _LossFunction.apply(y_fwd, y_bwd, weak_targets, bnd, seq_dev, cfg)
+
+        # summary side (host): same buffers / scalars as the reference (crnn.py:122,137,155-177)
+        w_mask = (weak_targets < .01) | (weak_targets > .99)
+        wm = w_mask.cpu().numpy()
+        w = (weak_targets * w_mask)
+        boundary_label_rate = 0.
+        if self.strong_fwd_bwd_loss_weight > 0.:
+            beta = w[..., None].expand(y_fwd.shape) if self.slat else bnd
+            b_mask = (beta > .99) | (beta < .01)
+            b_mask = b_mask * (b_mask.float().mean(-1, keepdim=True) > .999) * (w > .99)[..., None]
+            boundary_label_rate = b_mask.cpu().numpy().mean()
+        labeled = (wm == 1).all(-1)
+        idx = torch.as_tensor(np.asarray(seq_len) - 1, device=y_fwd.device, dtype=torch.long)
+        y_weak = y_fwd.detach()[torch.arange(y_fwd.shape[0], device=y_fwd.device), :, idx]
+        if y_bwd is not None:
+            y_weak = y_weak / 2 + y_bwd.detach()[..., 0] / 2
+        return dict(
+            loss=loss,
+            scalars=dict(seq_len=np.mean(inputs['seq_len']), weak_label_rate=wm.mean(),
+                         boundary_label_rate=boundary_label_rate),
+            images=dict(features=x[:3]),
+            buffers=dict(y_weak=y_weak.cpu().numpy()[labeled], targets_weak=w.cpu().numpy()[labeled]),
+        )
+
+    # ------------------------------------------------------------------ inference heads
+    def tagging(self, inputs):
+        y_fwd, y_bwd, seq_len_y, *_ = self.forward(inputs)
+        seq_len = np.ones_like(seq_len_y)
+        idx = torch.as_tensor(np.asarray(seq_len_y) - 1, device=y_fwd.device, dtype=torch.long)
+        last = y_fwd[torch.arange(y_fwd.shape[0], device=y_fwd.device), :, idx][..., None]
+        if y_bwd is None:
+            return last, seq_len
+        return (last + y_bwd[..., :1]) / 2, seq_len
+
+    def boundaries_detection(self, inputs):
+        y_fwd, y_bwd, seq_len_y, *_ = self.forward(inputs)
+        t = y_fwd.shape[-1]
+        m = (torch.arange(t, device=y_fwd.device)[None] <
+             torch.as_tensor(np.asarray(seq_len_y), device=y_fwd.device)[:, None])[:, None, :]
+        return torch.minimum(y_fwd * m, y_bwd * m), seq_len_y
+
+    def sound_event_detection(self, inputs, window_length, window_shift=1):
+        window_length = np.array(window_length, dtype=int)
+        key = 'audio_data' if 'audio_data' in inputs else 'stft'
+        seq_host, seq_dev = self._seq(inputs, inputs[key].device)
+        x = self._features(inputs, seq_host, seq_dev)
+        with torch.no_grad():
+            h = self._net(x, seq_host, seq_dev)[0]
+        if window_length.ndim == 0:
+            return self._single_window_length_sed(h, seq_host, int(window_length), window_shift)
+        y = None
+        for win_len in np.unique(window_length.flatten()):
+            yi, seq_len_y = self._single_window_length_sed(h, seq_host, int(win_len), window_shift)
+            b, k, t = yi.shape
+            if window_length.ndim == 1:
+                assert window_length.shape[0] in [1, k], window_length.shape
+            elif window_length.ndim == 2:
+                assert window_length.shape[1] in [1, k], window_length.shape
+                window_length = np.broadcast_to(window_length, (window_length.shape[0], k))
+                yi = yi[:, None]
+            else:
+                raise ValueError('window_length.ndim must not be greater than 2.')
+            if y is None:
+                y = torch.zeros((b, *window_length.shape, t), device=yi.device)
+            y += (torch.from_numpy(window_length.copy()).to(yi.device) == win_len)[..., None] * yi
+        return y, seq_len_y
+
+    def _single_window_length_sed(self, h, seq_len, window_length, window_shift):
+        b, f, t = h.shape
+        if window_length > window_shift:
+            p = window_length - window_shift
+            h = torch.nn.functional.pad(h, (p // 2, p - p // 2))
+        h = torch.nn.functional.pad(h, (0, window_shift - 1))
+        wins = [h[..., i:i + window_length] for i in np.arange(0, t, window_shift)]
+        n = len(wins)
+        hw = torch.cat(wins, dim=0).contiguous()
+        seq_host = np.full(n * b, window_length)
+        seq_dev = torch.full((n * b,), window_length, dtype=torch.int32, device=h.device)
+        with torch.no_grad():
+            ys = _HeadsFunction.apply(self, hw, seq_host, seq_dev)
+        y = ys[0][..., -1].reshape(n, b, -1).permute(1, 2, 0)
+        if self.rnn_bwd is not None:
+            y = (y + ys[1][..., 0].reshape(n, b, -1).permute(1, 2, 0)) / 2
+        return y, 1 + (np.asarray(seq_len) - 1) // window_shift

@@ -1,0 +1,177 @@
+"""Host-side mirror of the padertorch building blocks the reference model is assembled from.
+
+These ``nn.Module`` classes own the parameters (same tree / names as the reference's modules:
+``cnn.cnn_2d``, ``cnn.cnn_1d``, ``rnn_fwd.rnn`` with torch-GRU parameter names,
+``rnn_fwd.output_net`` - see reference pb_sed/experiments/weak_label_crnn/training.py:329-350) and
+describe the layer tables; all arithmetic is done by the HIP kernels driven from
+``pb_sed_amd.engine``.  Reference call sites: pb_sed/models/weak_label/crnn.py:86-100.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+
+def hz2mel(f):
+    return 2595.0 * np.log10(1.0 + np.asarray(f, dtype=np.float64) / 700.0)
+
+
+def mel2hz(m):
+    return 700.0 * (10.0 ** (np.asarray(m, dtype=np.float64) / 2595.0) - 1.0)
+
+
+def get_fbanks(sample_rate, stft_size, number_of_filters, lowest_frequency=50., highest_frequency=None):
+    """HTK-mel triangular filterbank, unit-sum filters (paderbox get_fbanks semantics)."""
+    highest_frequency = sample_rate / 2 if highest_frequency is None else highest_frequency
+    pts = mel2hz(np.linspace(hz2mel(lowest_frequency), hz2mel(highest_frequency), number_of_filters + 2))
+    frac = pts / sample_rate * stft_size
+    k = np.arange(stft_size // 2 + 1, dtype=np.float64)[None]
+    c, lo, hi = frac[1:-1, None], frac[:-2, None], frac[2:, None]
+    fb = np.maximum(np.minimum((k - lo) / (c - lo), (hi - k) / (hi - c)), 0.)
+    return (fb / fb.sum(-1, keepdims=True)).astype(np.float32)
+
+
+def num_frames(n_samples, shift=320, window_length=960):
+    pad = window_length - shift
+    return max(int(math.ceil((n_samples + pad - window_length) / shift)) + 1, 1)
+
+
+class NormalizedLogMelExtractor(nn.Module):
+    """Front-end description (STFT 1024/960/320 Blackman -> mel -> log -> global norm -> clamp)."""
+
+    def __init__(self, sample_rate=16000, stft_size=1024, number_of_filters=128, lowest_frequency=50.,
+                 highest_frequency=None, eps=1e-18, clamp=6.0, shift=320, window_length=960):
+        super().__init__()
+        if (stft_size, shift, window_length) != (1024, 320, 960):
+            raise NotImplementedError('the fused HIP front-end is built for STFT 1024/960/320 '
+                                      '(pb_sed/data_preparation/provider.py:315-323)')
+        self.sample_rate, self.stft_size, self.number_of_filters = sample_rate, stft_size, number_of_filters
+        self.shift, self.window_length, self.eps, self.clamp = shift, window_length, eps, clamp
+        fb = get_fbanks(sample_rate, stft_size, number_of_filters, lowest_frequency, highest_frequency)
+        self.register_buffer('fbanks', torch.from_numpy(fb))
+        self.register_buffer('mean', torch.zeros(number_of_filters))
+        self.register_buffer('inv_std', torch.ones(number_of_filters))
+        self._tables = None
+
+
+class Normalization(nn.Module):
+    def __init__(self, num_channels, eps=1e-3, momentum=0.95):
+        super().__init__()
+        self.num_channels, self.eps, self.momentum = num_channels, eps, momentum
+        self.gamma = nn.Parameter(torch.ones(num_channels))
+        self.beta = nn.Parameter(torch.zeros(num_channels))
+        self.register_buffer('running_mean', torch.zeros(num_channels))
+        self.register_buffer('running_power', torch.ones(num_channels))
+        self.freeze_stats = False
+
+
+class ConvLayer(nn.Module):
+    def __init__(self, ndim, cin, cout, k, pool=1, pre=False, post=False, eps=1e-3):
+        super().__init__()
+        self.ndim, self.k, self.pool, self.pre, self.post = ndim, k, pool, pre, post
+        self.conv = (nn.Conv2d if ndim == 2 else nn.Conv1d)(cin, cout, k)
+        nn.init.xavier_uniform_(self.conv.weight)
+        nn.init.zeros_(self.conv.bias)
+        self.norm = Normalization(cin if pre else cout, eps=eps) if (pre or post) else None
+        p = pool if isinstance(pool, (tuple, list)) else (pool, pool)
+        if ndim == 2 and tuple(p) not in ((1, 1), (2, 1)):
+            raise NotImplementedError(f'pool {pool}: kernels implement frequency-only (2,1) pooling '
+                                      '(pb_sed/experiments/weak_label_crnn/training.py:167)')
+        if ndim == 1 and tuple(p) != (1, 1):
+            raise NotImplementedError('CNN1d pooling is not used by the reference configs')
+        self.pool_f = ndim == 2 and tuple(p) == (2, 1)
+        if k not in (1, 3):
+            raise NotImplementedError('kernel sizes 1 and 3 only (reference shallow config)')
+
+
+class _CNN(nn.Module):
+    ndim = None
+
+    def __init__(self, in_channels, out_channels, kernel_size, pool_size=1, norm='batch', eps=1e-3,
+                 pre_activation=False, output_layer=True, input_layer=True):
+        super().__init__()
+        n = len(out_channels)
+        ks = kernel_size if isinstance(kernel_size, (list, tuple)) else n * [kernel_size]
+        ps = pool_size if isinstance(pool_size, list) and len(pool_size) == n else n * [pool_size]
+        self.in_channels, self.out_channels = in_channels, list(out_channels)
+        convs, cin = [], in_channels
+        for i, cout in enumerate(out_channels):
+            if pre_activation:
+                pre, post = norm is not None and not (i == 0 and input_layer), False
+            else:
+                pre, post = False, norm is not None and not (i == n - 1 and output_layer)
+            convs.append(ConvLayer(self.ndim, cin, cout, ks[i], ps[i], pre, post, eps))
+            cin = cout
+        self.convs = nn.ModuleList(convs)
+
+    def freeze(self, num_layers=None, freeze_norm_stats=True):
+        layers = self.convs if num_layers is None else self.convs[:num_layers]
+        for layer in layers:
+            for p in layer.parameters():
+                p.requires_grad = False
+            if freeze_norm_stats and layer.norm is not None:
+                layer.norm.freeze_stats = True
+
+
+class CNN2d(_CNN):
+    ndim = 2
+
+
+class CNN1d(_CNN):
+    ndim = 1
+
+
+class CNN(nn.Module):
+    def __init__(self, cnn_2d, cnn_1d, input_height=128, conditional_dims=0):
+        super().__init__()
+        self.cnn_2d, self.cnn_1d = cnn_2d, cnn_1d
+        self.input_height, self.conditional_dims = input_height, conditional_dims
+
+
+class GRU(nn.Module):
+    """padertorch GRU wrapper mirror: ``rnn`` (torch.nn.GRU parameter names) + ``output_net``."""
+
+    def __init__(self, input_size, hidden_size, num_layers=1, bidirectional=False, reverse=False,
+                 output_net=None):
+        super().__init__()
+        # torch.nn.GRU is used as the parameter container (names, shapes, U(+-1/sqrt(H)) init);
+        # its forward is never called - the scan runs in pb_sed_amd/csrc/gru.hip.
+        self.rnn = nn.GRU(input_size, hidden_size, num_layers, bias=True, batch_first=True, dropout=0.,
+                          bidirectional=bidirectional)
+        self.output_net = output_net
+        self.reverse = reverse
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.num_layers, self.bidirectional = num_layers, bidirectional
+        if hidden_size % 64:
+            raise NotImplementedError('GRU hidden size must be a multiple of 64')
+
+
+SHALLOW = dict(
+    out_channels_2d=[16, 16, 32, 32, 64, 64, 128, 128, 256],
+    pool_sizes_2d=4 * [1, (2, 1)] + [1],
+    kernel_size_2d=3,
+    out_channels_1d=5 * [256],
+    kernel_size_1d=[1, 3, 3, 3, 1],
+)
+
+
+def build_cnn(in_channels, out_channels_2d, pool_sizes_2d, kernel_size_2d, out_channels_1d, kernel_size_1d,
+              input_height, conditional_dims=0, eps=1e-3):
+    cnn_2d = CNN2d(in_channels + conditional_dims, out_channels_2d, kernel_size_2d, pool_sizes_2d, eps=eps,
+                   pre_activation=True, output_layer=False, input_layer=True)
+    f = input_height
+    ps = pool_sizes_2d if isinstance(pool_sizes_2d, list) else len(out_channels_2d) * [pool_sizes_2d]
+    for p in ps:
+        f //= (p[0] if isinstance(p, (tuple, list)) else p)
+    cnn_1d = CNN1d(out_channels_2d[-1] * f, out_channels_1d, kernel_size_1d, 1, eps=eps,
+                   pre_activation=True, output_layer=False, input_layer=False)
+    return CNN(cnn_2d, cnn_1d, input_height, conditional_dims)
+
+
+def build_rnn(input_size, hidden_size, num_layers, num_events, head_hidden, bidirectional=False,
+              reverse=False, eps=1e-3):
+    dirs = 2 if bidirectional else 1
+    output_net = CNN1d(hidden_size * dirs, [head_hidden, num_events], 1, 1, eps=eps, pre_activation=False,
+                       output_layer=True)
+    return GRU(input_size, hidden_size, num_layers, bidirectional, reverse, output_net)

@@ -1,0 +1,264 @@
+"""Thin functional wrappers over the C-ABI (one call = one or a few HIP launches, no autograd).
+
+Tensors are torch CUDA(HIP) tensors used purely as device memory; everything runs on torch's
+current stream.  Shapes follow the reference layouts: 2-D activations ``[B, C, F, T]``, 1-D
+``[B, C, T]`` (treated as F = 1), GRU scan buffers time-major ``[T, B, *]``.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+
+def _dims4(x):
+    if x.dim() == 3:
+        b, c, t = x.shape
+        return b, c, 1, t
+    return tuple(x.shape)
+
+
+class PackedConv:
+    """Weights of one conv layer packed for the forward and data-gradient kernels."""
+
+    def __init__(self, weight):
+        w = weight.detach()
+        if w.dim() == 3:
+            cout, cin, kw = w.shape
+            kh = 1
+        else:
+            cout, cin, kh, kw = w.shape
+        self.cout, self.cin, self.kh, self.kw = cout, cin, kh, kw
+        self.weight = weight
+
+    def _pack(self, dgrad):
+        inp, outp = C.c_int(), C.c_int()
+        _lib.lib().pbsed_conv_pack_dims(self.kh, self.kw, self.cin, self.cout, dgrad,
+                                        C.byref(inp), C.byref(outp))
+        wp = torch.empty(self.kh * self.kw * inp.value * outp.value, device=self.weight.device,
+                         dtype=torch.float32)
+        call('pbsed_pack_conv_weights', ptr(self.weight.detach().contiguous()), ptr(wp), self.cout,
+             self.cin, self.kh, self.kw, dgrad, stream())
+        return wp
+
+    def fwd(self):
+        return self._pack(0)
+
+    def dgrad(self):
+        return self._pack(1)
+
+
+def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=None, pool=False,
+             want_stats=False, stats_per_cf=False):
+    """y = conv(prologue(x)) [+pool].  Returns (y, pool_idx|None, stats|None)."""
+    _lib.require_gpu(x)
+    b, cin, f, t = _dims4(x)
+    assert cin == pc.cin, (cin, pc.cin)
+    fo = f // 2 if pool else f
+    shape = (b, pc.cout, t) if x.dim() == 3 else (b, pc.cout, fo, t)
+    y = torch.empty(shape, device=x.device, dtype=torch.float32)
+    idx = torch.empty(shape, device=x.device, dtype=torch.uint8) if pool else None
+    stats = None
+    if want_stats:
+        stats = torch.zeros((pc.cout * fo if stats_per_cf else pc.cout, 2), device=x.device,
+                            dtype=torch.float64)
+    call('pbsed_conv_fwd', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
+         ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, pc.kh, pc.kw,
+         int(pool), stream())
+    return y, idx, stats
+
+
+def conv_bwd_data(g, pc, wd, x_shape, unpool_idx=None, seq_len=None, bn=None, relu=True):
+    """Gradient wrt the conv input.  ``bn=(x, mean, invstd, scale, shift)`` additionally pushes it
+    back through mask/ReLU/BN-apply (returns dz and the (sum dz, sum dz*xhat) statistics)."""
+    b, cin, f, t = _dims4(torch.empty(x_shape, device='meta'))
+    dz = torch.empty(x_shape, device=g.device, dtype=torch.float32)
+    stats = None
+    bx = bmean = binv = bsc = bsh = None
+    if bn is not None:
+        bx, bmean, binv, bsc, bsh = bn
+        stats = torch.zeros((cin, 2), device=g.device, dtype=torch.float64)
+    call('pbsed_conv_bwd_data', ptr(g), ptr(wd), ptr(unpool_idx), ptr(seq_len), ptr(dz), ptr(bx),
+         ptr(bmean), ptr(binv), ptr(bsc), ptr(bsh), int(relu), ptr(stats), b, cin, pc.cout, f, t,
+         pc.kh, pc.kw, stream())
+    return dz, stats
+
+
+def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, seq_len=None,
+                    unpool_idx=None):
+    """dw (+=), db (+=): gradients of the conv parameters (buffers must be pre-zeroed/accumulating)."""
+    b, cin, f, t = _dims4(x)
+    call('pbsed_conv_bwd_weight', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(g),
+         ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream())
+
+
+class BNState:
+    """Per-layer batch statistics / fused scale+shift produced by bn_finalize (or eval params)."""
+
+    def __init__(self, c, device):
+        buf = torch.empty((6, c), device=device, dtype=torch.float32)
+        self.mean, self.invstd, self.scale, self.shift, self.m1, self.m2 = buf.unbind(0)
+        self.c = c
+
+
+def bn_finalize(stats, count, norm, training_update=True):
+    st = BNState(stats.shape[0], stats.device)
+    call('pbsed_bn_finalize', ptr(stats), float(count), ptr(norm.gamma.detach()), ptr(norm.beta.detach()),
+         float(norm.eps), float(norm.momentum), ptr(norm.running_mean if training_update else None),
+         ptr(norm.running_power if training_update else None), ptr(st.mean), ptr(st.invstd),
+         ptr(st.scale), ptr(st.shift), st.c, stream())
+    return st
+
+
+def bn_eval_params(norm):
+    st = BNState(norm.gamma.numel(), norm.gamma.device)
+    call('pbsed_bn_eval_params', ptr(norm.gamma.detach()), ptr(norm.beta.detach()), float(norm.eps),
+         ptr(norm.running_mean), ptr(norm.running_power), ptr(st.mean), ptr(st.invstd), ptr(st.scale),
+         ptr(st.shift), st.c, stream())
+    return st
+
+
+def bn_backward(dz, x, st, stats, count, dgamma, dbeta, seq_len):
+    """In place dz -> dx; accumulates dgamma/dbeta."""
+    b, c, s, t = _dims4(x)
+    call('pbsed_bn_bwd_finalize', ptr(stats), float(count), ptr(dgamma), ptr(dbeta), ptr(st.m1),
+         ptr(st.m2), c, stream())
+    call('pbsed_bn_bwd_apply', ptr(dz), ptr(x), ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.m1),
+         ptr(st.m2), ptr(seq_len), b, c, s, t, stream())
+    return dz
+
+
+def bct_to_tbc(x):
+    b, c, t = x.shape
+    y = torch.empty((t, b, c), device=x.device, dtype=torch.float32)
+    call('pbsed_bct_to_tbc', ptr(x), ptr(y), b, c, t, stream())
+    return y
+
+
+def tbc_to_bct(x, shift=0):
+    t, b, c = x.shape
+    y = torch.empty((b, c, t), device=x.device, dtype=torch.float32)
+    call('pbsed_tbc_to_bct', ptr(x), ptr(y), b, c, t, int(shift), stream())
+    return y
+
+
+def transpose2d(x):
+    r, c = x.shape
+    y = torch.empty((c, r), device=x.device, dtype=torch.float32)
+    call('pbsed_transpose2d', ptr(x.contiguous()), ptr(y), r, c, stream())
+    return y
+
+
+def gru_scan_fwd(gi, w_hh, b_hh, reverse, seq_len, save=True):
+    """gi: list of [T,B,3H] per chain.  Returns (hs list [T,B,H], save list [T,B,4,H]|None)."""
+    n = len(gi)
+    t, b, g = gi[0].shape
+    h = g // 3
+    dev = gi[0].device
+    hs = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
+    sv = [torch.empty((t, b, 4, h), device=dev, dtype=torch.float32) for _ in range(n)] if save else None
+    call('pbsed_gru_scan_fwd', n, _lib.ptr_array(gi), _lib.ptr_array([w.contiguous() for w in w_hh]),
+         _lib.ptr_array(b_hh), _lib.ptr_array(hs), _lib.ptr_array(sv) if save else None,
+         _lib.int_array(reverse), ptr(seq_len), b, h, t, stream())
+    return hs, sv
+
+
+def gru_scan_bwd(w_hh_t, hs, save, dy, reverse, seq_len):
+    n = len(hs)
+    t, b, h = hs[0].shape
+    dev = hs[0].device
+    dgi = [torch.empty((t, b, 3 * h), device=dev, dtype=torch.float32) for _ in range(n)]
+    dgh = [torch.empty((t, b, 3 * h), device=dev, dtype=torch.float32) for _ in range(n)]
+    dhz = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
+    call('pbsed_gru_scan_bwd', n, _lib.ptr_array(w_hh_t), _lib.ptr_array(hs), _lib.ptr_array(save),
+         _lib.ptr_array(dy), _lib.ptr_array(dgi), _lib.ptr_array(dgh), _lib.ptr_array(dhz),
+         _lib.int_array(reverse), ptr(seq_len), b, h, t, stream())
+    return dgi, dgh
+
+
+def squash_fwd(x, eps):
+    y = torch.empty_like(x)
+    call('pbsed_squash_fwd', ptr(x), ptr(y), x.numel(), float(eps), stream())
+    return y
+
+
+def squash_bwd(y, dy, eps):
+    dx = torch.empty_like(y)
+    call('pbsed_squash_bwd', ptr(y), ptr(dy.contiguous()), ptr(dx), y.numel(), float(eps), stream())
+    return dx
+
+
+def fbcrnn_loss(logit_fwd, logit_bwd, weak_targets, boundary_targets, seq_len, *, minimum_score=1e-5,
+                strong_weight=1., slat=False, label_smoothing=0., class_weights=None, want_grad=True,
+                inputs_are_scores=False):
+    b, k, t = logit_fwd.shape
+    dev = logit_fwd.device
+    y_f = torch.empty_like(logit_fwd)
+    y_b = torch.empty_like(logit_fwd) if logit_bwd is not None else None
+    d_f = torch.empty_like(logit_fwd) if want_grad else None
+    d_b = torch.empty_like(logit_fwd) if (want_grad and logit_bwd is not None) else None
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    call('pbsed_fbcrnn_loss', ptr(logit_fwd), ptr(logit_bwd), ptr(weak_targets.contiguous()),
+         ptr(None if boundary_targets is None else boundary_targets.contiguous()), ptr(class_weights),
+         ptr(seq_len), ptr(y_f), ptr(y_b), ptr(d_f), ptr(d_b), ptr(loss), b, k, t, float(minimum_score),
+         float(strong_weight), int(slat), float(label_smoothing), int(inputs_are_scores), stream())
+    return loss, y_f, y_b, d_f, d_b
+
+
+def bicrnn_loss(logit, strong_targets, seq_len, want_grad=True, inputs_are_scores=False):
+    b, k, t = logit.shape
+    y = torch.empty_like(logit)
+    d = torch.empty_like(logit) if want_grad else None
+    loss = torch.empty((), device=logit.device, dtype=torch.float32)
+    scratch = torch.empty((), device=logit.device, dtype=torch.float64)
+    call('pbsed_bicrnn_loss', ptr(logit), ptr(strong_targets.contiguous()), ptr(seq_len), ptr(y), ptr(d),
+         ptr(loss), ptr(scratch), b, k, t, int(inputs_are_scores), stream())
+    return loss, y, d
+
+
+class LogMelTables:
+    """Device tables for the fused front-end (window, twiddles, sparse mel filters)."""
+
+    def __init__(self, fbanks, device):
+        fb = np.asarray(fbanks, dtype=np.float32)
+        nz = fb > 0
+        start = np.array([int(np.argmax(r)) if r.any() else 0 for r in nz], dtype=np.int32)
+        end = np.array([len(r) - int(np.argmax(r[::-1])) if r.any() else 0 for r in nz], dtype=np.int32)
+        length = (end - start).astype(np.int32)
+        off = np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.int32)
+        w = np.concatenate([fb[m, start[m]:end[m]] for m in range(fb.shape[0])]).astype(np.float32)
+        k = np.arange(960, dtype=np.float64)
+        win = 0.42 - 0.5 * np.cos(2 * np.pi * k / 960) + 0.08 * np.cos(4 * np.pi * k / 960)
+        q = np.arange(1024, dtype=np.float64)
+        tw = np.stack([np.cos(-2 * np.pi * q / 1024), np.sin(-2 * np.pi * q / 1024)], -1)
+        as_dev = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(device)
+        self.window = as_dev(win, torch.float32)
+        self.twiddle = as_dev(tw, torch.float32)
+        self.start, self.len, self.off = (as_dev(a, torch.int32) for a in (start, length, off))
+        self.w = as_dev(w, torch.float32)
+        self.n_filters = fb.shape[0]
+
+
+def logmel_fwd(wav, tables, mean, inv_std, n_frames, seq_len=None, eps=1e-18, clamp=6.0):
+    """wav [B, N] f32 (device) -> normalised, clamped, masked log-mel [B, 1, F, T]."""
+    _lib.require_gpu(wav)
+    b, n = wav.shape
+    out = torch.empty((b, 1, tables.n_filters, n_frames), device=wav.device, dtype=torch.float32)
+    call('pbsed_logmel_fwd', ptr(wav.contiguous()), b, n, n_frames, ptr(seq_len), ptr(tables.window),
+         ptr(tables.twiddle), ptr(tables.start), ptr(tables.len), ptr(tables.off), ptr(tables.w),
+         tables.n_filters, ptr(mean), ptr(inv_std), float(eps), float(clamp if clamp is not None else 3e38),
+         ptr(out), stream())
+    return out
+
+
+def grad_sumsq(g, out):
+    call('pbsed_grad_sumsq', ptr(g), g.numel(), ptr(out), stream())
+
+
+def adam_step(p, g, m, v, *, lr, beta1=.9, beta2=.999, eps=1e-8, step, grad_scale=1., max_norm=1e10,
+              sumsq=None, norm_out=None):
+    call('pbsed_adam_step', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1),
+         float(beta2), float(eps), int(step), float(grad_scale), float(max_norm), ptr(sumsq),
+         ptr(norm_out), stream())

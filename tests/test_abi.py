@@ -1,0 +1,68 @@
+"""CPU-side checks: the C-ABI library builds/loads and exports every symbol include/pbsed.h declares
+(no compute calls without a GPU), and the product path refuses to run on CPU tensors."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def libpath():
+    from pb_sed_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.LIB_PATH
+
+
+def test_header_symbols_exported(libpath):
+    hdr = open(os.path.join(ROOT, 'include', 'pbsed.h')).read()
+    names = sorted(set(re.findall(r'\b(pbsed_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(names) >= 20
+    lib = ctypes.CDLL(libpath)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    from pb_sed_amd import _lib
+    assert set(_lib.SIGNATURES) == set(names), set(_lib.SIGNATURES) ^ set(names)
+
+
+def test_binding_loads_and_reports_version(libpath):
+    from pb_sed_amd import _lib
+    assert _lib.lib().pbsed_version() >= 1
+    assert _lib.lib().pbsed_last_error() is not None
+
+
+def test_no_cpu_fallback():
+    from pb_sed_amd import ops
+    from pb_sed_amd.modules import get_fbanks
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.conv_fwd(torch.zeros(1, 1, 4, 8), ops.PackedConv(torch.zeros(16, 1, 3, 3)), None)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.logmel_fwd(torch.zeros(1, 16000), None, None, None, 50)
+
+
+def test_pack_dims_host_logic(libpath):
+    from pb_sed_amd import _lib
+    i, o = ctypes.c_int(), ctypes.c_int()
+    for (kh, kw, cin, cout, dg), exp in {(3, 3, 1, 16, 0): (4, 16), (3, 3, 16, 32, 0): (16, 32),
+                                          (3, 3, 128, 256, 0): (128, 256), (1, 1, 2048, 256, 0): (2048, 256),
+                                          (1, 1, 256, 10, 0): (256, 16), (3, 3, 128, 256, 1): (256, 128),
+                                          (1, 1, 266, 768, 0): (272, 768)}.items():
+        _lib.lib().pbsed_conv_pack_dims(kh, kw, cin, cout, dg, ctypes.byref(i), ctypes.byref(o))
+        assert (i.value, o.value) == exp, ((kh, kw, cin, cout, dg), i.value, o.value)
+
+
+def test_model_structure_matches_oracle():
+    from oracle import models as om
+    from pb_sed_amd.models import strong_label, weak_label
+    a, b = weak_label.CRNN.build(), om.FBCRNN.build()
+    assert [(k, tuple(v.shape)) for k, v in a.state_dict().items()] == \
+           [(k, tuple(v.shape)) for k, v in b.state_dict().items()]
+    assert sum(p.numel() for p in a.parameters()) == 3493188
+    a, b = strong_label.CRNN.build(), om.BiCRNN.build()
+    assert [(k, tuple(v.shape)) for k, v in a.state_dict().items()] == \
+           [(k, tuple(v.shape)) for k, v in b.state_dict().items()]

@@ -1,0 +1,178 @@
+"""GPU parity tests, whole model: pb_sed_amd CRNNs (HIP path through the C-ABI) vs the CPU oracle with
+identical weights and inputs.  Scores within 1e-4 (fp32, BASELINE.json north_star), loss 1e-5 rel,
+gradients rtol 2e-3 of the per-tensor max (fp32 reductions over up to 2M positions)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+TINY = dict(out_channels_2d=[16, 16, 32], pool_sizes_2d=[1, (2, 1), (2, 1)], kernel_size_2d=3,
+            out_channels_1d=[64, 64, 64], kernel_size_1d=[1, 3, 1])
+
+
+def synth_batch(b, n_samples, k, seed=0, ragged=True):
+    from oracle.frontend import num_frames
+    g = torch.Generator().manual_seed(1234 + seed)
+    wav = torch.randn(b, n_samples, generator=g)
+    wav = wav / wav.abs().max(-1, keepdim=True)[0]
+    t = num_frames(n_samples)
+    rng = np.random.RandomState(1235 + seed)
+    seq = np.sort(rng.randint(int(t * .7), t + 1, b))[::-1].copy() if ragged else np.full(b, t)
+    seq[0] = t
+    weak = (rng.rand(b, k) < .25).astype(np.float32)
+    for i in range(b):
+        if weak[i].sum() == 0:
+            weak[i, rng.randint(k)] = 1
+    bnd = np.zeros((b, k, t), np.float32)
+    for i in range(b):
+        for c in range(k):
+            if weak[i, c]:
+                on = rng.randint(0, max(seq[i] - 12, 1))
+                bnd[i, c, on:min(on + rng.randint(4, 30), seq[i])] = 1
+    if b >= 4:                                     # one unlabeled clip (all 0.5 on absent classes)
+        weak[-1] += (1 - weak[-1]) * .5
+        bnd[-1] += (1 - bnd[-1]) * .5
+    return wav, seq, torch.tensor(weak), torch.tensor(bnd), t
+
+
+def rel_close(a, b, tol, name):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f'{name}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e})'
+
+
+def _copy_weights(dst, src):
+    missing, unexpected = dst.load_state_dict(src.state_dict(), strict=True)
+    assert not missing and not unexpected
+
+
+@pytest.mark.parametrize('cfg', ['tiny_ragged', 'tiny_full', 'shallow_b2'])
+def test_fbcrnn_train_step_parity(cfg):
+    from oracle import frontend as ofe, models as om
+    from pb_sed_amd.models import weak_label
+    torch.manual_seed(0)
+    if cfg.startswith('tiny'):
+        kw = dict(num_events=10, number_of_filters=128, hidden_size=64, num_layers=2, net=TINY)
+        b, n = 5, 16000 * 2
+    else:
+        kw = dict(num_events=10)
+        b, n = 2, 160000
+    ref = om.FBCRNN.build(**kw)
+    with torch.no_grad():                          # non-trivial norm / bias parameters
+        for name, p in ref.named_parameters():
+            if name.endswith('gamma'):
+                p.uniform_(.7, 1.3)
+            elif name.endswith('beta') or name.endswith('conv.bias'):
+                p.normal_(0, .1)
+        ref.feature_extractor.mean.fill_(-7.)
+        ref.feature_extractor.inv_std.fill_(.4)
+    model = weak_label.CRNN.build(**kw)
+    _copy_weights(model, ref)
+    model.to(DEV)
+    wav, seq, weak, bnd, t = synth_batch(b, n, 10, ragged=cfg != 'tiny_full')
+
+    ref.train()
+    inputs_ref = {'stft': ofe.stft(wav), 'seq_len': seq.tolist(), 'weak_targets': weak, 'boundary_targets': bnd}
+    out_ref = ref(inputs_ref)
+    rev_ref = ref.review(inputs_ref, out_ref)
+    rev_ref['loss'].backward()
+
+    model.train()
+    inputs = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV),
+              'boundary_targets': bnd.to(DEV)}
+    _, flat_grad = model.flat_parameters()
+    flat_grad.zero_()
+    out = model(dict(inputs))
+    rev = model.review(inputs, out)
+    rev['loss'].backward()
+    torch.cuda.synchronize()
+
+    rel_close(out[3], out_ref[3], 1e-4, 'features')
+    assert (out[0].cpu() - out_ref[0]).abs().max() < 1e-4, 'y_fwd'
+    assert (out[1].cpu() - out_ref[1]).abs().max() < 1e-4, 'y_bwd'
+    assert rev['loss'].item() == pytest.approx(rev_ref['loss'].item(), rel=1e-4)
+    np.testing.assert_allclose(rev['buffers']['y_weak'], rev_ref['buffers']['y_weak'], atol=1e-4)
+    refp = dict(ref.named_parameters())
+    bad = []
+    for name, p in model.named_parameters():
+        try:
+            rel_close(p.grad, refp[name].grad, 2e-3, name)
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, '\n'.join(bad)
+    # running statistics were updated like the oracle's
+    refb = dict(ref.named_buffers())
+    for name, buf in model.named_buffers():
+        if 'running' in name:
+            rel_close(buf, refb[name], 1e-4, name)
+
+
+def test_fbcrnn_eval_heads_parity():
+    from oracle import frontend as ofe, models as om
+    from pb_sed_amd.models import weak_label
+    torch.manual_seed(1)
+    kw = dict(num_events=10, number_of_filters=128, hidden_size=64, num_layers=2, net=TINY)
+    ref = om.FBCRNN.build(**kw).eval()
+    with torch.no_grad():
+        for name, buf in ref.named_buffers():
+            if name.endswith('running_mean'):
+                buf.normal_(0, .2)
+            elif name.endswith('running_power'):
+                buf.uniform_(.8, 1.5)
+        ref.feature_extractor.mean.fill_(-7.)
+        ref.feature_extractor.inv_std.fill_(.4)
+    model = weak_label.CRNN.build(**kw)
+    _copy_weights(model, ref)
+    model.to(DEV).eval()
+    wav, seq, *_ = synth_batch(4, 16000, 10, seed=3)
+    inp_ref = {'stft': ofe.stft(wav), 'seq_len': seq.tolist()}
+    inp = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist()}
+    with torch.no_grad():
+        for method, kwargs in [('tagging', {}), ('boundaries_detection', {}),
+                               ('sound_event_detection', dict(window_length=9, window_shift=2)),
+                               ('sound_event_detection', dict(window_length=[[5] * 10, [3, 9] * 5], window_shift=1))]:
+            y_ref, sl_ref = getattr(ref, method)(dict(inp_ref), **kwargs)
+            y, sl = getattr(model, method)(dict(inp), **kwargs)
+            np.testing.assert_array_equal(sl, sl_ref)
+            assert y.shape == y_ref.shape, (method, y.shape, y_ref.shape)
+            assert (y.cpu() - y_ref).abs().max() < 1e-4, method
+
+
+def test_bicrnn_train_step_parity():
+    from oracle import frontend as ofe, models as om
+    from pb_sed_amd.models import strong_label
+    torch.manual_seed(2)
+    kw = dict(num_events=10, number_of_filters=128, hidden_size=64, num_layers=2, net=TINY, tag_conditioning=True)
+    ref = om.BiCRNN.build(**kw)
+    model = strong_label.CRNN.build(**kw)
+    _copy_weights(model, ref)
+    model.to(DEV)
+    wav, seq, weak, strong, t = synth_batch(5, 24000, 10, seed=5)
+    tag = (weak > .99).float()
+    ref.train()
+    inp_ref = {'stft': ofe.stft(wav), 'seq_len': seq.tolist(), 'weak_targets': weak, 'strong_targets': strong,
+               'tag_condition': tag}
+    out_ref = ref(inp_ref)
+    loss_ref = ref.review(inp_ref, out_ref)['loss']
+    loss_ref.backward()
+    model.train()
+    inp = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV),
+           'strong_targets': strong.to(DEV), 'tag_condition': tag.to(DEV)}
+    model.flat_parameters()[1].zero_()
+    out = model(dict(inp))
+    loss = model.review(inp, out)['loss']
+    loss.backward()
+    assert (out[0].cpu() - out_ref[0]).abs().max() < 1e-4
+    assert loss.item() == pytest.approx(loss_ref.item(), rel=1e-4)
+    refp = dict(ref.named_parameters())
+    bad = []
+    for name, p in model.named_parameters():
+        try:
+            rel_close(p.grad, refp[name].grad, 2e-3, name)
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, '\n'.join(bad)

@@ -1,0 +1,271 @@
+"""GPU parity tests, per op: HIP kernels (through the C-ABI) vs the CPU oracle on seeded inputs.
+Tolerances: fp32 paths 1e-4 abs on O(1) activations (BASELINE.json north_star), gradients rtol 1e-3."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def close(a, b, atol=1e-4, rtol=1e-4, name=''):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    assert (err <= tol).all(), f'{name}: max err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)} ' \
+                               f'(ref {b.flat[err.argmax()]:.4e}, got {a.flat[err.argmax()]:.4e}, ' \
+                               f'{(err > tol).mean() * 100:.2f}% out of tol)'
+
+
+# ------------------------------------------------------------------------------------------ front-end
+@pytest.mark.parametrize('n,b', [(160000, 3), (16000, 2), (5000, 1)])
+def test_logmel_vs_oracle(n, b):
+    from oracle import frontend as fe
+    from pb_sed_amd import ops
+    from pb_sed_amd.modules import get_fbanks, num_frames
+    g = torch.Generator().manual_seed(1234)
+    wav = torch.randn(b, n, generator=g)
+    wav = wav / wav.abs().max(-1, keepdim=True)[0]
+    t = num_frames(n)
+    assert t == fe.num_frames(n)
+    seq = np.array([t, max(t - 7, 1), max(t // 2, 1)][:b])
+    ext = fe.LogMelExtractor()
+    ext.mean.copy_(torch.linspace(-8, -4, 128))
+    ext.inv_std.copy_(torch.linspace(.3, .6, 128))
+    ref, _ = ext(fe.stft(wav), seq_len=seq)
+    tables = ops.LogMelTables(get_fbanks(16000, 1024, 128), DEV)
+    out = ops.logmel_fwd(wav.to(DEV), tables, ext.mean.to(DEV), ext.inv_std.to(DEV), t,
+                         torch.as_tensor(seq, dtype=torch.int32).to(DEV))
+    close(out, ref, atol=2e-4, name='logmel')
+
+
+# ------------------------------------------------------------------------------------------ conv
+CONV_CASES = [
+    # cin, cout, F, T, k(2d? tuple), pool, prologue, ragged
+    dict(cin=1, cout=16, f=12, t=70, k=(3, 3), pool=False, pro=False),
+    dict(cin=16, cout=16, f=8, t=150, k=(3, 3), pool=True, pro=True),
+    dict(cin=16, cout=32, f=8, t=65, k=(3, 3), pool=False, pro=True),
+    dict(cin=32, cout=64, f=4, t=64, k=(3, 3), pool=True, pro=True),
+    dict(cin=24, cout=128, f=6, t=50, k=(3, 3), pool=True, pro=True),
+    dict(cin=20, cout=256, f=4, t=33, k=(3, 3), pool=False, pro=True),
+    dict(cin=11, cout=16, f=6, t=40, k=(3, 3), pool=False, pro=False),
+    dict(cin=64, cout=256, f=1, t=130, k=(1, 1), pool=False, pro=True),
+    dict(cin=40, cout=10, f=1, t=77, k=(1, 1), pool=False, pro=True),
+    dict(cin=48, cout=96, f=1, t=100, k=(1, 3), pool=False, pro=True),
+    dict(cin=266, cout=768, f=1, t=45, k=(1, 1), pool=False, pro=False),
+]
+
+
+def _conv_ref(x, w, bias, scale, shift, seq, k, pool):
+    """CPU reference of one layer: [BN-apply -> ReLU -> mask] -> pad -> conv -> pool."""
+    a = x
+    if scale is not None:
+        a = F.relu(x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+        m = (torch.arange(x.shape[-1])[None] < torch.as_tensor(seq)[:, None]).to(x.dtype)
+        a = a * m[:, None, None, :]
+    ph, pw = k[0] - 1, k[1] - 1
+    a = F.pad(a, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+    y = F.conv2d(a, w, bias)
+    if pool:
+        y, idx = F.max_pool2d(y, (2, 1), return_indices=True)
+    return y
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"{c['cin']}x{c['cout']}k{c['k'][0]}{c['k'][1]}p{int(c['pool'])}")
+def test_conv_fwd_bwd_vs_torch(case):
+    from pb_sed_amd import ops
+    torch.manual_seed(0)
+    b, cin, cout, f, t, k, pool, pro = 3, case['cin'], case['cout'], case['f'], case['t'], case['k'], case['pool'], case['pro']
+    x = torch.randn(b, cin, f, t, dtype=torch.float64)
+    w = (torch.randn(cout, cin, *k, dtype=torch.float64) / np.sqrt(cin * k[0] * k[1])).requires_grad_()
+    bias = torch.randn(cout, dtype=torch.float64).requires_grad_()
+    seq = np.array([t, max(t - 9, 1), max(t // 2, 1)])
+    scale = (torch.rand(cin, dtype=torch.float64) + .5) if pro else None
+    shift = torch.randn(cin, dtype=torch.float64) * .3 if pro else None
+    xr = x.clone().requires_grad_()
+    y_ref = _conv_ref(xr, w, bias, scale, shift, seq, k, pool)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+
+    dx = lambda a: None if a is None else a.float().to(DEV).contiguous()
+    seq_dev = torch.as_tensor(seq, dtype=torch.int32).to(DEV)
+    wd = w.detach().float().to(DEV)
+    pc = ops.PackedConv(wd if k[0] > 1 else wd)
+    xd = dx(x)
+    y, idx, stats = ops.conv_fwd(xd, pc, pc.fwd(), bias=dx(bias.detach()), scale=dx(scale), shift=dx(shift),
+                                 relu=True, seq_len=seq_dev, pool=pool, want_stats=True)
+    close(y, y_ref, name='conv_fwd')
+    # statistics epilogue: masked sums of the produced tensor
+    m = (torch.arange(t)[None] < torch.as_tensor(seq)[:, None]).double()[:, None, None, :]
+    yd = y_ref.detach()
+    close(stats[:, 0], (yd * m).sum((0, 2, 3)), atol=1e-3, rtol=1e-4, name='stats_sum')
+    close(stats[:, 1], (yd * yd * m).sum((0, 2, 3)), atol=1e-3, rtol=1e-4, name='stats_sumsq')
+    # weight / bias gradient
+    dw = torch.zeros_like(wd)
+    db = torch.zeros(cout, device=DEV)
+    ops.conv_bwd_weight(xd, dx(gy), pc, dw, db, scale=dx(scale), shift=dx(shift), relu=True, seq_len=seq_dev,
+                        unpool_idx=idx)
+    close(dw, w.grad, atol=2e-4, rtol=1e-3, name='conv_wgrad')
+    close(db, bias.grad, atol=2e-4, rtol=1e-3, name='conv_bgrad')
+    # data gradient (plain: only valid without prologue)
+    if not pro:
+        g, _ = ops.conv_bwd_data(dx(gy), pc, pc.dgrad(), xd.shape, idx, None)
+        close(g, xr.grad, atol=2e-4, rtol=1e-3, name='conv_dgrad')
+
+
+def test_conv_bn_relu_backward_chain_vs_autograd():
+    """conv_i output -> Normalization(train) -> ReLU -> conv_{i+1}: statistics epilogue, bn_finalize,
+    fused dgrad epilogue and bn_bwd_apply against autograd through the oracle layers."""
+    from oracle import nn as onn
+    from pb_sed_amd import ops
+    torch.manual_seed(1)
+    b, c0, c1, c2, f, t = 3, 8, 16, 24, 8, 90
+    seq = np.array([90, 71, 40])
+    l1 = onn._ConvLayer(2, c0, c1, 3, pool=(2, 1), pre=False).double()
+    l2 = onn._ConvLayer(2, c1, c2, 3, pool=1, pre=True).double()
+    with torch.no_grad():
+        l2.norm.gamma.uniform_(.5, 1.5)
+        l2.norm.beta.normal_(0, .2)
+        l1.conv.bias.normal_(0, .1)
+        l2.conv.bias.normal_(0, .1)
+    x = torch.randn(b, c0, f, t, dtype=torch.float64)
+    y1 = l1(x, seq)
+    y2 = l2(y1, seq)
+    gy = torch.randn_like(y2)
+    y2.backward(gy)
+
+    dd = lambda a: a.detach().float().to(DEV).contiguous()
+    seq_dev = torch.as_tensor(seq, dtype=torch.int32).to(DEV)
+    pc1, pc2 = ops.PackedConv(dd(l1.conv.weight)), ops.PackedConv(dd(l2.conv.weight))
+    y1d, idx1, stats = ops.conv_fwd(dd(x), pc1, pc1.fwd(), bias=dd(l1.conv.bias), seq_len=seq_dev, pool=True,
+                                    want_stats=True)
+    close(y1d, y1, name='y1')
+
+    class N:  # norm parameter holder on device
+        gamma, beta = dd(l2.norm.gamma), dd(l2.norm.beta)
+        eps, momentum = l2.norm.eps, l2.norm.momentum
+        running_mean, running_power = torch.zeros(c1, device=DEV), torch.ones(c1, device=DEV)
+    count = float(seq.sum() * (f // 2))
+    st = ops.bn_finalize(stats, count, N)
+    close(N.running_mean, l2.norm.running_mean, name='running_mean')
+    close(N.running_power, l2.norm.running_power, name='running_power')
+    y2d, _, _ = ops.conv_fwd(y1d, pc2, pc2.fwd(), bias=dd(l2.conv.bias), scale=st.scale, shift=st.shift,
+                             seq_len=seq_dev)
+    close(y2d, y2, name='y2')
+    dz, bstats = ops.conv_bwd_data(dd(gy), pc2, pc2.dgrad(), y1d.shape, None, seq_dev,
+                                   bn=(y1d, st.mean, st.invstd, st.scale, st.shift))
+    dgamma, dbeta = torch.zeros(c1, device=DEV), torch.zeros(c1, device=DEV)
+    g1 = ops.bn_backward(dz, y1d, st, bstats, count, dgamma, dbeta, seq_dev)
+    close(dgamma, l2.norm.gamma.grad, atol=2e-4, rtol=1e-3, name='dgamma')
+    close(dbeta, l2.norm.beta.grad, atol=2e-4, rtol=1e-3, name='dbeta')
+    dw1 = torch.zeros_like(dd(l1.conv.weight))
+    db1 = torch.zeros(c1, device=DEV)
+    ops.conv_bwd_weight(dd(x), g1, pc1, dw1, db1, seq_len=seq_dev, unpool_idx=idx1)
+    close(dw1, l1.conv.weight.grad, atol=2e-4, rtol=1e-3, name='dw1 (through pool + BN backward)')
+    close(db1, l1.conv.bias.grad, atol=2e-4, rtol=1e-3, name='db1')
+
+
+# ------------------------------------------------------------------------------------------ GRU
+@pytest.mark.parametrize('b,h,t,ragged', [(5, 64, 23, True), (32, 256, 40, False), (17, 128, 31, True)])
+def test_gru_scan_fwd_bwd_vs_torch(b, h, t, ragged):
+    from oracle import nn as onn
+    from pb_sed_amd import ops
+    torch.manual_seed(2)
+    cin = 24
+    seq = np.sort(np.random.RandomState(0).randint(t // 2, t + 1, b))[::-1].copy() if ragged else np.full(b, t)
+    seq[0] = t
+    x = torch.randn(b, cin, t)
+    grus = [onn.GRU(cin, h, 1, reverse=False), onn.GRU(cin, h, 1, reverse=True)]
+    xs = [x.clone().requires_grad_() for _ in grus]
+    ys = [g(xi, seq)[0] for g, xi in zip(grus, xs)]
+    gys = [torch.randn_like(y) for y in ys]
+    for y, gy in zip(ys, gys):
+        y.backward(gy)
+    seq_dev = torch.as_tensor(seq, dtype=torch.int32).to(DEV)
+    dd = lambda a: a.detach().float().to(DEV).contiguous()
+    gi = []
+    for g in grus:
+        gi_bct = torch.einsum('oc,bct->bot', g.rnn.weight_ih_l0, x) + g.rnn.bias_ih_l0[None, :, None]
+        gi.append(ops.bct_to_tbc(dd(gi_bct)))
+    hs, save = ops.gru_scan_fwd(gi, [dd(g.rnn.weight_hh_l0) for g in grus], [dd(g.rnn.bias_hh_l0) for g in grus],
+                                [0, 1], seq_dev)
+    for i in range(2):
+        close(ops.tbc_to_bct(hs[i]), ys[i], name=f'gru fwd chain{i}')
+    dy = [ops.bct_to_tbc(dd(gy)) for gy in gys]
+    dgi, dgh = ops.gru_scan_bwd([ops.transpose2d(dd(g.rnn.weight_hh_l0)) for g in grus], hs, save, dy, [0, 1], seq_dev)
+    for i, g in enumerate(grus):
+        dgi_b, dgh_b = ops.tbc_to_bct(dgi[i]).cpu(), ops.tbc_to_bct(dgh[i]).cpu()
+        hprev = ops.tbc_to_bct(hs[i], shift=1 if i else -1).cpu()
+        close(torch.einsum('bot,bct->oc', dgi_b, x), g.rnn.weight_ih_l0.grad, atol=3e-4, rtol=1e-3, name=f'dW_ih{i}')
+        close(dgi_b.sum((0, 2)), g.rnn.bias_ih_l0.grad, atol=3e-4, rtol=1e-3, name=f'db_ih{i}')
+        close(torch.einsum('bot,bct->oc', dgh_b, hprev), g.rnn.weight_hh_l0.grad, atol=3e-4, rtol=1e-3, name=f'dW_hh{i}')
+        close(dgh_b.sum((0, 2)), g.rnn.bias_hh_l0.grad, atol=3e-4, rtol=1e-3, name=f'db_hh{i}')
+        close(torch.einsum('bot,oc->bct', dgi_b, g.rnn.weight_ih_l0.detach()), xs[i].grad, atol=3e-4, rtol=1e-3, name=f'dx{i}')
+
+
+# ------------------------------------------------------------------------------------------ losses
+@pytest.mark.parametrize('name', ['ragged_strong', 'full_len', 'no_bwd', 'slat', 'weak_only',
+                                  'half_weight_smooth', 'class_weights'])
+def test_fbcrnn_loss_kernel_vs_reference_golden(golden, name):
+    import ast
+    from pb_sed_amd import ops
+    g = golden('ref_fbcrnn_loss.npz')
+    kw = ast.literal_eval(str(g[f'{name}/kw']))
+    dd = lambda a: torch.as_tensor(a).float().to(DEV).contiguous()
+    yb = dd(g[f'{name}/y_bwd']) if f'{name}/y_bwd' in g else None
+    cw = dd(np.array(kw['class_weights'], dtype=np.float32)) if 'class_weights' in kw else None
+    loss, _, _, d_f, d_b = ops.fbcrnn_loss(
+        dd(g[f'{name}/y_fwd']), yb, dd(g[f'{name}/weak_targets']), dd(g[f'{name}/boundary_targets']),
+        torch.as_tensor(g[f'{name}/seq_len'], dtype=torch.int32).to(DEV), minimum_score=1e-5,
+        strong_weight=kw.get('strong_fwd_bwd_loss_weight', 1.), slat=kw.get('slat', False),
+        label_smoothing=kw.get('label_smoothing', 0.), class_weights=cw, inputs_are_scores=True)
+    assert loss.item() == pytest.approx(float(g[f'{name}/loss']), rel=2e-5)
+    close(d_f, g[f'{name}/grad_y_fwd'], atol=1e-6, rtol=2e-4, name='dL/dy_fwd')
+    if yb is not None:
+        close(d_b, g[f'{name}/grad_y_bwd'], atol=1e-6, rtol=2e-4, name='dL/dy_bwd')
+
+
+@pytest.mark.parametrize('name', ['a', 'b'])
+def test_bicrnn_loss_kernel_vs_reference_golden(golden, name):
+    from pb_sed_amd import ops
+    g = golden('ref_bicrnn_loss.npz')
+    dd = lambda a: torch.as_tensor(a).float().to(DEV).contiguous()
+    loss, _, d = ops.bicrnn_loss(dd(g[f'{name}/y']), dd(g[f'{name}/strong_targets']),
+                                 torch.as_tensor(g[f'{name}/seq_len'], dtype=torch.int32).to(DEV),
+                                 inputs_are_scores=True)
+    assert loss.item() == pytest.approx(float(g[f'{name}/loss']), rel=2e-5)
+    close(d, g[f'{name}/grad_y'], atol=1e-7, rtol=2e-4, name='dL/dy')
+
+
+def test_squash_roundtrip():
+    from pb_sed_amd import ops
+    x = torch.randn(1000, device=DEV) * 4
+    y = ops.squash_fwd(x, 1e-5)
+    close(y, 1e-5 + (1 - 2e-5) * torch.sigmoid(x.cpu()), atol=1e-6)
+    dy = torch.randn(1000, device=DEV)
+    s = torch.sigmoid(x.cpu().double())
+    close(ops.squash_bwd(y, dy, 1e-5), dy.cpu().double() * (1 - 2e-5) * s * (1 - s), atol=1e-5, rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+def test_adam_and_grad_norm_vs_torch():
+    from pb_sed_amd import ops
+    torch.manual_seed(3)
+    n = 100003
+    p0, grads = torch.randn(n), [torch.randn(n) * s for s in (1., .1, 3.)]
+    pr = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([pr], lr=5e-4)
+    p, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    ss, norm = torch.zeros((), dtype=torch.float64, device=DEV), torch.zeros((), device=DEV)
+    for step, g in enumerate(grads, 1):
+        pr.grad = g.clone()
+        ref_norm = torch.nn.utils.clip_grad_norm_([pr], 5.)
+        opt.step()
+        gd = g.to(DEV)
+        ops.grad_sumsq(gd, ss)
+        ops.adam_step(p, gd, m, v, lr=5e-4, step=step, max_norm=5., sumsq=ss, norm_out=norm)
+        assert norm.item() == pytest.approx(ref_norm.item(), rel=1e-5)
+    close(p, pr, atol=1e-6, rtol=1e-5, name='adam params after 3 steps')
