@@ -116,7 +116,7 @@ class LogMelExtractor(torch.nn.Module):
 
     @torch.no_grad()
     def forward(self, x, seq_len=None, targets=None):
-        power = (x.to(torch.float32) ** 2).sum(-1)              # [B,1,T,bins]
+        power = (x.to(self.fbanks.dtype) ** 2).sum(-1)          # [B,1,T,bins] (f32; f64 if .double())
         mel = power @ self.fbanks.T                               # [B,1,T,F]
         logmel = torch.log(mel + self.eps).transpose(-1, -2)     # [B,1,F,T]
         y = (logmel - self.mean[:, None]) * self.inv_std[:, None]

@@ -92,11 +92,21 @@ def int_array(vals):
     return (C.c_int * len(vals))(*[int(v) for v in vals])
 
 
-def call(name, *args):
-    """Invoke a status-returning entry point; raise RuntimeError with the library's message."""
+timing = None   # set to a list to record (name, tag, flops, bytes, start_event, end_event) per call
+
+
+def call(name, *args, tag='', flops=0, nbytes=0):
+    """Invoke a status-returning entry point; raise RuntimeError with the library's message.
+    With ``timing`` enabled the call is bracketed by HIP events on the launch stream."""
+    if timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = getattr(lib(), name)(*args)
     if rc != 0:
         raise RuntimeError(f'{name} failed ({rc}): {lib().pbsed_last_error().decode()}')
+    if timing is not None:
+        e1.record()
+        timing.append((name, tag, flops, nbytes, e0, e1))
 
 
 def require_gpu(t):

@@ -28,11 +28,13 @@ struct ConvFwdCfg {
     static constexpr int NTW = FT * NTT;
     static constexpr int KK = KH * KW;
     static constexpr int ROWS = FT + KH - 1;
-    static constexpr int ROW = TT + KW - 1;
+    static constexpr int HALO = (KW > 1) ? 4 : 0;       // 16-byte aligned halo: row = t in [t0-4, t0+TT+4)
+    static constexpr int ROW = TT + 2 * HALO;
+    static constexpr int QR = ROW / 4;                  // float4 quads per row
     static constexpr int PLANE = pad16mod32(ROWS * ROW);
     static constexpr int COUT_P = pad16mod32(COUT_T);
-    static constexpr int IN_ELEMS = CK * ROWS * ROW;
-    static constexpr int IN_PER_T = (IN_ELEMS + 255) / 256;
+    static constexpr int IN_Q = CK * ROWS * QR;
+    static constexpr int IN_PER_T = (IN_Q + 255) / 256;
     static constexpr int W_VEC = KK * CK * COUT_T / 4;
     static constexpr int W_PER_T = (W_VEC + 255) / 256;
     static constexpr int FO_T = POOL ? FT / 2 : FT;
@@ -70,35 +72,73 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
 #pragma unroll
         for (int n = 0; n < C::NTW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float rin[C::IN_PER_T];
+    // ---- input staging: each thread owns IN_PER_T aligned float4 quads of the halo tile; their
+    // (channel, row, column) decomposition is fixed across channel chunks, so offsets are hoisted.
+    float4 rin[C::IN_PER_T];
     float4 rw[C::W_PER_T];
+    int q_off[C::IN_PER_T], q_lds[C::IN_PER_T], q_t[C::IN_PER_T], q_c[C::IN_PER_T];
+    const bool unpool = DGRAD && a.unpool_idx != nullptr;
+    const int Fsrc = unpool ? a.F / 2 : a.F;
+    const bool vec = (a.T & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < C::IN_PER_T; ++i) {
+        const int q = tid + i * 256;
+        const int c = q / (C::ROWS * C::QR), rem = q - c * (C::ROWS * C::QR);
+        const int r = rem / C::QR, qc = rem - r * C::QR;
+        const int f = f0 - PADH + r, tq = t0 - C::HALO + 4 * qc;
+        const bool ok = q < C::IN_Q && f >= 0 && f < a.F && tq + 3 >= 0 && tq < a.T;
+        q_c[i] = ok ? c : -1;
+        q_t[i] = tq;
+        q_lds[i] = c * C::PLANE + r * C::ROW + 4 * qc;
+        q_off[i] = (c * Fsrc + (unpool ? (f >> 1) : f)) * a.T + tq;
+        if (unpool && (f & 1)) q_t[i] |= (1 << 30);       // row parity for the argmax test
+    }
 
     auto load_chunk = [&](int c0) {
+        const float* xb = a.x + (size_t)(b * a.Cin + c0) * Fsrc * a.T;
+        const uint8_t* ib = unpool ? a.unpool_idx + (size_t)(b * a.Cin + c0) * Fsrc * a.T : nullptr;
+        const int tlim = pro ? sl : a.T;       // Normalization re-masks its output (y*mask)
 #pragma unroll
         for (int i = 0; i < C::IN_PER_T; ++i) {
-            const int idx = tid + i * 256;
-            float v = 0.f;
-            if (idx < C::IN_ELEMS) {
-                const int c = idx / (C::ROWS * C::ROW);
-                const int rem = idx - c * (C::ROWS * C::ROW);
-                const int r = rem / C::ROW, col = rem - r * C::ROW;
-                const int f = f0 - PADH + r, t = t0 - PADW + col, cin = c0 + c;
-                const int tlim = pro ? sl : a.T;   // Normalization re-masks its output (y*mask)
-                if (cin < a.Cin && f >= 0 && f < a.F && t >= 0 && t < tlim) {
-                    if (DGRAD && a.unpool_idx) {
-                        // input is the pooled gradient: route it to the argmax row of the (2,1) window
-                        const size_t o = ((size_t)(b * a.Cin + cin) * (a.F / 2) + (f >> 1)) * a.T + t;
-                        v = (a.unpool_idx[o] == (uint8_t)(f & 1)) ? a.x[o] : 0.f;
-                    } else {
-                        v = a.x[((size_t)(b * a.Cin + cin) * a.F + f) * a.T + t];
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            const int cin = c0 + q_c[i];
+            if (q_c[i] >= 0 && cin < a.Cin) {
+                const int tq = q_t[i] & ~(1 << 30);
+                const int par = (q_t[i] >> 30) & 1;
+                if (vec && tq >= 0 && tq + 4 <= a.T) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xb + q_off[i]);
+                    v[0] = xv.x; v[1] = xv.y; v[2] = xv.z; v[3] = xv.w;
+                    if (unpool) {
+                        const uchar4 iv = *reinterpret_cast<const uchar4*>(ib + q_off[i]);
+                        v[0] = (iv.x == par) ? v[0] : 0.f; v[1] = (iv.y == par) ? v[1] : 0.f;
+                        v[2] = (iv.z == par) ? v[2] : 0.f; v[3] = (iv.w == par) ? v[3] : 0.f;
                     }
-                    if (pro) {
-                        v = fmaf(v, a.scale[cin], a.shift[cin]);
-                        if (a.relu) v = fmaxf(v, 0.f);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int t = tq + e;
+                        if (t >= 0 && t < a.T) {
+                            v[e] = xb[q_off[i] + e];
+                            if (unpool) v[e] = (ib[q_off[i] + e] == par) ? v[e] : 0.f;
+                        }
                     }
                 }
+                if (pro) {
+                    const float sc = a.scale[cin], sh = a.shift[cin];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float u = fmaf(v[e], sc, sh);
+                        if (a.relu) u = fmaxf(u, 0.f);
+                        v[e] = u;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int t = tq + e;
+                    v[e] = (t >= 0 && t < tlim) ? v[e] : 0.f;     // zero padding is post-activation
+                }
             }
-            rin[i] = v;
+            rin[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
 #pragma unroll
         for (int i = 0; i < C::W_PER_T; ++i) {
@@ -116,14 +156,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int i = 0; i < C::IN_PER_T; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < C::IN_ELEMS) {
-                const int c = idx / (C::ROWS * C::ROW);
-                const int rem = idx - c * (C::ROWS * C::ROW);
-                in_s[c * C::PLANE + rem] = rin[i];
-            }
-        }
+        for (int i = 0; i < C::IN_PER_T; ++i)
+            if (tid + i * 256 < C::IN_Q) *reinterpret_cast<float4*>(in_s + q_lds[i]) = rin[i];
 #pragma unroll
         for (int i = 0; i < C::W_PER_T; ++i) {
             const int idx = tid + i * 256;
@@ -158,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
 #pragma unroll
                 for (int n = 0; n < C::NTW; ++n) {
                     const int fl = n / C::NTT, tt = wn * C::NTT + n % C::NTT;
-                    bf[n] = in_s[(cs * 4 + lq) * C::PLANE + (fl + kh) * C::ROW + tt * 16 + lr + kw];
+                    bf[n] = in_s[(cs * 4 + lq) * C::PLANE + (fl + kh) * C::ROW + tt * 16 + lr + kw + (C::HALO - PADW)];
                 }
 #pragma unroll
                 for (int m = 0; m < C::MTW; ++m)

@@ -112,8 +112,9 @@ def stack_forward(layers, x, seq_dev, seq_host, training):
     return x, ctx
 
 
-def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad):
-    """Backward of stack_forward; accumulates parameter grads, returns grad wrt the stack input."""
+def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_done=None):
+    """Backward of stack_forward; accumulates parameter grads, returns grad wrt the stack input.
+    ``on_layer_done(j)`` fires once every gradient owned by layers >= j is final."""
     for j in reversed(range(len(layers))):
         L, (x, st_in, pc, idx) = layers[j], ctx[j]
         c = L.conv
@@ -125,6 +126,8 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad):
                                 shift=None if st_in is None else st_in.shift,
                                 relu=True, seq_len=seq_dev, unpool_idx=idx)
         if j == 0 and not need_input_grad:
+            if on_layer_done is not None:
+                on_layer_done(0)
             return None
         wd = pc.dgrad()
         if st_in is not None:
@@ -136,6 +139,8 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad):
                                 _grad(norm.gamma), _grad(norm.beta), seq_dev)
         else:
             g, _ = ops.conv_bwd_data(g, pc, wd, x.shape, idx, None)
+        if on_layer_done is not None:
+            on_layer_done(j)        # layer j's in_norm belongs to it or to j-1's tail: both done now
     return g
 
 

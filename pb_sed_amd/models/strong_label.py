@@ -29,8 +29,12 @@ class _NetFunction(torch.autograd.Function):
         model, layers, cnn_ctx, rnn_ctx, y, n_h, seq_host, seq_dev = ctx.state
         ctx.state = None
         engine.flatten_parameters(model)
+        hook = getattr(model, '_grad_hook', None) or (lambda name: None)
         dh = engine.rnn_backward([model.rnn], rnn_ctx, [ops.squash_bwd(y, dy, 0.)], seq_dev, seq_host)
-        engine.stack_backward(layers, cnn_ctx, dh[:, :n_h].contiguous(), seq_dev, seq_host, need_input_grad=False)
+        hook('rnn')
+        n2d = len(model.cnn.cnn_2d.convs)
+        engine.stack_backward(layers, cnn_ctx, dh[:, :n_h].contiguous(), seq_dev, seq_host, need_input_grad=False,
+                              on_layer_done=lambda j: hook('cnn_1d') if j == n2d else (hook('cnn_2d') if j == 0 else None))
         return (None,) * (6 + len(model._net_params))
 
 

@@ -34,8 +34,12 @@ class _NetFunction(torch.autograd.Function):
         ctx.state = None
         engine.flatten_parameters(model)
         dlogits = [ops.squash_bwd(y, dy, model.minimum_score) for y, dy in zip(ys, dys)]
+        hook = getattr(model, '_grad_hook', None) or (lambda name: None)
         dh = engine.rnn_backward(wrappers, rnn_ctx, dlogits, seq_dev, seq_host)
-        engine.stack_backward(layers, cnn_ctx, dh, seq_dev, seq_host, need_input_grad=False)
+        hook('rnn')
+        n2d = len(model.cnn.cnn_2d.convs)
+        engine.stack_backward(layers, cnn_ctx, dh, seq_dev, seq_host, need_input_grad=False,
+                              on_layer_done=lambda j: hook('cnn_1d') if j == n2d else (hook('cnn_2d') if j == 0 else None))
         return (None,) * (5 + len(model._net_params))
 
 

@@ -20,6 +20,14 @@ def _dims4(x):
     return tuple(x.shape)
 
 
+def _conv_tag(b, cin, pc, f, t):
+    return f'{cin}->{pc.cout} k{pc.kh}x{pc.kw} B{b} F{f} T{t}'
+
+
+def _conv_flops(b, cin, pc, f, t):
+    return 2 * b * pc.cout * cin * pc.kh * pc.kw * f * t
+
+
 class PackedConv:
     """Weights of one conv layer packed for the forward and data-gradient kernels."""
 
@@ -66,7 +74,7 @@ def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=No
                             dtype=torch.float64)
     call('pbsed_conv_fwd', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
          ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, pc.kh, pc.kw,
-         int(pool), stream())
+         int(pool), stream(), tag=_conv_tag(b, cin, pc, f, t), flops=_conv_flops(b, cin, pc, f, t))
     return y, idx, stats
 
 
@@ -82,7 +90,7 @@ def conv_bwd_data(g, pc, wd, x_shape, unpool_idx=None, seq_len=None, bn=None, re
         stats = torch.zeros((cin, 2), device=g.device, dtype=torch.float64)
     call('pbsed_conv_bwd_data', ptr(g), ptr(wd), ptr(unpool_idx), ptr(seq_len), ptr(dz), ptr(bx),
          ptr(bmean), ptr(binv), ptr(bsc), ptr(bsh), int(relu), ptr(stats), b, cin, pc.cout, f, t,
-         pc.kh, pc.kw, stream())
+         pc.kh, pc.kw, stream(), tag=_conv_tag(b, cin, pc, f, t), flops=_conv_flops(b, cin, pc, f, t))
     return dz, stats
 
 
@@ -91,7 +99,8 @@ def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, se
     """dw (+=), db (+=): gradients of the conv parameters (buffers must be pre-zeroed/accumulating)."""
     b, cin, f, t = _dims4(x)
     call('pbsed_conv_bwd_weight', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(g),
-         ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream())
+         ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream(),
+         tag=_conv_tag(b, cin, pc, f, t), flops=_conv_flops(b, cin, pc, f, t))
 
 
 class BNState:

@@ -1,0 +1,66 @@
+"""Data-parallel plumbing on CPU (gloo, world_size 2): bucketed overlapped gradient all-reduce and
+batch sharding used by pb_sed_amd.trainer (the RCCL path on the GPUs uses the same code with backend
+'nccl').  No HIP kernels are involved here."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pb_sed_amd.trainer import GradSync, shard_batch
+    n = 1000
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    buckets = [(600, 1000), (250, 600), (0, 250)]
+    sync = GradSync(g, buckets)
+    assert sync.world == world
+    sync.bucket_ready(0)                 # announced in backward-completion order, third left to finish()
+    sync.bucket_ready(1)
+    sync.bucket_ready(1)                 # idempotent
+    scale = sync.finish()
+    expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    ok = torch.equal(g, expect) and scale == 1.0 / world
+    # second step re-arms
+    g.copy_(torch.ones(n) * (rank + 1))
+    sync.finish()
+    ok = ok and torch.equal(g, torch.full((n,), float(sum(r + 1 for r in range(world)))))
+    batch = {'audio_data': torch.arange(8 * 3).reshape(8, 3), 'seq_len': list(range(8)),
+             'weak_targets': np.arange(8 * 2).reshape(8, 2), 'meta': 'x'}
+    sh = shard_batch(batch, rank, world)
+    ok = ok and sh['seq_len'] == list(range(rank * 4, rank * 4 + 4)) and sh['meta'] == 'x'
+    ok = ok and torch.equal(sh['audio_data'], batch['audio_data'][rank * 4:rank * 4 + 4])
+    ok = ok and (sh['weak_targets'] == batch['weak_targets'][rank * 4:rank * 4 + 4]).all()
+    with open(os.path.join(out_dir, f'ok{rank}'), 'w') as f:
+        f.write(str(bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_gradsync_and_sharding_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f'ok{r}').read() == 'True'
+
+
+def test_gradsync_single_process_is_noop():
+    from pb_sed_amd.trainer import GradSync
+    g = torch.ones(10)
+    s = GradSync(g, [(0, 10)])
+    s.bucket_ready(0)
+    assert s.finish() == 1.0 and torch.equal(g, torch.ones(10))
