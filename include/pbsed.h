@@ -22,6 +22,9 @@ extern "C" {
 #define PBSED_E_ARG (-1)
 #define PBSED_E_HIP (-2)
 #define PBSED_E_UNSUPPORTED (-3)
+/* statistics accumulators (`stats`, `sums`) are [PBSED_STAT_SLOTS][C][2] doubles, zeroed by the caller;
+ * kernels spread their atomics over the slots, the *_finalize entry points sum them. */
+#define PBSED_STAT_SLOTS 32
 
 const char* pbsed_last_error(void);
 int pbsed_version(void);
@@ -79,6 +82,16 @@ int pbsed_gru_scan_bwd(int nchains, const float* const* w_hh_t, const float* con
                        const float* const* save, const float* const* dy, float* const* dgi, float* const* dgh,
                        float* const* dhz, const int* reverse /*host*/, const int* seq_len, int B, int H, int T,
                        void* stream);
+/* Multi-layer UNIDIRECTIONAL stacks (FBCRNN: forward + time-reversed 2-layer GRUs) as a layer wavefront:
+ * T + nlayers - 1 launches.  Pointer tables are host arrays indexed [chain*nlayers + layer]. */
+int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
+                        const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
+                        float* const* hs, float* const* save, const int* reverse /*host*/, const int* seq_len,
+                        int B, int H, int T, void* stream);
+int pbsed_gru_stack_bwd(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
+                        const float* const* hs, const float* const* save, const float* const* dy_top,
+                        float* const* dgi, float* const* dgh, float* const* dhz, const int* reverse /*host*/,
+                        const int* seq_len, int B, int H, int T, void* stream);
 int pbsed_bct_to_tbc(const float* src, float* dst, int B, int C, int T, void* stream);
 int pbsed_tbc_to_bct(const float* src, float* dst, int B, int C, int T, int shift, void* stream);
 int pbsed_transpose2d(const float* src, float* dst, int R, int C, void* stream);

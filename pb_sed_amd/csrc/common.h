@@ -9,6 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PBSED_E_ARG (-1)
 #define PBSED_E_HIP (-2)
 #define PBSED_E_UNSUPPORTED (-3)
+#define PBSED_STAT_SLOTS 32   // statistics accumulators are [PBSED_STAT_SLOTS][C][2] doubles
 
 namespace pbsed {
 

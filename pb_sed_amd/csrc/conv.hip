@@ -267,7 +267,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
             const int cout = cout0 + cl, fo = (POOL ? f0 / 2 : f0) + fo_l;
             if (cout < a.Cout && fo < Fo) {
                 const int sidx = a.stats_cf ? cout * Fo + fo : cout;
-                atomicAdd(&a.stats[sidx * 2 + which], (double)st_s[i]);
+                const int nstat = a.stats_cf ? a.Cout * Fo : a.Cout;
+                // PBSED_STAT_SLOTS copies of the accumulators spread same-address atomic contention
+                const int slot = blockIdx.x & (PBSED_STAT_SLOTS - 1);
+                atomicAdd(&a.stats[((size_t)slot * nstat + sidx) * 2 + which], (double)st_s[i]);
             }
         }
     }

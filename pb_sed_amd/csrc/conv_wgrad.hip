@@ -4,139 +4,252 @@
 // forward's pool argmax).  This is the backward twin of the op sites listed in conv.hip
 // (torch autograd of Conv2d/Conv1d in the reference: pb_sed/models/weak_label/crnn.py:93).
 //
-// GEMM view: M = Cout (A = dY), N = (cin,kh,kw) (B = shifted a), K = spatial (b,f,t), split over
-// blocks; partial results are reduced with float atomics into the [Cout,Cin,KH,KW] gradient.
+// GEMM view: M = Cout (A = dY), N = (cin, tap) (B = shifted a), K = spatial (b,f,t) split over
+// blocks.  Both operands are K-major in HBM (t contiguous), so tiles are staged with aligned 16-byte
+// loads into LDS planes padded to == 2 (mod 32) dwords, which makes the transposed ds_read_b32
+// operand fetches conflict-free.  The next spatial chunk is prefetched into registers during the
+// MFMAs.  Per-block partial sums are transposed through LDS and reduced with row-contiguous fp32
+// atomics into the [Cout,Cin,KH,KW] gradient (the bias gradient is one extra MFMA against ones).
 #include "common.h"
 #include "pbsed_internal.h"
 
 namespace pbsed {
 
 constexpr int pad2mod32(int n) { return ((n + 29) / 32) * 32 + 2; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int KH, int KW, int WAVES, int NCG, bool TAPN>
+template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN>
+struct WgradCfg {
+    static constexpr int FT = (KH == 3) ? 2 : 1, TT = 64;
+    static constexpr int KK = KH * KW, NT = WAVES * 64;
+    static constexpr int COUT_T = WAVES * MT * 16, CIN_T = TAPN ? 1 : NCG * 16;   // TAPN: Cin == 1, taps on N
+    static constexpr int HALO = (KW > 1) ? 4 : 0;
+    static constexpr int ROWS = FT + KH - 1, ROW = TT + 2 * HALO, QR = ROW / 4;
+    static constexpr int PLANE_Y = pad2mod32(FT * TT), PLANE_A = pad2mod32(ROWS * ROW);
+    static constexpr int YQ = COUT_T * FT * (TT / 4), AQ = CIN_T * ROWS * QR;
+    static constexpr int Y_PER_T = (YQ + NT - 1) / NT, A_PER_T = (AQ + NT - 1) / NT;
+    static constexpr int OUT_ROW = CIN_T * KK;
+    static constexpr int NACC = TAPN ? 1 : NCG * KK;
+    static constexpr int LDS_FLOATS = cmax(COUT_T * PLANE_Y + CIN_T * PLANE_A, COUT_T * OUT_ROW);
+};
+
+template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN>
 __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_kernel(ConvWgradArgs a) {
-    constexpr int FT = (KH == 3) ? 2 : 1, TT = 64;
-    constexpr int KK = KH * KW, NT = WAVES * 64, COUT_T = WAVES * 16;
-    constexpr int ROWS = FT + KH - 1, ROW = TT + KW - 1;
-    constexpr int PLANE_Y = pad2mod32(FT * TT), PLANE_A = pad2mod32(ROWS * ROW);
+    using C = WgradCfg<KH, KW, WAVES, MT, NCG, TAPN>;
+    constexpr int FT = C::FT, TT = C::TT, KK = C::KK, NT = C::NT;
     constexpr int PADH = (KH - 1) / 2, PADW = (KW - 1) / 2;
-    constexpr int NACC = TAPN ? 1 : NCG * KK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* dy_s = smem;                          // [COUT_T][PLANE_Y]
-    float* a_s = smem + COUT_T * PLANE_Y;        // [NCG*16][PLANE_A]
+    float* dy_s = smem;                              // [COUT_T][PLANE_Y]
+    float* a_s = smem + C::COUT_T * C::PLANE_Y;      // [CIN_T][PLANE_A]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
-    const int cin0 = blockIdx.y * NCG * 16, cout0 = blockIdx.z * COUT_T;
+    const int cin0 = blockIdx.y * C::CIN_T, cout0 = blockIdx.z * C::COUT_T;
     const int nTt = (a.T + TT - 1) / TT, nFt = (a.F + FT - 1) / FT;
     const int nChunks = a.B * nFt * nTt;
     const bool pro = a.scale != nullptr;
     const bool do_bias = (a.db != nullptr) && (blockIdx.y == 0);
-    const int Fg = a.unpool_idx ? a.F / 2 : a.F;
+    const bool unpool = a.unpool_idx != nullptr;
+    const int Fg = unpool ? a.F / 2 : a.F;
+    const bool vec = (a.T & 3) == 0;
 
-    f32x4 acc[NACC];
+    f32x4 acc[MT][C::NACC];
+    f32x4 accb[MT];
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m) {
+        accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < C::NACC; ++i) acc[m][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
-    for (int chunk = blockIdx.x; chunk < nChunks; chunk += gridDim.x) {
+    float4 ry[C::Y_PER_T], ra[C::A_PER_T];
+
+    auto load_chunk = [&](int chunk) {
         int c = chunk;
         const int t0 = (c % nTt) * TT; c /= nTt;
         const int f0 = (c % nFt) * FT;
         const int b = c / nFt;
         const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
-        __syncthreads();
-        for (int idx = tid; idx < COUT_T * FT * TT; idx += NT) {
-            const int cl = idx / (FT * TT), rem = idx % (FT * TT);
-            const int fl = rem / TT, tc = rem % TT;
-            const int cout = cout0 + cl, f = f0 + fl, t = t0 + tc;
-            float v = 0.f;
-            if (cout < a.Cout && f < a.F && t < a.T) {
-                if (a.unpool_idx) {
-                    const size_t o = ((size_t)(b * a.Cout + cout) * Fg + (f >> 1)) * a.T + t;
-                    v = (a.unpool_idx[o] == (uint8_t)(f & 1)) ? a.g[o] : 0.f;
+        // ---- dY tile (un-pooled through the argmax byte)
+#pragma unroll
+        for (int i = 0; i < C::Y_PER_T; ++i) {
+            const int q = tid + i * NT;
+            const int cl = q / (FT * (TT / 4)), rem = q % (FT * (TT / 4));
+            const int fl = rem / (TT / 4), qc = rem % (TT / 4);
+            const int cout = cout0 + cl, f = f0 + fl, tq = t0 + 4 * qc;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (q < C::YQ && cout < a.Cout && f < a.F && tq < a.T) {
+                const size_t o = ((size_t)(b * a.Cout + cout) * Fg + (unpool ? (f >> 1) : f)) * a.T + tq;
+                if (vec) {
+                    const float4 gv = *reinterpret_cast<const float4*>(a.g + o);
+                    v[0] = gv.x; v[1] = gv.y; v[2] = gv.z; v[3] = gv.w;
+                    if (unpool) {
+                        const uchar4 iv = *reinterpret_cast<const uchar4*>(a.unpool_idx + o);
+                        const int par = f & 1;
+                        v[0] = (iv.x == par) ? v[0] : 0.f; v[1] = (iv.y == par) ? v[1] : 0.f;
+                        v[2] = (iv.z == par) ? v[2] : 0.f; v[3] = (iv.w == par) ? v[3] : 0.f;
+                    }
                 } else {
-                    v = a.g[((size_t)(b * a.Cout + cout) * a.F + f) * a.T + t];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (tq + e < a.T) {
+                            v[e] = a.g[o + e];
+                            if (unpool) v[e] = (a.unpool_idx[o + e] == (uint8_t)(f & 1)) ? v[e] : 0.f;
+                        }
                 }
             }
-            dy_s[cl * PLANE_Y + rem] = v;
+            ry[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
-        for (int idx = tid; idx < NCG * 16 * ROWS * ROW; idx += NT) {
-            const int cl = idx / (ROWS * ROW), rem = idx % (ROWS * ROW);
-            const int r = rem / ROW, col = rem % ROW;
-            const int cin = cin0 + cl, f = f0 - PADH + r, t = t0 - PADW + col;
-            const int tlim = pro ? sl : a.T;
-            float v = 0.f;
-            if (cin < a.Cin && f >= 0 && f < a.F && t >= 0 && t < tlim) {
-                v = a.x[((size_t)(b * a.Cin + cin) * a.F + f) * a.T + t];
+        // ---- a tile = prologue(x) with halo, zero padding post-activation
+        const int tlim = pro ? sl : a.T;
+#pragma unroll
+        for (int i = 0; i < C::A_PER_T; ++i) {
+            const int q = tid + i * NT;
+            const int cl = q / (C::ROWS * C::QR), rem = q % (C::ROWS * C::QR);
+            const int r = rem / C::QR, qc = rem % C::QR;
+            const int cin = cin0 + cl, f = f0 - PADH + r, tq = t0 - C::HALO + 4 * qc;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (q < C::AQ && cin < a.Cin && f >= 0 && f < a.F && tq + 3 >= 0 && tq < a.T) {
+                const float* xp = a.x + ((size_t)(b * a.Cin + cin) * a.F + f) * a.T;
+                if (vec && tq >= 0) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xp + tq);
+                    v[0] = xv.x; v[1] = xv.y; v[2] = xv.z; v[3] = xv.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (tq + e >= 0 && tq + e < a.T) v[e] = xp[tq + e];
+                }
                 if (pro) {
-                    v = fmaf(v, a.scale[cin], a.shift[cin]);
-                    if (a.relu) v = fmaxf(v, 0.f);
+                    const float sc = a.scale[cin], sh = a.shift[cin];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float u = fmaf(v[e], sc, sh);
+                        if (a.relu) u = fmaxf(u, 0.f);
+                        v[e] = u;
+                    }
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (tq + e >= 0 && tq + e < tlim) ? v[e] : 0.f;
             }
-            a_s[cl * PLANE_A + rem] = v;
+            ra[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < C::Y_PER_T; ++i) {
+            const int q = tid + i * NT;
+            if (q < C::YQ) {
+                const int cl = q / (FT * (TT / 4)), rem = q % (FT * (TT / 4));
+                float* d = dy_s + cl * C::PLANE_Y + rem * 4;
+                d[0] = ry[i].x; d[1] = ry[i].y; d[2] = ry[i].z; d[3] = ry[i].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::A_PER_T; ++i) {
+            const int q = tid + i * NT;
+            if (q < C::AQ) {
+                const int cl = q / (C::ROWS * C::QR), rem = q % (C::ROWS * C::QR);
+                float* d = a_s + cl * C::PLANE_A + rem * 4;
+                d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+            }
+        }
+    };
+
+    int chunk = blockIdx.x;
+    if (chunk < nChunks) load_chunk(chunk);
+    for (; chunk < nChunks; chunk += gridDim.x) {
         __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (chunk + (int)gridDim.x < nChunks) load_chunk(chunk + gridDim.x);
 #pragma unroll
         for (int fl = 0; fl < FT; ++fl) {
-#pragma unroll 4
+#pragma unroll 2
             for (int tq = 0; tq < TT / 4; ++tq) {
-                const float af = dy_s[(wave * 16 + lr) * PLANE_Y + fl * TT + tq * 4 + lq];
+                float af[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    af[m] = dy_s[((wave * MT + m) * 16 + lr) * C::PLANE_Y + fl * TT + tq * 4 + lq];
                 if (TAPN) {
-                    const int kh = lr / KW, kw = lr % KW;
-                    const float bf = (lr < KK) ? a_s[(fl + kh) * ROW + tq * 4 + lq + kw] : 0.f;
-                    acc[0] = mfma16(af, bf, acc[0]);
+                    const int kh = lr / KW, kw = lr % KW;     // N index = tap
+                    const float bf = (lr < KK) ? a_s[(fl + kh) * C::ROW + tq * 4 + lq + kw + (C::HALO - PADW)] : 0.f;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m][0] = mfma16(af[m], bf, acc[m][0]);
                 } else {
 #pragma unroll
                     for (int g = 0; g < NCG; ++g)
 #pragma unroll
                         for (int kk = 0; kk < KK; ++kk) {
                             const int kh = kk / KW, kw = kk % KW;
-                            const float bf =
-                                a_s[(g * 16 + lr) * PLANE_A + (fl + kh) * ROW + tq * 4 + lq + kw];
-                            acc[g * KK + kk] = mfma16(af, bf, acc[g * KK + kk]);
+                            const float bf = a_s[(g * 16 + lr) * C::PLANE_A + (fl + kh) * C::ROW + tq * 4 + lq +
+                                                 kw + (C::HALO - PADW)];
+#pragma unroll
+                            for (int m = 0; m < MT; ++m)
+                                acc[m][g * KK + kk] = mfma16(af[m], bf, acc[m][g * KK + kk]);
                         }
                 }
-                if (do_bias) accb = mfma16(af, 1.0f, accb);
+                if (do_bias) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) accb[m] = mfma16(af[m], 1.0f, accb[m]);
+                }
             }
         }
     }
 
+    // ---- reduce: transpose the block's partial dW through LDS, then row-contiguous atomics
+    __syncthreads();
+    float* out_s = smem;                             // [COUT_T][OUT_ROW]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int cout = cout0 + wave * 16 + lq * 4 + r;
-        if (cout >= a.Cout) continue;
+    for (int m = 0; m < MT; ++m) {
         if (TAPN) {
-            if (lr < KK) atomicAdd(&a.dw[(size_t)cout * a.Cin * KK + lr], acc[0][r]);
+            if (lr < KK)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out_s[((wave * MT + m) * 16 + lq * 4 + r) * C::OUT_ROW + lr] = acc[m][0][r];
         } else {
 #pragma unroll
-            for (int g = 0; g < NCG; ++g) {
-                const int cin = cin0 + g * 16 + lr;
-                if (cin < a.Cin) {
+            for (int g = 0; g < NCG; ++g)
 #pragma unroll
-                    for (int kk = 0; kk < KK; ++kk)
-                        atomicAdd(&a.dw[((size_t)cout * a.Cin + cin) * KK + kk], acc[g * KK + kk][r]);
-                }
-            }
+                for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        out_s[((wave * MT + m) * 16 + lq * 4 + r) * C::OUT_ROW + (g * 16 + lr) * KK + kk] =
+                            acc[m][g * KK + kk][r];
         }
-        if (do_bias && lr == 0) atomicAdd(&a.db[cout], accb[r]);
+    }
+    __syncthreads();
+    const int ncol = min(C::CIN_T, a.Cin - cin0) * KK;      // valid, contiguous part of each row
+    for (int row = wave; row < C::COUT_T; row += WAVES) {
+        const int cout = cout0 + row;
+        if (cout >= a.Cout) break;
+        float* dst = a.dw + ((size_t)cout * a.Cin + cin0) * KK;
+        for (int col = lane; col < ncol; col += 64) atomicAdd(dst + col, out_s[row * C::OUT_ROW + col]);
+    }
+    if (do_bias && lr == 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cout = cout0 + (wave * MT + m) * 16 + lq * 4 + r;
+                if (cout < a.Cout) atomicAdd(&a.db[cout], accb[m][r]);
+            }
     }
 }
 
-template <int KH, int KW, int WAVES, int NCG, bool TAPN>
+template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN = false>
 static int launch_wgrad(const ConvWgradArgs& a, hipStream_t s) {
-    constexpr int FT = (KH == 3) ? 2 : 1, TT = 64;
-    const int nTt = (a.T + TT - 1) / TT, nFt = (a.F + FT - 1) / FT;
+    using C = WgradCfg<KH, KW, WAVES, MT, NCG, TAPN>;
+    const int nTt = (a.T + C::TT - 1) / C::TT, nFt = (a.F + C::FT - 1) / C::FT;
     const int nChunks = a.B * nFt * nTt;
-    const int gy = TAPN ? 1 : (a.Cin + NCG * 16 - 1) / (NCG * 16);
-    const int gz = (a.Cout + WAVES * 16 - 1) / (WAVES * 16);
+    const int gy = (a.Cin + C::CIN_T - 1) / C::CIN_T;
+    const int gz = (a.Cout + C::COUT_T - 1) / C::COUT_T;
     int split = 1024 / (gy * gz);
+    if (split >= 8) split &= ~7;       // multiple of 8: blocks sharing a spatial chunk share an XCD's L2
     if (split < 1) split = 1;
     if (split > nChunks) split = nChunks;
     dim3 grid(split, gy, gz);
-    constexpr int ROWS = FT + KH - 1, ROW = TT + KW - 1;
-    const size_t lds = (WAVES * 16 * pad2mod32(FT * TT) + NCG * 16 * pad2mod32(ROWS * ROW)) * sizeof(float);
-    auto kern = conv_wgrad_kernel<KH, KW, WAVES, NCG, TAPN>;
+    const size_t lds = C::LDS_FLOATS * sizeof(float);
+    auto kern = conv_wgrad_kernel<KH, KW, WAVES, MT, NCG, TAPN>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -149,19 +262,18 @@ static int launch_wgrad(const ConvWgradArgs& a, hipStream_t s) {
 
 int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     if (a.unpool_idx && (a.F % 2)) { set_error("conv_wgrad: unpool needs even F"); return PBSED_E_ARG; }
-    const bool big = a.Cout >= 64;
-    const bool wide = a.Cin >= 32;
+    const bool wide = a.Cin > 16;
     if (KH == 3 && KW == 3) {
-        if (a.Cin == 1) return big ? launch_wgrad<3, 3, 4, 1, true>(a, s) : launch_wgrad<3, 3, 1, 1, true>(a, s);
-        if (big) return wide ? launch_wgrad<3, 3, 4, 2, false>(a, s) : launch_wgrad<3, 3, 4, 1, false>(a, s);
-        if (a.Cout >= 32) return wide ? launch_wgrad<3, 3, 2, 2, false>(a, s) : launch_wgrad<3, 3, 2, 1, false>(a, s);
-        return launch_wgrad<3, 3, 1, 1, false>(a, s);
+        if (a.Cin == 1) return a.Cout >= 64 ? launch_wgrad<3, 3, 4, 1, 1, true>(a, s) : launch_wgrad<3, 3, 1, 1, 1, true>(a, s);
+        if (a.Cout >= 64) return wide ? launch_wgrad<3, 3, 4, 1, 2>(a, s) : launch_wgrad<3, 3, 4, 1, 1>(a, s);
+        if (a.Cout >= 32) return wide ? launch_wgrad<3, 3, 2, 1, 2>(a, s) : launch_wgrad<3, 3, 2, 1, 1>(a, s);
+        return launch_wgrad<3, 3, 1, 1, 1>(a, s);
     }
     if (KH == 1 && KW == 3) {
-        return big ? launch_wgrad<1, 3, 4, 2, false>(a, s) : launch_wgrad<1, 3, 1, 2, false>(a, s);
+        return a.Cout >= 128 ? launch_wgrad<1, 3, 4, 2, 2>(a, s) : launch_wgrad<1, 3, 1, 1, 2>(a, s);
     }
     if (KH == 1 && KW == 1) {
-        return big ? launch_wgrad<1, 1, 4, 2, false>(a, s) : launch_wgrad<1, 1, 1, 2, false>(a, s);
+        return a.Cout >= 128 ? launch_wgrad<1, 1, 4, 2, 4>(a, s) : launch_wgrad<1, 1, 1, 1, 4>(a, s);
     }
     set_error("conv_wgrad: unsupported kernel %dx%d", KH, KW);
     return PBSED_E_UNSUPPORTED;

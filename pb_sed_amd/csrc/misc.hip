@@ -34,8 +34,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
                                    float* shift, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double m = sums[2 * c] / count;
-    double var = sums[2 * c + 1] / count - m * m;
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < PBSED_STAT_SLOTS; ++k) { s1 += sums[((size_t)k * C + c) * 2]; s2 += sums[((size_t)k * C + c) * 2 + 1]; }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
     if (var < 0) var = 0;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     mean[c] = (float)m;
@@ -67,7 +69,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double c
                                        float* dbeta, float* m1, float* m2, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double s1 = sums[2 * c], s2 = sums[2 * c + 1];
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < PBSED_STAT_SLOTS; ++k) { s1 += sums[((size_t)k * C + c) * 2]; s2 += sums[((size_t)k * C + c) * 2 + 1]; }
     if (dbeta) dbeta[c] += (float)s1;
     if (dgamma) dgamma[c] += (float)s2;
     m1[c] = (float)(s1 / count);

@@ -13,6 +13,9 @@ from . import _lib
 from ._lib import call, ptr, stream
 
 
+STAT_SLOTS = 32     # PBSED_STAT_SLOTS in csrc/common.h / include/pbsed.h
+
+
 def _dims4(x):
     if x.dim() == 3:
         b, c, t = x.shape
@@ -70,7 +73,7 @@ def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=No
     idx = torch.empty(shape, device=x.device, dtype=torch.uint8) if pool else None
     stats = None
     if want_stats:
-        stats = torch.zeros((pc.cout * fo if stats_per_cf else pc.cout, 2), device=x.device,
+        stats = torch.zeros((STAT_SLOTS, pc.cout * fo if stats_per_cf else pc.cout, 2), device=x.device,
                             dtype=torch.float64)
     call('pbsed_conv_fwd', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
          ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, pc.kh, pc.kw,
@@ -87,7 +90,7 @@ def conv_bwd_data(g, pc, wd, x_shape, unpool_idx=None, seq_len=None, bn=None, re
     bx = bmean = binv = bsc = bsh = None
     if bn is not None:
         bx, bmean, binv, bsc, bsh = bn
-        stats = torch.zeros((cin, 2), device=g.device, dtype=torch.float64)
+        stats = torch.zeros((STAT_SLOTS, cin, 2), device=g.device, dtype=torch.float64)
     call('pbsed_conv_bwd_data', ptr(g), ptr(wd), ptr(unpool_idx), ptr(seq_len), ptr(dz), ptr(bx),
          ptr(bmean), ptr(binv), ptr(bsc), ptr(bsh), int(relu), ptr(stats), b, cin, pc.cout, f, t,
          pc.kh, pc.kw, stream(), tag=_conv_tag(b, cin, pc, f, t), flops=_conv_flops(b, cin, pc, f, t))
@@ -113,7 +116,7 @@ class BNState:
 
 
 def bn_finalize(stats, count, norm, training_update=True):
-    st = BNState(stats.shape[0], stats.device)
+    st = BNState(stats.shape[1], stats.device)
     call('pbsed_bn_finalize', ptr(stats), float(count), ptr(norm.gamma.detach()), ptr(norm.beta.detach()),
          float(norm.eps), float(norm.momentum), ptr(norm.running_mean if training_update else None),
          ptr(norm.running_power if training_update else None), ptr(st.mean), ptr(st.invstd),
@@ -183,6 +186,36 @@ def gru_scan_bwd(w_hh_t, hs, save, dy, reverse, seq_len):
     dhz = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
     call('pbsed_gru_scan_bwd', n, _lib.ptr_array(w_hh_t), _lib.ptr_array(hs), _lib.ptr_array(save),
          _lib.ptr_array(dy), _lib.ptr_array(dgi), _lib.ptr_array(dgh), _lib.ptr_array(dhz),
+         _lib.int_array(reverse), ptr(seq_len), b, h, t, stream())
+    return dgi, dgh
+
+
+def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=True):
+    """Layer-wavefront scan of unidirectional stacks.  gi0: per chain [T,B,3H]; weight lists are indexed
+    [chain*nlayers + layer] (w_ih/b_ih entries of layer 0 may be None).  Returns (hs, save) lists."""
+    nch = len(gi0)
+    t, b, g = gi0[0].shape
+    h = g // 3
+    dev = gi0[0].device
+    n = nch * nlayers
+    hs = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
+    sv = [torch.empty((t, b, 4, h), device=dev, dtype=torch.float32) for _ in range(n)] if save else None
+    call('pbsed_gru_stack_fwd', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih), _lib.ptr_array(b_ih),
+         _lib.ptr_array(w_hh), _lib.ptr_array(b_hh), _lib.ptr_array(hs), _lib.ptr_array(sv) if save else None,
+         _lib.int_array(reverse), ptr(seq_len), b, h, t, stream())
+    return hs, sv
+
+
+def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers):
+    nch = len(dy_top)
+    t, b, h = hs[0].shape
+    dev = hs[0].device
+    n = nch * nlayers
+    dgi = [torch.empty((t, b, 3 * h), device=dev, dtype=torch.float32) for _ in range(n)]
+    dgh = [torch.empty((t, b, 3 * h), device=dev, dtype=torch.float32) for _ in range(n)]
+    dhz = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
+    call('pbsed_gru_stack_bwd', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t), _lib.ptr_array(hs),
+         _lib.ptr_array(save), _lib.ptr_array(dy_top), _lib.ptr_array(dgi), _lib.ptr_array(dgh), _lib.ptr_array(dhz),
          _lib.int_array(reverse), ptr(seq_len), b, h, t, stream())
     return dgi, dgh
 
