@@ -167,11 +167,73 @@ def _chains(wrappers):
     return chains
 
 
+def _heads_forward(wrappers, x_w, seq_dev, seq_host, training):
+    logits, head_ctx = [], []
+    for wi, w in enumerate(wrappers):
+        layers = describe_stack([w.output_net])
+        y, c = stack_forward(layers, x_w[wi], seq_dev, seq_host, training)
+        logits.append(y)
+        head_ctx.append((layers, c))
+    return logits, head_ctx
+
+
+def _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training):
+    """Unidirectional multi-layer stacks (FBCRNN): layer-wavefront scan, T + L - 1 launches."""
+    nl = wrappers[0].num_layers
+    gi0, pcs0 = [], []
+    for ch in chains:
+        pc = PackedConv(ch.p('weight_ih', 0).unsqueeze(-1))
+        y, _, _ = ops.conv_fwd(h, pc, pc.fwd(), bias=ch.p('bias_ih', 0).detach(), seq_len=None)
+        gi0.append(ops.bct_to_tbc(y))
+        pcs0.append(pc)
+    idx = [(ch, l) for ch in chains for l in range(nl)]
+    hs, save = ops.gru_stack_fwd(
+        gi0, [ch.p('weight_ih', l).detach() if l else None for ch, l in idx],
+        [ch.p('bias_ih', l).detach() if l else None for ch, l in idx],
+        [ch.p('weight_hh', l).detach() for ch, l in idx], [ch.p('bias_hh', l).detach() for ch, l in idx],
+        [ch.reverse for ch in chains], seq_dev, nl, save=training)
+    x_w = [ops.tbc_to_bct(hs[ci * nl + nl - 1]) for ci in range(len(chains))]     # one chain per wrapper
+    logits, head_ctx = _heads_forward(wrappers, x_w, seq_dev, seq_host, training)
+    return logits, ('stack', chains, (h, pcs0, hs, save), head_ctx)
+
+
+def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
+    _, chains, (h, pcs0, hs, save), head_ctx = ctx
+    nl = wrappers[0].num_layers
+    dy_top = []
+    for wi, w in enumerate(wrappers):
+        layers, c = head_ctx[wi]
+        dy_top.append(ops.bct_to_tbc(stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True)))
+    idx = [(ch, l) for ch in chains for l in range(nl)]
+    w_hh_t = [ops.transpose2d(ch.p('weight_hh', l).detach()) for ch, l in idx]
+    w_ih_up_t = [ops.transpose2d(ch.p('weight_ih', l + 1).detach()) if l + 1 < nl else None for ch, l in idx]
+    dgi, dgh = ops.gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, [ch.reverse for ch in chains], seq_dev, nl)
+    dh = None
+    for ci, ch in enumerate(chains):
+        for l in range(nl):
+            i = ci * nl + l
+            dgi_b, dgh_b = ops.tbc_to_bct(dgi[i]), ops.tbc_to_bct(dgh[i])
+            hprev = ops.tbc_to_bct(hs[i], shift=1 if ch.reverse else -1)
+            x_in = h if l == 0 else ops.tbc_to_bct(hs[i - 1])
+            w_hh, w_ih = ch.p('weight_hh', l), ch.p('weight_ih', l)
+            if w_hh.requires_grad:
+                ops.conv_bwd_weight(hprev, dgh_b, PackedConv(w_hh.unsqueeze(-1)), _grad(w_hh), _grad(ch.p('bias_hh', l)))
+            if w_ih.requires_grad:
+                ops.conv_bwd_weight(x_in, dgi_b, PackedConv(w_ih.unsqueeze(-1)), _grad(w_ih), _grad(ch.p('bias_ih', l)))
+            if l == 0:
+                dx, _ = ops.conv_bwd_data(dgi_b, pcs0[ci], pcs0[ci].dgrad(), h.shape)
+                dh = dx if dh is None else dh.add_(dx)
+    return dh
+
+
 def rnn_forward(wrappers, h, seq_dev, seq_host, training):
     """wrappers: list of modules.GRU sharing the input h [B,C,T].  Returns (logits per wrapper, ctx)."""
     chains = _chains(wrappers)
     num_layers = wrappers[0].num_layers
     assert all(w.num_layers == num_layers for w in wrappers)
+    if not any(w.bidirectional for w in wrappers) and wrappers[0].hidden_size in (64, 128, 256, 512) \
+            and all(w.rnn.input_size == h.shape[1] for w in wrappers):
+        return _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training)
     x_w = [h for _ in wrappers]                  # per-wrapper layer input [B, In, T]
     layer_ctx = []
     for l in range(num_layers):
@@ -192,17 +254,14 @@ def rnn_forward(wrappers, h, seq_dev, seq_host, training):
         for wi, w in enumerate(wrappers):
             outs = [hs_bct[i] for i, ch in enumerate(chains) if ch.widx == wi]
             x_w.append(outs[0] if len(outs) == 1 else torch.cat(outs, dim=1))
-    logits, head_ctx = [], []
-    for wi, w in enumerate(wrappers):
-        layers = describe_stack([w.output_net])
-        y, c = stack_forward(layers, x_w[wi], seq_dev, seq_host, training)
-        logits.append(y)
-        head_ctx.append((layers, c))
+    logits, head_ctx = _heads_forward(wrappers, x_w, seq_dev, seq_host, training)
     return logits, (chains, layer_ctx, head_ctx)
 
 
 def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     """Returns grad wrt the shared input h."""
+    if ctx[0] == 'stack':
+        return _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host)
     chains, layer_ctx, head_ctx = ctx
     num_layers = wrappers[0].num_layers
     hid = wrappers[0].hidden_size

@@ -269,3 +269,52 @@ def test_adam_and_grad_norm_vs_torch():
         ops.adam_step(p, gd, m, v, lr=5e-4, step=step, max_norm=5., sumsq=ss, norm_out=norm)
         assert norm.item() == pytest.approx(ref_norm.item(), rel=1e-5)
     close(p, pr, atol=1e-6, rtol=1e-5, name='adam params after 3 steps')
+
+
+@pytest.mark.parametrize('b,h,t,ragged', [(5, 64, 23, True), (32, 256, 30, False), (19, 128, 17, True)])
+def test_gru_stack_wavefront_vs_torch(b, h, t, ragged):
+    """2-layer forward + time-reversed stacks (layer wavefront) vs the oracle wrapper around nn.GRU."""
+    from oracle import nn as onn
+    from pb_sed_amd import ops
+    torch.manual_seed(4)
+    cin, nl = 24, 2
+    seq = np.sort(np.random.RandomState(1).randint(t // 2, t + 1, b))[::-1].copy() if ragged else np.full(b, t)
+    seq[0] = t
+    x = torch.randn(b, cin, t)
+    grus = [onn.GRU(cin, h, nl, reverse=False), onn.GRU(cin, h, nl, reverse=True)]
+    xs = [x.clone().requires_grad_() for _ in grus]
+    ys = [g(xi, seq)[0] for g, xi in zip(grus, xs)]
+    gys = [torch.randn_like(y) for y in ys]
+    for y, gy in zip(ys, gys):
+        y.backward(gy)
+    seq_dev = torch.as_tensor(seq, dtype=torch.int32).to(DEV)
+    dd = lambda a: a.detach().float().to(DEV).contiguous()
+    P = lambda g, n, l: getattr(g.rnn, f'{n}_l{l}')
+    gi0 = []
+    for g in grus:
+        gi_bct = torch.einsum('oc,bct->bot', g.rnn.weight_ih_l0, x) + g.rnn.bias_ih_l0[None, :, None]
+        gi0.append(ops.bct_to_tbc(dd(gi_bct)))
+    idx = [(g, l) for g in grus for l in range(nl)]
+    hs, save = ops.gru_stack_fwd(gi0, [dd(P(g, 'weight_ih', l)) if l else None for g, l in idx],
+                                 [dd(P(g, 'bias_ih', l)) if l else None for g, l in idx],
+                                 [dd(P(g, 'weight_hh', l)) for g, l in idx], [dd(P(g, 'bias_hh', l)) for g, l in idx],
+                                 [0, 1], seq_dev, nl)
+    for c in range(2):
+        close(ops.tbc_to_bct(hs[c * nl + nl - 1]), ys[c], name=f'stack fwd chain{c}')
+    dy = [ops.bct_to_tbc(dd(gy)) for gy in gys]
+    dgi, dgh = ops.gru_stack_bwd([ops.transpose2d(dd(P(g, 'weight_hh', l))) for g, l in idx],
+                                 [ops.transpose2d(dd(P(g, 'weight_ih', l + 1))) if l + 1 < nl else None for g, l in idx],
+                                 hs, save, dy, [0, 1], seq_dev, nl)
+    for c, g in enumerate(grus):
+        for l in range(nl):
+            i = c * nl + l
+            dgi_b, dgh_b = ops.tbc_to_bct(dgi[i]).cpu(), ops.tbc_to_bct(dgh[i]).cpu()
+            hprev = ops.tbc_to_bct(hs[i], shift=1 if c else -1).cpu()
+            xin = x if l == 0 else ops.tbc_to_bct(hs[i - 1]).cpu()
+            tag = f'chain{c} layer{l}'
+            close(torch.einsum('bot,bct->oc', dgi_b, xin), P(g, 'weight_ih', l).grad, atol=3e-4, rtol=1e-3, name='dW_ih ' + tag)
+            close(dgi_b.sum((0, 2)), P(g, 'bias_ih', l).grad, atol=3e-4, rtol=1e-3, name='db_ih ' + tag)
+            close(torch.einsum('bot,bct->oc', dgh_b, hprev), P(g, 'weight_hh', l).grad, atol=3e-4, rtol=1e-3, name='dW_hh ' + tag)
+            close(dgh_b.sum((0, 2)), P(g, 'bias_hh', l).grad, atol=3e-4, rtol=1e-3, name='db_hh ' + tag)
+        dgi0 = ops.tbc_to_bct(dgi[c * nl]).cpu()
+        close(torch.einsum('bot,oc->bct', dgi0, g.rnn.weight_ih_l0.detach()), xs[c].grad, atol=3e-4, rtol=1e-3, name=f'dx chain{c}')
