@@ -11,6 +11,8 @@
 // t-contiguous across lanes (coalesced stores in the reference's [B,C,F,T] layout) and puts the
 // two frequency rows of a (2,1) pool window into the same lane.  No im2col is materialised: the
 // input halo tile [CK][FT+KH-1][TT+KW-1] is staged once in LDS (prologue applied while staging).
+#include <cstdlib>
+
 #include "common.h"
 #include "pbsed_internal.h"
 
@@ -300,10 +302,17 @@ static int launch_cfg(const ConvFwdArgs& a, hipStream_t s) {
 
 // Tile selection.  cin/cout padding granularity used by pack_conv_weights must match
 // (conv_tile_dims below is the single source of truth for both).
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 void conv_fwd_tile_dims(int KH, int KW, int Cin, int Cout, int* ck, int* cout_t) {
+    static const int max_ct = env_int("PBSED_CONV_CT", 128);      // tuning knob: cap the Cout tile of 3x3 convs
     if (KH == 3) {
         *ck = (Cin <= 4) ? 4 : 8;
         *cout_t = Cout <= 16 ? 16 : Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;
+        if (*cout_t > max_ct) *cout_t = max_ct;
     } else {
         *ck = (KW == 1) ? 16 : 8;
         *cout_t = Cout <= 16 ? 16 : 128;

@@ -10,6 +10,8 @@
 // operand fetches conflict-free.  The next spatial chunk is prefetched into registers during the
 // MFMAs.  Per-block partial sums are transposed through LDS and reduced with row-contiguous fp32
 // atomics into the [Cout,Cin,KH,KW] gradient (the bias gradient is one extra MFMA against ones).
+#include <cstdlib>
+
 #include "common.h"
 #include "pbsed_internal.h"
 
@@ -262,7 +264,8 @@ static int launch_wgrad(const ConvWgradArgs& a, hipStream_t s) {
 
 int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     if (a.unpool_idx && (a.F % 2)) { set_error("conv_wgrad: unpool needs even F"); return PBSED_E_ARG; }
-    const bool wide = a.Cin > 16;
+    static const int ncg_knob = getenv("PBSED_WGRAD_NCG") ? atoi(getenv("PBSED_WGRAD_NCG")) : 2;
+    const bool wide = a.Cin > 16 && ncg_knob >= 2;
     if (KH == 3 && KW == 3) {
         if (a.Cin == 1) return a.Cout >= 64 ? launch_wgrad<3, 3, 4, 1, 1, true>(a, s) : launch_wgrad<3, 3, 1, 1, 1, true>(a, s);
         if (a.Cout >= 64) return wide ? launch_wgrad<3, 3, 4, 1, 2>(a, s) : launch_wgrad<3, 3, 4, 1, 1>(a, s);

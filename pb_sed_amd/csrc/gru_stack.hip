@@ -64,10 +64,10 @@ __device__ __forceinline__ void mm_rows(f32x4 (&acc)[NG], const float* __restric
 
 // ------------------------------------------------------------------------------------------ forward
 // grid (H/16, ceil(B/16), nchains*nlayers), 256 threads; H = KB*64.
-template <int KB>
-__global__ __launch_bounds__(256) void gru_stack_fwd_kernel(GruStackArgs a) {
-    constexpr int H = KB * 64;
-    __shared__ float red[4][4][64][4];
+template <int KB, int NW>
+__global__ __launch_bounds__(NW * 64) void gru_stack_fwd_kernel(GruStackArgs a) {
+    constexpr int H = KB * NW * 16;
+    __shared__ float red[NW][4][64][4];
     const int chain = blockIdx.z % a.nchains, layer = blockIdx.z / a.nchains;
     const int step = a.launch - layer;
     if (step < 0 || step >= a.T) return;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_kernel(GruStackArgs a) {
     const bool has_prev = step > 0;
     // epilogue operands first: their HBM latency hides behind the matmuls
     const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
-    const bool bv = b < B;
+    const bool bv = tid < 256 && b < B;
     float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, hp = 0.f;
     if (bv) {
         if (layer == 0) {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_kernel(GruStackArgs a) {
         }
         if (has_prev) hp = L.hs[((size_t)tp * B + b) * H + j];
     }
-    const float bh_r = L.b_hh[j], bh_z = L.b_hh[H + j], bh_n = L.b_hh[2 * H + j];
+    const float bh_r = L.b_hh[j0 + u], bh_z = L.b_hh[H + j0 + u], bh_n = L.b_hh[2 * H + j0 + u];
     const int sl = bv ? a.seq_len[b] : 0;
 
     f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -117,7 +117,11 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_kernel(GruStackArgs a) {
     const int src = (u >> 2) * 16 + bb, reg = u & 3;
     float s[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) s[g] = red[0][g][src][reg] + red[1][g][src][reg] + red[2][g][src][reg] + red[3][g][src][reg];
+    for (int g = 0; g < 4; ++g) {
+        s[g] = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s[g] += red[w][g][src][reg];
+    }
     const float ghn = s[2] + bh_n;
     const float r = 1.f / (1.f + expf(-(gi_r + s[0] + bh_r)));
     const float z = 1.f / (1.f + expf(-(gi_z + s[1] + bh_z)));
@@ -134,10 +138,10 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_kernel(GruStackArgs a) {
 // ------------------------------------------------------------------------------------------ backward
 // Launch s: top layer handles reversed scan index s, layer l handles s - (nlayers-1-l).
 // w_hh holds W_hh^T [H][3H]; for l < top, w_ih holds (W_ih of layer l+1)^T [H][3H].
-template <int KB>
-__global__ __launch_bounds__(256) void gru_stack_bwd_kernel(GruStackArgs a) {
-    constexpr int H = KB * 64, G = 3 * H, KB3 = 3 * KB;
-    __shared__ float red[4][2][64][4];
+template <int KB, int NW>
+__global__ __launch_bounds__(NW * 64) void gru_stack_bwd_kernel(GruStackArgs a) {
+    constexpr int H = KB * NW * 16, G = 3 * H, KB3 = 3 * KB;
+    __shared__ float red[NW][2][64][4];
     const int chain = blockIdx.z % a.nchains, layer = blockIdx.z / a.nchains;
     const int top = a.nlayers - 1;
     const int bstep = a.launch - (top - layer);
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256) void gru_stack_bwd_kernel(GruStackArgs a) {
     const int tp = rev ? t + 1 : t - 1;
     const bool has_next = bstep > 0, has_prev = s > 0;
     const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
-    const bool bv = b < B;
+    const bool bv = tid < 256 && b < B;
     const size_t tb = (size_t)t * B + b;
     float r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, hp = 0.f, dyv = 0.f, dhzn = 0.f;
     int sl = 0;
@@ -177,8 +181,9 @@ __global__ __launch_bounds__(256) void gru_stack_bwd_kernel(GruStackArgs a) {
     __syncthreads();
     if (!bv) return;
     const int src = (u >> 2) * 16 + bb, reg = u & 3;
-    const float carry = red[0][0][src][reg] + red[1][0][src][reg] + red[2][0][src][reg] + red[3][0][src][reg];
-    const float dylow = red[0][1][src][reg] + red[1][1][src][reg] + red[2][1][src][reg] + red[3][1][src][reg];
+    float carry = 0.f, dylow = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { carry += red[w][0][src][reg]; dylow += red[w][1][src][reg]; }
     float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, dhzv = 0.f;
     if (t < sl) {
         const float dh = (layer == top ? dyv : dylow) + (has_next ? carry + dhzn : 0.f);
@@ -195,13 +200,13 @@ __global__ __launch_bounds__(256) void gru_stack_bwd_kernel(GruStackArgs a) {
     L.dhz[tb * H + j] = dhzv;
 }
 
-template <int KB>
+template <int KB, int NW>
 static void launch_stack(bool bwd, GruStackArgs& a, dim3 grid, hipStream_t s) {
     const int nl = a.T + a.nlayers - 1;
     for (int i = 0; i < nl; ++i) {
         a.launch = i;
-        if (bwd) hipLaunchKernelGGL(gru_stack_bwd_kernel<KB>, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(gru_stack_fwd_kernel<KB>, grid, dim3(256), 0, s, a);
+        if (bwd) hipLaunchKernelGGL((gru_stack_bwd_kernel<KB, NW>), grid, dim3(NW * 64), 0, s, a);
+        else hipLaunchKernelGGL((gru_stack_fwd_kernel<KB, NW>), grid, dim3(NW * 64), 0, s, a);
     }
 }
 
@@ -221,10 +226,10 @@ static int stack_check(int nchains, int nlayers, int B, int H, int T) {
 
 #define DISPATCH_KB(H, BWD, a, grid, s)                            \
     switch (H) {                                                   \
-        case 64: launch_stack<1>(BWD, a, grid, s); break;          \
-        case 128: launch_stack<2>(BWD, a, grid, s); break;         \
-        case 256: launch_stack<4>(BWD, a, grid, s); break;         \
-        default: launch_stack<8>(BWD, a, grid, s); break;          \
+        case 64: launch_stack<1, 4>(BWD, a, grid, s); break;       \
+        case 128: launch_stack<1, 8>(BWD, a, grid, s); break;      \
+        case 256: launch_stack<2, 8>(BWD, a, grid, s); break;      \
+        default: launch_stack<4, 8>(BWD, a, grid, s); break;       \
     }
 
 extern "C" {

@@ -78,25 +78,34 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double c
 }
 
 // in place: dz -> dx = gamma*invstd * (dz - m1 - xhat*m2) on masked positions (0 elsewhere).
-// tensors [B, C, S, T] with S = inner rows per channel (F for 2-D, 1 for 1-D).
+// tensors [B, C, S, T] with S = inner rows per channel (F for 2-D, 1 for 1-D).  VEC: 4 frames per thread.
+template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ dz, const float* __restrict__ x,
                                                            const float* mean, const float* invstd,
                                                            const float* scale, const float* m1,
                                                            const float* m2, const int* seq_len, int B,
                                                            int C, int S, int T) {
-    const size_t total = (size_t)B * C * S * T;
+    constexpr int W = VEC ? 4 : 1;
+    const int Tq = T / W;
+    const size_t total = (size_t)B * C * S * Tq;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
-        const int t = i % T;
-        const size_t row = i / T;
+        const int t = (i % Tq) * W;
+        const size_t row = i / Tq;
         const int c = (row / S) % C, b = row / ((size_t)S * C);
         const int sl = seq_len ? seq_len[b] : T;
-        float v = 0.f;
-        if (t < sl) {
-            const float xhat = (x[i] - mean[c]) * invstd[c];
-            v = scale[c] * (dz[i] - m1[c] - xhat * m2[c]);
+        const float mu = mean[c], is = invstd[c], sc = scale[c], a1 = m1[c], a2 = m2[c];
+        if (VEC) {
+            float4 d = reinterpret_cast<float4*>(dz)[i];
+            const float4 xv = reinterpret_cast<const float4*>(x)[i];
+            d.x = (t + 0 < sl) ? sc * (d.x - a1 - (xv.x - mu) * is * a2) : 0.f;
+            d.y = (t + 1 < sl) ? sc * (d.y - a1 - (xv.y - mu) * is * a2) : 0.f;
+            d.z = (t + 2 < sl) ? sc * (d.z - a1 - (xv.z - mu) * is * a2) : 0.f;
+            d.w = (t + 3 < sl) ? sc * (d.w - a1 - (xv.w - mu) * is * a2) : 0.f;
+            reinterpret_cast<float4*>(dz)[i] = d;
+        } else {
+            dz[i] = (t < sl) ? sc * (dz[i] - a1 - (x[i] - mu) * is * a2) : 0.f;
         }
-        dz[i] = v;
     }
 }
 
@@ -386,8 +395,12 @@ int pbsed_bn_bwd_apply(float* dz, const float* x, const float* mean, const float
                        const float* m1, const float* m2, const int* seq_len, int B, int C, int S, int T,
                        void* stream) {
     const size_t total = (size_t)B * C * S * T;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
-                       dz, x, mean, invstd, scale, m1, m2, seq_len, B, C, S, T);
+    if (T % 4 == 0)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(nblocks(total / 4, 256, 8192)), dim3(256), 0,
+                           (hipStream_t)stream, dz, x, mean, invstd, scale, m1, m2, seq_len, B, C, S, T);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(nblocks(total, 256, 8192)), dim3(256), 0,
+                           (hipStream_t)stream, dz, x, mean, invstd, scale, m1, m2, seq_len, B, C, S, T);
     return check_launch("bn_bwd_apply");
 }
 
