@@ -109,6 +109,16 @@ int pbsed_bicrnn_loss(const float* logit, const float* strong_targets, const int
                       float* dlogit, float* loss, double* scratch, int B, int K, int T, int inputs_are_scores,
                       void* stream);
 
+/* ---- ensemble post-processing (pb_sed/models/base/inference.py:142-184,225-289; pb_sed/filters.py:56-83,112-135;
+ * event extraction = sed_scores_eval scores_to_event_list, call site experiments/strong_label_crnn/inference.py:147-150).
+ * Rows = flattened leading dims of a [B,(n,)K,T] score tensor; n_row / thr / len are per-row device arrays. */
+int pbsed_ensemble_mean_mask(const float* const* scores /*host array of device ptrs*/, int n_models, float* out,
+                             const int* seq_len, int rows_per_clip, int R, int T, void* stream);
+int pbsed_medfilt(const float* in, float* out, const int* n_row, int R, int T, void* stream);
+int pbsed_boundariesfilt(const float* in, float* out, double* out64, const int* n_row, int R, int T, void* stream);
+int pbsed_event_frames(const float* scores, const float* thr, const int* len, int* events, int* counts, int R, int T,
+                       int max_events, void* stream);
+
 /* ---- optimiser (padertorch Adam(lr, gradient_clipping); pb_sed/experiments/weak_label_crnn/training.py:264-269) */
 int pbsed_grad_sumsq(const float* g, size_t n, double* out, void* stream);
 int pbsed_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,

@@ -44,6 +44,10 @@ SIGNATURES = {
     'pbsed_bicrnn_loss': [_v, _v, _v, _v, _v, _v, _v, I, I, I, I, _v],
     'pbsed_squash_fwd': [_v, _v, SZ, F32, _v],
     'pbsed_squash_bwd': [_v, _v, _v, SZ, F32, _v],
+    'pbsed_ensemble_mean_mask': [_pp, I, _v, _v, I, I, I, _v],
+    'pbsed_medfilt': [_v, _v, _v, I, I, _v],
+    'pbsed_boundariesfilt': [_v, _v, _v, _v, I, I, _v],
+    'pbsed_event_frames': [_v, _v, _v, _v, _v, I, I, I, _v],
     'pbsed_grad_sumsq': [_v, SZ, _v, _v],
     'pbsed_adam_step': [_v, _v, _v, _v, SZ, F32, F32, F32, F32, I, F32, F32, _v, _v, _v],
     'pbsed_memset_async': [_v, I, SZ, _v],

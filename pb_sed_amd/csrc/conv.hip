@@ -213,6 +213,22 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
             const int cl = (wm * C::MTW + m) * 16 + lq * 4 + r;
             const int cout = cout0 + cl;
             const float bias = (a.bias && cout < a.Cout) ? a.bias[cout] : 0.f;
+            const bool cv = cout < a.Cout;
+            const bool bnb = DGRAD && a.bx != nullptr;
+            float bsc = 0.f, bsh = 0.f, bmu = 0.f, bis = 0.f;
+            if (bnb && cv) { bsc = a.bscale[cout]; bsh = a.bshift[cout]; bmu = a.bmean[cout]; bis = a.binvstd[cout]; }
+            // DGRAD: fetch the layer's raw forward input for the whole row group first (independent loads)
+            float xin[C::FO_T][C::NTT];
+            if (DGRAD) {
+#pragma unroll
+                for (int fo_l = 0; fo_l < C::FO_T; ++fo_l)
+#pragma unroll
+                    for (int j = 0; j < C::NTT; ++j) {
+                        const int t = t0 + (wn * C::NTT + j) * 16 + lr, fo = f0 + fo_l;
+                        xin[fo_l][j] = (bnb && cv && fo < Fo && t < a.T)
+                                           ? a.bx[((size_t)(b * a.Cout + cout) * Fo + fo) * a.T + t] : 0.f;
+                    }
+            }
 #pragma unroll
             for (int fo_l = 0; fo_l < C::FO_T; ++fo_l) {
                 float s1 = 0.f, s2 = 0.f;
@@ -230,18 +246,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
                         v = acc[m][fo_l * C::NTT + j][r] + bias;
                     }
                     const int fo = (POOL ? f0 / 2 : f0) + fo_l;
-                    if (cout < a.Cout && fo < Fo && t < a.T) {
+                    if (cv && fo < Fo && t < a.T) {
                         const size_t o = ((size_t)(b * a.Cout + cout) * Fo + fo) * a.T + t;
                         if (DGRAD) {
-                            if (a.bx) {
+                            if (bnb) {
                                 // backward through mask -> ReLU -> BN-apply of the layer's prologue:
                                 // dz = da * [z > 0] * [t < seq_len];  partial sums for BN backward
-                                const float xv = a.bx[o];
-                                const float z = fmaf(xv, a.bscale[cout], a.bshift[cout]);
+                                const float xv = xin[fo_l][j];
+                                const float z = fmaf(xv, bsc, bsh);
                                 const bool keep = (t < sl) && (!a.relu || z > 0.f);
                                 v = keep ? v : 0.f;
-                                const float xhat = (xv - a.bmean[cout]) * a.binvstd[cout];
-                                s1 += v; s2 += v * xhat;
+                                s1 += v; s2 += v * ((xv - bmu) * bis);
                             }
                             a.y[o] = v;
                         } else {
@@ -308,7 +323,7 @@ static int env_int(const char* name, int dflt) {
 }
 
 void conv_fwd_tile_dims(int KH, int KW, int Cin, int Cout, int* ck, int* cout_t) {
-    static const int max_ct = env_int("PBSED_CONV_CT", 128);      // tuning knob: cap the Cout tile of 3x3 convs
+    static const int max_ct = env_int("PBSED_CONV_CT", 64);      // tuning knob: cap the Cout tile of 3x3 convs
     if (KH == 3) {
         *ck = (Cin <= 4) ? 4 : 8;
         *cout_t = Cout <= 16 ? 16 : Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;

@@ -20,10 +20,17 @@ namespace pbsed {
 constexpr int pad2mod32(int n) { return ((n + 29) / 32) * 32 + 2; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN>
+template <int KWAVES>
+__device__ __forceinline__ void lds_acc(float* p, float v) {
+    if (KWAVES > 1) atomicAdd(p, v); else *p = v;
+}
+
+template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN, int KWAVES>
 struct WgradCfg {
+    // WAVES waves tile Cout (MT M-tiles each); KWAVES groups of them split the spatial (K) dimension
     static constexpr int FT = (KH == 3) ? 2 : 1, TT = 64;
-    static constexpr int KK = KH * KW, NT = WAVES * 64;
+    static constexpr int KK = KH * KW, NT = WAVES * KWAVES * 64;
+    static constexpr int TQ_PER = (TT / 4) / KWAVES;
     static constexpr int COUT_T = WAVES * MT * 16, CIN_T = TAPN ? 1 : NCG * 16;   // TAPN: Cin == 1, taps on N
     static constexpr int HALO = (KW > 1) ? 4 : 0;
     static constexpr int ROWS = FT + KH - 1, ROW = TT + 2 * HALO, QR = ROW / 4;
@@ -35,16 +42,17 @@ struct WgradCfg {
     static constexpr int LDS_FLOATS = cmax(COUT_T * PLANE_Y + CIN_T * PLANE_A, COUT_T * OUT_ROW);
 };
 
-template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN>
-__global__ __launch_bounds__(WAVES * 64) void conv_wgrad_kernel(ConvWgradArgs a) {
-    using C = WgradCfg<KH, KW, WAVES, MT, NCG, TAPN>;
+template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN, int KWAVES>
+__global__ __launch_bounds__(WAVES * KWAVES * 64) void conv_wgrad_kernel(ConvWgradArgs a) {
+    using C = WgradCfg<KH, KW, WAVES, MT, NCG, TAPN, KWAVES>;
     constexpr int FT = C::FT, TT = C::TT, KK = C::KK, NT = C::NT;
     constexpr int PADH = (KH - 1) / 2, PADW = (KW - 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dy_s = smem;                              // [COUT_T][PLANE_Y]
     float* a_s = smem + C::COUT_T * C::PLANE_Y;      // [CIN_T][PLANE_A]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (tid >> 6) % WAVES, kwv = (tid >> 6) / WAVES;     // Cout tile / spatial slice of this wave
     const int lq = lane >> 4, lr = lane & 15;
     const int cin0 = blockIdx.y * C::CIN_T, cout0 = blockIdx.z * C::COUT_T;
     const int nTt = (a.T + TT - 1) / TT, nFt = (a.F + FT - 1) / FT;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_kernel(ConvWgradArgs a)
 #pragma unroll
         for (int fl = 0; fl < FT; ++fl) {
 #pragma unroll 2
-            for (int tq = 0; tq < TT / 4; ++tq) {
+            for (int tq = kwv * C::TQ_PER; tq < (kwv + 1) * C::TQ_PER; ++tq) {
                 float af[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -201,13 +209,17 @@ __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_kernel(ConvWgradArgs a)
     // ---- reduce: transpose the block's partial dW through LDS, then row-contiguous atomics
     __syncthreads();
     float* out_s = smem;                             // [COUT_T][OUT_ROW]
+    if (KWAVES > 1) {
+        for (int i = tid; i < C::COUT_T * C::OUT_ROW; i += NT) out_s[i] = 0.f;
+        __syncthreads();
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         if (TAPN) {
             if (lr < KK)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    out_s[((wave * MT + m) * 16 + lq * 4 + r) * C::OUT_ROW + lr] = acc[m][0][r];
+                    lds_acc<KWAVES>(out_s + ((wave * MT + m) * 16 + lq * 4 + r) * C::OUT_ROW + lr, acc[m][0][r]);
         } else {
 #pragma unroll
             for (int g = 0; g < NCG; ++g)
@@ -215,13 +227,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_kernel(ConvWgradArgs a)
                 for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        out_s[((wave * MT + m) * 16 + lq * 4 + r) * C::OUT_ROW + (g * 16 + lr) * KK + kk] =
-                            acc[m][g * KK + kk][r];
+                        lds_acc<KWAVES>(out_s + ((wave * MT + m) * 16 + lq * 4 + r) * C::OUT_ROW + (g * 16 + lr) * KK + kk,
+                                        acc[m][g * KK + kk][r]);
         }
     }
     __syncthreads();
     const int ncol = min(C::CIN_T, a.Cin - cin0) * KK;      // valid, contiguous part of each row
-    for (int row = wave; row < C::COUT_T; row += WAVES) {
+    for (int row = tid >> 6; row < C::COUT_T; row += NT / 64) {
         const int cout = cout0 + row;
         if (cout >= a.Cout) break;
         float* dst = a.dw + ((size_t)cout * a.Cin + cin0) * KK;
@@ -238,9 +250,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_kernel(ConvWgradArgs a)
     }
 }
 
-template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN = false>
+template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN = false, int KWAVES = 1>
 static int launch_wgrad(const ConvWgradArgs& a, hipStream_t s) {
-    using C = WgradCfg<KH, KW, WAVES, MT, NCG, TAPN>;
+    using C = WgradCfg<KH, KW, WAVES, MT, NCG, TAPN, KWAVES>;
     const int nTt = (a.T + C::TT - 1) / C::TT, nFt = (a.F + C::FT - 1) / C::FT;
     const int nChunks = a.B * nFt * nTt;
     const int gy = (a.Cin + C::CIN_T - 1) / C::CIN_T;
@@ -251,27 +263,29 @@ static int launch_wgrad(const ConvWgradArgs& a, hipStream_t s) {
     if (split > nChunks) split = nChunks;
     dim3 grid(split, gy, gz);
     const size_t lds = C::LDS_FLOATS * sizeof(float);
-    auto kern = conv_wgrad_kernel<KH, KW, WAVES, MT, NCG, TAPN>;
+    auto kern = conv_wgrad_kernel<KH, KW, WAVES, MT, NCG, TAPN, KWAVES>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * KWAVES * 64), lds, s, a);
     return check_launch("conv_wgrad");
 }
 
 int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     if (a.unpool_idx && (a.F % 2)) { set_error("conv_wgrad: unpool needs even F"); return PBSED_E_ARG; }
-    static const int ncg_knob = getenv("PBSED_WGRAD_NCG") ? atoi(getenv("PBSED_WGRAD_NCG")) : 2;
+    static const int ncg_knob = getenv("PBSED_WGRAD_NCG") ? atoi(getenv("PBSED_WGRAD_NCG")) : 1;
     const bool wide = a.Cin > 16 && ncg_knob >= 2;
     if (KH == 3 && KW == 3) {
-        if (a.Cin == 1) return a.Cout >= 64 ? launch_wgrad<3, 3, 4, 1, 1, true>(a, s) : launch_wgrad<3, 3, 1, 1, 1, true>(a, s);
+        if (a.Cin == 1) return a.Cout >= 64 ? launch_wgrad<3, 3, 4, 1, 1, true>(a, s) : launch_wgrad<3, 3, 1, 1, 1, true, 4>(a, s);
         if (a.Cout >= 64) return wide ? launch_wgrad<3, 3, 4, 1, 2>(a, s) : launch_wgrad<3, 3, 4, 1, 1>(a, s);
-        if (a.Cout >= 32) return wide ? launch_wgrad<3, 3, 2, 1, 2>(a, s) : launch_wgrad<3, 3, 2, 1, 1>(a, s);
-        return launch_wgrad<3, 3, 1, 1, 1>(a, s);
+        if (a.Cout >= 32) return wide ? launch_wgrad<3, 3, 2, 1, 2, false, 2>(a, s) : launch_wgrad<3, 3, 2, 1, 1, false, 2>(a, s);
+        return launch_wgrad<3, 3, 1, 1, 1, false, 4>(a, s);
     }
+    const bool wide1 = a.Cin > 16;
+    (void)wide1;
     if (KH == 1 && KW == 3) {
         return a.Cout >= 128 ? launch_wgrad<1, 3, 4, 2, 2>(a, s) : launch_wgrad<1, 3, 1, 1, 2>(a, s);
     }

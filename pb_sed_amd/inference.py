@@ -1,0 +1,184 @@
+"""Ensemble inference driver: counterpart of ``pb_sed.models.base.inference``
+(reference pb_sed/models/base/inference.py:12-222: ``tagging`` / ``boundaries_detection`` /
+``sound_event_detection`` / ``inference``) with the whole post-processing chain on the GPU.
+
+Per batch: every model's inference head runs on the device (HIP path), the scores stay there, and
+mean over models -> sequence mask -> median filter -> (boundaries filter) -> tag masking are HIP kernels
+that are bit-exact with the reference's numpy/scipy host code (tests/test_gpu_postproc.py replays the
+reference's own golden vectors).  Only the final per-clip ``[(n,)T,K]`` arrays go to the host, keyed by
+``example_id`` like the reference's result dict.
+
+Not carried over (SURVEY.md section 8 marks them out of scope for 10 s clips): ``max_segment_length`` /
+``merge_score_segments`` (utils/segment.py) and on-disk score storage.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def _as_dev_scores(y, device):
+    return y.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def filtering(scores, filter_fn, filter_length):
+    """Device twin of inference.py:225-263: 0-d, per-class (1-d) or per-variant (2-d -> [B,n,K,T]) lengths."""
+    filter_length = np.asarray(filter_length)
+    b, *_, k, t = scores.shape
+    if filter_length.ndim == 0:
+        return filter_fn(scores, filter_length)
+    if filter_length.ndim == 1:
+        assert filter_length.shape[0] == k, filter_length.shape
+        return filter_fn(scores, filter_length)                      # broadcasts over [..., K]
+    assert filter_length.ndim == 2 and filter_length.shape[1] in (1, k), filter_length.shape
+    n = filter_length.shape[0]
+    if scores.dim() == 3:
+        scores = scores[:, None].expand(b, n, k, t).contiguous()
+    else:
+        assert scores.shape[1] == n, (scores.shape, n)
+    return filter_fn(scores, np.broadcast_to(filter_length, (n, k)))
+
+
+def postprocess_batch(model_scores, seq_len, example_ids, *, medfilt_length=1, stepfilt_length=None,
+                      apply_mask=False, masks=None, post_processing_fn=None):
+    """inference.py:142-184 for one batch.  model_scores: list (one per model) of device tensors
+    [B,(n,)K,T]; seq_len: host int array [B].  Returns {example_id: np.ndarray [(n,)T,K]}."""
+    dev = model_scores[0].device
+    seq_dev = torch.as_tensor(np.asarray(seq_len), dtype=torch.int32).to(dev)
+    s = ops.ensemble_mean_mask(model_scores, seq_dev)
+    s = filtering(s, ops.medfilt, np.array(medfilt_length, dtype=int))
+    if stepfilt_length is not None:
+        sl_arr = np.array(stepfilt_length, dtype=int)
+        if sl_arr.ndim == 0 and sl_arr > 0:        # the reference returns the float64 step-filter output here
+            s = ops.boundariesfilt(s, sl_arr, want_f64=True)
+        else:
+            s = filtering(s, ops.boundariesfilt, sl_arr)
+    s = s.cpu().numpy()
+    out = {}
+    for i, (aid, sl) in enumerate(zip(example_ids, seq_len)):
+        x = s[i, ..., :sl].swapaxes(-2, -1)
+        out[aid] = x if post_processing_fn is None else post_processing_fn(x)
+    apply_mask = np.array(apply_mask, dtype=bool)
+    if apply_mask.any():
+        assert masks is not None
+        if apply_mask.ndim == 2:
+            apply_mask = apply_mask[..., None, :]
+        for aid in out:
+            assert aid in masks, aid
+            out[aid] = np.array(out[aid])
+            out[aid] *= np.maximum(masks[aid], 1 - apply_mask)        # in place: stays float32
+    return out
+
+
+def create_score_dataframe(scores, timestamps, event_classes):
+    """sed_scores_eval.utils.scores.create_score_dataframe restated: onset/offset columns + one per class."""
+    import pandas as pd
+    scores = np.asarray(scores)
+    timestamps = np.asarray(timestamps)
+    assert scores.ndim == 2 and len(timestamps) == scores.shape[0] + 1 and scores.shape[1] == len(event_classes)
+    return pd.DataFrame(np.concatenate((timestamps[:-1, None], timestamps[1:, None], scores), axis=1),
+                        columns=['onset', 'offset', *event_classes])
+
+
+def scores_to_dataframes(scores, timestamps, event_classes):
+    """inference.py:292-356 without the storage branch."""
+    if isinstance(scores, np.ndarray):
+        t, k = scores.shape
+        assert len(timestamps) > t and len(event_classes) == k
+        return create_score_dataframe(scores, timestamps[:t + 1], event_classes)
+    ids = sorted(scores)
+    if scores[ids[0]].ndim == 3:
+        n = scores[ids[0]].shape[0]
+        return [{a: scores_to_dataframes(scores[a][i], timestamps[a] if isinstance(timestamps, dict) else timestamps,
+                                         event_classes) for a in ids} for i in range(n)]
+    return {a: scores_to_dataframes(scores[a], timestamps[a] if isinstance(timestamps, dict) else timestamps,
+                                    event_classes) for a in ids}
+
+
+def inference(model, method, dataset, device, max_segment_length=None, segment_overlap=0,
+              merge_score_segments=False, score_segment_overlap=None, model_kwargs=None, medfilt_length=1,
+              stepfilt_length=None, apply_mask=False, masks=None, post_processing_fn=None, timestamps=None,
+              event_classes=None, score_storage_dir=None, rank=0, world_size=1):
+    """Same contract as the reference's ``inference`` (inference.py:86-222).  ``rank``/``world_size``
+    shard every batch over clips (config 5: no collective needed, results are keyed by example_id)."""
+    if max_segment_length is not None or merge_score_segments or score_storage_dir is not None:
+        raise NotImplementedError('segmenting / score storage are outside the MI355X hot path')
+    models = list(model) if isinstance(model, (list, tuple)) else [model]
+    model_kwargs = {} if model_kwargs is None else model_kwargs
+    kwargs = list(model_kwargs) if isinstance(model_kwargs, (list, tuple)) else len(models) * [model_kwargs]
+    assert len(kwargs) == len(models), (len(models), len(kwargs))
+    for m in models:
+        assert hasattr(m, method), (m, method)
+        m.to(device)
+        m.eval()
+    scores = {}
+    with torch.no_grad():
+        for batch in dataset:
+            batch = {k: v for k, v in batch.items() if k not in ('weak_targets', 'boundary_targets', 'strong_targets')}
+            if world_size > 1:
+                from .trainer import shard_batch
+                batch = shard_batch(batch, rank, world_size)
+            batch = models[0].example_to_device(batch, device)
+            per_model, seq_len = [], None
+            for m, kw in zip(models, kwargs):
+                y, sl = getattr(m, method)(batch, **kw)
+                per_model.append(_as_dev_scores(y, device))
+                if seq_len is None:
+                    seq_len = np.asarray(sl)
+                else:
+                    assert (np.asarray(sl) == seq_len).all(), (seq_len, sl)
+            scores.update(postprocess_batch(per_model, seq_len, batch['example_id'], medfilt_length=medfilt_length,
+                                            stepfilt_length=stepfilt_length, apply_mask=apply_mask, masks=masks,
+                                            post_processing_fn=post_processing_fn))
+    if timestamps is not None or event_classes is not None:
+        assert timestamps is not None and event_classes is not None
+        return scores_to_dataframes(scores, timestamps, event_classes)
+    return scores
+
+
+def tagging(models, dataset, device, model_kwargs=None, medfilt_length=1, method='tagging', timestamps=None,
+            event_classes=None, **kw):
+    return inference(models, method, dataset, device, model_kwargs=model_kwargs, medfilt_length=medfilt_length,
+                     post_processing_fn=lambda x: x.max(-2, keepdims=True), timestamps=timestamps,
+                     event_classes=event_classes, **kw)
+
+
+def boundaries_detection(models, dataset, device, model_kwargs=None, medfilt_length=1, stepfilt_length=0,
+                         apply_mask=False, masks=None, method='boundaries_detection', timestamps=None,
+                         event_classes=None, **kw):
+    return inference(models, method, dataset, device, model_kwargs=model_kwargs, medfilt_length=medfilt_length,
+                     stepfilt_length=stepfilt_length, apply_mask=apply_mask, masks=masks, timestamps=timestamps,
+                     event_classes=event_classes, **kw)
+
+
+def sound_event_detection(models, dataset, device, model_kwargs=None, medfilt_length=1, method='sound_event_detection',
+                          apply_mask=False, masks=None, timestamps=None, event_classes=None, **kw):
+    return inference(models, method, dataset, device, model_kwargs=model_kwargs, medfilt_length=medfilt_length,
+                     apply_mask=apply_mask, masks=masks, timestamps=timestamps, event_classes=event_classes, **kw)
+
+
+def scores_to_event_list(scores, thresholds, event_classes, timestamps, device='cuda'):
+    """Threshold -> change points -> (onset, offset, label) per clip; the frame indices come from the
+    ``pbsed_event_frames`` kernel (bit-exact index arithmetic), timestamps are looked up on the host.
+    scores: {example_id: [T,K] array}; thresholds: scalar or [K]."""
+    ids = sorted(scores)
+    k = len(event_classes)
+    thr = np.broadcast_to(np.asarray(thresholds, dtype=np.float32), (k,))
+    tmax = max(scores[a].shape[0] for a in ids)
+    dense = np.zeros((len(ids), k, tmax), np.float32)
+    lens = np.zeros((len(ids),), np.int64)
+    for i, a in enumerate(ids):
+        t = scores[a].shape[0]
+        dense[i, :, :t] = np.asarray(scores[a], dtype=np.float32).T
+        lens[i] = t
+    ev, cnt = ops.event_frames(torch.from_numpy(dense).to(device), thr[None, :], lens[:, None])
+    ev, cnt = ev.cpu().numpy().reshape(len(ids), k, -1, 2), cnt.cpu().numpy().reshape(len(ids), k)
+    out = {}
+    for i, a in enumerate(ids):
+        ts = timestamps[a] if isinstance(timestamps, dict) else timestamps
+        events = []
+        for c, label in enumerate(event_classes):
+            for e in range(cnt[i, c]):
+                events.append((float(ts[ev[i, c, e, 0]]), float(ts[ev[i, c, e, 1]]), label))
+        out[a] = sorted(events)
+    return out

@@ -304,3 +304,53 @@ def adam_step(p, g, m, v, *, lr, beta1=.9, beta2=.999, eps=1e-8, step, grad_scal
     call('pbsed_adam_step', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1),
          float(beta2), float(eps), int(step), float(grad_scale), float(max_norm), ptr(sumsq),
          ptr(norm_out), stream())
+
+
+# ------------------------------------------------------------------------------------- post-processing
+def ensemble_mean_mask(scores, seq_len):
+    """scores: list of [B,(n,)K,T] device tensors (one per model) -> mean over models * sequence mask."""
+    s0 = scores[0].contiguous()
+    b, t = s0.shape[0], s0.shape[-1]
+    r = s0.numel() // t
+    out = torch.empty_like(s0)
+    keep = [s.contiguous() for s in scores]
+    call('pbsed_ensemble_mean_mask', _lib.ptr_array(keep), len(keep), ptr(out), ptr(seq_len), r // b, r, t, stream())
+    return out
+
+
+def _rows(x, per_row):
+    t = x.shape[-1]
+    r = x.numel() // t
+    pr = torch.as_tensor(np.broadcast_to(np.asarray(per_row), x.shape[:-1]).reshape(-1).copy())
+    return r, t, pr
+
+
+def medfilt(scores, lengths):
+    """Zero-padded median filter along the last axis; ``lengths`` broadcasts against scores.shape[:-1]."""
+    x = scores.contiguous()
+    r, t, n = _rows(x, lengths)
+    out = torch.empty_like(x)
+    call('pbsed_medfilt', ptr(x), ptr(out), ptr(n.to(torch.int32).to(x.device)), r, t, stream())
+    return out
+
+
+def boundariesfilt(scores, lengths, want_f64=False):
+    x = scores.contiguous()
+    r, t, n = _rows(x, lengths)
+    out = torch.empty_like(x)
+    out64 = torch.empty(x.shape, device=x.device, dtype=torch.float64) if want_f64 else None
+    call('pbsed_boundariesfilt', ptr(x), ptr(out), ptr(out64), ptr(n.to(torch.int32).to(x.device)), r, t, stream())
+    return out64 if want_f64 else out
+
+
+def event_frames(scores, thresholds, lengths, max_events=None):
+    """scores [..., T] (class rows), per-row thresholds / valid lengths -> (events [R,max,2] int32, counts [R])."""
+    x = scores.contiguous()
+    r, t, th = _rows(x, thresholds)
+    _, _, ln = _rows(x, lengths)
+    max_events = max_events or (t // 2 + 1)
+    ev = torch.zeros((r, max_events, 2), dtype=torch.int32, device=x.device)
+    cnt = torch.zeros((r,), dtype=torch.int32, device=x.device)
+    call('pbsed_event_frames', ptr(x), ptr(th.to(torch.float32).to(x.device)), ptr(ln.to(torch.int32).to(x.device)),
+         ptr(ev), ptr(cnt), r, t, max_events, stream())
+    return ev, cnt

@@ -1,0 +1,127 @@
+"""GPU post-processing kernels vs the reference's own golden vectors (bit-exact) and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_medfilt_bit_exact_vs_reference(golden):
+    from pb_sed_amd import ops
+    g = golden('ref_filters.npz')
+    x = dev(g['x'])
+    for n in (1, 3, 5, 11, 41, 101):
+        np.testing.assert_array_equal(ops.medfilt(x, n).cpu().numpy(), g[f'medfilt_{n}'])
+    np.testing.assert_array_equal(ops.medfilt(x, g['len_1d']).cpu().numpy(), g['filtering_med_1d'])
+
+
+def test_boundariesfilt_vs_reference(golden):
+    from pb_sed_amd import ops
+    g = golden('ref_filters.npz')
+    x = dev(g['x'])
+    np.testing.assert_array_equal(ops.boundariesfilt(x, 0).cpu().numpy(), g['boundariesfilt_0'])
+    for n in (2, 6, 20):
+        out = ops.boundariesfilt(x, n, want_f64=True).cpu().numpy()
+        np.testing.assert_allclose(out, g[f'boundariesfilt_{n}'], rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(ops.boundariesfilt(x, g['steplen_1d']).cpu().numpy(), g['filtering_bnd_1d'])
+
+
+def test_filtering_variants_bit_exact(golden):
+    from pb_sed_amd import inference as inf, ops
+    g = golden('ref_filters.npz')
+    x = dev(g['x'])
+    np.testing.assert_array_equal(inf.filtering(x, ops.medfilt, np.array(5)).cpu().numpy(), g['filtering_med_0d'])
+    np.testing.assert_array_equal(inf.filtering(x, ops.medfilt, g['len_2d']).cpu().numpy(), g['filtering_med_2d'])
+    np.testing.assert_array_equal(inf.filtering(x, ops.medfilt, g['len_2d_bcast']).cpu().numpy(),
+                                  g['filtering_med_2d_bcast'])
+
+
+def test_ensemble_postprocess_bit_exact_vs_reference_inference(golden):
+    from pb_sed_amd import inference as inf
+    g = golden('ref_inference.npz')
+    scores, seq_len, ids = g['scores'], g['seq_len'], g['ids']
+    flat_ids = [a for batch in ids for a in batch]
+    tags = dict(zip(flat_ids, g['tags']))
+
+    def run(**kw):
+        out = {}
+        for j in range(scores.shape[1]):
+            out.update(inf.postprocess_batch([dev(scores[i, j]) for i in range(scores.shape[0])], seq_len[j],
+                                             list(ids[j]), **kw))
+        return out
+    flat = lambda o: np.concatenate([o[a].reshape(-1) for a in flat_ids])
+    o = run(medfilt_length=5)
+    assert o[flat_ids[0]].dtype.name == str(g['sed_med_scalar_dtype'])
+    np.testing.assert_array_equal(flat(o), g['sed_med_scalar'])
+    o = run(medfilt_length=g['medfilt_2d'], apply_mask=g['apply_mask_2d'], masks=tags)
+    assert tuple(o[flat_ids[0]].shape) == tuple(g['sed_med_2d_masked_shape0'])
+    np.testing.assert_array_equal(flat(o), g['sed_med_2d_masked'])
+    o = run(stepfilt_length=np.array([0, 2, 4, 10, 6]), apply_mask=True, masks=tags)
+    assert o[flat_ids[0]].dtype.name == str(g['bnd_step_dtype'])
+    np.testing.assert_array_equal(flat(o), g['bnd_step'])
+    o = run(post_processing_fn=lambda x: x.max(-2, keepdims=True))
+    np.testing.assert_array_equal(flat(o), g['tagging'])
+
+
+def test_event_frames_bit_exact_vs_oracle():
+    from oracle import postproc as pp
+    from pb_sed_amd import inference as inf
+    rng = np.random.default_rng(5)
+    classes = [f'c{i}' for i in range(6)]
+    scores = {f'clip{i}': rng.random((int(t), 6)).astype(np.float32) for i, t in enumerate((50, 37, 1, 64))}
+    scores['clip4'] = np.ones((20, 6), np.float32)          # event running to the last frame
+    scores['clip5'] = np.zeros((20, 6), np.float32)         # no events
+    thr = np.array([.5, .3, .9, .1, .7, .5], np.float32)
+    ts = np.round(np.arange(0, 1000) * .02, 6)
+    got = inf.scores_to_event_list(scores, thr, classes, ts, device=DEV)
+    for a, s in scores.items():
+        assert got[a] == pp.scores_to_event_list(s, ts, thr, classes), a
+
+
+def test_inference_driver_end_to_end_vs_oracle():
+    """Config-5 shape in miniature: 2 FBCRNN taggers -> tags -> 2 tag-conditioned BiCRNN detectors."""
+    from oracle import frontend as ofe, models as om, postproc as pp
+    from pb_sed_amd import inference as inf
+    from pb_sed_amd.models import strong_label, weak_label
+    from tests.test_gpu_model import TINY, synth_batch
+    torch.manual_seed(3)
+    kw = dict(num_events=10, number_of_filters=128, hidden_size=64, num_layers=2, net=TINY)
+    pairs_w, pairs_s = [], []
+    for _ in range(2):
+        r = om.FBCRNN.build(**kw).eval()
+        m = weak_label.CRNN.build(**kw)
+        m.load_state_dict(r.state_dict())
+        pairs_w.append((r, m))
+        r = om.BiCRNN.build(tag_conditioning=True, **kw).eval()
+        m = strong_label.CRNN.build(tag_conditioning=True, **kw)
+        m.load_state_dict(r.state_dict())
+        pairs_s.append((r, m))
+    wav, seq, *_ = synth_batch(4, 16000, 10, seed=7)
+    ids = [f'a{i}' for i in range(4)]
+    batch = {'audio_data': wav, 'seq_len': seq.tolist(), 'example_id': ids}
+    stft = ofe.stft(wav)
+    # taggers
+    tag_scores = inf.tagging([m for _, m in pairs_w], [dict(batch)], DEV)
+    with torch.no_grad():
+        ref = pp.postprocess([r.tagging({'stft': stft, 'seq_len': seq.tolist()})[0].numpy() for r, _ in pairs_w],
+                             np.ones(4, int), ids, tagging=True)
+    for a in ids:
+        np.testing.assert_allclose(tag_scores[a], ref[a], atol=1e-4)
+    tags = {a: (ref[a][0] > .5).astype(np.float32) for a in ids}
+    tag_cond = torch.tensor(np.stack([tags[a] for a in ids]))
+    # detectors, per-class median filters, two variants, masked by tags
+    ml = np.array([[1, 3, 5, 7, 9, 1, 3, 5, 7, 9], [3] * 10])
+    sed = inf.sound_event_detection([m for _, m in pairs_s], [dict(batch, tag_condition=tag_cond)], DEV,
+                                    medfilt_length=ml, apply_mask=True, masks=tags)
+    with torch.no_grad():
+        ref = pp.postprocess([r.sound_event_detection({'stft': stft, 'seq_len': seq.tolist(),
+                                                       'tag_condition': tag_cond})[0].numpy() for r, _ in pairs_s],
+                             seq, ids, medfilt_length=ml, apply_mask=True, masks=tags)
+    for a in ids:
+        assert sed[a].shape == ref[a].shape
+        np.testing.assert_allclose(sed[a], ref[a], atol=1e-4)
