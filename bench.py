@@ -137,6 +137,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     loss = float(review['loss'].item())
+    from pb_sed_amd import ops as _ops
+    _ops.check_gru_sync()
 
     if rank == 0:
         # ---- per-call timing -> dominant MFMA launch

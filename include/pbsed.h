@@ -83,15 +83,18 @@ int pbsed_gru_scan_bwd(int nchains, const float* const* w_hh_t, const float* con
                        float* const* dhz, const int* reverse /*host*/, const int* seq_len, int B, int H, int T,
                        void* stream);
 /* Multi-layer UNIDIRECTIONAL stacks (FBCRNN: forward + time-reversed 2-layer GRUs) as a layer wavefront:
- * T + nlayers - 1 launches.  Pointer tables are host arrays indexed [chain*nlayers + layer]. */
+ * T + nlayers - 1 launches, or - when `sync_ws` (device uint32[1 + nchains*nlayers*ceil(B/16)]) is given and the grid
+ * fits the chip - ONE persistent launch whose blocks hand h_t slices over through write-through stores and
+ * arrival counters (word 0 of sync_ws is an error flag: non-zero after a bounded spin timed out).
+ * Pointer tables are host arrays indexed [chain*nlayers + layer]. */
 int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
                         const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
                         float* const* hs, float* const* save, const int* reverse /*host*/, const int* seq_len,
-                        int B, int H, int T, void* stream);
+                        int B, int H, int T, unsigned int* sync_ws, void* stream);
 int pbsed_gru_stack_bwd(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
                         const float* const* hs, const float* const* save, const float* const* dy_top,
                         float* const* dgi, float* const* dgh, float* const* dhz, const int* reverse /*host*/,
-                        const int* seq_len, int B, int H, int T, void* stream);
+                        const int* seq_len, int B, int H, int T, unsigned int* sync_ws, void* stream);
 int pbsed_bct_to_tbc(const float* src, float* dst, int B, int C, int T, void* stream);
 int pbsed_tbc_to_bct(const float* src, float* dst, int B, int C, int T, int shift, void* stream);
 int pbsed_transpose2d(const float* src, float* dst, int R, int C, void* stream);

@@ -279,17 +279,17 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     static const int ncg_knob = getenv("PBSED_WGRAD_NCG") ? atoi(getenv("PBSED_WGRAD_NCG")) : 1;
     const bool wide = a.Cin > 16 && ncg_knob >= 2;
     if (KH == 3 && KW == 3) {
-        if (a.Cin == 1) return a.Cout >= 64 ? launch_wgrad<3, 3, 4, 1, 1, true>(a, s) : launch_wgrad<3, 3, 1, 1, 1, true, 4>(a, s);
+        if (a.Cin == 1) return a.Cout >= 64 ? launch_wgrad<3, 3, 4, 1, 1, true>(a, s) : launch_wgrad<3, 3, 1, 1, 1, true>(a, s);
         if (a.Cout >= 64) return wide ? launch_wgrad<3, 3, 4, 1, 2>(a, s) : launch_wgrad<3, 3, 4, 1, 1>(a, s);
-        if (a.Cout >= 32) return wide ? launch_wgrad<3, 3, 2, 1, 2, false, 2>(a, s) : launch_wgrad<3, 3, 2, 1, 1, false, 2>(a, s);
-        return launch_wgrad<3, 3, 1, 1, 1, false, 4>(a, s);
+        if (a.Cout >= 32) return wide ? launch_wgrad<3, 3, 2, 1, 2>(a, s) : launch_wgrad<3, 3, 2, 1, 1>(a, s);
+        return launch_wgrad<3, 3, 1, 1, 1>(a, s);
     }
-    const bool wide1 = a.Cin > 16;
-    (void)wide1;
     if (KH == 1 && KW == 3) {
         return a.Cout >= 128 ? launch_wgrad<1, 3, 4, 2, 2>(a, s) : launch_wgrad<1, 3, 1, 1, 2>(a, s);
     }
     if (KH == 1 && KW == 1) {
+        static const int big1 = getenv("PBSED_WGRAD_1x1_NCG") ? atoi(getenv("PBSED_WGRAD_1x1_NCG")) : 4;
+        if (a.Cout >= 128 && a.Cin >= 128 && big1 >= 8) return launch_wgrad<1, 1, 4, 2, 8>(a, s);
         return a.Cout >= 128 ? launch_wgrad<1, 1, 4, 2, 4>(a, s) : launch_wgrad<1, 1, 1, 1, 4>(a, s);
     }
     set_error("conv_wgrad: unsupported kernel %dx%d", KH, KW);

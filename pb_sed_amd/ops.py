@@ -50,8 +50,8 @@ class PackedConv:
                                         C.byref(inp), C.byref(outp))
         wp = torch.empty(self.kh * self.kw * inp.value * outp.value, device=self.weight.device,
                          dtype=torch.float32)
-        call('pbsed_pack_conv_weights', ptr(self.weight.detach().contiguous()), ptr(wp), self.cout,
-             self.cin, self.kh, self.kw, dgrad, stream())
+        w = self.weight.detach().contiguous()
+        call('pbsed_pack_conv_weights', ptr(w), ptr(wp), self.cout, self.cin, self.kh, self.kw, dgrad, stream())
         return wp
 
     def fwd(self):
@@ -190,6 +190,25 @@ def gru_scan_bwd(w_hh_t, hs, save, dy, reverse, seq_len):
     return dgi, dgh
 
 
+_GRU_SYNC = []          # every sync workspace handed to a persistent scan (word 0 = error flag)
+
+
+def _gru_sync_ws(device, n_rings):
+    ws = torch.zeros(1 + n_rings, dtype=torch.int32, device=device)
+    _GRU_SYNC.append(ws)
+    if len(_GRU_SYNC) > 64:
+        check_gru_sync()
+    return ws
+
+
+def check_gru_sync():
+    """Raise if any persistent GRU scan since the last check hit its bounded-spin timeout (host sync)."""
+    flags = [int(w[0].item()) for w in _GRU_SYNC]
+    del _GRU_SYNC[:]
+    if any(flags):
+        raise RuntimeError('persistent GRU scan: inter-workgroup hand-off timed out (PBSED_GRU_PERSIST=0 disables it)')
+
+
 def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=True):
     """Layer-wavefront scan of unidirectional stacks.  gi0: per chain [T,B,3H]; weight lists are indexed
     [chain*nlayers + layer] (w_ih/b_ih entries of layer 0 may be None).  Returns (hs, save) lists."""
@@ -200,9 +219,10 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
     n = nch * nlayers
     hs = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
     sv = [torch.empty((t, b, 4, h), device=dev, dtype=torch.float32) for _ in range(n)] if save else None
+    ws = _gru_sync_ws(dev, nch * nlayers * ((b + 15) // 16))
     call('pbsed_gru_stack_fwd', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih), _lib.ptr_array(b_ih),
          _lib.ptr_array(w_hh), _lib.ptr_array(b_hh), _lib.ptr_array(hs), _lib.ptr_array(sv) if save else None,
-         _lib.int_array(reverse), ptr(seq_len), b, h, t, stream())
+         _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(ws), stream())
     return hs, sv
 
 
@@ -214,9 +234,10 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
     dgi = [torch.empty((t, b, 3 * h), device=dev, dtype=torch.float32) for _ in range(n)]
     dgh = [torch.empty((t, b, 3 * h), device=dev, dtype=torch.float32) for _ in range(n)]
     dhz = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
+    ws = _gru_sync_ws(dev, nch * nlayers * ((b + 15) // 16))
     call('pbsed_gru_stack_bwd', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t), _lib.ptr_array(hs),
          _lib.ptr_array(save), _lib.ptr_array(dy_top), _lib.ptr_array(dgi), _lib.ptr_array(dgh), _lib.ptr_array(dhz),
-         _lib.int_array(reverse), ptr(seq_len), b, h, t, stream())
+         _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(ws), stream())
     return dgi, dgh
 
 
@@ -242,8 +263,9 @@ def fbcrnn_loss(logit_fwd, logit_bwd, weak_targets, boundary_targets, seq_len, *
     d_f = torch.empty_like(logit_fwd) if want_grad else None
     d_b = torch.empty_like(logit_fwd) if (want_grad and logit_bwd is not None) else None
     loss = torch.empty((), device=dev, dtype=torch.float32)
-    call('pbsed_fbcrnn_loss', ptr(logit_fwd), ptr(logit_bwd), ptr(weak_targets.contiguous()),
-         ptr(None if boundary_targets is None else boundary_targets.contiguous()), ptr(class_weights),
+    weak_c = weak_targets.contiguous()                  # named so two temporaries can never share storage
+    bnd_c = None if boundary_targets is None else boundary_targets.contiguous()
+    call('pbsed_fbcrnn_loss', ptr(logit_fwd), ptr(logit_bwd), ptr(weak_c), ptr(bnd_c), ptr(class_weights),
          ptr(seq_len), ptr(y_f), ptr(y_b), ptr(d_f), ptr(d_b), ptr(loss), b, k, t, float(minimum_score),
          float(strong_weight), int(slat), float(label_smoothing), int(inputs_are_scores), stream())
     return loss, y_f, y_b, d_f, d_b
@@ -330,7 +352,8 @@ def medfilt(scores, lengths):
     x = scores.contiguous()
     r, t, n = _rows(x, lengths)
     out = torch.empty_like(x)
-    call('pbsed_medfilt', ptr(x), ptr(out), ptr(n.to(torch.int32).to(x.device)), r, t, stream())
+    n_dev = n.to(torch.int32).to(x.device)          # keep alive until the launch is enqueued
+    call('pbsed_medfilt', ptr(x), ptr(out), ptr(n_dev), r, t, stream())
     return out
 
 
@@ -339,7 +362,8 @@ def boundariesfilt(scores, lengths, want_f64=False):
     r, t, n = _rows(x, lengths)
     out = torch.empty_like(x)
     out64 = torch.empty(x.shape, device=x.device, dtype=torch.float64) if want_f64 else None
-    call('pbsed_boundariesfilt', ptr(x), ptr(out), ptr(out64), ptr(n.to(torch.int32).to(x.device)), r, t, stream())
+    n_dev = n.to(torch.int32).to(x.device)
+    call('pbsed_boundariesfilt', ptr(x), ptr(out), ptr(out64), ptr(n_dev), r, t, stream())
     return out64 if want_f64 else out
 
 
@@ -351,6 +375,6 @@ def event_frames(scores, thresholds, lengths, max_events=None):
     max_events = max_events or (t // 2 + 1)
     ev = torch.zeros((r, max_events, 2), dtype=torch.int32, device=x.device)
     cnt = torch.zeros((r,), dtype=torch.int32, device=x.device)
-    call('pbsed_event_frames', ptr(x), ptr(th.to(torch.float32).to(x.device)), ptr(ln.to(torch.int32).to(x.device)),
-         ptr(ev), ptr(cnt), r, t, max_events, stream())
+    th_dev, ln_dev = th.to(torch.float32).to(x.device), ln.to(torch.int32).to(x.device)   # distinct live buffers
+    call('pbsed_event_frames', ptr(x), ptr(th_dev), ptr(ln_dev), ptr(ev), ptr(cnt), r, t, max_events, stream())
     return ev, cnt

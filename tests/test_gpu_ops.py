@@ -318,3 +318,4 @@ def test_gru_stack_wavefront_vs_torch(b, h, t, ragged):
             close(dgh_b.sum((0, 2)), P(g, 'bias_hh', l).grad, atol=3e-4, rtol=1e-3, name='db_hh ' + tag)
         dgi0 = ops.tbc_to_bct(dgi[c * nl]).cpu()
         close(torch.einsum('bot,oc->bct', dgi0, g.rnn.weight_ih_l0.detach()), xs[c].grad, atol=3e-4, rtol=1e-3, name=f'dx chain{c}')
+    ops.check_gru_sync()
