@@ -16,6 +16,23 @@ from . import ops
 from .ops import PackedConv
 
 
+# ------------------------------------------------------------------------------------- seq_len cache
+_SEQ_CACHE = {}
+
+
+def seq_to_device(seq_host, device):
+    """int32 device copy of a host seq_len array; cached by value (a pageable H2D copy stalls the host until
+    the stream drains, and training loops present the same few length vectors over and over)."""
+    key = (str(device), tuple(int(v) for v in np.asarray(seq_host).reshape(-1)))
+    t = _SEQ_CACHE.get(key)
+    if t is None:
+        if len(_SEQ_CACHE) > 4096:
+            _SEQ_CACHE.clear()
+        t = torch.as_tensor(np.asarray(seq_host), dtype=torch.int32).to(device)
+        _SEQ_CACHE[key] = t
+    return t
+
+
 # ------------------------------------------------------------------------------------- parameters
 def flatten_parameters(module):
     """Re-home every parameter (and its .grad) of ``module`` in one flat fp32 buffer each.
@@ -182,7 +199,7 @@ def _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training):
     nl = wrappers[0].num_layers
     gi0, pcs0 = [], []
     for ch in chains:
-        pc = PackedConv(ch.p('weight_ih', 0).unsqueeze(-1))
+        pc = PackedConv(ch.p('weight_ih', 0).unsqueeze(-1), owner=ch.p('weight_ih', 0))
         y, _, _ = ops.conv_fwd(h, pc, pc.fwd(), bias=ch.p('bias_ih', 0).detach(), seq_len=None)
         gi0.append(ops.bct_to_tbc(y))
         pcs0.append(pc)
@@ -240,7 +257,7 @@ def rnn_forward(wrappers, h, seq_dev, seq_host, training):
         gi, pcs = [], []
         for ch in chains:
             w_ih = ch.p('weight_ih', l)
-            pc = PackedConv(w_ih.unsqueeze(-1))
+            pc = PackedConv(w_ih.unsqueeze(-1), owner=w_ih)
             y, _, _ = ops.conv_fwd(x_w[ch.widx], pc, pc.fwd(), bias=ch.p('bias_ih', l).detach(),
                                    seq_len=None)
             gi.append(ops.bct_to_tbc(y))

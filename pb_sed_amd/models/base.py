@@ -6,7 +6,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from ..engine import flatten_parameters
+from ..engine import flatten_parameters, seq_to_device
 
 
 class SoundEventModel(nn.Module, abc.ABC):
@@ -50,5 +50,5 @@ class SoundEventModel(nn.Module, abc.ABC):
     # ---- helpers shared by both CRNNs
     def _seq(self, inputs, device):
         seq_host = np.array(inputs['seq_len'])
-        seq_dev = torch.as_tensor(seq_host, dtype=torch.int32).to(device)
+        seq_dev = seq_to_device(seq_host, device)
         return seq_host, seq_dev

@@ -97,7 +97,7 @@ class CRNN(SoundEventModel):
         assert targets is not None
         strong_targets = targets[1].to(torch.float32)
         assert strong_targets.shape == y.shape, (strong_targets.shape, y.shape)
-        seq_dev = torch.as_tensor(np.asarray(seq_len_y), dtype=torch.int32).to(y.device)
+        seq_dev = engine.seq_to_device(seq_len_y, y.device)
         loss = _LossFunction.apply(y, strong_targets, seq_dev)
         mask = (strong_targets > .99) | (strong_targets < .01)
         return dict(

@@ -146,7 +146,7 @@ class CRNN(SoundEventModel):
         y_fwd, y_bwd, seq_len, x, _, targets = outputs
         assert targets is not None
         weak_targets = targets[0].to(torch.float32)
-        seq_dev = torch.as_tensor(np.asarray(seq_len), dtype=torch.int32).to(y_fwd.device)
+        seq_dev = engine.seq_to_device(seq_len, y_fwd.device)
         bnd = None
         if self.strong_fwd_bwd_loss_weight > 0. and not self.slat:
             assert len(targets) == 2, len(targets)
@@ -156,27 +156,33 @@ class CRNN(SoundEventModel):
                    class_weights=None if self.class_weights is None else self.class_weights.to(y_fwd.device))
         loss = _LossFunction.apply(y_fwd, y_bwd, weak_targets, bnd, seq_dev, cfg)
 
-        # summary side (host): same buffers / scalars as the reference (crnn.py:122,137,155-177)
-        w_mask = (weak_targets < .01) | (weak_targets > .99)
-        wm = w_mask.cpu().numpy()
-        w = (weak_targets * w_mask)
-        boundary_label_rate = 0.
-        if self.strong_fwd_bwd_loss_weight > 0.:
-            beta = w[..., None].expand(y_fwd.shape) if self.slat else bnd
-            b_mask = (beta > .99) | (beta < .01)
-            b_mask = b_mask * (b_mask.float().mean(-1, keepdim=True) > .999) * (w > .99)[..., None]
-            boundary_label_rate = b_mask.cpu().numpy().mean()
-        labeled = (wm == 1).all(-1)
-        idx = torch.as_tensor(np.asarray(seq_len) - 1, device=y_fwd.device, dtype=torch.long)
-        y_weak = y_fwd.detach()[torch.arange(y_fwd.shape[0], device=y_fwd.device), :, idx]
-        if y_bwd is not None:
-            y_weak = y_weak / 2 + y_bwd.detach()[..., 0] / 2
+        # summary side (host): same buffers / scalars as the reference (crnn.py:122,137,155-177), gathered with
+        # ONE device->host transfer instead of the reference's five separate .cpu() syncs
+        with torch.no_grad():
+            w_mask = (weak_targets < .01) | (weak_targets > .99)
+            w = weak_targets * w_mask
+            b, k = w.shape
+            idx = engine.seq_to_device(np.asarray(seq_len) - 1, y_fwd.device).long()
+            y_weak = y_fwd.detach()[torch.arange(b, device=y_fwd.device), :, idx]
+            if y_bwd is not None:
+                y_weak = y_weak / 2 + y_bwd.detach()[..., 0] / 2
+            blr = torch.zeros((), device=w.device)
+            if self.strong_fwd_bwd_loss_weight > 0.:
+                beta = w[..., None].expand(y_fwd.shape) if self.slat else bnd
+                b_mask = (beta > .99) | (beta < .01)
+                b_mask = b_mask * (b_mask.float().mean(-1, keepdim=True) > .999) * (w > .99)[..., None]
+                blr = b_mask.float().mean()
+            packed = torch.cat([w_mask.float().reshape(-1), w.reshape(-1), y_weak.reshape(-1), blr.reshape(1)]).cpu().numpy()
+        wm = packed[:b * k].reshape(b, k) > .5
+        w_host = packed[b * k:2 * b * k].reshape(b, k)
+        y_weak_host = packed[2 * b * k:3 * b * k].reshape(b, k)
+        labeled = wm.all(-1)
         return dict(
             loss=loss,
             scalars=dict(seq_len=np.mean(inputs['seq_len']), weak_label_rate=wm.mean(),
-                         boundary_label_rate=boundary_label_rate),
+                         boundary_label_rate=float(packed[-1]) if self.strong_fwd_bwd_loss_weight > 0. else 0.),
             images=dict(features=x[:3]),
-            buffers=dict(y_weak=y_weak.cpu().numpy()[labeled], targets_weak=w.cpu().numpy()[labeled]),
+            buffers=dict(y_weak=y_weak_host[labeled], targets_weak=w_host[labeled]),
         )
 
     # ------------------------------------------------------------------ inference heads

@@ -31,10 +31,21 @@ def _conv_flops(b, cin, pc, f, t):
     return 2 * b * pc.cout * cin * pc.kh * pc.kw * f * t
 
 
-class PackedConv:
-    """Weights of one conv layer packed for the forward and data-gradient kernels."""
+PACK_EPOCH = [0]      # bump (invalidate_packed) whenever parameters are changed behind torch's back (fused Adam)
 
-    def __init__(self, weight):
+
+def invalidate_packed():
+    PACK_EPOCH[0] += 1
+
+
+class PackedConv:
+    """Weights of one conv layer packed for the forward and data-gradient kernels (cached per parameter
+    version, so inference loops pack each layer once)."""
+
+    def __init__(self, weight, owner=None):
+        """``owner``: the Parameter a (reshaped) ``weight`` view belongs to; the packed copies are cached ON that
+        object (so they die with it - device addresses are recycled) keyed by its version and PACK_EPOCH."""
+        self.owner = weight if owner is None else owner
         w = weight.detach()
         if w.dim() == 3:
             cout, cin, kw = w.shape
@@ -45,6 +56,16 @@ class PackedConv:
         self.weight = weight
 
     def _pack(self, dgrad):
+        key = (self.owner._version, PACK_EPOCH[0], self.owner.data_ptr(), dgrad)
+        cache = getattr(self.owner, '_pbsed_pack', None)
+        if cache is None or cache.get('key') != key[:3]:
+            cache = {'key': key[:3]}
+            try:
+                self.owner._pbsed_pack = cache
+            except AttributeError:
+                pass
+        if dgrad in cache:
+            return cache[dgrad]
         inp, outp = C.c_int(), C.c_int()
         _lib.lib().pbsed_conv_pack_dims(self.kh, self.kw, self.cin, self.cout, dgrad,
                                         C.byref(inp), C.byref(outp))
@@ -52,6 +73,7 @@ class PackedConv:
                          dtype=torch.float32)
         w = self.weight.detach().contiguous()
         call('pbsed_pack_conv_weights', ptr(w), ptr(wp), self.cout, self.cin, self.kh, self.kw, dgrad, stream())
+        cache[dgrad] = wp
         return wp
 
     def fwd(self):

@@ -108,5 +108,6 @@ class Trainer:
         ops.adam_step(self.flat_param, self.flat_grad, self.m, self.v, lr=self.lr, beta1=self.betas[0],
                       beta2=self.betas[1], eps=self.eps, step=self.iteration, grad_scale=scale,
                       max_norm=self.clip, sumsq=self.sumsq, norm_out=self.grad_norm)
+        ops.invalidate_packed()          # parameters changed in place behind torch's version counters
         review['scalars']['grad_norm'] = self.grad_norm
         return review
