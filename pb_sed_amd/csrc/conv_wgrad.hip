@@ -257,19 +257,27 @@ static int launch_wgrad(const ConvWgradArgs& a, hipStream_t s) {
     const int nChunks = a.B * nFt * nTt;
     const int gy = (a.Cin + C::CIN_T - 1) / C::CIN_T;
     const int gz = (a.Cout + C::COUT_T - 1) / C::COUT_T;
-    int split = 1024 / (gy * gz);
-    if (split >= 8) split &= ~7;       // multiple of 8: blocks sharing a spatial chunk share an XCD's L2
-    if (split < 1) split = 1;
-    if (split > nChunks) split = nChunks;
-    dim3 grid(split, gy, gz);
     const size_t lds = C::LDS_FLOATS * sizeof(float);
     auto kern = conv_wgrad_kernel<KH, KW, WAVES, MT, NCG, TAPN, KWAVES>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    // K-split so that the grid is (close to) an integer number of full residency rounds: blocks per CU from
+    // the occupancy query, n_cu * occ resident slots, one or two rounds depending on how much K there is.
+    static int slots = 0;
+    if (slots == 0) {
+        if (lds > 48 * 1024)
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int occ = 0, dev = 0, n_cu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, C::NT, lds) != hipSuccess || occ < 1) occ = 2;
+        slots = n_cu * occ;
     }
+    int split = slots / (gy * gz);
+    if (split >= 8) split &= ~7;       // multiple of 8: blocks sharing a spatial chunk share an XCD's L2
+    if (split < 1) split = 1;
+    if (nChunks >= 16 * split * 4) split *= 2;      // plenty of K: two rounds keep tail effects small
+    if (split > 1024 / (gy * gz)) split = 1024 / (gy * gz) > 0 ? 1024 / (gy * gz) : 1;   // atomics-per-address cap
+    if (split > nChunks) split = nChunks;
+    dim3 grid(split, gy, gz);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * KWAVES * 64), lds, s, a);
     return check_launch("conv_wgrad");
 }

@@ -40,6 +40,7 @@ struct GruStackArgs {
     const int* seq_len;
     int B, T, nchains, nlayers, launch;
     int one_xcd;          // experiment: grid.x is 8x larger and only blocks with blockIdx.x % 8 == 0 work
+    int debug;            // experiment (PBSED_GRU_DEBUG bitmask): 1 skip W_hh matmul, 2 skip W_ih matmul, 4 skip save stores
 };
 
 // acc[g] += W[g*H + j0 + lr][k..] * v[b0 + lr][k..] over this wave's quarter of K = KB*64.
@@ -65,8 +66,34 @@ __device__ __forceinline__ void mm_rows(f32x4 (&acc)[NG], const float* __restric
         }
 }
 
+// split form: issue every operand load of a step first, run the MFMAs afterwards (overlaps the L2/MALL
+// latencies of the recurrent and the input-projection operands)
+template <int KB, int NG>
+__device__ __forceinline__ void mm_load(float4 (&vv)[KB], float4 (&wv)[KB][NG], const float* __restrict__ w, size_t gstride,
+                                        const float* __restrict__ v, bool vvalid, int wave, int lq) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+        const int k = (wave * KB + i) * 16 + lq * 4;
+        vv[i] = vvalid ? *reinterpret_cast<const float4*>(v + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) wv[i][g] = *reinterpret_cast<const float4*>(w + g * gstride + k);
+    }
+}
+template <int KB, int NG>
+__device__ __forceinline__ void mm_fma(f32x4 (&acc)[NG], const float4 (&vv)[KB], const float4 (&wv)[KB][NG]) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            acc[g] = mfma16(wv[i][g].x, vv[i].x, acc[g]);
+            acc[g] = mfma16(wv[i][g].y, vv[i].y, acc[g]);
+            acc[g] = mfma16(wv[i][g].z, vv[i].z, acc[g]);
+            acc[g] = mfma16(wv[i][g].w, vv[i].w, acc[g]);
+        }
+}
+
 // ------------------------------------------------------------------------------------------ forward
-// grid (H/16, ceil(B/16), nchains*nlayers), 256 threads; H = KB*64.
+// grid (H/16, ceil(B/16), nchains*nlayers), NW*64 threads; H = KB*NW*16.
 template <int KB, int NW>
 __global__ __launch_bounds__(NW * 64) void gru_stack_fwd_kernel(GruStackArgs a) {
     constexpr int H = KB * NW * 16;
@@ -102,10 +129,11 @@ __global__ __launch_bounds__(NW * 64) void gru_stack_fwd_kernel(GruStackArgs a) 
     f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 acci[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const bool rowv = (b0 + lr) < B;
-    if (has_prev)
+    // (issuing both operand sets before any MFMA was measured 5 % slower than this sequential form)
+    if (has_prev && !(a.debug & 1))
         mm_rows<KB, 3>(acc, L.w_hh + (size_t)(j0 + lr) * H, H, H * H, L.hs + ((size_t)tp * B + b0 + lr) * H, H, rowv,
                        wave, lq);
-    if (layer > 0) {
+    if (layer > 0 && !(a.debug & 2)) {
         const float* x = a.lc[chain][layer - 1].hs + ((size_t)t * B + b0 + lr) * H;
         mm_rows<KB, 3>(acci, L.w_ih + (size_t)(j0 + lr) * H, H, H * H, x, H, rowv, wave, lq);
     }
@@ -134,7 +162,7 @@ __global__ __launch_bounds__(NW * 64) void gru_stack_fwd_kernel(GruStackArgs a) 
     const float h = (1.f - z) * n + z * hp;
     const size_t tb = (size_t)t * B + b;
     L.hs[tb * H + j] = (t < sl) ? h : 0.f;
-    if (L.save) {
+    if (L.save && !(a.debug & 4)) {
         float* sv = L.save + tb * 4 * H;
         sv[j] = r; sv[H + j] = z; sv[2 * H + j] = n; sv[3 * H + j] = ghn;
     }
@@ -534,6 +562,7 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
         return check_launch("gru_stack_fwd(persistent)");
     }
     if (one_xcd_knob()) { a.one_xcd = 1; grid.x *= 8; }
+    a.debug = getenv("PBSED_GRU_DEBUG") ? atoi(getenv("PBSED_GRU_DEBUG")) : 0;
     DISPATCH_KB(H, false, a, grid, (hipStream_t)stream);
     return check_launch("gru_stack_fwd");
 }

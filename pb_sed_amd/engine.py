@@ -46,7 +46,12 @@ def flatten_parameters(module):
                                 for p in params):
         for p in params:
             if p.grad is None or p.grad.data_ptr() != flat[1].data_ptr() + 4 * p._pbsed_off:
-                p.grad = flat[1][p._pbsed_off:p._pbsed_off + p.numel()].view(p.shape)
+                view = flat[1][p._pbsed_off:p._pbsed_off + p.numel()].view(p.shape)
+                if p.grad is None:
+                    view.zero_()          # optimizer.zero_grad(set_to_none=True): start from a clean slice
+                else:
+                    view.copy_(p.grad)    # keep gradients accumulated outside the flat buffer
+                p.grad = view
         return flat
     device = params[0].device
     n = sum(p.numel() for p in params)
