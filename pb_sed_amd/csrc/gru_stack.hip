@@ -97,7 +97,7 @@ __device__ __forceinline__ void mm_fma(f32x4 (&acc)[NG], const float4 (&vv)[KB],
 template <int KB, int NW>
 __global__ __launch_bounds__(NW * 64) void gru_stack_fwd_kernel(GruStackArgs a) {
     constexpr int H = KB * NW * 16;
-    __shared__ float red[NW][4][64][4];
+    __shared__ float red[NW][3][64][4];
     const int chain = blockIdx.z % a.nchains, layer = blockIdx.z / a.nchains;
     const int step = a.launch - layer;
     if (step < 0 || step >= a.T) return;
@@ -127,33 +127,39 @@ __global__ __launch_bounds__(NW * 64) void gru_stack_fwd_kernel(GruStackArgs a) 
     const int sl = bv ? a.seq_len[b] : 0;
 
     f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    f32x4 acci[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const bool rowv = (b0 + lr) < B;
-    // (issuing both operand sets before any MFMA was measured 5 % slower than this sequential form)
-    if (has_prev && !(a.debug & 1))
-        mm_rows<KB, 3>(acc, L.w_hh + (size_t)(j0 + lr) * H, H, H * H, L.hs + ((size_t)tp * B + b0 + lr) * H, H, rowv,
-                       wave, lq);
-    if (layer > 0 && !(a.debug & 2)) {
-        const float* x = a.lc[chain][layer - 1].hs + ((size_t)t * B + b0 + lr) * H;
-        mm_rows<KB, 3>(acci, L.w_ih + (size_t)(j0 + lr) * H, H, H * H, x, H, rowv, wave, lq);
+    constexpr int HW = NW / 2;
+    if (layer == 0) {
+        // all waves split K of the recurrent matmul
+        if (has_prev && !(a.debug & 1))
+            mm_rows<KB, 3>(acc, L.w_hh + (size_t)(j0 + lr) * H, H, H * H, L.hs + ((size_t)tp * B + b0 + lr) * H, H, rowv,
+                           wave, lq);
+    } else {
+        // upper layers: waves [0, HW) do W_hh h_{t-1}, waves [HW, NW) do W_ih x_t - the two operand streams are
+        // fetched concurrently instead of back to back (the step is bound by their L2/MALL latency)
+        const bool is_ih = wave >= HW;
+        const int wq = is_ih ? wave - HW : wave;
+        const float* W = (is_ih ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * H;
+        const float* V = is_ih ? a.lc[chain][layer - 1].hs + ((size_t)t * B + b0 + lr) * H
+                               : L.hs + ((size_t)tp * B + b0 + lr) * H;
+        const bool act = is_ih ? !(a.debug & 2) : (has_prev && !(a.debug & 1));
+        if (act) mm_rows<2 * KB, 3>(acc, W, H, H * H, V, H, rowv, wq, lq);
     }
-    // r and z only ever appear as sums; n keeps its input / hidden parts apart
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        red[wave][0][lane][r] = acc[0][r] + acci[0][r];
-        red[wave][1][lane][r] = acc[1][r] + acci[1][r];
+        red[wave][0][lane][r] = acc[0][r];
+        red[wave][1][lane][r] = acc[1][r];
         red[wave][2][lane][r] = acc[2][r];
-        red[wave][3][lane][r] = acci[2][r];
     }
     __syncthreads();
     if (!bv) return;
     const int src = (u >> 2) * 16 + bb, reg = u & 3;
-    float s[4];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};      // r, z, W_hn h, W_in x
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        s[g] = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) s[g] += red[w][g][src][reg];
+    for (int w = 0; w < NW; ++w) {
+        s[0] += red[w][0][src][reg];
+        s[1] += red[w][1][src][reg];
+        if (layer == 0 || w < HW) s[2] += red[w][2][src][reg]; else s[3] += red[w][2][src][reg];
     }
     const float ghn = s[2] + bh_n;
     const float r = 1.f / (1.f + expf(-(gi_r + s[0] + bh_r)));
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(NW * 64) void gru_stack_fwd_kernel(GruStackArgs a) 
 template <int KB, int NW>
 __global__ __launch_bounds__(NW * 64) void gru_stack_bwd_kernel(GruStackArgs a) {
     constexpr int H = KB * NW * 16, G = 3 * H, KB3 = 3 * KB;
-    __shared__ float red[NW][2][64][4];
+    __shared__ float red[NW][64][4];
     const int chain = blockIdx.z % a.nchains, layer = blockIdx.z / a.nchains;
     const int top = a.nlayers - 1;
     const int bstep = a.launch - (top - layer);
@@ -203,22 +209,32 @@ __global__ __launch_bounds__(NW * 64) void gru_stack_bwd_kernel(GruStackArgs a) 
         if (layer == top) dyv = L.dy[tb * H + j];
         if (has_next) dhzn = L.dhz[((size_t)tn * B + b) * H + j];
     }
-    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, accy[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
     const bool rowv = (b0 + lr) < B;
-    if (has_next)
-        mm_rows<KB3, 1>(acc, L.w_hh + (size_t)(j0 + lr) * G, G, 0, L.dgh + ((size_t)tn * B + b0 + lr) * G, G, rowv,
-                        wave, lq);
-    if (layer < top)
-        mm_rows<KB3, 1>(accy, L.w_ih + (size_t)(j0 + lr) * G, G, 0,
-                        a.lc[chain][layer + 1].dgi + ((size_t)t * B + b0 + lr) * G, G, rowv, wave, lq);
+    constexpr int HW = NW / 2;
+    if (layer == top) {
+        if (has_next)
+            mm_rows<KB3, 1>(acc, L.w_hh + (size_t)(j0 + lr) * G, G, 0, L.dgh + ((size_t)tn * B + b0 + lr) * G, G, rowv,
+                            wave, lq);
+    } else {
+        // waves [0, HW): carry = dgh_next W_hh; waves [HW, NW): dy = dgi_upper,t W_ih_upper (concurrent streams)
+        const bool is_dy = wave >= HW;
+        const int wq = is_dy ? wave - HW : wave;
+        const float* W = (is_dy ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * G;
+        const float* V = is_dy ? a.lc[chain][layer + 1].dgi + ((size_t)t * B + b0 + lr) * G
+                               : L.dgh + ((size_t)tn * B + b0 + lr) * G;
+        if (is_dy || has_next) mm_rows<2 * KB3, 1>(acc, W, G, 0, V, G, rowv, wq, lq);
+    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { red[wave][0][lane][q] = acc[0][q]; red[wave][1][lane][q] = accy[0][q]; }
+    for (int q = 0; q < 4; ++q) red[wave][lane][q] = acc[0][q];
     __syncthreads();
     if (!bv) return;
     const int src = (u >> 2) * 16 + bb, reg = u & 3;
     float carry = 0.f, dylow = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) { carry += red[w][0][src][reg]; dylow += red[w][1][src][reg]; }
+    for (int w = 0; w < NW; ++w) {
+        if (layer == top || w < HW) carry += red[w][src][reg]; else dylow += red[w][src][reg];
+    }
     float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, dhzv = 0.f;
     if (t < sl) {
         const float dh = (layer == top ? dyv : dylow) + (has_next ? carry + dhzn : 0.f);
