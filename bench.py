@@ -91,6 +91,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='clips per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--conv-precision', default='f32', choices=['f32', 'bf16', 'bf16x3'],
+                    help="operand format of the conv MFMAs; only 'f32' is the BASELINE configs[1] number")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -108,6 +110,7 @@ def main():
     from pb_sed_amd.trainer import Trainer
     torch.manual_seed(0)
     model = weak_label.CRNN.build().to(device)
+    model.conv_precision = args.conv_precision
     n_params = sum(p.numel() for p in model.parameters())
     trainer = Trainer(model, lr=5e-4, gradient_clipping=1e10)
     batch = synth_batch(args.batch, device, seed=rank)       # weak scaling: 32 clips per GPU
@@ -162,7 +165,9 @@ def main():
             'metric': '10s@16kHz clips/sec (train step) FBCRNN batch32',
             'value': round(clips / (dt / args.steps), 2), 'unit': 'clips/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': {'f32': 'f32', 'bf16': 'bf16 (conv MFMAs; fp32 accumulate/BN/GRU)',
+                      'bf16x3': 'bf16x3 (fp32 operands split into 3 bf16 terms, 6 MFMAs per product, fp32 accumulate)'}[args.conv_precision],
             'data': 'synthetic (randn waveforms, random-init weights)',
             'config': {'workload': 'FBCRNN weak_label_crnn.training batch 32/GPU fp32, 10 s 16 kHz clips '
                                    '(BASELINE.json configs[1]); full train step incl. fused log-mel front-end, '

@@ -60,6 +60,21 @@ int pbsed_conv_bwd_weight(const float* x, const float* scale, const float* shift
                           const int* seq_len, const float* g, const unsigned char* unpool_idx, float* dw,
                           float* db, int B, int Cin, int Cout, int F, int T, int KH, int KW, void* stream);
 
+/* bf16-MFMA variants (same contracts; activations stay fp32 in HBM, operands are converted while staging, fp32
+ * accumulate).  nsplit = 1: plain bf16 compute (BASELINE.json config 3).  nsplit = 3: exact 3-way bf16 split of both
+ * operands, 6 partial products -> fp32-class accuracy.  w_packed_bf16: uint16 [nsplit][KH*KW][out_padded][in_padded]. */
+void pbsed_conv_pack_dims_bf16(int Cin, int Cout, int dgrad, int* in_padded /*host*/, int* out_padded /*host*/);
+int pbsed_pack_conv_weights_bf16(const float* w, unsigned short* w_packed_bf16, int Cout, int Cin, int KH, int KW,
+                                 int dgrad, int nsplit, void* stream);
+int pbsed_conv_fwd_bf16(const float* x, const unsigned short* w_packed_bf16, const float* bias, const float* scale,
+                        const float* shift, int relu, const int* seq_len, float* y, unsigned char* pool_idx,
+                        double* stats, int stats_per_cf, int B, int Cin, int Cout, int F, int T, int KH, int KW, int pool,
+                        int nsplit, void* stream);
+int pbsed_conv_bwd_data_bf16(const float* g, const unsigned short* wd_packed_bf16, const unsigned char* unpool_idx,
+                             const int* seq_len, float* dz, const float* bx, const float* bmean, const float* binvstd,
+                             const float* bscale, const float* bshift, int relu, double* stats, int B, int Cin, int Cout,
+                             int F, int T, int KH, int KW, int nsplit, void* stream);
+
 /* ---- Normalization ('batch', eps 1e-3; pb_sed/experiments/weak_label_crnn/training.py:223-225) */
 int pbsed_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
                       float momentum, float* running_mean, float* running_power, float* mean, float* invstd,

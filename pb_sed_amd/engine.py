@@ -103,8 +103,13 @@ def _count(seq_host, t, rows):
     return float(np.minimum(np.asarray(seq_host), t).sum() * rows)
 
 
-def stack_forward(layers, x, seq_dev, seq_host, training):
-    """Run a conv stack.  Returns (y, ctx) - ctx is what stack_backward needs."""
+def _prec(precision, cin):
+XX
+
+
+def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32'):
+    """Run a conv stack.  Returns (y, ctx) - ctx is what stack_backward needs.  ``precision``: 'f32' |
+    'bf16' | 'bf16x3' operand format of the forward / data-gradient MFMAs (weight gradients are always fp32)."""
     ctx = []
     st_in = None
     for j, L in enumerate(layers):
@@ -118,11 +123,12 @@ def stack_forward(layers, x, seq_dev, seq_host, training):
         if c.ndim == 1 and x.dim() == 4:
             x = x.flatten(1, 2)                       # 'b c f t -> b (c f) t' is a view in this layout
         pc = PackedConv(c.conv.weight)
+        pr = _prec(precision, pc.cin)
         y, idx, stats = ops.conv_fwd(
-            x, pc, pc.fwd(), bias=c.conv.bias.detach(),
+            x, pc, pc.fwd(pr), bias=c.conv.bias.detach(),
             scale=None if st_in is None else st_in.scale, shift=None if st_in is None else st_in.shift,
-            relu=True, seq_len=seq_dev, pool=c.pool_f, want_stats=batch_stats, stats_per_cf=per_cf)
-        ctx.append((x, st_in, pc, idx))
+            relu=True, seq_len=seq_dev, pool=c.pool_f, want_stats=batch_stats, stats_per_cf=per_cf, precision=pr)
+        ctx.append((x, st_in, pc, idx, pr))
         if next_norm is None:
             st_in = None
         elif batch_stats:
@@ -138,7 +144,7 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
     """Backward of stack_forward; accumulates parameter grads, returns grad wrt the stack input.
     ``on_layer_done(j)`` fires once every gradient owned by layers >= j is final."""
     for j in reversed(range(len(layers))):
-        L, (x, st_in, pc, idx) = layers[j], ctx[j]
+        L, (x, st_in, pc, idx, pr) = layers[j], ctx[j]
         c = L.conv
         g = g.contiguous()
         dw, db = _grad(c.conv.weight), _grad(c.conv.bias)
@@ -151,16 +157,16 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
             if on_layer_done is not None:
                 on_layer_done(0)
             return None
-        wd = pc.dgrad()
+        wd = pc.dgrad(pr)
         if st_in is not None:
             dz, stats = ops.conv_bwd_data(g, pc, wd, x.shape, idx, seq_dev,
-                                          bn=(x, st_in.mean, st_in.invstd, st_in.scale, st_in.shift))
+                                          bn=(x, st_in.mean, st_in.invstd, st_in.scale, st_in.shift), precision=pr)
             rows = 1 if x.dim() == 3 else x.shape[2]
             norm = L.in_norm
             g = ops.bn_backward(dz, x, st_in, stats, _count(seq_host, x.shape[-1], rows),
                                 _grad(norm.gamma), _grad(norm.beta), seq_dev)
         else:
-            g, _ = ops.conv_bwd_data(g, pc, wd, x.shape, idx, None)
+            g, _ = ops.conv_bwd_data(g, pc, wd, x.shape, idx, None, precision=pr)
         if on_layer_done is not None:
             on_layer_done(j)        # layer j's in_norm belongs to it or to j-1's tail: both done now
     return g
@@ -189,23 +195,24 @@ def _chains(wrappers):
     return chains
 
 
-def _heads_forward(wrappers, x_w, seq_dev, seq_host, training):
+def _heads_forward(wrappers, x_w, seq_dev, seq_host, training, precision='f32'):
     logits, head_ctx = [], []
     for wi, w in enumerate(wrappers):
         layers = describe_stack([w.output_net])
-        y, c = stack_forward(layers, x_w[wi], seq_dev, seq_host, training)
+        y, c = stack_forward(layers, x_w[wi], seq_dev, seq_host, training, precision)
         logits.append(y)
         head_ctx.append((layers, c))
     return logits, head_ctx
 
 
-def _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training):
+def _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training, precision='f32'):
     """Unidirectional multi-layer stacks (FBCRNN): layer-wavefront scan, T + L - 1 launches."""
     nl = wrappers[0].num_layers
     gi0, pcs0 = [], []
     for ch in chains:
         pc = PackedConv(ch.p('weight_ih', 0).unsqueeze(-1), owner=ch.p('weight_ih', 0))
-        y, _, _ = ops.conv_fwd(h, pc, pc.fwd(), bias=ch.p('bias_ih', 0).detach(), seq_len=None)
+        pr = _prec(precision, pc.cin)
+        y, _, _ = ops.conv_fwd(h, pc, pc.fwd(pr), bias=ch.p('bias_ih', 0).detach(), seq_len=None, precision=pr)
         gi0.append(ops.bct_to_tbc(y))
         pcs0.append(pc)
     idx = [(ch, l) for ch in chains for l in range(nl)]
@@ -215,12 +222,12 @@ def _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training):
         [ch.p('weight_hh', l).detach() for ch, l in idx], [ch.p('bias_hh', l).detach() for ch, l in idx],
         [ch.reverse for ch in chains], seq_dev, nl, save=training)
     x_w = [ops.tbc_to_bct(hs[ci * nl + nl - 1]) for ci in range(len(chains))]     # one chain per wrapper
-    logits, head_ctx = _heads_forward(wrappers, x_w, seq_dev, seq_host, training)
-    return logits, ('stack', chains, (h, pcs0, hs, save), head_ctx)
+    logits, head_ctx = _heads_forward(wrappers, x_w, seq_dev, seq_host, training, precision)
+    return logits, ('stack', chains, (h, pcs0, hs, save, precision), head_ctx)
 
 
 def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
-    _, chains, (h, pcs0, hs, save), head_ctx = ctx
+    _, chains, (h, pcs0, hs, save, precision), head_ctx = ctx
     nl = wrappers[0].num_layers
     dy_top = []
     for wi, w in enumerate(wrappers):
@@ -243,19 +250,20 @@ def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
             if w_ih.requires_grad:
                 ops.conv_bwd_weight(x_in, dgi_b, PackedConv(w_ih.unsqueeze(-1)), _grad(w_ih), _grad(ch.p('bias_ih', l)))
             if l == 0:
-                dx, _ = ops.conv_bwd_data(dgi_b, pcs0[ci], pcs0[ci].dgrad(), h.shape)
+                pr = _prec(precision, pcs0[ci].cin)
+                dx, _ = ops.conv_bwd_data(dgi_b, pcs0[ci], pcs0[ci].dgrad(pr), h.shape, precision=pr)
                 dh = dx if dh is None else dh.add_(dx)
     return dh
 
 
-def rnn_forward(wrappers, h, seq_dev, seq_host, training):
+def rnn_forward(wrappers, h, seq_dev, seq_host, training, precision='f32'):
     """wrappers: list of modules.GRU sharing the input h [B,C,T].  Returns (logits per wrapper, ctx)."""
     chains = _chains(wrappers)
     num_layers = wrappers[0].num_layers
     assert all(w.num_layers == num_layers for w in wrappers)
     if not any(w.bidirectional for w in wrappers) and wrappers[0].hidden_size in (64, 128, 256, 512) \
             and all(w.rnn.input_size == h.shape[1] for w in wrappers):
-        return _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training)
+        return _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training, precision)
     x_w = [h for _ in wrappers]                  # per-wrapper layer input [B, In, T]
     layer_ctx = []
     for l in range(num_layers):
@@ -263,8 +271,9 @@ def rnn_forward(wrappers, h, seq_dev, seq_host, training):
         for ch in chains:
             w_ih = ch.p('weight_ih', l)
             pc = PackedConv(w_ih.unsqueeze(-1), owner=w_ih)
-            y, _, _ = ops.conv_fwd(x_w[ch.widx], pc, pc.fwd(), bias=ch.p('bias_ih', l).detach(),
-                                   seq_len=None)
+            pr = _prec(precision, pc.cin)
+            y, _, _ = ops.conv_fwd(x_w[ch.widx], pc, pc.fwd(pr), bias=ch.p('bias_ih', l).detach(),
+                                   seq_len=None, precision=pr)
             gi.append(ops.bct_to_tbc(y))
             pcs.append(pc)
         hs, save = ops.gru_scan_fwd(gi, [ch.p('weight_hh', l).detach() for ch in chains],
@@ -276,15 +285,15 @@ def rnn_forward(wrappers, h, seq_dev, seq_host, training):
         for wi, w in enumerate(wrappers):
             outs = [hs_bct[i] for i, ch in enumerate(chains) if ch.widx == wi]
             x_w.append(outs[0] if len(outs) == 1 else torch.cat(outs, dim=1))
-    logits, head_ctx = _heads_forward(wrappers, x_w, seq_dev, seq_host, training)
-    return logits, (chains, layer_ctx, head_ctx)
+    logits, head_ctx = _heads_forward(wrappers, x_w, seq_dev, seq_host, training, precision)
+    return logits, (chains, layer_ctx, head_ctx, precision)
 
 
 def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     """Returns grad wrt the shared input h."""
     if ctx[0] == 'stack':
         return _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host)
-    chains, layer_ctx, head_ctx = ctx
+    chains, layer_ctx, head_ctx, precision = ctx
     num_layers = wrappers[0].num_layers
     hid = wrappers[0].hidden_size
     d_out = []                                   # per wrapper: grad wrt top-layer output [B, H*dirs, T]
@@ -310,7 +319,8 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
                                     _grad(w_hh), _grad(ch.p('bias_hh', l)))
             if w_ih.requires_grad:
                 ops.conv_bwd_weight(x_w[ch.widx], dgi_b, pcs[i], _grad(w_ih), _grad(ch.p('bias_ih', l)))
-            dx, _ = ops.conv_bwd_data(dgi_b, pcs[i], pcs[i].dgrad(), x_w[ch.widx].shape)
+            pr = _prec(precision, pcs[i].cin)
+            dx, _ = ops.conv_bwd_data(dgi_b, pcs[i], pcs[i].dgrad(pr), x_w[ch.widx].shape, precision=pr)
             dx_w[ch.widx] = dx if dx_w[ch.widx] is None else dx_w[ch.widx].add_(dx)
         if l > 0:
             d_out = dx_w

@@ -15,6 +15,9 @@ class SoundEventModel(nn.Module, abc.ABC):
         self.labelwise_metrics = labelwise_metrics
         self.label_mapping = label_mapping
         self.test_labels = test_labels
+        # operand format of the conv / projection MFMAs: 'f32' (default), 'bf16' (BASELINE config 3) or
+        # 'bf16x3' (exact 3-way bf16 split, fp32-class accuracy); weight gradients, BN, GRU scans stay fp32
+        self.conv_precision = 'f32'
 
     @abc.abstractmethod
     def tagging(self, inputs, **params):

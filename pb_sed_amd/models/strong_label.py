@@ -15,11 +15,11 @@ class _NetFunction(torch.autograd.Function):
             b, _, f, t = x.shape
             x = torch.cat([x, tag.reshape(b, -1, 1, 1).to(x.dtype).expand(b, tag.shape[1], f, t)], dim=1).contiguous()
         layers = engine.describe_stack([model.cnn.cnn_2d, model.cnn.cnn_1d])
-        h, cnn_ctx = engine.stack_forward(layers, x, seq_dev, seq_host, training)
+        h, cnn_ctx = engine.stack_forward(layers, x, seq_dev, seq_host, training, model.conv_precision)
         n_h = h.shape[1]
         if tag is not None:
             h = torch.cat([h, tag.reshape(h.shape[0], -1, 1).to(h.dtype).expand(-1, -1, h.shape[-1])], dim=1).contiguous()
-        logits, rnn_ctx = engine.rnn_forward([model.rnn], h, seq_dev, seq_host, training)
+        logits, rnn_ctx = engine.rnn_forward([model.rnn], h, seq_dev, seq_host, training, model.conv_precision)
         y = ops.squash_fwd(logits[0], 0.)
         ctx.state = (model, layers, cnn_ctx, rnn_ctx, y, n_h, seq_host, seq_dev)
         return y

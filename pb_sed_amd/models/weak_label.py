@@ -20,9 +20,9 @@ class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, seq_host, seq_dev, training, *params):
         layers = engine.describe_stack([model.cnn.cnn_2d, model.cnn.cnn_1d])
-        h, cnn_ctx = engine.stack_forward(layers, x, seq_dev, seq_host, training)
+        h, cnn_ctx = engine.stack_forward(layers, x, seq_dev, seq_host, training, model.conv_precision)
         wrappers = [model.rnn_fwd] + ([model.rnn_bwd] if model.rnn_bwd is not None else [])
-        logits, rnn_ctx = engine.rnn_forward(wrappers, h, seq_dev, seq_host, training)
+        logits, rnn_ctx = engine.rnn_forward(wrappers, h, seq_dev, seq_host, training, model.conv_precision)
         ys = [ops.squash_fwd(l, model.minimum_score) for l in logits]
         ctx.state = (model, layers, cnn_ctx, wrappers, rnn_ctx, ys, seq_host, seq_dev)
         ctx.mark_non_differentiable(h)
@@ -49,7 +49,7 @@ class _HeadsFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, h, seq_host, seq_dev):
         wrappers = [model.rnn_fwd] + ([model.rnn_bwd] if model.rnn_bwd is not None else [])
-        logits, _ = engine.rnn_forward(wrappers, h, seq_dev, seq_host, False)
+        logits, _ = engine.rnn_forward(wrappers, h, seq_dev, seq_host, False, model.conv_precision)
         return tuple(ops.squash_fwd(l, model.minimum_score) for l in logits)
 
     @staticmethod

@@ -31,6 +31,7 @@ def _conv_flops(b, cin, pc, f, t):
     return 2 * b * pc.cout * cin * pc.kh * pc.kw * f * t
 
 
+NSPLIT = {'bf16': 1, 'bf16x3': 3}      # bf16-MFMA operand formats (csrc/conv_bf16.hip)
 PACK_EPOCH = [0]      # bump (invalidate_packed) whenever parameters are changed behind torch's back (fused Adam)
 
 
@@ -76,16 +77,39 @@ class PackedConv:
         cache[dgrad] = wp
         return wp
 
-    def fwd(self):
-        return self._pack(0)
+    def _pack_bf16(self, dgrad, nsplit):
+        key = (self.owner._version, PACK_EPOCH[0], self.owner.data_ptr())
+        cache = getattr(self.owner, '_pbsed_pack', None)
+        if cache is None or cache.get('key') != key:
+            cache = {'key': key}
+            try:
+                self.owner._pbsed_pack = cache
+            except AttributeError:
+                pass
+        ck = ('bf16', dgrad, nsplit)
+        if ck in cache:
+            return cache[ck]
+        inp, outp = C.c_int(), C.c_int()
+        _lib.lib().pbsed_conv_pack_dims_bf16(self.cin, self.cout, dgrad, C.byref(inp), C.byref(outp))
+        wp = torch.empty(nsplit * self.kh * self.kw * inp.value * outp.value, device=self.weight.device,
+                         dtype=torch.int16)
+        w = self.weight.detach().contiguous()
+        call('pbsed_pack_conv_weights_bf16', ptr(w), ptr(wp), self.cout, self.cin, self.kh, self.kw, dgrad, nsplit,
+             stream())
+        cache[ck] = wp
+        return wp
 
-    def dgrad(self):
-        return self._pack(1)
+    def fwd(self, precision='f32'):
+        return self._pack(0) if precision == 'f32' else self._pack_bf16(0, NSPLIT[precision])
+
+    def dgrad(self, precision='f32'):
+        return self._pack(1) if precision == 'f32' else self._pack_bf16(1, NSPLIT[precision])
 
 
 def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=None, pool=False,
-             want_stats=False, stats_per_cf=False):
-    """y = conv(prologue(x)) [+pool].  Returns (y, pool_idx|None, stats|None)."""
+             want_stats=False, stats_per_cf=False, precision='f32'):
+    """y = conv(prologue(x)) [+pool].  Returns (y, pool_idx|None, stats|None).  ``wp`` must have been packed with
+    the same ``precision`` ('f32' | 'bf16' | 'bf16x3')."""
     _lib.require_gpu(x)
     b, cin, f, t = _dims4(x)
     assert cin == pc.cin, (cin, pc.cin)
@@ -97,13 +121,19 @@ def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=No
     if want_stats:
         stats = torch.zeros((STAT_SLOTS, pc.cout * fo if stats_per_cf else pc.cout, 2), device=x.device,
                             dtype=torch.float64)
+    if precision != 'f32':
+        call('pbsed_conv_fwd_bf16', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
+             ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, pc.kh, pc.kw, int(pool),
+             NSPLIT[precision], stream(), tag=_conv_tag(b, cin, pc, f, t) + ' ' + precision,
+             flops=_conv_flops(b, cin, pc, f, t))
+        return y, idx, stats
     call('pbsed_conv_fwd', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
          ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, pc.kh, pc.kw,
          int(pool), stream(), tag=_conv_tag(b, cin, pc, f, t), flops=_conv_flops(b, cin, pc, f, t))
     return y, idx, stats
 
 
-def conv_bwd_data(g, pc, wd, x_shape, unpool_idx=None, seq_len=None, bn=None, relu=True):
+def conv_bwd_data(g, pc, wd, x_shape, unpool_idx=None, seq_len=None, bn=None, relu=True, precision='f32'):
     """Gradient wrt the conv input.  ``bn=(x, mean, invstd, scale, shift)`` additionally pushes it
     back through mask/ReLU/BN-apply (returns dz and the (sum dz, sum dz*xhat) statistics)."""
     b, cin, f, t = _dims4(torch.empty(x_shape, device='meta'))
@@ -113,6 +143,12 @@ def conv_bwd_data(g, pc, wd, x_shape, unpool_idx=None, seq_len=None, bn=None, re
     if bn is not None:
         bx, bmean, binv, bsc, bsh = bn
         stats = torch.zeros((STAT_SLOTS, cin, 2), device=g.device, dtype=torch.float64)
+    if precision != 'f32':
+        call('pbsed_conv_bwd_data_bf16', ptr(g), ptr(wd), ptr(unpool_idx), ptr(seq_len), ptr(dz), ptr(bx),
+             ptr(bmean), ptr(binv), ptr(bsc), ptr(bsh), int(relu), ptr(stats), b, cin, pc.cout, f, t,
+             pc.kh, pc.kw, NSPLIT[precision], stream(), tag=_conv_tag(b, cin, pc, f, t) + ' ' + precision,
+             flops=_conv_flops(b, cin, pc, f, t))
+        return dz, stats
     call('pbsed_conv_bwd_data', ptr(g), ptr(wd), ptr(unpool_idx), ptr(seq_len), ptr(dz), ptr(bx),
          ptr(bmean), ptr(binv), ptr(bsc), ptr(bsh), int(relu), ptr(stats), b, cin, pc.cout, f, t,
          pc.kh, pc.kw, stream(), tag=_conv_tag(b, cin, pc, f, t), flops=_conv_flops(b, cin, pc, f, t))

@@ -198,3 +198,73 @@ def test_bicrnn_train_step_parity():
         except AssertionError as e:
             bad.append(str(e))
     assert not bad, '\n'.join(bad)
+
+
+@pytest.mark.parametrize('precision,tol', [('bf16x3', 1e-4), ('bf16', 3e-2)])
+def test_fbcrnn_conv_precision_modes(precision, tol):
+    """conv_precision='bf16x3' must stay inside the fp32 tolerance (scores 1e-4); 'bf16' is the reduced-precision
+    compute dtype of BASELINE config 3 (scores within 3e-2, gradients in the L2 sense)."""
+    from oracle import frontend as ofe, models as om
+    from pb_sed_amd.models import weak_label
+    torch.manual_seed(0)
+    net = dict(out_channels_2d=[16, 32, 64], pool_sizes_2d=[1, (2, 1), (2, 1)], kernel_size_2d=3,
+               out_channels_1d=[64, 64, 64], kernel_size_1d=[1, 3, 1])
+    kw = dict(num_events=10, number_of_filters=128, hidden_size=64, num_layers=2, net=net)
+    ref = om.FBCRNN.build(**kw)
+    model = weak_label.CRNN.build(**kw)
+    _copy_weights(model, ref)
+    model.to(DEV)
+    model.conv_precision = precision
+    wav, seq, weak, bnd, t = synth_batch(5, 32000, 10, seed=11)
+    ref.train()
+    inputs_ref = {'stft': ofe.stft(wav), 'seq_len': seq.tolist(), 'weak_targets': weak, 'boundary_targets': bnd}
+    out_ref = ref(inputs_ref)
+    ref.review(inputs_ref, out_ref)['loss'].backward()
+    model.train()
+    inputs = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV),
+              'boundary_targets': bnd.to(DEV)}
+    model.flat_parameters()[1].zero_()
+    out = model(dict(inputs))
+    model.review(inputs, out)['loss'].backward()
+    assert (out[0].cpu() - out_ref[0]).abs().max() < tol
+    assert (out[1].cpu() - out_ref[1]).abs().max() < tol
+    refp = dict(ref.named_parameters())
+    gtol = 2e-3 if precision == 'bf16x3' else 4e-1      # plain bf16 gradients: sanity bound only
+    for name, p in model.named_parameters():
+        g = refp[name].grad
+        if g.norm() < 1e-6:
+            continue
+        l2 = ((p.grad.cpu() - g).norm() / g.norm()).item()
+        assert l2 < gtol, f'{name}: rel L2 grad err {l2:.2e} ({precision})'
+
+
+def test_bicrnn_bf16_train_step():
+    """BASELINE config 3 in miniature: tag-conditioned BiCRNN train step with bf16-MFMA convolutions."""
+    from oracle import frontend as ofe, models as om
+    from pb_sed_amd.models import strong_label
+    torch.manual_seed(2)
+    net = dict(out_channels_2d=[16, 32, 64], pool_sizes_2d=[1, (2, 1), (2, 1)], kernel_size_2d=3,
+               out_channels_1d=[64, 64, 64], kernel_size_1d=[1, 3, 1])
+    kw = dict(num_events=10, number_of_filters=128, hidden_size=64, num_layers=2, net=net, tag_conditioning=True)
+    ref = om.BiCRNN.build(**kw)
+    model = strong_label.CRNN.build(**kw)
+    _copy_weights(model, ref)
+    model.to(DEV)
+    model.conv_precision = 'bf16'
+    wav, seq, weak, strong, t = synth_batch(5, 24000, 10, seed=5)
+    tag = (weak > .99).float()
+    ref.train()
+    inp_ref = {'stft': ofe.stft(wav), 'seq_len': seq.tolist(), 'weak_targets': weak, 'strong_targets': strong,
+               'tag_condition': tag}
+    out_ref = ref(inp_ref)
+    loss_ref = ref.review(inp_ref, out_ref)['loss']
+    model.train()
+    inp = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV),
+           'strong_targets': strong.to(DEV), 'tag_condition': tag.to(DEV)}
+    model.flat_parameters()[1].zero_()
+    out = model(dict(inp))
+    loss = model.review(inp, out)['loss']
+    loss.backward()
+    assert (out[0].cpu() - out_ref[0]).abs().max() < 3e-2
+    assert loss.item() == pytest.approx(loss_ref.item(), rel=2e-2)
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())

@@ -319,3 +319,40 @@ def test_gru_stack_wavefront_vs_torch(b, h, t, ragged):
         dgi0 = ops.tbc_to_bct(dgi[c * nl]).cpu()
         close(torch.einsum('bot,oc->bct', dgi0, g.rnn.weight_ih_l0.detach()), xs[c].grad, atol=3e-4, rtol=1e-3, name=f'dx chain{c}')
     ops.check_gru_sync()
+
+
+BF16_CASES = [c for c in CONV_CASES if c['cin'] >= 20] + [
+    dict(cin=64, cout=64, f=8, t=70, k=(3, 3), pool=False, pro=False),
+    dict(cin=32, cout=40, f=1, t=200, k=(1, 3), pool=False, pro=False),
+]
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('case', BF16_CASES, ids=lambda c: f"{c['cin']}x{c['cout']}k{c['k'][0]}{c['k'][1]}p{int(c['pool'])}{'pro' if c['pro'] else ''}")
+def test_conv_bf16_mfma_vs_torch(case, precision):
+    """bf16-MFMA conv family: plain bf16 operands (config-3 compute dtype, bf16 tolerance) and the exact 3-way
+    split (fp32-class accuracy, checked at the fp32 tolerance)."""
+    from pb_sed_amd import ops
+    torch.manual_seed(0)
+    b, cin, cout, f, t, k, pool, pro = 3, case['cin'], case['cout'], case['f'], case['t'], case['k'], case['pool'], case['pro']
+    x = torch.randn(b, cin, f, t, dtype=torch.float64)
+    w = (torch.randn(cout, cin, *k, dtype=torch.float64) / np.sqrt(cin * k[0] * k[1]))
+    bias = torch.randn(cout, dtype=torch.float64)
+    seq = np.array([t, max(t - 9, 1), max(t // 2, 1)])
+    scale = (torch.rand(cin, dtype=torch.float64) + .5) if pro else None
+    shift = torch.randn(cin, dtype=torch.float64) * .3 if pro else None
+    xr = x.clone().requires_grad_()
+    y_ref = _conv_ref(xr, w, bias, scale, shift, seq, k, pool)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    tol = dict(atol=1e-4, rtol=1e-4) if precision == 'bf16x3' else dict(atol=4e-2, rtol=4e-2)
+    dx = lambda a: None if a is None else a.float().to(DEV).contiguous()
+    seq_dev = torch.as_tensor(seq, dtype=torch.int32).to(DEV)
+    pc = ops.PackedConv(dx(w))
+    xd = dx(x)
+    y, idx, stats = ops.conv_fwd(xd, pc, pc.fwd(precision), bias=dx(bias), scale=dx(scale), shift=dx(shift), relu=True,
+                                 seq_len=seq_dev, pool=pool, want_stats=True, precision=precision)
+    close(y, y_ref, name=f'conv_fwd {precision}', **tol)
+    if not pro and not pool:
+        g, _ = ops.conv_bwd_data(dx(gy), pc, pc.dgrad(precision), xd.shape, None, None, precision=precision)
+        close(g, xr.grad, name=f'conv_dgrad {precision}', **tol)
