@@ -104,7 +104,9 @@ def _count(seq_host, t, rows):
 
 
 def _prec(precision, cin):
-XX
+    """bf16-MFMA kernels work on 32-channel K steps; measured on MI355X they only beat the fp32-MFMA kernels from
+    32 input channels up (16->16 3x3: 0.30 ms bf16 vs 0.17 ms fp32), so thinner layers stay on fp32."""
+    return precision if (precision != 'f32' and cin >= 32) else 'f32'
 
 
 def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32'):
