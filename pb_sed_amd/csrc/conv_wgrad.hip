@@ -43,7 +43,8 @@ struct WgradCfg {
 };
 
 template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN, int KWAVES>
-__global__ __launch_bounds__(WAVES * KWAVES * 64) void conv_wgrad_kernel(ConvWgradArgs a) {
+__global__ __launch_bounds__(WAVES * KWAVES * 64, (KH == 3 && WAVES == 4 && NCG == 1 && !TAPN) ? 3 : 1)
+void conv_wgrad_kernel(ConvWgradArgs a) {
     using C = WgradCfg<KH, KW, WAVES, MT, NCG, TAPN, KWAVES>;
     constexpr int FT = C::FT, TT = C::TT, KK = C::KK, NT = C::NT;
     constexpr int PADH = (KH - 1) / 2, PADW = (KW - 1) / 2;
