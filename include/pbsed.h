@@ -106,10 +106,24 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
                         const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
                         float* const* hs, float* const* save, const int* reverse /*host*/, const int* seq_len,
                         int B, int H, int T, unsigned int* sync_ws, void* stream);
+/* Persistent forward scan exchanging h_t as 8-byte {epoch, value} granules (one launch for the whole scan).
+ * granules: device uint64 [nchains*nlayers][T][B][H], zero before first use, reusable with a fresh non-zero epoch. */
+int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
+                                const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
+                                float* const* hs, float* const* save, const int* reverse /*host*/, const int* seq_len,
+                                int B, int H, int T, unsigned long long* granules, unsigned int epoch,
+                                unsigned int* err_flag, void* stream);
 int pbsed_gru_stack_bwd(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
                         const float* const* hs, const float* const* save, const float* const* dy_top,
                         float* const* dgi, float* const* dgh, float* const* dhz, const int* reverse /*host*/,
                         const int* seq_len, int B, int H, int T, unsigned int* sync_ws, void* stream);
+/* Persistent BPTT exchanging the step's gate gradients as granules.  granules: device uint64
+ * [nchains*nlayers][T][B][4][H] (dr, dz, dn, dn*r), zero before first use. */
+int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
+                                const float* const* hs, const float* const* save, const float* const* dy_top,
+                                float* const* dgi, float* const* dgh, const int* reverse /*host*/, const int* seq_len,
+                                int B, int H, int T, unsigned long long* granules, unsigned int epoch,
+                                unsigned int* err_flag, void* stream);
 int pbsed_bct_to_tbc(const float* src, float* dst, int B, int C, int T, void* stream);
 int pbsed_tbc_to_bct(const float* src, float* dst, int B, int C, int T, int shift, void* stream);
 int pbsed_transpose2d(const float* src, float* dst, int R, int C, void* stream);

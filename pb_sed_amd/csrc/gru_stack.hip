@@ -40,6 +40,7 @@ struct GruStackArgs {
     const int* seq_len;
     int B, T, nchains, nlayers, launch;
     int one_xcd;          // experiment: grid.x is 8x larger and only blocks with blockIdx.x % 8 == 0 work
+    int ring_xcd, nby;    // granule kernels: 1-D grid, block id = jblk*ring_xcd + ring so that a ring's blocks share an XCD
     int debug;            // experiment (PBSED_GRU_DEBUG bitmask): 1 skip W_hh matmul, 2 skip W_ih matmul, 4 skip save stores
 };
 
@@ -491,6 +492,352 @@ __global__ __launch_bounds__(NW * 64) void gru_persist_bwd_kernel(GruStackArgs a
     }
 }
 
+// ============================================================================================
+// Persistent variant 2 ("granules"): the exchanged h_t values ARE the flags.  Every h value is published as one
+// aligned 8-byte {epoch tag, value} word with a single write-through (sc1) store into a [T][B][H] array that is
+// never overwritten within a call; consumers poll the words they need with L1-bypassing 8-byte loads until
+// all tags equal the call's epoch (cdna_hip_programming.md Guideline 16, form R2: no fence, no drain, no
+// counter).  W fragments stay in registers for all T steps, the previous state of a thread's own unit too.
+// ============================================================================================
+__device__ __forceinline__ float4 poll_granules4(const gu64* g, unsigned epoch, bool valid, unsigned* err_flag) {
+    unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int spin = 0;; ++spin) {
+        bool ok = true;
+        if (valid) {
+            a0 = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a2 = __hip_atomic_load(g + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a3 = __hip_atomic_load(g + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = (unsigned)(a0 >> 32) == epoch && (unsigned)(a1 >> 32) == epoch && (unsigned)(a2 >> 32) == epoch &&
+                 (unsigned)(a3 >> 32) == epoch;
+        }
+        if (__all(ok)) break;
+        if (spin > (1 << 18)) {                     // bounded: raise the error flag and go on with garbage
+            __hip_atomic_store((gu32*)err_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return make_float4(__uint_as_float((unsigned)a0), __uint_as_float((unsigned)a1), __uint_as_float((unsigned)a2),
+                       __uint_as_float((unsigned)a3));
+}
+
+// All granule loads of a step are issued before any tag is looked at: one fabric round trip per step instead of
+// one per K block (agent-scope loads miss the per-XCD L2 by construction).
+template <int NBLK>
+__device__ __forceinline__ void poll_batch(float4 (&out)[NBLK], const gu64* row, int kblk0, int nblk, int lq, unsigned epoch,
+                                           bool valid, unsigned* err_flag) {
+    unsigned long long q[NBLK][4];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) q[i][0] = q[i][1] = q[i][2] = q[i][3] = 0;
+    for (int spin = 0;; ++spin) {
+        bool ok = true;
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < NBLK; ++i) {
+                if (i < nblk) {
+                    const gu64* g = row + (kblk0 + i) * 16 + lq * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q[i][e] = __hip_atomic_load(g + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NBLK; ++i) {
+                if (i < nblk) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ok = ok && (unsigned)(q[i][e] >> 32) == epoch;
+                }
+            }
+        }
+        if (__all(ok)) break;
+        if (spin > (1 << 18)) {                     // bounded: raise the error flag and go on with garbage
+            __hip_atomic_store((gu32*)err_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        if (spin > 8) __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i)
+        out[i] = make_float4(__uint_as_float((unsigned)q[i][0]), __uint_as_float((unsigned)q[i][1]),
+                             __uint_as_float((unsigned)q[i][2]), __uint_as_float((unsigned)q[i][3]));
+}
+
+template <int NB, int NG>
+__device__ __forceinline__ void mm_gran(f32x4 (&acc)[NG], const float4 (&wv)[NB][NG], const gu64* v, bool vvalid, int kblk0,
+                                        int lq, unsigned epoch, unsigned* err_flag) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const float4 x = poll_granules4(v + (kblk0 + i) * 16 + lq * 4, epoch, vvalid, err_flag);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            acc[g] = mfma16(wv[i][g].x, x.x, acc[g]);
+            acc[g] = mfma16(wv[i][g].y, x.y, acc[g]);
+            acc[g] = mfma16(wv[i][g].z, x.z, acc[g]);
+            acc[g] = mfma16(wv[i][g].w, x.w, acc[g]);
+        }
+    }
+}
+
+template <int KB, int NW>
+__global__ __launch_bounds__(NW * 64) void gru_granule_fwd_kernel(GruStackArgs a, unsigned long long* gran_, unsigned epoch,
+                                                                 unsigned* err_flag) {
+    constexpr int H = KB * NW * 16, HW = NW / 2, NB = 2 * KB;
+    __shared__ float red[2][NW][3][64][4];
+    __shared__ int s_err;
+    gu64* gran = (gu64*)gran_;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (a.ring_xcd) {
+        const int ring = blockIdx.x % a.ring_xcd;
+        if (ring >= a.nby * a.nchains * a.nlayers) return;
+        bx = blockIdx.x / a.ring_xcd; by = ring % a.nby; bz = ring / a.nby;
+    }
+    const int chain = bz % a.nchains, layer = bz / a.nchains;
+    const GruStackLayer& L = a.lc[chain][layer];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+    const int j0 = bx * 16, b0 = by * 16, B = a.B;
+    const bool rev = a.reverse[chain] != 0;
+    const size_t per_cl = (size_t)a.T * B * H;
+    gu64* g_own = gran + (size_t)(chain * a.nlayers + layer) * per_cl;
+    const gu64* g_lo = layer > 0 ? gran + (size_t)(chain * a.nlayers + layer - 1) * per_cl : nullptr;
+    const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
+    const bool bv = tid < 256 && b < B;
+    const bool rowv = (b0 + lr) < B;
+    const float bh_r = L.b_hh[j0 + u], bh_z = L.b_hh[H + j0 + u], bh_n = L.b_hh[2 * H + j0 + u];
+    float bi_r = 0.f, bi_z = 0.f, bi_n = 0.f;
+    if (layer > 0) { bi_r = L.b_ih[j0 + u]; bi_z = L.b_ih[H + j0 + u]; bi_n = L.b_ih[2 * H + j0 + u]; }
+    const int sl = bv ? a.seq_len[b] : 0;
+    // wave -> operand stream and K range (layer 0: all waves split W_hh; above: half W_hh, half W_ih)
+    const bool is_ih = layer > 0 && wave >= HW;
+    const int nblk = layer == 0 ? KB : NB;
+    const int kblk0 = layer == 0 ? wave * KB : (is_ih ? wave - HW : wave) * NB;
+    float4 wv[NB][3];
+    {
+        const float* W = (is_ih ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * H;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                wv[i][g] = (i < nblk) ? *reinterpret_cast<const float4*>(W + (size_t)g * H * H + (kblk0 + i) * 16 + lq * 4)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float h_reg = 0.f;
+    if (tid == 0) s_err = 0;
+    __syncthreads();
+
+    for (int step = 0; step < a.T; ++step) {
+        const int t = rev ? a.T - 1 - step : step;
+        const int tp = rev ? t + 1 : t - 1;
+        const bool has_prev = step > 0;
+        const int par = step & 1;                     // `red` is double-buffered: one barrier per step
+        float gi_r = bi_r, gi_z = bi_z, gi_n = bi_n;
+        if (bv && layer == 0) {
+            const float* gi = L.gi + ((size_t)t * B + b) * 3 * H;
+            gi_r = gi[j]; gi_z = gi[H + j]; gi_n = gi[2 * H + j];
+        }
+        if (tid == 0 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
+        f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (is_ih || has_prev) {
+            const gu64* src = is_ih ? g_lo + ((size_t)t * B + b0 + lr) * H : g_own + ((size_t)tp * B + b0 + lr) * H;
+            float4 x[NB];
+            poll_batch<NB>(x, src, kblk0, nblk, lq, epoch, rowv, err_flag);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (i < nblk) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        acc[g] = mfma16(wv[i][g].x, x[i].x, acc[g]);
+                        acc[g] = mfma16(wv[i][g].y, x[i].y, acc[g]);
+                        acc[g] = mfma16(wv[i][g].z, x[i].z, acc[g]);
+                        acc[g] = mfma16(wv[i][g].w, x[i].w, acc[g]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[par][wave][0][lane][r] = acc[0][r];
+            red[par][wave][1][lane][r] = acc[1][r];
+            red[par][wave][2][lane][r] = acc[2][r];
+        }
+        __syncthreads();
+        if (s_err) return;                            // some hand-off timed out
+        if (bv) {
+            const int src = (u >> 2) * 16 + bb, reg = u & 3;
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                s[0] += red[par][w][0][src][reg];
+                s[1] += red[par][w][1][src][reg];
+                if (layer == 0 || w < HW) s[2] += red[par][w][2][src][reg]; else s[3] += red[par][w][2][src][reg];
+            }
+            const float ghn = s[2] + bh_n;
+            const float r = 1.f / (1.f + expf(-(gi_r + s[0] + bh_r)));
+            const float z = 1.f / (1.f + expf(-(gi_z + s[1] + bh_z)));
+            const float n = tanhf(gi_n + s[3] + r * ghn);
+            const float hp = h_reg;
+            const float h = (t < sl) ? (1.f - z) * n + z * hp : 0.f;
+            h_reg = h;
+            const size_t tb = (size_t)t * B + b;
+            __hip_atomic_store(g_own + tb * H + j, ((unsigned long long)epoch << 32) | __float_as_uint(h), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            L.hs[tb * H + j] = h;
+            if (L.save) {
+                // what BPTT multiplies dh_t with: d(r,z,n pre-activations)/dh, d(gh_n)/dh and z (granule save format)
+                float* sv = L.save + tb * 5 * H;
+                const float cn = (1.f - z) * (1.f - n * n);
+                sv[j] = cn * ghn * r * (1.f - r); sv[H + j] = (hp - n) * z * (1.f - z); sv[2 * H + j] = cn;
+                sv[3 * H + j] = cn * r; sv[4 * H + j] = z;
+            }
+        }
+    }
+}
+
+// Backward twin: every step publishes dh_t (masked by the sequence length) of its 16 units as granules
+// [T][B][H].  Consumers rebuild the gate gradients they contract with from dh and the saved gates, which are
+// plain loads issued before the poll, so only one granule per (row, unit) sits on the hand-off path; dh*z of a
+// thread's own unit stays in a register.
+template <int KB, int NW>
+__global__ __launch_bounds__(NW * 64) void gru_granule_bwd_kernel(GruStackArgs a, unsigned long long* gran_, unsigned epoch,
+                                                                 unsigned* err_flag) {
+    constexpr int H = KB * NW * 16, G = 3 * H, HW = NW / 2, JB = 2 * KB;
+    __shared__ float red[2][NW][64][4];
+    __shared__ int s_err;
+    gu64* gran = (gu64*)gran_;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (a.ring_xcd) {
+        const int ring = blockIdx.x % a.ring_xcd;
+        if (ring >= a.nby * a.nchains * a.nlayers) return;
+        bx = blockIdx.x / a.ring_xcd; by = ring % a.nby; bz = ring / a.nby;
+    }
+    const int chain = bz % a.nchains, layer = bz / a.nchains;
+    const int top = a.nlayers - 1;
+    const GruStackLayer& L = a.lc[chain][layer];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+    const int j0 = bx * 16, b0 = by * 16, B = a.B;
+    const bool rev = a.reverse[chain] != 0;
+    const size_t per_cl = (size_t)a.T * B * H;
+    gu64* g_own = gran + (size_t)(chain * a.nlayers + layer) * per_cl;
+    const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
+    const bool bv = tid < 256 && b < B;
+    const bool rowv = (b0 + lr) < B;
+    const int sl = bv ? a.seq_len[b] : 0;
+    const bool is_up = layer < top && wave >= HW;
+    const int nj = layer == top ? KB : JB;
+    const int jb0 = layer == top ? wave * KB : (is_up ? wave - HW : wave) * JB;
+    // the ring whose dh this wave contracts with: own (carry) or the layer above (input gradient)
+    const GruStackLayer& X = is_up ? a.lc[chain][layer + 1] : L;
+    const gu64* g_x = is_up ? gran + (size_t)(chain * a.nlayers + layer + 1) * per_cl : g_own;
+    float4 wv[JB][3];
+    {
+        const float* W = (is_up ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * G;
+#pragma unroll
+        for (int i = 0; i < JB; ++i)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                wv[i][g] = (i < nj) ? *reinterpret_cast<const float4*>(W + g * H + (jb0 + i) * 16 + lq * 4)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float dhz_prev = 0.f;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid == 0) s_err = 0;
+    __syncthreads();
+
+    // saved gates of the step whose gate gradients this wave rebuilds (tn of the own ring, whose h_prev is hs[t];
+    // t of the layer above) and of the thread's own unit: loaded one step ahead, off the hand-off path
+    float4 pr[JB], pz[JB], pn[JB];
+    float c_r = 0.f, c_z = 0.f, c_n = 0.f, c_nr = 0.f, z = 0.f, dyv = 0.f;
+    auto load_operands = [&](int bs) {
+        const int s = a.T - 1 - bs;
+        const int t = rev ? a.T - 1 - s : s;
+        const int tx = is_up ? t : (rev ? t - 1 : t + 1);
+        const bool act = (is_up || bs > 0) && rowv && !(a.debug & 8);
+#pragma unroll
+        for (int i = 0; i < JB; ++i) {
+            pr[i] = pz[i] = pn[i] = zero4;
+            if (i < nj && act) {
+                const float* sv = X.save + ((size_t)tx * B + b0 + lr) * 5 * H + (jb0 + i) * 16 + lq * 4;
+                pr[i] = *reinterpret_cast<const float4*>(sv);
+                pz[i] = *reinterpret_cast<const float4*>(sv + H);
+                pn[i] = *reinterpret_cast<const float4*>(sv + (is_up ? 2 : 3) * H);
+            }
+        }
+    };
+    auto load_own = [&](int bs) {
+        const int s = a.T - 1 - bs;
+        const int t = rev ? a.T - 1 - s : s;
+        if (bv) {
+            const size_t tb = (size_t)t * B + b;
+            const float* sv = L.save + tb * 5 * H;
+            c_r = sv[j]; c_z = sv[H + j]; c_n = sv[2 * H + j]; c_nr = sv[3 * H + j]; z = sv[4 * H + j];
+            if (layer == top) dyv = L.dy[tb * H + j];
+        }
+    };
+    load_operands(0);
+    load_own(0);
+
+    for (int bstep = 0; bstep < a.T; ++bstep) {
+        const int s = a.T - 1 - bstep;
+        const int t = rev ? a.T - 1 - s : s;
+        const int tn = rev ? t - 1 : t + 1;
+        const bool has_next = bstep > 0;
+        const size_t tb = (size_t)t * B + b;
+        const int par = bstep & 1;
+        if (tid == 0 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
+        f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (is_up || has_next) {
+            const int tx = is_up ? t : tn;
+            float4 dh4[JB];
+            poll_batch<JB>(dh4, g_x + ((size_t)tx * B + b0 + lr) * H, jb0, nj, lq, epoch, rowv, err_flag);
+#pragma unroll
+            for (int i = 0; i < JB; ++i) {
+                if (i < nj) {
+                    acc[0] = mfma16(wv[i][0].x, dh4[i].x * pr[i].x, acc[0]);
+                    acc[1] = mfma16(wv[i][1].x, dh4[i].x * pz[i].x, acc[1]);
+                    acc[2] = mfma16(wv[i][2].x, dh4[i].x * pn[i].x, acc[2]);
+                    acc[0] = mfma16(wv[i][0].y, dh4[i].y * pr[i].y, acc[0]);
+                    acc[1] = mfma16(wv[i][1].y, dh4[i].y * pz[i].y, acc[1]);
+                    acc[2] = mfma16(wv[i][2].y, dh4[i].y * pn[i].y, acc[2]);
+                    acc[0] = mfma16(wv[i][0].z, dh4[i].z * pr[i].z, acc[0]);
+                    acc[1] = mfma16(wv[i][1].z, dh4[i].z * pz[i].z, acc[1]);
+                    acc[2] = mfma16(wv[i][2].z, dh4[i].z * pn[i].z, acc[2]);
+                    acc[0] = mfma16(wv[i][0].w, dh4[i].w * pr[i].w, acc[0]);
+                    acc[1] = mfma16(wv[i][1].w, dh4[i].w * pz[i].w, acc[1]);
+                    acc[2] = mfma16(wv[i][2].w, dh4[i].w * pn[i].w, acc[2]);
+                }
+            }
+        }
+        if (bstep + 1 < a.T) load_operands(bstep + 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[par][wave][lane][q] = acc[0][q] + acc[1][q] + acc[2][q];
+        __syncthreads();
+        if (s_err) return;
+        if (bv) {
+            const int src = (u >> 2) * 16 + bb, reg = u & 3;
+            float carry = 0.f, dylow = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                if (layer == top || w < HW) carry += red[par][w][src][reg]; else dylow += red[par][w][src][reg];
+            }
+            float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, dhzv = 0.f, dh = 0.f;
+            if (t < sl) {
+                dh = (layer == top ? dyv : dylow) + (has_next ? carry + dhz_prev : 0.f);
+                dn = dh * c_n; dz = dh * c_z; dr = dh * c_r; dnr = dh * c_nr;
+                dhzv = dh * z;
+            }
+            dhz_prev = dhzv;
+            __hip_atomic_store(g_own + tb * H + j, ((unsigned long long)epoch << 32) | __float_as_uint(dh), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            if (!(a.debug & 16)) {
+                float* dgi = L.dgi + tb * G;
+                float* dgh = L.dgh + tb * G;
+                dgi[j] = dr; dgi[H + j] = dz; dgi[2 * H + j] = dn;
+                dgh[j] = dr; dgh[H + j] = dz; dgh[2 * H + j] = dnr;
+            }
+        }
+        if (bstep + 1 < a.T) load_own(bstep + 1);
+    }
+}
+
 template <int KB, int NW>
 static void launch_persist(bool bwd, const GruStackArgs& a, const GruPersistSync& sy, dim3 grid, hipStream_t s) {
     if (bwd) hipLaunchKernelGGL((gru_persist_bwd_kernel<KB, NW>), grid, dim3(NW * 64), 0, s, a, sy);
@@ -581,6 +928,87 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
     a.debug = getenv("PBSED_GRU_DEBUG") ? atoi(getenv("PBSED_GRU_DEBUG")) : 0;
     DISPATCH_KB(H, false, a, grid, (hipStream_t)stream);
     return check_launch("gru_stack_fwd");
+}
+
+static bool granule_ring_xcd() {
+    static const bool v = [] { const char* e = getenv("PBSED_GRU_RING_XCD"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
+
+// Granule-exchange persistent forward scan (see gru_granule_fwd_kernel).  granules: device uint64
+// [nchains*nlayers][T][B][H] workspace that must be ZERO before its first use and may be reused across calls with a
+// different non-zero `epoch` each time; err_flag: device uint32 (0 on entry; non-zero after a hand-off timed out).
+int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
+                                const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
+                                float* const* hs, float* const* save, const int* reverse, const int* seq_len, int B,
+                                int H, int T, unsigned long long* granules, unsigned int epoch, unsigned int* err_flag,
+                                void* stream) {
+    if (int e = stack_check(nchains, nlayers, B, H, T)) return e;
+    if (epoch == 0 || !granules || !err_flag) { set_error("gru_stack_fwd_granule: need workspace and epoch != 0"); return PBSED_E_ARG; }
+    GruStackArgs a{};
+    for (int c = 0; c < nchains; ++c) {
+        a.reverse[c] = reverse[c];
+        for (int l = 0; l < nlayers; ++l) {
+            GruStackLayer& L = a.lc[c][l];
+            const int i = c * nlayers + l;
+            L.gi = l == 0 ? gi0[c] : nullptr;
+            L.w_ih = l > 0 ? w_ih[i] : nullptr; L.b_ih = l > 0 ? b_ih[i] : nullptr;
+            L.w_hh = w_hh[i]; L.b_hh = b_hh[i]; L.hs = hs[i]; L.save = save ? save[i] : nullptr;
+        }
+    }
+    a.seq_len = seq_len; a.B = B; a.T = T; a.nchains = nchains; a.nlayers = nlayers;
+    dim3 grid(H / 16, (B + 15) / 16, nchains * nlayers);
+    if (granule_ring_xcd()) {                       // one ring (chain, layer, batch tile) per XCD: block id % 8 == ring % 8
+        a.nby = (B + 15) / 16;
+        a.ring_xcd = (a.nby * nchains * nlayers + 7) / 8 * 8;
+        grid = dim3(H / 16 * a.ring_xcd, 1, 1);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    switch (H) {
+        case 64: hipLaunchKernelGGL((gru_granule_fwd_kernel<1, 4>), grid, dim3(256), 0, s, a, granules, epoch, err_flag); break;
+        case 128: hipLaunchKernelGGL((gru_granule_fwd_kernel<1, 8>), grid, dim3(512), 0, s, a, granules, epoch, err_flag); break;
+        case 256: hipLaunchKernelGGL((gru_granule_fwd_kernel<2, 8>), grid, dim3(512), 0, s, a, granules, epoch, err_flag); break;
+        default: hipLaunchKernelGGL((gru_granule_fwd_kernel<4, 8>), grid, dim3(512), 0, s, a, granules, epoch, err_flag); break;
+    }
+    return check_launch("gru_stack_fwd_granule");
+}
+
+// Granule-exchange persistent BPTT.  granules: device uint64 [nchains*nlayers][T][B][H] (zero before first use).
+int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
+                                const float* const* hs, const float* const* save, const float* const* dy_top,
+                                float* const* dgi, float* const* dgh, const int* reverse, const int* seq_len, int B, int H,
+                                int T, unsigned long long* granules, unsigned int epoch, unsigned int* err_flag,
+                                void* stream) {
+    if (int e = stack_check(nchains, nlayers, B, H, T)) return e;
+    if (epoch == 0 || !granules || !err_flag) { set_error("gru_stack_bwd_granule: need workspace and epoch != 0"); return PBSED_E_ARG; }
+    GruStackArgs a{};
+    for (int c = 0; c < nchains; ++c) {
+        a.reverse[c] = reverse[c];
+        for (int l = 0; l < nlayers; ++l) {
+            GruStackLayer& L = a.lc[c][l];
+            const int i = c * nlayers + l;
+            L.w_hh = w_hh_t[i]; L.w_ih = l < nlayers - 1 ? w_ih_up_t[i] : nullptr;
+            L.hs = const_cast<float*>(hs[i]); L.save = const_cast<float*>(save[i]);
+            L.dy = l == nlayers - 1 ? dy_top[c] : nullptr;
+            L.dgi = dgi[i]; L.dgh = dgh[i];
+        }
+    }
+    a.seq_len = seq_len; a.B = B; a.T = T; a.nchains = nchains; a.nlayers = nlayers;
+    a.debug = getenv("PBSED_GRU_DEBUG") ? atoi(getenv("PBSED_GRU_DEBUG")) : 0;
+    dim3 grid(H / 16, (B + 15) / 16, nchains * nlayers);
+    if (granule_ring_xcd()) {                       // one ring (chain, layer, batch tile) per XCD: block id % 8 == ring % 8
+        a.nby = (B + 15) / 16;
+        a.ring_xcd = (a.nby * nchains * nlayers + 7) / 8 * 8;
+        grid = dim3(H / 16 * a.ring_xcd, 1, 1);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    switch (H) {
+        case 64: hipLaunchKernelGGL((gru_granule_bwd_kernel<1, 4>), grid, dim3(256), 0, s, a, granules, epoch, err_flag); break;
+        case 128: hipLaunchKernelGGL((gru_granule_bwd_kernel<1, 8>), grid, dim3(512), 0, s, a, granules, epoch, err_flag); break;
+        case 256: hipLaunchKernelGGL((gru_granule_bwd_kernel<2, 8>), grid, dim3(512), 0, s, a, granules, epoch, err_flag); break;
+        default: hipLaunchKernelGGL((gru_granule_bwd_kernel<4, 8>), grid, dim3(512), 0, s, a, granules, epoch, err_flag); break;
+    }
+    return check_launch("gru_stack_bwd_granule");
 }
 
 // BPTT of the same stacks.  w_hh_t[i] = W_hh^T [H][3H]; w_ih_up_t[i] = (W_ih of layer l+1)^T [H][3H] (ignored

@@ -5,6 +5,7 @@ current stream.  Shapes follow the reference layouts: 2-D activations ``[B, C, F
 ``[B, C, T]`` (treated as F = 1), GRU scan buffers time-major ``[T, B, *]``.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -248,6 +249,7 @@ def gru_scan_bwd(w_hh_t, hs, save, dy, reverse, seq_len):
     return dgi, dgh
 
 
+_GRANULE_WS = {}        # (device, shape) -> [granule workspace, epoch counter] of the persistent GRU scan
 _GRU_SYNC = []          # every sync workspace handed to a persistent scan (word 0 = error flag)
 
 
@@ -267,6 +269,11 @@ def check_gru_sync():
         raise RuntimeError('persistent GRU scan: inter-workgroup hand-off timed out (PBSED_GRU_PERSIST=0 disables it)')
 
 
+def _granule_scan(nch, nlayers, b, h):
+    """Persistent granule-exchange scans need every workgroup co-resident (one per CU, 256 CUs)."""
+    return os.environ.get('PBSED_GRU_PERSIST') == '2' and nch * nlayers * ((b + 15) // 16) * (h // 16) <= 192
+
+
 def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=True):
     """Layer-wavefront scan of unidirectional stacks.  gi0: per chain [T,B,3H]; weight lists are indexed
     [chain*nlayers + layer] (w_ih/b_ih entries of layer 0 may be None).  Returns (hs, save) lists."""
@@ -276,7 +283,21 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
     dev = gi0[0].device
     n = nch * nlayers
     hs = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
-    sv = [torch.empty((t, b, 4, h), device=dev, dtype=torch.float32) for _ in range(n)] if save else None
+    gran = _granule_scan(nch, nlayers, b, h)
+    # saved per step: (r, z, n, gh_n), or in granule mode the five factors BPTT multiplies dh_t with
+    sv = [torch.empty((t, b, 5 if gran else 4, h), device=dev, dtype=torch.float32) for _ in range(n)] if save else None
+    if gran:
+        key = (str(dev), n, t, b, h)
+        gw = _GRANULE_WS.get(key)
+        if gw is None:
+            gw = _GRANULE_WS[key] = [torch.zeros(n * t * b * h, dtype=torch.int64, device=dev), 0]
+        gw[1] += 1                                   # fresh epoch: stale tags of earlier calls never match
+        ws = _gru_sync_ws(dev, 0)
+        call('pbsed_gru_stack_fwd_granule', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih),
+             _lib.ptr_array(b_ih), _lib.ptr_array(w_hh), _lib.ptr_array(b_hh), _lib.ptr_array(hs),
+             _lib.ptr_array(sv) if save else None, _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]),
+             gw[1] & 0x7FFFFFFF or 1, ptr(ws), stream())
+        return hs, sv
     ws = _gru_sync_ws(dev, nch * nlayers * ((b + 15) // 16))
     call('pbsed_gru_stack_fwd', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih), _lib.ptr_array(b_ih),
          _lib.ptr_array(w_hh), _lib.ptr_array(b_hh), _lib.ptr_array(hs), _lib.ptr_array(sv) if save else None,
@@ -291,6 +312,18 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
     n = nch * nlayers
     dgi = [torch.empty((t, b, 3 * h), device=dev, dtype=torch.float32) for _ in range(n)]
     dgh = [torch.empty((t, b, 3 * h), device=dev, dtype=torch.float32) for _ in range(n)]
+    if _granule_scan(nch, nlayers, b, h):
+        assert save[0].shape[2] == 5, 'granule BPTT needs the granule forward scan\'s save format'
+        key = (str(dev), 'bwd', n, t, b, h)
+        gw = _GRANULE_WS.get(key)
+        if gw is None:
+            gw = _GRANULE_WS[key] = [torch.zeros(n * t * b * h, dtype=torch.int64, device=dev), 0]
+        gw[1] += 1
+        ws = _gru_sync_ws(dev, 0)
+        call('pbsed_gru_stack_bwd_granule', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t),
+             _lib.ptr_array(hs), _lib.ptr_array(save), _lib.ptr_array(dy_top), _lib.ptr_array(dgi), _lib.ptr_array(dgh),
+             _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]), gw[1] & 0x7FFFFFFF or 1, ptr(ws), stream())
+        return dgi, dgh
     dhz = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
     ws = _gru_sync_ws(dev, nch * nlayers * ((b + 15) // 16))
     call('pbsed_gru_stack_bwd', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t), _lib.ptr_array(hs),
