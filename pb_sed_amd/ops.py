@@ -271,7 +271,7 @@ def check_gru_sync():
 
 def _granule_scan(nch, nlayers, b, h):
     """Persistent granule-exchange scans need every workgroup co-resident (one per CU, 256 CUs)."""
-    return os.environ.get('PBSED_GRU_PERSIST') == '2' and nch * nlayers * ((b + 15) // 16) * (h // 16) <= 192
+    return os.environ.get('PBSED_GRU_PERSIST', '2') == '2' and nch * nlayers * ((b + 15) // 16) * (h // 16) <= 192
 
 
 def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=True):

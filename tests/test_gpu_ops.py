@@ -271,11 +271,14 @@ def test_adam_and_grad_norm_vs_torch():
     close(p, pr, atol=1e-6, rtol=1e-5, name='adam params after 3 steps')
 
 
+@pytest.mark.parametrize('persist', ['2', '0'])
 @pytest.mark.parametrize('b,h,t,ragged', [(5, 64, 23, True), (32, 256, 30, False), (19, 128, 17, True)])
-def test_gru_stack_wavefront_vs_torch(b, h, t, ragged):
-    """2-layer forward + time-reversed stacks (layer wavefront) vs the oracle wrapper around nn.GRU."""
+def test_gru_stack_wavefront_vs_torch(b, h, t, ragged, persist, monkeypatch):
+    """2-layer forward + time-reversed stacks vs the oracle wrapper around nn.GRU, through both scan
+    implementations: persistent granule exchange ('2', default) and one launch per step ('0')."""
     from oracle import nn as onn
     from pb_sed_amd import ops
+    monkeypatch.setenv('PBSED_GRU_PERSIST', persist)
     torch.manual_seed(4)
     cin, nl = 24, 2
     seq = np.sort(np.random.RandomState(1).randint(t // 2, t + 1, b))[::-1].copy() if ragged else np.full(b, t)
