@@ -499,57 +499,33 @@ __global__ __launch_bounds__(NW * 64) void gru_persist_bwd_kernel(GruStackArgs a
 // all tags equal the call's epoch (cdna_hip_programming.md Guideline 16, form R2: no fence, no drain, no
 // counter).  W fragments stay in registers for all T steps, the previous state of a thread's own unit too.
 // ============================================================================================
-__device__ __forceinline__ float4 poll_granules4(const gu64* g, unsigned epoch, bool valid, unsigned* err_flag) {
-    unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (int spin = 0;; ++spin) {
-        bool ok = true;
-        if (valid) {
-            a0 = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a2 = __hip_atomic_load(g + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a3 = __hip_atomic_load(g + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok = (unsigned)(a0 >> 32) == epoch && (unsigned)(a1 >> 32) == epoch && (unsigned)(a2 >> 32) == epoch &&
-                 (unsigned)(a3 >> 32) == epoch;
-        }
-        if (__all(ok)) break;
-        if (spin > (1 << 18)) {                     // bounded: raise the error flag and go on with garbage
-            __hip_atomic_store((gu32*)err_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return make_float4(__uint_as_float((unsigned)a0), __uint_as_float((unsigned)a1), __uint_as_float((unsigned)a2),
-                       __uint_as_float((unsigned)a3));
-}
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
-// All granule loads of a step are issued before any tag is looked at: one fabric round trip per step instead of
-// one per K block (agent-scope loads miss the per-XCD L2 by construction).
-template <int NBLK>
-__device__ __forceinline__ void poll_batch(float4 (&out)[NBLK], const gu64* row, int kblk0, int nblk, int lq, unsigned epoch,
-                                           bool valid, unsigned* err_flag) {
-    unsigned long long q[NBLK][4];
+// Position of hidden unit u (0..15 within its block of 16) in the granule scans' save arrays: the four units
+// {lq*2, lq*2+1, 8+lq*2, 8+lq*2+1} whose granules lane group lq polls sit next to each other (one float4).
+__device__ __forceinline__ int save_pos16(int u) { return ((u >> 1) & 3) * 4 + (u >> 3) * 2 + (u & 1); }
+
+// One wave polls the granules of its K range [k0, k0 + 8*nl) for 16 batch rows with 16-byte write-through-visible
+// (sc1) buffer loads: lane (lq, lr) reads, per load n, the two granules k0 + n*8 + lq*2 + {0,1} of row lr, so one
+// instruction fetches whole 32-byte sectors (16 rows x 64 B) and nothing is fetched twice.  All loads of a step are
+// issued before any tag is looked at (one fabric round trip per step); out[n] = the two values.
+template <int NL>
+__device__ __forceinline__ void poll_batch(float2 (&out)[NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, int nl, unsigned epoch,
+                                           bool valid, unsigned* err_flag, int dbg = 0) {
+    u32x4_t q[NL];
 #pragma unroll
-    for (int i = 0; i < NBLK; ++i) q[i][0] = q[i][1] = q[i][2] = q[i][3] = 0;
+    for (int n = 0; n < NL; ++n) q[n] = u32x4_t{0u, 0u, 0u, 0u};
     for (int spin = 0;; ++spin) {
         bool ok = true;
         if (valid) {
 #pragma unroll
-            for (int i = 0; i < NBLK; ++i) {
-                if (i < nblk) {
-                    const gu64* g = row + (kblk0 + i) * 16 + lq * 4;
+            for (int n = 0; n < NL; ++n)
+                if (n < nl) q[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + n * 64, 0, /*aux = sc1*/ 16);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) q[i][e] = __hip_atomic_load(g + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NBLK; ++i) {
-                if (i < nblk) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ok = ok && (unsigned)(q[i][e] >> 32) == epoch;
-                }
-            }
+            for (int n = 0; n < NL; ++n)
+                if (n < nl) ok = ok && q[n].y == epoch && q[n].w == epoch;
         }
-        if (__all(ok)) break;
+        if (__all(ok) || (dbg & 32)) break;
         if (spin > (1 << 18)) {                     // bounded: raise the error flag and go on with garbage
             __hip_atomic_store((gu32*)err_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
@@ -557,31 +533,13 @@ __device__ __forceinline__ void poll_batch(float4 (&out)[NBLK], const gu64* row,
         if (spin > 8) __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll
-    for (int i = 0; i < NBLK; ++i)
-        out[i] = make_float4(__uint_as_float((unsigned)q[i][0]), __uint_as_float((unsigned)q[i][1]),
-                             __uint_as_float((unsigned)q[i][2]), __uint_as_float((unsigned)q[i][3]));
-}
-
-template <int NB, int NG>
-__device__ __forceinline__ void mm_gran(f32x4 (&acc)[NG], const float4 (&wv)[NB][NG], const gu64* v, bool vvalid, int kblk0,
-                                        int lq, unsigned epoch, unsigned* err_flag) {
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const float4 x = poll_granules4(v + (kblk0 + i) * 16 + lq * 4, epoch, vvalid, err_flag);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            acc[g] = mfma16(wv[i][g].x, x.x, acc[g]);
-            acc[g] = mfma16(wv[i][g].y, x.y, acc[g]);
-            acc[g] = mfma16(wv[i][g].z, x.z, acc[g]);
-            acc[g] = mfma16(wv[i][g].w, x.w, acc[g]);
-        }
-    }
+    for (int n = 0; n < NL; ++n) out[n] = make_float2(__uint_as_float(q[n].x), __uint_as_float(q[n].z));
 }
 
 template <int KB, int NW>
 __global__ __launch_bounds__(NW * 64) void gru_granule_fwd_kernel(GruStackArgs a, unsigned long long* gran_, unsigned epoch,
                                                                  unsigned* err_flag) {
-    constexpr int H = KB * NW * 16, HW = NW / 2, NB = 2 * KB;
+    constexpr int H = KB * NW * 16, HW = NW / 2, NL = 4 * KB;   // NL: 16-byte loads per lane (8 k each) of a half-H range
     __shared__ float red[2][NW][3][64][4];
     __shared__ int s_err;
     gu64* gran = (gu64*)gran_;
@@ -597,8 +555,9 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_fwd_kernel(GruStackArgs a
     const int j0 = bx * 16, b0 = by * 16, B = a.B;
     const bool rev = a.reverse[chain] != 0;
     const size_t per_cl = (size_t)a.T * B * H;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(gran_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 8), 0x00020000);
     gu64* g_own = gran + (size_t)(chain * a.nlayers + layer) * per_cl;
-    const gu64* g_lo = layer > 0 ? gran + (size_t)(chain * a.nlayers + layer - 1) * per_cl : nullptr;
     const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
     const bool bv = tid < 256 && b < B;
     const bool rowv = (b0 + lr) < B;
@@ -606,20 +565,23 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_fwd_kernel(GruStackArgs a
     float bi_r = 0.f, bi_z = 0.f, bi_n = 0.f;
     if (layer > 0) { bi_r = L.b_ih[j0 + u]; bi_z = L.b_ih[H + j0 + u]; bi_n = L.b_ih[2 * H + j0 + u]; }
     const int sl = bv ? a.seq_len[b] : 0;
-    // wave -> operand stream and K range (layer 0: all waves split W_hh; above: half W_hh, half W_ih)
+    // wave -> operand stream and K range (layer 0: all waves split W_hh; above: half W_hh, half W_ih); within the
+    // range a lane owns k = k0 + n*8 + lq*2 + {0,1} (the granule load pattern), weights follow the same permutation
     const bool is_ih = layer > 0 && wave >= HW;
-    const int nblk = layer == 0 ? KB : NB;
-    const int kblk0 = layer == 0 ? wave * KB : (is_ih ? wave - HW : wave) * NB;
-    float4 wv[NB][3];
+    const int nl = layer == 0 ? NL / 2 : NL;
+    const int k0 = (layer == 0 ? wave : (is_ih ? wave - HW : wave)) * nl * 8;
+    float2 wv[NL][3];
     {
-        const float* W = (is_ih ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * H;
+        const float* W = (is_ih ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * H + k0 + lq * 2;
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
+        for (int n = 0; n < NL; ++n)
 #pragma unroll
             for (int g = 0; g < 3; ++g)
-                wv[i][g] = (i < nblk) ? *reinterpret_cast<const float4*>(W + (size_t)g * H * H + (kblk0 + i) * 16 + lq * 4)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                wv[n][g] = (n < nl) ? *reinterpret_cast<const float2*>(W + (size_t)g * H * H + n * 8) : make_float2(0.f, 0.f);
     }
+    // byte offset of this lane's first granule pair in the ring it reads, without the time index
+    const unsigned cl_src = chain * a.nlayers + (is_ih ? layer - 1 : layer);
+    const unsigned voff0 = (unsigned)((((size_t)cl_src * a.T * B + b0 + lr) * H + k0 + lq * 2) * 8);
     float h_reg = 0.f;
     if (tid == 0) s_err = 0;
     __syncthreads();
@@ -637,18 +599,16 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_fwd_kernel(GruStackArgs a
         if (tid == 0 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
         f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         if (is_ih || has_prev) {
-            const gu64* src = is_ih ? g_lo + ((size_t)t * B + b0 + lr) * H : g_own + ((size_t)tp * B + b0 + lr) * H;
-            float4 x[NB];
-            poll_batch<NB>(x, src, kblk0, nblk, lq, epoch, rowv, err_flag);
+            float2 x[NL];
+            poll_batch<NL>(x, rsrc, voff0 + (unsigned)(is_ih ? t : tp) * (unsigned)(B * H * 8), nl, epoch,
+                           rowv && !(a.debug & 64), err_flag, a.debug);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                if (i < nblk) {
+            for (int n = 0; n < NL; ++n) {
+                if (n < nl) {
 #pragma unroll
                     for (int g = 0; g < 3; ++g) {
-                        acc[g] = mfma16(wv[i][g].x, x[i].x, acc[g]);
-                        acc[g] = mfma16(wv[i][g].y, x[i].y, acc[g]);
-                        acc[g] = mfma16(wv[i][g].z, x[i].z, acc[g]);
-                        acc[g] = mfma16(wv[i][g].w, x[i].w, acc[g]);
+                        acc[g] = mfma16(wv[n][g].x, x[n].x, acc[g]);
+                        acc[g] = mfma16(wv[n][g].y, x[n].y, acc[g]);
                     }
                 }
             }
@@ -680,26 +640,26 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_fwd_kernel(GruStackArgs a
             const size_t tb = (size_t)t * B + b;
             __hip_atomic_store(g_own + tb * H + j, ((unsigned long long)epoch << 32) | __float_as_uint(h), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-            L.hs[tb * H + j] = h;
-            if (L.save) {
+            if (!(a.debug & 128)) L.hs[tb * H + j] = h;
+            if (L.save && !(a.debug & 128)) {
                 // what BPTT multiplies dh_t with: d(r,z,n pre-activations)/dh, d(gh_n)/dh and z (granule save format)
-                float* sv = L.save + tb * 5 * H;
+                float* sv = L.save + tb * 5 * H + j0 + save_pos16(u);
                 const float cn = (1.f - z) * (1.f - n * n);
-                sv[j] = cn * ghn * r * (1.f - r); sv[H + j] = (hp - n) * z * (1.f - z); sv[2 * H + j] = cn;
-                sv[3 * H + j] = cn * r; sv[4 * H + j] = z;
+                sv[0] = cn * ghn * r * (1.f - r); sv[H] = (hp - n) * z * (1.f - z); sv[2 * H] = cn;
+                sv[3 * H] = cn * r; sv[4 * H] = z;
             }
         }
     }
 }
 
 // Backward twin: every step publishes dh_t (masked by the sequence length) of its 16 units as granules
-// [T][B][H].  Consumers rebuild the gate gradients they contract with from dh and the saved gates, which are
-// plain loads issued before the poll, so only one granule per (row, unit) sits on the hand-off path; dh*z of a
-// thread's own unit stays in a register.
+// [T][B][H].  Consumers rebuild the gate gradients they contract with as dh * (factor saved by the forward scan);
+// the factors are plain loads issued one step ahead, so only one granule per (row, unit) sits on the hand-off
+// path; dh*z of a thread's own unit stays in a register.
 template <int KB, int NW>
 __global__ __launch_bounds__(NW * 64) void gru_granule_bwd_kernel(GruStackArgs a, unsigned long long* gran_, unsigned epoch,
                                                                  unsigned* err_flag) {
-    constexpr int H = KB * NW * 16, G = 3 * H, HW = NW / 2, JB = 2 * KB;
+    constexpr int H = KB * NW * 16, G = 3 * H, HW = NW / 2, NL = 4 * KB;
     __shared__ float red[2][NW][64][4];
     __shared__ int s_err;
     gu64* gran = (gu64*)gran_;
@@ -716,35 +676,38 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_bwd_kernel(GruStackArgs a
     const int j0 = bx * 16, b0 = by * 16, B = a.B;
     const bool rev = a.reverse[chain] != 0;
     const size_t per_cl = (size_t)a.T * B * H;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(gran_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 8), 0x00020000);
     gu64* g_own = gran + (size_t)(chain * a.nlayers + layer) * per_cl;
     const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
     const bool bv = tid < 256 && b < B;
     const bool rowv = (b0 + lr) < B;
     const int sl = bv ? a.seq_len[b] : 0;
+    // wave -> ring whose dh it contracts with: own (carry through W_hh) or the layer above (input gradient through
+    // W_ih of that layer) and a range of hidden units jj = k0 + n*8 + lq*2 + {0,1} (the granule load pattern)
     const bool is_up = layer < top && wave >= HW;
-    const int nj = layer == top ? KB : JB;
-    const int jb0 = layer == top ? wave * KB : (is_up ? wave - HW : wave) * JB;
-    // the ring whose dh this wave contracts with: own (carry) or the layer above (input gradient)
+    const int nl = layer == top ? NL / 2 : NL;
+    const int k0 = (layer == top ? wave : (is_up ? wave - HW : wave)) * nl * 8;
     const GruStackLayer& X = is_up ? a.lc[chain][layer + 1] : L;
-    const gu64* g_x = is_up ? gran + (size_t)(chain * a.nlayers + layer + 1) * per_cl : g_own;
-    float4 wv[JB][3];
+    float2 wv[NL][3];
     {
-        const float* W = (is_up ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * G;
+        const float* W = (is_up ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * G + k0 + lq * 2;
 #pragma unroll
-        for (int i = 0; i < JB; ++i)
+        for (int n = 0; n < NL; ++n)
 #pragma unroll
             for (int g = 0; g < 3; ++g)
-                wv[i][g] = (i < nj) ? *reinterpret_cast<const float4*>(W + g * H + (jb0 + i) * 16 + lq * 4)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                wv[n][g] = (n < nl) ? *reinterpret_cast<const float2*>(W + g * H + n * 8) : make_float2(0.f, 0.f);
     }
+    const unsigned cl_src = chain * a.nlayers + (is_up ? layer + 1 : layer);
+    const unsigned voff0 = (unsigned)((((size_t)cl_src * a.T * B + b0 + lr) * H + k0 + lq * 2) * 8);
     float dhz_prev = 0.f;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid == 0) s_err = 0;
     __syncthreads();
 
-    // saved gates of the step whose gate gradients this wave rebuilds (tn of the own ring, whose h_prev is hs[t];
-    // t of the layer above) and of the thread's own unit: loaded one step ahead, off the hand-off path
-    float4 pr[JB], pz[JB], pn[JB];
+    // factors of the step whose gate gradients this wave rebuilds (tn of the own ring, t of the layer above) and
+    // of the thread's own unit: loaded one step ahead, off the hand-off path
+    float4 pr[NL / 2], pz[NL / 2], pn[NL / 2];
     float c_r = 0.f, c_z = 0.f, c_n = 0.f, c_nr = 0.f, z = 0.f, dyv = 0.f;
     auto load_operands = [&](int bs) {
         const int s = a.T - 1 - bs;
@@ -752,13 +715,13 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_bwd_kernel(GruStackArgs a
         const int tx = is_up ? t : (rev ? t - 1 : t + 1);
         const bool act = (is_up || bs > 0) && rowv && !(a.debug & 8);
 #pragma unroll
-        for (int i = 0; i < JB; ++i) {
-            pr[i] = pz[i] = pn[i] = zero4;
-            if (i < nj && act) {
-                const float* sv = X.save + ((size_t)tx * B + b0 + lr) * 5 * H + (jb0 + i) * 16 + lq * 4;
-                pr[i] = *reinterpret_cast<const float4*>(sv);
-                pz[i] = *reinterpret_cast<const float4*>(sv + H);
-                pn[i] = *reinterpret_cast<const float4*>(sv + (is_up ? 2 : 3) * H);
+        for (int m = 0; m < NL / 2; ++m) {
+            pr[m] = pz[m] = pn[m] = zero4;
+            if (2 * m < nl && act) {
+                const float* sv = X.save + ((size_t)tx * B + b0 + lr) * 5 * H + k0 + m * 16 + lq * 4;
+                pr[m] = *reinterpret_cast<const float4*>(sv);
+                pz[m] = *reinterpret_cast<const float4*>(sv + H);
+                pn[m] = *reinterpret_cast<const float4*>(sv + (is_up ? 2 : 3) * H);
             }
         }
     };
@@ -767,8 +730,8 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_bwd_kernel(GruStackArgs a
         const int t = rev ? a.T - 1 - s : s;
         if (bv) {
             const size_t tb = (size_t)t * B + b;
-            const float* sv = L.save + tb * 5 * H;
-            c_r = sv[j]; c_z = sv[H + j]; c_n = sv[2 * H + j]; c_nr = sv[3 * H + j]; z = sv[4 * H + j];
+            const float* sv = L.save + tb * 5 * H + j0 + save_pos16(u);
+            c_r = sv[0]; c_z = sv[H]; c_n = sv[2 * H]; c_nr = sv[3 * H]; z = sv[4 * H];
             if (layer == top) dyv = L.dy[tb * H + j];
         }
     };
@@ -785,24 +748,21 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_bwd_kernel(GruStackArgs a
         if (tid == 0 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
         f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         if (is_up || has_next) {
-            const int tx = is_up ? t : tn;
-            float4 dh4[JB];
-            poll_batch<JB>(dh4, g_x + ((size_t)tx * B + b0 + lr) * H, jb0, nj, lq, epoch, rowv, err_flag);
+            float2 dh2[NL];
+            poll_batch<NL>(dh2, rsrc, voff0 + (unsigned)(is_up ? t : tn) * (unsigned)(B * H * 8), nl, epoch, rowv, err_flag);
 #pragma unroll
-            for (int i = 0; i < JB; ++i) {
-                if (i < nj) {
-                    acc[0] = mfma16(wv[i][0].x, dh4[i].x * pr[i].x, acc[0]);
-                    acc[1] = mfma16(wv[i][1].x, dh4[i].x * pz[i].x, acc[1]);
-                    acc[2] = mfma16(wv[i][2].x, dh4[i].x * pn[i].x, acc[2]);
-                    acc[0] = mfma16(wv[i][0].y, dh4[i].y * pr[i].y, acc[0]);
-                    acc[1] = mfma16(wv[i][1].y, dh4[i].y * pz[i].y, acc[1]);
-                    acc[2] = mfma16(wv[i][2].y, dh4[i].y * pn[i].y, acc[2]);
-                    acc[0] = mfma16(wv[i][0].z, dh4[i].z * pr[i].z, acc[0]);
-                    acc[1] = mfma16(wv[i][1].z, dh4[i].z * pz[i].z, acc[1]);
-                    acc[2] = mfma16(wv[i][2].z, dh4[i].z * pn[i].z, acc[2]);
-                    acc[0] = mfma16(wv[i][0].w, dh4[i].w * pr[i].w, acc[0]);
-                    acc[1] = mfma16(wv[i][1].w, dh4[i].w * pz[i].w, acc[1]);
-                    acc[2] = mfma16(wv[i][2].w, dh4[i].w * pn[i].w, acc[2]);
+            for (int n = 0; n < NL; ++n) {
+                if (n < nl) {
+                    const int m = n >> 1;
+                    const float fr0 = (n & 1) ? pr[m].z : pr[m].x, fr1 = (n & 1) ? pr[m].w : pr[m].y;
+                    const float fz0 = (n & 1) ? pz[m].z : pz[m].x, fz1 = (n & 1) ? pz[m].w : pz[m].y;
+                    const float fn0 = (n & 1) ? pn[m].z : pn[m].x, fn1 = (n & 1) ? pn[m].w : pn[m].y;
+                    acc[0] = mfma16(wv[n][0].x, dh2[n].x * fr0, acc[0]);
+                    acc[1] = mfma16(wv[n][1].x, dh2[n].x * fz0, acc[1]);
+                    acc[2] = mfma16(wv[n][2].x, dh2[n].x * fn0, acc[2]);
+                    acc[0] = mfma16(wv[n][0].y, dh2[n].y * fr1, acc[0]);
+                    acc[1] = mfma16(wv[n][1].y, dh2[n].y * fz1, acc[1]);
+                    acc[2] = mfma16(wv[n][2].y, dh2[n].y * fn1, acc[2]);
                 }
             }
         }
@@ -945,6 +905,7 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
                                 void* stream) {
     if (int e = stack_check(nchains, nlayers, B, H, T)) return e;
     if (epoch == 0 || !granules || !err_flag) { set_error("gru_stack_fwd_granule: need workspace and epoch != 0"); return PBSED_E_ARG; }
+    if ((size_t)nchains * nlayers * T * B * H * 8 >= (1ull << 32)) { set_error("gru_stack_fwd_granule: workspace over 4 GiB"); return PBSED_E_ARG; }
     GruStackArgs a{};
     for (int c = 0; c < nchains; ++c) {
         a.reverse[c] = reverse[c];
@@ -957,6 +918,7 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
         }
     }
     a.seq_len = seq_len; a.B = B; a.T = T; a.nchains = nchains; a.nlayers = nlayers;
+    a.debug = getenv("PBSED_GRU_DEBUG") ? atoi(getenv("PBSED_GRU_DEBUG")) : 0;
     dim3 grid(H / 16, (B + 15) / 16, nchains * nlayers);
     if (granule_ring_xcd()) {                       // one ring (chain, layer, batch tile) per XCD: block id % 8 == ring % 8
         a.nby = (B + 15) / 16;
@@ -981,6 +943,7 @@ int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_
                                 void* stream) {
     if (int e = stack_check(nchains, nlayers, B, H, T)) return e;
     if (epoch == 0 || !granules || !err_flag) { set_error("gru_stack_bwd_granule: need workspace and epoch != 0"); return PBSED_E_ARG; }
+    if ((size_t)nchains * nlayers * T * B * H * 8 >= (1ull << 32)) { set_error("gru_stack_bwd_granule: workspace over 4 GiB"); return PBSED_E_ARG; }
     GruStackArgs a{};
     for (int c = 0; c < nchains; ++c) {
         a.reverse[c] = reverse[c];

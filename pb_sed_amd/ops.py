@@ -269,9 +269,10 @@ def check_gru_sync():
         raise RuntimeError('persistent GRU scan: inter-workgroup hand-off timed out (PBSED_GRU_PERSIST=0 disables it)')
 
 
-def _granule_scan(nch, nlayers, b, h):
+def _granule_scan(nch, nlayers, b, h, t):
     """Persistent granule-exchange scans need every workgroup co-resident (one per CU, 256 CUs)."""
-    return os.environ.get('PBSED_GRU_PERSIST', '2') == '2' and nch * nlayers * ((b + 15) // 16) * (h // 16) <= 192
+    return (os.environ.get('PBSED_GRU_PERSIST', '2') == '2' and nch * nlayers * ((b + 15) // 16) * (h // 16) <= 192
+            and nch * nlayers * t * b * h * 8 < 2 ** 32)
 
 
 def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=True):
@@ -283,7 +284,7 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
     dev = gi0[0].device
     n = nch * nlayers
     hs = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
-    gran = _granule_scan(nch, nlayers, b, h)
+    gran = _granule_scan(nch, nlayers, b, h, t)
     # saved per step: (r, z, n, gh_n), or in granule mode the five factors BPTT multiplies dh_t with
     sv = [torch.empty((t, b, 5 if gran else 4, h), device=dev, dtype=torch.float32) for _ in range(n)] if save else None
     if gran:
@@ -312,7 +313,7 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
     n = nch * nlayers
     dgi = [torch.empty((t, b, 3 * h), device=dev, dtype=torch.float32) for _ in range(n)]
     dgh = [torch.empty((t, b, 3 * h), device=dev, dtype=torch.float32) for _ in range(n)]
-    if _granule_scan(nch, nlayers, b, h):
+    if _granule_scan(nch, nlayers, b, h, t):
         assert save[0].shape[2] == 5, 'granule BPTT needs the granule forward scan\'s save format'
         key = (str(dev), 'bwd', n, t, b, h)
         gw = _GRANULE_WS.get(key)
