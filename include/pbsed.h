@@ -127,6 +127,12 @@ int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_
 int pbsed_bct_to_tbc(const float* src, float* dst, int B, int C, int T, void* stream);
 int pbsed_tbc_to_bct(const float* src, float* dst, int B, int C, int T, int shift, void* stream);
 int pbsed_transpose2d(const float* src, float* dst, int R, int C, void* stream);
+/* Weight / bias gradients of n GRU matrices from the scans' time-major buffers (nn.GRU backward,
+ * pb_sed/models/base.py:64-68): dw[i][g][k] += sum_{t,b} dg[i][t][b][g] * x[i][t+shift[i]][b][k] (rows outside
+ * [0,T) are zero), db[i][g] += sum_{t,b} dg[i][t][b][g] (db or db[i] may be NULL).  dg: [T,B,G], x: [T,B,K];
+ * pointer tables and shift are host arrays; G, K multiples of 4. */
+int pbsed_gru_wgrad(int n, const float* const* dg, const float* const* x, const int* shift /*host*/,
+                    float* const* dw, float* const* db, int T, int B, int G, int K, void* stream);
 
 /* ---- heads' squash + losses (pb_sed/models/weak_label/crnn.py:58-59,107-206;
  * pb_sed/models/strong_label/crnn.py:93,106-112) */

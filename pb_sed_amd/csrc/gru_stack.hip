@@ -585,23 +585,31 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_fwd_kernel(GruStackArgs a
     float h_reg = 0.f;
     if (tid == 0) s_err = 0;
     __syncthreads();
+    float gn_r = bi_r, gn_z = bi_z, gn_n = bi_n;
+    auto load_gi = [&](int st) {
+        if (bv && layer == 0) {
+            const float* gi = L.gi + ((size_t)(rev ? a.T - 1 - st : st) * B + b) * 3 * H;
+            gn_r = gi[j]; gn_z = gi[H + j]; gn_n = gi[2 * H + j];
+        }
+    };
+    load_gi(0);
 
     for (int step = 0; step < a.T; ++step) {
         const int t = rev ? a.T - 1 - step : step;
         const int tp = rev ? t + 1 : t - 1;
         const bool has_prev = step > 0;
         const int par = step & 1;                     // `red` is double-buffered: one barrier per step
-        float gi_r = bi_r, gi_z = bi_z, gi_n = bi_n;
-        if (bv && layer == 0) {
-            const float* gi = L.gi + ((size_t)t * B + b) * 3 * H;
-            gi_r = gi[j]; gi_z = gi[H + j]; gi_n = gi[2 * H + j];
-        }
+        const float gi_r = gn_r, gi_z = gn_z, gi_n = gn_n;
         if (tid == 0 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
         f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        if (is_ih || has_prev) {
-            float2 x[NL];
+        float2 x[NL];
+        if (is_ih || has_prev)
             poll_batch<NL>(x, rsrc, voff0 + (unsigned)(is_ih ? t : tp) * (unsigned)(B * H * 8), nl, epoch,
                            rowv && !(a.debug & 64), err_flag, a.debug);
+        // next step's input projection: issued behind the poll (loads return in order, anything older would hold
+        // the poll back), lands during this step's gate phase
+        if (step + 1 < a.T) load_gi(step + 1);
+        if (is_ih || has_prev) {
 #pragma unroll
             for (int n = 0; n < NL; ++n) {
                 if (n < nl) {
@@ -709,6 +717,7 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_bwd_kernel(GruStackArgs a
     // of the thread's own unit: loaded one step ahead, off the hand-off path
     float4 pr[NL / 2], pz[NL / 2], pn[NL / 2];
     float c_r = 0.f, c_z = 0.f, c_n = 0.f, c_nr = 0.f, z = 0.f, dyv = 0.f;
+    float x_r = 0.f, x_z = 0.f, x_n = 0.f, x_nr = 0.f, x_zz = 0.f, x_dy = 0.f;    // the same for the next step
     auto load_operands = [&](int bs) {
         const int s = a.T - 1 - bs;
         const int t = rev ? a.T - 1 - s : s;
@@ -731,8 +740,8 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_bwd_kernel(GruStackArgs a
         if (bv) {
             const size_t tb = (size_t)t * B + b;
             const float* sv = L.save + tb * 5 * H + j0 + save_pos16(u);
-            c_r = sv[0]; c_z = sv[H]; c_n = sv[2 * H]; c_nr = sv[3 * H]; z = sv[4 * H];
-            if (layer == top) dyv = L.dy[tb * H + j];
+            x_r = sv[0]; x_z = sv[H]; x_n = sv[2 * H]; x_nr = sv[3 * H]; x_zz = sv[4 * H];
+            if (layer == top) x_dy = L.dy[tb * H + j];
         }
     };
     load_operands(0);
@@ -747,9 +756,12 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_bwd_kernel(GruStackArgs a
         const int par = bstep & 1;
         if (tid == 0 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
         f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        if (is_up || has_next) {
-            float2 dh2[NL];
+        c_r = x_r; c_z = x_z; c_n = x_n; c_nr = x_nr; z = x_zz; dyv = x_dy;
+        float2 dh2[NL];
+        if (is_up || has_next)
             poll_batch<NL>(dh2, rsrc, voff0 + (unsigned)(is_up ? t : tn) * (unsigned)(B * H * 8), nl, epoch, rowv, err_flag);
+        if (bstep + 1 < a.T) load_own(bstep + 1);       // behind the poll: loads return in order
+        if (is_up || has_next) {
 #pragma unroll
             for (int n = 0; n < NL; ++n) {
                 if (n < nl) {
@@ -794,7 +806,6 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_bwd_kernel(GruStackArgs a
                 dgh[j] = dr; dgh[H + j] = dz; dgh[2 * H + j] = dnr;
             }
         }
-        if (bstep + 1 < a.T) load_own(bstep + 1);
     }
 }
 

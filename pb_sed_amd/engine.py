@@ -240,22 +240,32 @@ def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     w_ih_up_t = [ops.transpose2d(ch.p('weight_ih', l + 1).detach()) if l + 1 < nl else None for ch, l in idx]
     dgi, dgh = ops.gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, [ch.reverse for ch in chains], seq_dev, nl)
     dh = None
+    jobs = {}                                    # K -> (dg, x, shift, dw, db) lists of one batched weight-gradient launch
+    h_tbc = None
     for ci, ch in enumerate(chains):
         for l in range(nl):
             i = ci * nl + l
-            dgi_b, dgh_b = ops.tbc_to_bct(dgi[i]), ops.tbc_to_bct(dgh[i])
-            hprev = ops.tbc_to_bct(hs[i], shift=1 if ch.reverse else -1)
-            x_in = h if l == 0 else ops.tbc_to_bct(hs[i - 1])
             w_hh, w_ih = ch.p('weight_hh', l), ch.p('weight_ih', l)
             if w_hh.requires_grad:
-                ops.conv_bwd_weight(hprev, dgh_b, PackedConv(w_hh.unsqueeze(-1)), _grad(w_hh), _grad(ch.p('bias_hh', l)))
+                _wgrad_job(jobs, dgh[i], hs[i], 1 if ch.reverse else -1, _grad(w_hh), _grad(ch.p('bias_hh', l)))
             if w_ih.requires_grad:
-                ops.conv_bwd_weight(x_in, dgi_b, PackedConv(w_ih.unsqueeze(-1)), _grad(w_ih), _grad(ch.p('bias_ih', l)))
+                if l == 0 and h_tbc is None:
+                    h_tbc = ops.bct_to_tbc(h)
+                _wgrad_job(jobs, dgi[i], h_tbc if l == 0 else hs[i - 1], 0, _grad(w_ih), _grad(ch.p('bias_ih', l)))
             if l == 0:
                 pr = _prec(precision, pcs0[ci].cin)
-                dx, _ = ops.conv_bwd_data(dgi_b, pcs0[ci], pcs0[ci].dgrad(pr), h.shape, precision=pr)
+                dx, _ = ops.conv_bwd_data(ops.tbc_to_bct(dgi[i]), pcs0[ci], pcs0[ci].dgrad(pr), h.shape, precision=pr)
                 dh = dx if dh is None else dh.add_(dx)
+    for job in jobs.values():
+        for a in range(0, len(job[0]), 16):
+            ops.gru_wgrad(*[v[a:a + 16] for v in job])
     return dh
+
+
+def _wgrad_job(jobs, dg, x, shift, dw, db):
+    job = jobs.setdefault(x.shape[2], ([], [], [], [], []))
+    for lst, v in zip(job, (dg, x, shift, dw, db)):
+        lst.append(v)
 
 
 def rnn_forward(wrappers, h, seq_dev, seq_host, training, precision='f32'):

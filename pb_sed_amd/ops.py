@@ -333,6 +333,16 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
     return dgi, dgh
 
 
+def gru_wgrad(dg, x, shift, dw, db):
+    """dw[i] += dg[i]^T x[i] (time shift shift[i] on x), db[i] += column sums of dg[i]; all time-major [T,B,*]."""
+    t, b, g = dg[0].shape
+    k = x[0].shape[2]
+    assert all(d.shape == (t, b, g) and d.is_contiguous() for d in dg) and all(v.shape == (t, b, k) and v.is_contiguous() for v in x)
+    assert all(w.shape == (g, k) and w.is_contiguous() for w in dw)
+    call('pbsed_gru_wgrad', len(dg), _lib.ptr_array(dg), _lib.ptr_array(x), _lib.int_array(shift), _lib.ptr_array(dw),
+         _lib.ptr_array(db), t, b, g, k, stream(), flops=2. * len(dg) * t * b * g * k)
+
+
 def squash_fwd(x, eps):
     y = torch.empty_like(x)
     call('pbsed_squash_fwd', ptr(x), ptr(y), x.numel(), float(eps), stream())

@@ -359,3 +359,31 @@ def test_conv_bf16_mfma_vs_torch(case, precision):
     if not pro and not pool:
         g, _ = ops.conv_bwd_data(dx(gy), pc, pc.dgrad(precision), xd.shape, None, None, precision=precision)
         close(g, xr.grad, name=f'conv_dgrad {precision}', **tol)
+
+
+@pytest.mark.parametrize('t,b,g,k', [(23, 5, 192, 24), (30, 32, 768, 256), (17, 19, 384, 128), (9, 3, 12, 8)])
+def test_gru_wgrad_vs_torch(t, b, g, k):
+    """Batched time-major weight/bias gradient GEMM (with the h_{t-1} / h_{t+1} row shift) vs fp64 einsum."""
+    from pb_sed_amd import ops
+    torch.manual_seed(7)
+    shifts = [0, -1, 1]
+    dg = [torch.randn(t, b, g) for _ in shifts]
+    x = [torch.randn(t, b, k) for _ in shifts]
+    dw0 = [torch.randn(g, k) for _ in shifts]
+    db0 = [torch.randn(g) for _ in shifts]
+    dw = [w.to(DEV) for w in dw0]
+    db = [v.to(DEV) for v in db0[:2]] + [None]
+    ops.gru_wgrad([d.to(DEV) for d in dg], [v.to(DEV) for v in x], shifts, dw, db)
+    for i, sh in enumerate(shifts):
+        xs = torch.zeros(t, b, k, dtype=torch.float64)
+        if sh == 0:
+            xs[:] = x[i]
+        elif sh < 0:
+            xs[1:] = x[i][:-1]
+        else:
+            xs[:-1] = x[i][1:]
+        ref = dw0[i].double() + torch.einsum('tbg,tbk->gk', dg[i].double(), xs)
+        close(dw[i], ref.float(), atol=2e-5 * (t * b) ** .5, rtol=1e-5, name=f'gru_wgrad dW shift {sh}')
+        if db[i] is not None:
+            close(db[i], (db0[i].double() + dg[i].double().sum((0, 1))).float(), atol=2e-5 * (t * b) ** .5, rtol=1e-5,
+                  name=f'gru_wgrad db shift {sh}')
