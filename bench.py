@@ -126,9 +126,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     _lib.timing = []                                          # per-call HIP events on the launch stream
+    ev_mode = os.environ.get('PBSED_BENCH_EVENTS', 'all' if os.environ.get('PBSED_BENCH_TABLE') else 'conv')
+    # HIP events bracket only the conv / front-end launches by default (what `roofline` needs): an event pair
+    # around each of the ~330 calls of a step costs ~1.3 ms/step of device idle time (PBSED_BENCH_EVENTS=all)
+    _lib.timing_filter = {'all': None, 'conv': (lambda n: n.startswith('pbsed_conv') or n == 'pbsed_logmel_fwd')}[ev_mode]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         review = trainer.step(batch)
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -181,6 +186,7 @@ def main():
                           'achieved_tflops_per_gpu': round(TRAIN_GFLOP_PER_CLIP * args.batch / 1e3 / (ms_step * 1e-3), 2),
                           'frac_of_fp32_mfma_peak': round(TRAIN_GFLOP_PER_CLIP * args.batch / 1e3 / (ms_step * 1e-3) / PEAK_FP32_MFMA_TFLOPS, 4)},
             'ms_per_step_by_entry_point': {k: round(v, 3) for k, v in sorted(by_family.items(), key=lambda kv: -kv[1])},
+            'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 3),
             'loss': loss,
         }
         if fe:

@@ -106,19 +106,21 @@ def int_array(vals):
     return (C.c_int * len(vals))(*[int(v) for v in vals])
 
 
+timing_filter = None   # optional predicate on the entry-point name: only those calls are bracketed
 timing = None   # set to a list to record (name, tag, flops, bytes, start_event, end_event) per call
 
 
 def call(name, *args, tag='', flops=0, nbytes=0):
     """Invoke a status-returning entry point; raise RuntimeError with the library's message.
     With ``timing`` enabled the call is bracketed by HIP events on the launch stream."""
-    if timing is not None:
+    timed = timing is not None and (timing_filter is None or timing_filter(name))
+    if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     rc = getattr(lib(), name)(*args)
     if rc != 0:
         raise RuntimeError(f'{name} failed ({rc}): {lib().pbsed_last_error().decode()}')
-    if timing is not None:
+    if timed:
         e1.record()
         timing.append((name, tag, flops, nbytes, e0, e1))
 

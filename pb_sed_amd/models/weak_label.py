@@ -142,7 +142,7 @@ class CRNN(SoundEventModel):
             return inputs['weak_targets'], inputs['boundary_targets']
         return inputs['weak_targets'],
 
-    def review(self, inputs, outputs):
+    def review(self, inputs, outputs, defer_summary=False):
         y_fwd, y_bwd, seq_len, x, _, targets = outputs
         assert targets is not None
         weak_targets = targets[0].to(torch.float32)
@@ -172,18 +172,32 @@ class CRNN(SoundEventModel):
                 b_mask = (beta > .99) | (beta < .01)
                 b_mask = b_mask * (b_mask.float().mean(-1, keepdim=True) > .999) * (w > .99)[..., None]
                 blr = b_mask.float().mean()
-            packed = torch.cat([w_mask.float().reshape(-1), w.reshape(-1), y_weak.reshape(-1), blr.reshape(1)]).cpu().numpy()
-        wm = packed[:b * k].reshape(b, k) > .5
-        w_host = packed[b * k:2 * b * k].reshape(b, k)
-        y_weak_host = packed[2 * b * k:3 * b * k].reshape(b, k)
-        labeled = wm.all(-1)
-        return dict(
-            loss=loss,
-            scalars=dict(seq_len=np.mean(inputs['seq_len']), weak_label_rate=wm.mean(),
-                         boundary_label_rate=float(packed[-1]) if self.strong_fwd_bwd_loss_weight > 0. else 0.),
-            images=dict(features=x[:3]),
-            buffers=dict(y_weak=y_weak_host[labeled], targets_weak=w_host[labeled]),
-        )
+            packed_dev = torch.cat([w_mask.float().reshape(-1), w.reshape(-1), y_weak.reshape(-1), blr.reshape(1)])
+            host = torch.empty(packed_dev.shape, dtype=packed_dev.dtype, pin_memory=True)
+            host.copy_(packed_dev, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record()
+        review = dict(loss=loss, scalars=dict(seq_len=np.mean(inputs['seq_len'])), images=dict(features=x[:3]), buffers={})
+
+        def finalize():
+            copied.synchronize()
+            packed = host.numpy()
+            wm = packed[:b * k].reshape(b, k) > .5
+            w_host = packed[b * k:2 * b * k].reshape(b, k)
+            y_weak_host = packed[2 * b * k:3 * b * k].reshape(b, k)
+            labeled = wm.all(-1)
+            review['scalars'].update(
+                weak_label_rate=wm.mean(),
+                boundary_label_rate=float(packed[-1]) if self.strong_fwd_bwd_loss_weight > 0. else 0.)
+            review['buffers'].update(y_weak=y_weak_host[labeled], targets_weak=w_host[labeled])
+            return review
+
+        if defer_summary:
+            # the caller (Trainer.step) enqueues backward + optimiser first and only then waits for the copy,
+            # so the device never idles on the host between forward and backward
+            review['_finalize'] = finalize
+            return review
+        return finalize()
 
     # ------------------------------------------------------------------ inference heads
     def tagging(self, inputs):

@@ -9,6 +9,8 @@ RCCL all-reduce (torch.distributed backend "nccl" = RCCL over xGMI), issued per 
 the backward pass as soon as a bucket's gradients are final, so the collective overlaps the
 remaining conv dgrad/wgrad kernels.  Adam folds the 1/world_size average and the clip coefficient.
 """
+import inspect
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -90,6 +92,7 @@ class Trainer:
         self.bucket_names, buckets = param_buckets(model)
         self.sync = GradSync(self.flat_grad, buckets)
         model._grad_hook = self._on_grads_ready
+        self._defer = 'defer_summary' in inspect.signature(model.review).parameters
 
     def _on_grads_ready(self, name):
         if name in self.bucket_names:
@@ -100,7 +103,7 @@ class Trainer:
         self.model.train()
         self.flat_grad.zero_()
         outputs = self.model(dict(batch))
-        review = self.model.review(batch, outputs)
+        review = self.model.review(batch, outputs, defer_summary=True) if self._defer else self.model.review(batch, outputs)
         review['loss'].backward()
         scale = self.sync.finish()
         self.iteration += 1
@@ -110,4 +113,7 @@ class Trainer:
                       max_norm=self.clip, sumsq=self.sumsq, norm_out=self.grad_norm)
         ops.invalidate_packed()          # parameters changed in place behind torch's version counters
         review['scalars']['grad_norm'] = self.grad_norm
+        finalize = review.pop('_finalize', None)
+        if finalize is not None:
+            finalize()                               # host-side summary: waits for a copy issued after the forward pass
         return review
