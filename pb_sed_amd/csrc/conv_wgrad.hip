@@ -25,10 +25,11 @@ __device__ __forceinline__ void lds_acc(float* p, float v) {
     if (KWAVES > 1) atomicAdd(p, v); else *p = v;
 }
 
-template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN, int KWAVES>
+template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN, int KWAVES, int FT_>
 struct WgradCfg {
-    // WAVES waves tile Cout (MT M-tiles each); KWAVES groups of them split the spatial (K) dimension
-    static constexpr int FT = (KH == 3) ? 2 : 1, TT = 64;
+    // WAVES waves tile Cout (MT M-tiles each); KWAVES groups of them split the spatial (K) dimension;
+    // FT_ > 0 overrides the number of frequency rows per chunk (more bytes in flight for few-channel layers)
+    static constexpr int FT = FT_ ? FT_ : ((KH == 3) ? 2 : 1), TT = 64;
     static constexpr int KK = KH * KW, NT = WAVES * KWAVES * 64;
     static constexpr int TQ_PER = (TT / 4) / KWAVES;
     static constexpr int COUT_T = WAVES * MT * 16, CIN_T = TAPN ? 1 : NCG * 16;   // TAPN: Cin == 1, taps on N
@@ -42,10 +43,10 @@ struct WgradCfg {
     static constexpr int LDS_FLOATS = cmax(COUT_T * PLANE_Y + CIN_T * PLANE_A, COUT_T * OUT_ROW);
 };
 
-template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN, int KWAVES>
+template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN, int KWAVES, int FT_>
 __global__ __launch_bounds__(WAVES * KWAVES * 64, (KH == 3 && WAVES == 4 && NCG == 1 && !TAPN) ? 3 : 1)
 void conv_wgrad_kernel(ConvWgradArgs a) {
-    using C = WgradCfg<KH, KW, WAVES, MT, NCG, TAPN, KWAVES>;
+    using C = WgradCfg<KH, KW, WAVES, MT, NCG, TAPN, KWAVES, FT_>;
     constexpr int FT = C::FT, TT = C::TT, KK = C::KK, NT = C::NT;
     constexpr int PADH = (KH - 1) / 2, PADW = (KW - 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -234,10 +235,12 @@ void conv_wgrad_kernel(ConvWgradArgs a) {
     }
     __syncthreads();
     const int ncol = min(C::CIN_T, a.Cin - cin0) * KK;      // valid, contiguous part of each row
+    const int slot = a.nslots > 1 ? (int)(blockIdx.x % a.nslots) : 0;
+    float* dwp = a.dw + (size_t)slot * a.slot_w;
     for (int row = tid >> 6; row < C::COUT_T; row += NT / 64) {
         const int cout = cout0 + row;
         if (cout >= a.Cout) break;
-        float* dst = a.dw + ((size_t)cout * a.Cin + cin0) * KK;
+        float* dst = dwp + ((size_t)cout * a.Cin + cin0) * KK;
         for (int col = lane; col < ncol; col += 64) atomicAdd(dst + col, out_s[row * C::OUT_ROW + col]);
     }
     if (do_bias && lr == 0) {
@@ -246,20 +249,43 @@ void conv_wgrad_kernel(ConvWgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int cout = cout0 + (wave * MT + m) * 16 + lq * 4 + r;
-                if (cout < a.Cout) atomicAdd(&a.db[cout], accb[m][r]);
+                if (cout < a.Cout) atomicAdd(&a.db[(size_t)slot * a.slot_b + cout], accb[m][r]);
             }
     }
 }
 
-template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN = false, int KWAVES = 1>
-static int launch_wgrad(const ConvWgradArgs& a, hipStream_t s) {
-    using C = WgradCfg<KH, KW, WAVES, MT, NCG, TAPN, KWAVES>;
+// Few-channel layers have so few gradient words that >1000 blocks adding into them serialise on a handful of L2
+// lines; their blocks add into WGRAD_SLOTS partial copies instead, summed into the gradient by this kernel.
+constexpr int WGRAD_SLOTS = 32, WGRAD_SLOT_MAX = 16384 + 64;      // floats per slot (weights + bias)
+
+__global__ void wgrad_slot_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                         int nw, int nb, int stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw + nb) return;
+    float v = 0.f;
+#pragma unroll 8
+    for (int sl = 0; sl < WGRAD_SLOTS; ++sl) v += part[(size_t)sl * stride + i];
+    if (i < nw) dw[i] += v; else if (db) db[i - nw] += v;
+}
+
+static float* wgrad_slot_scratch() {
+    static float* buf[16] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!buf[dev] && hipMalloc(&buf[dev], sizeof(float) * WGRAD_SLOTS * WGRAD_SLOT_MAX) != hipSuccess) buf[dev] = nullptr;
+    return buf[dev];
+}
+
+template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN = false, int KWAVES = 1, int FT_ = 0>
+static int launch_wgrad(const ConvWgradArgs& a_in, hipStream_t s) {
+    ConvWgradArgs a = a_in;
+    using C = WgradCfg<KH, KW, WAVES, MT, NCG, TAPN, KWAVES, FT_>;
     const int nTt = (a.T + C::TT - 1) / C::TT, nFt = (a.F + C::FT - 1) / C::FT;
     const int nChunks = a.B * nFt * nTt;
     const int gy = (a.Cin + C::CIN_T - 1) / C::CIN_T;
     const int gz = (a.Cout + C::COUT_T - 1) / C::COUT_T;
     const size_t lds = C::LDS_FLOATS * sizeof(float);
-    auto kern = conv_wgrad_kernel<KH, KW, WAVES, MT, NCG, TAPN, KWAVES>;
+    auto kern = conv_wgrad_kernel<KH, KW, WAVES, MT, NCG, TAPN, KWAVES, FT_>;
     // K-split so that the grid is (close to) an integer number of full residency rounds: blocks per CU from
     // the occupancy query, n_cu * occ resident slots, one or two rounds depending on how much K there is.
     static int slots = 0;
@@ -276,9 +302,25 @@ static int launch_wgrad(const ConvWgradArgs& a, hipStream_t s) {
     if (split >= 8) split &= ~7;       // multiple of 8: blocks sharing a spatial chunk share an XCD's L2
     if (split < 1) split = 1;
     if (nChunks >= 16 * split * 4) split *= 2;      // plenty of K: two rounds keep tail effects small
-    if (split > 1024 / (gy * gz)) split = 1024 / (gy * gz) > 0 ? 1024 / (gy * gz) : 1;   // atomics-per-address cap
+    static const bool slots_on = getenv("PBSED_WGRAD_SLOTS") ? atoi(getenv("PBSED_WGRAD_SLOTS")) != 0 : true;
+    static const int slot_cap = getenv("PBSED_WGRAD_SLOT_CAP") ? atoi(getenv("PBSED_WGRAD_SLOT_CAP")) : 4096;
+    const int nw = a.Cout * a.Cin * C::KK, nb = a.Cout;
+    const bool slot_ok = slots_on && nw + nb <= WGRAD_SLOT_MAX;
+    const int cap = (slot_ok ? slot_cap : 1024) / (gy * gz);                              // atomics-per-address cap
+    if (split > cap) split = cap > 0 ? cap : 1;
     if (split > nChunks) split = nChunks;
     dim3 grid(split, gy, gz);
+    float* scratch = (slot_ok && split >= 4 * WGRAD_SLOTS) ? wgrad_slot_scratch() : nullptr;
+    if (scratch) {
+        const int stride = (nw + nb + 63) / 64 * 64;
+        hipMemsetAsync(scratch, 0, sizeof(float) * WGRAD_SLOTS * stride, s);
+        a.dw = scratch; a.db = a_in.db ? scratch + nw : nullptr;
+        a.nslots = WGRAD_SLOTS; a.slot_w = stride; a.slot_b = stride;
+        hipLaunchKernelGGL(kern, grid, dim3(WAVES * KWAVES * 64), lds, s, a);
+        hipLaunchKernelGGL(wgrad_slot_reduce_kernel, dim3((nw + nb + 255) / 256), dim3(256), 0, s, scratch, a_in.dw, a_in.db,
+                           nw, nb, stride);
+        return check_launch("conv_wgrad(slotted)");
+    }
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * KWAVES * 64), lds, s, a);
     return check_launch("conv_wgrad");
 }
@@ -287,11 +329,24 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     if (a.unpool_idx && (a.F % 2)) { set_error("conv_wgrad: unpool needs even F"); return PBSED_E_ARG; }
     static const int ncg_knob = getenv("PBSED_WGRAD_NCG") ? atoi(getenv("PBSED_WGRAD_NCG")) : 1;
     const bool wide = a.Cin > 16 && ncg_knob >= 2;
+    // few output channels: the waves of a block also split the chunk's time range (KWAVES), otherwise a block is
+    // one or two waves and nothing hides the LDS / global latency
+    static const int kw_knob = getenv("PBSED_WGRAD_KWAVES") ? atoi(getenv("PBSED_WGRAD_KWAVES")) : 1;
+    static const int ft_knob = getenv("PBSED_WGRAD_FT") ? atoi(getenv("PBSED_WGRAD_FT")) : 1;
     if (KH == 3 && KW == 3) {
-        if (a.Cin == 1) return a.Cout >= 64 ? launch_wgrad<3, 3, 4, 1, 1, true>(a, s) : launch_wgrad<3, 3, 1, 1, 1, true>(a, s);
+        if (a.Cin == 1) {
+            if (a.Cout >= 64) return launch_wgrad<3, 3, 4, 1, 1, true>(a, s);
+            if (ft_knob > 1) return launch_wgrad<3, 3, 1, 1, 1, true, 4, 8>(a, s);
+            return kw_knob > 1 ? launch_wgrad<3, 3, 1, 1, 1, true, 4>(a, s) : launch_wgrad<3, 3, 1, 1, 1, true>(a, s);
+        }
         if (a.Cout >= 64) return wide ? launch_wgrad<3, 3, 4, 1, 2>(a, s) : launch_wgrad<3, 3, 4, 1, 1>(a, s);
-        if (a.Cout >= 32) return wide ? launch_wgrad<3, 3, 2, 1, 2>(a, s) : launch_wgrad<3, 3, 2, 1, 1>(a, s);
-        return launch_wgrad<3, 3, 1, 1, 1>(a, s);
+        if (a.Cout >= 32) {
+            if (wide) return launch_wgrad<3, 3, 2, 1, 2>(a, s);
+            if (ft_knob) return launch_wgrad<3, 3, 2, 1, 1, false, 2, 4>(a, s);
+            return kw_knob ? launch_wgrad<3, 3, 2, 1, 1, false, 2>(a, s) : launch_wgrad<3, 3, 2, 1, 1>(a, s);
+        }
+        if (ft_knob) return launch_wgrad<3, 3, 1, 1, 1, false, 4, 4>(a, s);
+        return kw_knob ? launch_wgrad<3, 3, 1, 1, 1, false, 4>(a, s) : launch_wgrad<3, 3, 1, 1, 1>(a, s);
     }
     if (KH == 1 && KW == 3) {
         return a.Cout >= 128 ? launch_wgrad<1, 3, 4, 2, 2>(a, s) : launch_wgrad<1, 3, 1, 1, 2>(a, s);

@@ -39,6 +39,8 @@ struct ConvWgradArgs {
     float* db;              // [Cout] (+=) or null
     int B, Cin, Cout, F, T;
     int relu;
+    int nslots;             // > 1: dw/db point at nslots partial copies (stride slot_w / slot_b floats), block x -> x % nslots
+    int slot_w, slot_b;
 };
 
 void conv_fwd_tile_dims(int KH, int KW, int Cin, int Cout, int* ck, int* cout_t);
