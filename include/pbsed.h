@@ -106,8 +106,10 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
                         const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
                         float* const* hs, float* const* save, const int* reverse /*host*/, const int* seq_len,
                         int B, int H, int T, unsigned int* sync_ws, void* stream);
-/* Persistent forward scan exchanging h_t as 8-byte {epoch, value} granules (one launch for the whole scan).
- * granules: device uint64 [nchains*nlayers][T][B][H], zero before first use, reusable with a fresh non-zero epoch. */
+/* Persistent forward scan exchanging h_t (and the projected inputs of layers > 0) as 8-byte {epoch, value}
+ * granules (one launch for the whole scan; needs nchains*(2*nlayers-1)*(H/16)*ceil(B/16) <= #CUs co-resident
+ * workgroups).  granules: device uint64 workspace of nchains*T*B*H*(nlayers + 3*(nlayers-1)) words, zero before
+ * first use, reusable with a fresh non-zero epoch.  `save` rows are [5][H] (factors of dh_t, see gru_stack.hip). */
 int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
                                 const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
                                 float* const* hs, float* const* save, const int* reverse /*host*/, const int* seq_len,

@@ -40,7 +40,7 @@ struct GruStackArgs {
     const int* seq_len;
     int B, T, nchains, nlayers, launch;
     int one_xcd;          // experiment: grid.x is 8x larger and only blocks with blockIdx.x % 8 == 0 work
-    int ring_xcd, nby;    // granule kernels: 1-D grid, block id = jblk*ring_xcd + ring so that a ring's blocks share an XCD
+    int ring_xcd, nby;    // granule kernels: ring_xcd = H/16 > 0 selects the 1-D XCD-aware role mapping (granule_role)
     int debug;            // experiment (PBSED_GRU_DEBUG bitmask): 1 skip W_hh matmul, 2 skip W_ih matmul, 4 skip save stores
 };
 
@@ -536,57 +536,114 @@ __device__ __forceinline__ void poll_batch(float2 (&out)[NL], __amdgpu_buffer_rs
     for (int n = 0; n < NL; ++n) out[n] = make_float2(__uint_as_float(q[n].x), __uint_as_float(q[n].z));
 }
 
+// Block roles of the granule scans.  Every (chain, layer) has a RING of H/16 x ceil(B/16) blocks that carries the
+// recurrence (h_{t-1} -> h_t, or dh_{t+1} -> dh_t) and, for every layer boundary, a group of the same size of
+// PROJECTION blocks that turn the neighbouring ring's step output into this ring's step input (forward:
+// gi_t = W_ih h^{l-1}_t + b_ih; backward: dy_t = W_ih^{l+1,T} dgi^{l+1}_t) and publish it as granules too.  The
+// projections have no recurrence, run ahead of the ring that consumes them, and keep every block at K = H per step.
+// Group id within a chain: 0 = ring of the first layer in scan order, 2m-1 = projection into / 2m = ring of the m-th.
+struct GranuleRole {
+    int bx, by, chain, gid;
+    bool idle;
+};
+__device__ __forceinline__ GranuleRole granule_role(const GruStackArgs& a) {
+    GranuleRole r;
+    r.idle = false;
+    if (a.ring_xcd) {
+        // 1-D grid, XCD = block id % 8: ring units (chain, layer, batch tile) one per XCD so that the recurrence's
+        // hand-off stays inside one L2; the projection blocks (no recurrence) are dealt round-robin over all XCDs
+        const int nj = a.ring_xcd, x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int R = a.nchains * a.nlayers * a.nby, P = a.nchains * (a.nlayers - 1) * a.nby;
+        const int ring_slots = (R + 7) / 8 * nj;
+        int unit, m;
+        if (slot < ring_slots) {
+            unit = (slot / nj) * 8 + x;
+            r.bx = slot % nj;
+            r.idle = unit >= R;
+            r.by = unit % a.nby; unit /= a.nby;
+            m = unit % a.nlayers; r.chain = unit / a.nlayers;
+            r.gid = 2 * m;
+        } else {
+            const int pidx = (slot - ring_slots) * 8 + x;
+            unit = pidx / nj;
+            r.bx = pidx % nj;
+            r.idle = unit >= P;
+            r.by = unit % a.nby; unit /= a.nby;
+            m = unit % (a.nlayers > 1 ? a.nlayers - 1 : 1); r.chain = unit / (a.nlayers > 1 ? a.nlayers - 1 : 1);
+            r.gid = 2 * m + 1;
+        }
+    } else {
+        r.bx = blockIdx.x; r.by = blockIdx.y;
+        r.chain = blockIdx.z % a.nchains; r.gid = blockIdx.z / a.nchains;
+    }
+    return r;
+}
+
+// One thread waits for NQ granules it alone consumes (stride `stride` words); they were requested earlier (q holds
+// the first answers) and are normally there already.
+template <int NQ>
+__device__ __forceinline__ void wait_own_granules(unsigned long long (&q)[NQ], const gu64* p, size_t stride, unsigned epoch,
+                                                  unsigned* err_flag) {
+    for (int spin = 0;; ++spin) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) ok = ok && (unsigned)(q[i] >> 32) == epoch;
+        if (ok) break;
+        if (spin > (1 << 18)) {
+            __hip_atomic_store((gu32*)err_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        if (spin > 8) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) q[i] = __hip_atomic_load(p + i * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <int KB, int NW>
-__global__ __launch_bounds__(NW * 64) void gru_granule_fwd_kernel(GruStackArgs a, unsigned long long* gran_, unsigned epoch,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gru_granule_fwd_kernel(GruStackArgs a, unsigned long long* gran_h_,
+                                                                 unsigned long long* gran_gi_, unsigned epoch,
                                                                  unsigned* err_flag) {
-    constexpr int H = KB * NW * 16, HW = NW / 2, NL = 4 * KB;   // NL: 16-byte loads per lane (8 k each) of a half-H range
+    constexpr int H = KB * NW * 16, NL = 2 * KB;       // NL: 16-byte loads per lane (8 k each) of this wave's H/NW range
     __shared__ float red[2][NW][3][64][4];
     __shared__ int s_err;
-    gu64* gran = (gu64*)gran_;
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (a.ring_xcd) {
-        const int ring = blockIdx.x % a.ring_xcd;
-        if (ring >= a.nby * a.nchains * a.nlayers) return;
-        bx = blockIdx.x / a.ring_xcd; by = ring % a.nby; bz = ring / a.nby;
-    }
-    const int chain = bz % a.nchains, layer = bz / a.nchains;
+    const GranuleRole role = granule_role(a);
+    if (role.idle) return;
+    const int chain = role.chain, layer = (role.gid + 1) >> 1;
+    const bool is_proj = role.gid & 1;
     const GruStackLayer& L = a.lc[chain][layer];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
-    const int j0 = bx * 16, b0 = by * 16, B = a.B;
+    const int j0 = role.bx * 16, b0 = role.by * 16, B = a.B;
     const bool rev = a.reverse[chain] != 0;
     const size_t per_cl = (size_t)a.T * B * H;
     const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(gran_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 8), 0x00020000);
-    gu64* g_own = gran + (size_t)(chain * a.nlayers + layer) * per_cl;
+        __builtin_amdgcn_make_buffer_rsrc(gran_h_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 8), 0x00020000);
+    gu64* g_own = (gu64*)gran_h_ + (size_t)(chain * a.nlayers + layer) * per_cl;                       // ring: h_t
+    gu64* g_gi = (gu64*)gran_gi_ + (size_t)(chain * (a.nlayers - 1) + (layer > 0 ? layer - 1 : 0)) * per_cl * 3;  // [T][B][3][H]
     const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
     const bool bv = tid < 256 && b < B;
     const bool rowv = (b0 + lr) < B;
-    const float bh_r = L.b_hh[j0 + u], bh_z = L.b_hh[H + j0 + u], bh_n = L.b_hh[2 * H + j0 + u];
-    float bi_r = 0.f, bi_z = 0.f, bi_n = 0.f;
-    if (layer > 0) { bi_r = L.b_ih[j0 + u]; bi_z = L.b_ih[H + j0 + u]; bi_n = L.b_ih[2 * H + j0 + u]; }
+    const float* bias = is_proj ? L.b_ih : L.b_hh;
+    const float bs_r = bias[j0 + u], bs_z = bias[H + j0 + u], bs_n = bias[2 * H + j0 + u];
     const int sl = bv ? a.seq_len[b] : 0;
-    // wave -> operand stream and K range (layer 0: all waves split W_hh; above: half W_hh, half W_ih); within the
-    // range a lane owns k = k0 + n*8 + lq*2 + {0,1} (the granule load pattern), weights follow the same permutation
-    const bool is_ih = layer > 0 && wave >= HW;
-    const int nl = layer == 0 ? NL / 2 : NL;
-    const int k0 = (layer == 0 ? wave : (is_ih ? wave - HW : wave)) * nl * 8;
+    // every wave contracts its H/NW slice of K; within it a lane owns k = k0 + n*8 + lq*2 + {0,1} (the granule
+    // load pattern) and the weights follow the same permutation
+    const int k0 = wave * NL * 8;
     float2 wv[NL][3];
     {
-        const float* W = (is_ih ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * H + k0 + lq * 2;
+        const float* W = (is_proj ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * H + k0 + lq * 2;
 #pragma unroll
         for (int n = 0; n < NL; ++n)
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
-                wv[n][g] = (n < nl) ? *reinterpret_cast<const float2*>(W + (size_t)g * H * H + n * 8) : make_float2(0.f, 0.f);
+            for (int g = 0; g < 3; ++g) wv[n][g] = *reinterpret_cast<const float2*>(W + (size_t)g * H * H + n * 8);
     }
-    // byte offset of this lane's first granule pair in the ring it reads, without the time index
-    const unsigned cl_src = chain * a.nlayers + (is_ih ? layer - 1 : layer);
+    // a projection reads h_t of the layer below, a ring its own h_{t-1}
+    const unsigned cl_src = chain * a.nlayers + (is_proj ? layer - 1 : layer);
     const unsigned voff0 = (unsigned)((((size_t)cl_src * a.T * B + b0 + lr) * H + k0 + lq * 2) * 8);
     float h_reg = 0.f;
     if (tid == 0) s_err = 0;
     __syncthreads();
-    float gn_r = bi_r, gn_z = bi_z, gn_n = bi_n;
-    auto load_gi = [&](int st) {
+    float gn_r = 0.f, gn_z = 0.f, gn_n = 0.f;
+    auto load_gi = [&](int st) {                    // first layer: input projection computed before the scan
         if (bv && layer == 0) {
             const float* gi = L.gi + ((size_t)(rev ? a.T - 1 - st : st) * B + b) * 3 * H;
             gn_r = gi[j]; gn_z = gi[H + j]; gn_n = gi[2 * H + j];
@@ -599,27 +656,31 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_fwd_kernel(GruStackArgs a
         const int tp = rev ? t + 1 : t - 1;
         const bool has_prev = step > 0;
         const int par = step & 1;                     // `red` is double-buffered: one barrier per step
-        const float gi_r = gn_r, gi_z = gn_z, gi_n = gn_n;
+        const size_t tb = (size_t)t * B + b;
+        float gi_r = gn_r, gi_z = gn_z, gi_n = gn_n;
         if (tid == 0 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
         f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         float2 x[NL];
-        if (is_ih || has_prev)
-            poll_batch<NL>(x, rsrc, voff0 + (unsigned)(is_ih ? t : tp) * (unsigned)(B * H * 8), nl, epoch,
-                           rowv && !(a.debug & 64), err_flag, a.debug);
-        // next step's input projection: issued behind the poll (loads return in order, anything older would hold
-        // the poll back), lands during this step's gate phase
+        const bool contract = is_proj || has_prev;
+        if (contract)
+            poll_batch<NL>(x, rsrc, voff0 + (unsigned)(is_proj ? t : tp) * (unsigned)(B * H * 8), NL, epoch, rowv, err_flag);
+        // requests issued behind the poll (loads return in order, anything older would hold the poll back):
+        // next step's input projection (first layer) / this step's projected input granules (other rings)
+        unsigned long long qg[3] = {0, 0, 0};
+        const gu64* gp = g_gi + tb * 3 * H + j;
+        if (!is_proj && layer > 0 && bv) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) qg[g] = __hip_atomic_load(gp + (size_t)g * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (step + 1 < a.T) load_gi(step + 1);
-        if (is_ih || has_prev) {
+        if (contract) {
 #pragma unroll
-            for (int n = 0; n < NL; ++n) {
-                if (n < nl) {
+            for (int n = 0; n < NL; ++n)
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) {
-                        acc[g] = mfma16(wv[n][g].x, x[n].x, acc[g]);
-                        acc[g] = mfma16(wv[n][g].y, x[n].y, acc[g]);
-                    }
+                for (int g = 0; g < 3; ++g) {
+                    acc[g] = mfma16(wv[n][g].x, x[n].x, acc[g]);
+                    acc[g] = mfma16(wv[n][g].y, x[n].y, acc[g]);
                 }
-            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -631,113 +692,120 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_fwd_kernel(GruStackArgs a
         if (s_err) return;                            // some hand-off timed out
         if (bv) {
             const int src = (u >> 2) * 16 + bb, reg = u & 3;
-            float s[4] = {0.f, 0.f, 0.f, 0.f};
+            float s[3] = {bs_r, bs_z, bs_n};
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
                 s[0] += red[par][w][0][src][reg];
                 s[1] += red[par][w][1][src][reg];
-                if (layer == 0 || w < HW) s[2] += red[par][w][2][src][reg]; else s[3] += red[par][w][2][src][reg];
+                s[2] += red[par][w][2][src][reg];
             }
-            const float ghn = s[2] + bh_n;
-            const float r = 1.f / (1.f + expf(-(gi_r + s[0] + bh_r)));
-            const float z = 1.f / (1.f + expf(-(gi_z + s[1] + bh_z)));
-            const float n = tanhf(gi_n + s[3] + r * ghn);
-            const float hp = h_reg;
-            const float h = (t < sl) ? (1.f - z) * n + z * hp : 0.f;
-            h_reg = h;
-            const size_t tb = (size_t)t * B + b;
-            __hip_atomic_store(g_own + tb * H + j, ((unsigned long long)epoch << 32) | __float_as_uint(h), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            if (!(a.debug & 128)) L.hs[tb * H + j] = h;
-            if (L.save && !(a.debug & 128)) {
-                // what BPTT multiplies dh_t with: d(r,z,n pre-activations)/dh, d(gh_n)/dh and z (granule save format)
-                float* sv = L.save + tb * 5 * H + j0 + save_pos16(u);
-                const float cn = (1.f - z) * (1.f - n * n);
-                sv[0] = cn * ghn * r * (1.f - r); sv[H] = (hp - n) * z * (1.f - z); sv[2 * H] = cn;
-                sv[3 * H] = cn * r; sv[4 * H] = z;
+            const unsigned long long tag = (unsigned long long)epoch << 32;
+            if (is_proj) {
+                gu64* dst = g_gi + tb * 3 * H + j;
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    __hip_atomic_store(dst + (size_t)g * H, tag | __float_as_uint(s[g]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (layer > 0) {
+                    wait_own_granules<3>(qg, gp, (size_t)H, epoch, err_flag);
+                    gi_r = __uint_as_float((unsigned)qg[0]); gi_z = __uint_as_float((unsigned)qg[1]);
+                    gi_n = __uint_as_float((unsigned)qg[2]);
+                }
+                const float ghn = s[2];
+                const float r = 1.f / (1.f + expf(-(gi_r + s[0])));
+                const float z = 1.f / (1.f + expf(-(gi_z + s[1])));
+                const float n = tanhf(gi_n + r * ghn);
+                const float hp = h_reg;
+                const float h = (t < sl) ? (1.f - z) * n + z * hp : 0.f;
+                h_reg = h;
+                __hip_atomic_store(g_own + tb * H + j, tag | __float_as_uint(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                L.hs[tb * H + j] = h;
+                if (L.save) {
+                    // what BPTT multiplies dh_t with: d(r,z,n pre-activations)/dh, d(gh_n)/dh and z (granule save format)
+                    float* sv = L.save + tb * 5 * H + j0 + save_pos16(u);
+                    const float cn = (1.f - z) * (1.f - n * n);
+                    sv[0] = cn * ghn * r * (1.f - r); sv[H] = (hp - n) * z * (1.f - z); sv[2 * H] = cn;
+                    sv[3 * H] = cn * r; sv[4 * H] = z;
+                }
             }
         }
     }
 }
 
-// Backward twin: every step publishes dh_t (masked by the sequence length) of its 16 units as granules
-// [T][B][H].  Consumers rebuild the gate gradients they contract with as dh * (factor saved by the forward scan);
-// the factors are plain loads issued one step ahead, so only one granule per (row, unit) sits on the hand-off
-// path; dh*z of a thread's own unit stays in a register.
+// Backward twin.  Rings publish dh_t (masked by the sequence length) of their 16 units as granules [T][B][H];
+// consumers rebuild the gate gradients they contract with as dh * (factor saved by the forward scan), the factors
+// being plain loads issued one step ahead.  Projection blocks turn dh_t of the layer above into dy_t of the layer
+// below (granules [T][B][H] as well); dh*z of a thread's own unit stays in a register.  Scan order = top layer first.
 template <int KB, int NW>
-__global__ __launch_bounds__(NW * 64) void gru_granule_bwd_kernel(GruStackArgs a, unsigned long long* gran_, unsigned epoch,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gru_granule_bwd_kernel(GruStackArgs a, unsigned long long* gran_dh_,
+                                                                 unsigned long long* gran_dy_, unsigned epoch,
                                                                  unsigned* err_flag) {
-    constexpr int H = KB * NW * 16, G = 3 * H, HW = NW / 2, NL = 4 * KB;
+    constexpr int H = KB * NW * 16, G = 3 * H, NL = 2 * KB;
     __shared__ float red[2][NW][64][4];
     __shared__ int s_err;
-    gu64* gran = (gu64*)gran_;
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (a.ring_xcd) {
-        const int ring = blockIdx.x % a.ring_xcd;
-        if (ring >= a.nby * a.nchains * a.nlayers) return;
-        bx = blockIdx.x / a.ring_xcd; by = ring % a.nby; bz = ring / a.nby;
-    }
-    const int chain = bz % a.nchains, layer = bz / a.nchains;
-    const int top = a.nlayers - 1;
+    const GranuleRole role = granule_role(a);
+    if (role.idle) return;
+    const int chain = role.chain, top = a.nlayers - 1;
+    const bool is_proj = role.gid & 1;
+    const int layer = top - ((role.gid + 1) >> 1);    // ring: its layer; projection: the layer it produces dy for
     const GruStackLayer& L = a.lc[chain][layer];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
-    const int j0 = bx * 16, b0 = by * 16, B = a.B;
+    const int j0 = role.bx * 16, b0 = role.by * 16, B = a.B;
     const bool rev = a.reverse[chain] != 0;
     const size_t per_cl = (size_t)a.T * B * H;
     const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(gran_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 8), 0x00020000);
-    gu64* g_own = gran + (size_t)(chain * a.nlayers + layer) * per_cl;
+        __builtin_amdgcn_make_buffer_rsrc(gran_dh_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 8), 0x00020000);
+    gu64* g_own = (gu64*)gran_dh_ + (size_t)(chain * a.nlayers + layer) * per_cl;
+    gu64* g_dy = (gu64*)gran_dy_ + (size_t)(chain * (a.nlayers - 1) + (layer < top ? layer : 0)) * per_cl;
     const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
     const bool bv = tid < 256 && b < B;
     const bool rowv = (b0 + lr) < B;
     const int sl = bv ? a.seq_len[b] : 0;
-    // wave -> ring whose dh it contracts with: own (carry through W_hh) or the layer above (input gradient through
-    // W_ih of that layer) and a range of hidden units jj = k0 + n*8 + lq*2 + {0,1} (the granule load pattern)
-    const bool is_up = layer < top && wave >= HW;
-    const int nl = layer == top ? NL / 2 : NL;
-    const int k0 = (layer == top ? wave : (is_up ? wave - HW : wave)) * nl * 8;
-    const GruStackLayer& X = is_up ? a.lc[chain][layer + 1] : L;
+    // ring: contracts dgh of its own step done before (t_next) with W_hh; projection: dgi_t of the layer above with
+    // that layer's W_ih.  Every wave takes H/NW hidden units jj = k0 + n*8 + lq*2 + {0,1} (granule load pattern).
+    const int k0 = wave * NL * 8;
+    const GruStackLayer& X = is_proj ? a.lc[chain][layer + 1] : L;
     float2 wv[NL][3];
     {
-        const float* W = (is_up ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * G + k0 + lq * 2;
+        const float* W = (is_proj ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * G + k0 + lq * 2;
 #pragma unroll
         for (int n = 0; n < NL; ++n)
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
-                wv[n][g] = (n < nl) ? *reinterpret_cast<const float2*>(W + g * H + n * 8) : make_float2(0.f, 0.f);
+            for (int g = 0; g < 3; ++g) wv[n][g] = *reinterpret_cast<const float2*>(W + g * H + n * 8);
     }
-    const unsigned cl_src = chain * a.nlayers + (is_up ? layer + 1 : layer);
+    const unsigned cl_src = chain * a.nlayers + (is_proj ? layer + 1 : layer);
     const unsigned voff0 = (unsigned)((((size_t)cl_src * a.T * B + b0 + lr) * H + k0 + lq * 2) * 8);
     float dhz_prev = 0.f;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid == 0) s_err = 0;
     __syncthreads();
 
-    // factors of the step whose gate gradients this wave rebuilds (tn of the own ring, t of the layer above) and
-    // of the thread's own unit: loaded one step ahead, off the hand-off path
-    float4 pr[NL / 2], pz[NL / 2], pn[NL / 2];
+    float pr[NL][2], pz[NL][2], pn[NL][2];
     float c_r = 0.f, c_z = 0.f, c_n = 0.f, c_nr = 0.f, z = 0.f, dyv = 0.f;
     float x_r = 0.f, x_z = 0.f, x_n = 0.f, x_nr = 0.f, x_zz = 0.f, x_dy = 0.f;    // the same for the next step
-    auto load_operands = [&](int bs) {
+    auto load_operands = [&](int bs) __attribute__((always_inline)) {
         const int s = a.T - 1 - bs;
         const int t = rev ? a.T - 1 - s : s;
-        const int tx = is_up ? t : (rev ? t - 1 : t + 1);
-        const bool act = (is_up || bs > 0) && rowv && !(a.debug & 8);
+        const int tx = is_proj ? t : (rev ? t - 1 : t + 1);
+        const bool act = (is_proj || bs > 0) && rowv;
 #pragma unroll
         for (int m = 0; m < NL / 2; ++m) {
-            pr[m] = pz[m] = pn[m] = zero4;
-            if (2 * m < nl && act) {
+            float4 vr = zero4, vz = zero4, vn = zero4;
+            if (act) {
                 const float* sv = X.save + ((size_t)tx * B + b0 + lr) * 5 * H + k0 + m * 16 + lq * 4;
-                pr[m] = *reinterpret_cast<const float4*>(sv);
-                pz[m] = *reinterpret_cast<const float4*>(sv + H);
-                pn[m] = *reinterpret_cast<const float4*>(sv + (is_up ? 2 : 3) * H);
+                vr = *reinterpret_cast<const float4*>(sv);
+                vz = *reinterpret_cast<const float4*>(sv + H);
+                vn = *reinterpret_cast<const float4*>(sv + (is_proj ? 2 : 3) * H);
             }
+            pr[2 * m][0] = vr.x; pr[2 * m][1] = vr.y; pr[2 * m + 1][0] = vr.z; pr[2 * m + 1][1] = vr.w;
+            pz[2 * m][0] = vz.x; pz[2 * m][1] = vz.y; pz[2 * m + 1][0] = vz.z; pz[2 * m + 1][1] = vz.w;
+            pn[2 * m][0] = vn.x; pn[2 * m][1] = vn.y; pn[2 * m + 1][0] = vn.z; pn[2 * m + 1][1] = vn.w;
         }
     };
-    auto load_own = [&](int bs) {
+    auto load_own = [&](int bs) __attribute__((always_inline)) {
         const int s = a.T - 1 - bs;
         const int t = rev ? a.T - 1 - s : s;
-        if (bv) {
+        if (bv && !is_proj) {
             const size_t tb = (size_t)t * B + b;
             const float* sv = L.save + tb * 5 * H + j0 + save_pos16(u);
             x_r = sv[0]; x_z = sv[H]; x_n = sv[2 * H]; x_nr = sv[3 * H]; x_zz = sv[4 * H];
@@ -758,24 +826,22 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_bwd_kernel(GruStackArgs a
         f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         c_r = x_r; c_z = x_z; c_n = x_n; c_nr = x_nr; z = x_zz; dyv = x_dy;
         float2 dh2[NL];
-        if (is_up || has_next)
-            poll_batch<NL>(dh2, rsrc, voff0 + (unsigned)(is_up ? t : tn) * (unsigned)(B * H * 8), nl, epoch, rowv, err_flag);
-        if (bstep + 1 < a.T) load_own(bstep + 1);       // behind the poll: loads return in order
-        if (is_up || has_next) {
+        const bool contract = is_proj || has_next;
+        if (contract)
+            poll_batch<NL>(dh2, rsrc, voff0 + (unsigned)(is_proj ? t : tn) * (unsigned)(B * H * 8), NL, epoch, rowv, err_flag);
+        unsigned long long qd[1] = {0};               // behind the poll: loads return in order
+        if (!is_proj && layer < top && bv)
+            qd[0] = __hip_atomic_load(g_dy + tb * H + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bstep + 1 < a.T) load_own(bstep + 1);
+        if (contract) {
 #pragma unroll
             for (int n = 0; n < NL; ++n) {
-                if (n < nl) {
-                    const int m = n >> 1;
-                    const float fr0 = (n & 1) ? pr[m].z : pr[m].x, fr1 = (n & 1) ? pr[m].w : pr[m].y;
-                    const float fz0 = (n & 1) ? pz[m].z : pz[m].x, fz1 = (n & 1) ? pz[m].w : pz[m].y;
-                    const float fn0 = (n & 1) ? pn[m].z : pn[m].x, fn1 = (n & 1) ? pn[m].w : pn[m].y;
-                    acc[0] = mfma16(wv[n][0].x, dh2[n].x * fr0, acc[0]);
-                    acc[1] = mfma16(wv[n][1].x, dh2[n].x * fz0, acc[1]);
-                    acc[2] = mfma16(wv[n][2].x, dh2[n].x * fn0, acc[2]);
-                    acc[0] = mfma16(wv[n][0].y, dh2[n].y * fr1, acc[0]);
-                    acc[1] = mfma16(wv[n][1].y, dh2[n].y * fz1, acc[1]);
-                    acc[2] = mfma16(wv[n][2].y, dh2[n].y * fn1, acc[2]);
-                }
+                acc[0] = mfma16(wv[n][0].x, dh2[n].x * pr[n][0], acc[0]);
+                acc[1] = mfma16(wv[n][1].x, dh2[n].x * pz[n][0], acc[1]);
+                acc[2] = mfma16(wv[n][2].x, dh2[n].x * pn[n][0], acc[2]);
+                acc[0] = mfma16(wv[n][0].y, dh2[n].y * pr[n][1], acc[0]);
+                acc[1] = mfma16(wv[n][1].y, dh2[n].y * pz[n][1], acc[1]);
+                acc[2] = mfma16(wv[n][2].y, dh2[n].y * pn[n][1], acc[2]);
             }
         }
         if (bstep + 1 < a.T) load_operands(bstep + 1);
@@ -785,21 +851,25 @@ __global__ __launch_bounds__(NW * 64) void gru_granule_bwd_kernel(GruStackArgs a
         if (s_err) return;
         if (bv) {
             const int src = (u >> 2) * 16 + bb, reg = u & 3;
-            float carry = 0.f, dylow = 0.f;
+            float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                if (layer == top || w < HW) carry += red[par][w][src][reg]; else dylow += red[par][w][src][reg];
-            }
-            float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, dhzv = 0.f, dh = 0.f;
-            if (t < sl) {
-                dh = (layer == top ? dyv : dylow) + (has_next ? carry + dhz_prev : 0.f);
-                dn = dh * c_n; dz = dh * c_z; dr = dh * c_r; dnr = dh * c_nr;
-                dhzv = dh * z;
-            }
-            dhz_prev = dhzv;
-            __hip_atomic_store(g_own + tb * H + j, ((unsigned long long)epoch << 32) | __float_as_uint(dh), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            if (!(a.debug & 16)) {
+            for (int w = 0; w < NW; ++w) sum += red[par][w][src][reg];
+            const unsigned long long tag = (unsigned long long)epoch << 32;
+            if (is_proj) {
+                __hip_atomic_store(g_dy + tb * H + j, tag | __float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (layer < top) {
+                    wait_own_granules<1>(qd, g_dy + tb * H + j, 0, epoch, err_flag);
+                    dyv = __uint_as_float((unsigned)qd[0]);
+                }
+                float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, dhzv = 0.f, dh = 0.f;
+                if (t < sl) {
+                    dh = dyv + (has_next ? sum + dhz_prev : 0.f);
+                    dn = dh * c_n; dz = dh * c_z; dr = dh * c_r; dnr = dh * c_nr;
+                    dhzv = dh * z;
+                }
+                dhz_prev = dhzv;
+                __hip_atomic_store(g_own + tb * H + j, tag | __float_as_uint(dh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 float* dgi = L.dgi + tb * G;
                 float* dgh = L.dgh + tb * G;
                 dgi[j] = dr; dgi[H + j] = dz; dgi[2 * H + j] = dn;
@@ -901,14 +971,29 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
     return check_launch("gru_stack_fwd");
 }
 
-static bool granule_ring_xcd() {
-    static const bool v = [] { const char* e = getenv("PBSED_GRU_RING_XCD"); return e ? atoi(e) != 0 : true; }();
+static size_t granule_lds_pad() {
+    static const size_t v = [] { const char* e = getenv("PBSED_GRU_LDS_PAD"); return (size_t)(e ? atoi(e) : 0) * 1024; }();
     return v;
 }
 
-// Granule-exchange persistent forward scan (see gru_granule_fwd_kernel).  granules: device uint64
-// [nchains*nlayers][T][B][H] workspace that must be ZERO before its first use and may be reused across calls with a
-// different non-zero `epoch` each time; err_flag: device uint32 (0 on entry; non-zero after a hand-off timed out).
+// 1-D grid of the XCD-aware role mapping (granule_role): per XCD, ring slots first, then projection slots.
+static dim3 granule_xcd_grid(GruStackArgs& a, int H) {
+    a.nby = (a.B + 15) / 16;
+    a.ring_xcd = H / 16;
+    const int R = a.nchains * a.nlayers * a.nby, P = a.nchains * (a.nlayers - 1) * a.nby;
+    const int slots = (R + 7) / 8 * a.ring_xcd + (P * a.ring_xcd + 7) / 8;
+    return dim3(8 * slots, 1, 1);
+}
+
+static bool granule_ring_xcd() {
+    static const bool v = [] { const char* e = getenv("PBSED_GRU_RING_XCD"); return e ? atoi(e) != 0 : false; }();
+    return v;
+}
+
+// Granule-exchange persistent forward scan (see gru_granule_fwd_kernel).  granules: device uint64 workspace of
+// nchains*T*B*H*(nlayers + 3*(nlayers-1)) words (h_t of every layer, then the projected inputs of layers > 0) that
+// must be ZERO before its first use and may be reused across calls with a different non-zero `epoch` each time;
+// err_flag: device uint32 (0 on entry; non-zero after a hand-off timed out).
 int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
                                 const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
                                 float* const* hs, float* const* save, const int* reverse, const int* seq_len, int B,
@@ -929,24 +1014,31 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
         }
     }
     a.seq_len = seq_len; a.B = B; a.T = T; a.nchains = nchains; a.nlayers = nlayers;
-    a.debug = getenv("PBSED_GRU_DEBUG") ? atoi(getenv("PBSED_GRU_DEBUG")) : 0;
-    dim3 grid(H / 16, (B + 15) / 16, nchains * nlayers);
-    if (granule_ring_xcd()) {                       // one ring (chain, layer, batch tile) per XCD: block id % 8 == ring % 8
-        a.nby = (B + 15) / 16;
-        a.ring_xcd = (a.nby * nchains * nlayers + 7) / 8 * 8;
-        grid = dim3(H / 16 * a.ring_xcd, 1, 1);
-    }
+    const int ngroups = nchains * (2 * nlayers - 1);     // rings + projection groups (see GranuleRole)
+    dim3 grid(H / 16, (B + 15) / 16, ngroups);
+    if (granule_ring_xcd()) grid = granule_xcd_grid(a, H);
+    unsigned long long* gran_gi = granules + (size_t)nchains * nlayers * T * B * H;
     hipStream_t s = (hipStream_t)stream;
+    // one workgroup per CU: a dynamic LDS request of more than half a CU's 160 KB keeps two from sharing one
+    const size_t pad = granule_lds_pad();
+#define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
+    do {                                                                                                             \
+        auto kern = gru_granule_fwd_kernel<KB_, NW_>;                                                                \
+        if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad); \
+        hipLaunchKernelGGL(kern, grid, dim3(NW_ * 64), pad, s, a, granules, gran_gi, epoch, err_flag);                    \
+    } while (0)
     switch (H) {
-        case 64: hipLaunchKernelGGL((gru_granule_fwd_kernel<1, 4>), grid, dim3(256), 0, s, a, granules, epoch, err_flag); break;
-        case 128: hipLaunchKernelGGL((gru_granule_fwd_kernel<1, 8>), grid, dim3(512), 0, s, a, granules, epoch, err_flag); break;
-        case 256: hipLaunchKernelGGL((gru_granule_fwd_kernel<2, 8>), grid, dim3(512), 0, s, a, granules, epoch, err_flag); break;
-        default: hipLaunchKernelGGL((gru_granule_fwd_kernel<4, 8>), grid, dim3(512), 0, s, a, granules, epoch, err_flag); break;
+        case 64: LAUNCH_GRANULE(1, 4); break;
+        case 128: LAUNCH_GRANULE(1, 8); break;
+        case 256: LAUNCH_GRANULE(2, 8); break;
+        default: LAUNCH_GRANULE(4, 8); break;
     }
+#undef LAUNCH_GRANULE
     return check_launch("gru_stack_fwd_granule");
 }
 
-// Granule-exchange persistent BPTT.  granules: device uint64 [nchains*nlayers][T][B][H] (zero before first use).
+// Granule-exchange persistent BPTT.  granules: device uint64 workspace of nchains*T*B*H*(2*nlayers-1) words
+// (dh_t of every layer, then dy_t of the layers below the top), zero before first use.
 int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
                                 const float* const* hs, const float* const* save, const float* const* dy_top,
                                 float* const* dgi, float* const* dgh, const int* reverse, const int* seq_len, int B, int H,
@@ -968,20 +1060,26 @@ int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_
         }
     }
     a.seq_len = seq_len; a.B = B; a.T = T; a.nchains = nchains; a.nlayers = nlayers;
-    a.debug = getenv("PBSED_GRU_DEBUG") ? atoi(getenv("PBSED_GRU_DEBUG")) : 0;
-    dim3 grid(H / 16, (B + 15) / 16, nchains * nlayers);
-    if (granule_ring_xcd()) {                       // one ring (chain, layer, batch tile) per XCD: block id % 8 == ring % 8
-        a.nby = (B + 15) / 16;
-        a.ring_xcd = (a.nby * nchains * nlayers + 7) / 8 * 8;
-        grid = dim3(H / 16 * a.ring_xcd, 1, 1);
-    }
+    const int ngroups = nchains * (2 * nlayers - 1);
+    dim3 grid(H / 16, (B + 15) / 16, ngroups);
+    if (granule_ring_xcd()) grid = granule_xcd_grid(a, H);
+    unsigned long long* gran_dy = granules + (size_t)nchains * nlayers * T * B * H;
     hipStream_t s = (hipStream_t)stream;
+    // one workgroup per CU: a dynamic LDS request of more than half a CU's 160 KB keeps two from sharing one
+    const size_t pad = granule_lds_pad();
+#define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
+    do {                                                                                                             \
+        auto kern = gru_granule_bwd_kernel<KB_, NW_>;                                                                \
+        if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad); \
+        hipLaunchKernelGGL(kern, grid, dim3(NW_ * 64), pad, s, a, granules, gran_dy, epoch, err_flag);                    \
+    } while (0)
     switch (H) {
-        case 64: hipLaunchKernelGGL((gru_granule_bwd_kernel<1, 4>), grid, dim3(256), 0, s, a, granules, epoch, err_flag); break;
-        case 128: hipLaunchKernelGGL((gru_granule_bwd_kernel<1, 8>), grid, dim3(512), 0, s, a, granules, epoch, err_flag); break;
-        case 256: hipLaunchKernelGGL((gru_granule_bwd_kernel<2, 8>), grid, dim3(512), 0, s, a, granules, epoch, err_flag); break;
-        default: hipLaunchKernelGGL((gru_granule_bwd_kernel<4, 8>), grid, dim3(512), 0, s, a, granules, epoch, err_flag); break;
+        case 64: LAUNCH_GRANULE(1, 4); break;
+        case 128: LAUNCH_GRANULE(1, 8); break;
+        case 256: LAUNCH_GRANULE(2, 8); break;
+        default: LAUNCH_GRANULE(4, 8); break;
     }
+#undef LAUNCH_GRANULE
     return check_launch("gru_stack_bwd_granule");
 }
 

@@ -270,8 +270,10 @@ def check_gru_sync():
 
 
 def _granule_scan(nch, nlayers, b, h, t):
-    """Persistent granule-exchange scans need every workgroup co-resident (one per CU, 256 CUs)."""
-    return (os.environ.get('PBSED_GRU_PERSIST', '2') == '2' and nch * nlayers * ((b + 15) // 16) * (h // 16) <= 192
+    """Persistent granule-exchange scans need every workgroup co-resident (one per CU, 256 CUs): a ring per
+    (chain, layer) plus a projection group per layer boundary, each H/16 x ceil(B/16) blocks."""
+    blocks = nch * (2 * nlayers - 1) * ((b + 15) // 16) * (h // 16)
+    return (os.environ.get('PBSED_GRU_PERSIST', '2') == '2' and blocks <= 224
             and nch * nlayers * t * b * h * 8 < 2 ** 32)
 
 
@@ -291,7 +293,7 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
         key = (str(dev), n, t, b, h)
         gw = _GRANULE_WS.get(key)
         if gw is None:
-            gw = _GRANULE_WS[key] = [torch.zeros(n * t * b * h, dtype=torch.int64, device=dev), 0]
+            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * b * h * (nlayers + 3 * (nlayers - 1)), dtype=torch.int64, device=dev), 0]
         gw[1] += 1                                   # fresh epoch: stale tags of earlier calls never match
         ws = _gru_sync_ws(dev, 0)
         call('pbsed_gru_stack_fwd_granule', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih),
@@ -318,7 +320,7 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
         key = (str(dev), 'bwd', n, t, b, h)
         gw = _GRANULE_WS.get(key)
         if gw is None:
-            gw = _GRANULE_WS[key] = [torch.zeros(n * t * b * h, dtype=torch.int64, device=dev), 0]
+            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * b * h * (2 * nlayers - 1), dtype=torch.int64, device=dev), 0]
         gw[1] += 1
         ws = _gru_sync_ws(dev, 0)
         call('pbsed_gru_stack_bwd_granule', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t),
