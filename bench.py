@@ -53,6 +53,17 @@ def synth_batch(b, device, n_samples=160000, k=10, t=500, seed=0):
             'boundary_targets': torch.tensor(bnd).to(device)}
 
 
+def pmc_traffic(kernel_tag):
+    """HBM bytes per launch of the roofline kernel from the PMC passes committed under profiles/ (counters need their
+    own rocprofv3 runs, tools/run_profiles.sh + tools/prof_summary.py); None if that layer was not profiled."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'roofline_traffic.json')
+    try:
+        row = json.load(open(path)).get(kernel_tag)
+    except (OSError, ValueError):
+        return None, None
+    return (None, None) if row is None else (row['hbm_bytes_per_launch'], row['source'])
+
+
 def cpu_baseline(batch=8, steps=2):
     """Oracle FBCRNN train step on the host cores (the checker, timed as the CPU baseline)."""
     from oracle import frontend as ofe, models as om
@@ -179,7 +190,9 @@ def main():
                                    'loss, backward, grad-norm clip, Adam' + (', RCCL grad all-reduce' if world > 1 else ''),
                        'global_batch': clips, 'n_params': n_params, 'parallelism': f'dp{world}'},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         'traffic': pmc_traffic(f'{dname} {dtag}')[0], 'traffic_unit': 'HBM bytes per launch (PMC)',
+                         'traffic_source': pmc_traffic(f'{dname} {dtag}')[1],
                          'kernel': f'{dname} {dtag}', 'avg_ms': round(avg_ms, 4), 'launches': cnt,
                          'flops_per_launch': flops},
             'step_mfma': {'algorithmic_tflop_per_step': round(TRAIN_GFLOP_PER_CLIP * args.batch / 1e3, 4),

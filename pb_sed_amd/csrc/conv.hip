@@ -244,8 +244,9 @@ void conv_fwd_tile_dims(int KH, int KW, int Cin, int Cout, int* ck, int* cout_t)
         *cout_t = Cout <= 16 ? 16 : Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;
         if (*cout_t > max_ct) *cout_t = max_ct;
     } else {
+        static const int ct1d = env_int("PBSED_CONV1D_CT", 128);   // tuning knob: Cout tile of the 1-D / 1x1 convs
         *ck = (KW == 1) ? 16 : 8;
-        *cout_t = Cout <= 16 ? 16 : 128;
+        *cout_t = Cout <= 16 ? 16 : (ct1d == 64 ? 64 : 128);
     }
 }
 
@@ -277,10 +278,12 @@ int conv_fwd_launch(const ConvFwdArgs& a, int KH, int KW, int pool, int dgrad, h
     } while (0)
         if (KW == 1) {
             if (ct == 16) CFG1(16, 1, 16);
+            if (ct == 64) CFG1(64, 1, 16);
             CFG1(128, 1, 16);
         }
         if (KW == 3) {
             if (ct == 16) CFG1(16, 3, 8);
+            if (ct == 64) CFG1(64, 3, 8);
             CFG1(128, 3, 8);
         }
 #undef CFG1

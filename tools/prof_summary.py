@@ -15,17 +15,51 @@ st = glob.glob(os.path.join(go, 'prof_stats', '*', '*_kernel_stats.csv'))
 if st:
     shutil.copy(st[0], os.path.join(out, f'{tag}_kernel_stats.csv'))
     print('wrote', f'profiles/{tag}_kernel_stats.csv')
+# per (kernel, grid) durations from the kernel trace: one template instance serves several layers, the grid tells them apart
+tr = glob.glob(os.path.join(go, 'prof_stats', '*', '*_kernel_trace.csv'))
+if tr:
+    per = defaultdict(list)
+    for r in csv.DictReader(open(tr[0])):
+        key = (r['Kernel_Name'], r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'], r['Workgroup_Size_X'])
+        per[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    with open(os.path.join(out, f'{tag}_kernel_by_grid.csv'), 'w') as fh:
+        w = csv.writer(fh)
+        w.writerow(['kernel', 'grid_x', 'grid_y', 'grid_z', 'wg', 'launches', 'avg_us', 'min_us', 'max_us', 'total_ms'])
+        for (k, gx, gy, gz, wg), v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            if sum(v) < 50.:
+                continue
+            w.writerow([k[:120], gx, gy, gz, wg, len(v), round(sum(v) / len(v), 1), round(min(v), 1), round(max(v), 1),
+                        round(sum(v) / 1e3, 3)])
+    print('wrote', f'profiles/{tag}_kernel_by_grid.csv')
+bj = os.path.join(go, 'prof_stats_bench.json')
+if os.path.exists(bj):
+    shutil.copy(bj, os.path.join(out, f'{tag}_bench_under_rocprof.json'))
+# PMC rows carry only the total grid size; several layers share it.  Every step issues the same dispatch sequence,
+# so the j-th dispatch of a kernel (mod its dispatches per step) has the 3-D grid of the trace's j-th one.
+seq3d, per_step = defaultdict(list), {}
+if tr:
+    n_steps = 0
+    for r in csv.DictReader(open(tr[0])):
+        seq3d[r['Kernel_Name']].append('x'.join((r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'])))
+        n_steps += 'adam_step' in r['Kernel_Name']
+    per_step = {k: len(v) // max(n_steps, 1) for k, v in seq3d.items()}
 rows = defaultdict(lambda: defaultdict(list))
 for name, ctr in (('prof_fetch', 'FETCH_SIZE'), ('prof_write', 'WRITE_SIZE')):
     for f in glob.glob(os.path.join(go, name, '*', '*_counter_collection.csv')):
-        for r in csv.DictReader(open(f)):
+        seen = defaultdict(int)
+        for r in sorted(csv.DictReader(open(f)), key=lambda r: int(r['Dispatch_Id'])):
             if r['Counter_Name'] == ctr:
-                key = (r['Kernel_Name'], r['Grid_Size'], r['Workgroup_Size'])
+                k = r['Kernel_Name']
+                j = seen[k]
+                seen[k] += 1
+                grid = seq3d[k][j % per_step[k]] if per_step.get(k) else r['Grid_Size']
+                key = (k, grid, r['Workgroup_Size'])
                 rows[key][ctr].append(float(r['Counter_Value']))
                 rows[key]['dur_us'].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 with open(os.path.join(out, f'{tag}_pmc_hbm_traffic.csv'), 'w') as fh:
     w = csv.writer(fh)
-    w.writerow(['kernel', 'grid_threads', 'wg', 'launches', 'avg_us(pmc run)', 'FETCH_SIZE_KB_avg', 'WRITE_SIZE_KB_avg',
+    w.writerow(['kernel', 'grid (threads, x*y*z from the trace run)', 'wg', 'launches', 'avg_us(pmc run)', 'FETCH_SIZE_KB_avg',
+                'WRITE_SIZE_KB_avg',
                 'hbm_MB_per_launch = (2*FETCH + WRITE)*1024/1e6  [gfx950: FETCH_SIZE counts 64 B per 128-B request]'])
     for (k, g, wg), v in sorted(rows.items(), key=lambda kv: -sum(kv[1]['dur_us'])):
         fe = sum(v['FETCH_SIZE']) / max(len(v['FETCH_SIZE']), 1)
@@ -34,3 +68,25 @@ with open(os.path.join(out, f'{tag}_pmc_hbm_traffic.csv'), 'w') as fh:
         w.writerow([k[:110], g, wg, n, round(sum(v['dur_us']) / len(v['dur_us']), 1), round(fe, 1), round(wr, 1),
                     round((2 * fe + wr) * 1024 / 1e6, 2)])
 print('wrote', f'profiles/{tag}_pmc_hbm_traffic.csv')
+
+# HBM bytes per launch of the layers bench.py may name as its roofline kernel (bench.py copies the value into
+# `roofline.traffic`); keyed by bench.py's "<entry point> <layer tag>", matched to (kernel template, 3-D grid).
+import json
+ROOFLINE_ROWS = {
+    'pbsed_conv_bwd_weight 128->128 k3x3 B32 F16 T500': ('conv_wgrad_kernel<3, 3, 4, 1, 1, false, 1, 0>', '12288x8x2'),
+    'pbsed_conv_bwd_weight 128->256 k3x3 B32 F8 T500': ('conv_wgrad_kernel<3, 3, 4, 1, 1, false, 1, 0>', '6144x8x4'),
+    'pbsed_conv_bwd_data 128->128 k3x3 B32 F16 T500': ('conv_fwd_kernel<64, 4, 64, 3, 3, 8, false, true>', '262144x2x1'),
+    'pbsed_conv_fwd 128->128 k3x3 B32 F16 T500': ('conv_fwd_kernel<64, 4, 64, 3, 3, 8, true, false>', '262144x2x1'),
+}
+traffic = {}
+for tagname, (kern, grid) in ROOFLINE_ROWS.items():
+    for (k, g, wg), v in rows.items():
+        if kern in k and g == grid and v['FETCH_SIZE'] and v['WRITE_SIZE']:
+            fe = sum(v['FETCH_SIZE']) / len(v['FETCH_SIZE'])
+            wr = sum(v['WRITE_SIZE']) / len(v['WRITE_SIZE'])
+            traffic[tagname] = {'hbm_bytes_per_launch': round((2 * fe + wr) * 1024), 'kernel': kern, 'grid': grid,
+                                'source': f'profiles/{tag}_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                                          'bytes = (2*FETCH_SIZE + WRITE_SIZE) KB)'}
+if traffic:
+    json.dump(traffic, open(os.path.join(out, 'roofline_traffic.json'), 'w'), indent=1)
+    print('wrote profiles/roofline_traffic.json', list(traffic))
