@@ -156,6 +156,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     loss = float(review['loss'].item())
+    # host -> device hand-over of one batch (pinned, PCIe), outside the timed region: `value` is HBM-resident
+    host_batch = {k: v.cpu().pin_memory() for k, v in batch.items() if isinstance(v, torch.Tensor)}
+    torch.cuda.synchronize()
+    t_h = time.perf_counter()
+    for _ in range(5):
+        for k, v in host_batch.items():
+            batch[k].copy_(v, non_blocking=True)
+    torch.cuda.synchronize()
+    h2d_ms = (time.perf_counter() - t_h) / 5 * 1e3
     from pb_sed_amd import ops as _ops
     _ops.check_gru_sync()
 
@@ -200,6 +209,8 @@ def main():
                           'frac_of_fp32_mfma_peak': round(TRAIN_GFLOP_PER_CLIP * args.batch / 1e3 / (ms_step * 1e-3) / PEAK_FP32_MFMA_TFLOPS, 4)},
             'ms_per_step_by_entry_point': {k: round(v, 3) for k, v in sorted(by_family.items(), key=lambda kv: -kv[1])},
             'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 3),
+            'h2d': {'ms_per_batch': round(h2d_ms, 3), 'bytes': int(sum(v.numel() * v.element_size() for v in host_batch.values())),
+                    'clips_per_s_if_serialised': round(clips / (dt / args.steps + h2d_ms * 1e-3), 2)},
             'loss': loss,
         }
         if fe:
