@@ -658,7 +658,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
         const int par = step & 1;                     // `red` is double-buffered: one barrier per step
         const size_t tb = (size_t)t * B + b;
         float gi_r = gn_r, gi_z = gn_z, gi_n = gn_n;
-        if (tid == 0 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
+        // another block's time-out is looked for every 32 steps only: the agent-scope load stalls its wave
+        if (tid == 0 && (step & 31) == 31 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
         f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         float2 x[NL];
         const bool contract = is_proj || has_prev;
@@ -822,7 +823,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
         const bool has_next = bstep > 0;
         const size_t tb = (size_t)t * B + b;
         const int par = bstep & 1;
-        if (tid == 0 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
+        if (tid == 0 && (bstep & 31) == 31 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
         f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         c_r = x_r; c_z = x_z; c_n = x_n; c_nr = x_nr; z = x_zz; dyv = x_dy;
         float2 dh2[NL];
