@@ -97,15 +97,13 @@ int pbsed_gru_scan_bwd(int nchains, const float* const* w_hh_t, const float* con
                        const float* const* save, const float* const* dy, float* const* dgi, float* const* dgh,
                        float* const* dhz, const int* reverse /*host*/, const int* seq_len, int B, int H, int T,
                        void* stream);
-/* Multi-layer UNIDIRECTIONAL stacks (FBCRNN: forward + time-reversed 2-layer GRUs) as a layer wavefront:
- * T + nlayers - 1 launches, or - when `sync_ws` (device uint32[1 + nchains*nlayers*ceil(B/16)]) is given and the grid
- * fits the chip - ONE persistent launch whose blocks hand h_t slices over through write-through stores and
- * arrival counters (word 0 of sync_ws is an error flag: non-zero after a bounded spin timed out).
+/* Multi-layer UNIDIRECTIONAL stacks (FBCRNN: forward + time-reversed 2-layer GRUs) as a layer wavefront of
+ * T + nlayers - 1 per-step launches (the fallback of the persistent *_granule scans below; `save` rows [4][H]).
  * Pointer tables are host arrays indexed [chain*nlayers + layer]. */
 int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
                         const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
                         float* const* hs, float* const* save, const int* reverse /*host*/, const int* seq_len,
-                        int B, int H, int T, unsigned int* sync_ws, void* stream);
+                        int B, int H, int T, void* stream);
 /* Persistent forward scan exchanging h_t (and the projected inputs of layers > 0) as 8-byte {epoch, value}
  * granules (one launch for the whole scan; needs nchains*(2*nlayers-1)*(H/16)*ceil(B/16) <= #CUs co-resident
  * workgroups).  granules: device uint64 workspace of nchains*T*B*H*(nlayers + 3*(nlayers-1)) words, zero before
@@ -118,7 +116,7 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
 int pbsed_gru_stack_bwd(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
                         const float* const* hs, const float* const* save, const float* const* dy_top,
                         float* const* dgi, float* const* dgh, float* const* dhz, const int* reverse /*host*/,
-                        const int* seq_len, int B, int H, int T, unsigned int* sync_ws, void* stream);
+                        const int* seq_len, int B, int H, int T, void* stream);
 /* Persistent BPTT exchanging the step's gate gradients as granules.  granules: device uint64
  * [nchains*nlayers][T][B][4][H] (dr, dz, dn, dn*r), zero before first use. */
 int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,

@@ -39,9 +39,7 @@ struct GruStackArgs {
     int reverse[GRU_MAX_CHAINS];
     const int* seq_len;
     int B, T, nchains, nlayers, launch;
-    int one_xcd;          // experiment: grid.x is 8x larger and only blocks with blockIdx.x % 8 == 0 work
     int ring_xcd, nby;    // granule kernels: ring_xcd = H/16 > 0 selects the 1-D XCD-aware role mapping (granule_role)
-    int debug;            // experiment (PBSED_GRU_DEBUG bitmask): 1 skip W_hh matmul, 2 skip W_ih matmul, 4 skip save stores
 };
 
 // acc[g] += W[g*H + j0 + lr][k..] * v[b0 + lr][k..] over this wave's quarter of K = KB*64.
@@ -102,8 +100,7 @@ __global__ __launch_bounds__(NW * 64) void gru_stack_fwd_kernel(GruStackArgs a) 
     const int chain = blockIdx.z % a.nchains, layer = blockIdx.z / a.nchains;
     const int step = a.launch - layer;
     if (step < 0 || step >= a.T) return;
-    if (a.one_xcd && (blockIdx.x & 7)) return;
-    const int bxj = a.one_xcd ? blockIdx.x >> 3 : blockIdx.x;
+    const int bxj = blockIdx.x;
     const GruStackLayer& L = a.lc[chain][layer];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
     const int j0 = bxj * 16, b0 = blockIdx.y * 16, B = a.B;
@@ -132,7 +129,7 @@ __global__ __launch_bounds__(NW * 64) void gru_stack_fwd_kernel(GruStackArgs a) 
     constexpr int HW = NW / 2;
     if (layer == 0) {
         // all waves split K of the recurrent matmul
-        if (has_prev && !(a.debug & 1))
+        if (has_prev)
             mm_rows<KB, 3>(acc, L.w_hh + (size_t)(j0 + lr) * H, H, H * H, L.hs + ((size_t)tp * B + b0 + lr) * H, H, rowv,
                            wave, lq);
     } else {
@@ -143,7 +140,7 @@ __global__ __launch_bounds__(NW * 64) void gru_stack_fwd_kernel(GruStackArgs a) 
         const float* W = (is_ih ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * H;
         const float* V = is_ih ? a.lc[chain][layer - 1].hs + ((size_t)t * B + b0 + lr) * H
                                : L.hs + ((size_t)tp * B + b0 + lr) * H;
-        const bool act = is_ih ? !(a.debug & 2) : (has_prev && !(a.debug & 1));
+        const bool act = is_ih || has_prev;
         if (act) mm_rows<2 * KB, 3>(acc, W, H, H * H, V, H, rowv, wq, lq);
     }
 #pragma unroll
@@ -169,7 +166,7 @@ __global__ __launch_bounds__(NW * 64) void gru_stack_fwd_kernel(GruStackArgs a) 
     const float h = (1.f - z) * n + z * hp;
     const size_t tb = (size_t)t * B + b;
     L.hs[tb * H + j] = (t < sl) ? h : 0.f;
-    if (L.save && !(a.debug & 4)) {
+    if (L.save) {
         float* sv = L.save + tb * 4 * H;
         sv[j] = r; sv[H + j] = z; sv[2 * H + j] = n; sv[3 * H + j] = ghn;
     }
@@ -186,8 +183,7 @@ __global__ __launch_bounds__(NW * 64) void gru_stack_bwd_kernel(GruStackArgs a) 
     const int top = a.nlayers - 1;
     const int bstep = a.launch - (top - layer);
     if (bstep < 0 || bstep >= a.T) return;
-    if (a.one_xcd && (blockIdx.x & 7)) return;
-    const int bxj = a.one_xcd ? blockIdx.x >> 3 : blockIdx.x;
+    const int bxj = blockIdx.x;
     const GruStackLayer& L = a.lc[chain][layer];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
     const int j0 = bxj * 16, b0 = blockIdx.y * 16, B = a.B;
@@ -263,237 +259,11 @@ static void launch_stack(bool bwd, GruStackArgs& a, dim3 grid, hipStream_t s) {
 }
 
 
-// ============================================================================================
-// Persistent variant: ONE launch runs the whole scan.  Blocks that share a (chain, layer, batch-16
-// group) form a ring of H/16 blocks; W fragments stay in registers for all T steps; h_t slices are
-// exchanged through HBM/L2 with write-through (sc1) stores + a drained monotonic arrival counter on the
-// producer side and a relaxed poll + sc1 (L1-bypassing) loads on the consumer side - the
-// placement-independent hand-off of cdna_hip_programming.md Guideline 16 (form R1).  Every spin is
-// bounded: on timeout the block raises err_flag and leaves (the host reports PBSED_E_HIP).
-// ============================================================================================
 typedef unsigned int __attribute__((address_space(1))) gu32;
 typedef unsigned long long __attribute__((address_space(1))) gu64;
 
-__device__ __forceinline__ float4 ld_sc1_f4(const float* p) {
-    const gu64* q = (const gu64*)p;
-    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float4 v;
-    v.x = __uint_as_float((unsigned)a); v.y = __uint_as_float((unsigned)(a >> 32));
-    v.z = __uint_as_float((unsigned)b); v.w = __uint_as_float((unsigned)(b >> 32));
-    return v;
-}
-__device__ __forceinline__ void st_sc1_f(float* p, float v) {
-    __hip_atomic_store((gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// One wave polls until *ctr >= target (relaxed, L1-bypassing); result is block-uniform via LDS.
-__device__ __forceinline__ bool ring_wait(unsigned* ctr, unsigned target, unsigned* err_flag, int* s_ok, int tid) {
-    if (tid == 0) {
-        int ok = 1;
-        if (target > 0) {
-            ok = 0;
-            for (int spin = 0; spin < (1 << 21); ++spin) {
-                if (__hip_atomic_load((gu32*)ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
-                if ((spin & 1023) == 1023 &&
-                    __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (!ok) __hip_atomic_store((gu32*)err_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        *s_ok = ok;
-    }
-    __syncthreads();
-    const bool ok = *s_ok != 0;
-    __syncthreads();
-    return ok;
-}
-
-// every storing wave drains its write-through stores, then one lane bumps the ring's arrival counter
-__device__ __forceinline__ void ring_publish(unsigned* ctr, int tid) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add((gu32*)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <int KB, int NG>
-__device__ __forceinline__ void load_w(float4 (&wv)[KB][NG], const float* __restrict__ w, size_t gstride, int wave, int lq) {
-#pragma unroll
-    for (int i = 0; i < KB; ++i)
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-            wv[i][g] = *reinterpret_cast<const float4*>(w + g * gstride + (wave * KB + i) * 16 + lq * 4);
-}
-
-template <int KB, int NG>
-__device__ __forceinline__ void mm_regw(f32x4 (&acc)[NG], const float4 (&wv)[KB][NG], const float* v, bool vvalid,
-                                        int wave, int lq) {
-    float4 vv[KB];
-#pragma unroll
-    for (int i = 0; i < KB; ++i)
-        vv[i] = vvalid ? ld_sc1_f4(v + (wave * KB + i) * 16 + lq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < KB; ++i)
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            acc[g] = mfma16(wv[i][g].x, vv[i].x, acc[g]);
-            acc[g] = mfma16(wv[i][g].y, vv[i].y, acc[g]);
-            acc[g] = mfma16(wv[i][g].z, vv[i].z, acc[g]);
-            acc[g] = mfma16(wv[i][g].w, vv[i].w, acc[g]);
-        }
-}
-
-struct GruPersistSync { unsigned* counters; unsigned* err_flag; };   // counters[nchains*nlayers*nB16], zeroed per call
-
-template <int KB, int NW>
-__global__ __launch_bounds__(NW * 64) void gru_persist_fwd_kernel(GruStackArgs a, GruPersistSync sy) {
-    constexpr int H = KB * NW * 16;
-    __shared__ float red[NW][4][64][4];
-    __shared__ int s_ok;
-    const int chain = blockIdx.z % a.nchains, layer = blockIdx.z / a.nchains;
-    const GruStackLayer& L = a.lc[chain][layer];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
-    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16, B = a.B, nJ = gridDim.x, nB = gridDim.y;
-    const bool rev = a.reverse[chain] != 0;
-    unsigned* ctr = sy.counters + (chain * a.nlayers + layer) * nB + blockIdx.y;
-    unsigned* ctr_lo = layer > 0 ? sy.counters + (chain * a.nlayers + layer - 1) * nB + blockIdx.y : nullptr;
-    const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
-    const bool bv = tid < 256 && b < B;
-    const bool rowv = (b0 + lr) < B;
-    const float bh_r = L.b_hh[j0 + u], bh_z = L.b_hh[H + j0 + u], bh_n = L.b_hh[2 * H + j0 + u];
-    float bi_r = 0.f, bi_z = 0.f, bi_n = 0.f;
-    if (layer > 0) { bi_r = L.b_ih[j0 + u]; bi_z = L.b_ih[H + j0 + u]; bi_n = L.b_ih[2 * H + j0 + u]; }
-    const int sl = bv ? a.seq_len[b] : 0;
-    float4 whh[KB][3], wih[KB][3];
-    load_w<KB, 3>(whh, L.w_hh + (size_t)(j0 + lr) * H, (size_t)H * H, wave, lq);
-    if (layer > 0) load_w<KB, 3>(wih, L.w_ih + (size_t)(j0 + lr) * H, (size_t)H * H, wave, lq);
-    const float* xlo = layer > 0 ? a.lc[chain][layer - 1].hs : nullptr;
-
-    for (int step = 0; step < a.T; ++step) {
-        const int t = rev ? a.T - 1 - step : step;
-        const int tp = rev ? t + 1 : t - 1;
-        const bool has_prev = step > 0;
-        float gi_r = bi_r, gi_z = bi_z, gi_n = bi_n;
-        if (bv && layer == 0) {
-            const float* gi = L.gi + ((size_t)t * B + b) * 3 * H;
-            gi_r = gi[j]; gi_z = gi[H + j]; gi_n = gi[2 * H + j];
-        }
-        // own ring finished step-1 (h_{t-1} complete); lower ring finished this step (x_t complete)
-        if (!ring_wait(ctr, (unsigned)nJ * step, sy.err_flag, &s_ok, tid)) return;
-        if (layer > 0 && !ring_wait(ctr_lo, (unsigned)nJ * (step + 1), sy.err_flag, &s_ok, tid)) return;
-        f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        f32x4 acci[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        float hp = 0.f;
-        if (has_prev) {
-            mm_regw<KB, 3>(acc, whh, L.hs + ((size_t)tp * B + b0 + lr) * H, rowv, wave, lq);
-            if (bv) hp = __uint_as_float(__hip_atomic_load((const gu32*)(L.hs + ((size_t)tp * B + b) * H + j),
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
-        if (layer > 0) mm_regw<KB, 3>(acci, wih, xlo + ((size_t)t * B + b0 + lr) * H, rowv, wave, lq);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            red[wave][0][lane][r] = acc[0][r] + acci[0][r];
-            red[wave][1][lane][r] = acc[1][r] + acci[1][r];
-            red[wave][2][lane][r] = acc[2][r];
-            red[wave][3][lane][r] = acci[2][r];
-        }
-        __syncthreads();
-        if (bv) {
-            const int src = (u >> 2) * 16 + bb, reg = u & 3;
-            float s[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                s[g] = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) s[g] += red[w][g][src][reg];
-            }
-            const float ghn = s[2] + bh_n;
-            const float r = 1.f / (1.f + expf(-(gi_r + s[0] + bh_r)));
-            const float z = 1.f / (1.f + expf(-(gi_z + s[1] + bh_z)));
-            const float n = tanhf(gi_n + s[3] + r * ghn);
-            const float h = (1.f - z) * n + z * hp;
-            const size_t tb = (size_t)t * B + b;
-            st_sc1_f(L.hs + tb * H + j, (t < sl) ? h : 0.f);
-            if (L.save) {
-                float* sv = L.save + tb * 4 * H;
-                sv[j] = r; sv[H + j] = z; sv[2 * H + j] = n; sv[3 * H + j] = ghn;
-            }
-        }
-        ring_publish(ctr, tid);        // also the barrier that protects `red` for the next step
-    }
-}
-
-template <int KB, int NW>
-__global__ __launch_bounds__(NW * 64) void gru_persist_bwd_kernel(GruStackArgs a, GruPersistSync sy) {
-    constexpr int H = KB * NW * 16, G = 3 * H, KB3 = 3 * KB;
-    __shared__ float red[NW][2][64][4];
-    __shared__ int s_ok;
-    const int chain = blockIdx.z % a.nchains, layer = blockIdx.z / a.nchains;
-    const int top = a.nlayers - 1;
-    const GruStackLayer& L = a.lc[chain][layer];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
-    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16, B = a.B, nJ = gridDim.x, nB = gridDim.y;
-    const bool rev = a.reverse[chain] != 0;
-    unsigned* ctr = sy.counters + (chain * a.nlayers + layer) * nB + blockIdx.y;
-    unsigned* ctr_up = layer < top ? sy.counters + (chain * a.nlayers + layer + 1) * nB + blockIdx.y : nullptr;
-    const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
-    const bool bv = tid < 256 && b < B;
-    const bool rowv = (b0 + lr) < B;
-    const int sl = bv ? a.seq_len[b] : 0;
-    float4 whh[KB3][1], wup[KB3][1];
-    load_w<KB3, 1>(whh, L.w_hh + (size_t)(j0 + lr) * G, 0, wave, lq);
-    if (layer < top) load_w<KB3, 1>(wup, L.w_ih + (size_t)(j0 + lr) * G, 0, wave, lq);
-    const float* dgi_up = layer < top ? a.lc[chain][layer + 1].dgi : nullptr;
-    float dhz_prev = 0.f;                                  // dh*z of the step this thread did last (same b, j)
-
-    for (int bstep = 0; bstep < a.T; ++bstep) {
-        const int s = a.T - 1 - bstep;
-        const int t = rev ? a.T - 1 - s : s;
-        const int tn = rev ? t - 1 : t + 1;
-        const int tp = rev ? t + 1 : t - 1;
-        const bool has_next = bstep > 0, has_prev = s > 0;
-        const size_t tb = (size_t)t * B + b;
-        float r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, hp = 0.f, dyv = 0.f;
-        if (bv) {
-            const float* sv = L.save + tb * 4 * H;
-            r = sv[j]; z = sv[H + j]; n = sv[2 * H + j]; ghn = sv[3 * H + j];
-            if (has_prev) hp = L.hs[((size_t)tp * B + b) * H + j];
-            if (layer == top) dyv = L.dy[tb * H + j];
-        }
-        if (!ring_wait(ctr, (unsigned)nJ * bstep, sy.err_flag, &s_ok, tid)) return;
-        if (layer < top && !ring_wait(ctr_up, (unsigned)nJ * (bstep + 1), sy.err_flag, &s_ok, tid)) return;
-        f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, accy[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-        if (has_next) mm_regw<KB3, 1>(acc, whh, L.dgh + ((size_t)tn * B + b0 + lr) * G, rowv, wave, lq);
-        if (layer < top) mm_regw<KB3, 1>(accy, wup, dgi_up + ((size_t)t * B + b0 + lr) * G, rowv, wave, lq);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { red[wave][0][lane][q] = acc[0][q]; red[wave][1][lane][q] = accy[0][q]; }
-        __syncthreads();
-        if (bv) {
-            const int src = (u >> 2) * 16 + bb, reg = u & 3;
-            float carry = 0.f, dylow = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) { carry += red[w][0][src][reg]; dylow += red[w][1][src][reg]; }
-            float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, dhzv = 0.f;
-            if (t < sl) {
-                const float dh = (layer == top ? dyv : dylow) + (has_next ? carry + dhz_prev : 0.f);
-                dn = dh * (1.f - z) * (1.f - n * n);
-                dz = dh * (hp - n) * z * (1.f - z);
-                dr = dn * ghn * r * (1.f - r);
-                dnr = dn * r;
-                dhzv = dh * z;
-            }
-            dhz_prev = dhzv;
-            float* dgi = L.dgi + tb * G;
-            float* dgh = L.dgh + tb * G;
-            st_sc1_f(dgi + j, dr); st_sc1_f(dgi + H + j, dz); st_sc1_f(dgi + 2 * H + j, dn);
-            st_sc1_f(dgh + j, dr); st_sc1_f(dgh + H + j, dz); st_sc1_f(dgh + 2 * H + j, dnr);
-        }
-        ring_publish(ctr, tid);
-    }
-}
-
 // ============================================================================================
-// Persistent variant 2 ("granules"): the exchanged h_t values ARE the flags.  Every h value is published as one
+// Persistent scans ("granules"): the exchanged h_t values ARE the flags.  Every h value is published as one
 // aligned 8-byte {epoch tag, value} word with a single write-through (sc1) store into a [T][B][H] array that is
 // never overwritten within a call; consumers poll the words they need with L1-bypassing 8-byte loads until
 // all tags equal the call's epoch (cdna_hip_programming.md Guideline 16, form R2: no fence, no drain, no
@@ -511,7 +281,7 @@ __device__ __forceinline__ int save_pos16(int u) { return ((u >> 1) & 3) * 4 + (
 // issued before any tag is looked at (one fabric round trip per step); out[n] = the two values.
 template <int NL>
 __device__ __forceinline__ void poll_batch(float2 (&out)[NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, int nl, unsigned epoch,
-                                           bool valid, unsigned* err_flag, int dbg = 0) {
+                                           bool valid, unsigned* err_flag) {
     u32x4_t q[NL];
 #pragma unroll
     for (int n = 0; n < NL; ++n) q[n] = u32x4_t{0u, 0u, 0u, 0u};
@@ -525,7 +295,7 @@ __device__ __forceinline__ void poll_batch(float2 (&out)[NL], __amdgpu_buffer_rs
             for (int n = 0; n < NL; ++n)
                 if (n < nl) ok = ok && q[n].y == epoch && q[n].w == epoch;
         }
-        if (__all(ok) || (dbg & 32)) break;
+        if (__all(ok)) break;
         if (spin > (1 << 18)) {                     // bounded: raise the error flag and go on with garbage
             __hip_atomic_store((gu32*)err_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
@@ -880,12 +650,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     }
 }
 
-template <int KB, int NW>
-static void launch_persist(bool bwd, const GruStackArgs& a, const GruPersistSync& sy, dim3 grid, hipStream_t s) {
-    if (bwd) hipLaunchKernelGGL((gru_persist_bwd_kernel<KB, NW>), grid, dim3(NW * 64), 0, s, a, sy);
-    else hipLaunchKernelGGL((gru_persist_fwd_kernel<KB, NW>), grid, dim3(NW * 64), 0, s, a, sy);
-}
-
 }  // namespace pbsed
 
 using namespace pbsed;
@@ -908,44 +672,15 @@ static int stack_check(int nchains, int nlayers, int B, int H, int T) {
         default: launch_stack<4, 8>(BWD, a, grid, s); break;       \
     }
 
-#define DISPATCH_PERSIST(H, BWD, a, sy, grid, s)                       \
-    switch (H) {                                                       \
-        case 64: launch_persist<1, 4>(BWD, a, sy, grid, s); break;     \
-        case 128: launch_persist<1, 8>(BWD, a, sy, grid, s); break;    \
-        case 256: launch_persist<2, 8>(BWD, a, sy, grid, s); break;    \
-        default: launch_persist<4, 8>(BWD, a, sy, grid, s); break;     \
-    }
-
-// The persistent path needs every block co-resident (one 512-thread block per CU): use it only when the
-// grid fits the device with margin and the caller provided the sync workspace.
-static bool persist_ok(const unsigned* sync_ws, dim3 grid) {
-    static int n_cu = -1;
-    if (n_cu < 0) {
-        hipDeviceProp_t p;
-        int dev = 0;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 0;
-    }
-    // measured on MI355X (round 1): 10.3 us/step persistent vs 7.2 us/step as per-step launches -> opt-in only
-    static const bool on = getenv("PBSED_GRU_PERSIST") && atoi(getenv("PBSED_GRU_PERSIST")) == 1;
-    return sync_ws != nullptr && on && (int)(grid.x * grid.y * grid.z) <= n_cu * 3 / 4;
-}
-
-static bool one_xcd_knob() {
-    static const bool on = getenv("PBSED_GRU_ONE_XCD") && atoi(getenv("PBSED_GRU_ONE_XCD")) == 1;
-    return on;
-}
-
 extern "C" {
 
-// sync_ws (may be NULL -> per-step launches): device uint32[1 + nchains*nlayers*ceil(B/16)] scratch; word 0 is
-// an error flag the caller may read back after synchronising (non-zero: a bounded spin timed out).
 // Forward scan of nchains independent UNIDIRECTIONAL stacks of nlayers GRU layers (hidden = input = H above
 // layer 0).  Pointer tables are HOST arrays indexed [chain*nlayers + layer] of device pointers:
 // gi0[chain] [T][B][3H]; w_ih/b_ih (layer > 0; entries for layer 0 ignored); w_hh [3H][H]; b_hh; hs; save.
 int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
                         const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
                         float* const* hs, float* const* save, const int* reverse, const int* seq_len, int B, int H,
-                        int T, unsigned int* sync_ws, void* stream) {
+                        int T, void* stream) {
     if (int e = stack_check(nchains, nlayers, B, H, T)) return e;
     GruStackArgs a{};
     for (int c = 0; c < nchains; ++c) {
@@ -960,21 +695,8 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
     }
     a.seq_len = seq_len; a.B = B; a.T = T; a.nchains = nchains; a.nlayers = nlayers;
     dim3 grid(H / 16, (B + 15) / 16, nchains * nlayers);
-    if (persist_ok(sync_ws, grid)) {
-        GruPersistSync sy{sync_ws + 1, sync_ws};
-        hipMemsetAsync(sync_ws, 0, (1 + grid.y * grid.z) * sizeof(unsigned), (hipStream_t)stream);
-        DISPATCH_PERSIST(H, false, a, sy, grid, (hipStream_t)stream);
-        return check_launch("gru_stack_fwd(persistent)");
-    }
-    if (one_xcd_knob()) { a.one_xcd = 1; grid.x *= 8; }
-    a.debug = getenv("PBSED_GRU_DEBUG") ? atoi(getenv("PBSED_GRU_DEBUG")) : 0;
     DISPATCH_KB(H, false, a, grid, (hipStream_t)stream);
     return check_launch("gru_stack_fwd");
-}
-
-static size_t granule_lds_pad() {
-    static const size_t v = [] { const char* e = getenv("PBSED_GRU_LDS_PAD"); return (size_t)(e ? atoi(e) : 0) * 1024; }();
-    return v;
 }
 
 // 1-D grid of the XCD-aware role mapping (granule_role): per XCD, ring slots first, then projection slots.
@@ -1020,13 +742,10 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
     if (granule_ring_xcd()) grid = granule_xcd_grid(a, H);
     unsigned long long* gran_gi = granules + (size_t)nchains * nlayers * T * B * H;
     hipStream_t s = (hipStream_t)stream;
-    // one workgroup per CU: a dynamic LDS request of more than half a CU's 160 KB keeps two from sharing one
-    const size_t pad = granule_lds_pad();
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
     do {                                                                                                             \
         auto kern = gru_granule_fwd_kernel<KB_, NW_>;                                                                \
-        if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad); \
-        hipLaunchKernelGGL(kern, grid, dim3(NW_ * 64), pad, s, a, granules, gran_gi, epoch, err_flag);                    \
+        hipLaunchKernelGGL(kern, grid, dim3(NW_ * 64), 0, s, a, granules, gran_gi, epoch, err_flag);                    \
     } while (0)
     switch (H) {
         case 64: LAUNCH_GRANULE(1, 4); break;
@@ -1066,13 +785,10 @@ int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_
     if (granule_ring_xcd()) grid = granule_xcd_grid(a, H);
     unsigned long long* gran_dy = granules + (size_t)nchains * nlayers * T * B * H;
     hipStream_t s = (hipStream_t)stream;
-    // one workgroup per CU: a dynamic LDS request of more than half a CU's 160 KB keeps two from sharing one
-    const size_t pad = granule_lds_pad();
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
     do {                                                                                                             \
         auto kern = gru_granule_bwd_kernel<KB_, NW_>;                                                                \
-        if (pad) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad); \
-        hipLaunchKernelGGL(kern, grid, dim3(NW_ * 64), pad, s, a, granules, gran_dy, epoch, err_flag);                    \
+        hipLaunchKernelGGL(kern, grid, dim3(NW_ * 64), 0, s, a, granules, gran_dy, epoch, err_flag);                    \
     } while (0)
     switch (H) {
         case 64: LAUNCH_GRANULE(1, 4); break;
@@ -1089,7 +805,7 @@ int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_
 int pbsed_gru_stack_bwd(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
                         const float* const* hs, const float* const* save, const float* const* dy_top,
                         float* const* dgi, float* const* dgh, float* const* dhz, const int* reverse,
-                        const int* seq_len, int B, int H, int T, unsigned int* sync_ws, void* stream) {
+                        const int* seq_len, int B, int H, int T, void* stream) {
     if (int e = stack_check(nchains, nlayers, B, H, T)) return e;
     GruStackArgs a{};
     for (int c = 0; c < nchains; ++c) {
@@ -1105,13 +821,6 @@ int pbsed_gru_stack_bwd(int nchains, int nlayers, const float* const* w_hh_t, co
     }
     a.seq_len = seq_len; a.B = B; a.T = T; a.nchains = nchains; a.nlayers = nlayers;
     dim3 grid(H / 16, (B + 15) / 16, nchains * nlayers);
-    if (persist_ok(sync_ws, grid)) {
-        GruPersistSync sy{sync_ws + 1, sync_ws};
-        hipMemsetAsync(sync_ws, 0, (1 + grid.y * grid.z) * sizeof(unsigned), (hipStream_t)stream);
-        DISPATCH_PERSIST(H, true, a, sy, grid, (hipStream_t)stream);
-        return check_launch("gru_stack_bwd(persistent)");
-    }
-    if (one_xcd_knob()) { a.one_xcd = 1; grid.x *= 8; }
     DISPATCH_KB(H, true, a, grid, (hipStream_t)stream);
     return check_launch("gru_stack_bwd");
 }

@@ -250,11 +250,11 @@ def gru_scan_bwd(w_hh_t, hs, save, dy, reverse, seq_len):
 
 
 _GRANULE_WS = {}        # (device, shape) -> [granule workspace, epoch counter] of the persistent GRU scan
-_GRU_SYNC = []          # every sync workspace handed to a persistent scan (word 0 = error flag)
+_GRU_SYNC = []          # error flags handed to persistent scans since the last check
 
 
-def _gru_sync_ws(device, n_rings):
-    ws = torch.zeros(1 + n_rings, dtype=torch.int32, device=device)
+def _gru_err_flag(device):
+    ws = torch.zeros(1, dtype=torch.int32, device=device)
     _GRU_SYNC.append(ws)
     if len(_GRU_SYNC) > 64:
         check_gru_sync()
@@ -295,16 +295,15 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
         if gw is None:
             gw = _GRANULE_WS[key] = [torch.zeros(nch * t * b * h * (nlayers + 3 * (nlayers - 1)), dtype=torch.int64, device=dev), 0]
         gw[1] += 1                                   # fresh epoch: stale tags of earlier calls never match
-        ws = _gru_sync_ws(dev, 0)
+        ws = _gru_err_flag(dev)
         call('pbsed_gru_stack_fwd_granule', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih),
              _lib.ptr_array(b_ih), _lib.ptr_array(w_hh), _lib.ptr_array(b_hh), _lib.ptr_array(hs),
              _lib.ptr_array(sv) if save else None, _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]),
              gw[1] & 0x7FFFFFFF or 1, ptr(ws), stream())
         return hs, sv
-    ws = _gru_sync_ws(dev, nch * nlayers * ((b + 15) // 16))
     call('pbsed_gru_stack_fwd', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih), _lib.ptr_array(b_ih),
          _lib.ptr_array(w_hh), _lib.ptr_array(b_hh), _lib.ptr_array(hs), _lib.ptr_array(sv) if save else None,
-         _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(ws), stream())
+         _lib.int_array(reverse), ptr(seq_len), b, h, t, stream())
     return hs, sv
 
 
@@ -322,16 +321,15 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
         if gw is None:
             gw = _GRANULE_WS[key] = [torch.zeros(nch * t * b * h * (2 * nlayers - 1), dtype=torch.int64, device=dev), 0]
         gw[1] += 1
-        ws = _gru_sync_ws(dev, 0)
+        ws = _gru_err_flag(dev)
         call('pbsed_gru_stack_bwd_granule', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t),
              _lib.ptr_array(hs), _lib.ptr_array(save), _lib.ptr_array(dy_top), _lib.ptr_array(dgi), _lib.ptr_array(dgh),
              _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]), gw[1] & 0x7FFFFFFF or 1, ptr(ws), stream())
         return dgi, dgh
     dhz = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
-    ws = _gru_sync_ws(dev, nch * nlayers * ((b + 15) // 16))
     call('pbsed_gru_stack_bwd', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t), _lib.ptr_array(hs),
          _lib.ptr_array(save), _lib.ptr_array(dy_top), _lib.ptr_array(dgi), _lib.ptr_array(dgh), _lib.ptr_array(dhz),
-         _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(ws), stream())
+         _lib.int_array(reverse), ptr(seq_len), b, h, t, stream())
     return dgi, dgh
 
 
