@@ -63,6 +63,18 @@ int pbsed_conv_bwd_weight(const float* x, const float* scale, const float* shift
 /* bf16-MFMA variants (same contracts; activations stay fp32 in HBM, operands are converted while staging, fp32
  * accumulate).  nsplit = 1: plain bf16 compute (BASELINE.json config 3).  nsplit = 3: exact 3-way bf16 split of both
  * operands, 6 partial products -> fp32-class accuracy.  w_packed_bf16: uint16 [nsplit][KH*KW][out_padded][in_padded]. */
+/* 3x3 convs with the time axis in the Winograd F(4,3) domain (csrc/conv_wino.hip): same tensors, fusions and results
+ * (fp32 MFMA, fp32 accumulate; ~1e-6 relative transform rounding) as pbsed_conv_fwd / pbsed_conv_bwd_data with
+ * KH = KW = 3, half the multiplications.  u_packed: [3][6][in_padded][out_padded] from pbsed_pack_conv_weights_wino. */
+void pbsed_conv_pack_dims_wino(int Cin, int Cout, int dgrad, int* in_padded /*host*/, int* out_padded /*host*/);
+int pbsed_pack_conv_weights_wino(const float* w, float* u_packed, int Cout, int Cin, int dgrad, void* stream);
+int pbsed_conv_fwd_wino(const float* x, const float* u_packed, const float* bias, const float* scale,
+                        const float* shift, int relu, const int* seq_len, float* y, unsigned char* pool_idx,
+                        double* stats, int stats_per_cf, int B, int Cin, int Cout, int F, int T, int pool, void* stream);
+int pbsed_conv_bwd_data_wino(const float* g, const float* ud_packed, const unsigned char* unpool_idx,
+                             const int* seq_len, float* dz, const float* bx, const float* bmean, const float* binvstd,
+                             const float* bscale, const float* bshift, int relu, double* stats, int B, int Cin,
+                             int Cout, int F, int T, void* stream);
 void pbsed_conv_pack_dims_bf16(int Cin, int Cout, int dgrad, int* in_padded /*host*/, int* out_padded /*host*/);
 int pbsed_pack_conv_weights_bf16(const float* w, unsigned short* w_packed_bf16, int Cout, int Cin, int KH, int KW,
                                  int dgrad, int nsplit, void* stream);

@@ -27,6 +27,10 @@ SIGNATURES = {
     'pbsed_pack_conv_weights': [_v, _v, I, I, I, I, I, _v],
     'pbsed_conv_fwd': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, I, I, _v],
     'pbsed_conv_bwd_data': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, _v, I, I, I, I, I, I, I, _v],
+    'pbsed_conv_pack_dims_wino': [I, I, I, _i, _i],
+    'pbsed_pack_conv_weights_wino': [_v, _v, I, I, I, _v],
+    'pbsed_conv_fwd_wino': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, _v],
+    'pbsed_conv_bwd_data_wino': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, _v, I, I, I, I, I, _v],
     'pbsed_conv_pack_dims_bf16': [I, I, I, _i, _i],
     'pbsed_pack_conv_weights_bf16': [_v, _v, I, I, I, I, I, I, _v],
     'pbsed_conv_fwd_bf16': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, I, I, I, _v],
@@ -60,7 +64,7 @@ SIGNATURES = {
     'pbsed_memset_async': [_v, I, SZ, _v],
 }
 _NON_STATUS = {'pbsed_last_error': C.c_char_p, 'pbsed_version': C.c_int, 'pbsed_conv_pack_dims': None,
-               'pbsed_conv_pack_dims_bf16': None}
+               'pbsed_conv_pack_dims_bf16': None, 'pbsed_conv_pack_dims_wino': None}
 
 _lib = None
 

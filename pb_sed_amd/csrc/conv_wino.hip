@@ -1,0 +1,418 @@
+// 3x3 convolution forward / data gradient with the multiplications of the time axis done in the Winograd
+// F(4,3) domain, on fp32 MFMA (gfx950).  Same op sites and contract as conv.hip (pb_sed/models/weak_label/
+// crnn.py:93; 3x3 layers of training.py:159-169), same tensors, same prologue / epilogue fusions; selected for
+// the layers whose direct kernel is MFMA-bound (>= 32 input and >= 64 output channels of the contraction).
+//
+// A 3x3 conv is three 1-D convs along t (one per kernel row kh) summed over kh and cin.  For every block of 4
+// consecutive outputs along t ("tile", 6 inputs d_0..d_5 = x[4i-1 .. 4i+4]):
+//     V_xi = (B^T d)_xi, xi = 0..5        U_xi[kh] = (G w[kh][0..2])_xi        M_xi = sum_{kh,cin} U_xi[kh] V_xi(row f+kh-1)
+//     y_0..y_3 = A^T M
+// so the MFMAs contract K = (kh, cin) for 6 transform points instead of 9 taps per output: 18 products per 4
+// outputs instead of 36.  GEMM view per point: M = Cout (A = U), N = 16 tiles = 64 consecutive t of one row
+// (B = V), D fragment = (cout, tile).  A wave keeps all 6 points of its (cout, row, tile) fragments, so the output
+// transform is register arithmetic and leaves 4 consecutive t per lane (float4 stores), with both rows of a
+// (2,1) pool window in the same lane as in conv.hip.  The input transform is applied between the global load and
+// the LDS store (the raw tile is never staged): one work item = (cin, row, 4 tiles) = 18 inputs -> 6 x float4.
+// Transform matrices: Lavin & Gray 2016, F(4,3); fp32 rounding error of the 1-D transform is ~1e-6 relative.
+#include <cstdlib>
+
+#include "common.h"
+#include "pbsed_internal.h"
+
+namespace pbsed {
+
+constexpr int WN_CT = 64;          // cout per block
+constexpr int WN_CK = 8;           // cin per LDS stage
+constexpr int WN_FT = 4;           // output rows per block
+constexpr int WN_TT = 64;          // output columns per block = 16 tiles
+constexpr int WN_ROWS = WN_FT + 2;
+constexpr int WN_PLANE_V = 112;    // [rows 6][tiles 16] = 96 floats padded to == 16 (mod 32)
+constexpr int WN_COUT_P = 80;      // 64 padded to == 16 (mod 32)
+constexpr int WN_V_FLOATS = 6 * WN_CK * WN_PLANE_V;
+constexpr int WN_U_FLOATS = 18 * WN_CK * WN_COUT_P;
+constexpr int WN_U_VEC = 18 * WN_CK * WN_CT / 4;       // float4 per U stage
+constexpr int WN_U_PER_T = (WN_U_VEC + 255) / 256;
+
+template <bool POOL>
+struct WinoCfg {
+    static constexpr int FO_T = POOL ? WN_FT / 2 : WN_FT;
+    static constexpr int LDS_FLOATS = WN_V_FLOATS + WN_U_FLOATS + WN_CT * FO_T * 2;
+};
+
+// U[kh][xi][InP][OutP] = sum_kw G[xi][kw] * g[kh][kw]; dgrad: g = flipped kernel with in/out channels swapped.
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin, int InP, int OutP,
+                                 int dgrad) {
+    const size_t total = (size_t)18 * InP * OutP;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int o = i % OutP, ii = (i / OutP) % InP, kx = i / ((size_t)OutP * InP);
+        const int kh = kx / 6, xi = kx % 6;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (!dgrad) {
+            if (o < Cout && ii < Cin) {
+                const float* p = w + ((size_t)o * Cin + ii) * 9 + kh * 3;
+                g0 = p[0]; g1 = p[1]; g2 = p[2];
+            }
+        } else if (o < Cin && ii < Cout) {
+            const float* p = w + ((size_t)ii * Cin + o) * 9 + (2 - kh) * 3;
+            g0 = p[2]; g1 = p[1]; g2 = p[0];
+        }
+        float v;
+        switch (xi) {
+            case 0: v = .25f * g0; break;
+            case 1: v = -(g0 + g1 + g2) * (1.f / 6.f); break;
+            case 2: v = (-g0 + g1 - g2) * (1.f / 6.f); break;
+            case 3: v = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f); break;
+            case 4: v = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f); break;
+            default: v = g2; break;
+        }
+        up[i] = v;
+    }
+}
+
+template <bool POOL, bool DGRAD>
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
+    using C = WinoCfg<POOL>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* v_s = smem;                               // [6][CK][PLANE_V]
+    float* u_s = smem + WN_V_FLOATS;                 // [3*6][CK][COUT_P]
+    float* st_s = u_s + WN_U_FLOATS;                 // [CT][FO_T][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;         // 2 x 2 waves: 32 cout x 2 output rows each
+    const int lq = lane >> 4, lr = lane & 15;
+
+    const int nTt = (a.T + WN_TT - 1) / WN_TT, nFt = (a.F + WN_FT - 1) / WN_FT;
+    int bx = blockIdx.x;
+    const int t0 = (bx % nTt) * WN_TT; bx /= nTt;
+    const int f0 = (bx % nFt) * WN_FT;
+    const int b = bx / nFt;
+    const int cout0 = blockIdx.y * WN_CT;
+    const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
+    const bool pro = a.scale != nullptr;
+    const bool unpool = DGRAD && a.unpool_idx != nullptr;
+    const int Fsrc = unpool ? a.F / 2 : a.F;
+    const bool vec = (a.T & 3) == 0;
+    const int tlim = pro ? sl : a.T;                 // Normalization re-masks its output (y*mask)
+
+    f32x4 acc[6][2][2];
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int fl = 0; fl < 2; ++fl) acc[x][m][fl] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- input work item of this thread: (cin ic, halo row ir, tile quad iq) -> inputs t0 + 16 iq - 1 .. + 16
+    const bool loader = tid < WN_CK * WN_ROWS * 4;
+    const int iq = tid & 3, ir = (tid >> 2) % WN_ROWS, ic = tid / (4 * WN_ROWS);
+    const int fin = f0 - 1 + ir, tq0 = t0 + 16 * iq;
+    const bool row_ok = loader && fin >= 0 && fin < a.F;
+    const int row_off = (ic * Fsrc + (unpool ? (fin >> 1) : fin)) * a.T;
+    const int par = fin & 1;
+    float rin[18];                                   // raw inputs t = tq0 - 1 .. tq0 + 16 of the chunk in flight
+    unsigned rpar = 0;                               // DGRAD + unpool: bit e set = element e comes from the other pool row
+    float4 ru[WN_U_PER_T];
+    int rcin = 0;
+
+    // global loads only: everything that depends on the loaded values happens in store_chunk, after the MFMAs
+    auto load_chunk = [&](int c0) __attribute__((always_inline)) {
+        rcin = c0 + ic;
+        rpar = 0;
+#pragma unroll
+        for (int e = 0; e < 18; ++e) rin[e] = 0.f;
+        if (row_ok && rcin < a.Cin) {
+            const float* xb = a.x + (size_t)(b * a.Cin + c0) * Fsrc * a.T + row_off;
+            const uint8_t* ib = unpool ? a.unpool_idx + (size_t)(b * a.Cin + c0) * Fsrc * a.T + row_off : nullptr;
+            if (vec && tq0 + 16 <= a.T) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xb + tq0 + 4 * q);
+                    rin[1 + 4 * q] = xv.x; rin[2 + 4 * q] = xv.y; rin[3 + 4 * q] = xv.z; rin[4 + 4 * q] = xv.w;
+                    if (unpool) {
+                        const uchar4 iv = *reinterpret_cast<const uchar4*>(ib + tq0 + 4 * q);
+                        rpar |= (unsigned)(iv.x != par) << (1 + 4 * q) | (unsigned)(iv.y != par) << (2 + 4 * q) |
+                                (unsigned)(iv.z != par) << (3 + 4 * q) | (unsigned)(iv.w != par) << (4 + 4 * q);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 1; e < 17; ++e) {
+                    const int t = tq0 - 1 + e;
+                    if (t < a.T) {
+                        rin[e] = xb[t];
+                        if (unpool) rpar |= (unsigned)(ib[t] != par) << e;
+                    }
+                }
+            }
+            if (tq0 - 1 >= 0) {
+                rin[0] = xb[tq0 - 1];
+                if (unpool) rpar |= (unsigned)(ib[tq0 - 1] != par);
+            }
+            if (tq0 + 16 < a.T) {
+                rin[17] = xb[tq0 + 16];
+                if (unpool) rpar |= (unsigned)(ib[tq0 + 16] != par) << 17;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WN_U_PER_T; ++i) {
+            const int idx = tid + i * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < WN_U_VEC) {
+                const int q = idx % (WN_CT / 4);
+                const int c = (idx / (WN_CT / 4)) % WN_CK;
+                const int kx = idx / (WN_CT / 4) / WN_CK;
+                v = *reinterpret_cast<const float4*>(a.wp + ((size_t)kx * a.CinP + c0 + c) * a.CoutP + cout0 + q * 4);
+            }
+            ru[i] = v;
+        }
+    };
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+        if (loader) {
+            float d[18];
+            const bool chan_ok = row_ok && rcin < a.Cin;
+            float sc = 1.f, sh = 0.f;
+            if (pro && chan_ok) { sc = a.scale[rcin]; sh = a.shift[rcin]; }
+#pragma unroll
+            for (int e = 0; e < 18; ++e) {
+                float u = ((rpar >> e) & 1u) ? 0.f : rin[e];
+                if (pro) {
+                    u = fmaf(u, sc, sh);
+                    if (a.relu) u = fmaxf(u, 0.f);
+                }
+                const int t = tq0 - 1 + e;
+                d[e] = (chan_ok && t >= 0 && t < tlim) ? u : 0.f;     // zero padding is post-activation
+            }
+            // B^T d for the 4 tiles of this item, one float4 (4 consecutive tiles) per transform point
+            float vx[6][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d0 = d[4 * i], d1 = d[4 * i + 1], d2 = d[4 * i + 2], d3 = d[4 * i + 3], d4 = d[4 * i + 4],
+                            d5 = d[4 * i + 5];
+                vx[0][i] = 4.f * d0 - 5.f * d2 + d4;
+                vx[1][i] = -4.f * (d1 + d2) + d3 + d4;
+                vx[2][i] = 4.f * (d1 - d2) - d3 + d4;
+                vx[3][i] = -2.f * d1 - d2 + 2.f * d3 + d4;
+                vx[4][i] = 2.f * d1 - d2 - 2.f * d3 + d4;
+                vx[5][i] = 4.f * d1 - 5.f * d3 + d5;
+            }
+#pragma unroll
+            for (int x = 0; x < 6; ++x)
+                *reinterpret_cast<float4*>(v_s + (x * WN_CK + ic) * WN_PLANE_V + ir * 16 + iq * 4) =
+                    make_float4(vx[x][0], vx[x][1], vx[x][2], vx[x][3]);
+        }
+#pragma unroll
+        for (int i = 0; i < WN_U_PER_T; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < WN_U_VEC) {
+                const int q = idx % (WN_CT / 4);
+                const int kc = idx / (WN_CT / 4);        // (kh*6 + xi)*CK + c
+                *reinterpret_cast<float4*>(u_s + kc * WN_COUT_P + q * 4) = ru[i];
+            }
+        }
+    };
+
+    for (int i = tid; i < WN_CT * C::FO_T * 2; i += 256) st_s[i] = 0.f;
+
+    const int nChunks = a.CinP / WN_CK;
+    load_chunk(0);
+    for (int ch = 0; ch < nChunks; ++ch) {
+        __syncthreads();            // previous chunk's MFMA reads are done
+        store_chunk();
+        __syncthreads();
+        if (ch + 1 < nChunks) load_chunk((ch + 1) * WN_CK);   // in flight during the MFMAs below
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+#pragma unroll
+            for (int cs = 0; cs < WN_CK / 4; ++cs) {
+                float bf[4], af[3][2];
+                const float* vp = v_s + (x * WN_CK + cs * 4 + lq) * WN_PLANE_V + (wn * 2) * 16 + lr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bf[r] = vp[r * 16];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        af[kh][m] = u_s[((kh * 6 + x) * WN_CK + cs * 4 + lq) * WN_COUT_P + (wm * 2 + m) * 16 + lr];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int fl = 0; fl < 2; ++fl) acc[x][m][fl] = mfma16(af[kh][m], bf[fl + kh], acc[x][m][fl]);
+            }
+        }
+    }
+
+    // ---- epilogue: A^T M in registers, then bias / pool / statistics / BN-ReLU backward exactly as conv_epilogue,
+    // on 4 consecutive t per lane:  t = t0 + 4*lr + e,  cout = cout0 + (wm*2+m)*16 + lq*4 + r,  f = f0 + wn*2 + fl
+    const int Fo = POOL ? a.F / 2 : a.F;
+    const int tb = t0 + 4 * lr;
+    const bool vec_out = vec && tb + 4 <= a.T;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cl = (wm * 2 + m) * 16 + lq * 4 + r;
+            const int cout = cout0 + cl;
+            const bool cv = cout < a.Cout;
+            const float bias = (a.bias && cv) ? a.bias[cout] : 0.f;
+            const bool bnb = DGRAD && a.bx != nullptr;
+            float bsc = 0.f, bsh = 0.f, bmu = 0.f, bis = 0.f;
+            if (bnb && cv) { bsc = a.bscale[cout]; bsh = a.bshift[cout]; bmu = a.bmean[cout]; bis = a.binvstd[cout]; }
+            float y[2][4];
+#pragma unroll
+            for (int fl = 0; fl < 2; ++fl) {
+                const float m0 = acc[0][m][fl][r], m1 = acc[1][m][fl][r], m2 = acc[2][m][fl][r], m3 = acc[3][m][fl][r],
+                            m4 = acc[4][m][fl][r], m5 = acc[5][m][fl][r];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                y[fl][0] = m0 + s12 + s34 + bias;
+                y[fl][1] = d12 + 2.f * d34 + bias;
+                y[fl][2] = s12 + 4.f * s34 + bias;
+                y[fl][3] = d12 + 8.f * d34 + m5 + bias;
+            }
+            constexpr int NFO = POOL ? 1 : 2;
+#pragma unroll
+            for (int fo_l = 0; fo_l < NFO; ++fo_l) {
+                float v[4];
+                int pidx[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (POOL) {
+                        pidx[e] = y[1][e] > y[0][e];
+                        v[e] = pidx[e] ? y[1][e] : y[0][e];
+                    } else {
+                        v[e] = y[fo_l][e];
+                    }
+                }
+                const int fo = (POOL ? f0 / 2 + wn : f0 + wn * 2 + fo_l);
+                const int st_row = POOL ? wn : wn * 2 + fo_l;
+                float s1 = 0.f, s2 = 0.f;
+                if (cv && fo < Fo && tb < a.T) {
+                    const size_t o = ((size_t)(b * a.Cout + cout) * Fo + fo) * a.T + tb;
+                    if (DGRAD && bnb) {
+                        // backward through mask -> ReLU -> BN-apply of the layer's prologue, with the BN-backward sums
+                        float xv[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (vec_out) {
+                            const float4 x4 = *reinterpret_cast<const float4*>(a.bx + o);
+                            xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (tb + e < a.T) xv[e] = a.bx[o + e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float z = fmaf(xv[e], bsc, bsh);
+                            const bool keep = (tb + e < sl) && (!a.relu || z > 0.f);
+                            v[e] = keep ? v[e] : 0.f;
+                            s1 += v[e]; s2 += v[e] * ((xv[e] - bmu) * bis);
+                        }
+                    } else if (!DGRAD) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (tb + e < sl) { s1 += v[e]; s2 += v[e] * v[e]; }
+                    }
+                    if (vec_out) {
+                        *reinterpret_cast<float4*>(a.y + o) = make_float4(v[0], v[1], v[2], v[3]);
+                        if (POOL && a.pool_idx)
+                            *reinterpret_cast<uchar4*>(a.pool_idx + o) =
+                                make_uchar4((uint8_t)pidx[0], (uint8_t)pidx[1], (uint8_t)pidx[2], (uint8_t)pidx[3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (tb + e < a.T) {
+                                a.y[o + e] = v[e];
+                                if (POOL && a.pool_idx) a.pool_idx[o + e] = (uint8_t)pidx[e];
+                            }
+                    }
+                }
+                if (a.stats) {
+                    s1 = wave_sum16(s1);
+                    s2 = wave_sum16(s2);
+                    if (lr == 0) {
+                        atomicAdd(&st_s[(cl * C::FO_T + st_row) * 2 + 0], s1);
+                        atomicAdd(&st_s[(cl * C::FO_T + st_row) * 2 + 1], s2);
+                    }
+                }
+            }
+        }
+    }
+    if (a.stats) {
+        __syncthreads();
+        for (int i = tid; i < WN_CT * C::FO_T * 2; i += 256) {
+            const int which = i & 1, fo_l = (i >> 1) % C::FO_T, cl = (i >> 1) / C::FO_T;
+            const int cout = cout0 + cl, fo = (POOL ? f0 / 2 : f0) + fo_l;
+            if (cout < a.Cout && fo < Fo) {
+                const int sidx = a.stats_cf ? cout * Fo + fo : cout;
+                const int nstat = a.stats_cf ? a.Cout * Fo : a.Cout;
+                const int slot = blockIdx.x & (PBSED_STAT_SLOTS - 1);
+                atomicAdd(&a.stats[((size_t)slot * nstat + sidx) * 2 + which], (double)st_s[i]);
+            }
+        }
+    }
+}
+
+template <bool POOL, bool DGRAD>
+static int launch_wino(const ConvFwdArgs& a, hipStream_t s) {
+    using C = WinoCfg<POOL>;
+    const int nTt = (a.T + WN_TT - 1) / WN_TT, nFt = (a.F + WN_FT - 1) / WN_FT;
+    dim3 grid(nTt * nFt * a.B, a.CoutP / WN_CT);
+    const size_t lds = C::LDS_FLOATS * sizeof(float);
+    auto kern = conv_wino_kernel<POOL, DGRAD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    return check_launch("conv_wino");
+}
+
+}  // namespace pbsed
+
+using namespace pbsed;
+
+extern "C" {
+
+void pbsed_conv_pack_dims_wino(int Cin, int Cout, int dgrad, int* InP, int* OutP) {
+    const int in = dgrad ? Cout : Cin, out = dgrad ? Cin : Cout;
+    *InP = (in + WN_CK - 1) / WN_CK * WN_CK;
+    *OutP = (out + WN_CT - 1) / WN_CT * WN_CT;
+}
+
+int pbsed_pack_conv_weights_wino(const float* w, float* up, int Cout, int Cin, int dgrad, void* stream) {
+    int InP, OutP;
+    pbsed_conv_pack_dims_wino(Cin, Cout, dgrad, &InP, &OutP);
+    const size_t total = (size_t)18 * InP * OutP;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, up, Cout, Cin, InP, OutP, dgrad);
+    return check_launch("pack_conv_weights_wino");
+}
+
+int pbsed_conv_fwd_wino(const float* x, const float* u_packed, const float* bias, const float* scale, const float* shift,
+                        int relu, const int* seq_len, float* y, unsigned char* pool_idx, double* stats, int stats_per_cf,
+                        int B, int Cin, int Cout, int F, int T, int pool, void* stream) {
+    if (pool && (F % 2)) { set_error("conv_fwd_wino: pool needs even F"); return PBSED_E_ARG; }
+    ConvFwdArgs a{};
+    a.x = x; a.wp = u_packed; a.bias = bias; a.scale = scale; a.shift = shift; a.seq_len = seq_len;
+    a.y = y; a.pool_idx = pool_idx; a.stats = stats; a.stats_cf = stats_per_cf; a.relu = relu;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.F = F; a.T = T;
+    pbsed_conv_pack_dims_wino(Cin, Cout, 0, &a.CinP, &a.CoutP);
+    return pool ? launch_wino<true, false>(a, (hipStream_t)stream) : launch_wino<false, false>(a, (hipStream_t)stream);
+}
+
+int pbsed_conv_bwd_data_wino(const float* g, const float* ud_packed, const unsigned char* unpool_idx, const int* seq_len,
+                             float* dz, const float* bx, const float* bmean, const float* binvstd, const float* bscale,
+                             const float* bshift, int relu, double* stats, int B, int Cin, int Cout, int F, int T,
+                             void* stream) {
+    if (unpool_idx && (F % 2)) { set_error("conv_bwd_data_wino: unpool needs even F"); return PBSED_E_ARG; }
+    ConvFwdArgs a{};
+    a.x = g; a.wp = ud_packed; a.seq_len = seq_len; a.y = dz; a.unpool_idx = unpool_idx;
+    a.bx = bx; a.bmean = bmean; a.binvstd = binvstd; a.bscale = bscale; a.bshift = bshift;
+    a.relu = relu; a.stats = bx ? stats : nullptr;
+    a.B = B; a.Cin = Cout; a.Cout = Cin; a.F = F; a.T = T;      // roles swapped
+    pbsed_conv_pack_dims_wino(Cin, Cout, 1, &a.CinP, &a.CoutP);
+    return launch_wino<false, true>(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -100,10 +100,35 @@ class PackedConv:
         cache[ck] = wp
         return wp
 
+    def _pack_wino(self, dgrad):
+        assert self.kh == 3 and self.kw == 3
+        key = (self.owner._version, PACK_EPOCH[0], self.owner.data_ptr())
+        cache = getattr(self.owner, '_pbsed_pack', None)
+        if cache is None or cache.get('key') != key:
+            cache = {'key': key}
+            try:
+                self.owner._pbsed_pack = cache
+            except AttributeError:
+                pass
+        ck = ('wino', dgrad)
+        if ck in cache:
+            return cache[ck]
+        inp, outp = C.c_int(), C.c_int()
+        _lib.lib().pbsed_conv_pack_dims_wino(self.cin, self.cout, dgrad, C.byref(inp), C.byref(outp))
+        up = torch.empty(18 * inp.value * outp.value, device=self.weight.device, dtype=torch.float32)
+        w = self.weight.detach().contiguous()
+        call('pbsed_pack_conv_weights_wino', ptr(w), ptr(up), self.cout, self.cin, dgrad, stream())
+        cache[ck] = up
+        return up
+
     def fwd(self, precision='f32'):
+        if precision == 'wino':
+            return self._pack_wino(0)
         return self._pack(0) if precision == 'f32' else self._pack_bf16(0, NSPLIT[precision])
 
     def dgrad(self, precision='f32'):
+        if precision == 'wino':
+            return self._pack_wino(1)
         return self._pack(1) if precision == 'f32' else self._pack_bf16(1, NSPLIT[precision])
 
 
@@ -122,6 +147,11 @@ def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=No
     if want_stats:
         stats = torch.zeros((STAT_SLOTS, pc.cout * fo if stats_per_cf else pc.cout, 2), device=x.device,
                             dtype=torch.float64)
+    if precision == 'wino':
+        call('pbsed_conv_fwd_wino', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
+             ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, int(pool), stream(),
+             tag=_conv_tag(b, cin, pc, f, t) + ' wino', flops=_conv_flops(b, cin, pc, f, t))
+        return y, idx, stats
     if precision != 'f32':
         call('pbsed_conv_fwd_bf16', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
              ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, pc.kh, pc.kw, int(pool),
@@ -144,6 +174,11 @@ def conv_bwd_data(g, pc, wd, x_shape, unpool_idx=None, seq_len=None, bn=None, re
     if bn is not None:
         bx, bmean, binv, bsc, bsh = bn
         stats = torch.zeros((STAT_SLOTS, cin, 2), device=g.device, dtype=torch.float64)
+    if precision == 'wino':
+        call('pbsed_conv_bwd_data_wino', ptr(g), ptr(wd), ptr(unpool_idx), ptr(seq_len), ptr(dz), ptr(bx),
+             ptr(bmean), ptr(binv), ptr(bsc), ptr(bsh), int(relu), ptr(stats), b, cin, pc.cout, f, t, stream(),
+             tag=_conv_tag(b, cin, pc, f, t) + ' wino', flops=_conv_flops(b, cin, pc, f, t))
+        return dz, stats
     if precision != 'f32':
         call('pbsed_conv_bwd_data_bf16', ptr(g), ptr(wd), ptr(unpool_idx), ptr(seq_len), ptr(dz), ptr(bx),
              ptr(bmean), ptr(binv), ptr(bsc), ptr(bsh), int(relu), ptr(stats), b, cin, pc.cout, f, t,

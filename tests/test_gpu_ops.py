@@ -387,3 +387,48 @@ def test_gru_wgrad_vs_torch(t, b, g, k):
         if db[i] is not None:
             close(db[i], (db0[i].double() + dg[i].double().sum((0, 1))).float(), atol=2e-5 * (t * b) ** .5, rtol=1e-5,
                   name=f'gru_wgrad db shift {sh}')
+
+
+WINO_CASES = [c for c in CONV_CASES if c['k'] == (3, 3) and c['cin'] >= 16] + [
+    dict(cin=64, cout=64, f=8, t=70, k=(3, 3), pool=False, pro=False),
+    dict(cin=32, cout=64, f=6, t=500, k=(3, 3), pool=True, pro=True),
+    dict(cin=40, cout=72, f=5, t=131, k=(3, 3), pool=False, pro=False),
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES, ids=lambda c: f"{c['cin']}x{c['cout']}f{c['f']}t{c['t']}p{int(c['pool'])}{'pro' if c['pro'] else ''}")
+def test_conv_winograd_vs_torch(case):
+    """3x3 conv with the time axis in the Winograd F(4,3) domain: forward (prologue, bias, pool + argmax, statistics)
+    and data gradient (plain and through the pool argmax) at the fp32 tolerances of the direct kernels."""
+    from pb_sed_amd import ops
+    torch.manual_seed(0)
+    b, cin, cout, f, t, k, pool, pro = 3, case['cin'], case['cout'], case['f'], case['t'], case['k'], case['pool'], case['pro']
+    x = torch.randn(b, cin, f, t, dtype=torch.float64)
+    w = (torch.randn(cout, cin, *k, dtype=torch.float64) / np.sqrt(cin * 9))
+    bias = torch.randn(cout, dtype=torch.float64)
+    seq = np.array([t, max(t - 9, 1), max(t // 2, 1)])
+    scale = (torch.rand(cin, dtype=torch.float64) + .5) if pro else None
+    shift = torch.randn(cin, dtype=torch.float64) * .3 if pro else None
+    xr = x.clone().requires_grad_()
+    y_ref = _conv_ref(xr, w, bias, scale, shift, seq, k, pool)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    dx = lambda a: None if a is None else a.float().to(DEV).contiguous()
+    seq_dev = torch.as_tensor(seq, dtype=torch.int32).to(DEV)
+    pc = ops.PackedConv(dx(w))
+    xd = dx(x)
+    y, idx, stats = ops.conv_fwd(xd, pc, pc.fwd('wino'), bias=dx(bias), scale=dx(scale), shift=dx(shift), relu=True,
+                                 seq_len=seq_dev, pool=pool, want_stats=True, precision='wino')
+    close(y, y_ref, name='conv_fwd wino')
+    m = (torch.arange(t)[None] < torch.as_tensor(seq)[:, None]).double()[:, None, None, :]
+    yd = y_ref.detach()
+    close(stats.sum(0)[:, 0], (yd * m).sum((0, 2, 3)), atol=1e-3, rtol=1e-4, name='stats_sum wino')
+    close(stats.sum(0)[:, 1], (yd * yd * m).sum((0, 2, 3)), atol=1e-3, rtol=1e-4, name='stats_sumsq wino')
+    if pool:        # same argmax as the direct kernel (ties aside) -> same un-pooling in the backward kernels
+        _, idx_d, _ = ops.conv_fwd(xd, pc, pc.fwd(), bias=dx(bias), scale=dx(scale), shift=dx(shift), relu=True,
+                                   seq_len=seq_dev, pool=True)
+        valid = (torch.arange(t, device=DEV)[None] < seq_dev[:, None])[:, None, None, :]     # masked frames tie exactly
+        assert ((idx != idx_d) & valid).float().mean().item() < 2e-3      # near-ties of the pooled rows may resolve differently
+    if not pro:
+        g, _ = ops.conv_bwd_data(dx(gy), pc, pc.dgrad('wino'), xd.shape, idx, None, precision='wino')
+        close(g, xr.grad, atol=2e-4, rtol=1e-3, name='conv_dgrad wino')
