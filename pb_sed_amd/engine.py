@@ -9,6 +9,8 @@ Parameter gradients are accumulated by the kernels straight into ``p.grad`` (ali
 gradient buffer, see ``flatten_parameters``), which is what the fused Adam and the data-parallel
 all-reduce operate on.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -103,10 +105,18 @@ def _count(seq_host, t, rows):
     return float(np.minimum(np.asarray(seq_host), t).sum() * rows)
 
 
-def _prec(precision, cin):
-    """bf16-MFMA kernels work on 32-channel K steps; measured on MI355X they only beat the fp32-MFMA kernels from
-    32 input channels up (16->16 3x3: 0.30 ms bf16 vs 0.17 ms fp32), so thinner layers stay on fp32."""
-    return precision if (precision != 'f32' and cin >= 32) else 'f32'
+def _prec(precision, cin, pc=None, dgrad=False):
+    """Operand format / algorithm of one conv launch.  bf16 modes need >= 32 input channels (below that the conv
+    is HBM-bound and the fp32 kernel is as fast).  In fp32 mode the MFMA-bound 3x3 layers run the Winograd-F(4,3)
+    kernels (csrc/conv_wino.hip: same arithmetic type and results, half the multiplications): contraction over
+    >= 32 channels into >= 64 output channels of the launch (a data gradient produces the layer's cin)."""
+    if precision != 'f32':
+        return precision if cin >= 32 else 'f32'
+    if pc is not None and pc.kh == 3 and pc.kw == 3 and os.environ.get('PBSED_CONV_WINO', '1') != '0':
+        k_in, n_out = (pc.cout, pc.cin) if dgrad else (pc.cin, pc.cout)
+        if k_in >= 32 and n_out >= 64:
+            return 'wino'
+    return 'f32'
 
 
 def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32'):
@@ -125,7 +135,7 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32'):
         if c.ndim == 1 and x.dim() == 4:
             x = x.flatten(1, 2)                       # 'b c f t -> b (c f) t' is a view in this layout
         pc = PackedConv(c.conv.weight)
-        pr = _prec(precision, pc.cin)
+        pr = _prec(precision, pc.cin, pc)
         y, idx, stats = ops.conv_fwd(
             x, pc, pc.fwd(pr), bias=c.conv.bias.detach(),
             scale=None if st_in is None else st_in.scale, shift=None if st_in is None else st_in.shift,
@@ -159,6 +169,7 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
             if on_layer_done is not None:
                 on_layer_done(0)
             return None
+        pr = _prec('f32' if pr == 'wino' else pr, pc.cin, pc, dgrad=True)
         wd = pc.dgrad(pr)
         if st_in is not None:
             dz, stats = ops.conv_bwd_data(g, pc, wd, x.shape, idx, seq_dev,
