@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
                     }
                 }
             }
-            if (tq0 - 1 >= 0) {
+            if (tq0 - 1 >= 0 && tq0 - 1 < a.T) {
                 rin[0] = xb[tq0 - 1];
                 if (unpool) rpar |= (unsigned)(ib[tq0 - 1] != par);
             }
