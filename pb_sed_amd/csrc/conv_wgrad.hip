@@ -276,18 +276,17 @@ static float* wgrad_slot_scratch() {
     return buf[dev];
 }
 
-template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN = false, int KWAVES = 1, int FT_ = 0>
-static int launch_wgrad(const ConvWgradArgs& a_in, hipStream_t s) {
+// Shared launcher: K-split so that the grid is (close to) an integer number of full residency rounds (blocks per CU
+// from the occupancy query, n_cu * occ resident slots, one or two rounds depending on how much K there is), slotted
+// accumulation for small gradients.  C supplies TT, FT, CIN_T, COUT_T, KK, NT, LDS_FLOATS.
+template <class C, class Kern>
+static int launch_wgrad_cfg(Kern kern, const ConvWgradArgs& a_in, hipStream_t s) {
     ConvWgradArgs a = a_in;
-    using C = WgradCfg<KH, KW, WAVES, MT, NCG, TAPN, KWAVES, FT_>;
     const int nTt = (a.T + C::TT - 1) / C::TT, nFt = (a.F + C::FT - 1) / C::FT;
     const int nChunks = a.B * nFt * nTt;
     const int gy = (a.Cin + C::CIN_T - 1) / C::CIN_T;
     const int gz = (a.Cout + C::COUT_T - 1) / C::COUT_T;
     const size_t lds = C::LDS_FLOATS * sizeof(float);
-    auto kern = conv_wgrad_kernel<KH, KW, WAVES, MT, NCG, TAPN, KWAVES, FT_>;
-    // K-split so that the grid is (close to) an integer number of full residency rounds: blocks per CU from
-    // the occupancy query, n_cu * occ resident slots, one or two rounds depending on how much K there is.
     static int slots = 0;
     if (slots == 0) {
         if (lds > 48 * 1024)
@@ -316,13 +315,232 @@ static int launch_wgrad(const ConvWgradArgs& a_in, hipStream_t s) {
         hipMemsetAsync(scratch, 0, sizeof(float) * WGRAD_SLOTS * stride, s);
         a.dw = scratch; a.db = a_in.db ? scratch + nw : nullptr;
         a.nslots = WGRAD_SLOTS; a.slot_w = stride; a.slot_b = stride;
-        hipLaunchKernelGGL(kern, grid, dim3(WAVES * KWAVES * 64), lds, s, a);
+        hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, s, a);
         hipLaunchKernelGGL(wgrad_slot_reduce_kernel, dim3((nw + nb + 255) / 256), dim3(256), 0, s, scratch, a_in.dw, a_in.db,
                            nw, nb, stride);
         return check_launch("conv_wgrad(slotted)");
     }
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * KWAVES * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, s, a);
     return check_launch("conv_wgrad");
+}
+
+template <int KH, int KW, int WAVES, int MT, int NCG, bool TAPN = false, int KWAVES = 1, int FT_ = 0>
+static int launch_wgrad(const ConvWgradArgs& a, hipStream_t s) {
+    return launch_wgrad_cfg<WgradCfg<KH, KW, WAVES, MT, NCG, TAPN, KWAVES, FT_>>(
+        conv_wgrad_kernel<KH, KW, WAVES, MT, NCG, TAPN, KWAVES, FT_>, a, s);
+}
+
+// ============================================================================================
+// 3x3 weight gradient with the time axis in the Winograd F(4,3) domain (the bilinear algorithm of conv_wino.hip
+// transposed): per tile of 4 outputs   dU_xi[kh] += (A dy)_xi * (B^T d)_xi(row f+kh-1),   dw[kh][0..2] = G^T dU[kh].
+// 18 products per 4 output positions instead of 36.  GEMM per point and kernel row: M = Cout (A = transformed dY),
+// N = 16 cin (B = transformed prologue(x)), K = tiles; both transforms are applied between the global load and the
+// LDS store, the G^T transform on the accumulators before the common LDS-transposed atomic reduction.  The bias
+// gradient is the (A dy)_1 = dy0+dy1+dy2+dy3 plane against a ones-vector.
+// ============================================================================================
+struct WinoWgradCfg {
+    static constexpr int FT = 2, TT = 64, KK = 9, NT = 256;
+    static constexpr int COUT_T = 64, CIN_T = 16, TILES = TT / 4, ROWS = FT + 2;
+    static constexpr int PLANE_P = pad2mod32(FT * TILES), PLANE_V = pad2mod32(ROWS * TILES);
+    static constexpr int P_FLOATS = 6 * COUT_T * PLANE_P, V_FLOATS = 6 * CIN_T * PLANE_V;
+    static constexpr int YQ_PER_T = COUT_T * FT * TILES / NT;        // dY tiles (float4) per thread
+    static constexpr int OUT_ROW = CIN_T * KK;
+    static constexpr int LDS_FLOATS = cmax(P_FLOATS + V_FLOATS, COUT_T * OUT_ROW);
+};
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(ConvWgradArgs a) {
+    using C = WinoWgradCfg;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* p_s = smem;                               // [6][COUT_T][PLANE_P]   (row fl, tile) along the plane
+    float* v_s = smem + C::P_FLOATS;                 // [6][CIN_T][PLANE_V]    (halo row, tile)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+    const int cin0 = blockIdx.y * C::CIN_T, cout0 = blockIdx.z * C::COUT_T;
+    const int nTt = (a.T + C::TT - 1) / C::TT, nFt = (a.F + C::FT - 1) / C::FT;
+    const int nChunks = a.B * nFt * nTt;
+    const bool pro = a.scale != nullptr;
+    const bool do_bias = (a.db != nullptr) && (blockIdx.y == 0);
+    const bool unpool = a.unpool_idx != nullptr;
+    const int Fg = unpool ? a.F / 2 : a.F;
+    const bool vec = (a.T & 3) == 0;
+
+    f32x4 acc[3][6];
+    f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int x = 0; x < 6; ++x) acc[kh][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this thread's x item: (cin ic, halo row ir, tile quad iq) and its 8 dY tiles q = tid + i*256 -> (cout, row, tile)
+    const int iq = tid & 3, ir = (tid >> 2) & 3, ic = tid >> 4;
+    float4 ry[C::YQ_PER_T];
+    float rin[18];
+    int r_tq0 = 0, r_tlim = 0;
+    bool r_ok = false;
+
+    auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
+        int c = chunk;
+        const int t0 = (c % nTt) * C::TT; c /= nTt;
+        const int f0 = (c % nFt) * C::FT;
+        const int b = c / nFt;
+        const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
+#pragma unroll
+        for (int i = 0; i < C::YQ_PER_T; ++i) {
+            const int q = tid + i * C::NT;
+            const int tile = q & 15, fl = (q >> 4) & 1, cl = q >> 5;
+            const int cout = cout0 + cl, f = f0 + fl, tq = t0 + 4 * tile;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (cout < a.Cout && f < a.F && tq < a.T) {
+                const size_t o = ((size_t)(b * a.Cout + cout) * Fg + (unpool ? (f >> 1) : f)) * a.T + tq;
+                if (vec) {
+                    const float4 gv = *reinterpret_cast<const float4*>(a.g + o);
+                    v[0] = gv.x; v[1] = gv.y; v[2] = gv.z; v[3] = gv.w;
+                    if (unpool) {
+                        const uchar4 iv = *reinterpret_cast<const uchar4*>(a.unpool_idx + o);
+                        const int par = f & 1;
+                        v[0] = (iv.x == par) ? v[0] : 0.f; v[1] = (iv.y == par) ? v[1] : 0.f;
+                        v[2] = (iv.z == par) ? v[2] : 0.f; v[3] = (iv.w == par) ? v[3] : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (tq + e < a.T) {
+                            v[e] = a.g[o + e];
+                            if (unpool) v[e] = (a.unpool_idx[o + e] == (uint8_t)(f & 1)) ? v[e] : 0.f;
+                        }
+                }
+            }
+            ry[i] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        // raw inputs t = tq0 - 1 .. tq0 + 16 of (cin, halo row); prologue / mask / transform happen in store_chunk
+        const int cin = cin0 + ic, f = f0 - 1 + ir, tq0 = t0 + 16 * iq;
+        r_tq0 = tq0; r_tlim = pro ? sl : a.T;
+        r_ok = cin < a.Cin && f >= 0 && f < a.F;
+#pragma unroll
+        for (int e = 0; e < 18; ++e) rin[e] = 0.f;
+        if (r_ok) {
+            const float* xp = a.x + ((size_t)(b * a.Cin + cin) * a.F + f) * a.T;
+            if (vec && tq0 + 16 <= a.T) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xp + tq0 + 4 * q);
+                    rin[1 + 4 * q] = xv.x; rin[2 + 4 * q] = xv.y; rin[3 + 4 * q] = xv.z; rin[4 + 4 * q] = xv.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 1; e < 17; ++e)
+                    if (tq0 - 1 + e < a.T) rin[e] = xp[tq0 - 1 + e];
+            }
+            if (tq0 - 1 >= 0 && tq0 - 1 < a.T) rin[0] = xp[tq0 - 1];
+            if (tq0 + 16 < a.T) rin[17] = xp[tq0 + 16];
+        }
+    };
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+        // A dy: one tile (float4) -> 6 points
+#pragma unroll
+        for (int i = 0; i < C::YQ_PER_T; ++i) {
+            const int q = tid + i * C::NT;
+            const int pos = q & 31, cl = q >> 5;            // pos = fl*16 + tile
+            const float y0 = ry[i].x, y1 = ry[i].y, y2 = ry[i].z, y3 = ry[i].w;
+            const float e02 = y0 + y2, o13 = y1 + y3, e04 = y0 + 4.f * y2, o28 = 2.f * y1 + 8.f * y3;
+            float* d = p_s + cl * C::PLANE_P + pos;
+            d[0 * C::COUT_T * C::PLANE_P] = y0;
+            d[1 * C::COUT_T * C::PLANE_P] = e02 + o13;
+            d[2 * C::COUT_T * C::PLANE_P] = e02 - o13;
+            d[3 * C::COUT_T * C::PLANE_P] = e04 + o28;
+            d[4 * C::COUT_T * C::PLANE_P] = e04 - o28;
+            d[5 * C::COUT_T * C::PLANE_P] = y3;
+        }
+        // B^T d of prologue(x)
+        float dv[18];
+        float sc = 1.f, sh = 0.f;
+        if (pro && r_ok) { sc = a.scale[cin0 + ic]; sh = a.shift[cin0 + ic]; }
+#pragma unroll
+        for (int e = 0; e < 18; ++e) {
+            float u = rin[e];
+            if (pro) {
+                u = fmaf(u, sc, sh);
+                if (a.relu) u = fmaxf(u, 0.f);
+            }
+            const int t = r_tq0 - 1 + e;
+            dv[e] = (r_ok && t >= 0 && t < r_tlim) ? u : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d0 = dv[4 * i], d1 = dv[4 * i + 1], d2 = dv[4 * i + 2], d3 = dv[4 * i + 3], d4 = dv[4 * i + 4],
+                        d5 = dv[4 * i + 5];
+            float* d = v_s + ic * C::PLANE_V + ir * 16 + iq * 4 + i;
+            d[0 * C::CIN_T * C::PLANE_V] = 4.f * d0 - 5.f * d2 + d4;
+            d[1 * C::CIN_T * C::PLANE_V] = -4.f * (d1 + d2) + d3 + d4;
+            d[2 * C::CIN_T * C::PLANE_V] = 4.f * (d1 - d2) - d3 + d4;
+            d[3 * C::CIN_T * C::PLANE_V] = -2.f * d1 - d2 + 2.f * d3 + d4;
+            d[4 * C::CIN_T * C::PLANE_V] = 2.f * d1 - d2 - 2.f * d3 + d4;
+            d[5 * C::CIN_T * C::PLANE_V] = 4.f * d1 - 5.f * d3 + d5;
+        }
+    };
+
+    int chunk = blockIdx.x;
+    if (chunk < nChunks) load_chunk(chunk);
+    for (; chunk < nChunks; chunk += gridDim.x) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (chunk + (int)gridDim.x < nChunks) load_chunk(chunk + gridDim.x);
+#pragma unroll 2
+        for (int kk = 0; kk < C::TILES / 4; ++kk) {
+#pragma unroll
+            for (int x = 0; x < 6; ++x) {
+                float af[2], bf[4];
+                const float* pp = p_s + (x * C::COUT_T + wave * 16 + lr) * C::PLANE_P + kk * 4 + lq;
+                af[0] = pp[0]; af[1] = pp[16];
+                const float* vp = v_s + (x * C::CIN_T + lr) * C::PLANE_V + kk * 4 + lq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bf[r] = vp[r * 16];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    acc[kh][x] = mfma16(af[0], bf[kh], acc[kh][x]);
+                    acc[kh][x] = mfma16(af[1], bf[kh + 1], acc[kh][x]);
+                }
+                if (x == 1 && do_bias) {
+                    accb = mfma16(af[0], 1.0f, accb);
+                    accb = mfma16(af[1], 1.0f, accb);
+                }
+            }
+        }
+    }
+
+    // ---- G^T on the accumulators, then transpose the block's partial dW through LDS and reduce with row-contiguous atomics
+    __syncthreads();
+    float* out_s = smem;                             // [COUT_T][OUT_ROW]
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float u0 = acc[kh][0][r], u1 = acc[kh][1][r], u2 = acc[kh][2][r], u3 = acc[kh][3][r], u4 = acc[kh][4][r],
+                        u5 = acc[kh][5][r];
+            const float s12 = u1 + u2, s34 = u3 + u4;
+            float* o = out_s + (wave * 16 + lq * 4 + r) * C::OUT_ROW + lr * 9 + kh * 3;
+            o[0] = .25f * u0 - s12 * (1.f / 6.f) + s34 * (1.f / 24.f);
+            o[1] = (u2 - u1) * (1.f / 6.f) + (u3 - u4) * (1.f / 12.f);
+            o[2] = (s34 - s12) * (1.f / 6.f) + u5;
+        }
+    __syncthreads();
+    const int ncol = min(C::CIN_T, a.Cin - cin0) * 9;      // valid, contiguous part of each row
+    const int slot = a.nslots > 1 ? (int)(blockIdx.x % a.nslots) : 0;
+    float* dwp = a.dw + (size_t)slot * a.slot_w;
+    for (int row = tid >> 6; row < C::COUT_T; row += C::NT / 64) {
+        const int cout = cout0 + row;
+        if (cout >= a.Cout) break;
+        float* dst = dwp + ((size_t)cout * a.Cin + cin0) * 9;
+        for (int col = lane; col < ncol; col += 64) atomicAdd(dst + col, out_s[row * C::OUT_ROW + col]);
+    }
+    if (do_bias && lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cout = cout0 + wave * 16 + lq * 4 + r;
+            if (cout < a.Cout) atomicAdd(&a.db[(size_t)slot * a.slot_b + cout], accb[r]);
+        }
+    }
 }
 
 int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
@@ -339,6 +557,8 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
             if (ft_knob > 1) return launch_wgrad<3, 3, 1, 1, 1, true, 4, 8>(a, s);
             return kw_knob > 1 ? launch_wgrad<3, 3, 1, 1, 1, true, 4>(a, s) : launch_wgrad<3, 3, 1, 1, 1, true>(a, s);
         }
+        static const int wino_knob = getenv("PBSED_WGRAD_WINO") ? atoi(getenv("PBSED_WGRAD_WINO")) : 1;
+        if (a.Cout >= 64 && a.Cin >= 16 && wino_knob) return launch_wgrad_cfg<WinoWgradCfg>(conv_wgrad_wino_kernel, a, s);
         if (a.Cout >= 64) return wide ? launch_wgrad<3, 3, 4, 1, 2>(a, s) : launch_wgrad<3, 3, 4, 1, 1>(a, s);
         if (a.Cout >= 32) {
             if (wide) return launch_wgrad<3, 3, 2, 1, 2>(a, s);
