@@ -195,9 +195,11 @@ def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, se
                     unpool_idx=None):
     """dw (+=), db (+=): gradients of the conv parameters (buffers must be pre-zeroed/accumulating)."""
     b, cin, f, t = _dims4(x)
+    # the library runs its Winograd-F(4,3) weight-gradient kernel for these shapes (conv_wgrad.hip dispatch)
+    wino = pc.kh == 3 and pc.kw == 3 and pc.cout >= 64 and cin >= 16 and os.environ.get('PBSED_WGRAD_WINO', '1') != '0'
     call('pbsed_conv_bwd_weight', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(g),
          ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream(),
-         tag=_conv_tag(b, cin, pc, f, t), flops=_conv_flops(b, cin, pc, f, t))
+         tag=_conv_tag(b, cin, pc, f, t) + (' wino' if wino else ''), flops=_conv_flops(b, cin, pc, f, t))
 
 
 class BNState:
