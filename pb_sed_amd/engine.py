@@ -279,6 +279,10 @@ def _wgrad_job(jobs, dg, x, shift, dw, db):
         lst.append(v)
 
 
+def _scan_as_stack(wrappers):
+    return wrappers[0].hidden_size in (64, 128, 256, 512)
+
+
 def rnn_forward(wrappers, h, seq_dev, seq_host, training, precision='f32'):
     """wrappers: list of modules.GRU sharing the input h [B,C,T].  Returns (logits per wrapper, ctx)."""
     chains = _chains(wrappers)
@@ -299,9 +303,15 @@ def rnn_forward(wrappers, h, seq_dev, seq_host, training, precision='f32'):
                                    seq_len=None, precision=pr)
             gi.append(ops.bct_to_tbc(y))
             pcs.append(pc)
-        hs, save = ops.gru_scan_fwd(gi, [ch.p('weight_hh', l).detach() for ch in chains],
-                                    [ch.p('bias_hh', l).detach() for ch in chains],
-                                    [ch.reverse for ch in chains], seq_dev, save=training)
+        w_hh_l = [ch.p('weight_hh', l).detach() for ch in chains]
+        b_hh_l = [ch.p('bias_hh', l).detach() for ch in chains]
+        if _scan_as_stack(wrappers):
+            # one layer of a (bi)directional GRU = len(chains) independent one-layer stacks: persistent scan
+            none = [None] * len(chains)
+            hs, save = ops.gru_stack_fwd(gi, none, none, w_hh_l, b_hh_l, [ch.reverse for ch in chains], seq_dev, 1,
+                                         save=training)
+        else:
+            hs, save = ops.gru_scan_fwd(gi, w_hh_l, b_hh_l, [ch.reverse for ch in chains], seq_dev, save=training)
         hs_bct = [ops.tbc_to_bct(h_) for h_ in hs]
         layer_ctx.append((list(x_w), pcs, hs, save))
         x_w = []
@@ -331,7 +341,11 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
             k = [j for j, c2 in enumerate(chains) if c2.widx == ch.widx].index(i)
             dy.append(ops.bct_to_tbc(d_out[ch.widx][:, k * hid:(k + 1) * hid].contiguous()))
         w_hh_t = [ops.transpose2d(ch.p('weight_hh', l).detach()) for ch in chains]
-        dgi, dgh = ops.gru_scan_bwd(w_hh_t, hs, save, dy, [ch.reverse for ch in chains], seq_dev)
+        if _scan_as_stack(wrappers):
+            dgi, dgh = ops.gru_stack_bwd(w_hh_t, [None] * len(chains), hs, save, dy, [ch.reverse for ch in chains],
+                                         seq_dev, 1)
+        else:
+            dgi, dgh = ops.gru_scan_bwd(w_hh_t, hs, save, dy, [ch.reverse for ch in chains], seq_dev)
         dx_w = [None for _ in wrappers]
         for i, ch in enumerate(chains):
             dgi_b, dgh_b = ops.tbc_to_bct(dgi[i]), ops.tbc_to_bct(dgh[i])
