@@ -306,11 +306,18 @@ def check_gru_sync():
         raise RuntimeError('persistent GRU scan: inter-workgroup hand-off timed out (PBSED_GRU_PERSIST=0 disables it)')
 
 
-def _granule_scan(nch, nlayers, b, h, t):
-    """Persistent granule-exchange scans need every workgroup co-resident (one per CU, 256 CUs): a ring per
-    (chain, layer) plus a projection group per layer boundary, each H/16 x ceil(B/16) blocks."""
+_CU_COUNT = {}
+
+
+def _granule_scan(nch, nlayers, b, h, t, device=None):
+    """Persistent granule-exchange scans need every workgroup co-resident (one per CU): a ring per (chain, layer)
+    plus a projection group per layer boundary, each H/16 x ceil(B/16) blocks, on at most 7/8 of the device's CUs
+    (256 on an MI355X in SPX mode; a partitioned device falls back to the launch-per-step scans)."""
     blocks = nch * (2 * nlayers - 1) * ((b + 15) // 16) * (h // 16)
-    return (os.environ.get('PBSED_GRU_PERSIST', '2') == '2' and blocks <= 224
+    dev = torch.cuda.current_device() if device is None else device
+    if dev not in _CU_COUNT:
+        _CU_COUNT[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    return (os.environ.get('PBSED_GRU_PERSIST', '2') == '2' and blocks <= _CU_COUNT[dev] * 7 // 8
             and nch * nlayers * t * b * h * 8 < 2 ** 32)
 
 
@@ -323,7 +330,7 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
     dev = gi0[0].device
     n = nch * nlayers
     hs = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
-    gran = _granule_scan(nch, nlayers, b, h, t)
+    gran = _granule_scan(nch, nlayers, b, h, t, dev)
     # saved per step: (r, z, n, gh_n), or in granule mode the five factors BPTT multiplies dh_t with
     sv = [torch.empty((t, b, 5 if gran else 4, h), device=dev, dtype=torch.float32) for _ in range(n)] if save else None
     if gran:
@@ -351,7 +358,7 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
     n = nch * nlayers
     dgi = [torch.empty((t, b, 3 * h), device=dev, dtype=torch.float32) for _ in range(n)]
     dgh = [torch.empty((t, b, 3 * h), device=dev, dtype=torch.float32) for _ in range(n)]
-    if _granule_scan(nch, nlayers, b, h, t):
+    if _granule_scan(nch, nlayers, b, h, t, dev):
         assert save[0].shape[2] == 5, 'granule BPTT needs the granule forward scan\'s save format'
         key = (str(dev), 'bwd', n, t, b, h)
         gw = _GRANULE_WS.get(key)
