@@ -63,6 +63,15 @@ int pbsed_conv_bwd_weight(const float* x, const float* scale, const float* shift
 /* bf16-MFMA variants (same contracts; activations stay fp32 in HBM, operands are converted while staging, fp32
  * accumulate).  nsplit = 1: plain bf16 compute (BASELINE.json config 3).  nsplit = 3: exact 3-way bf16 split of both
  * operands, 6 partial products -> fp32-class accuracy.  w_packed_bf16: uint16 [nsplit][KH*KW][out_padded][in_padded]. */
+/* Refresh many packed copies in one launch (e.g. all layers of a model after an optimiser step).  descs: DEVICE array. */
+typedef struct {
+    const float* src;       /* [Cout, Cin, KH, KW] weights */
+    float* dst;             /* packed copy (sizes from pbsed_conv_pack_dims / pbsed_conv_pack_dims_wino) */
+    int Cout, Cin, KH, KW, InP, OutP;
+    int mode;               /* 0 / 1: direct forward / data-gradient layout, 2 / 3: Winograd forward / data-gradient */
+    int pad_;
+} pbsed_pack_desc;
+int pbsed_pack_conv_weights_batched(const pbsed_pack_desc* descs /*device*/, int n, void* stream);
 /* 3x3 convs with the time axis in the Winograd F(4,3) domain (csrc/conv_wino.hip): same tensors, fusions and results
  * (fp32 MFMA, fp32 accumulate; ~1e-6 relative transform rounding) as pbsed_conv_fwd / pbsed_conv_bwd_data with
  * KH = KW = 3, half the multiplications.  u_packed: [3][6][in_padded][out_padded] from pbsed_pack_conv_weights_wino. */

@@ -27,6 +27,7 @@ SIGNATURES = {
     'pbsed_pack_conv_weights': [_v, _v, I, I, I, I, I, _v],
     'pbsed_conv_fwd': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, I, I, _v],
     'pbsed_conv_bwd_data': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, _v, I, I, I, I, I, I, I, _v],
+    'pbsed_pack_conv_weights_batched': [_v, I, _v],
     'pbsed_conv_pack_dims_wino': [I, I, I, _i, _i],
     'pbsed_pack_conv_weights_wino': [_v, _v, I, I, I, _v],
     'pbsed_conv_fwd_wino': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, _v],

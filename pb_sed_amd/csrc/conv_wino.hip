@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "pack_elems.h"
 #include "pbsed_internal.h"
 
 namespace pbsed {
@@ -39,34 +40,11 @@ struct WinoCfg {
     static constexpr int LDS_FLOATS = WN_V_FLOATS + WN_U_FLOATS + WN_CT * FO_T * 2;
 };
 
-// U[kh][xi][InP][OutP] = sum_kw G[xi][kw] * g[kh][kw]; dgrad: g = flipped kernel with in/out channels swapped.
 __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin, int InP, int OutP,
                                  int dgrad) {
     const size_t total = (size_t)18 * InP * OutP;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int o = i % OutP, ii = (i / OutP) % InP, kx = i / ((size_t)OutP * InP);
-        const int kh = kx / 6, xi = kx % 6;
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-        if (!dgrad) {
-            if (o < Cout && ii < Cin) {
-                const float* p = w + ((size_t)o * Cin + ii) * 9 + kh * 3;
-                g0 = p[0]; g1 = p[1]; g2 = p[2];
-            }
-        } else if (o < Cin && ii < Cout) {
-            const float* p = w + ((size_t)ii * Cin + o) * 9 + (2 - kh) * 3;
-            g0 = p[2]; g1 = p[1]; g2 = p[0];
-        }
-        float v;
-        switch (xi) {
-            case 0: v = .25f * g0; break;
-            case 1: v = -(g0 + g1 + g2) * (1.f / 6.f); break;
-            case 2: v = (-g0 + g1 - g2) * (1.f / 6.f); break;
-            case 3: v = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f); break;
-            case 4: v = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f); break;
-            default: v = g2; break;
-        }
-        up[i] = v;
-    }
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        up[i] = pack_wino_elem(w, i, Cout, Cin, InP, OutP, dgrad);
 }
 
 template <bool POOL, bool DGRAD>

@@ -3,6 +3,7 @@
 // weak_label_crnn/training.py:223-225), losses pb_sed/models/weak_label/crnn.py:107-206 and
 // pb_sed/models/strong_label/crnn.py:106-112, optimiser training.py:264-269 (Adam + grad-norm clip).
 #include "common.h"
+#include "pack_elems.h"
 #include "pbsed_internal.h"
 
 namespace pbsed {
@@ -14,17 +15,27 @@ __global__ void pack_conv_weights_kernel(const float* __restrict__ w, float* __r
     const int KK = KH * KW;
     const size_t total = (size_t)KK * InP * OutP;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const int o = i % OutP, ii = (i / OutP) % InP, kk = i / ((size_t)OutP * InP);
-        float v = 0.f;
-        if (!dgrad) {
-            if (o < Cout && ii < Cin) v = w[((size_t)o * Cin + ii) * KK + kk];
-        } else {
-            // kernel-input channel ii = layer cout, kernel-output channel o = layer cin
-            if (o < Cin && ii < Cout) v = w[((size_t)ii * Cin + o) * KK + (KK - 1 - kk)];
-        }
-        wp[i] = v;
-    }
+         i += (size_t)gridDim.x * blockDim.x)
+        wp[i] = pack_direct_elem(w, i, Cout, Cin, KK, InP, OutP, dgrad);
+}
+
+// Every packed copy of a model in one launch: blockIdx.y = descriptor (device array), blockIdx.x strides its elements.
+struct PackDesc {
+    const float* src;
+    float* dst;
+    int Cout, Cin, KH, KW, InP, OutP;
+    int mode;      // 0/1: direct forward / data-gradient layout, 2/3: Winograd forward / data-gradient layout
+    int pad_;
+};
+
+__global__ void pack_batched_kernel(const PackDesc* __restrict__ descs) {
+    const PackDesc d = descs[blockIdx.y];
+    const bool wino = d.mode >= 2;
+    const int KK = d.KH * d.KW;
+    const size_t total = (size_t)(wino ? 18 : KK) * d.InP * d.OutP;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        d.dst[i] = wino ? pack_wino_elem(d.src, i, d.Cout, d.Cin, d.InP, d.OutP, d.mode & 1)
+                        : pack_direct_elem(d.src, i, d.Cout, d.Cin, KK, d.InP, d.OutP, d.mode & 1);
 }
 
 // sums [C][2] (sum x, sum x^2 over masked positions) -> batch statistics + fused scale/shift.
@@ -365,6 +376,12 @@ int pbsed_pack_conv_weights(const float* w, float* wp, int Cout, int Cin, int KH
     hipLaunchKernelGGL(pack_conv_weights_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream,
                        w, wp, Cout, Cin, KH, KW, InP, OutP, dgrad);
     return check_launch("pack_conv_weights");
+}
+
+int pbsed_pack_conv_weights_batched(const void* descs, int n, void* stream) {
+    if (n < 1) return PBSED_OK;
+    hipLaunchKernelGGL(pack_batched_kernel, dim3(128, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
+    return check_launch("pack_conv_weights_batched");
 }
 
 int pbsed_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,

@@ -6,6 +6,8 @@ current stream.  Shapes follow the reference layouts: 2-D activations ``[B, C, F
 """
 import ctypes as C
 import os
+import struct
+import weakref
 
 import numpy as np
 import torch
@@ -38,6 +40,44 @@ PACK_EPOCH = [0]      # bump (invalidate_packed) whenever parameters are changed
 
 def invalidate_packed():
     PACK_EPOCH[0] += 1
+
+
+_PACKS = {}          # (src data_ptr, mode) -> _PackEntry: every fp32 packed copy made so far (for refresh_packs)
+_PACK_DESC = [None, None]     # (tuple of registry keys, device descriptor array)
+
+
+class _PackEntry:
+    def __init__(self, owner, src_ptr, dst, dims, mode, cache_key):
+        self.owner, self.src_ptr, self.dst, self.dims, self.mode, self.cache_key = weakref.ref(owner), src_ptr, dst, dims, mode, cache_key
+
+
+def _register_pack(owner, weight, dst, dims, mode, cache_key):
+    if weight.is_contiguous():
+        _PACKS[(weight.data_ptr(), mode)] = _PackEntry(owner, weight.data_ptr(), dst, dims, mode, cache_key)
+
+
+def refresh_packs():
+    """Re-pack every registered fp32 / Winograd weight copy in ONE launch and mark the per-parameter caches current
+    (called by Trainer.step after the fused Adam changed the parameters in place): ~40 pack launches -> 1."""
+    dead = [k for k, e in _PACKS.items() if e.owner() is None or e.owner().data_ptr() != e.src_ptr]
+    for k in dead:
+        del _PACKS[k]
+    if not _PACKS:
+        return
+    keys = tuple(_PACKS)
+    if _PACK_DESC[0] != keys:
+        raw = b''.join(struct.pack('<QQiiiiiiii', e.src_ptr, e.dst.data_ptr(), *e.dims, e.mode, 0) for e in _PACKS.values())
+        dev = next(iter(_PACKS.values())).dst.device
+        _PACK_DESC[0], _PACK_DESC[1] = keys, torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    call('pbsed_pack_conv_weights_batched', ptr(_PACK_DESC[1]), len(keys), stream())
+    for e in _PACKS.values():
+        owner = e.owner()
+        key = (owner._version, PACK_EPOCH[0], owner.data_ptr())
+        cache = getattr(owner, '_pbsed_pack', None)
+        if cache is None or cache.get('key') != key:
+            cache = {'key': key}
+            owner._pbsed_pack = cache
+        cache[e.cache_key] = e.dst
 
 
 class PackedConv:
@@ -76,6 +116,7 @@ class PackedConv:
         w = self.weight.detach().contiguous()
         call('pbsed_pack_conv_weights', ptr(w), ptr(wp), self.cout, self.cin, self.kh, self.kw, dgrad, stream())
         cache[dgrad] = wp
+        _register_pack(self.owner, self.weight, wp, (self.cout, self.cin, self.kh, self.kw, inp.value, outp.value), dgrad, dgrad)
         return wp
 
     def _pack_bf16(self, dgrad, nsplit):
@@ -119,6 +160,7 @@ class PackedConv:
         w = self.weight.detach().contiguous()
         call('pbsed_pack_conv_weights_wino', ptr(w), ptr(up), self.cout, self.cin, dgrad, stream())
         cache[ck] = up
+        _register_pack(self.owner, self.weight, up, (self.cout, self.cin, 3, 3, inp.value, outp.value), 2 + dgrad, ck)
         return up
 
     def fwd(self, precision='f32'):
@@ -130,6 +172,29 @@ class PackedConv:
         if precision == 'wino':
             return self._pack_wino(1)
         return self._pack(1) if precision == 'f32' else self._pack_bf16(1, NSPLIT[precision])
+
+
+class _ZeroArena:
+    """Zero-initialised float64 scratch handed out in slices that are each used once (the statistics accumulators of
+    the conv epilogues): one 32 MB fill every few steps instead of one fill launch per conv layer and pass."""
+
+    def __init__(self):
+        self.buf, self.off = None, 0
+
+    def take(self, n, device):
+        if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
+            self.buf = torch.zeros(max(1 << 22, n), dtype=torch.float64, device=device)
+            self.off = 0
+        out = self.buf[self.off:self.off + n]
+        self.off += (n + 15) // 16 * 16
+        return out
+
+
+_STATS_ARENA = _ZeroArena()
+
+
+def _zero_stats(c, device):
+    return _STATS_ARENA.take(STAT_SLOTS * c * 2, torch.device(device)).view(STAT_SLOTS, c, 2)
 
 
 def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=None, pool=False,
@@ -145,8 +210,7 @@ def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=No
     idx = torch.empty(shape, device=x.device, dtype=torch.uint8) if pool else None
     stats = None
     if want_stats:
-        stats = torch.zeros((STAT_SLOTS, pc.cout * fo if stats_per_cf else pc.cout, 2), device=x.device,
-                            dtype=torch.float64)
+        stats = _zero_stats(pc.cout * fo if stats_per_cf else pc.cout, x.device)
     if precision == 'wino':
         call('pbsed_conv_fwd_wino', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
              ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, int(pool), stream(),
@@ -173,7 +237,7 @@ def conv_bwd_data(g, pc, wd, x_shape, unpool_idx=None, seq_len=None, bn=None, re
     bx = bmean = binv = bsc = bsh = None
     if bn is not None:
         bx, bmean, binv, bsc, bsh = bn
-        stats = torch.zeros((STAT_SLOTS, cin, 2), device=g.device, dtype=torch.float64)
+        stats = _zero_stats(cin, g.device)
     if precision == 'wino':
         call('pbsed_conv_bwd_data_wino', ptr(g), ptr(wd), ptr(unpool_idx), ptr(seq_len), ptr(dz), ptr(bx),
              ptr(bmean), ptr(binv), ptr(bsc), ptr(bsh), int(relu), ptr(stats), b, cin, pc.cout, f, t, stream(),

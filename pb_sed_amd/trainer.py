@@ -112,6 +112,7 @@ class Trainer:
                       beta2=self.betas[1], eps=self.eps, step=self.iteration, grad_scale=scale,
                       max_norm=self.clip, sumsq=self.sumsq, norm_out=self.grad_norm)
         ops.invalidate_packed()          # parameters changed in place behind torch's version counters
+        ops.refresh_packs()              # ... and every packed copy is rebuilt in one launch
         review['scalars']['grad_norm'] = self.grad_norm
         finalize = review.pop('_finalize', None)
         if finalize is not None:
