@@ -91,11 +91,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
     unsigned rpar = 0;                               // DGRAD + unpool: bit e set = element e comes from the other pool row
     float4 ru[WN_U_PER_T];
     int rcin = 0;
+    float rsc = 1.f, rsh = 0.f;                      // BN-apply factors of this item's channel, fetched with the chunk
 
     // global loads only: everything that depends on the loaded values happens in store_chunk, after the MFMAs
     auto load_chunk = [&](int c0) __attribute__((always_inline)) {
         rcin = c0 + ic;
         rpar = 0;
+        if (pro && row_ok && rcin < a.Cin) { rsc = a.scale[rcin]; rsh = a.shift[rcin]; }
 #pragma unroll
         for (int e = 0; e < 18; ++e) rin[e] = 0.f;
         if (row_ok && rcin < a.Cin) {
@@ -148,13 +150,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
         if (loader) {
             float d[18];
             const bool chan_ok = row_ok && rcin < a.Cin;
-            float sc = 1.f, sh = 0.f;
-            if (pro && chan_ok) { sc = a.scale[rcin]; sh = a.shift[rcin]; }
 #pragma unroll
             for (int e = 0; e < 18; ++e) {
                 float u = ((rpar >> e) & 1u) ? 0.f : rin[e];
                 if (pro) {
-                    u = fmaf(u, sc, sh);
+                    u = fmaf(u, rsc, rsh);
                     if (a.relu) u = fmaxf(u, 0.f);
                 }
                 const int t = tq0 - 1 + e;

@@ -432,3 +432,29 @@ def test_conv_winograd_vs_torch(case):
     if not pro:
         g, _ = ops.conv_bwd_data(dx(gy), pc, pc.dgrad('wino'), xd.shape, idx, None, precision='wino')
         close(g, xr.grad, atol=2e-4, rtol=1e-3, name='conv_dgrad wino')
+
+
+@pytest.mark.parametrize('cin,cout,f,t,pool', [(64, 64, 8, 150, True), (32, 96, 6, 65, False), (128, 64, 4, 500, True)])
+def test_conv_winograd_dgrad_bn_epilogue_matches_direct(cin, cout, f, t, pool):
+    """Data gradient with the fused BN-ReLU-mask backward epilogue (and un-pooling): Winograd vs direct kernel on
+    the same inputs - dz, and the (sum dz, sum dz*xhat) statistics BN backward needs."""
+    from pb_sed_amd import ops
+    torch.manual_seed(3)
+    b = 3
+    fo = f // 2 if pool else f
+    x = torch.randn(b, cin, f, t, device=DEV)                       # the layer's raw (pre-BN) forward input
+    w = torch.randn(cout, cin, 3, 3, device=DEV) / (cin * 9) ** .5
+    g = torch.randn(b, cout, fo, t, device=DEV)
+    idx = torch.randint(0, 2, (b, cout, fo, t), device=DEV, dtype=torch.uint8) if pool else None
+    seq = torch.tensor([t, max(t - 9, 1), max(t // 2, 1)], dtype=torch.int32, device=DEV)
+    mean, invstd = torch.randn(cin, device=DEV) * .1, torch.rand(cin, device=DEV) + .5
+    gamma, beta = torch.rand(cin, device=DEV) + .5, torch.randn(cin, device=DEV) * .3
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    pc = ops.PackedConv(w)
+    out = {}
+    for prec in ('f32', 'wino'):
+        dz, st = ops.conv_bwd_data(g, pc, pc.dgrad(prec), x.shape, idx, seq, bn=(x, mean, invstd, scale, shift),
+                                   precision=prec)
+        out[prec] = (dz, st.sum(0))
+    close(out['wino'][0], out['f32'][0], atol=2e-5, rtol=1e-4, name='dz wino vs direct')
+    close(out['wino'][1], out['f32'][1], atol=2e-3, rtol=1e-4, name='bn-backward sums wino vs direct')
