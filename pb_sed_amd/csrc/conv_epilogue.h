@@ -88,15 +88,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvFwdArgs& a, f32x4 (&acc)
     }
     if (a.stats) {
         __syncthreads();
-        for (int i = tid; i < COUT_T * FO_T * 2; i += 256) {
-            const int which = i & 1, fo_l = (i >> 1) % FO_T, cl = (i >> 1) / FO_T;
-            const int cout = cout0 + cl, fo = (POOL ? f0 / 2 : f0) + fo_l;
-            if (cout < a.Cout && fo < Fo) {
-                const int sidx = a.stats_cf ? cout * Fo + fo : cout;
-                const int nstat = a.stats_cf ? a.Cout * Fo : a.Cout;
-                // PBSED_STAT_SLOTS copies of the accumulators spread same-address atomic contention
-                const int slot = blockIdx.x & (PBSED_STAT_SLOTS - 1);
-                atomicAdd(&a.stats[((size_t)slot * nstat + sidx) * 2 + which], (double)st_s[i]);
+        const int Fo_ = POOL ? a.F / 2 : a.F;
+        // PBSED_STAT_SLOTS copies of the accumulators spread same-address atomic contention
+        const int slot = blockIdx.x & (PBSED_STAT_SLOTS - 1);
+        if (a.stats_cf) {
+            for (int i = tid; i < COUT_T * FO_T * 2; i += 256) {
+                const int which = i & 1, fo_l = (i >> 1) % FO_T, cl = (i >> 1) / FO_T;
+                const int cout = cout0 + cl, fo = (POOL ? f0 / 2 : f0) + fo_l;
+                if (cout < a.Cout && fo < Fo_)
+                    atomicAdd(&a.stats[((size_t)slot * a.Cout * Fo_ + cout * Fo_ + fo) * 2 + which], (double)st_s[i]);
+            }
+        } else {
+            // per-channel statistics: the block's rows are summed first, one atomic per (channel, moment)
+            for (int i = tid; i < COUT_T * 2; i += 256) {
+                const int which = i & 1, cl = i >> 1, cout = cout0 + cl;
+                float v = 0.f;
+#pragma unroll
+                for (int fo_l = 0; fo_l < FO_T; ++fo_l) v += st_s[(cl * FO_T + fo_l) * 2 + which];
+                if (cout < a.Cout) atomicAdd(&a.stats[((size_t)slot * a.Cout + cout) * 2 + which], (double)v);
             }
         }
     }

@@ -317,14 +317,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
     }
     if (a.stats) {
         __syncthreads();
-        for (int i = tid; i < WN_CT * C::FO_T * 2; i += 256) {
-            const int which = i & 1, fo_l = (i >> 1) % C::FO_T, cl = (i >> 1) / C::FO_T;
-            const int cout = cout0 + cl, fo = (POOL ? f0 / 2 : f0) + fo_l;
-            if (cout < a.Cout && fo < Fo) {
-                const int sidx = a.stats_cf ? cout * Fo + fo : cout;
-                const int nstat = a.stats_cf ? a.Cout * Fo : a.Cout;
-                const int slot = blockIdx.x & (PBSED_STAT_SLOTS - 1);
-                atomicAdd(&a.stats[((size_t)slot * nstat + sidx) * 2 + which], (double)st_s[i]);
+        const int slot = blockIdx.x & (PBSED_STAT_SLOTS - 1);
+        if (a.stats_cf) {
+            for (int i = tid; i < WN_CT * C::FO_T * 2; i += 256) {
+                const int which = i & 1, fo_l = (i >> 1) % C::FO_T, cl = (i >> 1) / C::FO_T;
+                const int cout = cout0 + cl, fo = (POOL ? f0 / 2 : f0) + fo_l;
+                if (cout < a.Cout && fo < Fo)
+                    atomicAdd(&a.stats[((size_t)slot * a.Cout * Fo + cout * Fo + fo) * 2 + which], (double)st_s[i]);
+            }
+        } else {
+            for (int i = tid; i < WN_CT * 2; i += 256) {
+                const int which = i & 1, cl = i >> 1, cout = cout0 + cl;
+                float v = 0.f;
+#pragma unroll
+                for (int fo_l = 0; fo_l < C::FO_T; ++fo_l) v += st_s[(cl * C::FO_T + fo_l) * 2 + which];
+                if (cout < a.Cout) atomicAdd(&a.stats[((size_t)slot * a.Cout + cout) * 2 + which], (double)v);
             }
         }
     }
