@@ -226,6 +226,22 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
     const int Fo = POOL ? a.F / 2 : a.F;
     const int tb = t0 + 4 * lr;
     const bool vec_out = vec && tb + 4 <= a.T;
+    // DGRAD: the layer's raw forward input for every fragment this thread finishes, requested before any arithmetic
+    // (inside the loops each load would wait behind the stores of the previous fragment)
+    float4 xq[2][4][2];
+    if (DGRAD && a.bx != nullptr && vec_out) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int fl = 0; fl < 2; ++fl) {
+                    const int cout = cout0 + (wm * 2 + m) * 16 + lq * 4 + r, fo = f0 + wn * 2 + fl;
+                    xq[m][r][fl] = (cout < a.Cout && fo < Fo)
+                                       ? *reinterpret_cast<const float4*>(a.bx + ((size_t)(b * a.Cout + cout) * Fo + fo) * a.T + tb)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -271,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
                         // backward through mask -> ReLU -> BN-apply of the layer's prologue, with the BN-backward sums
                         float xv[4] = {0.f, 0.f, 0.f, 0.f};
                         if (vec_out) {
-                            const float4 x4 = *reinterpret_cast<const float4*>(a.bx + o);
+                            const float4 x4 = xq[m][r][fo_l];
                             xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
                         } else {
 #pragma unroll
