@@ -103,6 +103,11 @@ int pbsed_bn_finalize(const double* sums, double count, const float* gamma, cons
 int pbsed_bn_eval_params(const float* gamma, const float* beta, float eps, const float* running_mean,
                          const float* running_power, float* mean, float* invstd, float* scale, float* shift,
                          int C, void* stream);
+/* bn_bwd_finalize + bn_bwd_apply fused (one launch): dz [B,C,S,T] in place -> gradient wrt the BN input; sums =
+ * [PBSED_STAT_SLOTS][C][2] partial (sum dz, sum dz*xhat) from pbsed_conv_bwd_data; dgamma / dbeta accumulate. */
+int pbsed_bn_bwd(float* dz, const float* x, const double* sums, double count, const float* mean, const float* invstd,
+                 const float* scale, float* dgamma, float* dbeta, const int* seq_len, int B, int C, int S, int T,
+                 void* stream);
 int pbsed_bn_bwd_finalize(const double* sums, double count, float* dgamma, float* dbeta, float* m1, float* m2,
                           int C, void* stream);
 int pbsed_bn_bwd_apply(float* dz, const float* x, const float* mean, const float* invstd, const float* scale,

@@ -295,10 +295,8 @@ def bn_eval_params(norm):
 def bn_backward(dz, x, st, stats, count, dgamma, dbeta, seq_len):
     """In place dz -> dx; accumulates dgamma/dbeta."""
     b, c, s, t = _dims4(x)
-    call('pbsed_bn_bwd_finalize', ptr(stats), float(count), ptr(dgamma), ptr(dbeta), ptr(st.m1),
-         ptr(st.m2), c, stream())
-    call('pbsed_bn_bwd_apply', ptr(dz), ptr(x), ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.m1),
-         ptr(st.m2), ptr(seq_len), b, c, s, t, stream())
+    call('pbsed_bn_bwd', ptr(dz), ptr(x), ptr(stats), float(count), ptr(st.mean), ptr(st.invstd), ptr(st.scale),
+         ptr(dgamma), ptr(dbeta), ptr(seq_len), b, c, s, t, stream())
     return dz
 
 
