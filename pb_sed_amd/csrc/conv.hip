@@ -234,21 +234,14 @@ static int launch_cfg(const ConvFwdArgs& a, hipStream_t s) {
 
 // Tile selection.  cin/cout padding granularity used by pack_conv_weights must match
 // (conv_tile_dims below is the single source of truth for both).
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 void conv_fwd_tile_dims(int KH, int KW, int Cin, int Cout, int* ck, int* cout_t) {
-    static const int max_ct = env_int("PBSED_CONV_CT", 64);      // tuning knob: cap the Cout tile of 3x3 convs
     if (KH == 3) {
+        // measured on MI355X: a 128-wide Cout tile is slower than two 64-wide ones (accumulator registers halve the occupancy)
         *ck = (Cin <= 4) ? 4 : 8;
-        *cout_t = Cout <= 16 ? 16 : Cout <= 32 ? 32 : Cout <= 64 ? 64 : 128;
-        if (*cout_t > max_ct) *cout_t = max_ct;
+        *cout_t = Cout <= 16 ? 16 : Cout <= 32 ? 32 : 64;
     } else {
-        static const int ct1d = env_int("PBSED_CONV1D_CT", 128);   // tuning knob: Cout tile of the 1-D / 1x1 convs
         *ck = (KW == 1) ? 16 : 8;
-        *cout_t = Cout <= 16 ? 16 : (ct1d == 64 ? 64 : 128);
+        *cout_t = Cout <= 16 ? 16 : 128;
     }
 }
 
@@ -268,10 +261,7 @@ int conv_fwd_launch(const ConvFwdArgs& a, int KH, int KW, int pool, int dgrad, h
         if (ck == 4 && ct == 16) CFG(16, 4, 128, 3, 3, 4);
         if (ct == 16) CFG(16, 4, 128, 3, 3, 8);
         if (ct == 32) CFG(32, 4, 64, 3, 3, 8);
-        static const int ft_knob = env_int("PBSED_CONV_FT", 4);
-        if (ct == 64 && ft_knob == 2) CFG(64, 2, 64, 3, 3, 8);
         if (ct == 64) CFG(64, 4, 64, 3, 3, 8);
-        if (ct == 128) CFG(128, 4, 64, 3, 3, 8);
     } else if (KH == 1 && !pool) {
 #define CFG1(CT, KW_, CK_)                                                            \
     do {                                                                              \
@@ -280,12 +270,10 @@ int conv_fwd_launch(const ConvFwdArgs& a, int KH, int KW, int pool, int dgrad, h
     } while (0)
         if (KW == 1) {
             if (ct == 16) CFG1(16, 1, 16);
-            if (ct == 64) CFG1(64, 1, 16);
             CFG1(128, 1, 16);
         }
         if (KW == 3) {
             if (ct == 16) CFG1(16, 3, 8);
-            if (ct == 64) CFG1(64, 3, 8);
             CFG1(128, 3, 8);
         }
 #undef CFG1

@@ -545,37 +545,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(ConvWgradArgs a
 
 int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     if (a.unpool_idx && (a.F % 2)) { set_error("conv_wgrad: unpool needs even F"); return PBSED_E_ARG; }
-    static const int ncg_knob = getenv("PBSED_WGRAD_NCG") ? atoi(getenv("PBSED_WGRAD_NCG")) : 1;
-    const bool wide = a.Cin > 16 && ncg_knob >= 2;
-    // few output channels: the waves of a block also split the chunk's time range (KWAVES), otherwise a block is
-    // one or two waves and nothing hides the LDS / global latency
-    static const int kw_knob = getenv("PBSED_WGRAD_KWAVES") ? atoi(getenv("PBSED_WGRAD_KWAVES")) : 1;
-    static const int ft_knob = getenv("PBSED_WGRAD_FT") ? atoi(getenv("PBSED_WGRAD_FT")) : 1;
+    // Configurations measured on MI355X at B=32, T=500: one per channel regime.
     if (KH == 3 && KW == 3) {
-        if (a.Cin == 1) {
-            if (a.Cout >= 64) return launch_wgrad<3, 3, 4, 1, 1, true>(a, s);
-            if (ft_knob > 1) return launch_wgrad<3, 3, 1, 1, 1, true, 4, 8>(a, s);
-            return kw_knob > 1 ? launch_wgrad<3, 3, 1, 1, 1, true, 4>(a, s) : launch_wgrad<3, 3, 1, 1, 1, true>(a, s);
-        }
-        static const int wino_knob = getenv("PBSED_WGRAD_WINO") ? atoi(getenv("PBSED_WGRAD_WINO")) : 1;
-        if (a.Cout >= 64 && a.Cin >= 16 && wino_knob) return launch_wgrad_cfg<WinoWgradCfg>(conv_wgrad_wino_kernel, a, s);
-        if (a.Cout >= 64) return wide ? launch_wgrad<3, 3, 4, 1, 2>(a, s) : launch_wgrad<3, 3, 4, 1, 1>(a, s);
-        if (a.Cout >= 32) {
-            if (wide) return launch_wgrad<3, 3, 2, 1, 2>(a, s);
-            if (ft_knob) return launch_wgrad<3, 3, 2, 1, 1, false, 2, 4>(a, s);
-            return kw_knob ? launch_wgrad<3, 3, 2, 1, 1, false, 2>(a, s) : launch_wgrad<3, 3, 2, 1, 1>(a, s);
-        }
-        if (ft_knob) return launch_wgrad<3, 3, 1, 1, 1, false, 4, 4>(a, s);
-        return kw_knob ? launch_wgrad<3, 3, 1, 1, 1, false, 4>(a, s) : launch_wgrad<3, 3, 1, 1, 1>(a, s);
+        if (a.Cin == 1) return a.Cout >= 64 ? launch_wgrad<3, 3, 4, 1, 1, true>(a, s) : launch_wgrad<3, 3, 1, 1, 1, true>(a, s);
+        static const bool wino = getenv("PBSED_WGRAD_WINO") ? atoi(getenv("PBSED_WGRAD_WINO")) != 0 : true;
+        if (a.Cout >= 64 && a.Cin >= 16 && wino) return launch_wgrad_cfg<WinoWgradCfg>(conv_wgrad_wino_kernel, a, s);
+        if (a.Cout >= 64) return launch_wgrad<3, 3, 4, 1, 1>(a, s);
+        // few output channels: the waves of a block also split the chunk's time range (KWAVES) and chunks are 4 rows
+        // tall, otherwise a block is one or two waves and nothing hides the LDS / global latency
+        if (a.Cout >= 32) return launch_wgrad<3, 3, 2, 1, 1, false, 2, 4>(a, s);
+        return launch_wgrad<3, 3, 1, 1, 1, false, 4, 4>(a, s);
     }
-    if (KH == 1 && KW == 3) {
-        return a.Cout >= 128 ? launch_wgrad<1, 3, 4, 2, 2>(a, s) : launch_wgrad<1, 3, 1, 1, 2>(a, s);
-    }
-    if (KH == 1 && KW == 1) {
-        static const int big1 = getenv("PBSED_WGRAD_1x1_NCG") ? atoi(getenv("PBSED_WGRAD_1x1_NCG")) : 4;
-        if (a.Cout >= 128 && a.Cin >= 128 && big1 >= 8) return launch_wgrad<1, 1, 4, 2, 8>(a, s);
-        return a.Cout >= 128 ? launch_wgrad<1, 1, 4, 2, 4>(a, s) : launch_wgrad<1, 1, 1, 1, 4>(a, s);
-    }
+    if (KH == 1 && KW == 3) return a.Cout >= 128 ? launch_wgrad<1, 3, 4, 2, 2>(a, s) : launch_wgrad<1, 3, 1, 1, 2>(a, s);
+    if (KH == 1 && KW == 1) return a.Cout >= 128 ? launch_wgrad<1, 1, 4, 2, 4>(a, s) : launch_wgrad<1, 1, 1, 1, 4>(a, s);
     set_error("conv_wgrad: unsupported kernel %dx%d", KH, KW);
     return PBSED_E_UNSUPPORTED;
 }
