@@ -140,7 +140,8 @@ def main():
     ev_mode = os.environ.get('PBSED_BENCH_EVENTS', 'all' if os.environ.get('PBSED_BENCH_TABLE') else 'conv')
     # HIP events bracket only the conv / front-end launches by default (what `roofline` needs): an event pair
     # around each of the ~330 calls of a step costs ~1.3 ms/step of device idle time (PBSED_BENCH_EVENTS=all)
-    _lib.timing_filter = {'all': None, 'conv': (lambda n: n.startswith('pbsed_conv') or n == 'pbsed_logmel_fwd')}[ev_mode]
+    _lib.timing_filter = {'all': None, 'conv': (lambda n: n.startswith(('pbsed_conv', 'pbsed_gru_stack_fwd')) or
+                                                          n == 'pbsed_logmel_fwd')}[ev_mode]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         review = trainer.step(batch)
@@ -211,6 +212,14 @@ def main():
             'step_mfma': {'algorithmic_tflop_per_step': round(TRAIN_GFLOP_PER_CLIP * args.batch / 1e3, 4),
                           'achieved_tflops_per_gpu': round(TRAIN_GFLOP_PER_CLIP * args.batch / 1e3 / (ms_step * 1e-3), 2),
                           'frac_of_fp32_mfma_peak': round(TRAIN_GFLOP_PER_CLIP * args.batch / 1e3 / (ms_step * 1e-3) / PEAK_FP32_MFMA_TFLOPS, 4)},
+            # BASELINE north_star target: MFMA roofline of the conv + GRU forward pass (algorithmic forward FLOPs over the
+            # summed event time of the forward conv / GRU-scan / front-end launches)
+            'forward_conv_gru': (lambda ms: {'ms_per_step': round(ms, 3),
+                                             'algorithmic_tflop': round(FWD_GFLOP_PER_CLIP * args.batch / 1e3, 4),
+                                             'achieved_tflops': round(FWD_GFLOP_PER_CLIP * args.batch / 1e3 / (ms * 1e-3), 2),
+                                             'frac_of_fp32_mfma_peak': round(FWD_GFLOP_PER_CLIP * args.batch / 1e3 / (ms * 1e-3)
+                                                                             / PEAK_FP32_MFMA_TFLOPS, 4)})(
+                sum(v for k, v in by_family.items() if k.startswith(('pbsed_conv_fwd', 'pbsed_gru_stack_fwd', 'pbsed_logmel')))),
             'ms_per_step_by_entry_point': {k: round(v, 3) for k, v in sorted(by_family.items(), key=lambda kv: -kv[1])},
             'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 3),
             'h2d': {'ms_per_batch': round(h2d_ms, 3), 'bytes': int(sum(v.numel() * v.element_size() for v in host_batch.values())),
