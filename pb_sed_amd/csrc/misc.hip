@@ -365,13 +365,20 @@ __global__ void squash_bwd_kernel(const float* __restrict__ y, const float* __re
 
 // ------------------------------------------------------------------------------------ optimiser
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, double* out) {
+    __shared__ double part[4];
     double s = 0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const double v = g[i];
-        s += v * v;
+    const size_t n4 = n / 4;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = g4[i];
+        s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
     }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const double v = g[n4 * 4 + threadIdx.x]; s += v * v; }
     s = wave_sum64d(s);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    // one same-address f64 atomic per block (4096 of them used to serialise for ~50 us)
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
 // torch.optim.Adam (no amsgrad / weight decay) preceded by clip_grad_norm_(max_norm):
@@ -522,7 +529,7 @@ int pbsed_squash_bwd(const float* y, const float* dy, float* dx, size_t n, float
 
 int pbsed_grad_sumsq(const float* g, size_t n, double* out, void* stream) {
     hipMemsetAsync(out, 0, sizeof(double), (hipStream_t)stream);
-    hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks(n / 4 + 1, 256, 256)), dim3(256), 0, (hipStream_t)stream, g, n, out);
     return check_launch("grad_sumsq");
 }
 
