@@ -10,6 +10,7 @@
 //
 // Reference op site: torch.nn.GRU(num_layers=2) inside padertorch's GRU wrapper,
 // pb_sed/models/weak_label/crnn.py:61-67,338-340 (config training.py:243-248).
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.h"
@@ -39,6 +40,7 @@ struct GruStackArgs {
     int reverse[GRU_MAX_CHAINS];
     const int* seq_len;
     int B, T, nchains, nlayers, launch;
+    int poll_delay, poll_delay_gate;   // granule kernels: first-poll delays (PollPacer) of the non-gate / gate waves
     int ring_xcd, nby;    // granule kernels: ring_xcd = H/16 > 0 selects the 1-D XCD-aware role mapping (granule_role)
 };
 
@@ -275,17 +277,32 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // {lq*2, lq*2+1, 8+lq*2, 8+lq*2+1} whose granules lane group lq polls sit next to each other (one float4).
 __device__ __forceinline__ int save_pos16(int u) { return ((u >> 1) & 3) * 4 + (u >> 3) * 2 + (u & 1); }
 
+// First-poll pacing.  Polls that come before the data only add fabric traffic (32 KB per workgroup and attempt) and
+// slow everybody's hand-off down (two batches in flight per wave: 2x slower scans), and a missed first poll costs a
+// full round trip.  The waves that do not take part in the gate phase reach the next step's poll a gate phase early,
+// the gate waves one store-to-visible latency early; both sleep a fixed number of 64-clock units before the first
+// poll of a step.  Measured on MI355X (B=32, H=256; 0/0 = no pacing): forward 26/6 -> 1.60 ms (1.75), BPTT 20/0 ->
+// 1.80 ms (2.08); a self-tuning delay (+4 on a miss, -1 per 8 clean steps) over-shoots during the pipeline fill and
+// ends up slower (1.80 ms forward).
+struct PollPacer {
+    int delay;
+    __device__ __forceinline__ void wait() const {
+        for (int d = 0; d < delay; ++d) __builtin_amdgcn_s_sleep(1);
+    }
+};
+
 // One wave polls the granules of its K range [k0, k0 + 8*nl) for 16 batch rows with 16-byte write-through-visible
 // (sc1) buffer loads: lane (lq, lr) reads, per load n, the two granules k0 + n*8 + lq*2 + {0,1} of row lr, so one
 // instruction fetches whole 32-byte sectors (16 rows x 64 B) and nothing is fetched twice.  All loads of a step are
 // issued before any tag is looked at (one fabric round trip per step); out[n] = the two values.
 template <int NL>
-__device__ __forceinline__ void poll_batch(float2 (&out)[NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, int nl, unsigned epoch,
-                                           bool valid, unsigned* err_flag) {
+__device__ __forceinline__ int poll_batch(float2 (&out)[NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, int nl, unsigned epoch,
+                                          bool valid, unsigned* err_flag) {
     u32x4_t q[NL];
 #pragma unroll
     for (int n = 0; n < NL; ++n) q[n] = u32x4_t{0u, 0u, 0u, 0u};
-    for (int spin = 0;; ++spin) {
+    int spin = 0;
+    for (;; ++spin) {
         bool ok = true;
         if (valid) {
 #pragma unroll
@@ -304,6 +321,7 @@ __device__ __forceinline__ void poll_batch(float2 (&out)[NL], __amdgpu_buffer_rs
     }
 #pragma unroll
     for (int n = 0; n < NL; ++n) out[n] = make_float2(__uint_as_float(q[n].x), __uint_as_float(q[n].z));
+    return spin;
 }
 
 // Block roles of the granule scans.  Every (chain, layer) has a RING of H/16 x ceil(B/16) blocks that carries the
@@ -410,6 +428,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     const unsigned cl_src = chain * a.nlayers + (is_proj ? layer - 1 : layer);
     const unsigned voff0 = (unsigned)((((size_t)cl_src * a.T * B + b0 + lr) * H + k0 + lq * 2) * 8);
     float h_reg = 0.f;
+    const PollPacer pacer{threadIdx.x >= 256 ? a.poll_delay : a.poll_delay_gate};
     if (tid == 0) s_err = 0;
     __syncthreads();
     float gn_r = 0.f, gn_z = 0.f, gn_n = 0.f;
@@ -433,8 +452,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
         f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         float2 x[NL];
         const bool contract = is_proj || has_prev;
-        if (contract)
+        if (contract) {
+            pacer.wait();
             poll_batch<NL>(x, rsrc, voff0 + (unsigned)(is_proj ? t : tp) * (unsigned)(B * H * 8), NL, epoch, rowv, err_flag);
+        }
         // requests issued behind the poll (loads return in order, anything older would hold the poll back):
         // next step's input projection (first layer) / this step's projected input granules (other rings)
         unsigned long long qg[3] = {0, 0, 0};
@@ -548,6 +569,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     const unsigned voff0 = (unsigned)((((size_t)cl_src * a.T * B + b0 + lr) * H + k0 + lq * 2) * 8);
     float dhz_prev = 0.f;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const PollPacer pacer{threadIdx.x >= 256 ? a.poll_delay : a.poll_delay_gate};
     if (tid == 0) s_err = 0;
     __syncthreads();
 
@@ -598,8 +620,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
         c_r = x_r; c_z = x_z; c_n = x_n; c_nr = x_nr; z = x_zz; dyv = x_dy;
         float2 dh2[NL];
         const bool contract = is_proj || has_next;
-        if (contract)
+        if (contract) {
+            pacer.wait();
             poll_batch<NL>(dh2, rsrc, voff0 + (unsigned)(is_proj ? t : tn) * (unsigned)(B * H * 8), NL, epoch, rowv, err_flag);
+        }
         unsigned long long qd[1] = {0};               // behind the poll: loads return in order
         if (!is_proj && layer < top && bv)
             qd[0] = __hip_atomic_load(g_dy + tb * H + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -708,6 +732,18 @@ static dim3 granule_xcd_grid(GruStackArgs& a, int H) {
     return dim3(8 * slots, 1, 1);
 }
 
+// PBSED_GRU_POLL_DELAYS="fwd,fwd_gate,bwd,bwd_gate" overrides the measured defaults (PollPacer).
+static void granule_poll_delays(bool bwd, GruStackArgs& a) {
+    static int d[4] = {26, 6, 20, 0};
+    static const bool parsed = [] {
+        if (const char* e = getenv("PBSED_GRU_POLL_DELAYS")) sscanf(e, "%d,%d,%d,%d", &d[0], &d[1], &d[2], &d[3]);
+        return true;
+    }();
+    (void)parsed;
+    a.poll_delay = d[bwd ? 2 : 0];
+    a.poll_delay_gate = d[bwd ? 3 : 1];
+}
+
 static bool granule_ring_xcd() {
     static const bool v = [] { const char* e = getenv("PBSED_GRU_RING_XCD"); return e ? atoi(e) != 0 : false; }();
     return v;
@@ -738,6 +774,7 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
     }
     a.seq_len = seq_len; a.B = B; a.T = T; a.nchains = nchains; a.nlayers = nlayers;
     const int ngroups = nchains * (2 * nlayers - 1);     // rings + projection groups (see GranuleRole)
+    granule_poll_delays(false, a);
     dim3 grid(H / 16, (B + 15) / 16, ngroups);
     if (granule_ring_xcd()) grid = granule_xcd_grid(a, H);
     unsigned long long* gran_gi = granules + (size_t)nchains * nlayers * T * B * H;
@@ -781,6 +818,7 @@ int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_
     }
     a.seq_len = seq_len; a.B = B; a.T = T; a.nchains = nchains; a.nlayers = nlayers;
     const int ngroups = nchains * (2 * nlayers - 1);
+    granule_poll_delays(true, a);
     dim3 grid(H / 16, (B + 15) / 16, ngroups);
     if (granule_ring_xcd()) grid = granule_xcd_grid(a, H);
     unsigned long long* gran_dy = granules + (size_t)nchains * nlayers * T * B * H;
