@@ -130,25 +130,28 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
                         const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
                         float* const* hs, float* const* save, const int* reverse /*host*/, const int* seq_len,
                         int B, int H, int T, void* stream);
-/* Persistent forward scan exchanging h_t (and the projected inputs of layers > 0) as 8-byte {epoch, value}
- * granules (one launch for the whole scan; needs nchains*(2*nlayers-1)*(H/16)*ceil(B/16) <= #CUs co-resident
- * workgroups).  granules: device uint64 workspace of nchains*T*B*H*(nlayers + 3*(nlayers-1)) words, zero before
- * first use, reusable with a fresh non-zero epoch.  `save` rows are [5][H] (factors of dh_t, see gru_stack.hip). */
+/* Persistent forward scan (one launch for the whole scan; needs nchains*(2*nlayers-1)*(H/16)*ceil(B/16) <= #CUs
+ * co-resident workgroups) exchanging h_t (and the projected inputs of layers > 0) between workgroups as 4-byte words
+ * = the fp32 value with its mantissa LSB replaced by the call's parity bit (the exchanged quantity is defined as the
+ * truncated value).  granules: device uint32 workspace of nchains*T*B*H*(nlayers + 3*(nlayers-1)) words, ZERO before
+ * its first use; epoch: odd on the first use of a workspace, parity flipped on every further call with it.
+ * err_flag: device uint32, non-zero afterwards if a hand-off timed out (re-zero the workspace then).
+ * `save` rows are [5][H] (factors of dh_t, see gru_stack.hip). */
 int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
                                 const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
                                 float* const* hs, float* const* save, const int* reverse /*host*/, const int* seq_len,
-                                int B, int H, int T, unsigned long long* granules, unsigned int epoch,
+                                int B, int H, int T, unsigned int* granules, unsigned int epoch,
                                 unsigned int* err_flag, void* stream);
 int pbsed_gru_stack_bwd(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
                         const float* const* hs, const float* const* save, const float* const* dy_top,
                         float* const* dgi, float* const* dgh, float* const* dhz, const int* reverse /*host*/,
                         const int* seq_len, int B, int H, int T, void* stream);
-/* Persistent BPTT exchanging the step's gate gradients as granules.  granules: device uint64
- * [nchains*nlayers][T][B][4][H] (dr, dz, dn, dn*r), zero before first use. */
+/* Persistent BPTT exchanging dh_t / dy_t the same way (gate gradients are rebuilt by the consumer from the factors
+ * the granule forward scan saved).  granules: device uint32 workspace of nchains*T*B*H*(2*nlayers-1) words. */
 int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
                                 const float* const* hs, const float* const* save, const float* const* dy_top,
                                 float* const* dgi, float* const* dgh, const int* reverse /*host*/, const int* seq_len,
-                                int B, int H, int T, unsigned long long* granules, unsigned int epoch,
+                                int B, int H, int T, unsigned int* granules, unsigned int epoch,
                                 unsigned int* err_flag, void* stream);
 int pbsed_bct_to_tbc(const float* src, float* dst, int B, int C, int T, void* stream);
 int pbsed_tbc_to_bct(const float* src, float* dst, int B, int C, int T, int shift, void* stream);

@@ -262,28 +262,30 @@ static void launch_stack(bool bwd, GruStackArgs& a, dim3 grid, hipStream_t s) {
 
 
 typedef unsigned int __attribute__((address_space(1))) gu32;
-typedef unsigned long long __attribute__((address_space(1))) gu64;
 
 // ============================================================================================
-// Persistent scans ("granules"): the exchanged h_t values ARE the flags.  Every h value is published as one
-// aligned 8-byte {epoch tag, value} word with a single write-through (sc1) store into a [T][B][H] array that is
-// never overwritten within a call; consumers poll the words they need with L1-bypassing 8-byte loads until
-// all tags equal the call's epoch (cdna_hip_programming.md Guideline 16, form R2: no fence, no drain, no
-// counter).  W fragments stay in registers for all T steps, the previous state of a thread's own unit too.
+// Persistent scans ("granules"): the exchanged values ARE the flags.  Every h value is published as one 4-byte word
+// - the fp32 value with its mantissa LSB replaced by the call's parity bit - with a single write-through (sc1) store
+// into a [T][B][H] array that is written exactly once per call; consumers poll the words they need with
+// L1-bypassing 16-byte loads until all parity bits equal the call's (cdna_hip_programming.md Guideline 16, form R2
+// with a 1-bit tag: no fence, no drain, no counter).  The workspace is zero before its first use and every call
+// flips the parity, so the previous call's words never match.  The exchanged quantity is DEFINED as the truncated
+// value (LSB cleared, <= 1 ulp): producer, consumers and the saved outputs all use exactly that number.  Half the
+// bytes of {tag, value} granules: the polls (16 KB per workgroup and step instead of 32) are what loads the fabric.
+// W fragments stay in registers for all T steps, the previous state of a thread's own unit too.
 // ============================================================================================
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
-// Position of hidden unit u (0..15 within its block of 16) in the granule scans' save arrays: the four units
-// {lq*2, lq*2+1, 8+lq*2, 8+lq*2+1} whose granules lane group lq polls sit next to each other (one float4).
-__device__ __forceinline__ int save_pos16(int u) { return ((u >> 1) & 3) * 4 + (u >> 3) * 2 + (u & 1); }
+__device__ __forceinline__ float tag_clear(float v) { return __uint_as_float(__float_as_uint(v) & ~1u); }
+__device__ __forceinline__ void publish(gu32* p, float v_cleared, unsigned parity) {
+    __hip_atomic_store(p, __float_as_uint(v_cleared) | parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
-// First-poll pacing.  Polls that come before the data only add fabric traffic (32 KB per workgroup and attempt) and
-// slow everybody's hand-off down (two batches in flight per wave: 2x slower scans), and a missed first poll costs a
-// full round trip.  The waves that do not take part in the gate phase reach the next step's poll a gate phase early,
-// the gate waves one store-to-visible latency early; both sleep a fixed number of 64-clock units before the first
-// poll of a step.  Measured on MI355X (B=32, H=256; 0/0 = no pacing): forward 26/6 -> 1.60 ms (1.75), BPTT 20/0 ->
-// 1.80 ms (2.08); a self-tuning delay (+4 on a miss, -1 per 8 clean steps) over-shoots during the pipeline fill and
-// ends up slower (1.80 ms forward).
+// First-poll pacing.  Polls that come before the data only add fabric traffic and slow everybody's hand-off down (two
+// batches in flight per wave: 2x slower scans), and a missed first poll costs a full round trip.  The waves that do
+// not take part in the gate phase reach the next step's poll a gate phase early, the gate waves one store-to-visible
+// latency early; both sleep a fixed number of 64-clock units before the first poll of a step (measured defaults in
+// granule_poll_delays; a self-tuning delay over-shoots during the pipeline fill and ends up slower).
 struct PollPacer {
     int delay;
     __device__ __forceinline__ void wait() const {
@@ -291,12 +293,12 @@ struct PollPacer {
     }
 };
 
-// One wave polls the granules of its K range [k0, k0 + 8*nl) for 16 batch rows with 16-byte write-through-visible
-// (sc1) buffer loads: lane (lq, lr) reads, per load n, the two granules k0 + n*8 + lq*2 + {0,1} of row lr, so one
-// instruction fetches whole 32-byte sectors (16 rows x 64 B) and nothing is fetched twice.  All loads of a step are
-// issued before any tag is looked at (one fabric round trip per step); out[n] = the two values.
+// One wave polls the words of its K range [k0, k0 + 16*NL) for 16 batch rows with 16-byte write-through-visible
+// (sc1) buffer loads: lane (lq, lr) reads, per load n, the four words k0 + n*16 + lq*4 + {0..3} of row lr, so one
+// instruction fetches whole 64-byte row segments and nothing is fetched twice.  All loads of a step are issued
+// before any tag is looked at (one fabric round trip per step); out[n] = the four (tag-cleared) values.
 template <int NL>
-__device__ __forceinline__ int poll_batch(float2 (&out)[NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, int nl, unsigned epoch,
+__device__ __forceinline__ int poll_batch(float4 (&out)[NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned parity,
                                           bool valid, unsigned* err_flag) {
     u32x4_t q[NL];
 #pragma unroll
@@ -306,11 +308,14 @@ __device__ __forceinline__ int poll_batch(float2 (&out)[NL], __amdgpu_buffer_rsr
         bool ok = true;
         if (valid) {
 #pragma unroll
-            for (int n = 0; n < NL; ++n)
-                if (n < nl) q[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + n * 64, 0, /*aux = sc1*/ 16);
+            for (int n = 0; n < NL; ++n) q[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + n * 64, 0, /*aux = sc1*/ 16);
+            unsigned all1 = 1u, any1 = 0u;
 #pragma unroll
-            for (int n = 0; n < NL; ++n)
-                if (n < nl) ok = ok && q[n].y == epoch && q[n].w == epoch;
+            for (int n = 0; n < NL; ++n) {
+                all1 &= q[n].x & q[n].y & q[n].z & q[n].w;
+                any1 |= q[n].x | q[n].y | q[n].z | q[n].w;
+            }
+            ok = parity ? (all1 & 1u) != 0u : (any1 & 1u) == 0u;
         }
         if (__all(ok)) break;
         if (spin > (1 << 18)) {                     // bounded: raise the error flag and go on with garbage
@@ -320,7 +325,9 @@ __device__ __forceinline__ int poll_batch(float2 (&out)[NL], __amdgpu_buffer_rsr
         if (spin > 8) __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll
-    for (int n = 0; n < NL; ++n) out[n] = make_float2(__uint_as_float(q[n].x), __uint_as_float(q[n].z));
+    for (int n = 0; n < NL; ++n)
+        out[n] = make_float4(__uint_as_float(q[n].x & ~1u), __uint_as_float(q[n].y & ~1u), __uint_as_float(q[n].z & ~1u),
+                             __uint_as_float(q[n].w & ~1u));
     return spin;
 }
 
@@ -367,15 +374,15 @@ __device__ __forceinline__ GranuleRole granule_role(const GruStackArgs& a) {
     return r;
 }
 
-// One thread waits for NQ granules it alone consumes (stride `stride` words); they were requested earlier (q holds
-// the first answers) and are normally there already.
+// One thread waits for NQ words it alone consumes (stride `stride` words); they were requested earlier (q holds the
+// first answers) and are normally there already.
 template <int NQ>
-__device__ __forceinline__ void wait_own_granules(unsigned long long (&q)[NQ], const gu64* p, size_t stride, unsigned epoch,
+__device__ __forceinline__ void wait_own_granules(unsigned (&q)[NQ], const gu32* p, size_t stride, unsigned parity,
                                                   unsigned* err_flag) {
     for (int spin = 0;; ++spin) {
         bool ok = true;
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) ok = ok && (unsigned)(q[i] >> 32) == epoch;
+        for (int i = 0; i < NQ; ++i) ok = ok && (q[i] & 1u) == parity;
         if (ok) break;
         if (spin > (1 << 18)) {
             __hip_atomic_store((gu32*)err_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -388,10 +395,10 @@ __device__ __forceinline__ void wait_own_granules(unsigned long long (&q)[NQ], c
 }
 
 template <int KB, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gru_granule_fwd_kernel(GruStackArgs a, unsigned long long* gran_h_,
-                                                                 unsigned long long* gran_gi_, unsigned epoch,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gru_granule_fwd_kernel(GruStackArgs a, unsigned* gran_h_,
+                                                                 unsigned* gran_gi_, unsigned epoch,
                                                                  unsigned* err_flag) {
-    constexpr int H = KB * NW * 16, NL = 2 * KB;       // NL: 16-byte loads per lane (8 k each) of this wave's H/NW range
+    constexpr int H = KB * NW * 16, NL = KB;           // NL: 16-byte loads per lane (16 k each) of this wave's H/NW range
     __shared__ float red[2][NW][3][64][4];
     __shared__ int s_err;
     const GranuleRole role = granule_role(a);
@@ -404,29 +411,30 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     const bool rev = a.reverse[chain] != 0;
     const size_t per_cl = (size_t)a.T * B * H;
     const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(gran_h_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 8), 0x00020000);
-    gu64* g_own = (gu64*)gran_h_ + (size_t)(chain * a.nlayers + layer) * per_cl;                       // ring: h_t
-    gu64* g_gi = (gu64*)gran_gi_ + (size_t)(chain * (a.nlayers - 1) + (layer > 0 ? layer - 1 : 0)) * per_cl * 3;  // [T][B][3][H]
+        __builtin_amdgcn_make_buffer_rsrc(gran_h_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 4), 0x00020000);
+    const unsigned parity = epoch & 1u;
+    gu32* g_own = (gu32*)gran_h_ + (size_t)(chain * a.nlayers + layer) * per_cl;                       // ring: h_t
+    gu32* g_gi = (gu32*)gran_gi_ + (size_t)(chain * (a.nlayers - 1) + (layer > 0 ? layer - 1 : 0)) * per_cl * 3;  // [T][B][3][H]
     const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
     const bool bv = tid < 256 && b < B;
     const bool rowv = (b0 + lr) < B;
     const float* bias = is_proj ? L.b_ih : L.b_hh;
     const float bs_r = bias[j0 + u], bs_z = bias[H + j0 + u], bs_n = bias[2 * H + j0 + u];
     const int sl = bv ? a.seq_len[b] : 0;
-    // every wave contracts its H/NW slice of K; within it a lane owns k = k0 + n*8 + lq*2 + {0,1} (the granule
-    // load pattern) and the weights follow the same permutation
-    const int k0 = wave * NL * 8;
-    float2 wv[NL][3];
+    // every wave contracts its H/NW slice of K; within it a lane owns k = k0 + n*16 + lq*4 + {0..3} (the poll's
+    // load pattern) and the weights follow the same order
+    const int k0 = wave * NL * 16;
+    float4 wv[NL][3];
     {
-        const float* W = (is_proj ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * H + k0 + lq * 2;
+        const float* W = (is_proj ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * H + k0 + lq * 4;
 #pragma unroll
         for (int n = 0; n < NL; ++n)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) wv[n][g] = *reinterpret_cast<const float2*>(W + (size_t)g * H * H + n * 8);
+            for (int g = 0; g < 3; ++g) wv[n][g] = *reinterpret_cast<const float4*>(W + (size_t)g * H * H + n * 16);
     }
     // a projection reads h_t of the layer below, a ring its own h_{t-1}
     const unsigned cl_src = chain * a.nlayers + (is_proj ? layer - 1 : layer);
-    const unsigned voff0 = (unsigned)((((size_t)cl_src * a.T * B + b0 + lr) * H + k0 + lq * 2) * 8);
+    const unsigned voff0 = (unsigned)((((size_t)cl_src * a.T * B + b0 + lr) * H + k0 + lq * 4) * 4);
     float h_reg = 0.f;
     const PollPacer pacer{threadIdx.x >= 256 ? a.poll_delay : a.poll_delay_gate};
     if (tid == 0) s_err = 0;
@@ -450,16 +458,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
         // another block's time-out is looked for every 32 steps only: the agent-scope load stalls its wave
         if (tid == 0 && (step & 31) == 31 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
         f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        float2 x[NL];
+        float4 x[NL];
         const bool contract = is_proj || has_prev;
         if (contract) {
             pacer.wait();
-            poll_batch<NL>(x, rsrc, voff0 + (unsigned)(is_proj ? t : tp) * (unsigned)(B * H * 8), NL, epoch, rowv, err_flag);
+            poll_batch<NL>(x, rsrc, voff0 + (unsigned)(is_proj ? t : tp) * (unsigned)(B * H * 4), parity, rowv, err_flag);
         }
         // requests issued behind the poll (loads return in order, anything older would hold the poll back):
         // next step's input projection (first layer) / this step's projected input granules (other rings)
-        unsigned long long qg[3] = {0, 0, 0};
-        const gu64* gp = g_gi + tb * 3 * H + j;
+        unsigned qg[3] = {0, 0, 0};
+        const gu32* gp = g_gi + tb * 3 * H + j;
         if (!is_proj && layer > 0 && bv) {
 #pragma unroll
             for (int g = 0; g < 3; ++g) qg[g] = __hip_atomic_load(gp + (size_t)g * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -472,6 +480,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
                 for (int g = 0; g < 3; ++g) {
                     acc[g] = mfma16(wv[n][g].x, x[n].x, acc[g]);
                     acc[g] = mfma16(wv[n][g].y, x[n].y, acc[g]);
+                    acc[g] = mfma16(wv[n][g].z, x[n].z, acc[g]);
+                    acc[g] = mfma16(wv[n][g].w, x[n].w, acc[g]);
                 }
         }
 #pragma unroll
@@ -491,30 +501,28 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
                 s[1] += red[par][w][1][src][reg];
                 s[2] += red[par][w][2][src][reg];
             }
-            const unsigned long long tag = (unsigned long long)epoch << 32;
             if (is_proj) {
-                gu64* dst = g_gi + tb * 3 * H + j;
+                gu32* dst = g_gi + tb * 3 * H + j;
 #pragma unroll
-                for (int g = 0; g < 3; ++g)
-                    __hip_atomic_store(dst + (size_t)g * H, tag | __float_as_uint(s[g]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int g = 0; g < 3; ++g) publish(dst + (size_t)g * H, tag_clear(s[g]), parity);
             } else {
                 if (layer > 0) {
-                    wait_own_granules<3>(qg, gp, (size_t)H, epoch, err_flag);
-                    gi_r = __uint_as_float((unsigned)qg[0]); gi_z = __uint_as_float((unsigned)qg[1]);
-                    gi_n = __uint_as_float((unsigned)qg[2]);
+                    wait_own_granules<3>(qg, gp, (size_t)H, parity, err_flag);
+                    gi_r = __uint_as_float(qg[0] & ~1u); gi_z = __uint_as_float(qg[1] & ~1u);
+                    gi_n = __uint_as_float(qg[2] & ~1u);
                 }
                 const float ghn = s[2];
                 const float r = 1.f / (1.f + expf(-(gi_r + s[0])));
                 const float z = 1.f / (1.f + expf(-(gi_z + s[1])));
                 const float n = tanhf(gi_n + r * ghn);
                 const float hp = h_reg;
-                const float h = (t < sl) ? (1.f - z) * n + z * hp : 0.f;
+                const float h = tag_clear((t < sl) ? (1.f - z) * n + z * hp : 0.f);    // the state IS the truncated value
                 h_reg = h;
-                __hip_atomic_store(g_own + tb * H + j, tag | __float_as_uint(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                publish(g_own + tb * H + j, h, parity);
                 L.hs[tb * H + j] = h;
                 if (L.save) {
                     // what BPTT multiplies dh_t with: d(r,z,n pre-activations)/dh, d(gh_n)/dh and z (granule save format)
-                    float* sv = L.save + tb * 5 * H + j0 + save_pos16(u);
+                    float* sv = L.save + tb * 5 * H + j;
                     const float cn = (1.f - z) * (1.f - n * n);
                     sv[0] = cn * ghn * r * (1.f - r); sv[H] = (hp - n) * z * (1.f - z); sv[2 * H] = cn;
                     sv[3 * H] = cn * r; sv[4 * H] = z;
@@ -529,10 +537,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 // being plain loads issued one step ahead.  Projection blocks turn dh_t of the layer above into dy_t of the layer
 // below (granules [T][B][H] as well); dh*z of a thread's own unit stays in a register.  Scan order = top layer first.
 template <int KB, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gru_granule_bwd_kernel(GruStackArgs a, unsigned long long* gran_dh_,
-                                                                 unsigned long long* gran_dy_, unsigned epoch,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gru_granule_bwd_kernel(GruStackArgs a, unsigned* gran_dh_,
+                                                                 unsigned* gran_dy_, unsigned epoch,
                                                                  unsigned* err_flag) {
-    constexpr int H = KB * NW * 16, G = 3 * H, NL = 2 * KB;
+    constexpr int H = KB * NW * 16, G = 3 * H, NL = KB;     // NL: 16-byte loads per lane (16 units each)
     __shared__ float red[2][NW][64][4];
     __shared__ int s_err;
     const GranuleRole role = granule_role(a);
@@ -546,34 +554,35 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     const bool rev = a.reverse[chain] != 0;
     const size_t per_cl = (size_t)a.T * B * H;
     const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(gran_dh_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 8), 0x00020000);
-    gu64* g_own = (gu64*)gran_dh_ + (size_t)(chain * a.nlayers + layer) * per_cl;
-    gu64* g_dy = (gu64*)gran_dy_ + (size_t)(chain * (a.nlayers - 1) + (layer < top ? layer : 0)) * per_cl;
+        __builtin_amdgcn_make_buffer_rsrc(gran_dh_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 4), 0x00020000);
+    const unsigned parity = epoch & 1u;
+    gu32* g_own = (gu32*)gran_dh_ + (size_t)(chain * a.nlayers + layer) * per_cl;
+    gu32* g_dy = (gu32*)gran_dy_ + (size_t)(chain * (a.nlayers - 1) + (layer < top ? layer : 0)) * per_cl;
     const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
     const bool bv = tid < 256 && b < B;
     const bool rowv = (b0 + lr) < B;
     const int sl = bv ? a.seq_len[b] : 0;
     // ring: contracts dgh of its own step done before (t_next) with W_hh; projection: dgi_t of the layer above with
-    // that layer's W_ih.  Every wave takes H/NW hidden units jj = k0 + n*8 + lq*2 + {0,1} (granule load pattern).
-    const int k0 = wave * NL * 8;
+    // that layer's W_ih.  Every wave takes H/NW hidden units jj = k0 + n*16 + lq*4 + {0..3} (the poll's load pattern).
+    const int k0 = wave * NL * 16;
     const GruStackLayer& X = is_proj ? a.lc[chain][layer + 1] : L;
-    float2 wv[NL][3];
+    float4 wv[NL][3];
     {
-        const float* W = (is_proj ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * G + k0 + lq * 2;
+        const float* W = (is_proj ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * G + k0 + lq * 4;
 #pragma unroll
         for (int n = 0; n < NL; ++n)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) wv[n][g] = *reinterpret_cast<const float2*>(W + g * H + n * 8);
+            for (int g = 0; g < 3; ++g) wv[n][g] = *reinterpret_cast<const float4*>(W + g * H + n * 16);
     }
     const unsigned cl_src = chain * a.nlayers + (is_proj ? layer + 1 : layer);
-    const unsigned voff0 = (unsigned)((((size_t)cl_src * a.T * B + b0 + lr) * H + k0 + lq * 2) * 8);
+    const unsigned voff0 = (unsigned)((((size_t)cl_src * a.T * B + b0 + lr) * H + k0 + lq * 4) * 4);
     float dhz_prev = 0.f;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const PollPacer pacer{threadIdx.x >= 256 ? a.poll_delay : a.poll_delay_gate};
     if (tid == 0) s_err = 0;
     __syncthreads();
 
-    float pr[NL][2], pz[NL][2], pn[NL][2];
+    float pr[NL][4], pz[NL][4], pn[NL][4];
     float c_r = 0.f, c_z = 0.f, c_n = 0.f, c_nr = 0.f, z = 0.f, dyv = 0.f;
     float x_r = 0.f, x_z = 0.f, x_n = 0.f, x_nr = 0.f, x_zz = 0.f, x_dy = 0.f;    // the same for the next step
     auto load_operands = [&](int bs) __attribute__((always_inline)) {
@@ -582,17 +591,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
         const int tx = is_proj ? t : (rev ? t - 1 : t + 1);
         const bool act = (is_proj || bs > 0) && rowv;
 #pragma unroll
-        for (int m = 0; m < NL / 2; ++m) {
+        for (int n = 0; n < NL; ++n) {
             float4 vr = zero4, vz = zero4, vn = zero4;
             if (act) {
-                const float* sv = X.save + ((size_t)tx * B + b0 + lr) * 5 * H + k0 + m * 16 + lq * 4;
+                const float* sv = X.save + ((size_t)tx * B + b0 + lr) * 5 * H + k0 + n * 16 + lq * 4;
                 vr = *reinterpret_cast<const float4*>(sv);
                 vz = *reinterpret_cast<const float4*>(sv + H);
                 vn = *reinterpret_cast<const float4*>(sv + (is_proj ? 2 : 3) * H);
             }
-            pr[2 * m][0] = vr.x; pr[2 * m][1] = vr.y; pr[2 * m + 1][0] = vr.z; pr[2 * m + 1][1] = vr.w;
-            pz[2 * m][0] = vz.x; pz[2 * m][1] = vz.y; pz[2 * m + 1][0] = vz.z; pz[2 * m + 1][1] = vz.w;
-            pn[2 * m][0] = vn.x; pn[2 * m][1] = vn.y; pn[2 * m + 1][0] = vn.z; pn[2 * m + 1][1] = vn.w;
+            pr[n][0] = vr.x; pr[n][1] = vr.y; pr[n][2] = vr.z; pr[n][3] = vr.w;
+            pz[n][0] = vz.x; pz[n][1] = vz.y; pz[n][2] = vz.z; pz[n][3] = vz.w;
+            pn[n][0] = vn.x; pn[n][1] = vn.y; pn[n][2] = vn.z; pn[n][3] = vn.w;
         }
     };
     auto load_own = [&](int bs) __attribute__((always_inline)) {
@@ -600,7 +609,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
         const int t = rev ? a.T - 1 - s : s;
         if (bv && !is_proj) {
             const size_t tb = (size_t)t * B + b;
-            const float* sv = L.save + tb * 5 * H + j0 + save_pos16(u);
+            const float* sv = L.save + tb * 5 * H + j;
             x_r = sv[0]; x_z = sv[H]; x_n = sv[2 * H]; x_nr = sv[3 * H]; x_zz = sv[4 * H];
             if (layer == top) x_dy = L.dy[tb * H + j];
         }
@@ -618,25 +627,31 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
         if (tid == 0 && (bstep & 31) == 31 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
         f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         c_r = x_r; c_z = x_z; c_n = x_n; c_nr = x_nr; z = x_zz; dyv = x_dy;
-        float2 dh2[NL];
+        float4 dh4[NL];
         const bool contract = is_proj || has_next;
         if (contract) {
             pacer.wait();
-            poll_batch<NL>(dh2, rsrc, voff0 + (unsigned)(is_proj ? t : tn) * (unsigned)(B * H * 8), NL, epoch, rowv, err_flag);
+            poll_batch<NL>(dh4, rsrc, voff0 + (unsigned)(is_proj ? t : tn) * (unsigned)(B * H * 4), parity, rowv, err_flag);
         }
-        unsigned long long qd[1] = {0};               // behind the poll: loads return in order
+        unsigned qd[1] = {0};                         // behind the poll: loads return in order
         if (!is_proj && layer < top && bv)
             qd[0] = __hip_atomic_load(g_dy + tb * H + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (bstep + 1 < a.T) load_own(bstep + 1);
         if (contract) {
 #pragma unroll
             for (int n = 0; n < NL; ++n) {
-                acc[0] = mfma16(wv[n][0].x, dh2[n].x * pr[n][0], acc[0]);
-                acc[1] = mfma16(wv[n][1].x, dh2[n].x * pz[n][0], acc[1]);
-                acc[2] = mfma16(wv[n][2].x, dh2[n].x * pn[n][0], acc[2]);
-                acc[0] = mfma16(wv[n][0].y, dh2[n].y * pr[n][1], acc[0]);
-                acc[1] = mfma16(wv[n][1].y, dh2[n].y * pz[n][1], acc[1]);
-                acc[2] = mfma16(wv[n][2].y, dh2[n].y * pn[n][1], acc[2]);
+                acc[0] = mfma16(wv[n][0].x, dh4[n].x * pr[n][0], acc[0]);
+                acc[1] = mfma16(wv[n][1].x, dh4[n].x * pz[n][0], acc[1]);
+                acc[2] = mfma16(wv[n][2].x, dh4[n].x * pn[n][0], acc[2]);
+                acc[0] = mfma16(wv[n][0].y, dh4[n].y * pr[n][1], acc[0]);
+                acc[1] = mfma16(wv[n][1].y, dh4[n].y * pz[n][1], acc[1]);
+                acc[2] = mfma16(wv[n][2].y, dh4[n].y * pn[n][1], acc[2]);
+                acc[0] = mfma16(wv[n][0].z, dh4[n].z * pr[n][2], acc[0]);
+                acc[1] = mfma16(wv[n][1].z, dh4[n].z * pz[n][2], acc[1]);
+                acc[2] = mfma16(wv[n][2].z, dh4[n].z * pn[n][2], acc[2]);
+                acc[0] = mfma16(wv[n][0].w, dh4[n].w * pr[n][3], acc[0]);
+                acc[1] = mfma16(wv[n][1].w, dh4[n].w * pz[n][3], acc[1]);
+                acc[2] = mfma16(wv[n][2].w, dh4[n].w * pn[n][3], acc[2]);
             }
         }
         if (bstep + 1 < a.T) load_operands(bstep + 1);
@@ -649,22 +664,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) sum += red[par][w][src][reg];
-            const unsigned long long tag = (unsigned long long)epoch << 32;
             if (is_proj) {
-                __hip_atomic_store(g_dy + tb * H + j, tag | __float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                publish(g_dy + tb * H + j, tag_clear(sum), parity);
             } else {
                 if (layer < top) {
-                    wait_own_granules<1>(qd, g_dy + tb * H + j, 0, epoch, err_flag);
-                    dyv = __uint_as_float((unsigned)qd[0]);
+                    wait_own_granules<1>(qd, g_dy + tb * H + j, 0, parity, err_flag);
+                    dyv = __uint_as_float(qd[0] & ~1u);
                 }
                 float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, dhzv = 0.f, dh = 0.f;
                 if (t < sl) {
-                    dh = dyv + (has_next ? sum + dhz_prev : 0.f);
+                    dh = tag_clear(dyv + (has_next ? sum + dhz_prev : 0.f));       // dh IS the truncated value
                     dn = dh * c_n; dz = dh * c_z; dr = dh * c_r; dnr = dh * c_nr;
                     dhzv = dh * z;
                 }
                 dhz_prev = dhzv;
-                __hip_atomic_store(g_own + tb * H + j, tag | __float_as_uint(dh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                publish(g_own + tb * H + j, dh, parity);
                 float* dgi = L.dgi + tb * G;
                 float* dgh = L.dgh + tb * G;
                 dgi[j] = dr; dgi[H + j] = dz; dgi[2 * H + j] = dn;
@@ -749,18 +763,19 @@ static bool granule_ring_xcd() {
     return v;
 }
 
-// Granule-exchange persistent forward scan (see gru_granule_fwd_kernel).  granules: device uint64 workspace of
+// Granule-exchange persistent forward scan (see gru_granule_fwd_kernel).  granules: device uint32 workspace of
 // nchains*T*B*H*(nlayers + 3*(nlayers-1)) words (h_t of every layer, then the projected inputs of layers > 0) that
-// must be ZERO before its first use and may be reused across calls with a different non-zero `epoch` each time;
-// err_flag: device uint32 (0 on entry; non-zero after a hand-off timed out).
+// must be ZERO before its first use; `epoch` must be odd on the first use of a workspace and change parity with
+// every call that uses it (the words of the previous call then never match); same T, B, H for the life of a
+// workspace.  err_flag: device uint32 (0 on entry; non-zero after a hand-off timed out: re-zero the workspace).
 int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
                                 const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
                                 float* const* hs, float* const* save, const int* reverse, const int* seq_len, int B,
-                                int H, int T, unsigned long long* granules, unsigned int epoch, unsigned int* err_flag,
+                                int H, int T, unsigned int* granules, unsigned int epoch, unsigned int* err_flag,
                                 void* stream) {
     if (int e = stack_check(nchains, nlayers, B, H, T)) return e;
     if (epoch == 0 || !granules || !err_flag) { set_error("gru_stack_fwd_granule: need workspace and epoch != 0"); return PBSED_E_ARG; }
-    if ((size_t)nchains * nlayers * T * B * H * 8 >= (1ull << 32)) { set_error("gru_stack_fwd_granule: workspace over 4 GiB"); return PBSED_E_ARG; }
+    if ((size_t)nchains * nlayers * T * B * H * 4 >= (1ull << 32)) { set_error("gru_stack_fwd_granule: workspace over 4 GiB"); return PBSED_E_ARG; }
     GruStackArgs a{};
     for (int c = 0; c < nchains; ++c) {
         a.reverse[c] = reverse[c];
@@ -777,7 +792,7 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
     granule_poll_delays(false, a);
     dim3 grid(H / 16, (B + 15) / 16, ngroups);
     if (granule_ring_xcd()) grid = granule_xcd_grid(a, H);
-    unsigned long long* gran_gi = granules + (size_t)nchains * nlayers * T * B * H;
+    unsigned* gran_gi = granules + (size_t)nchains * nlayers * T * B * H;
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
     do {                                                                                                             \
@@ -794,16 +809,16 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
     return check_launch("gru_stack_fwd_granule");
 }
 
-// Granule-exchange persistent BPTT.  granules: device uint64 workspace of nchains*T*B*H*(2*nlayers-1) words
-// (dh_t of every layer, then dy_t of the layers below the top), zero before first use.
+// Granule-exchange persistent BPTT.  granules: device uint32 workspace of nchains*T*B*H*(2*nlayers-1) words
+// (dh_t of every layer, then dy_t of the layers below the top), zero before first use, epoch parity as above.
 int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
                                 const float* const* hs, const float* const* save, const float* const* dy_top,
                                 float* const* dgi, float* const* dgh, const int* reverse, const int* seq_len, int B, int H,
-                                int T, unsigned long long* granules, unsigned int epoch, unsigned int* err_flag,
+                                int T, unsigned int* granules, unsigned int epoch, unsigned int* err_flag,
                                 void* stream) {
     if (int e = stack_check(nchains, nlayers, B, H, T)) return e;
     if (epoch == 0 || !granules || !err_flag) { set_error("gru_stack_bwd_granule: need workspace and epoch != 0"); return PBSED_E_ARG; }
-    if ((size_t)nchains * nlayers * T * B * H * 8 >= (1ull << 32)) { set_error("gru_stack_bwd_granule: workspace over 4 GiB"); return PBSED_E_ARG; }
+    if ((size_t)nchains * nlayers * T * B * H * 4 >= (1ull << 32)) { set_error("gru_stack_bwd_granule: workspace over 4 GiB"); return PBSED_E_ARG; }
     GruStackArgs a{};
     for (int c = 0; c < nchains; ++c) {
         a.reverse[c] = reverse[c];
@@ -821,7 +836,7 @@ int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_
     granule_poll_delays(true, a);
     dim3 grid(H / 16, (B + 15) / 16, ngroups);
     if (granule_ring_xcd()) grid = granule_xcd_grid(a, H);
-    unsigned long long* gran_dy = granules + (size_t)nchains * nlayers * T * B * H;
+    unsigned* gran_dy = granules + (size_t)nchains * nlayers * T * B * H;
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
     do {                                                                                                             \

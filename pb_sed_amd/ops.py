@@ -365,6 +365,7 @@ def check_gru_sync():
     flags = [int(w[0].item()) for w in _GRU_SYNC]
     del _GRU_SYNC[:]
     if any(flags):
+        _GRANULE_WS.clear()                      # partially written workspaces must not be reused
         raise RuntimeError('persistent GRU scan: inter-workgroup hand-off timed out (PBSED_GRU_PERSIST=0 disables it)')
 
 
@@ -380,7 +381,7 @@ def _granule_scan(nch, nlayers, b, h, t, device=None):
     if dev not in _CU_COUNT:
         _CU_COUNT[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
     return (os.environ.get('PBSED_GRU_PERSIST', '2') == '2' and blocks <= _CU_COUNT[dev] * 7 // 8
-            and nch * nlayers * t * b * h * 8 < 2 ** 32)
+            and nch * nlayers * t * b * h * 4 < 2 ** 32)
 
 
 def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=True):
@@ -399,13 +400,13 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
         key = (str(dev), n, t, b, h)
         gw = _GRANULE_WS.get(key)
         if gw is None:
-            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * b * h * (nlayers + 3 * (nlayers - 1)), dtype=torch.int64, device=dev), 0]
-        gw[1] += 1                                   # fresh epoch: stale tags of earlier calls never match
+            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * b * h * (nlayers + 3 * (nlayers - 1)), dtype=torch.int32, device=dev), 0]
         ws = _gru_err_flag(dev)
         call('pbsed_gru_stack_fwd_granule', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih),
              _lib.ptr_array(b_ih), _lib.ptr_array(w_hh), _lib.ptr_array(b_hh), _lib.ptr_array(hs),
              _lib.ptr_array(sv) if save else None, _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]),
-             gw[1] & 0x7FFFFFFF or 1, ptr(ws), stream())
+             gw[1] + 1, ptr(ws), stream())
+        gw[1] += 1                                   # parity flips per launched call: the previous call's words never match
         return hs, sv
     call('pbsed_gru_stack_fwd', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih), _lib.ptr_array(b_ih),
          _lib.ptr_array(w_hh), _lib.ptr_array(b_hh), _lib.ptr_array(hs), _lib.ptr_array(sv) if save else None,
@@ -425,12 +426,12 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
         key = (str(dev), 'bwd', n, t, b, h)
         gw = _GRANULE_WS.get(key)
         if gw is None:
-            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * b * h * (2 * nlayers - 1), dtype=torch.int64, device=dev), 0]
-        gw[1] += 1
+            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * b * h * (2 * nlayers - 1), dtype=torch.int32, device=dev), 0]
         ws = _gru_err_flag(dev)
         call('pbsed_gru_stack_bwd_granule', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t),
              _lib.ptr_array(hs), _lib.ptr_array(save), _lib.ptr_array(dy_top), _lib.ptr_array(dgi), _lib.ptr_array(dgh),
-             _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]), gw[1] & 0x7FFFFFFF or 1, ptr(ws), stream())
+             _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]), gw[1] + 1, ptr(ws), stream())
+        gw[1] += 1
         return dgi, dgh
     dhz = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
     call('pbsed_gru_stack_bwd', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t), _lib.ptr_array(hs),
