@@ -758,9 +758,11 @@ static void granule_poll_delays(bool bwd, GruStackArgs& a) {
     a.poll_delay_gate = d[bwd ? 3 : 1];
 }
 
-static bool granule_ring_xcd() {
-    static const bool v = [] { const char* e = getenv("PBSED_GRU_RING_XCD"); return e ? atoi(e) != 0 : false; }();
-    return v;
+// Ring-per-XCD placement (granule_role) per scan direction: bit 0 = forward, bit 1 = BPTT.  Measured on MI355X with the
+// paced 4-byte polls: forward 1.35 ms with / 1.48 ms without, BPTT 1.66 / 1.64 ms.
+static bool granule_ring_xcd(bool bwd) {
+    static const int v = [] { const char* e = getenv("PBSED_GRU_RING_XCD"); return e ? atoi(e) : 1; }();
+    return (v >> (bwd ? 1 : 0)) & 1;
 }
 
 // Granule-exchange persistent forward scan (see gru_granule_fwd_kernel).  granules: device uint32 workspace of
@@ -791,7 +793,7 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
     const int ngroups = nchains * (2 * nlayers - 1);     // rings + projection groups (see GranuleRole)
     granule_poll_delays(false, a);
     dim3 grid(H / 16, (B + 15) / 16, ngroups);
-    if (granule_ring_xcd()) grid = granule_xcd_grid(a, H);
+    if (granule_ring_xcd(false)) grid = granule_xcd_grid(a, H);
     unsigned* gran_gi = granules + (size_t)nchains * nlayers * T * B * H;
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
@@ -835,7 +837,7 @@ int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_
     const int ngroups = nchains * (2 * nlayers - 1);
     granule_poll_delays(true, a);
     dim3 grid(H / 16, (B + 15) / 16, ngroups);
-    if (granule_ring_xcd()) grid = granule_xcd_grid(a, H);
+    if (granule_ring_xcd(true)) grid = granule_xcd_grid(a, H);
     unsigned* gran_dy = granules + (size_t)nchains * nlayers * T * B * H;
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
