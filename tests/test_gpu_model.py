@@ -268,3 +268,48 @@ def test_bicrnn_bf16_train_step():
     assert (out[0].cpu() - out_ref[0]).abs().max() < 3e-2
     assert loss.item() == pytest.approx(loss_ref.item(), rel=2e-2)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_trainer_three_steps_follow_the_oracle():
+    """pb_sed_amd.trainer.Trainer (flat buffers, fused clip + Adam, one batched weight re-pack per step, deferred
+    host summary) for three optimisation steps vs the oracle driven by clip_grad_norm_ + torch.optim.Adam: loss
+    trajectory, gradient norm and the parameters after the last step."""
+    from oracle import frontend as ofe, models as om
+    from pb_sed_amd.models import weak_label
+    from pb_sed_amd.trainer import Trainer
+    torch.manual_seed(1)
+    wide = dict(out_channels_2d=[16, 32, 64], pool_sizes_2d=[1, (2, 1), (2, 1)], kernel_size_2d=3,
+                out_channels_1d=[64, 64], kernel_size_1d=[3, 1])          # 32->64 3x3: Winograd kernels in the loop
+    kw = dict(num_events=10, number_of_filters=128, hidden_size=64, num_layers=2, net=wide)
+    ref = om.FBCRNN.build(**kw)
+    model = weak_label.CRNN.build(**kw)
+    _copy_weights(model, ref)
+    model.to(DEV)
+    wav, seq, weak, bnd, t = synth_batch(6, 16000 * 2, 10)
+    inputs_ref = {'stft': ofe.stft(wav), 'seq_len': seq.tolist(), 'weak_targets': weak, 'boundary_targets': bnd}
+    inputs = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV),
+              'boundary_targets': bnd.to(DEV)}
+    lr, clip = 2e-3, 1.5
+    opt = torch.optim.Adam(ref.parameters(), lr=lr)
+    trainer = Trainer(model, lr=lr, gradient_clipping=clip)
+    ref.train()
+    for step in range(3):
+        opt.zero_grad()
+        rev_ref = ref.review(inputs_ref, ref(inputs_ref))
+        rev_ref['loss'].backward()
+        norm_ref = torch.nn.utils.clip_grad_norm_(ref.parameters(), clip)
+        opt.step()
+        rev = trainer.step(inputs)
+        assert rev['loss'].item() == pytest.approx(rev_ref['loss'].item(), rel=2e-4), f'loss at step {step}'
+        assert rev['scalars']['grad_norm'].item() == pytest.approx(norm_ref.item(), rel=5e-3), f'grad norm at step {step}'
+        assert rev['scalars']['weak_label_rate'] == pytest.approx(float(rev_ref['scalars']['weak_label_rate']), abs=1e-6)
+    refp = dict(ref.named_parameters())
+    for name, p in model.named_parameters():
+        # three Adam steps of size <= lr each: a wrong / stale weight copy anywhere shows up as O(lr) differences
+        if refp[name].grad.abs().max().item() < 1e-6:
+            continue          # a bias in front of a batch norm: exactly-zero gradient, Adam random-walks on rounding noise
+        # Adam's first steps move every element by ~lr * sign(g): elements whose gradient is at rounding-noise level may
+        # walk differently, anything systematic (a stale weight copy, a wrong moment) moves whole tensors by O(lr)
+        diff = (p.detach().cpu() - refp[name].detach()).abs()
+        assert (diff > 0.5 * lr).float().mean().item() < 0.01 and diff.mean().item() < 0.05 * lr, \
+            f'{name}: parameters differ (mean {diff.mean():.2e}, max {diff.max():.2e}) after 3 steps of lr {lr}'
