@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(ConvWgradArgs a
         store_chunk();
         __syncthreads();
         if (chunk + (int)gridDim.x < nChunks) load_chunk(chunk + gridDim.x);
-#pragma unroll 2
+#pragma unroll
         for (int kk = 0; kk < C::TILES / 4; ++kk) {
 #pragma unroll
             for (int x = 0; x < 6; ++x) {
