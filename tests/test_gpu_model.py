@@ -313,3 +313,53 @@ def test_trainer_three_steps_follow_the_oracle():
         diff = (p.detach().cpu() - refp[name].detach()).abs()
         assert (diff > 0.5 * lr).float().mean().item() < 0.01 and diff.mean().item() < 0.05 * lr, \
             f'{name}: parameters differ (mean {diff.mean():.2e}, max {diff.max():.2e}) after 3 steps of lr {lr}'
+
+
+def test_fbcrnn_full_size_properties():
+    """BASELINE configs[1] size (shallow FBCRNN, batch 32, 10 s clips), where the CPU oracle takes minutes: properties
+    that do not depend on the size.  (1) Clips are independent up to the batch statistics, which are permutation
+    invariant: permuting the batch permutes scores and leaves the loss and every gradient unchanged.  (2) Frames past
+    seq_len never influence anything: garbage audio there changes neither scores inside the sequence nor the loss."""
+    from pb_sed_amd.models import weak_label
+    torch.manual_seed(0)
+    model = weak_label.CRNN.build(num_events=10).to(DEV).train()
+    b = 32
+    wav, seq, weak, bnd, t = synth_batch(b, 160000, 10, ragged=True)
+    seq[:4] = t                                                   # several full-length clips to permute among
+    order = np.argsort(-seq, kind='stable')                       # packed-sequence contract: sorted by length
+    wav, seq, weak, bnd = wav[order], seq[order], weak[order], bnd[order]
+
+    def run(wav_, seq_, weak_, bnd_):
+        inputs = {'audio_data': wav_.to(DEV), 'seq_len': seq_.tolist(), 'weak_targets': weak_.to(DEV),
+                  'boundary_targets': bnd_.to(DEV)}
+        _, flat_grad = model.flat_parameters()
+        flat_grad.zero_()
+        for m_ in model.modules():                                # same running statistics before every run
+            if hasattr(m_, 'running_mean'):
+                m_.running_mean.zero_(), m_.running_power.fill_(1.)
+        out = model(dict(inputs))
+        rev = model.review(inputs, out)
+        rev['loss'].backward()
+        torch.cuda.synchronize()
+        return out[0].detach().clone(), out[1].detach().clone(), rev['loss'].item(), flat_grad.detach().clone()
+
+    y_f, y_b, loss, grad = run(wav, seq, weak, bnd)
+    assert np.isfinite(loss) and torch.isfinite(grad).all()
+    # (1) permutation among clips of equal length (keeps the batch sorted)
+    perm = np.arange(b)
+    full = np.nonzero(seq == seq[0])[0]
+    assert len(full) >= 2
+    perm[full] = full[::-1]
+    y_f2, y_b2, loss2, grad2 = run(wav[perm], seq[perm], weak[perm], bnd[perm])
+    assert (y_f2 - y_f[perm]).abs().max().item() < 1e-4 and (y_b2 - y_b[perm]).abs().max().item() < 1e-4
+    assert loss2 == pytest.approx(loss, rel=1e-5)
+    assert ((grad2 - grad).norm() / grad.norm()).item() < 1e-3
+    # (2) audio past the end of the shortest clip (frame t covers samples 320 t - 320 .. 320 t + 639)
+    wav3 = wav.clone()
+    wav3[-1, 320 * int(seq[-1]) + 640:] = torch.randn(wav3.shape[1] - (320 * int(seq[-1]) + 640)) * 3
+    y_f3, y_b3, loss3, _ = run(wav3, seq, weak, bnd)
+    sl = int(seq[-1])
+    assert (y_f3[-1, :, :sl] - y_f[-1, :, :sl]).abs().max().item() < 1e-4
+    assert (y_b3[-1, :, :sl] - y_b[-1, :, :sl]).abs().max().item() < 1e-4
+    assert (y_f3[:-1] - y_f[:-1]).abs().max().item() < 1e-4
+    assert loss3 == pytest.approx(loss, rel=1e-5)
