@@ -37,6 +37,11 @@ int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, const int* s
                      const float* window, const float* twiddle, const int* mel_start, const int* mel_len,
                      const int* mel_off, const float* mel_w, int F, const float* mean, const float* inv_std,
                      float eps, float clampv, float* out, void* stream);
+/* Training-only feature augmentation (NormalizedLogMelExtractor config, pb_sed/experiments/weak_label_crnn/
+ * training.py:209-216): x [B,F,T] in place; x += noise_scale[b] * noise (noise may be NULL), then the time mask
+ * [masks[b][0], masks[b][1]) and the frequency mask [masks[b][2], masks[b][3]) are zeroed, then frames >= seq_len[b]. */
+int pbsed_augment_logmel(float* x, const float* noise, const float* noise_scale, const int* masks /*[B][4]*/,
+                         const int* seq_len, int B, int F, int T, void* stream);
 
 /* ---- convolutions (CNN2d 3x3 / CNN1d k=1,3 / GRU input projections / heads): the `self.cnn(...)`,
  * `self.rnn_*` op sites pb_sed/models/weak_label/crnn.py:93,61-67; layer list

@@ -126,3 +126,21 @@ class LogMelExtractor(torch.nn.Module):
         if targets is None:
             return y, seq_len
         return y, seq_len, targets
+
+
+def augment(y, seq_len, masks, noise=None, noise_scale=None):
+    """Training-only augmentation of NormalizedLogMelExtractor (config pb_sed/experiments/weak_label_crnn/
+    training.py:209-216; padertorch semantics restated from SURVEY.md A.3 - parity unpinned): y [B,1,F,T] (or
+    [B,F,T]) + noise_scale[b] * noise, one time mask [t_on, t_off) and one frequency mask [f_on, f_off) per clip
+    (``masks`` [B,4]) set to zero, frames >= seq_len[b] zero."""
+    y = y.clone()
+    b, f, t = y.shape[0], y.shape[-2], y.shape[-1]
+    if noise is not None:
+        y = y + torch.as_tensor(noise_scale, dtype=y.dtype).reshape(b, *([1] * (y.dim() - 1))) * noise
+    tt, ff = torch.arange(t), torch.arange(f)
+    for i in range(b):
+        t_on, t_off, f_on, f_off = (int(v) for v in masks[i])
+        y[i][..., (tt >= t_on) & (tt < t_off)] = 0
+        y[i][..., (ff >= f_on) & (ff < f_off), :] = 0
+        y[i][..., tt >= int(seq_len[i])] = 0
+    return y

@@ -99,9 +99,38 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelArgs a) {
     }
 }
 
+// Training-time augmentation of the normalised log-mel features (NormalizedLogMelExtractor config of
+// pb_sed/experiments/weak_label_crnn/training.py:209-216; padertorch semantics restated): additive
+// noise scale[b] * noise, then one time mask [t_on, t_off) and one frequency mask [f_on, f_off) per clip set to 0,
+// then the sequence mask again.  The random draws (scales, mask positions, the N(0,1) field) are the caller's.
+__global__ __launch_bounds__(256) void augment_logmel_kernel(float* __restrict__ x, const float* __restrict__ noise,
+                                                             const float* __restrict__ noise_scale,
+                                                             const int* __restrict__ masks /*[B][4]*/,
+                                                             const int* __restrict__ seq_len, int B, int F, int T) {
+    const size_t total = (size_t)B * F * T;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = i % T, f = (i / T) % F, b = i / ((size_t)T * F);
+        float v = x[i];
+        if (noise) v = fmaf(noise_scale[b], noise[i], v);
+        const int* m = masks + 4 * b;
+        const bool dropped = (t >= m[0] && t < m[1]) || (f >= m[2] && f < m[3]) || (seq_len && t >= seq_len[b]);
+        x[i] = dropped ? 0.f : v;
+    }
+}
+
 }  // namespace pbsed
 
 using namespace pbsed;
+
+extern "C" int pbsed_augment_logmel(float* x, const float* noise, const float* noise_scale, const int* masks,
+                                    const int* seq_len, int B, int F, int T, void* stream) {
+    if (!masks || (noise && !noise_scale)) { set_error("augment_logmel: need masks, and noise_scale with noise"); return PBSED_E_ARG; }
+    const size_t total = (size_t)B * F * T;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(augment_logmel_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, (hipStream_t)stream, x, noise, noise_scale,
+                       masks, seq_len, B, F, T);
+    return check_launch("augment_logmel");
+}
 
 extern "C" int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, const int* seq_len_frames,
                                 const float* window, const float* twiddle, const int* mel_start,

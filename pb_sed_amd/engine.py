@@ -369,11 +369,21 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
 
 
 # ------------------------------------------------------------------------------------- front-end
-def features_from_audio(fe, audio, seq_dev, n_frames):
+def features_from_audio(fe, audio, seq_dev, n_frames, seq_host=None):
     if fe._tables is None or fe._tables.window.device != audio.device:
         fe._tables = ops.LogMelTables(fe.fbanks.detach().cpu().numpy(), audio.device)
-    return ops.logmel_fwd(audio, fe._tables, fe.mean, fe.inv_std, n_frames, seq_dev, eps=fe.eps,
-                          clamp=fe.clamp)
+    x = ops.logmel_fwd(audio, fe._tables, fe.mean, fe.inv_std, n_frames, seq_dev, eps=fe.eps, clamp=fe.clamp)
+    return augment_features(fe, x, seq_dev, seq_host) if (fe.training and fe.augments) else x
+
+
+def augment_features(fe, x, seq_dev, seq_host=None):
+    """Training-only augmentation of the features (noise, time mask, frequency mask): draws on the host, one launch."""
+    if seq_host is None:
+        seq_host = seq_dev.cpu().numpy()
+    masks, scales = fe.sample_augmentation(seq_host)
+    noise = torch.randn_like(x) if scales is not None else None
+    return ops.augment_logmel(x, torch.from_numpy(masks).to(x.device), seq_dev, noise,
+                              None if scales is None else torch.from_numpy(scales).to(x.device))
 
 
 def features_from_stft(fe, stft, seq_host):
@@ -386,4 +396,7 @@ def features_from_stft(fe, stft, seq_host):
         y = y.clamp(-fe.clamp, fe.clamp)
     t = y.shape[-1]
     m = torch.arange(t, device=y.device)[None] < torch.as_tensor(np.asarray(seq_host), device=y.device)[:, None]
-    return (y * m[:, None, None, :]).contiguous()
+    y = (y * m[:, None, None, :]).contiguous()
+    if fe.training and fe.augments:
+        y = augment_features(fe, y, seq_to_device(seq_host, y.device), seq_host)
+    return y

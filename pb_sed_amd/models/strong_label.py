@@ -81,7 +81,7 @@ class CRNN(SoundEventModel):
         seq_host, seq_dev = self._seq(inputs, x_in.device)
         if key == 'audio_data':
             audio = x_in.reshape(x_in.shape[0], -1).to(torch.float32)
-            x = engine.features_from_audio(self.feature_extractor, audio, seq_dev, num_frames(audio.shape[1]))
+            x = engine.features_from_audio(self.feature_extractor, audio, seq_dev, num_frames(audio.shape[1]), seq_host)
         else:
             x = engine.features_from_stft(self.feature_extractor, x_in, seq_host)
         targets = (inputs['weak_targets'], inputs['strong_targets']) if 'strong_targets' in inputs else None

@@ -100,10 +100,12 @@ class CRNN(SoundEventModel):
 
     @classmethod
     def build(cls, num_events=10, number_of_filters=128, stft_size=1024, sample_rate=16000,
-              hidden_size=256, num_layers=2, net=None, rnn_bwd=True, **kw):
-        """Reference model factory (pb_sed/experiments/weak_label_crnn/training.py:158-260)."""
+              hidden_size=256, num_layers=2, net=None, rnn_bwd=True, feature_extractor=None, **kw):
+        """Reference model factory (pb_sed/experiments/weak_label_crnn/training.py:158-260).  ``feature_extractor``:
+        extra NormalizedLogMelExtractor fields, e.g. the training augmentation of training.py:209-216
+        (dict(n_time_masks=1, n_frequency_masks=1, max_noise_scale=.2))."""
         net = dict(SHALLOW if net is None else net)
-        fe = NormalizedLogMelExtractor(sample_rate, stft_size, number_of_filters)
+        fe = NormalizedLogMelExtractor(sample_rate, stft_size, number_of_filters, **(feature_extractor or {}))
         cnn = build_cnn(1, input_height=number_of_filters, **net)
         c = net['out_channels_1d'][-1]
         fwd = build_rnn(c, hidden_size, num_layers, num_events, hidden_size)
@@ -115,7 +117,7 @@ class CRNN(SoundEventModel):
         if 'audio_data' in inputs:
             audio = inputs['audio_data']
             audio = audio.reshape(audio.shape[0], -1).to(torch.float32)
-            return engine.features_from_audio(self.feature_extractor, audio, seq_dev, num_frames(audio.shape[1]))
+            return engine.features_from_audio(self.feature_extractor, audio, seq_dev, num_frames(audio.shape[1]), seq_host)
         return engine.features_from_stft(self.feature_extractor, inputs['stft'], seq_host)
 
     def _net(self, x, seq_host, seq_dev):

@@ -41,8 +41,22 @@ class NormalizedLogMelExtractor(nn.Module):
     """Front-end description (STFT 1024/960/320 Blackman -> mel -> log -> global norm -> clamp)."""
 
     def __init__(self, sample_rate=16000, stft_size=1024, number_of_filters=128, lowest_frequency=50.,
-                 highest_frequency=None, eps=1e-18, clamp=6.0, shift=320, window_length=960):
+                 highest_frequency=None, eps=1e-18, clamp=6.0, shift=320, window_length=960,
+                 n_time_masks=0, max_masked_time_steps=70, max_masked_time_rate=.2,
+                 n_frequency_masks=0, max_masked_frequency_bands=20, max_masked_frequency_rate=.2,
+                 max_noise_scale=0., frequency_warping_fn=None, augmentation_seed=0):
+        """The augmentation fields are those of the reference's training config
+        (pb_sed/experiments/weak_label_crnn/training.py:194-216); all default to off (as in the reference's class
+        defaults), training scripts switch them on.  They act in training mode only."""
         super().__init__()
+        if frequency_warping_fn is not None:
+            raise NotImplementedError('mel warping (MelWarping, training.py:194-208) is not built: SURVEY.md 8(f) f2')
+        if n_time_masks > 1 or n_frequency_masks > 1:
+            raise NotImplementedError('one time mask and one frequency mask per clip (the reference configuration)')
+        self.n_time_masks, self.max_masked_time_steps, self.max_masked_time_rate = n_time_masks, max_masked_time_steps, max_masked_time_rate
+        self.n_frequency_masks, self.max_masked_frequency_bands = n_frequency_masks, max_masked_frequency_bands
+        self.max_masked_frequency_rate, self.max_noise_scale = max_masked_frequency_rate, max_noise_scale
+        self._rng = np.random.RandomState(augmentation_seed)
         if (stft_size, shift, window_length) != (1024, 320, 960):
             raise NotImplementedError('the fused HIP front-end is built for STFT 1024/960/320 '
                                       '(pb_sed/data_preparation/provider.py:315-323)')
@@ -53,6 +67,29 @@ class NormalizedLogMelExtractor(nn.Module):
         self.register_buffer('mean', torch.zeros(number_of_filters))
         self.register_buffer('inv_std', torch.ones(number_of_filters))
         self._tables = None
+
+    @property
+    def augments(self):
+        return self.n_time_masks > 0 or self.n_frequency_masks > 0 or self.max_noise_scale > 0.
+
+    def sample_augmentation(self, seq_len):
+        """Host-side draws of one training batch: (masks int32 [B,4] = t_on, t_off, f_on, f_off; noise scales [B]).
+        Mask widths ~ U{0..min(max_steps, floor(max_rate * extent))}, onsets uniform over the positions where the mask
+        fits (time: inside the clip's seq_len), noise scale ~ U(0, max_noise_scale) per clip."""
+        seq_len = np.asarray(seq_len)
+        b, f = len(seq_len), self.number_of_filters
+        masks = np.zeros((b, 4), np.int32)
+        for i in range(b):
+            if self.n_time_masks:
+                w = self._rng.randint(0, int(min(self.max_masked_time_steps, self.max_masked_time_rate * seq_len[i])) + 1)
+                on = self._rng.randint(0, max(int(seq_len[i]) - w, 0) + 1)
+                masks[i, :2] = on, on + w
+            if self.n_frequency_masks:
+                w = self._rng.randint(0, int(min(self.max_masked_frequency_bands, self.max_masked_frequency_rate * f)) + 1)
+                on = self._rng.randint(0, f - w + 1)
+                masks[i, 2:] = on, on + w
+        scales = self._rng.uniform(0., self.max_noise_scale, b).astype(np.float32) if self.max_noise_scale > 0. else None
+        return masks, scales
 
 
 class Normalization(nn.Module):

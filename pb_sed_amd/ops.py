@@ -300,6 +300,16 @@ def bn_backward(dz, x, st, stats, count, dgamma, dbeta, seq_len):
     return dz
 
 
+def augment_logmel(x, masks, seq_len, noise=None, noise_scale=None):
+    """In place: x [B,1,F,T] or [B,F,T] += noise_scale[b]*noise, then per-clip time / frequency masks (int32 [B,4] =
+    t_on, t_off, f_on, f_off) and the sequence mask."""
+    _lib.require_gpu(x)
+    b, f, t = x.shape[0], x.shape[-2], x.shape[-1]
+    assert x.is_contiguous() and masks.shape == (b, 4) and masks.dtype == torch.int32
+    call('pbsed_augment_logmel', ptr(x), ptr(noise), ptr(noise_scale), ptr(masks), ptr(seq_len), b, f, t, stream())
+    return x
+
+
 def bct_to_tbc(x):
     b, c, t = x.shape
     y = torch.empty((t, b, c), device=x.device, dtype=torch.float32)

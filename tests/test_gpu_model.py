@@ -363,3 +363,31 @@ def test_fbcrnn_full_size_properties():
     assert (y_b3[-1, :, :sl] - y_b[-1, :, :sl]).abs().max().item() < 1e-4
     assert (y_f3[:-1] - y_f[:-1]).abs().max().item() < 1e-4
     assert loss3 == pytest.approx(loss, rel=1e-5)
+
+
+def test_fbcrnn_training_augmentation_in_the_loop():
+    """The reference's training configuration of the feature extractor (one time mask, one frequency mask, noise;
+    training.py:209-216): active in train mode only, masks visible in the returned features, loss finite, and the
+    train step still runs through backward."""
+    from pb_sed_amd.models import weak_label
+    torch.manual_seed(0)
+    kw = dict(num_events=10, hidden_size=64, num_layers=2, net=TINY,
+              feature_extractor=dict(n_time_masks=1, n_frequency_masks=1, max_noise_scale=.2, augmentation_seed=1))
+    model = weak_label.CRNN.build(**kw).to(DEV)
+    wav, seq, weak, bnd, t = synth_batch(5, 16000 * 2, 10)
+    inputs = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV),
+              'boundary_targets': bnd.to(DEV)}
+    model.eval()
+    x_eval = model(dict(inputs))[3]
+    x_eval2 = model(dict(inputs))[3]
+    assert torch.equal(x_eval, x_eval2)                          # no augmentation outside training
+    model.train()
+    out = model(dict(inputs))
+    x_tr = out[3]
+    assert not torch.equal(x_tr, x_eval)
+    zero_rows = (x_tr.abs().sum(-1) == 0).squeeze(1)              # [B,F]: fully masked mel bands
+    zero_cols = (x_tr.abs().sum(-2) == 0).squeeze(1)              # [B,T]: masked or padded frames
+    assert zero_rows.any() or zero_cols[:, : int(seq.min())].any()
+    rev = model.review(inputs, out)
+    rev['loss'].backward()
+    assert np.isfinite(rev['loss'].item())

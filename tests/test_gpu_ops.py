@@ -458,3 +458,28 @@ def test_conv_winograd_dgrad_bn_epilogue_matches_direct(cin, cout, f, t, pool):
         out[prec] = (dz, st.sum(0))
     close(out['wino'][0], out['f32'][0], atol=2e-5, rtol=1e-4, name='dz wino vs direct')
     close(out['wino'][1], out['f32'][1], atol=2e-3, rtol=1e-4, name='bn-backward sums wino vs direct')
+
+
+def test_logmel_augmentation_vs_oracle():
+    """Training-only front-end augmentation (noise + time mask + frequency mask + sequence mask) against the oracle's
+    restatement on the same draws; and the sampler keeps to the reference configuration's bounds."""
+    from oracle import frontend as ofe
+    from pb_sed_amd import modules, ops
+    torch.manual_seed(5)
+    b, f, t = 6, 128, 200
+    y = torch.randn(b, 1, f, t)
+    seq = np.array([200, 190, 150, 100, 64, 10])
+    fe = modules.NormalizedLogMelExtractor(n_time_masks=1, n_frequency_masks=1, max_noise_scale=.2, augmentation_seed=3)
+    for _ in range(20):
+        masks, scales = fe.sample_augmentation(seq)
+        assert ((masks[:, 1] - masks[:, 0]) <= np.minimum(70, np.floor(.2 * seq))).all() and (masks[:, 1] <= seq).all()
+        assert ((masks[:, 3] - masks[:, 2]) <= 20).all() and (masks[:, 3] <= f).all() and (masks[:, [0, 2]] >= 0).all()
+        assert (scales >= 0).all() and (scales <= .2).all()
+    noise = torch.randn(b, 1, f, t)
+    ref = ofe.augment(y, seq, masks, noise, scales)
+    out = ops.augment_logmel(y.to(DEV).contiguous(), torch.from_numpy(masks).to(DEV),
+                             torch.as_tensor(seq, dtype=torch.int32).to(DEV), noise.to(DEV), torch.from_numpy(scales).to(DEV))
+    close(out, ref, atol=1e-6, rtol=1e-6, name='augment_logmel')
+    out2 = ops.augment_logmel(y.to(DEV).contiguous(), torch.from_numpy(masks).to(DEV),
+                              torch.as_tensor(seq, dtype=torch.int32).to(DEV))
+    close(out2, ofe.augment(y, seq, masks), atol=0, rtol=0, name='augment_logmel masks only')
