@@ -347,18 +347,25 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
         else:
             dgi, dgh = ops.gru_scan_bwd(w_hh_t, hs, save, dy, [ch.reverse for ch in chains], seq_dev)
         dx_w = [None for _ in wrappers]
+        jobs, x_tbc = {}, {}                       # batched time-major weight-gradient launches (ops.gru_wgrad)
         for i, ch in enumerate(chains):
-            dgi_b, dgh_b = ops.tbc_to_bct(dgi[i]), ops.tbc_to_bct(dgh[i])
-            hprev = ops.tbc_to_bct(hs[i], shift=1 if ch.reverse else -1)
             w_hh, w_ih = ch.p('weight_hh', l), ch.p('weight_ih', l)
+            dgi_b = ops.tbc_to_bct(dgi[i])
             if w_hh.requires_grad:
-                ops.conv_bwd_weight(hprev, dgh_b, PackedConv(w_hh.unsqueeze(-1)),
-                                    _grad(w_hh), _grad(ch.p('bias_hh', l)))
+                _wgrad_job(jobs, dgh[i], hs[i], 1 if ch.reverse else -1, _grad(w_hh), _grad(ch.p('bias_hh', l)))
             if w_ih.requires_grad:
-                ops.conv_bwd_weight(x_w[ch.widx], dgi_b, pcs[i], _grad(w_ih), _grad(ch.p('bias_ih', l)))
+                if w_ih.shape[1] % 4 == 0:
+                    if ch.widx not in x_tbc:         # the layer input once per wrapper, time-major
+                        x_tbc[ch.widx] = ops.bct_to_tbc(x_w[ch.widx])
+                    _wgrad_job(jobs, dgi[i], x_tbc[ch.widx], 0, _grad(w_ih), _grad(ch.p('bias_ih', l)))
+                else:                                # e.g. 266 = 256 + 10 tag-conditioned inputs: not a float4 multiple
+                    ops.conv_bwd_weight(x_w[ch.widx], dgi_b, pcs[i], _grad(w_ih), _grad(ch.p('bias_ih', l)))
             pr = _prec(precision, pcs[i].cin)
             dx, _ = ops.conv_bwd_data(dgi_b, pcs[i], pcs[i].dgrad(pr), x_w[ch.widx].shape, precision=pr)
             dx_w[ch.widx] = dx if dx_w[ch.widx] is None else dx_w[ch.widx].add_(dx)
+        for job in jobs.values():
+            for a in range(0, len(job[0]), 16):
+                ops.gru_wgrad(*[v[a:a + 16] for v in job])
         if l > 0:
             d_out = dx_w
         else:
