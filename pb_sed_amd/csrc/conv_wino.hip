@@ -33,6 +33,7 @@ constexpr int WN_V_FLOATS = 6 * WN_CK * WN_PLANE_V;
 constexpr int WN_U_FLOATS = 18 * WN_CK * WN_COUT_P;
 constexpr int WN_U_VEC = 18 * WN_CK * WN_CT / 4;       // float4 per U stage
 constexpr int WN_U_PER_T = (WN_U_VEC + 255) / 256;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 template <bool POOL>
 struct WinoCfg {
@@ -85,80 +86,97 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
     const int iq = tid & 3, ir = (tid >> 2) % WN_ROWS, ic = tid / (4 * WN_ROWS);
     const int fin = f0 - 1 + ir, tq0 = t0 + 16 * iq;
     const bool row_ok = loader && fin >= 0 && fin < a.F;
-    const int row_off = (ic * Fsrc + (unpool ? (fin >> 1) : fin)) * a.T;
     const int par = fin & 1;
-    float rin[18];                                   // raw inputs t = tq0 - 1 .. tq0 + 16 of the chunk in flight
-    unsigned rpar = 0;                               // DGRAD + unpool: bit e set = element e comes from the other pool row
-    float4 ru[WN_U_PER_T];
-    int rcin = 0;
-    float rsc = 1.f, rsh = 0.f;                      // BN-apply factors of this item's channel, fetched with the chunk
+    // valid elements of the item: e in [e_lo, e_hi)  (t = tq0 - 1 + e in [0, tlim), zero padding is post-activation)
+    const int e_hi = row_ok ? max(tlim - tq0 + 1, 0) : 0;
+    const bool e0_ok = tq0 > 0 && e_hi > 0;
+
+    // All loads are raw buffer loads on clip-relative resources: addresses are one 32-bit VGPR per stream, advanced by
+    // a uniform step per chunk (fp32 MFMAs and VALU instructions share the SIMD's fp32 pipe on gfx950 - they do not
+    // overlap - so every address instruction here is paid in MFMA time); out-of-range lanes (halo rows outside the
+    // plane, padded channels, the element before the first row) read 0 without a branch.
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned clip_elems = (unsigned)(a.Cin * Fsrc * a.T);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x) + (size_t)b * clip_elems, 0, clip_elems * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
+        unpool ? const_cast<uint8_t*>(a.unpool_idx) + (size_t)b * clip_elems : nullptr, 0, unpool ? clip_elems : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.wp), 0, (unsigned)(18 * a.CinP * a.CoutP) * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.scale), 0, pro ? (unsigned)a.Cin * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.shift), 0, pro ? (unsigned)a.Cin * 4u : 0u, 0x00020000);
+    const unsigned elem0 = (unsigned)((ic * Fsrc + (unpool ? (fin >> 1) : fin)) * a.T + tq0);
+    unsigned voff_x = row_ok ? elem0 * 4u : OOB;     // byte offset of element e = 1 in the chunk to load next
+    unsigned voff_i = row_ok ? elem0 : OOB;
+    unsigned voff_c = row_ok ? (unsigned)ic * 4u : OOB;
+    unsigned voff_u = (unsigned)(((tid >> 7) * a.CinP + ((tid >> 4) & 7)) * a.CoutP + cout0 + (tid & 15) * 4) * 4u;
+    const unsigned step_x = (unsigned)(WN_CK * Fsrc * a.T) * 4u, step_u = (unsigned)(WN_CK * a.CoutP) * 4u;
+    const unsigned stride_u = (unsigned)(2 * a.CinP * a.CoutP) * 4u;     // U load i: kx = tid/128 + 2 i
+
+    unsigned rin[18];                                // raw inputs t = tq0 - 1 .. tq0 + 16 of the chunk in flight (bits)
+    unsigned ridx[6];                                // DGRAD + unpool: pool-row bytes of the same elements
+    u32x4_t ru[WN_U_PER_T];
+    unsigned rsc = 0u, rsh = 0u;                     // BN-apply factors of this item's channel, fetched with the chunk
 
     // global loads only: everything that depends on the loaded values happens in store_chunk, after the MFMAs
-    auto load_chunk = [&](int c0) __attribute__((always_inline)) {
-        rcin = c0 + ic;
-        rpar = 0;
-        if (pro && row_ok && rcin < a.Cin) { rsc = a.scale[rcin]; rsh = a.shift[rcin]; }
+    auto load_chunk = [&]() __attribute__((always_inline)) {
+        if (pro) {
+            rsc = __builtin_amdgcn_raw_buffer_load_b32(rs_sc, voff_c, 0, 0);
+            rsh = __builtin_amdgcn_raw_buffer_load_b32(rs_sh, voff_c, 0, 0);
+        }
+        if (vec) {
 #pragma unroll
-        for (int e = 0; e < 18; ++e) rin[e] = 0.f;
-        if (row_ok && rcin < a.Cin) {
-            const float* xb = a.x + (size_t)(b * a.Cin + c0) * Fsrc * a.T + row_off;
-            const uint8_t* ib = unpool ? a.unpool_idx + (size_t)(b * a.Cin + c0) * Fsrc * a.T + row_off : nullptr;
-            if (vec && tq0 + 16 <= a.T) {
+            for (int q = 0; q < 4; ++q) {
+                const u32x4_t xv = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff_x + q * 16, 0, 0);
+                rin[1 + 4 * q] = xv.x; rin[2 + 4 * q] = xv.y; rin[3 + 4 * q] = xv.z; rin[4 + 4 * q] = xv.w;
+            }
+            rin[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, voff_x - 4u, 0, 0);
+            rin[17] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, voff_x + 64u, 0, 0);
+            if (unpool) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ridx[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, voff_i + q * 4, 0, 0);
+                ridx[4] = __builtin_amdgcn_raw_buffer_load_b8(rs_i, voff_i - 1u, 0, 0);
+                ridx[5] = __builtin_amdgcn_raw_buffer_load_b8(rs_i, voff_i + 16u, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 18; ++e) rin[e] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, voff_x + (unsigned)(e - 1) * 4u, 0, 0);
+            if (unpool) {
+                // bytes gathered into the layout of the vector path: ridx[q] = elements 1 + 4q .. 4 + 4q
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 xv = *reinterpret_cast<const float4*>(xb + tq0 + 4 * q);
-                    rin[1 + 4 * q] = xv.x; rin[2 + 4 * q] = xv.y; rin[3 + 4 * q] = xv.z; rin[4 + 4 * q] = xv.w;
-                    if (unpool) {
-                        const uchar4 iv = *reinterpret_cast<const uchar4*>(ib + tq0 + 4 * q);
-                        rpar |= (unsigned)(iv.x != par) << (1 + 4 * q) | (unsigned)(iv.y != par) << (2 + 4 * q) |
-                                (unsigned)(iv.z != par) << (3 + 4 * q) | (unsigned)(iv.w != par) << (4 + 4 * q);
-                    }
-                }
-            } else {
+                    unsigned w = 0;
 #pragma unroll
-                for (int e = 1; e < 17; ++e) {
-                    const int t = tq0 - 1 + e;
-                    if (t < a.T) {
-                        rin[e] = xb[t];
-                        if (unpool) rpar |= (unsigned)(ib[t] != par) << e;
-                    }
+                    for (int k = 0; k < 4; ++k)
+                        w |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_i, voff_i + (unsigned)(4 * q + k), 0, 0) << (8 * k);
+                    ridx[q] = w;
                 }
-            }
-            if (tq0 - 1 >= 0 && tq0 - 1 < a.T) {
-                rin[0] = xb[tq0 - 1];
-                if (unpool) rpar |= (unsigned)(ib[tq0 - 1] != par);
-            }
-            if (tq0 + 16 < a.T) {
-                rin[17] = xb[tq0 + 16];
-                if (unpool) rpar |= (unsigned)(ib[tq0 + 16] != par) << 17;
+                ridx[4] = __builtin_amdgcn_raw_buffer_load_b8(rs_i, voff_i - 1u, 0, 0);
+                ridx[5] = __builtin_amdgcn_raw_buffer_load_b8(rs_i, voff_i + 16u, 0, 0);
             }
         }
 #pragma unroll
-        for (int i = 0; i < WN_U_PER_T; ++i) {
-            const int idx = tid + i * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < WN_U_VEC) {
-                const int q = idx % (WN_CT / 4);
-                const int c = (idx / (WN_CT / 4)) % WN_CK;
-                const int kx = idx / (WN_CT / 4) / WN_CK;
-                v = *reinterpret_cast<const float4*>(a.wp + ((size_t)kx * a.CinP + c0 + c) * a.CoutP + cout0 + q * 4);
-            }
-            ru[i] = v;
-        }
+        for (int i = 0; i < WN_U_PER_T; ++i) ru[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u, i * stride_u, 0);
+        voff_x += step_x; voff_i += step_x >> 2; voff_c += WN_CK * 4u; voff_u += step_u;
     };
     auto store_chunk = [&]() __attribute__((always_inline)) {
         if (loader) {
             float d[18];
-            const bool chan_ok = row_ok && rcin < a.Cin;
+            const float sc = __uint_as_float(rsc), sh = __uint_as_float(rsh);
 #pragma unroll
             for (int e = 0; e < 18; ++e) {
-                float u = ((rpar >> e) & 1u) ? 0.f : rin[e];
+                float u = __uint_as_float(rin[e]);
+                if (unpool) {
+                    const unsigned byte = e == 0 ? ridx[4] : e == 17 ? ridx[5] : (ridx[(e - 1) >> 2] >> (8 * ((e - 1) & 3))) & 0xffu;
+                    u = (int)byte != par ? 0.f : u;
+                }
                 if (pro) {
-                    u = fmaf(u, rsc, rsh);
+                    u = fmaf(u, sc, sh);
                     if (a.relu) u = fmaxf(u, 0.f);
                 }
-                const int t = tq0 - 1 + e;
-                d[e] = (chan_ok && t >= 0 && t < tlim) ? u : 0.f;     // zero padding is post-activation
+                d[e] = (e == 0 ? e0_ok : e < e_hi) ? u : 0.f;
             }
             // B^T d for the 4 tiles of this item, one float4 (4 consecutive tiles) per transform point
             float vx[6][4];
@@ -178,45 +196,59 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
                 *reinterpret_cast<float4*>(v_s + (x * WN_CK + ic) * WN_PLANE_V + ir * 16 + iq * 4) =
                     make_float4(vx[x][0], vx[x][1], vx[x][2], vx[x][3]);
         }
+        static_assert(WN_U_VEC % 256 == 0, "U stage = whole float4 rounds of the block");
 #pragma unroll
-        for (int i = 0; i < WN_U_PER_T; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < WN_U_VEC) {
-                const int q = idx % (WN_CT / 4);
-                const int kc = idx / (WN_CT / 4);        // (kh*6 + xi)*CK + c
-                *reinterpret_cast<float4*>(u_s + kc * WN_COUT_P + q * 4) = ru[i];
-            }
-        }
+        for (int i = 0; i < WN_U_PER_T; ++i)            // float4 idx = tid + 256 i: kc = tid/16 + 16 i, q = tid % 16
+            *reinterpret_cast<u32x4_t*>(u_s + ((tid >> 4) + 16 * i) * WN_COUT_P + (tid & 15) * 4) = ru[i];
     };
 
     for (int i = tid; i < WN_CT * C::FO_T * 2; i += 256) st_s[i] = 0.f;
 
     const int nChunks = a.CinP / WN_CK;
-    load_chunk(0);
+    load_chunk();
     for (int ch = 0; ch < nChunks; ++ch) {
         __syncthreads();            // previous chunk's MFMA reads are done
+        __builtin_amdgcn_s_setprio(3);
         store_chunk();
         __syncthreads();
-        if (ch + 1 < nChunks) load_chunk((ch + 1) * WN_CK);   // in flight during the MFMAs below
+        if (ch + 1 < nChunks) load_chunk();                   // in flight during the MFMAs below
+        __builtin_amdgcn_s_setprio(0);
+        // operand fragments of group g + 1 are read while the MFMAs of group g issue
+        constexpr int NG = 6 * (WN_CK / 4);
+        float bf[2][4], af[2][3][2];
+        auto read_group = [&](int g, float (&b)[4], float (&am)[3][2]) __attribute__((always_inline)) {
+            const int x = g / (WN_CK / 4), cs = g % (WN_CK / 4);
+            const float* vp = v_s + (x * WN_CK + cs * 4 + lq) * WN_PLANE_V + (wn * 2) * 16 + lr;
 #pragma unroll
-        for (int x = 0; x < 6; ++x) {
+            for (int r = 0; r < 4; ++r) b[r] = vp[r * 16];
 #pragma unroll
-            for (int cs = 0; cs < WN_CK / 4; ++cs) {
-                float bf[4], af[3][2];
-                const float* vp = v_s + (x * WN_CK + cs * 4 + lq) * WN_PLANE_V + (wn * 2) * 16 + lr;
+            for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bf[r] = vp[r * 16];
+                for (int m = 0; m < 2; ++m)
+                    am[kh][m] = u_s[((kh * 6 + x) * WN_CK + cs * 4 + lq) * WN_COUT_P + (wm * 2 + m) * 16 + lr];
+        };
+        read_group(0, bf[0], af[0]);
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
+        for (int g = 0; g < NG; ++g) {
+            const int x = g / (WN_CK / 4), cur = g & 1;
+            if (g + 1 < NG) read_group(g + 1, bf[cur ^ 1], af[cur ^ 1]);
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        af[kh][m] = u_s[((kh * 6 + x) * WN_CK + cs * 4 + lq) * WN_COUT_P + (wm * 2 + m) * 16 + lr];
+            for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
+                    for (int fl = 0; fl < 2; ++fl)
+                        acc[x][m][fl] = mfma16(af[cur][kh][m], bf[cur][fl + kh], acc[x][m][fl]);
+            // pin the interleave: 5 x {1 ds_read2, 2 MFMA} + 2 MFMA (the scheduler otherwise sinks every read to its use)
+            if (g + 1 < NG) {
 #pragma unroll
-                        for (int fl = 0; fl < 2; ++fl) acc[x][m][fl] = mfma16(af[kh][m], bf[fl + kh], acc[x][m][fl]);
+                for (int i = 0; i < 5; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
             }
         }
     }
