@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));   // raw_buffer_load_b128 result
 
 #define PBSED_OK 0
 #define PBSED_E_ARG (-1)

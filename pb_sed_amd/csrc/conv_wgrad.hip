@@ -373,67 +373,65 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(ConvWgradArgs a
 
     // this thread's x item: (cin ic, halo row ir, tile quad iq) and its 8 dY tiles q = tid + i*256 -> (cout, row, tile)
     const int iq = tid & 3, ir = (tid >> 2) & 3, ic = tid >> 4;
-    float4 ry[C::YQ_PER_T];
-    float rin[18];
-    int r_tq0 = 0, r_tlim = 0;
-    bool r_ok = false;
+    u32x4_t ry[C::YQ_PER_T];
+    unsigned ryi[C::YQ_PER_T];                       // pool-row bytes of the same tiles (unpool)
+    unsigned rin[18];
+    int r_ehi = 0;                                   // valid elements of the x item in flight: e < r_ehi (and e = 0: r_e0)
+    bool r_e0 = false;
+    int r_ylim = 4;                                  // valid elements of the dY tiles in flight (T % 4 != 0 only)
 
-    auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
-        int c = chunk;
-        const int t0 = (c % nTt) * C::TT; c /= nTt;
-        const int f0 = (c % nFt) * C::FT;
-        const int b = c / nFt;
+    // Chunk cursor (clip, row block, time block) of the chunk to load next, advanced by gridDim.x chunks per step with
+    // carries instead of divisions; every load is a raw buffer load on a clip-relative resource, so channels past the
+    // end, halo rows outside the plane and tiles past the row end read 0 without branches and the per-chunk address
+    // arithmetic is a handful of adds (VALU instructions are paid in fp32-MFMA time on gfx950).
+    int cb, cf, ct;
+    { int c = blockIdx.x; ct = c % nTt; c /= nTt; cf = c % nFt; cb = c / nFt; }
+    int sb, sf, st;
+    { int c = gridDim.x; st = c % nTt; c /= nTt; sf = c % nFt; sb = c / nFt; }
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned gclip = (unsigned)(a.Cout * Fg * a.T), xclip = (unsigned)(a.Cin * a.F * a.T);
+    const int ytile = tid & 15, yfl = (tid >> 4) & 1;
+    const unsigned gthr = (unsigned)(((cout0 + (tid >> 5)) * Fg + (unpool ? 0 : yfl)) * a.T + 4 * ytile);
+    const unsigned gstride = (unsigned)(8 * Fg * a.T);                       // cout + 8 per dY tile i
+    const int xthr = (((cin0 + ic) * a.F + ir - 1) * a.T + 16 * iq);
+    float sc = 1.f, sh = 0.f;
+    if (pro && cin0 + ic < a.Cin) { sc = a.scale[cin0 + ic]; sh = a.shift[cin0 + ic]; }
+
+    auto load_chunk = [&]() __attribute__((always_inline)) {
+        const int t0 = ct * C::TT, f0 = cf * C::FT, b = cb;
         const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.g) + (size_t)b * gclip, 0, gclip * 4u, 0x00020000);
+        const unsigned gch = (unsigned)((unpool ? (f0 >> 1) : f0) * a.T + t0);
+        const unsigned goff = (t0 + 4 * ytile < a.T) ? gthr + gch : OOB / 4u;  // element offset of dY tile 0 (x 4 below)
 #pragma unroll
-        for (int i = 0; i < C::YQ_PER_T; ++i) {
-            const int q = tid + i * C::NT;
-            const int tile = q & 15, fl = (q >> 4) & 1, cl = q >> 5;
-            const int cout = cout0 + cl, f = f0 + fl, tq = t0 + 4 * tile;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (cout < a.Cout && f < a.F && tq < a.T) {
-                const size_t o = ((size_t)(b * a.Cout + cout) * Fg + (unpool ? (f >> 1) : f)) * a.T + tq;
-                if (vec) {
-                    const float4 gv = *reinterpret_cast<const float4*>(a.g + o);
-                    v[0] = gv.x; v[1] = gv.y; v[2] = gv.z; v[3] = gv.w;
-                    if (unpool) {
-                        const uchar4 iv = *reinterpret_cast<const uchar4*>(a.unpool_idx + o);
-                        const int par = f & 1;
-                        v[0] = (iv.x == par) ? v[0] : 0.f; v[1] = (iv.y == par) ? v[1] : 0.f;
-                        v[2] = (iv.z == par) ? v[2] : 0.f; v[3] = (iv.w == par) ? v[3] : 0.f;
-                    }
-                } else {
+        for (int i = 0; i < C::YQ_PER_T; ++i)
+            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (goff + i * gstride) * 4u, 0, 0);
+        if (unpool) {
+            const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint8_t*>(a.unpool_idx) + (size_t)b * gclip, 0, gclip, 0x00020000);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (tq + e < a.T) {
-                            v[e] = a.g[o + e];
-                            if (unpool) v[e] = (a.unpool_idx[o + e] == (uint8_t)(f & 1)) ? v[e] : 0.f;
-                        }
-                }
-            }
-            ry[i] = make_float4(v[0], v[1], v[2], v[3]);
+            for (int i = 0; i < C::YQ_PER_T; ++i) ryi[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, goff + i * gstride, 0, 0);
         }
         // raw inputs t = tq0 - 1 .. tq0 + 16 of (cin, halo row); prologue / mask / transform happen in store_chunk
-        const int cin = cin0 + ic, f = f0 - 1 + ir, tq0 = t0 + 16 * iq;
-        r_tq0 = tq0; r_tlim = pro ? sl : a.T;
-        r_ok = cin < a.Cin && f >= 0 && f < a.F;
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.x) + (size_t)b * xclip, 0, xclip * 4u, 0x00020000);
+        const int f = f0 - 1 + ir, tq0 = t0 + 16 * iq;
+        const bool row_ok = f >= 0 && f < a.F;
+        const unsigned xoff = row_ok ? (unsigned)(xthr + f0 * a.T + t0) * 4u : OOB;
 #pragma unroll
-        for (int e = 0; e < 18; ++e) rin[e] = 0.f;
-        if (r_ok) {
-            const float* xp = a.x + ((size_t)(b * a.Cin + cin) * a.F + f) * a.T;
-            if (vec && tq0 + 16 <= a.T) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 xv = *reinterpret_cast<const float4*>(xp + tq0 + 4 * q);
-                    rin[1 + 4 * q] = xv.x; rin[2 + 4 * q] = xv.y; rin[3 + 4 * q] = xv.z; rin[4 + 4 * q] = xv.w;
-                }
-            } else {
-#pragma unroll
-                for (int e = 1; e < 17; ++e)
-                    if (tq0 - 1 + e < a.T) rin[e] = xp[tq0 - 1 + e];
-            }
-            if (tq0 - 1 >= 0 && tq0 - 1 < a.T) rin[0] = xp[tq0 - 1];
-            if (tq0 + 16 < a.T) rin[17] = xp[tq0 + 16];
+        for (int q = 0; q < 4; ++q) {
+            const u32x4_t xv = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff + q * 16, 0, 0);
+            rin[1 + 4 * q] = xv.x; rin[2 + 4 * q] = xv.y; rin[3 + 4 * q] = xv.z; rin[4 + 4 * q] = xv.w;
         }
+        rin[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, xoff - 4u, 0, 0);
+        rin[17] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, xoff + 64u, 0, 0);
+        r_ehi = row_ok ? max((pro ? sl : a.T) - tq0 + 1, 0) : 0;
+        r_e0 = tq0 > 0 && r_ehi > 0;
+        r_ylim = a.T - (t0 + 4 * ytile);
+        ct += st; if (ct >= nTt) { ct -= nTt; ++cf; }
+        cf += sf; if (cf >= nFt) { cf -= nFt; ++cb; }
+        cb += sb;
     };
     auto store_chunk = [&]() __attribute__((always_inline)) {
         // A dy: one tile (float4) -> 6 points
@@ -441,7 +439,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(ConvWgradArgs a
         for (int i = 0; i < C::YQ_PER_T; ++i) {
             const int q = tid + i * C::NT;
             const int pos = q & 31, cl = q >> 5;            // pos = fl*16 + tile
-            const float y0 = ry[i].x, y1 = ry[i].y, y2 = ry[i].z, y3 = ry[i].w;
+            float y0 = __uint_as_float(ry[i].x), y1 = __uint_as_float(ry[i].y), y2 = __uint_as_float(ry[i].z),
+                  y3 = __uint_as_float(ry[i].w);
+            if (!vec) { y1 = r_ylim > 1 ? y1 : 0.f; y2 = r_ylim > 2 ? y2 : 0.f; y3 = r_ylim > 3 ? y3 : 0.f; }
+            if (unpool) {                            // tile row f0 + yfl: keep the elements whose window maximum was this row
+                const unsigned iv = ryi[i];
+                y0 = (int)(iv & 0xffu) == yfl ? y0 : 0.f; y1 = (int)((iv >> 8) & 0xffu) == yfl ? y1 : 0.f;
+                y2 = (int)((iv >> 16) & 0xffu) == yfl ? y2 : 0.f; y3 = (int)(iv >> 24) == yfl ? y3 : 0.f;
+            }
             const float e02 = y0 + y2, o13 = y1 + y3, e04 = y0 + 4.f * y2, o28 = 2.f * y1 + 8.f * y3;
             float* d = p_s + cl * C::PLANE_P + pos;
             d[0 * C::COUT_T * C::PLANE_P] = y0;
@@ -453,17 +458,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(ConvWgradArgs a
         }
         // B^T d of prologue(x)
         float dv[18];
-        float sc = 1.f, sh = 0.f;
-        if (pro && r_ok) { sc = a.scale[cin0 + ic]; sh = a.shift[cin0 + ic]; }
 #pragma unroll
         for (int e = 0; e < 18; ++e) {
-            float u = rin[e];
+            float u = __uint_as_float(rin[e]);
             if (pro) {
                 u = fmaf(u, sc, sh);
                 if (a.relu) u = fmaxf(u, 0.f);
             }
-            const int t = r_tq0 - 1 + e;
-            dv[e] = (r_ok && t >= 0 && t < r_tlim) ? u : 0.f;
+            dv[e] = (e == 0 ? r_e0 : e < r_ehi) ? u : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -480,12 +482,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(ConvWgradArgs a
     };
 
     int chunk = blockIdx.x;
-    if (chunk < nChunks) load_chunk(chunk);
+    if (chunk < nChunks) load_chunk();
     for (; chunk < nChunks; chunk += gridDim.x) {
         __syncthreads();
         store_chunk();
         __syncthreads();
-        if (chunk + (int)gridDim.x < nChunks) load_chunk(chunk + gridDim.x);
+        if (chunk + (int)gridDim.x < nChunks) load_chunk();
 #pragma unroll
         for (int kk = 0; kk < C::TILES / 4; ++kk) {
 #pragma unroll

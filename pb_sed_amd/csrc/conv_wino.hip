@@ -33,7 +33,6 @@ constexpr int WN_V_FLOATS = 6 * WN_CK * WN_PLANE_V;
 constexpr int WN_U_FLOATS = 18 * WN_CK * WN_COUT_P;
 constexpr int WN_U_VEC = 18 * WN_CK * WN_CT / 4;       // float4 per U stage
 constexpr int WN_U_PER_T = (WN_U_VEC + 255) / 256;
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 template <bool POOL>
 struct WinoCfg {

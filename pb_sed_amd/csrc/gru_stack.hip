@@ -274,7 +274,6 @@ typedef unsigned int __attribute__((address_space(1))) gu32;
 // bytes of {tag, value} granules: the polls (16 KB per workgroup and step instead of 32) are what loads the fabric.
 // W fragments stay in registers for all T steps, the previous state of a thread's own unit too.
 // ============================================================================================
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float tag_clear(float v) { return __uint_as_float(__float_as_uint(v) & ~1u); }
 __device__ __forceinline__ void publish(gu32* p, float v_cleared, unsigned parity) {
