@@ -41,7 +41,7 @@ struct ConvFwdCfg {
     static constexpr int W_VEC = KK * CK * COUT_T / 4;
     static constexpr int W_PER_T = (W_VEC + 255) / 256;
     static constexpr int FO_T = POOL ? FT / 2 : FT;
-    static constexpr int LDS_FLOATS = CK * PLANE + KK * CK * COUT_P + COUT_T * FO_T * 2;
+    static constexpr int LDS_FLOATS = CK * PLANE + KK * CK * COUT_P + WN * COUT_T * FO_T * 2;
     static_assert(TT16 % WN == 0, "t tiles must split over waves");
     static_assert(!POOL || FT % 2 == 0, "pool needs row pairs");
     static_assert(CK % 4 == 0 && COUT_T % 16 == 0, "tile granularity");
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* in_s = smem;                               // [CK][PLANE]
     float* w_s = smem + CK * C::PLANE;                // [KK][CK][COUT_P]
-    float* st_s = w_s + C::KK * CK * C::COUT_P;       // [COUT_T][FO_T][2]
+    float* st_s = w_s + C::KK * CK * C::COUT_P;       // [WN][COUT_T][FO_T][2]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WN, wn = wave % C::WN;
@@ -75,116 +75,123 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
 #pragma unroll
         for (int n = 0; n < C::NTW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- input staging: each thread owns IN_PER_T aligned float4 quads of the halo tile; their
-    // (channel, row, column) decomposition is fixed across channel chunks, so offsets are hoisted.
-    float4 rin[C::IN_PER_T];
-    float4 rw[C::W_PER_T];
-    int q_off[C::IN_PER_T], q_lds[C::IN_PER_T], q_t[C::IN_PER_T], q_c[C::IN_PER_T];
+    // ---- input staging: each thread owns IN_PER_T aligned float4 quads of the halo tile; their (channel, row,
+    // column) decomposition is fixed across channel chunks.  Loads are raw buffer loads on clip-relative resources
+    // with one 32-bit offset per quad, advanced by a uniform step per chunk: halo rows outside the plane, quads
+    // outside the row and padded channels read 0 without branches (fp32 MFMAs and VALU instructions share the
+    // SIMD's fp32 pipe on gfx950, so address arithmetic and predication are paid in MFMA time).  load_chunk only
+    // issues loads; prologue and masks run in store_chunk, after the MFMAs of the previous chunk.
+    u32x4_t rin[C::IN_PER_T];
+    unsigned ridx[C::IN_PER_T], rsc[C::IN_PER_T], rsh[C::IN_PER_T];
+    u32x4_t rw[C::W_PER_T];
+    unsigned q_voff[C::IN_PER_T], q_cv[C::IN_PER_T], w_voff[C::W_PER_T];
+    int q_lds[C::IN_PER_T], q_m[C::IN_PER_T];        // q_m: valid elements of the quad (e < q_m & 7), bit 8 = pool-row parity
     const bool unpool = DGRAD && a.unpool_idx != nullptr;
     const int Fsrc = unpool ? a.F / 2 : a.F;
+    const int tlim = pro ? sl : a.T;                 // Normalization re-masks its output (y*mask)
     const bool vec = (a.T & 3) == 0;
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned clip_elems = (unsigned)(a.Cin * Fsrc * a.T);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x) + (size_t)b * clip_elems, 0, clip_elems * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
+        unpool ? const_cast<uint8_t*>(a.unpool_idx) + (size_t)b * clip_elems : nullptr, 0, unpool ? clip_elems : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.wp), 0, (unsigned)(C::KK * a.CinP * a.CoutP) * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.scale), 0, pro ? (unsigned)a.Cin * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.shift), 0, pro ? (unsigned)a.Cin * 4u : 0u, 0x00020000);
+    const unsigned step_x = (unsigned)(CK * Fsrc * a.T) * 4u, step_w = (unsigned)(CK * a.CoutP) * 4u;
 #pragma unroll
     for (int i = 0; i < C::IN_PER_T; ++i) {
         const int q = tid + i * 256;
         const int c = q / (C::ROWS * C::QR), rem = q - c * (C::ROWS * C::QR);
         const int r = rem / C::QR, qc = rem - r * C::QR;
         const int f = f0 - PADH + r, tq = t0 - C::HALO + 4 * qc;
-        const bool ok = q < C::IN_Q && f >= 0 && f < a.F && tq + 3 >= 0 && tq < a.T;
-        q_c[i] = ok ? c : -1;
-        q_t[i] = tq;
+        const bool ok = q < C::IN_Q && f >= 0 && f < a.F && tq >= 0 && tq < a.T;
         q_lds[i] = c * C::PLANE + r * C::ROW + 4 * qc;
-        q_off[i] = (c * Fsrc + (unpool ? (f >> 1) : f)) * a.T + tq;
-        if (unpool && (f & 1)) q_t[i] |= (1 << 30);       // row parity for the argmax test
+        q_voff[i] = ok ? (unsigned)((c * Fsrc + (unpool ? (f >> 1) : f)) * a.T + tq) * 4u : OOB;
+        q_cv[i] = ok ? (unsigned)c * 4u : OOB;
+        q_m[i] = (ok ? min(max(tlim - tq, 0), 4) : 0) | ((f & 1) << 8);
+    }
+#pragma unroll
+    for (int i = 0; i < C::W_PER_T; ++i) {
+        const int idx = tid + i * 256;
+        const int q = idx % (COUT_T / 4), c = (idx / (COUT_T / 4)) % CK, kk = idx / (COUT_T / 4) / CK;
+        w_voff[i] = idx < C::W_VEC ? (unsigned)((kk * a.CinP + c) * a.CoutP + cout0 + q * 4) * 4u : OOB;
     }
 
-    auto load_chunk = [&](int c0) {
-        const float* xb = a.x + (size_t)(b * a.Cin + c0) * Fsrc * a.T;
-        const uint8_t* ib = unpool ? a.unpool_idx + (size_t)(b * a.Cin + c0) * Fsrc * a.T : nullptr;
-        const int tlim = pro ? sl : a.T;       // Normalization re-masks its output (y*mask)
+    auto load_chunk = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < C::IN_PER_T; ++i) {
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            const int cin = c0 + q_c[i];
-            if (q_c[i] >= 0 && cin < a.Cin) {
-                const int tq = q_t[i] & ~(1 << 30);
-                const int par = (q_t[i] >> 30) & 1;
-                if (vec && tq >= 0 && tq + 4 <= a.T) {
-                    const float4 xv = *reinterpret_cast<const float4*>(xb + q_off[i]);
-                    v[0] = xv.x; v[1] = xv.y; v[2] = xv.z; v[3] = xv.w;
-                    if (unpool) {
-                        const uchar4 iv = *reinterpret_cast<const uchar4*>(ib + q_off[i]);
-                        v[0] = (iv.x == par) ? v[0] : 0.f; v[1] = (iv.y == par) ? v[1] : 0.f;
-                        v[2] = (iv.z == par) ? v[2] : 0.f; v[3] = (iv.w == par) ? v[3] : 0.f;
-                    }
-                } else {
+            rin[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, q_voff[i], 0, 0);
+            if (unpool) {
+                if (vec) {
+                    ridx[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, q_voff[i] >> 2, 0, 0);
+                } else {                             // a dword straddling the end of the clip would read 0 as a whole
+                    unsigned w = 0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int t = tq + e;
-                        if (t >= 0 && t < a.T) {
-                            v[e] = xb[q_off[i] + e];
-                            if (unpool) v[e] = (ib[q_off[i] + e] == par) ? v[e] : 0.f;
-                        }
-                    }
-                }
-                if (pro) {
-                    const float sc = a.scale[cin], sh = a.shift[cin];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float u = fmaf(v[e], sc, sh);
-                        if (a.relu) u = fmaxf(u, 0.f);
-                        v[e] = u;
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int t = tq + e;
-                    v[e] = (t >= 0 && t < tlim) ? v[e] : 0.f;     // zero padding is post-activation
+                    for (int e = 0; e < 4; ++e)
+                        w |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_i, (q_voff[i] >> 2) + e, 0, 0) << (8 * e);
+                    ridx[i] = w;
                 }
             }
-            rin[i] = make_float4(v[0], v[1], v[2], v[3]);
+            if (pro) {
+                rsc[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_sc, q_cv[i], 0, 0);
+                rsh[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_sh, q_cv[i], 0, 0);
+            }
+            q_voff[i] += step_x; q_cv[i] += CK * 4u;
         }
 #pragma unroll
         for (int i = 0; i < C::W_PER_T; ++i) {
-            const int idx = tid + i * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < C::W_VEC) {
-                const int q = idx % (COUT_T / 4);
-                const int c = (idx / (COUT_T / 4)) % CK;
-                const int kk = idx / (COUT_T / 4) / CK;
-                v = *reinterpret_cast<const float4*>(
-                    a.wp + ((size_t)kk * a.CinP + c0 + c) * a.CoutP + cout0 + q * 4);
-            }
-            rw[i] = v;
+            rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_voff[i], 0, 0);
+            w_voff[i] += step_w;
         }
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < C::IN_PER_T; ++i)
-            if (tid + i * 256 < C::IN_Q) *reinterpret_cast<float4*>(in_s + q_lds[i]) = rin[i];
+        for (int i = 0; i < C::IN_PER_T; ++i) {
+            float v[4] = {__uint_as_float(rin[i].x), __uint_as_float(rin[i].y), __uint_as_float(rin[i].z), __uint_as_float(rin[i].w)};
+            const int n_ok = q_m[i] & 7;
+            if (unpool) {
+                const int par = q_m[i] >> 8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (int)((ridx[i] >> (8 * e)) & 0xffu) == par ? v[e] : 0.f;
+            }
+            if (pro) {
+                const float sc = __uint_as_float(rsc[i]), sh = __uint_as_float(rsh[i]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaf(v[e], sc, sh);
+                    if (a.relu) v[e] = fmaxf(v[e], 0.f);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = e < n_ok ? v[e] : 0.f;          // zero padding is post-activation
+            if (tid + i * 256 < C::IN_Q) *reinterpret_cast<float4*>(in_s + q_lds[i]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
 #pragma unroll
         for (int i = 0; i < C::W_PER_T; ++i) {
             const int idx = tid + i * 256;
             if (idx < C::W_VEC) {
                 const int q = idx % (COUT_T / 4);
                 const int ck = idx / (COUT_T / 4);   // kk*CK + c
-                *reinterpret_cast<float4*>(w_s + ck * C::COUT_P + q * 4) = rw[i];
+                *reinterpret_cast<u32x4_t*>(w_s + ck * C::COUT_P + q * 4) = rw[i];
             }
         }
     };
 
-    if (tid < COUT_T * C::FO_T * 2) st_s[tid] = 0.f;
-    if (COUT_T * C::FO_T * 2 > 256)
-        for (int i = tid + 256; i < COUT_T * C::FO_T * 2; i += 256) st_s[i] = 0.f;
 
     // the data-gradient instances gain ~4 % from exposing three taps to the scheduler, the forward ones lose occupancy
     constexpr int KK_UNROLL = (DGRAD && COUT_T != 32) ? 3 : 1;
     const int nChunks = a.CinP / CK;
-    load_chunk(0);
+    load_chunk();
     for (int ch = 0; ch < nChunks; ++ch) {
         __syncthreads();            // previous chunk's MFMA reads are done
         store_chunk();
         __syncthreads();
-        if (ch + 1 < nChunks) load_chunk((ch + 1) * CK);   // in flight during the MFMAs below
+        if (ch + 1 < nChunks) load_chunk();                // in flight during the MFMAs below
 #pragma unroll KK_UNROLL
         for (int kk = 0; kk < C::KK; ++kk) {
             const int kh = kk / KW, kw = kk % KW;
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         }
     }
 
-    conv_epilogue<COUT_T, FT, TT, C::MTW, C::NTT, POOL, DGRAD>(a, acc, st_s, b, f0, t0, cout0, sl, wm, wn, lq, lr, tid);
+    conv_epilogue<COUT_T, FT, TT, C::MTW, C::NTT, C::WN, POOL, DGRAD>(a, acc, st_s, b, f0, t0, cout0, sl, wm, wn, lq, lr, tid);
 }
 
 template <int COUT_T, int FT, int TT, int KH, int KW, int CK, bool POOL, bool DGRAD>

@@ -56,7 +56,7 @@ struct ConvBCfg {
     static constexpr int W_ITEMS = KW * CB_COUT_T * (CB_CK / 8), W_PER_T = (W_ITEMS + 255) / 256;
     static constexpr int IN_HALFS = NSPLIT * ROWS * ROW * CB_CKP, W_HALFS = NSPLIT * KW * CB_COUT_T * CB_CKP;
     static constexpr int FO_T = POOL ? FT / 2 : FT;
-    static constexpr size_t LDS_BYTES = (size_t)(IN_HALFS + W_HALFS) * 2 + CB_COUT_T * FO_T * 2 * sizeof(float);
+    static constexpr size_t LDS_BYTES = (size_t)(IN_HALFS + W_HALFS) * 2 + WN * CB_COUT_T * FO_T * 2 * sizeof(float);
     static_assert(TT16 % WN == 0 && (IN_HALFS % 8) == 0 && (W_HALFS % 8) == 0, "tile granularity");
 };
 
@@ -89,7 +89,6 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvFwdArgs a, const uns
     for (int m = 0; m < C::MTW; ++m)
 #pragma unroll
         for (int n = 0; n < C::NTW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < CB_COUT_T * C::FO_T * 2; i += 256) st_s[i] = 0.f;
 
     for (int c0 = 0; c0 < a.CinP; c0 += CB_CK) {
         __syncthreads();                       // all MFMA reads of the previous chunk are done
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvFwdArgs a, const uns
             }
         }
     }
-    conv_epilogue<CB_COUT_T, FT, TT, C::MTW, C::NTT, POOL, DGRAD>(a, acc, st_s, b, f0, t0, cout0, sl, wm, wn, lq, lr, tid);
+    conv_epilogue<CB_COUT_T, FT, TT, C::MTW, C::NTT, C::WN, POOL, DGRAD>(a, acc, st_s, b, f0, t0, cout0, sl, wm, wn, lq, lr, tid);
 }
 
 // w [Cout][Cin][KH][KW] fp32 -> bf16 splits [split][tap][CoutP][CinP]; dgrad: roles swapped + taps flipped.

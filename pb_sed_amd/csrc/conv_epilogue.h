@@ -8,7 +8,9 @@
 
 namespace pbsed {
 
-template <int COUT_T, int FT, int TT, int MTW, int NTT, bool POOL, bool DGRAD>
+// st_s: [WN][COUT_T][FO_T][2] floats, WN = waves along t; every (wave column, channel, row) entry is written by exactly
+// one lane and the columns are summed in a fixed order, so a block's partial statistics do not depend on wave timing.
+template <int COUT_T, int FT, int TT, int MTW, int NTT, int WN, bool POOL, bool DGRAD>
 __device__ __forceinline__ void conv_epilogue(const ConvFwdArgs& a, f32x4 (&acc)[MTW][FT * NTT], float* st_s, int b,
                                               int f0, int t0, int cout0, int sl, int wm, int wn, int lq, int lr,
                                               int tid) {
@@ -79,8 +81,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvFwdArgs& a, f32x4 (&acc)
                     s1 = wave_sum16(s1);
                     s2 = wave_sum16(s2);
                     if (lr == 0) {
-                        atomicAdd(&st_s[(cl * FO_T + fo_l) * 2 + 0], s1);
-                        atomicAdd(&st_s[(cl * FO_T + fo_l) * 2 + 1], s2);
+                        st_s[((wn * COUT_T + cl) * FO_T + fo_l) * 2 + 0] = s1;
+                        st_s[((wn * COUT_T + cl) * FO_T + fo_l) * 2 + 1] = s2;
                     }
                 }
             }
@@ -95,8 +97,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvFwdArgs& a, f32x4 (&acc)
             for (int i = tid; i < COUT_T * FO_T * 2; i += 256) {
                 const int which = i & 1, fo_l = (i >> 1) % FO_T, cl = (i >> 1) / FO_T;
                 const int cout = cout0 + cl, fo = (POOL ? f0 / 2 : f0) + fo_l;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) v += st_s[w * COUT_T * FO_T * 2 + i];
                 if (cout < a.Cout && fo < Fo_)
-                    atomicAdd(&a.stats[((size_t)slot * a.Cout * Fo_ + cout * Fo_ + fo) * 2 + which], (double)st_s[i]);
+                    atomicAdd(&a.stats[((size_t)slot * a.Cout * Fo_ + cout * Fo_ + fo) * 2 + which], (double)v);
             }
         } else {
             // per-channel statistics: the block's rows are summed first, one atomic per (channel, moment)
@@ -104,7 +109,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvFwdArgs& a, f32x4 (&acc)
                 const int which = i & 1, cl = i >> 1, cout = cout0 + cl;
                 float v = 0.f;
 #pragma unroll
-                for (int fo_l = 0; fo_l < FO_T; ++fo_l) v += st_s[(cl * FO_T + fo_l) * 2 + which];
+                for (int w = 0; w < WN; ++w)
+#pragma unroll
+                    for (int fo_l = 0; fo_l < FO_T; ++fo_l) v += st_s[((w * COUT_T + cl) * FO_T + fo_l) * 2 + which];
                 if (cout < a.Cout) atomicAdd(&a.stats[((size_t)slot * a.Cout + cout) * 2 + which], (double)v);
             }
         }

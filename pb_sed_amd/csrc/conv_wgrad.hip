@@ -411,7 +411,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(ConvWgradArgs a
             const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<uint8_t*>(a.unpool_idx) + (size_t)b * gclip, 0, gclip, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < C::YQ_PER_T; ++i) ryi[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, goff + i * gstride, 0, 0);
+            for (int i = 0; i < C::YQ_PER_T; ++i) {
+                if (vec) {
+                    ryi[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, goff + i * gstride, 0, 0);
+                } else {                             // a dword straddling the end of the clip would read 0 as a whole
+                    unsigned w = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        w |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_i, goff + i * gstride + e, 0, 0) << (8 * e);
+                    ryi[i] = w;
+                }
+            }
         }
         // raw inputs t = tq0 - 1 .. tq0 + 16 of (cin, halo row); prologue / mask / transform happen in store_chunk
         const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
