@@ -74,86 +74,104 @@ void conv_wgrad_kernel(ConvWgradArgs a) {
         for (int i = 0; i < C::NACC; ++i) acc[m][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    float4 ry[C::Y_PER_T], ra[C::A_PER_T];
+    // Loads are raw buffer loads on clip-relative resources (channels past the end read 0 without a branch) with
+    // per-quad element offsets hoisted out of the chunk loop; the chunk cursor advances with carries instead of
+    // divisions; prologue and masks run in store_chunk (fp32 MFMAs and VALU share the SIMD's fp32 pipe on gfx950,
+    // so every address / predicate instruction is paid in MFMA time, and load_chunk must not wait on its loads).
+    u32x4_t ry[C::Y_PER_T], ra[C::A_PER_T];
+    unsigned ryi[C::Y_PER_T];                        // pool-row bytes of the dY quads (unpool)
+    int y_thr[C::Y_PER_T], y_fq[C::Y_PER_T];         // element offset inside the clip; (fl << 8) | qc
+    int a_thr[C::A_PER_T], a_rq[C::A_PER_T];         // element offset inside the clip; (r << 8) | qc
+    float a_sc[C::A_PER_T], a_sh[C::A_PER_T];
+    int r_ym[C::Y_PER_T], r_am[C::A_PER_T];          // per chunk in flight: valid elements of the quad (| parity << 8)
+    constexpr unsigned OOB = 0x20000000u;            // element offset beyond every clip (x 4 = 2^31 bytes)
+    const unsigned gclip = (unsigned)(a.Cout * Fg * a.T), xclip = (unsigned)(a.Cin * a.F * a.T);
+#pragma unroll
+    for (int i = 0; i < C::Y_PER_T; ++i) {
+        const int q = tid + i * NT;
+        const int cl = q / (FT * (TT / 4)), rem = q % (FT * (TT / 4));
+        const int fl = rem / (TT / 4), qc = rem % (TT / 4);
+        y_thr[i] = q < C::YQ ? ((cout0 + cl) * Fg + (unpool ? (fl >> 1) : fl)) * a.T + 4 * qc : (int)OOB;
+        y_fq[i] = (fl << 8) | qc;
+    }
+#pragma unroll
+    for (int i = 0; i < C::A_PER_T; ++i) {
+        const int q = tid + i * NT;
+        const int cl = q / (C::ROWS * C::QR), rem = q % (C::ROWS * C::QR);
+        const int r = rem / C::QR, qc = rem % C::QR;
+        const int cin = cin0 + cl;
+        const bool ok = q < C::AQ && cin < a.Cin;
+        a_thr[i] = ok ? (cin * a.F + r - PADH) * a.T + 4 * qc - C::HALO : (int)OOB;
+        a_rq[i] = (r << 8) | qc;
+        a_sc[i] = (pro && ok) ? a.scale[cin] : 0.f;
+        a_sh[i] = (pro && ok) ? a.shift[cin] : 0.f;
+    }
+    int cb, cf, ct, sb, sf, st;                      // chunk to load next and the stride of gridDim.x chunks
+    { int c = blockIdx.x; ct = c % nTt; c /= nTt; cf = c % nFt; cb = c / nFt; }
+    { int c = gridDim.x; st = c % nTt; c /= nTt; sf = c % nFt; sb = c / nFt; }
 
-    auto load_chunk = [&](int chunk) {
-        int c = chunk;
-        const int t0 = (c % nTt) * TT; c /= nTt;
-        const int f0 = (c % nFt) * FT;
-        const int b = c / nFt;
+    auto load_chunk = [&]() __attribute__((always_inline)) {
+        const int t0 = ct * TT, f0 = cf * FT, b = cb;
         const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
-        // ---- dY tile (un-pooled through the argmax byte)
+        const int tlim = pro ? sl : a.T;
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.g) + (size_t)b * gclip, 0, gclip * 4u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
+            unpool ? const_cast<uint8_t*>(a.unpool_idx) + (size_t)b * gclip : nullptr, 0, unpool ? gclip : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.x) + (size_t)b * xclip, 0, xclip * 4u, 0x00020000);
+        const int gch = (unpool ? (f0 >> 1) : f0) * a.T + t0, xch = f0 * a.T + t0;
+        // ---- dY tile (un-pooled through the argmax byte in store_chunk)
 #pragma unroll
         for (int i = 0; i < C::Y_PER_T; ++i) {
-            const int q = tid + i * NT;
-            const int cl = q / (FT * (TT / 4)), rem = q % (FT * (TT / 4));
-            const int fl = rem / (TT / 4), qc = rem % (TT / 4);
-            const int cout = cout0 + cl, f = f0 + fl, tq = t0 + 4 * qc;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (q < C::YQ && cout < a.Cout && f < a.F && tq < a.T) {
-                const size_t o = ((size_t)(b * a.Cout + cout) * Fg + (unpool ? (f >> 1) : f)) * a.T + tq;
+            const int fl = y_fq[i] >> 8, tq = t0 + 4 * (y_fq[i] & 0xff);
+            const bool ok = f0 + fl < a.F && tq < a.T;
+            const unsigned off = ok ? (unsigned)(y_thr[i] + gch) : OOB;
+            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, off * 4u, 0, 0);
+            if (unpool) {
                 if (vec) {
-                    const float4 gv = *reinterpret_cast<const float4*>(a.g + o);
-                    v[0] = gv.x; v[1] = gv.y; v[2] = gv.z; v[3] = gv.w;
-                    if (unpool) {
-                        const uchar4 iv = *reinterpret_cast<const uchar4*>(a.unpool_idx + o);
-                        const int par = f & 1;
-                        v[0] = (iv.x == par) ? v[0] : 0.f; v[1] = (iv.y == par) ? v[1] : 0.f;
-                        v[2] = (iv.z == par) ? v[2] : 0.f; v[3] = (iv.w == par) ? v[3] : 0.f;
-                    }
-                } else {
+                    ryi[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, off, 0, 0);
+                } else {                             // a dword straddling the end of the clip would read 0 as a whole
+                    unsigned w = 0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (tq + e < a.T) {
-                            v[e] = a.g[o + e];
-                            if (unpool) v[e] = (a.unpool_idx[o + e] == (uint8_t)(f & 1)) ? v[e] : 0.f;
-                        }
+                    for (int e = 0; e < 4; ++e) w |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_i, off + e, 0, 0) << (8 * e);
+                    ryi[i] = w;
                 }
             }
-            ry[i] = make_float4(v[0], v[1], v[2], v[3]);
+            r_ym[i] = (ok ? min(a.T - tq, 4) : 0) | (((f0 + fl) & 1) << 8);
         }
-        // ---- a tile = prologue(x) with halo, zero padding post-activation
-        const int tlim = pro ? sl : a.T;
+        // ---- a tile = x with halo; prologue, zero padding (post-activation) and masks in store_chunk
 #pragma unroll
         for (int i = 0; i < C::A_PER_T; ++i) {
-            const int q = tid + i * NT;
-            const int cl = q / (C::ROWS * C::QR), rem = q % (C::ROWS * C::QR);
-            const int r = rem / C::QR, qc = rem % C::QR;
-            const int cin = cin0 + cl, f = f0 - PADH + r, tq = t0 - C::HALO + 4 * qc;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (q < C::AQ && cin < a.Cin && f >= 0 && f < a.F && tq + 3 >= 0 && tq < a.T) {
-                const float* xp = a.x + ((size_t)(b * a.Cin + cin) * a.F + f) * a.T;
-                if (vec && tq >= 0) {
-                    const float4 xv = *reinterpret_cast<const float4*>(xp + tq);
-                    v[0] = xv.x; v[1] = xv.y; v[2] = xv.z; v[3] = xv.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (tq + e >= 0 && tq + e < a.T) v[e] = xp[tq + e];
-                }
-                if (pro) {
-                    const float sc = a.scale[cin], sh = a.shift[cin];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float u = fmaf(v[e], sc, sh);
-                        if (a.relu) u = fmaxf(u, 0.f);
-                        v[e] = u;
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (tq + e >= 0 && tq + e < tlim) ? v[e] : 0.f;
-            }
-            ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+            const int f = f0 - PADH + (a_rq[i] >> 8), tq = t0 - C::HALO + 4 * (a_rq[i] & 0xff);
+            const bool ok = f >= 0 && f < a.F && tq >= 0 && tq < a.T;
+            const unsigned off = ok ? (unsigned)(a_thr[i] + xch) : OOB;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off * 4u, 0, 0);
+            r_am[i] = ok ? min(max(tlim - tq, 0), 4) : 0;
         }
+        ct += st; if (ct >= nTt) { ct -= nTt; ++cf; }
+        cf += sf; if (cf >= nFt) { cf -= nFt; ++cb; }
+        cb += sb;
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < C::Y_PER_T; ++i) {
             const int q = tid + i * NT;
             if (q < C::YQ) {
                 const int cl = q / (FT * (TT / 4)), rem = q % (FT * (TT / 4));
+                float v[4] = {__uint_as_float(ry[i].x), __uint_as_float(ry[i].y), __uint_as_float(ry[i].z), __uint_as_float(ry[i].w)};
+                const int n_ok = r_ym[i] & 7;
+                if (!vec) {
+#pragma unroll
+                    for (int e = 1; e < 4; ++e) v[e] = e < n_ok ? v[e] : 0.f;
+                }
+                if (unpool) {
+                    const int par = r_ym[i] >> 8;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (int)((ryi[i] >> (8 * e)) & 0xffu) == par ? v[e] : 0.f;
+                }
                 float* d = dy_s + cl * C::PLANE_Y + rem * 4;
-                d[0] = ry[i].x; d[1] = ry[i].y; d[2] = ry[i].z; d[3] = ry[i].w;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
             }
         }
 #pragma unroll
@@ -161,19 +179,29 @@ void conv_wgrad_kernel(ConvWgradArgs a) {
             const int q = tid + i * NT;
             if (q < C::AQ) {
                 const int cl = q / (C::ROWS * C::QR), rem = q % (C::ROWS * C::QR);
+                float v[4] = {__uint_as_float(ra[i].x), __uint_as_float(ra[i].y), __uint_as_float(ra[i].z), __uint_as_float(ra[i].w)};
+                if (pro) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = fmaf(v[e], a_sc[i], a_sh[i]);
+                        if (a.relu) v[e] = fmaxf(v[e], 0.f);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = e < r_am[i] ? v[e] : 0.f;
                 float* d = a_s + cl * C::PLANE_A + rem * 4;
-                d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
             }
         }
     };
 
     int chunk = blockIdx.x;
-    if (chunk < nChunks) load_chunk(chunk);
+    if (chunk < nChunks) load_chunk();
     for (; chunk < nChunks; chunk += gridDim.x) {
         __syncthreads();
         store_chunk();
         __syncthreads();
-        if (chunk + (int)gridDim.x < nChunks) load_chunk(chunk + gridDim.x);
+        if (chunk + (int)gridDim.x < nChunks) load_chunk();
 #pragma unroll
         for (int fl = 0; fl < FT; ++fl) {
 #pragma unroll 2
