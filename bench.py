@@ -205,9 +205,13 @@ def main():
                          'traffic_source': pmc_traffic(f'{dname} {dtag}')[1],
                          'kernel': f'{dname} {dtag}', 'avg_ms': round(avg_ms, 4), 'launches': cnt,
                          'flops_per_launch': flops,
+                         # MFMA instructions actually issued: Winograd F(4,3) executes half the direct convolution's MACs
+                         'achieved_executed': round(achieved / (2 if dtag.endswith('wino') else 1), 2),
+                         'frac_executed': round(achieved / (2 if dtag.endswith('wino') else 1) / PEAK_FP32_MFMA_TFLOPS, 4),
                          'note': ('algorithmic FLOPs = 2*MACs of the direct 3x3 convolution; this launch runs the '
                                   'Winograd-F(4,3) kernel, which executes half of those multiplications on the MFMA '
-                                  f'pipe ({achieved / 2:.1f} TFLOP/s executed)') if dtag.endswith('wino') else
+                                  f'pipe ({achieved / 2:.1f} TFLOP/s executed): frac = algorithmic / peak can exceed 1, frac_executed is the '
+                                  'MFMA-pipe utilisation') if dtag.endswith('wino') else
                                  'algorithmic FLOPs = 2*MACs, all executed on the MFMA pipe'},
             'step_mfma': {'algorithmic_tflop_per_step': round(TRAIN_GFLOP_PER_CLIP * args.batch / 1e3, 4),
                           'achieved_tflops_per_gpu': round(TRAIN_GFLOP_PER_CLIP * args.batch / 1e3 / (ms_step * 1e-3), 2),

@@ -391,3 +391,34 @@ def test_fbcrnn_training_augmentation_in_the_loop():
     rev = model.review(inputs, out)
     rev['loss'].backward()
     assert np.isfinite(rev['loss'].item())
+
+
+def test_fbcrnn_forward_is_reproducible():
+    """Same batch, same state, several runs: scores are bitwise identical (block-level BN statistics are summed in a
+    fixed order, the cross-block sums are f64) and the flat gradient agrees to fp32-atomics noise."""
+    from pb_sed_amd.models import weak_label
+    torch.manual_seed(0)
+    model = weak_label.CRNN.build(num_events=10).to(DEV).train()
+    wav, seq, weak, bnd, t = synth_batch(16, 160000, 10, ragged=True)
+    order = np.argsort(-seq, kind='stable')
+    wav, seq, weak, bnd = wav[order], seq[order], weak[order], bnd[order]
+    inputs = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV),
+              'boundary_targets': bnd.to(DEV)}
+
+    def run():
+        _, flat_grad = model.flat_parameters()
+        flat_grad.zero_()
+        for m_ in model.modules():
+            if hasattr(m_, 'running_mean'):
+                m_.running_mean.zero_(), m_.running_power.fill_(1.)
+        out = model(dict(inputs))
+        rev = model.review(inputs, out)
+        rev['loss'].backward()
+        torch.cuda.synchronize()
+        return out[0].detach().clone(), out[1].detach().clone(), flat_grad.detach().clone()
+
+    y_f, y_b, grad = run()
+    for _ in range(4):
+        y_f2, y_b2, grad2 = run()
+        assert torch.equal(y_f2, y_f) and torch.equal(y_b2, y_b)
+        assert ((grad2 - grad).norm() / grad.norm()).item() < 2e-5
