@@ -92,6 +92,13 @@ class CRNN(SoundEventModel):
         y = _NetFunction.apply(self, x, tag, seq_host, seq_dev, training, *self._net_params)
         return y, seq_host, x, seq_host, targets
 
+    def modify_summary(self, summary):
+        """Called by the trainer before dumping a summary (reference models/strong_label/crnn.py modify_summary): metrics
+        from the validation buffers, then the base class' scalar means / image grid."""
+        if 'targets_strong' in summary['buffers']:
+            self.add_metrics_to_summary(summary, 'strong')
+        return super().modify_summary(summary)
+
     def review(self, inputs, outputs):
         y, seq_len_y, x, _, targets = outputs
         assert targets is not None

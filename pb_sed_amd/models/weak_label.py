@@ -144,6 +144,13 @@ class CRNN(SoundEventModel):
             return inputs['weak_targets'], inputs['boundary_targets']
         return inputs['weak_targets'],
 
+    def modify_summary(self, summary):
+        """Called by the trainer before dumping a summary (reference models/weak_label/crnn.py modify_summary): metrics
+        from the validation buffers, then the base class' scalar means / image grid."""
+        if 'targets_weak' in summary['buffers']:
+            self.add_metrics_to_summary(summary, 'weak')
+        return super().modify_summary(summary)
+
     def review(self, inputs, outputs, defer_summary=False):
         y_fwd, y_bwd, seq_len, x, _, targets = outputs
         assert targets is not None

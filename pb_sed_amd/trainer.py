@@ -79,6 +79,43 @@ def param_buckets(model):
     return order, [spans[k] for k in order]
 
 
+
+def load_init_checkpoint(model, state_dict):
+    """Initialise a weak-label CRNN from another model's ``state_dict`` the way the reference's training script does
+    (pb_sed/experiments/weak_label_crnn/training.py:327-342): CNN and both GRUs are loaded completely, of the two
+    output nets everything but the last layer (whose width is the source task's number of classes).  The build's
+    parameter / buffer names are the reference's (``cnn.cnn_2d.convs.<i>.conv.weight``, ``...norm.gamma|beta|
+    running_mean|running_power``, ``rnn_fwd.rnn.weight_ih_l0`` ...), so a ``torch.load(path)['model']`` dict written by
+    the reference's trainer is accepted as is.  Buffers the build does not keep are ignored; missing or mis-shaped
+    tensors of the loaded parts raise."""
+    own = model.state_dict()
+
+    def sub(prefix):
+        return {k: v for k, v in state_dict.items() if k.startswith(prefix)}
+
+    picked = {}
+    for prefix in ('cnn.', 'rnn_fwd.rnn.', 'rnn_bwd.rnn.'):
+        part = sub(prefix)
+        if not part and prefix == 'rnn_bwd.rnn.' and getattr(model, 'rnn_bwd', None) is None:
+            continue
+        missing = [k for k in own if k.startswith(prefix) and k not in part]
+        if missing:
+            raise KeyError(f'init checkpoint lacks {missing[:4]}{" ..." if len(missing) > 4 else ""}')
+        picked.update({k: v for k, v in part.items() if k in own})
+    for head in ('rnn_fwd.output_net.', 'rnn_bwd.output_net.'):
+        part = sub(head)
+        if not part:
+            continue
+        last = sorted(k[len(head):].split('.')[1] for k in part)[-1]        # 'convs.<idx>....': pop the output layer
+        picked.update({k: v for k, v in part.items() if k[len(head):].split('.')[1] != last and k in own})
+    for k, v in picked.items():
+        if tuple(own[k].shape) != tuple(v.shape):
+            raise ValueError(f'init checkpoint: {k} has shape {tuple(v.shape)}, model expects {tuple(own[k].shape)}')
+    with torch.no_grad():
+        for k, v in picked.items():
+            own[k].copy_(v)                          # aliases the parameter storage; bumps the version the packed-weight caches key on
+    return sorted(picked)
+
 class Trainer:
     def __init__(self, model, lr=5e-4, gradient_clipping=1e10, betas=(.9, .999), eps=1e-8):
         self.model = model

@@ -134,3 +134,87 @@ def test_event_extraction_internal():
     fr = pp.event_frames(s, [.5, .5])
     np.testing.assert_array_equal(fr[0], [[1, 3], [4, 5]])
     np.testing.assert_array_equal(fr[1], [[0, 2], [3, 4]])
+
+
+# ------------------------------------------------------------------ validation metrics
+def test_instance_based_metrics_match_reference(golden):
+    """pb_sed_amd.evaluation.instance_based against vectors produced by executing the reference's
+    pb_sed/evaluation/instance_based.py (tools/gen_golden.py: gen_instance_based): threshold searches with and without
+    ties, rate constraints, beta / bias arguments (honoured for vectors, ignored for matrices exactly as the reference
+    does), binary-decision metrics, lwlrap, and the module's own docstring example."""
+    from pb_sed_amd.evaluation import instance_based as ib
+    g = golden('ref_instance_based.npz')
+    targets, decisions = g['targets'], g['decisions']
+
+    def check(name, out):
+        out = out if isinstance(out, tuple) else (out,)
+        for i, o in enumerate(out):
+            ref = g[f'{name}_{i}']
+            np.testing.assert_allclose(np.asarray(o, dtype=np.float64), ref, rtol=1e-12, atol=1e-12, err_msg=f'{name}[{i}]')
+
+    for tag, sc in (('c', g['scores']), ('q', g['scores_q'])):
+        check(f'best_f_2d_{tag}', ib.get_best_fscore_thresholds(targets, sc))
+        check(f'best_f_2d_minp_{tag}', ib.get_best_fscore_thresholds(targets, sc, min_precision=.6))
+        check(f'best_f_2d_minr_{tag}', ib.get_best_fscore_thresholds(targets, sc, min_recall=.8))
+        check(f'best_f_2d_beta2_{tag}', ib.get_best_fscore_thresholds(targets, sc, beta=2.))
+        check(f'best_er_2d_{tag}', ib.get_best_er_thresholds(targets, sc))
+        check(f'best_er_2d_maxi_{tag}', ib.get_best_er_thresholds(targets, sc, max_insertion_rate=.1))
+        check(f'best_er_2d_maxd_{tag}', ib.get_best_er_thresholds(targets, sc, max_deletion_rate=.2))
+        check(f'curve_f_2d_{tag}', ib.fscore_curve(targets, sc))
+        check(f'curve_er_2d_{tag}', ib.er_curve(targets, sc))
+        for c in (0, 2, 4):
+            check(f'best_f_1d_{tag}{c}', ib.get_best_fscore_thresholds(targets[:, c], sc[:, c]))
+            check(f'best_f_1d_beta2_bias_{tag}{c}', ib.get_best_fscore_thresholds(
+                targets[:, c], sc[:, c], beta=2., tp_bias=1, n_ref_bias=2, n_pos_bias=3))
+            check(f'best_er_1d_{tag}{c}', ib.get_best_er_thresholds(targets[:, c], sc[:, c]))
+    check('lwlrap', ib.lwlrap(targets, g['scores']))
+    for ew in (False, True):
+        check(f'fscore_ew{int(ew)}', ib.fscore(targets, decisions, event_wise=ew))
+        check(f'fscore_beta2_ew{int(ew)}', ib.fscore(targets, decisions, beta=2., event_wise=ew))
+        check(f'error_rate_ew{int(ew)}', ib.error_rate(targets, decisions[1], event_wise=ew))
+    t9, s9 = g['t9'], g['s9']
+    check('t9_curve_f', ib.fscore_curve(t9, s9))
+    check('t9_best_f', ib.get_best_fscore_thresholds(t9, s9))
+    check('t9_best_f_minp', ib.get_best_fscore_thresholds(t9, s9, min_precision=.51))
+    check('t9_best_er', ib.get_best_er_thresholds(t9, s9))
+    # the known answers printed in the reference's docstrings (instance_based.py:283-287, 339-343)
+    thr, f, p, r = ib.get_best_fscore_thresholds(t9[:, None], s9[:, None])
+    assert np.allclose([thr[0], f[0], p[0], r[0]], [0.15, 2 / 3, 0.5, 1.0])
+    assert ib.get_best_er_thresholds(t9, s9) == (np.inf, 1.0, 0.0, 1.0)
+
+
+def test_summary_metrics_match_reference(golden):
+    """SoundEventModel.add_metrics_to_summary of the build against the scalars the reference's own method produced
+    (tools/gen_golden.py: gen_summary_metrics): label subsets by index and by name, label-wise keys, and the
+    mAP / mAUC branch that is skipped when a class has a single positive."""
+    from pb_sed_amd.models import base
+    g = golden('ref_summary_metrics.npz')
+    labels = [str(x) for x in g['labels']]
+
+    class Model(base.SoundEventModel):
+        def tagging(self, inputs, **params): pass
+        def boundaries_detection(self, inputs, **params): pass
+        def sound_event_detection(self, inputs, **params): pass
+
+    configs = {
+        'plain': dict(labelwise_metrics=(), label_mapping=None, test_labels=None),
+        'labelwise': dict(labelwise_metrics=('fscore_weak', 'lwlrap_weak', 'ap_weak'), label_mapping=labels, test_labels=None),
+        'subset_idx': dict(labelwise_metrics=('error_rate_weak',), label_mapping=None, test_labels=[0, 3, 4]),
+        'subset_names': dict(labelwise_metrics=('fscore_weak', 'auc_weak'), label_mapping=labels, test_labels=['dog', 'water']),
+    }
+    scores = g['scores']
+    for name, cfg in configs.items():
+        for tname in ('all', 'rare'):
+            t = g['targets'] if tname == 'all' else g['targets_rare']
+            summary = dict(scalars={}, images={}, buffers={'y_weak': [scores[:40], scores[40:]], 'targets_weak': [t[:40], t[40:]]})
+            Model(**cfg).add_metrics_to_summary(summary, 'weak')
+            keys = sorted(summary['scalars'])
+            assert keys == [str(k) for k in g[f'{name}/{tname}/keys']], (name, tname)
+            np.testing.assert_allclose([float(summary['scalars'][k]) for k in keys], g[f'{name}/{tname}/values'],
+                                       rtol=1e-12, atol=1e-12, err_msg=f'{name}/{tname}')
+            assert not summary['buffers']
+    # modify_summary: scalar lists -> means, images -> one normalised column
+    m = Model()
+    out = m.modify_summary(dict(scalars=dict(loss=[1., 2., 6.]), images=dict(x=torch.arange(24.).reshape(2, 1, 3, 4)), buffers={}))
+    assert out['scalars']['loss'] == 3.0 and out['images']['x'].shape == (3, 2 * (3 + 2) + 2, 4 + 4)
+    assert out['images']['x'].max().item() == 1.0 and out['images']['x'][:, 2, 2].eq(out['images']['x'][0, 2, 2]).all()

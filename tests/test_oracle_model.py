@@ -1,6 +1,7 @@
 """Shape doctests of the reference re-expressed (weak_label/crnn.py:16-35, strong_label/crnn.py:15-43)
 plus self-consistency checks of the restated third-party layers."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import frontend as fe
@@ -78,3 +79,29 @@ def test_gru_wrapper_reverse_is_time_flip_for_full_length():
     # ragged: outputs past seq_len are zero
     y, _ = g(x, np.array([9, 5]))
     assert (y[1, :, 5:] == 0).all()
+
+
+def test_load_init_checkpoint_surgery():
+    """Reference training.py:327-342: CNN + GRUs loaded completely, output nets without their last layer; a checkpoint
+    from a 10-class model initialises a 7-class one; a checkpoint that lacks CNN tensors is refused."""
+    from pb_sed_amd.models import weak_label
+    from pb_sed_amd.trainer import load_init_checkpoint
+    torch.manual_seed(1)
+    src = weak_label.CRNN.build(num_events=10)
+    torch.manual_seed(2)
+    dst = weak_label.CRNN.build(num_events=7)
+    before = {k: v.clone() for k, v in dst.state_dict().items()}
+    ckpt = {k: v.clone() for k, v in src.state_dict().items()}
+    ckpt['cnn.cnn_2d.convs.1.norm.num_tracked_values'] = torch.zeros(())         # a buffer the build does not keep
+    loaded = load_init_checkpoint(dst, ckpt)
+    after = dst.state_dict()
+    for k in after:
+        head_last = k.startswith(('rnn_fwd.output_net.convs.1.', 'rnn_bwd.output_net.convs.1.'))
+        if k.startswith(('cnn.', 'rnn_fwd.', 'rnn_bwd.')) and not head_last:
+            assert k in loaded and torch.equal(after[k], ckpt[k]), k
+        else:
+            assert k not in loaded and torch.equal(after[k], before[k]), k
+    assert after['rnn_fwd.output_net.convs.1.conv.weight'].shape[0] == 7
+    broken = {k: v for k, v in ckpt.items() if k != 'cnn.cnn_1d.convs.2.conv.weight'}
+    with pytest.raises(KeyError):
+        load_init_checkpoint(dst, broken)

@@ -6,7 +6,7 @@ so they are replaced by stub modules; the few third-party helpers the reference-
 (compute_mask, TakeLast/Mean/Sum/Max, Pad) are the oracle's restatements.  What is
 pinned is therefore the reference-OWNED code:  pb_sed/models/weak_label/crnn.py (review, losses,
 heads), pb_sed/models/strong_label/crnn.py (review), pb_sed/filters.py,
-pb_sed/models/base/inference.py (inference, filtering, boundariesfilt).
+pb_sed/models/base/inference.py (inference, filtering, boundariesfilt), pb_sed/evaluation/instance_based.py.
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py   ->  tests/golden/ref_*.npz
 No reference source is copied; only input/output arrays are stored.
@@ -322,10 +322,91 @@ def gen_inference():
     print('ref_inference', {k: v.shape for k, v in cases.items()})
 
 
+def gen_instance_based():
+    """Validation metrics (pb_sed/evaluation/instance_based.py, pure numpy): threshold searches on score matrices with
+    ties, the rate constraints, binary-decision metrics and lwlrap."""
+    import pb_sed.evaluation.instance_based as ref_ib
+    rng = np.random.default_rng(16)
+    n, k = 240, 6
+    targets = (rng.random((n, k)) < np.array([.5, .3, .1, .7, .02, .4])).astype(np.float64)
+    scores = np.clip(targets * .35 + rng.random((n, k)) * .8, 0, 1)
+    scores_q = np.round(scores * 12) / 12                       # many ties
+    cases = dict(targets=targets, scores=scores, scores_q=scores_q)
+
+    def put(name, out):
+        for i, o in enumerate(out):
+            cases[f'{name}_{i}'] = np.asarray(o, dtype=np.float64)
+
+    for tag, sc in (('c', scores), ('q', scores_q)):
+        put(f'best_f_2d_{tag}', ref_ib.get_best_fscore_thresholds(targets, sc))
+        put(f'best_f_2d_minp_{tag}', ref_ib.get_best_fscore_thresholds(targets, sc, min_precision=.6))
+        put(f'best_f_2d_minr_{tag}', ref_ib.get_best_fscore_thresholds(targets, sc, min_recall=.8))
+        put(f'best_f_2d_beta2_{tag}', ref_ib.get_best_fscore_thresholds(targets, sc, beta=2.))
+        put(f'best_er_2d_{tag}', ref_ib.get_best_er_thresholds(targets, sc))
+        put(f'best_er_2d_maxi_{tag}', ref_ib.get_best_er_thresholds(targets, sc, max_insertion_rate=.1))
+        put(f'best_er_2d_maxd_{tag}', ref_ib.get_best_er_thresholds(targets, sc, max_deletion_rate=.2))
+        put(f'curve_f_2d_{tag}', ref_ib.fscore_curve(targets, sc))
+        put(f'curve_er_2d_{tag}', ref_ib.er_curve(targets, sc))
+        for c in (0, 2, 4):
+            put(f'best_f_1d_{tag}{c}', ref_ib.get_best_fscore_thresholds(targets[:, c], sc[:, c]))
+            put(f'best_f_1d_beta2_bias_{tag}{c}', ref_ib.get_best_fscore_thresholds(
+                targets[:, c], sc[:, c], beta=2., tp_bias=1, n_ref_bias=2, n_pos_bias=3))
+            put(f'best_er_1d_{tag}{c}', ref_ib.get_best_er_thresholds(targets[:, c], sc[:, c]))
+    put('lwlrap', ref_ib.lwlrap(targets, scores))
+    decisions = (scores[None] > np.array([.3, .5, .7])[:, None, None]).astype(np.float64)
+    cases['decisions'] = decisions
+    for ew in (False, True):
+        put(f'fscore_ew{int(ew)}', ref_ib.fscore(targets, decisions, event_wise=ew))
+        put(f'fscore_beta2_ew{int(ew)}', ref_ib.fscore(targets, decisions, beta=2., event_wise=ew))
+        put(f'error_rate_ew{int(ew)}', ref_ib.error_rate(targets, decisions[1], event_wise=ew))
+    # the module's own known-answer example (docstrings of fscore_curve / get_best_*_thresholds)
+    t9 = np.array([1.0, 1.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+    s9 = np.array([0.6, 0.2, 0.5, 0.4, 0.3, 0.1, 0.7, 0.0, 0.0])
+    cases['t9'], cases['s9'] = t9, s9
+    put('t9_curve_f', ref_ib.fscore_curve(t9, s9))
+    put('t9_best_f', ref_ib.get_best_fscore_thresholds(t9, s9))
+    put('t9_best_f_minp', ref_ib.get_best_fscore_thresholds(t9, s9, min_precision=.51))
+    put('t9_best_er', ref_ib.get_best_er_thresholds(t9, s9))
+    np.savez_compressed(os.path.join(OUT, 'ref_instance_based.npz'), **cases)
+    print('ref_instance_based', len(cases), 'arrays')
+
+
+def gen_summary_metrics():
+    """SoundEventModel.add_metrics_to_summary (pb_sed/models/base/model.py:44-88) called as a plain function on a
+    stand-in object: summary scalars for label subsets / label-wise metrics / the mAP-mAUC branch."""
+    import pb_sed.models.base.model as ref_model
+    fn = ref_model.SoundEventModel.__dict__['add_metrics_to_summary']
+    rng = np.random.default_rng(17)
+    n, k = 90, 5
+    targets = (rng.random((n, k)) < np.array([.5, .3, .2, .6, .4])).astype(np.float64)
+    scores = np.clip(targets * .3 + rng.random((n, k)) * .8, 0, 1)
+    rare = targets.copy(); rare[:, 2] = 0; rare[0, 2] = 1          # a class with a single positive: no mAP / mAUC
+    labels = ['alarm', 'dog', 'dishes', 'speech', 'water']
+    cases = dict(targets=targets, scores=scores, targets_rare=rare, labels=np.array(labels))
+    configs = {
+        'plain': dict(labelwise_metrics=(), label_mapping=None, test_labels=None),
+        'labelwise': dict(labelwise_metrics=('fscore_weak', 'lwlrap_weak', 'ap_weak'), label_mapping=labels, test_labels=None),
+        'subset_idx': dict(labelwise_metrics=('error_rate_weak',), label_mapping=None, test_labels=[0, 3, 4]),
+        'subset_names': dict(labelwise_metrics=('fscore_weak', 'auc_weak'), label_mapping=labels, test_labels=['dog', 'water']),
+    }
+    for name, cfg in configs.items():
+        for tname, t in (('all', targets), ('rare', rare)):
+            me = types.SimpleNamespace(**cfg)
+            summary = dict(scalars={}, buffers={'y_weak': [scores[:40], scores[40:]], 'targets_weak': [t[:40], t[40:]]})
+            fn(me, summary, 'weak')
+            keys = sorted(summary['scalars'])
+            cases[f'{name}/{tname}/keys'] = np.array(keys)
+            cases[f'{name}/{tname}/values'] = np.array([float(summary['scalars'][q]) for q in keys])
+    np.savez_compressed(os.path.join(OUT, 'ref_summary_metrics.npz'), **cases)
+    print('ref_summary_metrics', len(cases), 'arrays')
+
+
 if __name__ == '__main__':
     gen_fbcrnn_loss()
     gen_bicrnn_loss()
     gen_fbcrnn_heads()
     gen_filters()
     gen_inference()
+    gen_instance_based()
+    gen_summary_metrics()
     assert not os.path.exists('/root/reference/pb_sed/__pycache__'), 'bytecode written to reference'
