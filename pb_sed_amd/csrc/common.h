@@ -20,12 +20,19 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_shuffled(float v) {
+    // lane permutation inside a 16-lane DPP row as an operand modifier (folds into v_add_f32_dpp): no LDS crossbar trip
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
 __device__ __forceinline__ float wave_sum16(float v) {
-    // sum over the 16 lanes sharing lane>>4 (xor 1,2,4,8 stays inside the 16-lane group)
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    // sum over the 16 lanes sharing lane>>4 (one DPP row): pairs, quads, then the two mirror steps; every lane ends
+    // with the total
+    v += dpp_shuffled<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_shuffled<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_shuffled<0x141>(v);     // row_half_mirror
+    v += dpp_shuffled<0x140>(v);     // row_mirror
     return v;
 }
 

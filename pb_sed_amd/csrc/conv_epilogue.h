@@ -40,6 +40,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvFwdArgs& a, f32x4 (&acc)
                                            ? a.bx[((size_t)(b * a.Cout + cout) * Fo + fo) * a.T + t] : 0.f;
                     }
             }
+            float c1 = 0.f, c2 = 0.f;               // per-channel statistics: the rows are summed before the lane reduction
 #pragma unroll
             for (int fo_l = 0; fo_l < FO_T; ++fo_l) {
                 float s1 = 0.f, s2 = 0.f;
@@ -77,13 +78,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvFwdArgs& a, f32x4 (&acc)
                         }
                     }
                 }
-                if (a.stats) {
+                if (a.stats && a.stats_cf) {
                     s1 = wave_sum16(s1);
                     s2 = wave_sum16(s2);
                     if (lr == 0) {
                         st_s[((wn * COUT_T + cl) * FO_T + fo_l) * 2 + 0] = s1;
                         st_s[((wn * COUT_T + cl) * FO_T + fo_l) * 2 + 1] = s2;
                     }
+                }
+                c1 += s1; c2 += s2;
+            }
+            if (a.stats && !a.stats_cf) {
+                c1 = wave_sum16(c1);
+                c2 = wave_sum16(c2);
+                if (lr == 0) {
+                    st_s[(wn * COUT_T + cl) * FO_T * 2 + 0] = c1;
+                    st_s[(wn * COUT_T + cl) * FO_T * 2 + 1] = c2;
                 }
             }
         }
@@ -109,9 +119,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvFwdArgs& a, f32x4 (&acc)
                 const int which = i & 1, cl = i >> 1, cout = cout0 + cl;
                 float v = 0.f;
 #pragma unroll
-                for (int w = 0; w < WN; ++w)
-#pragma unroll
-                    for (int fo_l = 0; fo_l < FO_T; ++fo_l) v += st_s[((w * COUT_T + cl) * FO_T + fo_l) * 2 + which];
+                for (int w = 0; w < WN; ++w) v += st_s[(w * COUT_T + cl) * FO_T * 2 + which];
                 if (cout < a.Cout) atomicAdd(&a.stats[((size_t)slot * a.Cout + cout) * 2 + which], (double)v);
             }
         }

@@ -585,6 +585,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(ConvWgradArgs a
 
 int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     if (a.unpool_idx && (a.F % 2)) { set_error("conv_wgrad: unpool needs even F"); return PBSED_E_ARG; }
+    // the loaders address one clip with 32-bit element offsets (buffer loads; 2^29 elements marks "out of range")
+    if ((size_t)a.Cin * a.F * a.T >= (1ull << 28) || (size_t)a.Cout * a.F * a.T >= (1ull << 28)) {
+        set_error("conv_wgrad: one clip of x / dy must stay below 1 GiB (Cin=%d Cout=%d F=%d T=%d)", a.Cin, a.Cout, a.F, a.T);
+        return PBSED_E_ARG;
+    }
     // Configurations measured on MI355X at B=32, T=500: one per channel regime.
     if (KH == 3 && KW == 3) {
         if (a.Cin == 1) return a.Cout >= 64 ? launch_wgrad<3, 3, 4, 1, 1, true>(a, s) : launch_wgrad<3, 3, 1, 1, 1, true>(a, s);

@@ -201,8 +201,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
             *reinterpret_cast<u32x4_t*>(u_s + ((tid >> 4) + 16 * i) * WN_COUT_P + (tid & 15) * 4) = ru[i];
     };
 
-    for (int i = tid; i < WN_CT * C::FO_T * 2; i += 256) st_s[i] = 0.f;
-
     const int nChunks = a.CinP / WN_CK;
     load_chunk();
     for (int ch = 0; ch < nChunks; ++ch) {
@@ -296,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
                 y[fl][3] = d12 + 8.f * d34 + m5 + bias;
             }
             constexpr int NFO = POOL ? 1 : 2;
+            float c1 = 0.f, c2 = 0.f;               // per-channel statistics: both rows summed before the lane reduction
 #pragma unroll
             for (int fo_l = 0; fo_l < NFO; ++fo_l) {
                 float v[4];
@@ -351,12 +350,26 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
                             }
                     }
                 }
-                if (a.stats) {
+                // every (channel, row) entry of st_s has exactly one writer: plain stores, fixed summation order
+                if (a.stats && a.stats_cf) {
                     s1 = wave_sum16(s1);
                     s2 = wave_sum16(s2);
                     if (lr == 0) {
-                        atomicAdd(&st_s[(cl * C::FO_T + st_row) * 2 + 0], s1);
-                        atomicAdd(&st_s[(cl * C::FO_T + st_row) * 2 + 1], s2);
+                        st_s[(cl * C::FO_T + st_row) * 2 + 0] = s1;
+                        st_s[(cl * C::FO_T + st_row) * 2 + 1] = s2;
+                    }
+                }
+                c1 += s1; c2 += s2;
+            }
+            if (a.stats && !a.stats_cf) {
+                c1 = wave_sum16(c1);
+                c2 = wave_sum16(c2);
+                if (lr == 0) {
+#pragma unroll
+                    for (int fo_l = 0; fo_l < NFO; ++fo_l) {
+                        const int st_row = POOL ? wn : wn * 2 + fo_l;
+                        st_s[(cl * C::FO_T + st_row) * 2 + 0] = fo_l == 0 ? c1 : 0.f;
+                        st_s[(cl * C::FO_T + st_row) * 2 + 1] = fo_l == 0 ? c2 : 0.f;
                     }
                 }
             }
@@ -387,6 +400,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
 template <bool POOL, bool DGRAD>
 static int launch_wino(const ConvFwdArgs& a, hipStream_t s) {
     using C = WinoCfg<POOL>;
+    // the loaders address one clip with 32-bit byte offsets (buffer loads; 2^31 marks "out of range")
+    if ((size_t)a.Cin * a.F * a.T * 4 >= (1ull << 30)) {
+        set_error("conv_wino: one clip of the input must stay below 1 GiB (Cin=%d F=%d T=%d)", a.Cin, a.F, a.T);
+        return PBSED_E_ARG;
+    }
     const int nTt = (a.T + WN_TT - 1) / WN_TT, nFt = (a.F + WN_FT - 1) / WN_FT;
     dim3 grid(nTt * nFt * a.B, a.CoutP / WN_CT);
     const size_t lds = C::LDS_FLOATS * sizeof(float);
