@@ -257,8 +257,10 @@ int conv_fwd_launch(const ConvFwdArgs& a, int KH, int KW, int pool, int dgrad, h
     conv_fwd_tile_dims(KH, KW, a.Cin, a.Cout, &ck, &ct);
     if (pool && (a.F % 2)) { set_error("conv_fwd: pool needs even F"); return PBSED_E_ARG; }
     // the loaders address one clip with 32-bit byte offsets (buffer loads; 2^31 marks "out of range")
-    if ((size_t)a.Cin * a.F * a.T * 4 >= (1ull << 30) || (size_t)KH * KW * a.CinP * a.CoutP * 4 >= (1ull << 31)) {
-        set_error("conv_fwd: one clip of the input must stay below 1 GiB (Cin=%d F=%d T=%d)", a.Cin, a.F, a.T);
+    if ((size_t)a.Cin * a.F * a.T * 4 >= (1ull << 30) || (size_t)a.Cout * a.F * a.T * 4 >= (1ull << 29) ||
+        (size_t)KH * KW * a.CinP * a.CoutP * 4 >= (1ull << 31)) {
+        set_error("conv_fwd: one clip of the input / output must stay below 1 GiB / 512 MiB (Cin=%d Cout=%d F=%d T=%d)", a.Cin,
+                  a.Cout, a.F, a.T);
         return PBSED_E_ARG;
     }
     if (dgrad && pool) { set_error("conv dgrad: pool epilogue not valid"); return PBSED_E_ARG; }

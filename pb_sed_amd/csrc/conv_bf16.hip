@@ -206,6 +206,10 @@ __global__ void pack_conv_weights_bf16_kernel(const float* __restrict__ w, unsig
 template <int FT, int TT, int KH, int KW, int NSPLIT, bool POOL, bool DGRAD>
 static int launch_b(const ConvFwdArgs& a, const unsigned short* wpb, hipStream_t s) {
     using C = ConvBCfg<FT, TT, KH, KW, NSPLIT, POOL>;
+    if ((size_t)a.Cout * a.F * a.T * 4 >= (1ull << 29)) {     // conv_epilogue addresses one clip with 32-bit offsets
+        set_error("conv_bf16: one clip of the output must stay below 512 MiB (Cout=%d F=%d T=%d)", a.Cout, a.F, a.T);
+        return PBSED_E_ARG;
+    }
     const int nTt = (a.T + TT - 1) / TT, nFt = (a.F + FT - 1) / FT;
     dim3 grid(nTt * nFt * a.B, a.CoutP / CB_COUT_T);
     auto kern = conv_bf16_kernel<FT, TT, KH, KW, NSPLIT, POOL, DGRAD>;
