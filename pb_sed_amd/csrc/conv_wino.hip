@@ -251,25 +251,45 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
     }
 
     // ---- epilogue: A^T M in registers, then bias / pool / statistics / BN-ReLU backward exactly as conv_epilogue,
-    // on 4 consecutive t per lane:  t = t0 + 4*lr + e,  cout = cout0 + (wm*2+m)*16 + lq*4 + r,  f = f0 + wn*2 + fl
+    // on 4 consecutive t per lane:  t = t0 + 4*lr + e,  cout = cout0 + (wm*2+m)*16 + lq*4 + r,  f = f0 + wn*2 + fl.
+    // Stores and the DGRAD re-load of the layer input are raw buffer accesses on clip-relative resources with one
+    // 32-bit byte offset = channel + row + column part; a part is 2^31 / 2^29 when its index is out of range, so
+    // invalid fragments drop out without branches (conv_epilogue.h).
+    constexpr unsigned OOB_C = 0x80000000u, OOB_T = 0x20000000u;
     const int Fo = POOL ? a.F / 2 : a.F;
     const int tb = t0 + 4 * lr;
-    const bool vec_out = vec && tb + 4 <= a.T;
+    const unsigned oclip = (unsigned)(a.Cout * Fo * a.T);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)b * oclip, 0, oclip * 4u, 0x00020000);
+    const bool want_idx = POOL && a.pool_idx != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(
+        want_idx ? a.pool_idx + (size_t)b * oclip : nullptr, 0, want_idx ? oclip : 0u, 0x00020000);
+    const bool bnb = DGRAD && a.bx != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_bx = __builtin_amdgcn_make_buffer_rsrc(
+        bnb ? const_cast<float*>(a.bx) + (size_t)b * oclip : nullptr, 0, bnb ? oclip * 4u : 0u, 0x00020000);
+    const unsigned tcol = tb < a.T ? (unsigned)tb * 4u : OOB_T;
+    const int n_seq = min(max(sl - tb, 0), 4);                    // elements of the quad inside the sequence
+    constexpr int NFO = POOL ? 1 : 2;
+    unsigned roff[NFO];
+    bool orow_ok[NFO];
+#pragma unroll
+    for (int fo_l = 0; fo_l < NFO; ++fo_l) {
+        const int fo = POOL ? f0 / 2 + wn : f0 + wn * 2 + fo_l;
+        orow_ok[fo_l] = fo < Fo;
+        roff[fo_l] = orow_ok[fo_l] ? (unsigned)(fo * a.T) * 4u : OOB_T;
+    }
     // DGRAD: the layer's raw forward input for every fragment this thread finishes, requested before any arithmetic
     // (inside the loops each load would wait behind the stores of the previous fragment)
-    float4 xq[2][4][2];
-    if (DGRAD && a.bx != nullptr && vec_out) {
+    u32x4_t xq[2][4][2];
+    if (bnb) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r) {
+                const int cout = cout0 + (wm * 2 + m) * 16 + lq * 4 + r;
+                const unsigned coff = cout < a.Cout ? (unsigned)(cout * Fo * a.T) * 4u : OOB_C;
 #pragma unroll
-                for (int fl = 0; fl < 2; ++fl) {
-                    const int cout = cout0 + (wm * 2 + m) * 16 + lq * 4 + r, fo = f0 + wn * 2 + fl;
-                    xq[m][r][fl] = (cout < a.Cout && fo < Fo)
-                                       ? *reinterpret_cast<const float4*>(a.bx + ((size_t)(b * a.Cout + cout) * Fo + fo) * a.T + tb)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                for (int fl = 0; fl < NFO; ++fl) xq[m][r][fl] = __builtin_amdgcn_raw_buffer_load_b128(rs_bx, coff + roff[fl] + tcol, 0, 0);
+            }
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -279,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
             const int cout = cout0 + cl;
             const bool cv = cout < a.Cout;
             const float bias = (a.bias && cv) ? a.bias[cout] : 0.f;
-            const bool bnb = DGRAD && a.bx != nullptr;
+            const unsigned coff = cv ? (unsigned)(cout * Fo * a.T) * 4u : OOB_C;
             float bsc = 0.f, bsh = 0.f, bmu = 0.f, bis = 0.f;
             if (bnb && cv) { bsc = a.bscale[cout]; bsh = a.bshift[cout]; bmu = a.bmean[cout]; bis = a.binvstd[cout]; }
             float y[2][4];
@@ -293,61 +313,55 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvFwdArgs a) {
                 y[fl][2] = s12 + 4.f * s34 + bias;
                 y[fl][3] = d12 + 8.f * d34 + m5 + bias;
             }
-            constexpr int NFO = POOL ? 1 : 2;
             float c1 = 0.f, c2 = 0.f;               // per-channel statistics: both rows summed before the lane reduction
 #pragma unroll
             for (int fo_l = 0; fo_l < NFO; ++fo_l) {
                 float v[4];
-                int pidx[4] = {0, 0, 0, 0};
+                unsigned pbytes = 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (POOL) {
-                        pidx[e] = y[1][e] > y[0][e];
-                        v[e] = pidx[e] ? y[1][e] : y[0][e];
+                        const bool second = y[1][e] > y[0][e];
+                        v[e] = second ? y[1][e] : y[0][e];
+                        pbytes |= (unsigned)second << (8 * e);
                     } else {
                         v[e] = y[fo_l][e];
                     }
                 }
-                const int fo = (POOL ? f0 / 2 + wn : f0 + wn * 2 + fo_l);
                 const int st_row = POOL ? wn : wn * 2 + fo_l;
+                const int n_cnt = orow_ok[fo_l] ? n_seq : 0;           // padded channels produce exact zeros
                 float s1 = 0.f, s2 = 0.f;
-                if (cv && fo < Fo && tb < a.T) {
-                    const size_t o = ((size_t)(b * a.Cout + cout) * Fo + fo) * a.T + tb;
-                    if (DGRAD && bnb) {
+                if (DGRAD) {
+                    if (bnb) {
                         // backward through mask -> ReLU -> BN-apply of the layer's prologue, with the BN-backward sums
-                        float xv[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (vec_out) {
-                            const float4 x4 = xq[m][r][fo_l];
-                            xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (tb + e < a.T) xv[e] = a.bx[o + e];
-                        }
+                        const u32x4_t x4 = xq[m][r][fo_l];
+                        const float xv[4] = {__uint_as_float(x4.x), __uint_as_float(x4.y), __uint_as_float(x4.z), __uint_as_float(x4.w)};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float z = fmaf(xv[e], bsc, bsh);
-                            const bool keep = (tb + e < sl) && (!a.relu || z > 0.f);
+                            const bool keep = e < n_cnt && (!a.relu || z > 0.f);
                             v[e] = keep ? v[e] : 0.f;
-                            s1 += v[e]; s2 += v[e] * ((xv[e] - bmu) * bis);
+                            s1 += v[e]; s2 = fmaf(v[e], (xv[e] - bmu) * bis, s2);
                         }
-                    } else if (!DGRAD) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (tb + e < sl) { s1 += v[e]; s2 += v[e] * v[e]; }
                     }
-                    if (vec_out) {
-                        *reinterpret_cast<float4*>(a.y + o) = make_float4(v[0], v[1], v[2], v[3]);
-                        if (POOL && a.pool_idx)
-                            *reinterpret_cast<uchar4*>(a.pool_idx + o) =
-                                make_uchar4((uint8_t)pidx[0], (uint8_t)pidx[1], (uint8_t)pidx[2], (uint8_t)pidx[3]);
-                    } else {
+                } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (tb + e < a.T) {
-                                a.y[o + e] = v[e];
-                                if (POOL && a.pool_idx) a.pool_idx[o + e] = (uint8_t)pidx[e];
-                            }
+                    for (int e = 0; e < 4; ++e) {
+                        const float vm = e < n_cnt ? v[e] : 0.f;
+                        s1 += vm; s2 = fmaf(vm, vm, s2);
+                    }
+                }
+                const unsigned off = coff + roff[fo_l] + tcol;
+                if (vec) {
+                    const u32x4_t q = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(q, rs_y, off, 0, 0);
+                    if (want_idx) __builtin_amdgcn_raw_buffer_store_b32(pbytes, rs_p, off >> 2, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned oe = tb + e < a.T ? off + 4u * e : OOB_C;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[e]), rs_y, oe, 0, 0);
+                        if (want_idx) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(pbytes >> (8 * e)), rs_p, oe >> 2, 0, 0);
                     }
                 }
                 // every (channel, row) entry of st_s has exactly one writer: plain stores, fixed summation order
@@ -401,8 +415,9 @@ template <bool POOL, bool DGRAD>
 static int launch_wino(const ConvFwdArgs& a, hipStream_t s) {
     using C = WinoCfg<POOL>;
     // the loaders address one clip with 32-bit byte offsets (buffer loads; 2^31 marks "out of range")
-    if ((size_t)a.Cin * a.F * a.T * 4 >= (1ull << 30)) {
-        set_error("conv_wino: one clip of the input must stay below 1 GiB (Cin=%d F=%d T=%d)", a.Cin, a.F, a.T);
+    if ((size_t)a.Cin * a.F * a.T * 4 >= (1ull << 30) || (size_t)a.Cout * a.F * a.T * 4 >= (1ull << 29)) {
+        set_error("conv_wino: one clip of the input / output must stay below 1 GiB / 512 MiB (Cin=%d Cout=%d F=%d T=%d)", a.Cin,
+                  a.Cout, a.F, a.T);
         return PBSED_E_ARG;
     }
     const int nTt = (a.T + WN_TT - 1) / WN_TT, nFt = (a.F + WN_FT - 1) / WN_FT;
