@@ -602,7 +602,12 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
         return launch_wgrad<3, 3, 1, 1, 1, false, 4, 4>(a, s);
     }
     if (KH == 1 && KW == 3) return a.Cout >= 128 ? launch_wgrad<1, 3, 4, 2, 2>(a, s) : launch_wgrad<1, 3, 1, 1, 2>(a, s);
-    if (KH == 1 && KW == 1) return a.Cout >= 128 ? launch_wgrad<1, 1, 4, 2, 4>(a, s) : launch_wgrad<1, 1, 1, 1, 4>(a, s);
+    if (KH == 1 && KW == 1) {
+        // many input channels: 128-wide cin tiles halve the re-reads of dY (2048->256: 0.277 -> 0.248 ms); with few of
+        // them the launch has too few block columns (256->256: 0.173 -> 0.247 ms)
+        if (a.Cout >= 128 && a.Cin >= 1024) return launch_wgrad<1, 1, 4, 2, 8>(a, s);
+        return a.Cout >= 128 ? launch_wgrad<1, 1, 4, 2, 4>(a, s) : launch_wgrad<1, 1, 1, 1, 4>(a, s);
+    }
     set_error("conv_wgrad: unsupported kernel %dx%d", KH, KW);
     return PBSED_E_UNSUPPORTED;
 }
