@@ -66,3 +66,18 @@ def test_model_structure_matches_oracle():
     a, b = strong_label.CRNN.build(), om.BiCRNN.build()
     assert [(k, tuple(v.shape)) for k, v in a.state_dict().items()] == \
            [(k, tuple(v.shape)) for k, v in b.state_dict().items()]
+
+
+def test_oversized_clip_is_refused_before_any_launch(libpath):
+    """The conv loaders / epilogues address one clip with 32-bit offsets; the entry points refuse larger clips with
+    PBSED_E_ARG and a message instead of launching (argument check only: null pointers, no GPU needed)."""
+    from pb_sed_amd import _lib
+    L = _lib.lib()
+    # x, w_packed, bias, scale, shift, relu, seq_len, y, pool_idx, stats, stats_per_cf, B, Cin, Cout, F, T, KH, KW, pool, stream
+    rc = L.pbsed_conv_fwd(None, None, None, None, None, 1, None, None, None, None, 0, 1, 4096, 64, 512, 100000, 3, 3, 0, None)
+    assert rc != 0 and b'clip' in L.pbsed_last_error()
+    rc = L.pbsed_conv_fwd_wino(None, None, None, None, None, 1, None, None, None, None, 0, 1, 4096, 64, 512, 100000, 0, None)
+    assert rc != 0 and b'clip' in L.pbsed_last_error()
+    # x, g, unpool_idx, ..., see include/pbsed.h: B, Cin, Cout, F, T, KH, KW
+    rc = L.pbsed_conv_bwd_weight(None, None, None, 1, None, None, None, None, None, 1, 4096, 64, 512, 100000, 3, 3, None)
+    assert rc != 0 and b'clip' in L.pbsed_last_error()
