@@ -84,7 +84,7 @@ __global__ __launch_bounds__(BN * 2) void gru_wgrad_kernel(GruWgradArgs a) {
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;                                   // column sum of dG (threads 0..127, N tile 0 only)
+    float bsum = 0.f;                                   // partial column sum of dG (N tile 0 only)
 
     fetch(r_begin);
     stage(0);
@@ -105,9 +105,10 @@ __global__ __launch_bounds__(BN * 2) void gru_wgrad_kernel(GruWgradArgs a) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma16(av[mi], bv[ni], acc[mi][ni]);
         }
-        if (blockIdx.y == 0 && tid < GW_BM) {
+        if (blockIdx.y == 0) {                       // column sums of dG: every thread a slice of the stage's rows
+            constexpr int PARTS = NT / GW_BM, ROWS = GW_KC / PARTS;
 #pragma unroll
-            for (int r = 0; r < GW_KC; ++r) bsum += As[buf][r][tid];
+            for (int r = 0; r < ROWS; ++r) bsum += As[buf][(tid / GW_BM) * ROWS + r][tid % GW_BM];
         }
         if (more) stage(buf ^ 1);
         __syncthreads();
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(BN * 2) void gru_wgrad_kernel(GruWgradArgs a) {
                 if (g < a.G && k < a.K) unsafeAtomicAdd(dw + (size_t)g * a.K + k, acc[mi][ni][r]);
             }
         }
-    if (blockIdx.y == 0 && tid < GW_BM && m0 + tid < a.G && a.db[gemm]) unsafeAtomicAdd(a.db[gemm] + m0 + tid, bsum);
+    if (blockIdx.y == 0 && m0 + tid % GW_BM < a.G && a.db[gemm]) unsafeAtomicAdd(a.db[gemm] + m0 + tid % GW_BM, bsum);
 }
 
 }  // namespace pbsed
