@@ -1,6 +1,6 @@
 """Micro-benchmark (GPU box): time conv fwd / dgrad / wgrad of every FBCRNN layer shape at batch 32.
-Tile-selection knobs are read by the library from the environment (PBSED_CONV_CT, PBSED_WGRAD_NCG, ...), so
-A/B runs are separate processes:   PBSED_CONV_CT=64 python tools/gpu_conv_bench.py"""
+The library reads its switches from the environment once per process (README.md, "Environment switches"), so A/B
+runs are separate processes:   PBSED_WGRAD_WINO=0 python tools/gpu_conv_bench.py"""
 import os
 import sys
 
