@@ -244,8 +244,8 @@ static int launch_cfg(const ConvFwdArgs& a, hipStream_t s) {
 void conv_fwd_tile_dims(int KH, int KW, int Cin, int Cout, int* ck, int* cout_t) {
     if (KH == 3) {
         // measured on MI355X: a 128-wide Cout tile is slower than two 64-wide ones (accumulator registers halve the occupancy)
-        *ck = (Cin <= 4) ? 4 : 8;
         *cout_t = Cout <= 16 ? 16 : Cout <= 32 ? 32 : 64;
+        *ck = (Cin <= 4 && *cout_t == 16) ? 4 : 8;       // the 4-channel stage exists for the 16-wide first layer only
     } else {
         *ck = (KW == 1) ? 16 : 8;
         *cout_t = Cout <= 16 ? 16 : 128;

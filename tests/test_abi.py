@@ -48,7 +48,7 @@ def test_no_cpu_fallback():
 def test_pack_dims_host_logic(libpath):
     from pb_sed_amd import _lib
     i, o = ctypes.c_int(), ctypes.c_int()
-    for (kh, kw, cin, cout, dg), exp in {(3, 3, 1, 16, 0): (4, 16), (3, 3, 16, 32, 0): (16, 32),
+    for (kh, kw, cin, cout, dg), exp in {(3, 3, 1, 16, 0): (4, 16), (3, 3, 16, 32, 0): (16, 32), (3, 3, 1, 32, 0): (8, 32), (3, 3, 3, 160, 0): (8, 192),
                                           (3, 3, 128, 256, 0): (128, 256), (1, 1, 2048, 256, 0): (2048, 256),
                                           (1, 1, 256, 10, 0): (256, 16), (3, 3, 128, 256, 1): (256, 128),
                                           (1, 1, 266, 768, 0): (272, 768)}.items():

@@ -52,6 +52,8 @@ CONV_CASES = [
     dict(cin=24, cout=128, f=6, t=50, k=(3, 3), pool=True, pro=True),
     dict(cin=20, cout=256, f=4, t=33, k=(3, 3), pool=False, pro=True),
     dict(cin=11, cout=16, f=6, t=40, k=(3, 3), pool=False, pro=False),
+    dict(cin=1, cout=48, f=6, t=70, k=(3, 3), pool=True, pro=False),      # few input channels, wide output (width-2 first layer)
+    dict(cin=3, cout=160, f=4, t=33, k=(3, 3), pool=False, pro=True),
     dict(cin=64, cout=256, f=1, t=130, k=(1, 1), pool=False, pro=True),
     dict(cin=40, cout=10, f=1, t=77, k=(1, 1), pool=False, pro=True),
     dict(cin=48, cout=96, f=1, t=100, k=(1, 3), pool=False, pro=True),
