@@ -777,12 +777,28 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
 }
 
 // 1-D grid of the XCD-aware role mapping (granule_role): per XCD, ring slots first, then projection slots.
-static dim3 granule_xcd_grid(GruStackArgs& a, int H) {
-    a.nby = (a.B + 15) / 16;
-    a.ring_xcd = H / 16;
-    const int R = a.nchains * a.nlayers * a.nby, P = a.nchains * (a.nlayers - 1) * a.nby;
-    const int slots = (R + 7) / 8 * a.ring_xcd + (P * a.ring_xcd + 7) / 8;
-    return dim3(8 * slots, 1, 1);
+// Returns false when an XCD could not hold all of its blocks at once: the round-robin dispatch gives XCD x the blocks
+// with id % 8 = x, i.e. `slots` blocks each, and a scan only makes progress if every active block of it is resident -
+// with one (12-wave, register-heavy) block per CU a ring pinned to an XCD can fill its 32 CUs and lock the projection
+// blocks of that XCD out (found by tools/fuzz_gru.py: H = 512, B = 16).  The caller then keeps the 3-D grid, whose
+// blocks spread evenly over the XCDs.
+static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid) {
+    static int cus_per_xcd = 0;
+    if (cus_per_xcd == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus_per_xcd = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                          ? prop.multiProcessorCount / 8 : 32;
+        if (cus_per_xcd < 1) cus_per_xcd = 1;
+    }
+    const int nby = (a.B + 15) / 16, nj = H / 16;
+    const int R = a.nchains * a.nlayers * nby, P = a.nchains * (a.nlayers - 1) * nby;
+    const int slots = (R + 7) / 8 * nj + (P * nj + 7) / 8;
+    if (slots > cus_per_xcd) return false;
+    a.nby = nby;
+    a.ring_xcd = nj;
+    *grid = dim3(8 * slots, 1, 1);
+    return true;
 }
 
 // PBSED_GRU_POLL_DELAYS="fwd,fwd_gate,bwd,bwd_gate" overrides the measured defaults (PollPacer).
@@ -832,7 +848,7 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
     const int ngroups = nchains * (2 * nlayers - 1);     // rings + projection groups (see GranuleRole)
     granule_poll_delays(false, a);
     dim3 grid(H / 16, (B + 15) / 16, ngroups);
-    if (granule_ring_xcd(false)) grid = granule_xcd_grid(a, H);
+    if (granule_ring_xcd(false)) granule_xcd_grid(a, H, &grid);
     unsigned* gran_gi = granules + (size_t)nchains * nlayers * T * B * H;
     hipStream_t s = (hipStream_t)stream;
     // PBSED_GRU_GW: bit 0 forward / bit 1 BPTT scan with dedicated gate waves (default both; 1.35 -> 1.21 ms and
@@ -884,7 +900,7 @@ int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_
     const int ngroups = nchains * (2 * nlayers - 1);
     granule_poll_delays(true, a);
     dim3 grid(H / 16, (B + 15) / 16, ngroups);
-    if (granule_ring_xcd(true)) grid = granule_xcd_grid(a, H);
+    if (granule_ring_xcd(true)) granule_xcd_grid(a, H, &grid);
     unsigned* gran_dy = granules + (size_t)nchains * nlayers * T * B * H;
     hipStream_t s = (hipStream_t)stream;
     // PBSED_GRU_GW: bit 0 forward / bit 1 BPTT scan with dedicated gate waves (default both; 1.35 -> 1.21 ms and

@@ -274,7 +274,8 @@ def test_adam_and_grad_norm_vs_torch():
 
 
 @pytest.mark.parametrize('persist', ['2', '0'])
-@pytest.mark.parametrize('b,h,t,ragged', [(5, 64, 23, True), (32, 256, 30, False), (19, 128, 17, True)])
+@pytest.mark.parametrize('b,h,t,ragged', [(5, 64, 23, True), (32, 256, 30, False), (19, 128, 17, True), (16, 512, 5, False),
+                                          (1, 128, 40, True)])
 def test_gru_stack_wavefront_vs_torch(b, h, t, ragged, persist, monkeypatch):
     """2-layer forward + time-reversed stacks vs the oracle wrapper around nn.GRU, through both scan
     implementations: persistent granule exchange ('2', default) and one launch per step ('0')."""
