@@ -43,10 +43,15 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
                                    const float* beta, float eps, float momentum, float* running_mean,
                                    float* running_power, float* mean, float* invstd, float* scale,
                                    float* shift, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // one 32-lane half-wave per channel: lane k fetches slot k, the two sums are folded with shuffles (one memory
+    // round trip instead of a chain of PBSED_STAT_SLOTS dependent additions behind their loads)
+    static_assert(PBSED_STAT_SLOTS == 32, "half-wave per channel");
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, k = threadIdx.x & 31;
     double s1 = 0, s2 = 0;
-    for (int k = 0; k < PBSED_STAT_SLOTS; ++k) { s1 += sums[((size_t)k * C + c) * 2]; s2 += sums[((size_t)k * C + c) * 2 + 1]; }
+    if (c < C) { s1 = sums[((size_t)k * C + c) * 2]; s2 = sums[((size_t)k * C + c) * 2 + 1]; }
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (c >= C || k != 0) return;
     const double m = s1 / count;
     double var = s2 / count - m * m;
     if (var < 0) var = 0;
@@ -444,7 +449,7 @@ int pbsed_pack_conv_weights_batched(const void* descs, int n, void* stream) {
 int pbsed_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
                       float momentum, float* running_mean, float* running_power, float* mean,
                       float* invstd, float* scale, float* shift, int C, void* stream) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C * 32 + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums,
                        count, gamma, beta, eps, momentum, running_mean, running_power, mean, invstd, scale,
                        shift, C);
     return check_launch("bn_finalize");
