@@ -15,6 +15,8 @@ bad = 0
 for case in range(n_cases):
     b = int(rng.choice([1, 2, 3, 5, 8, 17]))
     n = int(rng.integers(25, 160)) * 320 + int(rng.integers(0, 320))
+    if os.environ.get('FUZZ_LONG'):                # long clips: 20 .. 60 s
+        n = int(rng.integers(1000, 3000)) * 320 + int(rng.integers(0, 320)); b = min(b, 3)
     hidden = int(rng.choice([64, 128]))
     ragged = bool(rng.random() < .7)
     if rng.random() < .4:                          # tag-conditioned BiCRNN (bidirectional GRU layers as one-layer scans)
