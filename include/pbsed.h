@@ -176,7 +176,9 @@ int pbsed_fbcrnn_loss(const float* logit_fwd, const float* logit_bwd, const floa
                       const float* boundary_targets, const float* class_weights, const int* seq_len,
                       float* y_fwd, float* y_bwd, float* dlogit_fwd, float* dlogit_bwd, float* loss, int B, int K,
                       int T, float minimum_score, float strong_weight, int slat, float label_smoothing,
-                      int inputs_are_scores, void* stream);
+                      int inputs_are_scores, float* summary /* optional [3*B*K + 1]: weak-label mask, masked weak targets,
+                      clip-level scores y_fwd[L-1] (/2 + y_bwd[0]/2), boundary label rate (CRNN.review's host side) */,
+                      void* stream);
 int pbsed_bicrnn_loss(const float* logit, const float* strong_targets, const int* seq_len, float* y,
                       float* dlogit, float* loss, double* scratch, int B, int K, int T, int inputs_are_scores,
                       void* stream);

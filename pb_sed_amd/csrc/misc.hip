@@ -192,6 +192,7 @@ struct FbLossArgs {
     int B, K, T, slat;
     float eps, lambda, ls;
     int prob_in;           // 1: lf/lb already hold squashed scores y, gradients are wrt y
+    float* summary;        // optional [3*B*K + 1]: weak mask, masked weak targets, clip-level scores, boundary label rate
 };
 
 __device__ __forceinline__ float bce_f(float p, float t) {
@@ -243,6 +244,26 @@ __global__ __launch_bounds__(256) void fbcrnn_loss_kernel(FbLossArgs a) {
     if (tid == 0) {
         float s = 0.f; for (int i = 0; i < (int)blockDim.x / 64; ++i) s += red[i];
         s_rowok = (strong && (s / (float)T > .999f) && (w > .99f)) ? 1.f : 0.f;
+        if (a.summary) {
+            // what CRNN.review hands to the host (reference crnn.py:120-137,155-177): the weak-label mask, the masked
+            // weak targets, the clip-level score y_fwd[L-1] (averaged with y_bwd[0] if there is a backward head) and
+            // the share of frames whose boundary targets count, summed over rows
+            const int BK = a.B * a.K;
+            float yw = 0.f;
+            if (L > 0) {
+                const float sc_ = 1.f - 2.f * a.eps;
+                const float vf = a.prob_in ? lf[L - 1] : a.eps + sc_ / (1.f + expf(-lf[L - 1]));
+                yw = vf;
+                if (lb) {
+                    const float vb = a.prob_in ? lb[0] : a.eps + sc_ / (1.f + expf(-lb[0]));
+                    yw = vf / 2.f + vb / 2.f;
+                }
+            }
+            a.summary[row] = wm ? 1.f : 0.f;
+            a.summary[BK + row] = w;
+            a.summary[2 * BK + row] = yw;
+            if (s_rowok > 0.f) atomicAdd(&a.summary[3 * BK], s / ((float)BK * (float)T));
+        }
         if (strong) for (int t = 1; t < T; ++t) tf[t] = fmaxf(tf[t], tf[t - 1]);
     }
     if (tid == 64 && strong) for (int t = T - 2; t >= 0; --t) tb[t] = fmaxf(tb[t], tb[t + 1]);
@@ -501,11 +522,12 @@ int pbsed_fbcrnn_loss(const float* logit_fwd, const float* logit_bwd, const floa
                       const float* boundary_targets, const float* class_weights, const int* seq_len,
                       float* y_fwd, float* y_bwd, float* dlogit_fwd, float* dlogit_bwd, float* loss,
                       int B, int K, int T, float minimum_score, float strong_weight, int slat,
-                      float label_smoothing, int inputs_are_scores, void* stream) {
+                      float label_smoothing, int inputs_are_scores, float* summary, void* stream) {
     FbLossArgs a{logit_fwd, logit_bwd, weak_targets, boundary_targets, class_weights, seq_len, y_fwd, y_bwd,
                  dlogit_fwd, dlogit_bwd, loss, B, K, T, slat, minimum_score, strong_weight, label_smoothing,
-                 inputs_are_scores};
+                 inputs_are_scores, summary};
     hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream);
+    if (summary) hipMemsetAsync(summary + (size_t)3 * B * K, 0, sizeof(float), (hipStream_t)stream);
     hipLaunchKernelGGL(fbcrnn_loss_kernel, dim3(B * K), dim3(256), 2 * T * sizeof(float), (hipStream_t)stream, a);
     return check_launch("fbcrnn_loss");
 }

@@ -66,7 +66,7 @@ class _LossFunction(torch.autograd.Function):
             y_fwd.contiguous(), None if y_bwd is None else y_bwd.contiguous(), weak, bnd, seq_dev,
             minimum_score=cfg['minimum_score'], strong_weight=cfg['strong_weight'], slat=cfg['slat'],
             label_smoothing=cfg['label_smoothing'], class_weights=cfg['class_weights'],
-            inputs_are_scores=True)
+            inputs_are_scores=True, summary=cfg.get('summary'))
         ctx.grads = (d_f, d_b)
         return loss
 
@@ -163,25 +163,13 @@ class CRNN(SoundEventModel):
         cfg = dict(minimum_score=self.minimum_score, strong_weight=self.strong_fwd_bwd_loss_weight,
                    slat=self.slat, label_smoothing=self.label_smoothing,
                    class_weights=None if self.class_weights is None else self.class_weights.to(y_fwd.device))
+        # summary side (host): same buffers / scalars as the reference (crnn.py:122,137,155-177), written by the loss
+        # launch itself and fetched with ONE device->host transfer instead of the reference's five separate .cpu() syncs
+        b, k = weak_targets.shape
+        packed_dev = torch.empty(3 * b * k + 1, device=y_fwd.device, dtype=torch.float32)
+        cfg['summary'] = packed_dev
         loss = _LossFunction.apply(y_fwd, y_bwd, weak_targets, bnd, seq_dev, cfg)
-
-        # summary side (host): same buffers / scalars as the reference (crnn.py:122,137,155-177), gathered with
-        # ONE device->host transfer instead of the reference's five separate .cpu() syncs
         with torch.no_grad():
-            w_mask = (weak_targets < .01) | (weak_targets > .99)
-            w = weak_targets * w_mask
-            b, k = w.shape
-            idx = engine.seq_to_device(np.asarray(seq_len) - 1, y_fwd.device).long()
-            y_weak = y_fwd.detach()[torch.arange(b, device=y_fwd.device), :, idx]
-            if y_bwd is not None:
-                y_weak = y_weak / 2 + y_bwd.detach()[..., 0] / 2
-            blr = torch.zeros((), device=w.device)
-            if self.strong_fwd_bwd_loss_weight > 0.:
-                beta = w[..., None].expand(y_fwd.shape) if self.slat else bnd
-                b_mask = (beta > .99) | (beta < .01)
-                b_mask = b_mask * (b_mask.float().mean(-1, keepdim=True) > .999) * (w > .99)[..., None]
-                blr = b_mask.float().mean()
-            packed_dev = torch.cat([w_mask.float().reshape(-1), w.reshape(-1), y_weak.reshape(-1), blr.reshape(1)])
             host = torch.empty(packed_dev.shape, dtype=packed_dev.dtype, pin_memory=True)
             host.copy_(packed_dev, non_blocking=True)
             copied = torch.cuda.Event()

@@ -474,7 +474,9 @@ def squash_bwd(y, dy, eps):
 
 def fbcrnn_loss(logit_fwd, logit_bwd, weak_targets, boundary_targets, seq_len, *, minimum_score=1e-5,
                 strong_weight=1., slat=False, label_smoothing=0., class_weights=None, want_grad=True,
-                inputs_are_scores=False):
+                inputs_are_scores=False, summary=None):
+    """``summary``: optional float32 [3*B*K + 1] device buffer the same launch fills with what CRNN.review reports to
+    the host (weak-label mask, masked weak targets, clip-level scores, boundary label rate)."""
     b, k, t = logit_fwd.shape
     dev = logit_fwd.device
     y_f = torch.empty_like(logit_fwd)
@@ -486,7 +488,7 @@ def fbcrnn_loss(logit_fwd, logit_bwd, weak_targets, boundary_targets, seq_len, *
     bnd_c = None if boundary_targets is None else boundary_targets.contiguous()
     call('pbsed_fbcrnn_loss', ptr(logit_fwd), ptr(logit_bwd), ptr(weak_c), ptr(bnd_c), ptr(class_weights),
          ptr(seq_len), ptr(y_f), ptr(y_b), ptr(d_f), ptr(d_b), ptr(loss), b, k, t, float(minimum_score),
-         float(strong_weight), int(slat), float(label_smoothing), int(inputs_are_scores), stream())
+         float(strong_weight), int(slat), float(label_smoothing), int(inputs_are_scores), ptr(summary), stream())
     return loss, y_f, y_b, d_f, d_b
 
 

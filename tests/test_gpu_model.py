@@ -108,6 +108,10 @@ def test_fbcrnn_train_step_parity(cfg):
     assert (out[1].cpu() - out_ref[1]).abs().max() < 1e-4, 'y_bwd'
     assert rev['loss'].item() == pytest.approx(rev_ref['loss'].item(), rel=1e-4)
     np.testing.assert_allclose(rev['buffers']['y_weak'], rev_ref['buffers']['y_weak'], atol=1e-4)
+    # the rest of the summary the loss launch writes for the host (reference crnn.py:122,137,155-177)
+    np.testing.assert_array_equal(rev['buffers']['targets_weak'], np.asarray(rev_ref['buffers']['targets_weak']))
+    for key in ('weak_label_rate', 'boundary_label_rate'):
+        assert float(rev['scalars'][key]) == pytest.approx(float(rev_ref['scalars'][key]), abs=1e-6), key
     refp, refp32 = dict(ref64.named_parameters()), dict(ref.named_parameters())
     bad = []
     for name, p in model.named_parameters():
