@@ -1,7 +1,7 @@
 """Oracle: FBCRNN / BiCRNN forward, losses and inference heads restated (CPU, stock torch).
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  The maths below is reference-OWNED and is
-pinned by ``tests/golden/ref_*.npz`` (reference source executed under shims, tools/gen_golden.py):
+pinned by ``tests/golden/ref_*.npz`` (reference source executed under shims, tests/golden/gen_golden.py):
 * FBCRNN: pb_sed/models/weak_label/crnn.py:58-100 (forward), :107-206 (losses), :223-302 (heads)
 * BiCRNN: pb_sed/models/strong_label/crnn.py:60-93 (forward), :106-112 (loss), :200-210 (heads)
 Architecture constants: pb_sed/experiments/weak_label_crnn/training.py:158-260,

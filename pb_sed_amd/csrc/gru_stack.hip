@@ -780,7 +780,7 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
 // Returns false when an XCD could not hold all of its blocks at once: the round-robin dispatch gives XCD x the blocks
 // with id % 8 = x, i.e. `slots` blocks each, and a scan only makes progress if every active block of it is resident -
 // with one (12-wave, register-heavy) block per CU a ring pinned to an XCD can fill its 32 CUs and lock the projection
-// blocks of that XCD out (found by tools/fuzz_gru.py: H = 512, B = 16).  The caller then keeps the 3-D grid, whose
+// blocks of that XCD out (found by tests/sweeps/fuzz_gru.py: H = 512, B = 16).  The caller then keeps the 3-D grid, whose
 // blocks spread evenly over the XCDs.
 static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid) {
     static int cus_per_xcd = 0;

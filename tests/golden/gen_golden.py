@@ -8,7 +8,7 @@ pinned is therefore the reference-OWNED code:  pb_sed/models/weak_label/crnn.py 
 heads), pb_sed/models/strong_label/crnn.py (review), pb_sed/filters.py,
 pb_sed/models/base/inference.py (inference, filtering, boundariesfilt), pb_sed/evaluation/instance_based.py.
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py   ->  tests/golden/ref_*.npz
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py   ->  tests/golden/ref_*.npz
 No reference source is copied; only input/output arrays are stored.
 """
 import importlib.abc
@@ -18,7 +18,7 @@ import sys
 import types
 
 sys.dont_write_bytecode = True
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 
 import numpy as np

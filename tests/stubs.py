@@ -1,5 +1,5 @@
 """Tiny deterministic stand-ins for feature extractor / CNN / RNN used to pin the reference's
-inference heads (tools/gen_golden.py) and to replay them against the oracle / product classes."""
+inference heads (tests/golden/gen_golden.py) and to replay them against the oracle / product classes."""
 import torch
 
 

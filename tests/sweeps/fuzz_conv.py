@@ -2,7 +2,7 @@
 BN-backward epilogue, weight / bias gradient) against torch on the CPU in float64: odd T and F, channel counts that are
 not multiples of the tiles, pooled and un-pooled layers, direct and Winograd kernels.  Usage: fuzz_conv.py [cases] [seed]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import torch.nn.functional as F
 from pb_sed_amd import ops

@@ -1,7 +1,7 @@
 """Randomised sweep of the FBCRNN inference heads (tagging, boundaries detection, windowed sound event detection with
 scalar and per-class window lengths) against the oracle in eval mode: random batch, clip length, window length / shift."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import frontend as ofe, models as om
 from pb_sed_amd.models import weak_label

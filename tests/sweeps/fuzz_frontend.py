@@ -1,7 +1,7 @@
 """Randomised clip-length sweep of the fused STFT -> mel -> log front-end against the oracle (reuses
 tests/test_gpu_ops.py::test_logmel_vs_oracle): lengths from less than one frame shift to 12.5 s, batch 1..3."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tests import test_gpu_ops as T
 

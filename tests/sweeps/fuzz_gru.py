@@ -2,7 +2,7 @@
 launch-per-step fallback) against torch.nn.GRU through the oracle wrapper: reuses the body of
 tests/test_gpu_ops.py::test_gru_stack_wavefront_vs_torch.  Usage: fuzz_gru.py [cases] [seed]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, pytest
 from tests import test_gpu_ops as T
 from pb_sed_amd import ops as _ops

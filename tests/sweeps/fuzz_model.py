@@ -2,7 +2,7 @@
 CPU: features, both score tensors, loss and the gradient in the L2 sense.  Clip lengths give odd frame counts (T not a
 multiple of 4 or of the kernels' tiles).  Usage: fuzz_model.py [cases] [seed]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import frontend as ofe, models as om
 from pb_sed_amd.models import weak_label, strong_label

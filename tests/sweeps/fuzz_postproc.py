@@ -2,7 +2,7 @@
 (bit-exact for the median filter, 1e-15 for the f64 boundaries filter): random [clips, classes, frames] shapes and
 per-class filter lengths incl. lengths above the sequence length.  Usage: fuzz_postproc.py [cases] [seed]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import postproc as pp
 from pb_sed_amd import ops, inference as inf

@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import nn as onn, models as om          # noqa: E402
 from pb_sed_amd import engine, modules               # noqa: E402
 

@@ -1,4 +1,4 @@
-"""Short fixed-seed runs of the randomised shape sweeps in tools/ (separate processes: the library reads its switches
+"""Short fixed-seed runs of the randomised shape sweeps in tests/sweeps/ (separate processes: the library reads its switches
 once per process and a failed scan must not leak state into other tests)."""
 import os
 import subprocess
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize('tool,args', [('fuzz_conv.py', ['30', '11']), ('fuzz_gru.py', ['10', '12']),
                                        ('fuzz_postproc.py', ['24', '13']), ('fuzz_frontend.py', ['12', '14'])])
 def test_randomised_sweep(tool, args):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', tool), *args], capture_output=True, text=True,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'sweeps', tool), *args], capture_output=True, text=True,
                          timeout=600, cwd=ROOT)
     text = out.stdout + out.stderr
     assert out.returncode == 0, text[-2000:]

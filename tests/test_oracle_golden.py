@@ -1,5 +1,5 @@
 """Pin the oracle's restatement of reference-OWNED maths against golden vectors produced by the
-reference's own source (tools/gen_golden.py -> tests/golden/ref_*.npz)."""
+reference's own source (tests/golden/gen_golden.py -> tests/golden/ref_*.npz)."""
 import ast
 
 import numpy as np
@@ -139,7 +139,7 @@ def test_event_extraction_internal():
 # ------------------------------------------------------------------ validation metrics
 def test_instance_based_metrics_match_reference(golden):
     """pb_sed_amd.evaluation.instance_based against vectors produced by executing the reference's
-    pb_sed/evaluation/instance_based.py (tools/gen_golden.py: gen_instance_based): threshold searches with and without
+    pb_sed/evaluation/instance_based.py (tests/golden/gen_golden.py: gen_instance_based): threshold searches with and without
     ties, rate constraints, beta / bias arguments (honoured for vectors, ignored for matrices exactly as the reference
     does), binary-decision metrics, lwlrap, and the module's own docstring example."""
     from pb_sed_amd.evaluation import instance_based as ib
@@ -185,7 +185,7 @@ def test_instance_based_metrics_match_reference(golden):
 
 def test_summary_metrics_match_reference(golden):
     """SoundEventModel.add_metrics_to_summary of the build against the scalars the reference's own method produced
-    (tools/gen_golden.py: gen_summary_metrics): label subsets by index and by name, label-wise keys, and the
+    (tests/golden/gen_golden.py: gen_summary_metrics): label subsets by index and by name, label-wise keys, and the
     mAP / mAUC branch that is skipped when a class has a single positive."""
     from pb_sed_amd.models import base
     g = golden('ref_summary_metrics.npz')
