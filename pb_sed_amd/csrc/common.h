@@ -54,4 +54,14 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// runtime calls in front of a launch (attributes, memsets): report a failure like a failed launch
+#define PBSED_HIP_TRY(expr, what)                                               \
+    do {                                                                        \
+        const hipError_t pbsed_e_ = (expr);                                     \
+        if (pbsed_e_ != hipSuccess) {                                           \
+            set_error("%s: %s", what, hipGetErrorString(pbsed_e_));             \
+            return PBSED_E_HIP;                                                 \
+        }                                                                       \
+    } while (0)
+
 }  // namespace pbsed

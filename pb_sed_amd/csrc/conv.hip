@@ -231,8 +231,8 @@ static int launch_cfg(const ConvFwdArgs& a, hipStream_t s) {
     auto kern = conv_fwd_kernel<COUT_T, FT, TT, KH, KW, CK, POOL, DGRAD>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        PBSED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);

@@ -215,7 +215,7 @@ static int launch_b(const ConvFwdArgs& a, const unsigned short* wpb, hipStream_t
     auto kern = conv_bf16_kernel<FT, TT, KH, KW, NSPLIT, POOL, DGRAD>;
     static bool attr_set = false;
     if (!attr_set && C::LDS_BYTES > 48 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        PBSED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES), "hipFuncSetAttribute");
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, a, wpb);

@@ -318,7 +318,7 @@ static int launch_wgrad_cfg(Kern kern, const ConvWgradArgs& a_in, hipStream_t s)
     static int slots = 0;
     if (slots == 0) {
         if (lds > 48 * 1024)
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            PBSED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
         int occ = 0, dev = 0, n_cu = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
@@ -341,7 +341,7 @@ static int launch_wgrad_cfg(Kern kern, const ConvWgradArgs& a_in, hipStream_t s)
     float* scratch = (slot_ok && split >= 4 * WGRAD_SLOTS) ? wgrad_slot_scratch() : nullptr;
     if (scratch) {
         const int stride = (nw + nb + 63) / 64 * 64;
-        hipMemsetAsync(scratch, 0, sizeof(float) * WGRAD_SLOTS * stride, s);
+        PBSED_HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(float) * WGRAD_SLOTS * stride, s), "hipMemsetAsync");
         a.dw = scratch; a.db = a_in.db ? scratch + nw : nullptr;
         a.nslots = WGRAD_SLOTS; a.slot_w = stride; a.slot_b = stride;
         hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, s, a);

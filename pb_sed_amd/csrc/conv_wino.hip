@@ -426,7 +426,7 @@ static int launch_wino(const ConvFwdArgs& a, hipStream_t s) {
     auto kern = conv_wino_kernel<POOL, DGRAD>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        PBSED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);

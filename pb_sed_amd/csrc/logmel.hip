@@ -145,8 +145,8 @@ extern "C" int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, c
                        4 * 2 * 512 * sizeof(cpx) + (size_t)F * (LM_FR + 1) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        PBSED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
         attr_set = true;
     }
     hipLaunchKernelGGL(logmel_kernel, dim3(B * nTt), dim3(256), lds, (hipStream_t)stream, a);

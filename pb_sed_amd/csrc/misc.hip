@@ -526,7 +526,7 @@ int pbsed_fbcrnn_loss(const float* logit_fwd, const float* logit_bwd, const floa
     FbLossArgs a{logit_fwd, logit_bwd, weak_targets, boundary_targets, class_weights, seq_len, y_fwd, y_bwd,
                  dlogit_fwd, dlogit_bwd, loss, B, K, T, slat, minimum_score, strong_weight, label_smoothing,
                  inputs_are_scores, summary};
-    hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream);
+    PBSED_HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream), "hipMemsetAsync");
     if (summary) hipMemsetAsync(summary + (size_t)3 * B * K, 0, sizeof(float), (hipStream_t)stream);
     hipLaunchKernelGGL(fbcrnn_loss_kernel, dim3(B * K), dim3(256), 2 * T * sizeof(float), (hipStream_t)stream, a);
     return check_launch("fbcrnn_loss");
@@ -536,8 +536,8 @@ int pbsed_bicrnn_loss(const float* logit, const float* strong_targets, const int
                       float* dlogit, float* loss, double* scratch, int B, int K, int T,
                       int inputs_are_scores, void* stream) {
     BiLossArgs a{logit, strong_targets, seq_len, y, dlogit, loss, scratch, B, K, T, inputs_are_scores};
-    hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream);
-    hipMemsetAsync(scratch, 0, sizeof(double), (hipStream_t)stream);
+    PBSED_HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream), "hipMemsetAsync");
+    PBSED_HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(double), (hipStream_t)stream), "hipMemsetAsync");
     const size_t total = (size_t)B * K * T;
     hipLaunchKernelGGL(bicrnn_mask_count_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(bicrnn_loss_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, a);
@@ -555,7 +555,7 @@ int pbsed_squash_bwd(const float* y, const float* dy, float* dx, size_t n, float
 }
 
 int pbsed_grad_sumsq(const float* g, size_t n, double* out, void* stream) {
-    hipMemsetAsync(out, 0, sizeof(double), (hipStream_t)stream);
+    PBSED_HIP_TRY(hipMemsetAsync(out, 0, sizeof(double), (hipStream_t)stream), "hipMemsetAsync");
     hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks(n / 4 + 1, 256, 256)), dim3(256), 0, (hipStream_t)stream, g, n, out);
     return check_launch("grad_sumsq");
 }
