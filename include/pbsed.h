@@ -7,6 +7,9 @@
  *     retains them; `stream` is a hipStream_t (NULL = default stream); every call is asynchronous.
  *   - activations use the reference layouts: 2-D [B, C, F, T], 1-D [B, C, T] (passed as F = 1);
  *     GRU scan buffers are time-major [T, B, *].
+ *   - one-time kernel attributes are set per device ordinal, so one process may drive several GPUs; calls for ONE
+ *     device must come from one host thread / stream at a time (scratch such as the weight-gradient partial slots
+ *     and the persistent-scan workspaces is per device, not per stream).
  *   - every function returns 0 on success or a negative PBSED_E_* code; pbsed_last_error() returns the
  *     thread-local message.  No C++ exception crosses the boundary.
  */
@@ -36,12 +39,32 @@ int pbsed_version(void);
 int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, const int* seq_len_frames,
                      const float* window, const float* twiddle, const int* mel_start, const int* mel_len,
                      const int* mel_off, const float* mel_w, int F, const float* mean, const float* inv_std,
-                     float eps, float clampv, float* out, void* stream);
+                     float eps, float clampv, float* out, double* stats, void* stream);
+/* `stats` (both front-end entry points): NULL, or [PBSED_STAT_SLOTS][F][2] zeroed doubles that receive the per-mel sum
+ * and sum of squares of the values written for frames < seq_len - the training-mode statistics pass of the feature
+ * normalisation (call with mean = 0, inv_std = 1, clampv = inf, then pbsed_feature_norm_update, then
+ * pbsed_augment_logmel(mean, inv_std, clampv) to normalise in place).
+ * The reference's own input contract: inputs['stft'] [B,1,T,bins,2] fp32 complex STFT computed by the CPU data loader
+ * (pb_sed/models/weak_label/crnn.py:31,79-83 pops it; feature extractor call :86-90) -> |X|^2 -> sparse mel -> log ->
+ * (x - mean) * inv_std -> clamp -> frames >= seq_len zeroed -> out [B, 1, F, T].  Same tables as pbsed_logmel_fwd. */
+int pbsed_logmel_from_stft(const float* stft, int B, int T, int bins, const int* seq_len_frames,
+                           const int* mel_start, const int* mel_len, const int* mel_off, const float* mel_w,
+                           int F, const float* mean, const float* inv_std, float eps, float clampv,
+                           float* out, double* stats, void* stream);
+/* Cumulative statistics of NormalizedLogMelExtractor's Normalization(statistics_axis='bt', momentum=None) (config
+ * pb_sed/experiments/weak_label_crnn/training.py:190-217): running_mean / running_power [F] over all `num_tracked`
+ * valid (clip, frame) positions so far are advanced by this batch's `count` positions with sums `stats`; mean and
+ * inv_std = 1/sqrt(power - mean^2 + eps) [F] are what the normalising pass applies. */
+int pbsed_feature_norm_update(const double* stats, double count, float* running_mean, float* running_power,
+                              double* num_tracked, float eps, float* mean, float* inv_std, int F, void* stream);
 /* Training-only feature augmentation (NormalizedLogMelExtractor config, pb_sed/experiments/weak_label_crnn/
- * training.py:209-216): x [B,F,T] in place; x += noise_scale[b] * noise (noise may be NULL), then the time mask
- * [masks[b][0], masks[b][1]) and the frequency mask [masks[b][2], masks[b][3]) are zeroed, then frames >= seq_len[b]. */
+ * training.py:209-216): x [B,F,T] in place; if mean != NULL first x = clamp((x - mean[f]) * inv_std[f], +-clampv) (the
+ * normalisation of a statistics-tracking pass); x += noise_scale[b] * noise (noise may be NULL), then the time mask
+ * [masks[b][0], masks[b][1]) and the frequency mask [masks[b][2], masks[b][3]) are zeroed (masks may be NULL), then
+ * frames >= seq_len[b]. */
 int pbsed_augment_logmel(float* x, const float* noise, const float* noise_scale, const int* masks /*[B][4]*/,
-                         const int* seq_len, int B, int F, int T, void* stream);
+                         const int* seq_len, const float* mean, const float* inv_std, float clampv,
+                         int B, int F, int T, void* stream);
 
 /* ---- convolutions (CNN2d 3x3 / CNN1d k=1,3 / GRU input projections / heads): the `self.cnn(...)`,
  * `self.rnn_*` op sites pb_sed/models/weak_label/crnn.py:93,61-67; layer list

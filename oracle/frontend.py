@@ -94,15 +94,16 @@ def compute_mask(x, seq_len, batch_axis=0, sequence_axis=-1):
 
 
 class LogMelExtractor(torch.nn.Module):
-    """Eval-mode NormalizedLogMelExtractor: [B,1,T,513,2] -> [B,1,F,T].
+    """NormalizedLogMelExtractor restated: [B,1,T,513,2] -> [B,1,F,T].
 
-    Normalisation statistics are explicit buffers ``mean[F]``, ``inv_std[F]`` (global
-    per-mel-bin statistics); augmentation (mel warping, masks, noise) is
-    training-only in the reference and out of scope here.
+    Eval mode (or ``freeze_stats``) normalises with the explicit buffers ``mean[F]``, ``inv_std[F]``.  Training mode
+    follows SURVEY A.3: padertorch ``Normalization(statistics_axis='bt', momentum=None, eps=1e-5)`` - per-mel mean and
+    power accumulated cumulatively over every valid (clip, frame) seen so far, updated with the current batch and
+    then used for the normalisation (parity unpinned: padertorch is absent).  Augmentation is ``augment`` below.
     """
 
     def __init__(self, sample_rate=16000, stft_size=FFT_SIZE, number_of_filters=128,
-                 lowest_frequency=50.0, highest_frequency=None, eps=1e-18, clamp=6.0):
+                 lowest_frequency=50.0, highest_frequency=None, eps=1e-18, clamp=6.0, norm_eps=1e-5):
         super().__init__()
         self.stft_size = stft_size
         self.number_of_filters = number_of_filters
@@ -111,14 +112,34 @@ class LogMelExtractor(torch.nn.Module):
         fb = get_fbanks(sample_rate, stft_size, number_of_filters, lowest_frequency,
                         highest_frequency)
         self.register_buffer('fbanks', torch.from_numpy(fb))
+        self.norm_eps = norm_eps
+        self.freeze_stats = False
+        self.register_buffer('running_mean', torch.zeros(number_of_filters))
+        self.register_buffer('running_power', torch.ones(number_of_filters))
+        self.register_buffer('num_tracked_values', torch.zeros(1, dtype=torch.float64))
         self.register_buffer('mean', torch.zeros(number_of_filters))
         self.register_buffer('inv_std', torch.ones(number_of_filters))
+
+    def _track(self, logmel, seq_len):
+        m = compute_mask(logmel, seq_len).double()
+        lm = logmel.double() * m
+        n = m[:, 0, 0].sum()                                      # valid (clip, frame) positions
+        s, q = lm.sum((0, 1, 3)), (lm * lm).sum((0, 1, 3))
+        n0 = self.num_tracked_values.double()
+        mu = (n0 * self.running_mean.double() + s) / (n0 + n)
+        pw = (n0 * self.running_power.double() + q) / (n0 + n)
+        self.running_mean.copy_(mu), self.running_power.copy_(pw)
+        self.num_tracked_values.copy_(n0 + n)
+        self.mean.copy_(mu)
+        self.inv_std.copy_(1. / torch.sqrt((pw - mu * mu).clamp_min(0.) + self.norm_eps))
 
     @torch.no_grad()
     def forward(self, x, seq_len=None, targets=None):
         power = (x.to(self.fbanks.dtype) ** 2).sum(-1)          # [B,1,T,bins] (f32; f64 if .double())
         mel = power @ self.fbanks.T                               # [B,1,T,F]
         logmel = torch.log(mel + self.eps).transpose(-1, -2)     # [B,1,F,T]
+        if self.training and not self.freeze_stats:
+            self._track(logmel, seq_len)
         y = (logmel - self.mean[:, None]) * self.inv_std[:, None]
         if self.clamp is not None:
             y = torch.clamp(y, -self.clamp, self.clamp)

@@ -64,4 +64,21 @@ int check_launch(const char* what);
         }                                                                       \
     } while (0)
 
+// One-time kernel setup (opt-in to > 48 KB of dynamic LDS) is per DEVICE, not per process: a bit per device ordinal
+// in a per-call-site mask, so a process driving several GPUs through the C-ABI sets the attribute on each of them.
+#define PBSED_DYN_LDS_ONCE(kern, bytes)                                                                         \
+    do {                                                                                                        \
+        static unsigned long long pbsed_mask_ = 0ull;                                                           \
+        int pbsed_dev_ = 0;                                                                                     \
+        PBSED_HIP_TRY(hipGetDevice(&pbsed_dev_), "hipGetDevice");                                                \
+        const unsigned long long pbsed_bit_ = 1ull << (pbsed_dev_ & 63);                                        \
+        if (!(__atomic_load_n(&pbsed_mask_, __ATOMIC_ACQUIRE) & pbsed_bit_)) {                                  \
+            if ((size_t)(bytes) > 48 * 1024)                                                                    \
+                PBSED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                          \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)),    \
+                              "hipFuncSetAttribute");                                                           \
+            __atomic_fetch_or(&pbsed_mask_, pbsed_bit_, __ATOMIC_RELEASE);                                      \
+        }                                                                                                       \
+    } while (0)
+
 }  // namespace pbsed

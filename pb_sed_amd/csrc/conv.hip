@@ -229,12 +229,7 @@ static int launch_cfg(const ConvFwdArgs& a, hipStream_t s) {
     dim3 grid(nTt * nFt * a.B, a.CoutP / COUT_T);
     const size_t lds = C::LDS_FLOATS * sizeof(float);
     auto kern = conv_fwd_kernel<COUT_T, FT, TT, KH, KW, CK, POOL, DGRAD>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        PBSED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
-        attr_set = true;
-    }
+    PBSED_DYN_LDS_ONCE(kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     return check_launch("conv_fwd");
 }

@@ -213,11 +213,7 @@ static int launch_b(const ConvFwdArgs& a, const unsigned short* wpb, hipStream_t
     const int nTt = (a.T + TT - 1) / TT, nFt = (a.F + FT - 1) / FT;
     dim3 grid(nTt * nFt * a.B, a.CoutP / CB_COUT_T);
     auto kern = conv_bf16_kernel<FT, TT, KH, KW, NSPLIT, POOL, DGRAD>;
-    static bool attr_set = false;
-    if (!attr_set && C::LDS_BYTES > 48 * 1024) {
-        PBSED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES), "hipFuncSetAttribute");
-        attr_set = true;
-    }
+    PBSED_DYN_LDS_ONCE(kern, C::LDS_BYTES);
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, a, wpb);
     return check_launch("conv_bf16");
 }

@@ -315,13 +315,15 @@ static int launch_wgrad_cfg(Kern kern, const ConvWgradArgs& a_in, hipStream_t s)
     const int gy = (a.Cin + C::CIN_T - 1) / C::CIN_T;
     const int gz = (a.Cout + C::COUT_T - 1) / C::COUT_T;
     const size_t lds = C::LDS_FLOATS * sizeof(float);
-    static int slots = 0;
+    PBSED_DYN_LDS_ONCE(kern, lds);
+    static int slots_dev[64] = {0};                   // resident block slots of this kernel, per device ordinal
+    int dev = 0;
+    PBSED_HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
+    int& slots = slots_dev[dev & 63];
     if (slots == 0) {
-        if (lds > 48 * 1024)
-            PBSED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
-        int occ = 0, dev = 0, n_cu = 256;
+        int occ = 0, n_cu = 256;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, C::NT, lds) != hipSuccess || occ < 1) occ = 2;
         slots = n_cu * occ;
     }

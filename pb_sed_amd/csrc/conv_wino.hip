@@ -424,11 +424,7 @@ static int launch_wino(const ConvFwdArgs& a, hipStream_t s) {
     dim3 grid(nTt * nFt * a.B, a.CoutP / WN_CT);
     const size_t lds = C::LDS_FLOATS * sizeof(float);
     auto kern = conv_wino_kernel<POOL, DGRAD>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PBSED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
-        attr_set = true;
-    }
+    PBSED_DYN_LDS_ONCE(kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     return check_launch("conv_wino");
 }

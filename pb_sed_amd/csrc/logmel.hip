@@ -29,10 +29,26 @@ struct LogmelArgs {
     const float* inv_std;    // [F]
     const int* seq_len;      // [B] frames, or null
     float* out;              // [B][1][F][T]
-    float* stft;             // optional [B][1][T][513][2]?  (unused: never materialised)
+    double* stats;           // optional [PBSED_STAT_SLOTS][F][2]: masked sum / sum of squares of the written values
     int B, N, T, F;
     float eps, clampv;
 };
+
+// Per-mel sums of one block's output tile (frames past seq_len hold 0 and add nothing) into one of the slot copies.
+__device__ __forceinline__ void logmel_tile_stats(const float* tile, double* stats, int F, int tid) {
+    double* dst = stats + (size_t)(blockIdx.x % PBSED_STAT_SLOTS) * F * 2;
+    for (int m = tid; m < F; m += 256) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int fl = 0; fl < LM_FR; ++fl) {
+            const float v = tile[m * (LM_FR + 1) + fl];
+            s += v;
+            q = fmaf(v, v, q);
+        }
+        atomicAdd(dst + 2 * m, (double)s);
+        atomicAdd(dst + 2 * m + 1, (double)q);
+    }
+}
 
 __global__ __launch_bounds__(256) void logmel_kernel(LogmelArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -93,9 +109,71 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelArgs a) {
         }
         __syncthreads();
     }
+    if (a.stats) logmel_tile_stats(tile, a.stats, a.F, tid);
     for (int i = tid; i < a.F * LM_FR; i += 256) {
         const int m = i / LM_FR, fl = i % LM_FR;
         if (t0 + fl < a.T) a.out[((size_t)b * a.F + m) * a.T + t0 + fl] = tile[m * (LM_FR + 1) + fl];
+    }
+}
+
+// The reference's own input contract: a CPU-computed complex STFT inputs['stft'] [B,1,T,bins,2] fp32
+// (pb_sed/models/weak_label/crnn.py:31,80-83) -> |X|^2 -> sparse triangular mel -> log -> norm -> clamp -> seq mask,
+// written as [B,1,F,T] (pb_sed/models/weak_label/crnn.py:86-90).  HBM-bound: 8 B/(bin,frame) in + 4 B/(mel,frame) out.
+// Block = LM_FR frames of one clip: the re/im pairs are read as coalesced float2 rows, squared into an LDS power tile
+// [LM_FR][bins+1], each thread then owns (mel, frame) outputs; the output tile is transposed in LDS for t-contiguous stores.
+struct LogmelStftArgs {
+    const float* stft;       // [B][T][bins][2]
+    const int* mel_start;
+    const int* mel_len;
+    const int* mel_off;
+    const float* mel_w;
+    const float* mean;
+    const float* inv_std;
+    const int* seq_len;
+    float* out;              // [B][1][F][T]
+    double* stats;           // optional, as LogmelArgs::stats
+    int B, T, F, bins;
+    float eps, clampv;
+};
+
+__global__ __launch_bounds__(256) void logmel_from_stft_kernel(LogmelStftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int PS = a.bins + 1;                                    // odd row stride: frames land in different banks
+    float* P = smem;                                              // [LM_FR][PS]
+    float* tile = P + LM_FR * PS;                                 // [F][LM_FR+1]
+    const int tid = threadIdx.x;
+    const int nTt = (a.T + LM_FR - 1) / LM_FR;
+    const int b = blockIdx.x / nTt, t0 = (blockIdx.x % nTt) * LM_FR;
+    const int nfr = min(LM_FR, a.T - t0);
+    const float2* src = reinterpret_cast<const float2*>(a.stft) + ((size_t)b * a.T + t0) * a.bins;
+    const int total = nfr * a.bins;                               // the nfr frames are contiguous in memory
+    for (int i = tid; i < total; i += 256) {
+        const float2 v = src[i];
+        const int fl = i / a.bins, k = i - fl * a.bins;
+        P[fl * PS + k] = fmaf(v.x, v.x, v.y * v.y);
+    }
+    __syncthreads();
+    const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
+    for (int i = tid; i < a.F * LM_FR; i += 256) {
+        const int fl = i % LM_FR, m = i / LM_FR;                  // 16 consecutive lanes share a filter (broadcast weights)
+        float v = 0.f;
+        if (fl < nfr) {
+            const int st = a.mel_start[m], ln = a.mel_len[m];
+            const float* w = a.mel_w + a.mel_off[m];
+            const float* p = P + fl * PS + st;
+            float s = 0.f;
+            for (int j = 0; j < ln; ++j) s = fmaf(p[j], w[j], s);
+            v = (logf(s + a.eps) - a.mean[m]) * a.inv_std[m];
+            v = fminf(fmaxf(v, -a.clampv), a.clampv);
+            if (t0 + fl >= sl) v = 0.f;
+        }
+        tile[m * (LM_FR + 1) + fl] = v;
+    }
+    __syncthreads();
+    if (a.stats) logmel_tile_stats(tile, a.stats, a.F, tid);
+    for (int i = tid; i < a.F * LM_FR; i += 256) {
+        const int m = i / LM_FR, fl = i % LM_FR;
+        if (fl < nfr) a.out[((size_t)b * a.F + m) * a.T + t0 + fl] = tile[m * (LM_FR + 1) + fl];
     }
 }
 
@@ -106,29 +184,74 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelArgs a) {
 __global__ __launch_bounds__(256) void augment_logmel_kernel(float* __restrict__ x, const float* __restrict__ noise,
                                                              const float* __restrict__ noise_scale,
                                                              const int* __restrict__ masks /*[B][4]*/,
-                                                             const int* __restrict__ seq_len, int B, int F, int T) {
+                                                             const int* __restrict__ seq_len,
+                                                             const float* __restrict__ mean, const float* __restrict__ inv_std,
+                                                             float clampv, int B, int F, int T) {
     const size_t total = (size_t)B * F * T;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int t = i % T, f = (i / T) % F, b = i / ((size_t)T * F);
         float v = x[i];
+        if (mean) v = fminf(fmaxf((v - mean[f]) * inv_std[f], -clampv), clampv);   // raw log-mel of a statistics-tracking pass
         if (noise) v = fmaf(noise_scale[b], noise[i], v);
-        const int* m = masks + 4 * b;
-        const bool dropped = (t >= m[0] && t < m[1]) || (f >= m[2] && f < m[3]) || (seq_len && t >= seq_len[b]);
+        bool dropped = seq_len && t >= seq_len[b];
+        if (masks) {
+            const int* m = masks + 4 * b;
+            dropped = dropped || (t >= m[0] && t < m[1]) || (f >= m[2] && f < m[3]);
+        }
         x[i] = dropped ? 0.f : v;
     }
+}
+
+// Cumulative per-mel statistics of the feature normalisation (padertorch Normalization(momentum=None) inside
+// NormalizedLogMelExtractor): running mean / power over every valid (clip, frame) seen so far, and the
+// (mean, 1/std) pair the normalising pass uses.  One block.
+__global__ __launch_bounds__(256) void feature_norm_update_kernel(const double* __restrict__ stats, double count,
+                                                                  float* __restrict__ running_mean, float* __restrict__ running_power,
+                                                                  double* __restrict__ num_tracked, float eps,
+                                                                  float* __restrict__ mean, float* __restrict__ inv_std, int F) {
+    const double n0 = *num_tracked;
+    __syncthreads();
+    for (int m = threadIdx.x; m < F; m += blockDim.x) {
+        double s = 0., q = 0.;
+        for (int k = 0; k < PBSED_STAT_SLOTS; ++k) {
+            s += stats[((size_t)k * F + m) * 2];
+            q += stats[((size_t)k * F + m) * 2 + 1];
+        }
+        const double n1 = n0 + count;
+        const double mu = n1 > 0. ? (n0 * (double)running_mean[m] + s) / n1 : 0.;
+        const double pw = n1 > 0. ? (n0 * (double)running_power[m] + q) / n1 : 1.;
+        running_mean[m] = (float)mu;
+        running_power[m] = (float)pw;
+        mean[m] = (float)mu;
+        inv_std[m] = (float)(1. / sqrt(fmax(pw - mu * mu, 0.) + (double)eps));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *num_tracked = n0 + count;
 }
 
 }  // namespace pbsed
 
 using namespace pbsed;
 
+extern "C" int pbsed_feature_norm_update(const double* stats, double count, float* running_mean, float* running_power,
+                                         double* num_tracked, float eps, float* mean, float* inv_std, int F, void* stream) {
+    if (!stats || !running_mean || !running_power || !num_tracked || !mean || !inv_std || F < 1) {
+        set_error("feature_norm_update: null argument");
+        return PBSED_E_ARG;
+    }
+    hipLaunchKernelGGL(feature_norm_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, count, running_mean,
+                       running_power, num_tracked, eps, mean, inv_std, F);
+    return check_launch("feature_norm_update");
+}
+
 extern "C" int pbsed_augment_logmel(float* x, const float* noise, const float* noise_scale, const int* masks,
-                                    const int* seq_len, int B, int F, int T, void* stream) {
-    if (!masks || (noise && !noise_scale)) { set_error("augment_logmel: need masks, and noise_scale with noise"); return PBSED_E_ARG; }
+                                    const int* seq_len, const float* mean, const float* inv_std, float clampv,
+                                    int B, int F, int T, void* stream) {
+    if ((noise && !noise_scale) || (mean && !inv_std)) { set_error("augment_logmel: noise needs noise_scale, mean needs inv_std"); return PBSED_E_ARG; }
     const size_t total = (size_t)B * F * T;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(augment_logmel_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, (hipStream_t)stream, x, noise, noise_scale,
-                       masks, seq_len, B, F, T);
+                       masks, seq_len, mean, inv_std, clampv, B, F, T);
     return check_launch("augment_logmel");
 }
 
@@ -136,19 +259,28 @@ extern "C" int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, c
                                 const float* window, const float* twiddle, const int* mel_start,
                                 const int* mel_len, const int* mel_off, const float* mel_w, int F,
                                 const float* mean, const float* inv_std, float eps, float clampv,
-                                float* out, void* stream) {
+                                float* out, double* stats, void* stream) {
     if (F > LM_NMEL_MAX * 4 || F < 1 || T < 1) { set_error("logmel: bad F=%d T=%d", F, T); return PBSED_E_ARG; }
     LogmelArgs a{wav, window, twiddle, mel_start, mel_len, mel_off, mel_w, mean, inv_std, seq_len_frames,
-                 out, nullptr, B, n_samples, T, F, eps, clampv};
+                 out, stats, B, n_samples, T, F, eps, clampv};
     const int nTt = (T + LM_FR - 1) / LM_FR;
     const size_t lds = ((LM_FR - 1) * LM_SHIFT + LM_WIN + LM_WIN) * sizeof(float) + 1024 * sizeof(cpx) +
                        4 * 2 * 512 * sizeof(cpx) + (size_t)F * (LM_FR + 1) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PBSED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
-        attr_set = true;
-    }
+    PBSED_DYN_LDS_ONCE(logmel_kernel, lds);
     hipLaunchKernelGGL(logmel_kernel, dim3(B * nTt), dim3(256), lds, (hipStream_t)stream, a);
     return check_launch("logmel_fwd");
+}
+
+extern "C" int pbsed_logmel_from_stft(const float* stft, int B, int T, int bins, const int* seq_len_frames,
+                                      const int* mel_start, const int* mel_len, const int* mel_off, const float* mel_w,
+                                      int F, const float* mean, const float* inv_std, float eps, float clampv,
+                                      float* out, double* stats, void* stream) {
+    if (F < 1 || T < 1 || bins < 2 || B < 1) { set_error("logmel_from_stft: bad B=%d T=%d bins=%d F=%d", B, T, bins, F); return PBSED_E_ARG; }
+    const size_t lds = ((size_t)LM_FR * (bins + 1) + (size_t)F * (LM_FR + 1)) * sizeof(float);
+    if (lds > 160 * 1024) { set_error("logmel_from_stft: %d bins x %d filters need %zu B of LDS", bins, F, lds); return PBSED_E_UNSUPPORTED; }
+    LogmelStftArgs a{stft, mel_start, mel_len, mel_off, mel_w, mean, inv_std, seq_len_frames, out, stats, B, T, F, bins, eps, clampv};
+    PBSED_DYN_LDS_ONCE(logmel_from_stft_kernel, lds);
+    const int nTt = (T + LM_FR - 1) / LM_FR;
+    hipLaunchKernelGGL(logmel_from_stft_kernel, dim3(B * nTt), dim3(256), lds, (hipStream_t)stream, a);
+    return check_launch("logmel_from_stft");
 }

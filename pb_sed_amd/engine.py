@@ -376,34 +376,56 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
 
 
 # ------------------------------------------------------------------------------------- front-end
+def _tables(fe, device):
+    if fe._tables is None or fe._tables.window.device != device:
+        fe._tables = ops.LogMelTables(fe.fbanks.detach().cpu().numpy(), device)
+    return fe._tables
+
+
+def _features(fe, raw_fn, seq_dev, seq_host, n_frames):
+    """Shared driver of both front-end entry points.  Eval / frozen statistics: ONE fused launch (normalised, clamped,
+    masked).  Training with statistics tracking (the reference's NormalizedLogMelExtractor default): raw
+    log-mel + per-mel sums in the same launch -> cumulative statistics update -> normalise / clamp (+ augmentation) in
+    place.  ``raw_fn(mean, inv_std, clamp, stats)`` launches the front-end kernel."""
+    track = fe.training and not fe.freeze_stats
+    if not track:
+        x = raw_fn(fe.mean, fe.inv_std, fe.clamp, None)
+        return augment_features(fe, x, seq_dev, seq_host) if (fe.training and fe.augments) else x
+    stats = ops.feature_norm_stats(fe.number_of_filters, seq_dev.device)
+    x = raw_fn(None, None, None, stats)
+    count = float(np.minimum(np.asarray(seq_host), n_frames).sum())
+    ops.feature_norm_update(stats, count, fe)
+    return augment_features(fe, x, seq_dev, seq_host, normalise=True)
+
+
 def features_from_audio(fe, audio, seq_dev, n_frames, seq_host=None):
-    if fe._tables is None or fe._tables.window.device != audio.device:
-        fe._tables = ops.LogMelTables(fe.fbanks.detach().cpu().numpy(), audio.device)
-    x = ops.logmel_fwd(audio, fe._tables, fe.mean, fe.inv_std, n_frames, seq_dev, eps=fe.eps, clamp=fe.clamp)
-    return augment_features(fe, x, seq_dev, seq_host) if (fe.training and fe.augments) else x
-
-
-def augment_features(fe, x, seq_dev, seq_host=None):
-    """Training-only augmentation of the features (noise, time mask, frequency mask): draws on the host, one launch."""
+    tables = _tables(fe, audio.device)
     if seq_host is None:
         seq_host = seq_dev.cpu().numpy()
-    masks, scales = fe.sample_augmentation(seq_host)
-    noise = torch.randn_like(x) if scales is not None else None
-    return ops.augment_logmel(x, torch.from_numpy(masks).to(x.device), seq_dev, noise,
-                              None if scales is None else torch.from_numpy(scales).to(x.device))
+    return _features(fe, lambda mean, inv_std, clamp, stats: ops.logmel_fwd(
+        audio, tables, mean, inv_std, n_frames, seq_dev, eps=fe.eps, clamp=clamp, stats=stats), seq_dev, seq_host, n_frames)
 
 
-def features_from_stft(fe, stft, seq_host):
-    """Compatibility path for callers that still hand over the reference's CPU STFT
-    ([B,1,T,bins,2], pb_sed/models/weak_label/crnn.py:80-83).  Plain tensor ops, not a hot path."""
-    power = (stft.to(torch.float32) ** 2).sum(-1)
-    logmel = torch.log(power @ fe.fbanks.T + fe.eps).transpose(-1, -2)
-    y = (logmel - fe.mean[:, None]) * fe.inv_std[:, None]
-    if fe.clamp is not None:
-        y = y.clamp(-fe.clamp, fe.clamp)
-    t = y.shape[-1]
-    m = torch.arange(t, device=y.device)[None] < torch.as_tensor(np.asarray(seq_host), device=y.device)[:, None]
-    y = (y * m[:, None, None, :]).contiguous()
-    if fe.training and fe.augments:
-        y = augment_features(fe, y, seq_to_device(seq_host, y.device), seq_host)
-    return y
+def augment_features(fe, x, seq_dev, seq_host=None, normalise=False):
+    """Training-only second pass over the features: optional normalisation with the just-updated statistics, then the
+    augmentation of the reference's training config (noise, time mask, frequency mask; draws on the host) - one launch."""
+    masks = scales = noise = None
+    if fe.augments:
+        if seq_host is None:
+            seq_host = seq_dev.cpu().numpy()
+        masks, scales = fe.sample_augmentation(seq_host)
+        masks = torch.from_numpy(masks).to(x.device)
+        if scales is not None:
+            noise, scales = torch.randn_like(x), torch.from_numpy(scales).to(x.device)
+    return ops.augment_logmel(x, masks, seq_dev, noise, scales, fe.mean if normalise else None,
+                              fe.inv_std if normalise else None, fe.clamp if normalise else None)
+
+
+def features_from_stft(fe, stft, seq_host, seq_dev=None):
+    """The reference's own input contract: a CPU-computed complex STFT ``inputs['stft']`` [B,1,T,bins,2]
+    (pb_sed/models/weak_label/crnn.py:79-90) through ``pbsed_logmel_from_stft`` (same epilogue as the audio path)."""
+    tables = _tables(fe, stft.device)
+    if seq_dev is None:
+        seq_dev = seq_to_device(seq_host, stft.device)
+    return _features(fe, lambda mean, inv_std, clamp, stats: ops.logmel_from_stft(
+        stft, tables, mean, inv_std, seq_dev, eps=fe.eps, clamp=clamp, stats=stats), seq_dev, seq_host, stft.shape[2])

@@ -34,6 +34,8 @@ class SoundEventModel(nn.Module, abc.ABC):
         # operand format of the conv / projection MFMAs: 'f32' (default), 'bf16' (BASELINE config 3) or
         # 'bf16x3' (exact 3-way bf16 split, fp32-class accuracy); weight gradients, BN, GRU scans stay fp32
         self.conv_precision = 'f32'
+        self.keep_logits = False      # True: forward stores the pre-sigmoid head outputs in ``last_logits``
+        self.last_logits = None
 
     @abc.abstractmethod
     def tagging(self, inputs, **params):

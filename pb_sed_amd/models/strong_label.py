@@ -20,6 +20,8 @@ class _NetFunction(torch.autograd.Function):
         if tag is not None:
             h = torch.cat([h, tag.reshape(h.shape[0], -1, 1).to(h.dtype).expand(-1, -1, h.shape[-1])], dim=1).contiguous()
         logits, rnn_ctx = engine.rnn_forward([model.rnn], h, seq_dev, seq_host, training, model.conv_precision)
+        if model.keep_logits:
+            model.last_logits = [logits[0].detach().clone()]
         y = ops.squash_fwd(logits[0], 0.)
         ctx.state = (model, layers, cnn_ctx, rnn_ctx, y, n_h, seq_host, seq_dev)
         return y
@@ -83,7 +85,7 @@ class CRNN(SoundEventModel):
             audio = x_in.reshape(x_in.shape[0], -1).to(torch.float32)
             x = engine.features_from_audio(self.feature_extractor, audio, seq_dev, num_frames(audio.shape[1]), seq_host)
         else:
-            x = engine.features_from_stft(self.feature_extractor, x_in, seq_host)
+            x = engine.features_from_stft(self.feature_extractor, x_in, seq_host, seq_dev)
         targets = (inputs['weak_targets'], inputs['strong_targets']) if 'strong_targets' in inputs else None
         tag = inputs['tag_condition'].to(torch.float32) if self.tag_conditioning else None
         self._net_params = [p for p in self.parameters()]

@@ -23,6 +23,8 @@ class _NetFunction(torch.autograd.Function):
         h, cnn_ctx = engine.stack_forward(layers, x, seq_dev, seq_host, training, model.conv_precision)
         wrappers = [model.rnn_fwd] + ([model.rnn_bwd] if model.rnn_bwd is not None else [])
         logits, rnn_ctx = engine.rnn_forward(wrappers, h, seq_dev, seq_host, training, model.conv_precision)
+        if model.keep_logits:                       # pre-squash head outputs, for parity checks at the logit level
+            model.last_logits = [l.detach().clone() for l in logits]
         ys = [ops.squash_fwd(l, model.minimum_score) for l in logits]
         ctx.state = (model, layers, cnn_ctx, wrappers, rnn_ctx, ys, seq_host, seq_dev)
         ctx.mark_non_differentiable(h)
@@ -118,7 +120,7 @@ class CRNN(SoundEventModel):
             audio = inputs['audio_data']
             audio = audio.reshape(audio.shape[0], -1).to(torch.float32)
             return engine.features_from_audio(self.feature_extractor, audio, seq_dev, num_frames(audio.shape[1]), seq_host)
-        return engine.features_from_stft(self.feature_extractor, inputs['stft'], seq_host)
+        return engine.features_from_stft(self.feature_extractor, inputs['stft'], seq_host, seq_dev)
 
     def _net(self, x, seq_host, seq_dev):
         self._net_params = [p for p in self.parameters()]

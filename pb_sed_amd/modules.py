@@ -44,7 +44,7 @@ class NormalizedLogMelExtractor(nn.Module):
                  highest_frequency=None, eps=1e-18, clamp=6.0, shift=320, window_length=960,
                  n_time_masks=0, max_masked_time_steps=70, max_masked_time_rate=.2,
                  n_frequency_masks=0, max_masked_frequency_bands=20, max_masked_frequency_rate=.2,
-                 max_noise_scale=0., frequency_warping_fn=None, augmentation_seed=0):
+                 max_noise_scale=0., frequency_warping_fn=None, augmentation_seed=0, norm_eps=1e-5):
         """The augmentation fields are those of the reference's training config
         (pb_sed/experiments/weak_label_crnn/training.py:194-216); all default to off (as in the reference's class
         defaults), training scripts switch them on.  They act in training mode only."""
@@ -64,9 +64,39 @@ class NormalizedLogMelExtractor(nn.Module):
         self.shift, self.window_length, self.eps, self.clamp = shift, window_length, eps, clamp
         fb = get_fbanks(sample_rate, stft_size, number_of_filters, lowest_frequency, highest_frequency)
         self.register_buffer('fbanks', torch.from_numpy(fb))
+        # Normalisation state.  Training mode tracks cumulative per-mel statistics over every valid frame seen so far
+        # (padertorch Normalization(statistics_axis='bt', momentum=None) inside the reference's extractor, SURVEY.md
+        # A.3) and normalises with them; eval mode (or ``freeze_stats``) applies the stored ``mean`` / ``inv_std``.
+        self.norm_eps = norm_eps
+        self.register_buffer('running_mean', torch.zeros(number_of_filters))
+        self.register_buffer('running_power', torch.ones(number_of_filters))
+        self.register_buffer('num_tracked_values', torch.zeros(1, dtype=torch.float64))
         self.register_buffer('mean', torch.zeros(number_of_filters))
         self.register_buffer('inv_std', torch.ones(number_of_filters))
+        self.freeze_stats = False
         self._tables = None
+
+    def set_statistics(self, mean, std):
+        """Fixed normalisation statistics (e.g. from a data-set pass); training stops tracking."""
+        with torch.no_grad():
+            self.mean.copy_(torch.as_tensor(mean, dtype=torch.float32))
+            self.inv_std.copy_(1. / torch.as_tensor(std, dtype=torch.float32))
+        self.freeze_stats = True
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """Accept the reference's key layout: ``feature_extractor.norm.{running_mean,running_power,num_tracked_values}``
+        with the broadcast shape [1, 1, F, 1] of padertorch's Normalization, and derive ``mean`` / ``inv_std``."""
+        for name in ('running_mean', 'running_power', 'num_tracked_values'):
+            ref_key = f'{prefix}norm.{name}'
+            if ref_key in state_dict:
+                v = state_dict.pop(ref_key)
+                state_dict[prefix + name] = (v.reshape(-1)[:1].to(torch.float64) if name == 'num_tracked_values'
+                                             else v.reshape(-1).to(torch.float32))
+        if prefix + 'running_mean' in state_dict and prefix + 'mean' not in state_dict:
+            rm, rp = state_dict[prefix + 'running_mean'], state_dict[prefix + 'running_power']
+            state_dict[prefix + 'mean'] = rm.clone()
+            state_dict[prefix + 'inv_std'] = 1. / torch.sqrt((rp - rm * rm).clamp_min(0.) + self.norm_eps)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     @property
     def augments(self):

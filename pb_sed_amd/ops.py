@@ -300,14 +300,28 @@ def bn_backward(dz, x, st, stats, count, dgamma, dbeta, seq_len):
     return dz
 
 
-def augment_logmel(x, masks, seq_len, noise=None, noise_scale=None):
-    """In place: x [B,1,F,T] or [B,F,T] += noise_scale[b]*noise, then per-clip time / frequency masks (int32 [B,4] =
-    t_on, t_off, f_on, f_off) and the sequence mask."""
+def augment_logmel(x, masks, seq_len, noise=None, noise_scale=None, mean=None, inv_std=None, clamp=None):
+    """In place on x [B,1,F,T] or [B,F,T]: optional normalisation clamp((x - mean[f]) * inv_std[f]) (second half of a
+    statistics-tracking front-end pass), += noise_scale[b]*noise, per-clip time / frequency masks (int32 [B,4] = t_on,
+    t_off, f_on, f_off; None: no masks) and the sequence mask."""
     _lib.require_gpu(x)
     b, f, t = x.shape[0], x.shape[-2], x.shape[-1]
-    assert x.is_contiguous() and masks.shape == (b, 4) and masks.dtype == torch.int32
-    call('pbsed_augment_logmel', ptr(x), ptr(noise), ptr(noise_scale), ptr(masks), ptr(seq_len), b, f, t, stream())
+    assert x.is_contiguous() and (masks is None or (masks.shape == (b, 4) and masks.dtype == torch.int32))
+    call('pbsed_augment_logmel', ptr(x), ptr(noise), ptr(noise_scale), ptr(masks), ptr(seq_len), ptr(mean), ptr(inv_std),
+         float(clamp if clamp is not None else 3e38), b, f, t, stream())
     return x
+
+
+def feature_norm_stats(n_filters, device):
+    """Zeroed [PBSED_STAT_SLOTS][F][2] accumulators for the statistics pass of the front-end kernels."""
+    return _zero_stats(n_filters, device)
+
+
+def feature_norm_update(stats, count, fe):
+    """Advance the cumulative per-mel statistics of ``fe`` (modules.NormalizedLogMelExtractor) by one batch and refresh
+    its ``mean`` / ``inv_std`` buffers (all on the device, no host sync)."""
+    call('pbsed_feature_norm_update', ptr(stats), float(count), ptr(fe.running_mean), ptr(fe.running_power),
+         ptr(fe.num_tracked_values), float(fe.norm_eps), ptr(fe.mean), ptr(fe.inv_std), fe.mean.numel(), stream())
 
 
 def bct_to_tbc(x):
@@ -524,17 +538,35 @@ class LogMelTables:
         self.start, self.len, self.off = (as_dev(a, torch.int32) for a in (start, length, off))
         self.w = as_dev(w, torch.float32)
         self.n_filters = fb.shape[0]
+        self.zero = torch.zeros(self.n_filters, device=device)
+        self.one = torch.ones(self.n_filters, device=device)
 
 
-def logmel_fwd(wav, tables, mean, inv_std, n_frames, seq_len=None, eps=1e-18, clamp=6.0):
-    """wav [B, N] f32 (device) -> normalised, clamped, masked log-mel [B, 1, F, T]."""
+def logmel_fwd(wav, tables, mean, inv_std, n_frames, seq_len=None, eps=1e-18, clamp=6.0, stats=None):
+    """wav [B, N] f32 (device) -> normalised, clamped, masked log-mel [B, 1, F, T].  ``stats``: see
+    feature_norm_stats (then pass mean = inv_std = None, clamp = None to get the raw log-mel)."""
     _lib.require_gpu(wav)
     b, n = wav.shape
     out = torch.empty((b, 1, tables.n_filters, n_frames), device=wav.device, dtype=torch.float32)
     call('pbsed_logmel_fwd', ptr(wav.contiguous()), b, n, n_frames, ptr(seq_len), ptr(tables.window),
          ptr(tables.twiddle), ptr(tables.start), ptr(tables.len), ptr(tables.off), ptr(tables.w),
-         tables.n_filters, ptr(mean), ptr(inv_std), float(eps), float(clamp if clamp is not None else 3e38),
-         ptr(out), stream())
+         tables.n_filters, ptr(tables.zero if mean is None else mean), ptr(tables.one if inv_std is None else inv_std),
+         float(eps), float(clamp if clamp is not None else 3e38), ptr(out), ptr(stats), stream(),
+         nbytes=b * (n * 4 + tables.n_filters * n_frames * 4))
+    return out
+
+
+def logmel_from_stft(stft, tables, mean, inv_std, seq_len=None, eps=1e-18, clamp=6.0, stats=None):
+    """stft [B, 1, T, bins, 2] f32 (the reference's ``inputs['stft']``) -> normalised, clamped, masked log-mel [B, 1, F, T]."""
+    _lib.require_gpu(stft)
+    b, c, t, bins, two = stft.shape
+    assert c == 1 and two == 2, stft.shape
+    x = stft.to(torch.float32).contiguous()
+    out = torch.empty((b, 1, tables.n_filters, t), device=stft.device, dtype=torch.float32)
+    call('pbsed_logmel_from_stft', ptr(x), b, t, bins, ptr(seq_len), ptr(tables.start), ptr(tables.len), ptr(tables.off),
+         ptr(tables.w), tables.n_filters, ptr(tables.zero if mean is None else mean),
+         ptr(tables.one if inv_std is None else inv_std), float(eps), float(clamp if clamp is not None else 3e38),
+         ptr(out), ptr(stats), stream(), nbytes=b * t * (bins * 8 + tables.n_filters * 4))
     return out
 
 

@@ -1,0 +1,477 @@
+"""GPU parity tests at the REAL sizes of BASELINE.json's configs (the tiny-net tests live in test_gpu_model.py):
+
+* C2: 'shallow' FBCRNN, 10 s clips, B = 8 against the oracle - pre-sigmoid head outputs ("logits") within 1e-4 as the
+  north_star states, scores, loss, every parameter gradient per tensor against the oracle in float64.
+* C3: 'shallow' tag-conditioned BiCRNN (11 input channels, 266 / 512-wide Bi-GRU inputs, H = 256), B = 8 in fp32 and in
+  bf16 at a stated tolerance; B = 32 / T = 500 through size-independent properties.
+* C5: the 5-model ensemble (2 FBCRNN taggers + 3 tag-conditioned BiCRNN detectors) at batch 64 - clip independence in
+  eval mode, a 4-clip slice against the oracle (batch 64 takes the launch-per-step GRU path the smaller tests never see).
+* the reference's own ``inputs['stft']`` contract through ``pbsed_logmel_from_stft``; feature-statistics tracking.
+* the persistent GRU scan at T = 500 / H = 256 / B = 32 against ``torch.nn.GRU`` (bounds the tagged-LSB drift).
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_model import _copy_weights, rel_close, synth_batch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _randomise(ref, seed=0):
+    """Non-trivial norm / bias parameters and running statistics (a fresh model has gamma = 1, beta = bias = 0)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in ref.named_parameters():
+            if name.endswith('gamma'):
+                p.copy_(torch.empty_like(p).uniform_(.7, 1.3, generator=g))
+            elif name.endswith('beta') or name.endswith('conv.bias'):
+                p.copy_(torch.empty_like(p).normal_(0, .1, generator=g))
+        for name, buf in ref.named_buffers():
+            if name.endswith('running_mean') and 'feature_extractor' not in name:
+                buf.copy_(torch.empty_like(buf).normal_(0, .2, generator=g))
+            elif name.endswith('running_power') and 'feature_extractor' not in name:
+                buf.copy_(torch.empty_like(buf).uniform_(.8, 1.5, generator=g))
+
+
+def _sorted_batch(b, n, seed, ragged=True):
+    wav, seq, weak, tgt, t = synth_batch(b, n, 10, seed=seed, ragged=ragged)
+    order = np.argsort(-seq, kind='stable')
+    return wav[order], seq[order], weak[order], tgt[order], t
+
+
+class _Capture:
+    """Forward hook keeping a module's first output (the oracle's pre-sigmoid head output)."""
+
+    def __init__(self, module):
+        self.out = None
+        module.register_forward_hook(lambda m, i, o: setattr(self, 'out', o[0].detach()))
+
+
+def _train_step(model, inp):
+    """One forward + review + backward on a clean gradient buffer / clean statistics; returns a clone of every gradient."""
+    model.flat_parameters()[1].zero_()
+    for m_ in model.modules():
+        if hasattr(m_, 'num_tracked_values'):
+            m_.num_tracked_values.zero_()
+    out = model(dict(inp))
+    rev = model.review(inp, out)
+    rev['loss'].backward()
+    torch.cuda.synchronize()
+    return out, rev, {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+
+
+def _rounding_sensitivity(model, inp, grads):
+    """How far rounding-level input changes move each gradient tensor of the HIP path itself: the step is repeated with
+    the waveform scaled by 1 +- 2^-21 and 1 + 2^-20 (the exact gradient moves by ~1e-6 relative) and the largest
+    per-tensor max-abs difference relative to the tensor's max is returned.  At this size that is NOT ~1e-6: a conv layer
+    has 8..130 M pre-activations, a rounding-level change puts a few of them on the other side of their ReLU (or flips a
+    pool argmax), each flip switches one position's contribution on or off and moves the layer's gradient by
+    ~sqrt(flips / positions).  No fp32 implementation can be pinned below this floor, the CPU oracle included."""
+    state = {n: b.detach().clone() for n, b in model.named_buffers()}
+    noise = {n: 0. for n in grads}
+    for f in (1 + 2. ** -21, 1 - 2. ** -21, 1 + 2. ** -20):
+        model.load_state_dict(state, strict=False)
+        _, _, g = _train_step(model, dict(inp, audio_data=inp['audio_data'] * f))
+        for n in g:
+            scale = grads[n].abs().max().item()
+            if scale > 0:
+                noise[n] = max(noise[n], (g[n] - grads[n]).abs().max().item() / scale)
+    model.load_state_dict(state, strict=False)
+    return noise
+
+
+def _grad_table(grads, ref64, ref32, noise, tol=2e-3):
+    """Per-tensor max-abs gradient error relative to the tensor's max against the float64 oracle (no L2 averaging).
+    A tensor passes at ``tol``, or at 3x the rounding sensitivity of the HIP path on that tensor (see
+    _rounding_sensitivity), or at 2x what stock fp32 PyTorch on the CPU reaches on the same tensor against float64 -
+    i.e. the bar is 2e-3 wherever fp32 arithmetic allows 2e-3 at all (tools/grad_error_table.py prints the columns)."""
+    p64, p32 = dict(ref64.named_parameters()), dict(ref32.named_parameters())
+    bad, rows = [], []
+    for name, g in grads.items():
+        g64 = p64[name].grad
+        scale = g64.abs().max().item()
+        if scale < 1e-9:
+            continue                                      # bias in front of a batch norm: exactly-zero gradient
+        err = (g.cpu().double() - g64).abs().max().item() / scale
+        err32 = (p32[name].grad.double() - g64).abs().max().item() / scale
+        rows.append((err, name, err32, noise[name]))
+        if err > max(tol, 3 * noise[name], 2 * err32):
+            bad.append(f'{name}: rel err {err:.2e} (rounding sensitivity {noise[name]:.2e}, fp32 CPU oracle {err32:.2e})')
+    rows.sort(reverse=True)
+    for err, name, err32, nz in rows[:8]:
+        print(f'  {name:40s} err {err:.2e}   rounding sensitivity {nz:.2e}   fp32 CPU oracle {err32:.2e}')
+    print(f'  {sum(1 for r in rows if r[0] <= tol)} of {len(rows)} tensors within {tol:g} outright')
+    return bad
+
+
+# ------------------------------------------------------------------------------------------------ C2
+def test_c2_fbcrnn_shallow_b8_logits_loss_grads():
+    from oracle import frontend as ofe, models as om
+    from pb_sed_amd.models import weak_label
+    torch.manual_seed(0)
+    ref = om.FBCRNN.build(num_events=10)
+    _randomise(ref)
+    model = weak_label.CRNN.build(num_events=10)
+    _copy_weights(model, ref)
+    model.to(DEV).train()
+    model.keep_logits = True
+    ref64 = copy.deepcopy(ref).double().train()
+    wav, seq, weak, bnd, t = _sorted_batch(8, 160000, seed=21)
+    assert t == 500
+    cap_f, cap_b = _Capture(ref.rnn_fwd), _Capture(ref.rnn_bwd)
+    ref.train()
+    inp_ref = {'stft': ofe.stft(wav), 'seq_len': seq.tolist(), 'weak_targets': weak, 'boundary_targets': bnd}
+    out_ref = ref(inp_ref)
+    rev_ref = ref.review(inp_ref, out_ref)
+    rev_ref['loss'].backward()
+    in64 = {'stft': ofe.stft(wav).double(), 'seq_len': seq.tolist(), 'weak_targets': weak.double(),
+            'boundary_targets': bnd.double()}
+    cap64_f, cap64_b = _Capture(ref64.rnn_fwd), _Capture(ref64.rnn_bwd)
+    ref64.review(in64, ref64(in64))['loss'].backward()
+
+    inp = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV), 'boundary_targets': bnd.to(DEV)}
+    state0 = {n: b.detach().clone() for n, b in model.named_buffers()}
+    out, rev, grads = _train_step(model, inp)
+    logits = [l.clone() for l in model.last_logits]
+    buffers = {n: b.detach().clone() for n, b in model.named_buffers()}
+    model.load_state_dict(state0, strict=False)
+    noise = _rounding_sensitivity(model, inp, grads)
+    m = (torch.arange(t)[None] < torch.as_tensor(seq)[:, None])[:, None, :]        # logits past seq_len are padding
+    for name, got, want32, want64 in (('fwd', logits[0], cap_f.out, cap64_f.out), ('bwd', logits[1], cap_b.out, cap64_b.out)):
+        e = ((got.cpu() - want32) * m).abs().max().item()
+        e64 = ((got.cpu().double() - want64) * m).abs().max().item()
+        e_ref = ((want32.double() - want64) * m).abs().max().item()
+        print(f'logits {name}: |hip - cpu32| {e:.2e}  |hip - cpu64| {e64:.2e}  |cpu32 - cpu64| {e_ref:.2e}  '
+              f'(|logit| max {want32.abs().max():.2f})')
+        assert e < 1e-4, f'pre-sigmoid {name} head output differs from the CPU oracle by {e:.2e}'
+    assert (out[0].cpu() - out_ref[0]).abs().max() < 2.5e-5 and (out[1].cpu() - out_ref[1]).abs().max() < 2.5e-5
+    assert rev['loss'].item() == pytest.approx(rev_ref['loss'].item(), rel=2e-5)
+    bad = _grad_table(grads, ref64, ref, noise)
+    assert not bad, '\n'.join(bad)
+    refb = dict(ref.named_buffers())
+    for name, buf in buffers.items():
+        if 'running' in name:
+            rel_close(buf.double(), refb[name].double(), 1e-4, name)
+
+
+# ------------------------------------------------------------------------------------------------ C3
+def _bicrnn_pair(seed=2):
+    from oracle import models as om
+    from pb_sed_amd.models import strong_label
+    torch.manual_seed(seed)
+    ref = om.BiCRNN.build(num_events=10, tag_conditioning=True)
+    _randomise(ref, seed)
+    model = strong_label.CRNN.build(num_events=10, tag_conditioning=True)
+    _copy_weights(model, ref)
+    return ref, model.to(DEV)
+
+
+def _bicrnn_inputs(wav, seq, weak, strong, device=None, dtype=torch.float32):
+    from oracle import frontend as ofe
+    tag = (weak > .99).float()
+    if device is None:
+        return {'stft': ofe.stft(wav).to(dtype), 'seq_len': seq.tolist(), 'weak_targets': weak.to(dtype),
+                'strong_targets': strong.to(dtype), 'tag_condition': tag.to(dtype)}
+    return {'audio_data': wav.to(device), 'seq_len': seq.tolist(), 'weak_targets': weak.to(device),
+            'strong_targets': strong.to(device), 'tag_condition': tag.to(device)}
+
+
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_c3_bicrnn_shallow_b8(precision):
+    """BASELINE configs[2] network at its real width (B = 8 so that the CPU oracle finishes in seconds).  fp32: the
+    fp32 bars (logits 1e-4, scores 2.5e-5, loss 2e-5, per-tensor gradients 2e-3 where fp32 allows it, see _grad_table).  bf16 (the config's dtype: bf16 MFMA
+    operands, fp32 accumulation / BN / GRU state): logits 0.3, scores 6e-2, loss 2 %, gradients 0.3 in the L2 sense
+    over all parameters - bf16 has 8 mantissa bits and the net is 16 layers deep."""
+    ref, model = _bicrnn_pair()
+    model.conv_precision = precision
+    model.keep_logits = True
+    ref64 = copy.deepcopy(ref).double().train()
+    wav, seq, weak, strong, t = _sorted_batch(8, 160000, seed=31)
+    cap, cap64 = _Capture(ref.rnn), _Capture(ref64.rnn)
+    ref.train()
+    inp_ref = _bicrnn_inputs(wav, seq, weak, strong)
+    out_ref = ref(inp_ref)
+    loss_ref = ref.review(inp_ref, out_ref)['loss']
+    loss_ref.backward()
+    in64 = _bicrnn_inputs(wav, seq, weak, strong, dtype=torch.float64)
+    ref64.review(in64, ref64(in64))['loss'].backward()
+    model.train()
+    inp = _bicrnn_inputs(wav, seq, weak, strong, DEV)
+    state0 = {n: b.detach().clone() for n, b in model.named_buffers()}
+    out, rev, grads = _train_step(model, inp)
+    logit = model.last_logits[0].clone()
+    model.load_state_dict(state0, strict=False)
+    m = (torch.arange(t)[None] < torch.as_tensor(seq)[:, None])[:, None, :]
+    e_logit = ((logit.cpu() - cap.out) * m).abs().max().item()
+    e_score = (out[0].cpu() - out_ref[0]).abs().max().item()
+    e_loss = abs(rev['loss'].item() - loss_ref.item()) / abs(loss_ref.item())
+    p64 = dict(ref64.named_parameters())
+    g = torch.cat([grads[n].cpu().double().reshape(-1) for n, _ in model.named_parameters()])
+    g64 = torch.cat([p64[n].grad.reshape(-1) for n, _ in model.named_parameters()])
+    e_g = ((g - g64).norm() / g64.norm()).item()
+    print(f'{precision}: logits {e_logit:.2e} (|cpu32-cpu64| {((cap.out.double() - cap64.out) * m).abs().max():.2e}) '
+          f'scores {e_score:.2e} loss {e_loss:.2e} grad(L2) {e_g:.2e}')
+    if precision == 'f32':
+        assert e_logit < 1e-4 and e_score < 2.5e-5 and e_loss < 2e-5
+        bad = _grad_table(grads, ref64, ref, _rounding_sensitivity(model, inp, grads))
+        assert not bad, '\n'.join(bad)
+    else:
+        assert e_logit < .3 and e_score < 6e-2 and e_loss < 2e-2 and e_g < .3
+        assert all(torch.isfinite(g_).all() for g_ in grads.values())
+
+
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_c3_bicrnn_full_size_properties(precision):
+    """BASELINE configs[2] at its size (batch 32, T = 500): (1) permuting clips of equal length permutes the scores and
+    leaves loss and gradients unchanged; (2) audio past seq_len influences nothing; (3) the tag condition matters."""
+    from pb_sed_amd.models import strong_label
+    torch.manual_seed(0)
+    model = strong_label.CRNN.build(num_events=10, tag_conditioning=True).to(DEV).train()
+    model.conv_precision = precision
+    b = 32
+    wav, seq, weak, strong, t = synth_batch(b, 160000, 10, ragged=True, seed=41)
+    seq[:4] = t
+    order = np.argsort(-seq, kind='stable')
+    wav, seq, weak, strong = wav[order], seq[order], weak[order], strong[order]
+    fe = model.feature_extractor
+    fe.freeze_stats = True                            # same normalisation for every run below
+
+    def run(wav_, seq_, weak_, strong_, tag_=None):
+        inputs = _bicrnn_inputs(wav_, seq_, weak_, strong_, DEV)
+        if tag_ is not None:
+            inputs['tag_condition'] = tag_.to(DEV)
+        _, flat_grad = model.flat_parameters()
+        flat_grad.zero_()
+        for m_ in model.modules():
+            if hasattr(m_, 'running_mean') and m_ is not fe:
+                m_.running_mean.zero_(), m_.running_power.fill_(1.)
+        out = model(dict(inputs))
+        rev = model.review(inputs, out)
+        rev['loss'].backward()
+        torch.cuda.synchronize()
+        return out[0].detach().clone(), rev['loss'].item(), flat_grad.detach().clone()
+
+    tol = 1e-4 if precision == 'f32' else 2e-3        # bf16: atomics order only changes fp32 sums, operands are identical
+    y, loss, grad = run(wav, seq, weak, strong)
+    assert np.isfinite(loss) and torch.isfinite(grad).all() and grad.norm() > 0
+    perm = np.arange(b)
+    full = np.nonzero(seq == seq[0])[0]
+    perm[full] = full[::-1]
+    y2, loss2, grad2 = run(wav[perm], seq[perm], weak[perm], strong[perm])
+    assert (y2 - y[perm]).abs().max().item() < tol
+    assert loss2 == pytest.approx(loss, rel=1e-4)
+    assert ((grad2 - grad).norm() / grad.norm()).item() < 2e-3
+    wav3 = wav.clone()
+    sl = int(seq[-1])
+    wav3[-1, 320 * sl + 640:] = torch.randn(wav3.shape[1] - (320 * sl + 640)) * 3
+    y3, loss3, _ = run(wav3, seq, weak, strong)
+    assert (y3[-1, :, :sl] - y[-1, :, :sl]).abs().max().item() < tol
+    assert (y3[:-1] - y[:-1]).abs().max().item() < tol
+    assert loss3 == pytest.approx(loss, rel=1e-4)
+    y4, _, _ = run(wav, seq, weak, strong, tag_=1 - (weak > .99).float())
+    assert (y4 - y).abs().max().item() > 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ C5
+def test_c5_ensemble_batch64():
+    """BASELINE configs[4]: 2 FBCRNN taggers + 3 tag-conditioned BiCRNN detectors, 'shallow' nets, batch 64.
+    Eval mode makes clips independent (running statistics), so (a) the batch-64 scores of clips 0..3 must equal a
+    batch-4 run of the same clips (different GRU kernels: persistent scans at batch 4, launch-per-step or wide-tile
+    scans at batch 64) and (b) equal the CPU oracle's; (c) the driver's tagging -> condition -> detection ->
+    median filter -> event list chain runs at batch 64 and agrees with the oracle chain on those clips."""
+    from oracle import frontend as ofe, models as om, postproc as opp
+    from pb_sed_amd import inference as inf
+    from pb_sed_amd.models import strong_label, weak_label
+    refs_t, refs_d, taggers, detectors = [], [], [], []
+    for i in range(2):
+        torch.manual_seed(100 + i)
+        r = om.FBCRNN.build(num_events=10)
+        _randomise(r, 100 + i)
+        m = weak_label.CRNN.build(num_events=10)
+        _copy_weights(m, r)
+        refs_t.append(r.eval()), taggers.append(m.to(DEV).eval())
+    for i in range(3):
+        torch.manual_seed(200 + i)
+        r = om.BiCRNN.build(num_events=10, tag_conditioning=True)
+        _randomise(r, 200 + i)
+        m = strong_label.CRNN.build(num_events=10, tag_conditioning=True)
+        _copy_weights(m, r)
+        refs_d.append(r.eval()), detectors.append(m.to(DEV).eval())
+    b = 64
+    wav, seq, *_ = synth_batch(b, 160000, 10, ragged=True, seed=51)
+    order = np.argsort(-seq, kind='stable')
+    wav, seq = wav[order], seq[order]
+    pick = np.array([0, 17, 40, 63])                   # stays sorted by length
+    ids = [f'clip{i}' for i in range(b)]
+    wav_d = wav.to(DEV)
+    batch = {'audio_data': wav_d, 'seq_len': seq.tolist(), 'example_id': ids}
+    sub = {'audio_data': wav_d[pick], 'seq_len': seq[pick].tolist(), 'example_id': [ids[i] for i in pick]}
+    sub_ref = {'stft': ofe.stft(wav[pick]), 'seq_len': seq[pick].tolist()}
+    tags64 = None
+    with torch.no_grad():
+        for m, r in zip(taggers, refs_t):
+            y64, _ = m.tagging(dict(batch))
+            y4, _ = m.tagging(dict(sub))
+            yr, _ = r.tagging(dict(sub_ref))
+            assert (y64[pick] - y4).abs().max().item() < 2e-5, 'tagger: batch 64 vs batch 4'
+            assert (y64[pick].cpu() - yr).abs().max().item() < 2.5e-5, 'tagger vs oracle'
+            tags64 = y64 if tags64 is None else tags64 + y64
+        cond64 = ((tags64 / len(taggers))[..., 0] > .5).float()
+        cond64[:, 0] = 1.                              # at least one active tag per clip
+        for m, r in zip(detectors, refs_d):
+            y64, _ = m.sound_event_detection(dict(batch, tag_condition=cond64))
+            y4, _ = m.sound_event_detection(dict(sub, tag_condition=cond64[pick]))
+            yr, _ = r.sound_event_detection(dict(sub_ref, tag_condition=cond64[pick].cpu()))
+            assert (y64[pick] - y4).abs().max().item() < 2e-5, 'detector: batch 64 vs batch 4'
+            assert (y64[pick].cpu() - yr).abs().max().item() < 2.5e-5, 'detector vs oracle'
+    # the driver chain (pb_sed/experiments/strong_label_crnn/inference.py:267-285,353-380) at batch 64
+    tag_scores = inf.tagging(taggers, [dict(batch)], DEV)
+    tags = {a: (s[0] > .5).astype(np.float32) for a, s in tag_scores.items()}
+    for a in tags:
+        tags[a][0] = 1.
+    cond = torch.tensor(np.stack([tags[a] for a in ids])).to(DEV)
+    medfilt = np.array([[1, 3, 5, 7, 9, 11, 21, 31, 41, 51], [11] * 10])
+    sed = inf.sound_event_detection(detectors, [dict(batch, tag_condition=cond)], DEV, medfilt_length=medfilt,
+                                    apply_mask=True, masks=tags)
+    assert len(sed) == b and all(sed[a].shape == (2, seq[i], 10) for i, a in enumerate(ids))
+    with torch.no_grad():
+        ys = [r.sound_event_detection(dict(sub_ref, tag_condition=cond[pick].cpu()))[0].numpy() for r in refs_d]
+    mean = np.mean(ys, 0)
+    for j, i in enumerate(pick):
+        sl = int(seq[i])
+        s = mean[j] * (np.arange(mean.shape[-1]) < sl)
+        want = np.stack([np.stack([opp.medfilt(s[k], int(n)) for k, n in enumerate(row)]) for row in medfilt])   # [2,K,T]
+        want = want[..., :sl].transpose(0, 2, 1) * np.maximum(tags[ids[i]], 0.)[None, None]
+        # median selection is exact, the scores differ by <= 2.5e-5
+        assert np.abs(sed[ids[i]] - want).max() < 5e-5, ids[i]
+    classes = [f'class{k}' for k in range(10)]
+    ts = np.round(np.arange(0, 100000) * .02, 6)
+    events = inf.scores_to_event_list({a: s[0] for a, s in sed.items()}, .5, classes, ts, device=DEV)
+    assert set(events) == set(ids)
+
+
+# ------------------------------------------------------------------------------------------------ front-end contracts
+def test_stft_input_contract():
+    """``inputs['stft']`` (the reference's own contract, weak_label/crnn.py:79-90) runs ``pbsed_logmel_from_stft``:
+    features equal the oracle's and the fused waveform path's, ragged lengths and a frame count that is no tile multiple."""
+    from oracle import frontend as ofe
+    from pb_sed_amd.models import weak_label
+    from tests.test_gpu_model import TINY
+    torch.manual_seed(3)
+    model = weak_label.CRNN.build(num_events=10, hidden_size=64, net=TINY).to(DEV).eval()
+    fe_ref = ofe.LogMelExtractor().eval()
+    with torch.no_grad():
+        mean, inv_std = torch.randn(128) * .5 - 7., torch.rand(128) * .3 + .3
+        fe_ref.mean.copy_(mean), fe_ref.inv_std.copy_(inv_std)
+        model.feature_extractor.mean.copy_(mean), model.feature_extractor.inv_std.copy_(inv_std)
+    wav, seq, *_ = synth_batch(5, 16000 * 3 + 123, 10, seed=7)
+    stft = ofe.stft(wav)
+    assert stft.shape[2] % 16 != 0
+    x_ref, _ = fe_ref(stft, seq_len=seq)
+    with torch.no_grad():
+        x_stft = model({'stft': stft.to(DEV), 'seq_len': seq.tolist()})[3]
+        x_wav = model({'audio_data': wav.to(DEV), 'seq_len': seq.tolist()})[3]
+    rel_close(x_stft, x_ref, 1e-5, 'features from stft vs oracle')
+    rel_close(x_stft, x_wav, 1e-4, 'features from stft vs fused waveform path')
+    # and the whole model accepts it in training (the reference pops the key, crnn.py:79-82)
+    model.train()
+    inputs = {'stft': stft.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': torch.ones(5, 10, device=DEV)}
+    model.strong_fwd_bwd_loss_weight = 0.
+    out = model(inputs)
+    assert 'stft' not in inputs
+    model.review(dict(inputs, seq_len=seq.tolist()), out)['loss'].backward()
+
+
+def test_feature_statistics_tracking():
+    """Training mode accumulates per-mel statistics cumulatively over batches and normalises with them;
+    eval mode re-uses them; three ragged batches against the oracle's extractor."""
+    from oracle import frontend as ofe
+    from pb_sed_amd import engine
+    from pb_sed_amd.modules import NormalizedLogMelExtractor
+    fe = NormalizedLogMelExtractor().to(DEV).train()
+    fe_ref = ofe.LogMelExtractor().train()
+    for step in range(3):
+        wav, seq, *_ = synth_batch(4, 16000 * 2, 10, seed=60 + step)
+        wav = wav * (step + 1)                           # level changes between batches: the statistics must move
+        x_ref, _ = fe_ref(ofe.stft(wav), seq_len=seq)
+        seq_dev = engine.seq_to_device(seq, DEV)
+        x = engine.features_from_audio(fe, wav.to(DEV), seq_dev, x_ref.shape[-1], seq)
+        rel_close(x, x_ref, 1e-4, f'features step {step}')
+        rel_close(fe.running_mean, fe_ref.running_mean, 1e-5, 'running_mean')
+        rel_close(fe.running_power, fe_ref.running_power, 1e-5, 'running_power')
+        assert fe.num_tracked_values.item() == fe_ref.num_tracked_values.item()
+    fe.eval(), fe_ref.eval()
+    wav, seq, *_ = synth_batch(3, 16000, 10, seed=70)
+    x_ref, _ = fe_ref(ofe.stft(wav), seq_len=seq)
+    x = engine.features_from_audio(fe, wav.to(DEV), engine.seq_to_device(seq, DEV), x_ref.shape[-1], seq)
+    rel_close(x, x_ref, 1e-4, 'eval features')
+    assert fe.num_tracked_values.item() == fe_ref.num_tracked_values.item()
+    # the reference's state_dict layout (feature_extractor.norm.* with padertorch's broadcast shape) loads
+    sd = {'norm.running_mean': fe_ref.running_mean.reshape(1, 1, -1, 1), 'norm.running_power': fe_ref.running_power.reshape(1, 1, -1, 1),
+          'norm.num_tracked_values': fe_ref.num_tracked_values.reshape(1, 1, 1, 1), 'fbanks': fe_ref.fbanks}
+    fe2 = NormalizedLogMelExtractor()
+    fe2.load_state_dict(sd, strict=False)
+    rel_close(fe2.mean, fe_ref.mean, 1e-6, 'mean from the reference layout')
+    rel_close(fe2.inv_std, fe_ref.inv_std, 1e-5, 'inv_std from the reference layout')
+
+
+# ------------------------------------------------------------------------------------------------ GRU scan drift
+@pytest.mark.parametrize('b', [32, 64])
+def test_gru_stack_t500_h256_vs_torch(b):
+    """The persistent scan hands h_t between workgroups as fp32 words whose mantissa LSB carries a parity tag (<= 1 ulp
+    per step, csrc/gru_stack.hip): 2 chains x 2 layers, T = 500, H = 256 at batch 32 (and 64) against torch.nn.GRU on
+    the same inputs - forward states and the BPTT gradients."""
+    from pb_sed_amd import ops
+    torch.manual_seed(5)
+    t, h = 500, 256
+    seq = np.sort(np.random.RandomState(5).randint(350, t + 1, b))[::-1].copy()
+    seq[0] = t
+    x = torch.randn(b, t, h) * .7
+    grus = [torch.nn.GRU(h, h, 2, batch_first=True) for _ in range(2)]
+    reverse = [False, True]
+    outs_ref, xs = [], []
+    for g, rev in zip(grus, reverse):
+        xi = x.clone().requires_grad_(True)
+        xs.append(xi)
+        from oracle.nn import reverse_sequence
+        inp = reverse_sequence(xi, seq) if rev else xi
+        packed = torch.nn.utils.rnn.pack_padded_sequence(inp, torch.as_tensor(seq), batch_first=True)
+        y, _ = g(packed)
+        y, _ = torch.nn.utils.rnn.pad_packed_sequence(y, batch_first=True, total_length=t)
+        outs_ref.append(reverse_sequence(y, seq) if rev else y)
+    dy = [torch.randn(b, t, h) * (torch.arange(t)[None, :, None] < torch.as_tensor(seq)[:, None, None]) for _ in grus]
+    (outs_ref[0] * dy[0]).sum().backward()
+    (outs_ref[1] * dy[1]).sum().backward()
+
+    seq_dev = torch.as_tensor(seq, dtype=torch.int32).to(DEV)
+    x_tbc = x.transpose(0, 1).contiguous().to(DEV)
+    gi0 = []
+    for g in grus:
+        gi0.append((x_tbc.reshape(t * b, h) @ g.weight_ih_l0.detach().to(DEV).T + g.bias_ih_l0.detach().to(DEV)).reshape(t, b, 3 * h).contiguous())
+    idx = [(g, l) for g in grus for l in range(2)]
+    dev = lambda v: v.detach().to(DEV).contiguous()
+    hs, save = ops.gru_stack_fwd(gi0, [dev(getattr(g, f'weight_ih_l{l}')) if l else None for g, l in idx],
+                                 [dev(getattr(g, f'bias_ih_l{l}')) if l else None for g, l in idx],
+                                 [dev(getattr(g, f'weight_hh_l{l}')) for g, l in idx],
+                                 [dev(getattr(g, f'bias_hh_l{l}')) for g, l in idx], reverse, seq_dev, 2, save=True)
+    for ci in range(2):
+        got = hs[ci * 2 + 1].transpose(0, 1).cpu()
+        e = (got - outs_ref[ci].detach()).abs().max().item()
+        print(f'B={b} chain {ci}: max |h - nn.GRU| after T=500 = {e:.2e}')
+        assert e < 2e-5, f'chain {ci}: top-layer states drift {e:.2e} from nn.GRU'
+    w_hh_t = [ops.transpose2d(dev(getattr(g, f'weight_hh_l{l}'))) for g, l in idx]
+    w_ih_up_t = [ops.transpose2d(dev(getattr(g, f'weight_ih_l{l + 1}'))) if l == 0 else None for g, l in idx]
+    dy_top = [d.transpose(0, 1).contiguous().to(DEV) for d in dy]
+    dgi, dgh = ops.gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_dev, 2)
+    ops.check_gru_sync()
+    for ci, g in enumerate(grus):
+        # dL/dx of the stack = dgi(layer 0) @ W_ih_l0 ; dL/db_hh etc. follow from dgh
+        dx = (dgi[ci * 2].reshape(t * b, 3 * h) @ g.weight_ih_l0.detach().to(DEV)).reshape(t, b, h).transpose(0, 1).cpu()
+        rel_close(dx, xs[ci].grad, 2e-4, f'chain {ci} dx')
+        for l in range(2):
+            db = dgh[ci * 2 + l].sum((0, 1)).cpu()
+            rel_close(db, getattr(g, f'bias_hh_l{l}').grad, 2e-4, f'chain {ci} layer {l} db_hh')
