@@ -1,15 +1,26 @@
-"""Headline benchmark: 10 s @ 16 kHz clips/sec for one full FBCRNN train step (fused log-mel front-end
--> CNN2d/CNN1d -> fwd/bwd GRUs -> heads -> loss -> backward -> grad-norm clip -> Adam [+ RCCL gradient
-all-reduce]) at batch 32 per GPU, fp32, synthetic waveforms / random-init weights.
+"""Benchmarks of the pb_sed hot path on MI355X.  Default = the headline metric (BASELINE.json configs[1]):
 
-    python bench.py --gpus 1 --steps K --warmup W
+    10 s @ 16 kHz clips/sec for one full FBCRNN train step (fused log-mel front-end -> CNN2d/CNN1d -> fwd/bwd GRUs ->
+    heads -> loss -> backward -> grad-norm clip -> Adam [+ RCCL gradient all-reduce]) at batch 32 per GPU, fp32.
+
+    python bench.py --gpus 1 --steps K --warmup W                  [--config c2|c3|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     - the dominant MFMA kernel launch (largest total time among conv launches), timed live with
-                 HIP events on the launch stream inside the timed region; algorithmic FLOPs = 2*MACs of that
-                 launch (SURVEY.md 8(d) / DESIGN.md "Rooflines"); peak = 157.3 TFLOP/s dense fp32 MFMA.
-  cpu_baseline - the oracle (CPU restatement, kind "port") timed on this host on a bounded sample.
+  --config c2  FBCRNN train step, batch 32/GPU, fp32                     (BASELINE.json configs[1], configs[3] at N > 1)
+  --config c3  tag-conditioned BiCRNN train step, batch 32/GPU, bf16     (BASELINE.json configs[2])
+  --config c5  5-model ensemble inference (2 FBCRNN taggers -> tags -> 3 tag-conditioned BiCRNN detectors -> GPU
+               post-processing -> event lists), batch 64, clips sharded over ranks   (BASELINE.json configs[4])
+
+Rank 0 prints ONE JSON line (contract in the task statement).  The timed region holds NO event pairs: K steps over >= 2
+distinct HBM-resident batches between barrier + synchronize pairs, max over ranks.  Per-kernel figures come from a second,
+separate pass with HIP events on the launch stream:
+  roofline      the conv launch with the largest total time: `achieved` / `frac` = EXECUTED flops on the MFMA pipe (a
+                Winograd-F(4,3) launch executes half the multiplications of the direct convolution) over the dense peak of
+                the operand type, always <= 1; `achieved_algorithmic` = 2*MACs of the direct convolution over the same time.
+  roofline_gru  forward / BPTT persistent scans: recurrent + layer-boundary projection flops over the scan's duration.
+  frontend_hbm  896 000 B per clip over the front-end kernel's duration against 8 TB/s.
+  cpu_baseline  the oracle (CPU restatement, kind "port") on this host: same workload at batch 32 and at batch 16
+                (the stand-in for configs[0]), 1 warm-up + 3 timed steps, per-stage breakdown, CPU model string.
 """
 import argparse
 import json
@@ -23,15 +34,16 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md (dense f32-in MFMA)
+PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}      # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA, f32 / bf16 operands
 PEAK_HBM_GBS = 8000.0
-FWD_GFLOP_PER_CLIP = 11.82         # BASELINE.md section 2 (conv+GRU+heads+mel, forward)
-TRAIN_GFLOP_PER_CLIP = 35.3
+XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7
+FWD_GFLOP = {'c2': 11.82, 'c3': 12.34}            # forward per clip (train step = 3x)
 
 
-def synth_batch(b, device, n_samples=160000, k=10, t=500, seed=0):
-    """SURVEY.md 8(d) synthetic inputs: randn waveforms (max-abs normalised), Bernoulli(.25) weak targets
-    with >=1 positive, 1/8 of clips unlabeled (0.5), one segment per positive class."""
+# ------------------------------------------------------------------------------------------------ synthetic data
+def synth_batch(b, device, n_samples=160000, k=10, t=500, seed=0, kind='c2'):
+    """SURVEY.md 8(d) synthetic inputs: randn waveforms (max-abs normalised), Bernoulli(.25) weak targets with >= 1
+    positive, 1/8 of the clips unlabeled (0.5), one segment per positive class; c3: strong targets + tag condition."""
     g = torch.Generator().manual_seed(1234 + seed)
     wav = torch.randn(b, n_samples, generator=g)
     wav = wav / wav.abs().max(-1, keepdim=True)[0]
@@ -40,59 +52,451 @@ def synth_batch(b, device, n_samples=160000, k=10, t=500, seed=0):
     for i in range(b):
         if weak[i].sum() == 0:
             weak[i, rng.randint(k)] = 1
-    bnd = np.zeros((b, k, t), np.float32)
+    tgt = np.zeros((b, k, t), np.float32)
     for i in range(b):
         for c in range(k):
             if weak[i, c]:
                 on = rng.randint(0, 401)
-                bnd[i, c, on:on + rng.randint(10, 101)] = 1
+                tgt[i, c, on:on + rng.randint(10, 101)] = 1
+    batch = {'audio_data': wav.to(device), 'seq_len': [t] * b}
+    if kind == 'c3':
+        batch.update(weak_targets=torch.tensor(weak).to(device), strong_targets=torch.tensor(tgt).to(device),
+                     tag_condition=torch.tensor(weak).to(device))
+        return batch
     for i in range(0, b, 8):
         weak[i] += (1 - weak[i]) * .5
-        bnd[i] += (1 - bnd[i]) * .5
-    return {'audio_data': wav.to(device), 'seq_len': [t] * b, 'weak_targets': torch.tensor(weak).to(device),
-            'boundary_targets': torch.tensor(bnd).to(device)}
+        tgt[i] += (1 - tgt[i]) * .5
+    batch.update(weak_targets=torch.tensor(weak).to(device), boundary_targets=torch.tensor(tgt).to(device))
+    return batch
 
 
 def pmc_traffic(kernel_tag):
     """HBM bytes per launch of the roofline kernel from the PMC passes committed under profiles/ (counters need their
     own rocprofv3 runs, tools/run_profiles.sh + tools/prof_summary.py); None if that layer was not profiled."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'roofline_traffic.json')
     try:
-        row = json.load(open(path)).get(kernel_tag)
+        row = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json'))).get(kernel_tag)
     except (OSError, ValueError):
         return None, None
     return (None, None) if row is None else (row['hbm_bytes_per_launch'], row['source'])
 
 
-def cpu_baseline(batch=8, steps=2):
-    """Oracle FBCRNN train step on the host cores (the checker, timed as the CPU baseline)."""
-    from oracle import frontend as ofe, models as om
-    torch.manual_seed(0)
-    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    n = min(n, 32)       # beyond ~32 threads the small GRU/conv ops of this model only get slower on CPU
+def host_cpu():
+    model = 'unknown'
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    return model, os.cpu_count() or 1, aff
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def _cpu_threads():
+    _, _, aff = host_cpu()
+    n = min(aff, 32)        # measured: beyond ~32 threads the small GRU / conv ops of this model only get slower on CPU
     torch.set_num_threads(n)
-    model = om.FBCRNN.build().train()
-    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
-    b = synth_batch(batch, 'cpu')
+    return n
+
+
+def cpu_train_baseline(kind, batches=(32, 16), steps=3):
+    """Oracle train step (stock PyTorch CPU ops) on this host's cores, per-stage breakdown; the checker timed as baseline."""
+    from oracle import frontend as ofe, models as om
+    n = _cpu_threads()
+    model_name, n_logical, aff = host_cpu()
+    res = {}
+    for batch in batches:
+        torch.manual_seed(0)
+        model = (om.FBCRNN.build() if kind == 'c2' else om.BiCRNN.build(tag_conditioning=True)).train()
+        opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+        b = synth_batch(batch, 'cpu', kind=kind)
+        times, stages = [], []
+        for i in range(steps + 1):
+            st = {}
+            t0 = time.perf_counter()
+            stft = ofe.stft(b['audio_data'])
+            seq = np.array(b['seq_len'])
+            x, seq_x = model.feature_extractor(stft, seq_len=seq)
+            st['front_end_incl_stft'] = time.perf_counter() - t0
+            opt.zero_grad()
+            t1 = time.perf_counter()
+            if kind == 'c2':
+                h, seq_h = model.cnn(x, seq_x)
+                st['cnn_fwd'] = time.perf_counter() - t1
+                t1 = time.perf_counter()
+                y_fwd, seq_y = model.fwd_tagging(h, seq_h)
+                y_bwd, _ = model.bwd_tagging(h, seq_h)
+                st['gru_heads_fwd'] = time.perf_counter() - t1
+                out = (y_fwd, y_bwd, seq_y, x, seq_x, (b['weak_targets'], b['boundary_targets']))
+            else:
+                tag = b['tag_condition'].unsqueeze(-1)
+                h, seq_h = model.cnn(x, seq_x, tag)
+                st['cnn_fwd'] = time.perf_counter() - t1
+                t1 = time.perf_counter()
+                h = torch.cat([h, tag.expand(-1, -1, h.shape[-1])], dim=1)
+                y, seq_y = model.rnn(h, seq_h)
+                st['gru_heads_fwd'] = time.perf_counter() - t1
+                out = (torch.sigmoid(y), seq_y, x, seq_x, (b['weak_targets'], b['strong_targets']))
+            t1 = time.perf_counter()
+            loss = model.review(b, out)['loss']
+            loss.backward()
+            st['loss_backward'] = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1e10)
+            opt.step()
+            st['clip_adam'] = time.perf_counter() - t1
+            times.append(time.perf_counter() - t0)
+            stages.append(st)
+            print(f'[bench] cpu_baseline {kind} batch {batch} step {i}: {times[-1]:.2f} s on {n} threads', file=sys.stderr, flush=True)
+            if sum(times) > 60.:                     # bounded sample: stop early on a slow host
+                break
+        timed = times[1:] if len(times) > 1 else times
+        dt = float(np.median(timed))
+        med = stages[1 + int(np.argsort(timed)[len(timed) // 2])] if len(times) > 1 else stages[0]
+        res[batch] = {'clips_per_s': round(batch / dt, 3), 's_per_step': round(dt, 3), 'timed_steps': len(timed),
+                      'stage_s': {k: round(v, 3) for k, v in med.items()}}
+    main_b = batches[0]
+    what = 'FBCRNN' if kind == 'c2' else 'tag-conditioned BiCRNN'
+    out = {'value': res[main_b]['clips_per_s'], 'unit': 'clips/s', 'cores': n, 'kind': 'port',
+           'sample': f'oracle (stock-PyTorch CPU restatement, fp32) {what} train step incl. STFT, batch {main_b} x 10 s clips, '
+                     f'1 warm-up + {res[main_b]["timed_steps"]} timed steps, median',
+           'cpu_model': model_name, 'host_logical_cpus': n_logical, 'affinity_cpus': aff, 'threads_used': n,
+           f'batch{main_b}': res[main_b]}
+    for bb in batches[1:]:
+        out[f'batch{bb}'] = res[bb]
+    if kind == 'c2' and 16 in res:
+        out['configs0_stand_in'] = ('BASELINE.json configs[0] (reference plumbing on DESED-weak, batch 16, CPU) is not runnable '
+                                    '(padertorch / DESED audio absent): batch16 above is the oracle on synthetic clips')
+    return out
+
+
+def cpu_inference_baseline(clips=8):
+    """Oracle ensemble inference (2 FBCRNN + 3 tag-conditioned BiCRNN, median filters, event extraction) on a bounded sample."""
+    from oracle import frontend as ofe, models as om, postproc as opp
+    n = _cpu_threads()
+    model_name, n_logical, aff = host_cpu()
+    torch.manual_seed(0)
+    taggers = [om.FBCRNN.build().eval() for _ in range(2)]
+    detectors = [om.BiCRNN.build(tag_conditioning=True).eval() for _ in range(3)]
+    b = synth_batch(clips, 'cpu')
+    medfilt = np.array([[1, 3, 5, 7, 9, 11, 21, 31, 41, 51], [11] * 10, [51] * 10])
     times = []
-    for i in range(steps + 1):
+    for i in range(3):
         t0 = time.perf_counter()
-        inp = {'stft': ofe.stft(b['audio_data']), 'seq_len': b['seq_len'], 'weak_targets': b['weak_targets'],
-               'boundary_targets': b['boundary_targets']}
-        opt.zero_grad()
-        out = model(inp)
-        loss = model.review(inp, out)['loss']
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1e10)
-        opt.step()
+        with torch.no_grad():
+            inp = {'stft': ofe.stft(b['audio_data']), 'seq_len': b['seq_len']}
+            tags = (np.mean([m.tagging(dict(inp))[0].numpy() for m in taggers], 0)[..., 0] > .5).astype(np.float32)
+            inp['tag_condition'] = torch.tensor(tags)
+            s = np.mean([m.sound_event_detection(dict(inp))[0].numpy() for m in detectors], 0)
+        s = np.stack([np.stack([opp.medfilt(s[:, k], int(nn)) for k, nn in enumerate(row)], 1) for row in medfilt], 1)
+        s = s * tags[:, None, :, None]
+        n_ev = sum(len(opp.scores_to_event_list(s[j, 0].T, np.round(np.arange(0, 100000) * .02, 6), .5,
+                                                [f'c{k}' for k in range(10)])) for j in range(clips))
         times.append(time.perf_counter() - t0)
-        print(f'[bench] cpu_baseline step {i}: {times[-1]:.2f} s on {n} threads', file=sys.stderr, flush=True)
-        if sum(times) > 45.:                     # bounded sample: stop early on a slow host
-            break
-    dt = float(np.median(times[1:])) if len(times) > 1 else times[0]
-    return {'value': round(batch / dt, 3), 'unit': 'clips/s', 'cores': n, 'kind': 'port',
-            'sample': f'oracle (stock-PyTorch CPU restatement) FBCRNN train step incl. STFT, batch {batch} x 10 s '
-                      f'clips, 1 warm-up + {steps} timed steps, median'}
+        print(f'[bench] cpu_baseline c5 pass {i}: {times[-1]:.2f} s on {n} threads ({n_ev} events)', file=sys.stderr, flush=True)
+    dt = float(np.median(times[1:]))
+    return {'value': round(clips / dt, 3), 'unit': 'clips/s', 'cores': n, 'kind': 'port',
+            'sample': f'oracle ensemble inference (2 FBCRNN taggers + 3 tag-conditioned BiCRNN detectors, 3 median-filter '
+                      f'variants, event extraction) on {clips} x 10 s clips, 1 warm-up + 2 timed passes, median',
+            'cpu_model': model_name, 'host_logical_cpus': n_logical, 'affinity_cpus': aff, 'threads_used': n}
+
+
+# ------------------------------------------------------------------------------------------------ per-kernel figures
+def _aggregate(events, steps):
+    agg = {}
+    for name, tag, flops, byts, e0, e1 in events:
+        a = agg.setdefault((name, tag), [0.0, 0, flops, byts])
+        a[0] += e0.elapsed_time(e1)
+        a[1] += 1
+    by_family = {}
+    for (name, tag), (ms, c, fl, by) in agg.items():
+        by_family[name] = by_family.get(name, 0.0) + ms / steps
+    return agg, by_family
+
+
+def _executed(flops, tag):
+    """flops a launch issues on the MFMA pipe: the Winograd-F(4,3) kernels need 18 products per 4 outputs instead of 36."""
+    return flops / 2 if tag.endswith('wino') else flops
+
+
+def roofline_objects(agg, by_family, steps, batch, precision, gru_shape, kind):
+    out = {}
+    conv = {k: v for k, v in agg.items() if k[0].startswith('pbsed_conv') and v[2]}
+    (dname, dtag), (tot_ms, cnt, flops, _) = max(conv.items(), key=lambda kv: kv[1][0])
+    avg_ms = tot_ms / cnt
+    bf16_launch = precision == 'bf16' and ('bf16' in dtag or dname.endswith('_bf16'))
+    peak = PEAK_TFLOPS['bf16' if bf16_launch else 'f32']
+    alg = flops / (avg_ms * 1e-3) / 1e12
+    exe = _executed(flops, dtag) / (avg_ms * 1e-3) / 1e12
+    traffic, source = pmc_traffic(f'{dname} {dtag}')
+    out['roofline'] = {
+        'bound': 'mfma', 'achieved': round(exe, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(exe / peak, 4),
+        'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': source,
+        'kernel': f'{dname} {dtag}', 'avg_ms': round(avg_ms, 4), 'launches': cnt, 'flops_per_launch': flops,
+        'flops_executed_per_launch': _executed(flops, dtag),
+        'achieved_algorithmic': round(alg, 2), 'frac_algorithmic': round(alg / peak, 4),
+        'operands': 'bf16' if bf16_launch else 'f32',
+        'note': ('achieved / frac = flops EXECUTED on the MFMA pipe over the dense peak of the operand type (utilisation, <= 1); '
+                 'achieved_algorithmic = 2*MACs of the direct convolution over the same time'
+                 + ('; this launch is a Winograd-F(4,3) kernel and executes half of the direct products' if dtag.endswith('wino') else ''))}
+    # whole step / forward: algorithmic (BASELINE.md section 2) and executed (sum over the bracketed launches)
+    exe_step = sum(_executed(fl, tag) * c for (name, tag), (ms, c, fl, by) in agg.items()) / steps
+    out['_exe_step_flop'] = exe_step
+    if gru_shape is not None:
+        nch, nl, t, b, h = gru_shape
+        g = {}
+        for key, fam in (('forward_scan', 'pbsed_gru_stack_fwd_granule'), ('bptt_scan', 'pbsed_gru_stack_bwd_granule')):
+            rows = [v for k, v in agg.items() if k[0] == fam]
+            if not rows:
+                continue
+            ms = sum(r[0] for r in rows) / steps            # all scans of one step (FBCRNN: one launch; BiGRU: one per layer)
+            fl = sum(r[2] * r[1] for r in rows) / steps
+            g[key] = {'ms_per_step': round(ms, 4), 'launches_per_step': round(sum(r[1] for r in rows) / steps, 2),
+                      'gflop_per_step': round(fl / 1e9, 2), 'achieved': round(fl / (ms * 1e-3) / 1e12, 2),
+                      'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_TFLOPS['f32'], 4),
+                      'us_per_time_step': round(ms * 1e3 / (t * sum(r[1] for r in rows) / steps), 3)}
+        if g:
+            g.update(bound='mfma (fp32 operands); latency-bound in practice: T dependent steps with an inter-workgroup hand-off each',
+                     peak=PEAK_TFLOPS['f32'], unit='TFLOP/s', shape=dict(chains=nch, layers=nl, T=t, B=b, H=h))
+            out['roofline_gru'] = g
+    fe = [v for k, v in agg.items() if k[0] in ('pbsed_logmel_fwd', 'pbsed_logmel_from_stft')]
+    if fe:
+        fe_ms = fe[0][0] / fe[0][1]
+        gbs = 896000.0 * batch / (fe_ms * 1e-3) / 1e9
+        out['frontend_hbm'] = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                               'frac': round(gbs / PEAK_HBM_GBS, 4), 'avg_ms': round(fe_ms, 4),
+                               'bytes_per_launch': int(896000 * batch)}
+    return out
+
+
+EVENT_FILTER = lambda n: n.startswith(('pbsed_conv', 'pbsed_gru_stack', 'pbsed_gru_wgrad', 'pbsed_logmel'))
+
+
+def event_pass(step_fn, steps):
+    """Second pass, outside the timed region: HIP events (on the launch stream) around the conv / GRU / front-end calls."""
+    from pb_sed_amd import _lib
+    _lib.timing, _lib.timing_filter = [], (None if os.environ.get('PBSED_BENCH_TABLE') else EVENT_FILTER)
+    for i in range(steps):
+        step_fn(i)
+    torch.cuda.synchronize()
+    events, _lib.timing, _lib.timing_filter = _lib.timing, None, None
+    return events
+
+
+def print_table(agg, steps):
+    print('[bench] per-call table (ms/step, calls/step, TFLOP/s algorithmic):', file=sys.stderr)
+    for (name, tag), (ms, c, fl, _) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:48]:
+        tf = fl * c / (ms * 1e-3) / 1e12 if fl else 0.
+        print(f'   {ms / steps:8.3f} {c / steps:5.1f} {tf:7.1f}  {name[6:]} {tag}', file=sys.stderr)
+
+
+# ------------------------------------------------------------------------------------------------ train configs
+def bench_train(args, kind, world, rank, device):
+    import torch.distributed as dist
+    from pb_sed_amd import _lib, ops
+    from pb_sed_amd.models import strong_label, weak_label
+    from pb_sed_amd.trainer import Trainer
+    torch.manual_seed(0)
+    precision = args.conv_precision or ('f32' if kind == 'c2' else 'bf16')
+    model = (weak_label.CRNN.build() if kind == 'c2' else strong_label.CRNN.build(tag_conditioning=True)).to(device)
+    model.conv_precision = precision
+    n_params = sum(p.numel() for p in model.parameters())
+    trainer = Trainer(model, lr=5e-4, gradient_clipping=1e10)
+    trainer.measure_sync = world > 1
+    batches = [synth_batch(args.batch, device, seed=2 * rank + j, kind=kind) for j in range(2)]   # weak scaling: 32 clips per GPU
+
+    for i in range(args.warmup):
+        t_w = time.perf_counter()
+        trainer.step(batches[i % 2])
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(f'[bench] warm-up step {i}: {(time.perf_counter() - t_w) * 1e3:.1f} ms', file=sys.stderr, flush=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    calls0, enq, trainer.sync_events = _lib.n_calls, 0., []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        review = trainer.step(batches[i % 2])
+        enq += trainer.last_enqueue_s
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    calls = (_lib.n_calls - calls0) / max(args.steps, 1)
+    sync_events, trainer.sync_events = trainer.sync_events, None
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    loss = float(review['loss'].item())
+    exposed_ms = (sum(a.elapsed_time(b) for a, b in sync_events) / max(args.steps, 1)) if sync_events else None
+    ev_steps = min(max(args.steps, 1), 10)
+    events = event_pass(lambda i: trainer.step(batches[i % 2]), ev_steps)
+    # host -> device hand-over of one batch (pinned, PCIe), outside the timed region: `value` is HBM-resident
+    host_batch = {k: v.cpu().pin_memory() for k, v in batches[0].items() if isinstance(v, torch.Tensor)}
+    torch.cuda.synchronize()
+    t_h = time.perf_counter()
+    for _ in range(5):
+        for k, v in host_batch.items():
+            batches[0][k].copy_(v, non_blocking=True)
+    torch.cuda.synchronize()
+    h2d_ms = (time.perf_counter() - t_h) / 5 * 1e3
+    ops.check_gru_sync()
+    if rank != 0:
+        return None
+    agg, by_family = _aggregate(events, ev_steps)
+    ms_step = dt / args.steps * 1e3
+    clips = args.batch * world
+    what = {'c2': 'FBCRNN weak_label_crnn.training batch 32/GPU fp32, 10 s 16 kHz clips (BASELINE.json configs[1])',
+            'c3': 'tag-conditioned strong_label BiCRNN training batch 32/GPU bf16, 10 s 16 kHz clips (BASELINE.json configs[2])'}[kind]
+    gru_shape = (2, 2, 500, args.batch, 256) if kind == 'c2' else (2, 1, 500, args.batch, 256)
+    out = {
+        'metric': {'c2': '10s@16kHz clips/sec (train step) FBCRNN batch32',
+                   'c3': '10s@16kHz clips/sec (train step) tag-conditioned BiCRNN batch32 bf16'}[kind],
+        'value': round(clips / (dt / args.steps), 2), 'unit': 'clips/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': {'f32': 'f32', 'bf16': 'bf16 (MFMA operands of conv / projection / head launches; fp32 accumulate, BN, GRU state, '
+                                        'master weights)',
+                  'bf16x3': 'bf16x3 (fp32 operands split into 3 bf16 terms, fp32 accumulate)'}[precision],
+        'data': 'synthetic (randn waveforms, random-init weights, 2 distinct resident batches in rotation)',
+        'config': {'workload': what + '; full train step incl. fused log-mel front-end, loss, backward, grad-norm clip, Adam'
+                                      + (', RCCL grad all-reduce' if world > 1 else ''),
+                   'global_batch': clips, 'n_params': n_params, 'parallelism': f'dp{world}'},
+    }
+    rf = roofline_objects(agg, by_family, ev_steps, args.batch, precision, gru_shape, kind)
+    exe_step = rf.pop('_exe_step_flop')
+    out.update(rf)
+    train_tflop = 3 * FWD_GFLOP[kind] * args.batch / 1e3
+    fwd_tflop = FWD_GFLOP[kind] * args.batch / 1e3
+    peak = PEAK_TFLOPS['f32']            # whole-step figures are priced against the fp32 peak (GRU, wgrad and BN stay fp32)
+    out['step_mfma'] = {'algorithmic_tflop_per_step': round(train_tflop, 4),
+                        'algorithmic_tflops_per_gpu': round(train_tflop / (ms_step * 1e-3), 2),
+                        'executed_tflop_per_step_in_bracketed_launches': round(exe_step / 1e12, 4),
+                        'executed_tflops_per_gpu': round(exe_step / 1e12 / (ms_step * 1e-3), 2),
+                        'frac_executed_of_fp32_mfma_peak': round(exe_step / 1e12 / (ms_step * 1e-3) / peak, 4),
+                        'frac_algorithmic_of_fp32_mfma_peak': round(train_tflop / (ms_step * 1e-3) / peak, 4)}
+    fwd_ms = sum(v for k, v in by_family.items() if k.startswith(('pbsed_conv_fwd', 'pbsed_gru_stack_fwd', 'pbsed_logmel')))
+    fwd_exe = sum(_executed(fl, tag) * c for (name, tag), (ms, c, fl, by) in agg.items()
+                  if name.startswith(('pbsed_conv_fwd', 'pbsed_gru_stack_fwd'))) / ev_steps
+    out['forward_conv_gru'] = {'ms_per_step': round(fwd_ms, 3), 'algorithmic_tflop': round(fwd_tflop, 4),
+                               'algorithmic_tflops': round(fwd_tflop / (fwd_ms * 1e-3), 2),
+                               'executed_tflops': round(fwd_exe / 1e12 / (fwd_ms * 1e-3), 2),
+                               'frac_executed_of_fp32_mfma_peak': round(fwd_exe / 1e12 / (fwd_ms * 1e-3) / peak, 4),
+                               'frac_algorithmic_of_fp32_mfma_peak': round(fwd_tflop / (fwd_ms * 1e-3) / peak, 4)}
+    out['ms_per_step_by_entry_point'] = {k: round(v, 3) for k, v in sorted(by_family.items(), key=lambda kv: -kv[1])}
+    out['host'] = {'enqueue_ms_per_step': round(enq / args.steps * 1e3, 3), 'c_abi_calls_per_step': round(calls, 1),
+                   'note': 'host time of a step up to (not including) the wait for its deferred review summary'}
+    out['h2d'] = {'ms_per_batch': round(h2d_ms, 3), 'bytes': int(sum(v.numel() * v.element_size() for v in host_batch.values())),
+                  'clips_per_s_if_serialised': round(clips / (dt / args.steps + h2d_ms * 1e-3), 2)}
+    out['loss'] = loss
+    if world > 1:
+        s_bytes = 4 * n_params
+        out['allreduce'] = {
+            'bytes_per_step': s_bytes, 'buckets': trainer.bucket_names,
+            'exposed_ms_per_step': None if exposed_ms is None else round(exposed_ms, 4),
+            'bus_bytes_per_step': round(s_bytes * 2 * (world - 1) / world),
+            'busbw_GBs_if_fully_exposed': None if not exposed_ms else round(s_bytes * 2 * (world - 1) / world / (exposed_ms * 1e-3) / 1e9, 1),
+            'time_at_ring_bound_ms': round(s_bytes * 2 * (world - 1) / world / (XGMI_LINK_GBS * 1e9) * 1e3, 4),
+            'time_at_direct_bound_ms': round(s_bytes * 2 * (world - 1) / world / (XGMI_LINKS * XGMI_LINK_GBS * 1e9) * 1e3, 4),
+            'note': 'exposed = time the compute stream waits in GradSync.finish() (collectives are issued per bucket from inside '
+                    'backward and overlap the remaining conv launches); bounds: 153 GB/s per xGMI link (ring) and 7 links (direct)'}
+    print('[bench] gpu: ' + json.dumps({k: out[k] for k in ('value', 'ms_per_step', 'roofline')}), file=sys.stderr, flush=True)
+    if os.environ.get('PBSED_BENCH_TABLE'):
+        print_table(agg, ev_steps)
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_train_baseline(kind, batches=(32, 16) if kind == 'c2' else (32,))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ ensemble inference
+def bench_inference(args, world, rank, device):
+    import torch.distributed as dist
+    from pb_sed_amd import inference as inf, ops
+    from pb_sed_amd.models import strong_label, weak_label
+    torch.manual_seed(0)
+    precision = args.conv_precision or 'f32'
+    taggers = [weak_label.CRNN.build() for _ in range(2)]
+    detectors = [strong_label.CRNN.build(tag_conditioning=True) for _ in range(3)]
+    for m in taggers + detectors:
+        m.conv_precision = precision
+    classes = [f'class{i}' for i in range(10)]
+    total = args.batch if args.batch != 32 else 64                 # configs[4]: batch 64 (the default --batch is the train size)
+    assert total % world == 0, (total, world)
+    per = total // world
+    data = []
+    for j in range(2):                                              # two distinct resident batches, this rank's shard of each
+        b = synth_batch(total, 'cpu', seed=10 + j)
+        ids = [f'clip{j}_{i}' for i in range(total)]
+        sl = slice(rank * per, (rank + 1) * per)
+        data.append({'audio_data': b['audio_data'][sl].to(device), 'seq_len': b['seq_len'][sl], 'example_id': ids[sl]})
+    medfilt = np.array([[1, 3, 5, 7, 9, 11, 21, 31, 41, 51], [11] * 10, [51] * 10])
+    ts = np.round(np.arange(0, 100000) * .02, 6)
+
+    def run(i):
+        batch = data[i % 2]
+        tag_scores = inf.tagging(taggers, [dict(batch)], device)
+        tags = {a: (s[0] > .5).astype(np.float32) for a, s in tag_scores.items()}
+        cond = torch.tensor(np.stack([tags[a] for a in batch['example_id']])).to(device)
+        sed = inf.sound_event_detection(detectors, [dict(batch, tag_condition=cond)], device, medfilt_length=medfilt,
+                                        apply_mask=True, masks=tags)
+        events = inf.scores_to_event_list({a: s[0] for a, s in sed.items()}, .5, classes, ts, device=device)
+        return len(events)
+
+    for i in range(args.warmup):
+        run(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        n = run(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    ev_steps = min(max(args.steps, 1), 5)
+    events = event_pass(run, ev_steps)
+    ops.check_gru_sync()
+    if rank != 0:
+        return None
+    agg, by_family = _aggregate(events, ev_steps)
+    ms = dt / args.steps * 1e3
+    out = {
+        'metric': '10s@16kHz clips/sec, 5-model FBCRNN+BiCRNN ensemble inference, batch 64',
+        'value': round(total / (dt / args.steps), 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'strong',
+        'vs_baseline': None, 'dtype': precision,
+        'data': 'synthetic (randn waveforms, random-init weights, 2 distinct resident batches in rotation)',
+        'config': {'workload': 'strong_label_crnn_inference: 2 FBCRNN taggers -> tags -> 3 tag-conditioned BiCRNN detectors, '
+                               'ensemble mean, 3 per-class median-filter variants, tag masking, event lists on the host '
+                               f'(BASELINE.json configs[4]); batch {total} sharded over {world} rank(s), no collective',
+                   'global_batch': total, 'clips_per_rank': per, 'models': 5, 'parallelism': f'clips/{world}'},
+    }
+    rf = roofline_objects(agg, by_family, ev_steps, per, precision, None, 'c5')
+    rf.pop('_exe_step_flop')
+    out.update(rf)
+    fwd_tflop = (2 * FWD_GFLOP['c2'] + 3 * FWD_GFLOP['c3']) * per / 1e3
+    out['step_mfma'] = {'algorithmic_tflop_per_step_per_gpu': round(fwd_tflop, 4),
+                        'algorithmic_tflops_per_gpu': round(fwd_tflop / (ms * 1e-3), 2),
+                        'frac_algorithmic_of_fp32_mfma_peak': round(fwd_tflop / (ms * 1e-3) / PEAK_TFLOPS['f32'], 4)}
+    out['ms_per_step_by_entry_point'] = {k: round(v, 3) for k, v in sorted(by_family.items(), key=lambda kv: -kv[1])}
+    if os.environ.get('PBSED_BENCH_TABLE'):
+        print_table(agg, ev_steps)
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_inference_baseline()
+    return out
 
 
 def main():
@@ -100,10 +504,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='clips per GPU')
+    ap.add_argument('--batch', type=int, default=32, help='clips per GPU (c5: total clips, default 64)')
+    ap.add_argument('--config', default='c2', choices=['c2', 'c3', 'c5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--conv-precision', default='f32', choices=['f32', 'bf16', 'bf16x3'],
-                    help="operand format of the conv MFMAs; only 'f32' is the BASELINE configs[1] number")
+    ap.add_argument('--conv-precision', default=None, choices=['f32', 'bf16', 'bf16x3'],
+                    help="operand format of the conv MFMAs; default: f32 (c2, c5), bf16 (c3)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -115,135 +520,8 @@ def main():
     if world > 1:
         dist.init_process_group('nccl', device_id=torch.device(device))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-
-    from pb_sed_amd import _lib
-    from pb_sed_amd.models import weak_label
-    from pb_sed_amd.trainer import Trainer
-    torch.manual_seed(0)
-    model = weak_label.CRNN.build().to(device)
-    model.conv_precision = args.conv_precision
-    n_params = sum(p.numel() for p in model.parameters())
-    trainer = Trainer(model, lr=5e-4, gradient_clipping=1e10)
-    batch = synth_batch(args.batch, device, seed=rank)       # weak scaling: 32 clips per GPU
-
-    for i in range(args.warmup):
-        t_w = time.perf_counter()
-        trainer.step(batch)
-        torch.cuda.synchronize()
-        if rank == 0:
-            print(f'[bench] warm-up step {i}: {(time.perf_counter() - t_w) * 1e3:.1f} ms', file=sys.stderr, flush=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    _lib.timing = []                                          # per-call HIP events on the launch stream
-    ev_mode = os.environ.get('PBSED_BENCH_EVENTS', 'all' if os.environ.get('PBSED_BENCH_TABLE') else 'conv')
-    # HIP events bracket only the conv / front-end launches by default (what `roofline` needs): an event pair
-    # around each of the ~330 calls of a step costs ~1.3 ms/step of device idle time (PBSED_BENCH_EVENTS=all)
-    _lib.timing_filter = {'all': None, 'conv': (lambda n: n.startswith(('pbsed_conv', 'pbsed_gru_stack_fwd')) or
-                                                          n == 'pbsed_logmel_fwd')}[ev_mode]
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        review = trainer.step(batch)
-    t_enq = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    events, _lib.timing = _lib.timing, None
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
-    loss = float(review['loss'].item())
-    # host -> device hand-over of one batch (pinned, PCIe), outside the timed region: `value` is HBM-resident
-    host_batch = {k: v.cpu().pin_memory() for k, v in batch.items() if isinstance(v, torch.Tensor)}
-    torch.cuda.synchronize()
-    t_h = time.perf_counter()
-    for _ in range(5):
-        for k, v in host_batch.items():
-            batch[k].copy_(v, non_blocking=True)
-    torch.cuda.synchronize()
-    h2d_ms = (time.perf_counter() - t_h) / 5 * 1e3
-    from pb_sed_amd import ops as _ops
-    _ops.check_gru_sync()
-
+    out = bench_inference(args, world, rank, device) if args.config == 'c5' else bench_train(args, args.config, world, rank, device)
     if rank == 0:
-        # ---- per-call timing -> dominant MFMA launch
-        agg = {}
-        for name, tag, flops, byts, e0, e1 in events:
-            ms = e0.elapsed_time(e1)
-            a = agg.setdefault((name, tag), [0.0, 0, flops, byts])
-            a[0] += ms
-            a[1] += 1
-        conv = {k: v for k, v in agg.items() if k[0].startswith('pbsed_conv')}
-        (dname, dtag), (tot_ms, cnt, flops, _) = max(conv.items(), key=lambda kv: kv[1][0])
-        avg_ms = tot_ms / cnt
-        achieved = flops / (avg_ms * 1e-3) / 1e12
-        fe = [v for k, v in agg.items() if k[0] == 'pbsed_logmel_fwd']
-        by_family = {}
-        for (name, tag), (ms, c, fl, by) in agg.items():
-            by_family[name] = by_family.get(name, 0.0) + ms / args.steps
-        ms_step = dt / args.steps * 1e3
-        clips = args.batch * world
-        out = {
-            'metric': '10s@16kHz clips/sec (train step) FBCRNN batch32',
-            'value': round(clips / (dt / args.steps), 2), 'unit': 'clips/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'f32': 'f32', 'bf16': 'bf16 (conv MFMAs; fp32 accumulate/BN/GRU)',
-                      'bf16x3': 'bf16x3 (fp32 operands split into 3 bf16 terms, 6 MFMAs per product, fp32 accumulate)'}[args.conv_precision],
-            'data': 'synthetic (randn waveforms, random-init weights)',
-            'config': {'workload': 'FBCRNN weak_label_crnn.training batch 32/GPU fp32, 10 s 16 kHz clips '
-                                   '(BASELINE.json configs[1]); full train step incl. fused log-mel front-end, '
-                                   'loss, backward, grad-norm clip, Adam' + (', RCCL grad all-reduce' if world > 1 else ''),
-                       'global_batch': clips, 'n_params': n_params, 'parallelism': f'dp{world}'},
-            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         'traffic': pmc_traffic(f'{dname} {dtag}')[0], 'traffic_unit': 'HBM bytes per launch (PMC)',
-                         'traffic_source': pmc_traffic(f'{dname} {dtag}')[1],
-                         'kernel': f'{dname} {dtag}', 'avg_ms': round(avg_ms, 4), 'launches': cnt,
-                         'flops_per_launch': flops,
-                         # MFMA instructions actually issued: Winograd F(4,3) executes half the direct convolution's MACs
-                         'achieved_executed': round(achieved / (2 if dtag.endswith('wino') else 1), 2),
-                         'frac_executed': round(achieved / (2 if dtag.endswith('wino') else 1) / PEAK_FP32_MFMA_TFLOPS, 4),
-                         'note': ('algorithmic FLOPs = 2*MACs of the direct 3x3 convolution; this launch runs the '
-                                  'Winograd-F(4,3) kernel, which executes half of those multiplications on the MFMA '
-                                  f'pipe ({achieved / 2:.1f} TFLOP/s executed): frac = algorithmic / peak can exceed 1, frac_executed is the '
-                                  'MFMA-pipe utilisation') if dtag.endswith('wino') else
-                                 'algorithmic FLOPs = 2*MACs, all executed on the MFMA pipe'},
-            'step_mfma': {'algorithmic_tflop_per_step': round(TRAIN_GFLOP_PER_CLIP * args.batch / 1e3, 4),
-                          'achieved_tflops_per_gpu': round(TRAIN_GFLOP_PER_CLIP * args.batch / 1e3 / (ms_step * 1e-3), 2),
-                          'frac_of_fp32_mfma_peak': round(TRAIN_GFLOP_PER_CLIP * args.batch / 1e3 / (ms_step * 1e-3) / PEAK_FP32_MFMA_TFLOPS, 4)},
-            # BASELINE north_star target: MFMA roofline of the conv + GRU forward pass (algorithmic forward FLOPs over the
-            # summed event time of the forward conv / GRU-scan / front-end launches)
-            'forward_conv_gru': (lambda ms: {'ms_per_step': round(ms, 3),
-                                             'algorithmic_tflop': round(FWD_GFLOP_PER_CLIP * args.batch / 1e3, 4),
-                                             'achieved_tflops': round(FWD_GFLOP_PER_CLIP * args.batch / 1e3 / (ms * 1e-3), 2),
-                                             'frac_of_fp32_mfma_peak': round(FWD_GFLOP_PER_CLIP * args.batch / 1e3 / (ms * 1e-3)
-                                                                             / PEAK_FP32_MFMA_TFLOPS, 4)})(
-                sum(v for k, v in by_family.items() if k.startswith(('pbsed_conv_fwd', 'pbsed_gru_stack_fwd', 'pbsed_logmel')))),
-            'ms_per_step_by_entry_point': {k: round(v, 3) for k, v in sorted(by_family.items(), key=lambda kv: -kv[1])},
-            'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 3),
-            'h2d': {'ms_per_batch': round(h2d_ms, 3), 'bytes': int(sum(v.numel() * v.element_size() for v in host_batch.values())),
-                    'clips_per_s_if_serialised': round(clips / (dt / args.steps + h2d_ms * 1e-3), 2)},
-            'loss': loss,
-        }
-        if fe:
-            fe_ms = fe[0][0] / fe[0][1]
-            gbs = 896000.0 * args.batch / (fe_ms * 1e-3) / 1e9
-            out['frontend_hbm'] = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                   'frac': round(gbs / PEAK_HBM_GBS, 4), 'avg_ms': round(fe_ms, 4)}
-        print('[bench] gpu: ' + json.dumps({k: out[k] for k in ('value', 'ms_per_step', 'roofline')}),
-              file=sys.stderr, flush=True)
-        if os.environ.get('PBSED_BENCH_TABLE'):
-            print('[bench] per-call table (ms/step, calls/step, TFLOP/s):', file=sys.stderr)
-            for (name, tag), (ms, c, fl, _) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
-                tf = fl * c / (ms * 1e-3) / 1e12 if fl else 0.
-                print(f'   {ms / args.steps:8.3f} {c / args.steps:5.1f} {tf:7.1f}  {name[6:]} {tag}', file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -218,9 +218,11 @@ int pbsed_event_frames(const float* scores, const float* thr, const int* len, in
 
 /* ---- optimiser (padertorch Adam(lr, gradient_clipping); pb_sed/experiments/weak_label_crnn/training.py:264-269) */
 int pbsed_grad_sumsq(const float* g, size_t n, double* out, void* stream);
+/* skip_flags [n_flags] (or NULL): device error words of this step's persistent GRU scans (their `err` argument); if
+ * any is non-zero the update is skipped on the device, so gradients of a timed-out scan are never applied. */
 int pbsed_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                     float eps, int step, float grad_scale, float max_norm, const double* sumsq, float* norm_out,
-                    void* stream);
+                    const int* skip_flags, int n_flags, void* stream);
 int pbsed_memset_async(void* p, int value, size_t bytes, void* stream);
 
 #ifdef __cplusplus

@@ -65,7 +65,7 @@ SIGNATURES = {
     'pbsed_boundariesfilt': [_v, _v, _v, _v, I, I, _v],
     'pbsed_event_frames': [_v, _v, _v, _v, _v, I, I, I, _v],
     'pbsed_grad_sumsq': [_v, SZ, _v, _v],
-    'pbsed_adam_step': [_v, _v, _v, _v, SZ, F32, F32, F32, F32, I, F32, F32, _v, _v, _v],
+    'pbsed_adam_step': [_v, _v, _v, _v, SZ, F32, F32, F32, F32, I, F32, F32, _v, _v, _v, I, _v],
     'pbsed_memset_async': [_v, I, SZ, _v],
 }
 _NON_STATUS = {'pbsed_last_error': C.c_char_p, 'pbsed_version': C.c_int, 'pbsed_conv_pack_dims': None,
@@ -115,6 +115,7 @@ def int_array(vals):
     return (C.c_int * len(vals))(*[int(v) for v in vals])
 
 
+n_calls = 0            # C-ABI calls made so far (bench.py reports launches-class calls per step)
 timing_filter = None   # optional predicate on the entry-point name: only those calls are bracketed
 timing = None   # set to a list to record (name, tag, flops, bytes, start_event, end_event) per call
 
@@ -122,6 +123,8 @@ timing = None   # set to a list to record (name, tag, flops, bytes, start_event,
 def call(name, *args, tag='', flops=0, nbytes=0):
     """Invoke a status-returning entry point; raise RuntimeError with the library's message.
     With ``timing`` enabled the call is bracketed by HIP events on the launch stream."""
+    global n_calls
+    n_calls += 1
     timed = timing is not None and (timing_filter is None or timing_filter(name))
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -413,7 +413,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, size_t n,
                                                    float lr, float b1, float b2, float eps, float bc1,
                                                    float bc2_sqrt, float gscale, float max_norm,
-                                                   const double* sumsq, float* norm_out) {
+                                                   const double* sumsq, float* norm_out,
+                                                   const int* __restrict__ skip_flags, int n_flags) {
+    // gradients produced behind a raised error flag (a persistent GRU scan that hit its bounded-spin time-out) are
+    // never applied: the step becomes a no-op on the device, the host raises when it reads the same flags
+    for (int i = 0; i < n_flags; ++i)
+        if (skip_flags[i]) return;
     float coef = gscale;
     if (sumsq) {
         const float norm = (float)sqrt(*sumsq) * gscale;
@@ -527,7 +532,7 @@ int pbsed_fbcrnn_loss(const float* logit_fwd, const float* logit_bwd, const floa
                  dlogit_fwd, dlogit_bwd, loss, B, K, T, slat, minimum_score, strong_weight, label_smoothing,
                  inputs_are_scores, summary};
     PBSED_HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream), "hipMemsetAsync");
-    if (summary) hipMemsetAsync(summary + (size_t)3 * B * K, 0, sizeof(float), (hipStream_t)stream);
+    if (summary) PBSED_HIP_TRY(hipMemsetAsync(summary + (size_t)3 * B * K, 0, sizeof(float), (hipStream_t)stream), "hipMemsetAsync");
     hipLaunchKernelGGL(fbcrnn_loss_kernel, dim3(B * K), dim3(256), 2 * T * sizeof(float), (hipStream_t)stream, a);
     return check_launch("fbcrnn_loss");
 }
@@ -562,11 +567,11 @@ int pbsed_grad_sumsq(const float* g, size_t n, double* out, void* stream) {
 
 int pbsed_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
                     float beta2, float eps, int step, float grad_scale, float max_norm,
-                    const double* sumsq, float* norm_out, void* stream) {
+                    const double* sumsq, float* norm_out, const int* skip_flags, int n_flags, void* stream) {
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                       n, lr, beta1, beta2, eps, bc1, bc2s, grad_scale, max_norm, sumsq, norm_out);
+                       n, lr, beta1, beta2, eps, bc1, bc2s, grad_scale, max_norm, sumsq, norm_out, skip_flags, skip_flags ? n_flags : 0);
     return check_launch("adam_step");
 }
 

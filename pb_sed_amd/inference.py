@@ -130,6 +130,7 @@ def inference(model, method, dataset, device, max_segment_length=None, segment_o
             scores.update(postprocess_batch(per_model, seq_len, batch['example_id'], medfilt_length=medfilt_length,
                                             stepfilt_length=stepfilt_length, apply_mask=apply_mask, masks=masks,
                                             post_processing_fn=post_processing_fn))
+            ops.check_gru_sync()        # the scores are on the host already: a timed-out persistent scan raises here
     if timestamps is not None or event_classes is not None:
         assert timestamps is not None and event_classes is not None
         return scores_to_dataframes(scores, timestamps, event_classes)

@@ -373,24 +373,49 @@ def gru_scan_bwd(w_hh_t, hs, save, dy, reverse, seq_len):
 
 
 _GRANULE_WS = {}        # (device, shape) -> [granule workspace, epoch counter] of the persistent GRU scan
-_GRU_SYNC = []          # error flags handed to persistent scans since the last check
+_GRU_FLAGS = {}         # device -> [int32 flag words, words handed out since the last check]
+GRU_FLAG_WORDS = 64
+
+
+def gru_flags(device):
+    """The device's error words of the persistent scans ([GRU_FLAG_WORDS] int32; a scan that hits its bounded-spin
+    time-out sets its word).  Trainer.step hands them to the fused Adam (which then skips the update) and copies them to
+    the host with the step's summary; inference checks them at the end of every batch."""
+    key = str(torch.device(device))
+    st = _GRU_FLAGS.get(key)
+    if st is None:
+        st = _GRU_FLAGS[key] = [torch.zeros(GRU_FLAG_WORDS, dtype=torch.int32, device=device), 0]
+    return st
 
 
 def _gru_err_flag(device):
-    ws = torch.zeros(1, dtype=torch.int32, device=device)
-    _GRU_SYNC.append(ws)
-    if len(_GRU_SYNC) > 64:
-        check_gru_sync()
-    return ws
+    st = gru_flags(device)
+    if st[1] >= GRU_FLAG_WORDS:
+        check_gru_sync()                             # nobody looked for a long time: look now (host sync)
+    word = st[0][st[1]:st[1] + 1]
+    st[1] += 1
+    return word
+
+
+def gru_flags_raise(host_words):
+    """``host_words``: a host copy of gru_flags()[0].  Drops the scan workspaces (they hold words of mixed parity after
+    a time-out) and raises if any word is set."""
+    if np.any(np.asarray(host_words)):
+        _GRANULE_WS.clear()
+        for st in _GRU_FLAGS.values():
+            st[0].zero_()
+            st[1] = 0
+        raise RuntimeError('persistent GRU scan: inter-workgroup hand-off timed out; this step\'s results were discarded '
+                           '(the optimiser update was skipped on the device).  PBSED_GRU_PERSIST=0 selects the '
+                           'launch-per-step scans.')
 
 
 def check_gru_sync():
     """Raise if any persistent GRU scan since the last check hit its bounded-spin timeout (host sync)."""
-    flags = [int(w[0].item()) for w in _GRU_SYNC]
-    del _GRU_SYNC[:]
-    if any(flags):
-        _GRANULE_WS.clear()                      # partially written workspaces must not be reused
-        raise RuntimeError('persistent GRU scan: inter-workgroup hand-off timed out (PBSED_GRU_PERSIST=0 disables it)')
+    for st in list(_GRU_FLAGS.values()):
+        if st[1]:
+            st[1] = 0
+            gru_flags_raise(st[0].cpu().numpy())
 
 
 _CU_COUNT = {}
@@ -429,7 +454,8 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
         call('pbsed_gru_stack_fwd_granule', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih),
              _lib.ptr_array(b_ih), _lib.ptr_array(w_hh), _lib.ptr_array(b_hh), _lib.ptr_array(hs),
              _lib.ptr_array(sv) if save else None, _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]),
-             gw[1] + 1, ptr(ws), stream())
+             gw[1] + 1, ptr(ws), stream(), tag=f'{nch}x{nlayers} B{b} H{h} T{t}',
+             flops=2. * nch * (2 * nlayers - 1) * t * b * 3 * h * h)        # recurrent + layer-boundary projection products
         gw[1] += 1                                   # parity flips per launched call: the previous call's words never match
         return hs, sv
     call('pbsed_gru_stack_fwd', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih), _lib.ptr_array(b_ih),
@@ -454,7 +480,8 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
         ws = _gru_err_flag(dev)
         call('pbsed_gru_stack_bwd_granule', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t),
              _lib.ptr_array(hs), _lib.ptr_array(save), _lib.ptr_array(dy_top), _lib.ptr_array(dgi), _lib.ptr_array(dgh),
-             _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]), gw[1] + 1, ptr(ws), stream())
+             _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]), gw[1] + 1, ptr(ws), stream(),
+             tag=f'{nch}x{nlayers} B{b} H{h} T{t}', flops=2. * nch * (2 * nlayers - 1) * t * b * 3 * h * h)
         gw[1] += 1
         return dgi, dgh
     dhz = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
@@ -575,10 +602,10 @@ def grad_sumsq(g, out):
 
 
 def adam_step(p, g, m, v, *, lr, beta1=.9, beta2=.999, eps=1e-8, step, grad_scale=1., max_norm=1e10,
-              sumsq=None, norm_out=None):
+              sumsq=None, norm_out=None, skip_flags=None):
     call('pbsed_adam_step', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1),
          float(beta2), float(eps), int(step), float(grad_scale), float(max_norm), ptr(sumsq),
-         ptr(norm_out), stream())
+         ptr(norm_out), ptr(skip_flags), 0 if skip_flags is None else skip_flags.numel(), stream())
 
 
 # ------------------------------------------------------------------------------------- post-processing

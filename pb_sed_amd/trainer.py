@@ -10,6 +10,7 @@ the backward pass as soon as a bucket's gradients are final, so the collective o
 remaining conv dgrad/wgrad kernels.  Adam folds the 1/world_size average and the clip coefficient.
 """
 import inspect
+import time
 
 import numpy as np
 import torch
@@ -130,6 +131,9 @@ class Trainer:
         self.sync = GradSync(self.flat_grad, buckets)
         model._grad_hook = self._on_grads_ready
         self._defer = 'defer_summary' in inspect.signature(model.review).parameters
+        self._flags_host = torch.zeros(ops.GRU_FLAG_WORDS, dtype=torch.int32).pin_memory() if self.flat_param.is_cuda else None
+        self.last_enqueue_s = 0.            # host time of the last step up to (not including) the wait for its summary
+        self.measure_sync, self.sync_events = False, None   # bench.py: event pairs around the wait for the collectives
 
     def _on_grads_ready(self, name):
         if name in self.bucket_names:
@@ -137,21 +141,41 @@ class Trainer:
 
     def step(self, batch):
         """One optimisation step.  Returns the review dict (loss is a device scalar, no host sync)."""
+        t_start = time.perf_counter()
         self.model.train()
         self.flat_grad.zero_()
+        flags = ops.gru_flags(self.flat_param.device) if self.flat_param.is_cuda else None
         outputs = self.model(dict(batch))
         review = self.model.review(batch, outputs, defer_summary=True) if self._defer else self.model.review(batch, outputs)
         review['loss'].backward()
-        scale = self.sync.finish()
+        if self.measure_sync and self.sync_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            scale = self.sync.finish()               # the compute stream waits here for whatever is not overlapped
+            e1.record()
+            self.sync_events.append((e0, e1))
+        else:
+            scale = self.sync.finish()
         self.iteration += 1
         ops.grad_sumsq(self.flat_grad, self.sumsq)
         ops.adam_step(self.flat_param, self.flat_grad, self.m, self.v, lr=self.lr, beta1=self.betas[0],
                       beta2=self.betas[1], eps=self.eps, step=self.iteration, grad_scale=scale,
-                      max_norm=self.clip, sumsq=self.sumsq, norm_out=self.grad_norm)
+                      max_norm=self.clip, sumsq=self.sumsq, norm_out=self.grad_norm,
+                      skip_flags=None if flags is None else flags[0])     # a timed-out scan: no update on the device
         ops.invalidate_packed()          # parameters changed in place behind torch's version counters
         ops.refresh_packs()              # ... and every packed copy is rebuilt in one launch
         review['scalars']['grad_norm'] = self.grad_norm
+        checked = None
+        if flags is not None and flags[1]:
+            self._flags_host.copy_(flags[0], non_blocking=True)       # rides along with the summary copy
+            checked = torch.cuda.Event()
+            checked.record()
+            flags[1] = 0
+        self.last_enqueue_s = time.perf_counter() - t_start
         finalize = review.pop('_finalize', None)
         if finalize is not None:
             finalize()                               # host-side summary: waits for a copy issued after the forward pass
+        if checked is not None:
+            checked.synchronize()
+            ops.gru_flags_raise(self._flags_host.numpy())   # once per step, before the caller can use the results
         return review

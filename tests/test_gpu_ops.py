@@ -273,6 +273,26 @@ def test_adam_and_grad_norm_vs_torch():
     close(p, pr, atol=1e-6, rtol=1e-5, name='adam params after 3 steps')
 
 
+def test_adam_skips_the_update_behind_a_raised_scan_flag():
+    """A persistent GRU scan that timed out leaves an error word set; the fused Adam given those words must not touch
+    parameters or moments (Trainer.step hands them over, the host raises once it has read them)."""
+    from pb_sed_amd import ops
+    n = 4099
+    p, g = torch.randn(n, device=DEV), torch.randn(n, device=DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    p0 = p.clone()
+    flags = torch.zeros(ops.GRU_FLAG_WORDS, dtype=torch.int32, device=DEV)
+    flags[5] = 1
+    ops.adam_step(p, g, m, v, lr=1e-2, step=1, skip_flags=flags)
+    assert torch.equal(p, p0) and not m.any() and not v.any()
+    flags.zero_()
+    ops.adam_step(p, g, m, v, lr=1e-2, step=1, skip_flags=flags)
+    assert not torch.equal(p, p0) and m.any()
+    with pytest.raises(RuntimeError, match='timed out'):
+        ops.gru_flags_raise(np.array([0, 0, 1]))
+    ops.gru_flags_raise(np.zeros(4))
+
+
 @pytest.mark.parametrize('persist', ['2', '0'])
 @pytest.mark.parametrize('b,h,t,ragged', [(5, 64, 23, True), (32, 256, 30, False), (19, 128, 17, True), (16, 512, 5, False),
                                           (1, 128, 40, True)])
