@@ -39,8 +39,10 @@ int pbsed_version(void);
 int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, const int* seq_len_frames,
                      const float* window, const float* twiddle, const int* mel_start, const int* mel_len,
                      const int* mel_off, const float* mel_w, int F, const float* mean, const float* inv_std,
-                     float eps, float clampv, float* out, double* stats, void* stream);
-/* `stats` (both front-end entry points): NULL, or [PBSED_STAT_SLOTS][F][2] zeroed doubles that receive the per-mel sum
+                     float eps, float clampv, float* out, double* stats, int pad_front, void* stream);
+/* `pad_front`: zero samples assumed before wav[0]; frame t covers samples [320 t - pad_front, +960).  320 is the
+ * reference's 'half' fading (provider.py:315-323); 0 for a slice cut out of the middle of a long clip.
+ * `stats` (both front-end entry points): NULL, or [PBSED_STAT_SLOTS][F][2] zeroed doubles that receive the per-mel sum
  * and sum of squares of the values written for frames < seq_len - the training-mode statistics pass of the feature
  * normalisation (call with mean = 0, inv_std = 1, clampv = inf, then pbsed_feature_norm_update, then
  * pbsed_augment_logmel(mean, inv_std, clampv) to normalise in place).
@@ -205,6 +207,13 @@ int pbsed_fbcrnn_loss(const float* logit_fwd, const float* logit_bwd, const floa
 int pbsed_bicrnn_loss(const float* logit, const float* strong_targets, const int* seq_len, float* y,
                       float* dlogit, float* loss, double* scratch, int B, int K, int T, int inputs_are_scores,
                       void* stream);
+
+/* Validation summary of strong_label.CRNN.review (pb_sed/models/strong_label/crnn.py:114-136): y, strong_targets
+ * [B,K,T] -> segment maxima over `segment_length` frames y_seg / t_seg [B, T/segment_length, K] (segments not fully
+ * inside seq_len[b] hold 0), mask_mean [B,K] = share of labelled frames (target > .99 or < .01) inside the sequence,
+ * mask_cnt [B,K] = labelled frames over all T. */
+int pbsed_bicrnn_review_summary(const float* y, const float* strong_targets, const int* seq_len, float* y_seg, float* t_seg,
+                                float* mask_mean, float* mask_cnt, int B, int K, int T, int segment_length, void* stream);
 
 /* ---- ensemble post-processing (pb_sed/models/base/inference.py:142-184,225-289; pb_sed/filters.py:56-83,112-135;
  * event extraction = sed_scores_eval scores_to_event_list, call site experiments/strong_label_crnn/inference.py:147-150).

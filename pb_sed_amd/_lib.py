@@ -43,7 +43,7 @@ SIGNATURES = {
     'pbsed_bn_bwd_finalize': [_v, F64, _v, _v, _v, _v, I, _v],
     'pbsed_bn_bwd_apply': [_v, _v, _v, _v, _v, _v, _v, _v, I, I, I, I, _v],
     'pbsed_augment_logmel': [_v, _v, _v, _v, _v, _v, _v, F32, I, I, I, _v],
-    'pbsed_logmel_fwd': [_v, I, I, I, _v, _v, _v, _v, _v, _v, _v, I, _v, _v, F32, F32, _v, _v, _v],
+    'pbsed_logmel_fwd': [_v, I, I, I, _v, _v, _v, _v, _v, _v, _v, I, _v, _v, F32, F32, _v, _v, I, _v],
     'pbsed_logmel_from_stft': [_v, I, I, I, _v, _v, _v, _v, _v, I, _v, _v, F32, F32, _v, _v, _v],
     'pbsed_feature_norm_update': [_v, F64, _v, _v, _v, F32, _v, _v, I, _v],
     'pbsed_bct_to_tbc': [_v, _v, I, I, I, _v],
@@ -58,6 +58,7 @@ SIGNATURES = {
     'pbsed_gru_stack_bwd': [I, I, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _i, _v, I, I, I, _v],
     'pbsed_fbcrnn_loss': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, I, I, F32, F32, I, F32, I, _v, _v],
     'pbsed_bicrnn_loss': [_v, _v, _v, _v, _v, _v, _v, I, I, I, I, _v],
+    'pbsed_bicrnn_review_summary': [_v, _v, _v, _v, _v, _v, _v, I, I, I, I, _v],
     'pbsed_squash_fwd': [_v, _v, SZ, F32, _v],
     'pbsed_squash_bwd': [_v, _v, _v, SZ, F32, _v],
     'pbsed_ensemble_mean_mask': [_pp, I, _v, _v, I, I, I, _v],

@@ -32,6 +32,8 @@ struct LogmelArgs {
     double* stats;           // optional [PBSED_STAT_SLOTS][F][2]: masked sum / sum of squares of the written values
     int B, N, T, F;
     float eps, clampv;
+    int pad_front;           // zero samples assumed in front of wav[0] (320 = the reference's 'half' fading; 0 for a slice
+                             // cut out of the middle of a clip, pb_sed_amd/utils/segment.py)
 };
 
 // Per-mel sums of one block's output tile (frames past seq_len hold 0 and add nothing) into one of the slot copies.
@@ -62,8 +64,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nTt = (a.T + LM_FR - 1) / LM_FR;
     const int b = blockIdx.x / nTt, t0 = (blockIdx.x % nTt) * LM_FR;
-    const int pad_front = (LM_WIN - LM_SHIFT) / 2;
-    const long s0 = (long)t0 * LM_SHIFT - pad_front;
+    const long s0 = (long)t0 * LM_SHIFT - a.pad_front;
     const float* wav = a.wav + (size_t)b * a.N;
     for (int i = tid; i < NS_SAMP; i += 256) {
         const long n = s0 + i;
@@ -259,10 +260,11 @@ extern "C" int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, c
                                 const float* window, const float* twiddle, const int* mel_start,
                                 const int* mel_len, const int* mel_off, const float* mel_w, int F,
                                 const float* mean, const float* inv_std, float eps, float clampv,
-                                float* out, double* stats, void* stream) {
+                                float* out, double* stats, int pad_front, void* stream) {
+    if (pad_front < 0 || pad_front > LM_WIN) { set_error("logmel: pad_front %d", pad_front); return PBSED_E_ARG; }
     if (F > LM_NMEL_MAX * 4 || F < 1 || T < 1) { set_error("logmel: bad F=%d T=%d", F, T); return PBSED_E_ARG; }
     LogmelArgs a{wav, window, twiddle, mel_start, mel_len, mel_off, mel_w, mean, inv_std, seq_len_frames,
-                 out, stats, B, n_samples, T, F, eps, clampv};
+                 out, stats, B, n_samples, T, F, eps, clampv, pad_front};
     const int nTt = (T + LM_FR - 1) / LM_FR;
     const size_t lds = ((LM_FR - 1) * LM_SHIFT + LM_WIN + LM_WIN) * sizeof(float) + 1024 * sizeof(cpx) +
                        4 * 2 * 512 * sizeof(cpx) + (size_t)F * (LM_FR + 1) * sizeof(float);

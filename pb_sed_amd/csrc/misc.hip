@@ -434,6 +434,46 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+
+// BiCRNN review summary (pb_sed/models/strong_label/crnn.py:114-136): per (clip, class) the share of labelled frames
+// inside the sequence (-> strongly labelled clips), the labelled-frame count over ALL T frames (-> strong_label_rate),
+// and the segment-wise maxima of scores and targets over eval_segment_length frames ([B, S, K], S = T / L; segments that
+// do not fit into seq_len[b] completely hold 0 and are dropped by the host).  One block per (b, k) row.
+__global__ __launch_bounds__(256) void bicrnn_review_summary_kernel(const float* __restrict__ y, const float* __restrict__ st,
+                                                                    const int* __restrict__ seq_len, float* __restrict__ y_seg,
+                                                                    float* __restrict__ t_seg, float* __restrict__ mask_mean,
+                                                                    float* __restrict__ mask_cnt, int B, int K, int T, int L) {
+    const int row = blockIdx.x, b = row / K, k = row % K;
+    const int sl = min(seq_len[b], T), S = T / L, s_valid = sl / L;
+    const float* yr = y + (size_t)row * T;
+    const float* tr = st + (size_t)row * T;
+    float in_seq = 0.f, all = 0.f;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const float v = tr[t];
+        const float m = (v > .99f || v < .01f) ? 1.f : 0.f;
+        all += m;
+        if (t < sl) in_seq += m;
+    }
+    in_seq = wave_sum64(in_seq);
+    all = wave_sum64(all);
+    __shared__ float red[2][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = in_seq; red[1][threadIdx.x >> 6] = all; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mask_mean[row] = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)max(sl, 1);
+        mask_cnt[row] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        float my = 0.f, mt = 0.f;
+        if (s < s_valid) {
+            my = yr[s * L]; mt = tr[s * L];
+            for (int j = 1; j < L; ++j) { my = fmaxf(my, yr[s * L + j]); mt = fmaxf(mt, tr[s * L + j]); }
+        }
+        y_seg[((size_t)b * S + s) * K + k] = my;
+        t_seg[((size_t)b * S + s) * K + k] = mt;
+    }
+}
+
 }  // namespace pbsed
 
 using namespace pbsed;
@@ -547,6 +587,14 @@ int pbsed_bicrnn_loss(const float* logit, const float* strong_targets, const int
     hipLaunchKernelGGL(bicrnn_mask_count_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(bicrnn_loss_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("bicrnn_loss");
+}
+
+int pbsed_bicrnn_review_summary(const float* y, const float* strong_targets, const int* seq_len, float* y_seg, float* t_seg,
+                                float* mask_mean, float* mask_cnt, int B, int K, int T, int segment_length, void* stream) {
+    if (segment_length < 1 || segment_length > T) { set_error("bicrnn_review_summary: segment length %d for T=%d", segment_length, T); return PBSED_E_ARG; }
+    hipLaunchKernelGGL(bicrnn_review_summary_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, y, strong_targets, seq_len,
+                       y_seg, t_seg, mask_mean, mask_cnt, B, K, T, segment_length);
+    return check_launch("bicrnn_review_summary");
 }
 
 int pbsed_squash_fwd(const float* x, float* y, size_t n, float eps, void* stream) {

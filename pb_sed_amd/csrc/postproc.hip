@@ -25,40 +25,47 @@ __global__ void ensemble_mean_mask_kernel(MeanArgs a, int M, float* __restrict__
     }
 }
 
-// Zero-padded running median of odd length n[row] (n == 1: copy).  One block per row, row staged in LDS.
+// Zero-padded running median of odd length n[row] (n == 1: copy).  One block per row, row staged in LDS as order-preserving
+// integer keys.  Exact selection in O(32 n) per output instead of O(n^2): the median is the (h+1)-th smallest of the
+// window's n values (zeros outside [0, T) included), found by bisecting on the key space - 32 counting passes over the
+// window, no candidate loop, no divergence between the outputs of a wave (tested up to n = 301, the reference's tuning
+// range, pb_sed/experiments/strong_label_crnn/tuning.py:64).  -0.0 is folded into +0.0 (scipy's sort treats them equal
+// and the padding is +0.0).
+__device__ __forceinline__ unsigned med_key(float v) {
+    unsigned u = __float_as_uint(v + 0.f);                        // -0.0 + 0.0 = +0.0
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);            // monotone: a < b  <=>  key(a) < key(b)
+}
+__device__ __forceinline__ float med_unkey(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
 __global__ __launch_bounds__(256) void medfilt_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                       const int* __restrict__ n_row, int R, int T) {
-    extern __shared__ float xs[];
+    extern __shared__ unsigned xk[];
     const int row = blockIdx.x;
     const float* x = in + (size_t)row * T;
     float* y = out + (size_t)row * T;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) xs[t] = x[t];
-    __syncthreads();
     const int n = n_row[row];
     if (n <= 1) {
-        for (int t = threadIdx.x; t < T; t += blockDim.x) y[t] = xs[t];
+        for (int t = threadIdx.x; t < T; t += blockDim.x) y[t] = x[t];
         return;
     }
+    for (int t = threadIdx.x; t < T; t += blockDim.x) xk[t] = med_key(x[t]);
+    __syncthreads();
     const int h = n / 2;
+    const unsigned zero_key = 0x80000000u;
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
-        const int lo = t - h, hi = t + h;                       // window [lo, hi], zeros outside [0, T)
-        const int a0 = max(lo, 0), a1 = min(hi, T - 1);
+        const int a0 = max(t - h, 0), a1 = min(t + h, T - 1);
         const int nzero = n - (a1 - a0 + 1);                    // padded zeros inside the window
-        float med = 0.f;
-        bool found = false;
-        // candidate 0 (only if padding contributes zeros)
-        if (nzero > 0) {
-            int less = 0, eq = nzero;
-            for (int k = a0; k <= a1; ++k) { const float v = xs[k]; less += v < 0.f; eq += v == 0.f; }
-            if (less <= h && h < less + eq) { med = 0.f; found = true; }
+        // smallest key K with #{window values <= K} >= h + 1
+        unsigned lo = 0u, hi = 0xffffffffu;
+        while (lo < hi) {
+            const unsigned mid = lo + ((hi - lo) >> 1);
+            int cnt = (zero_key <= mid) ? nzero : 0;
+            for (int k = a0; k <= a1; ++k) cnt += xk[k] <= mid;
+            if (cnt >= h + 1) hi = mid; else lo = mid + 1;
         }
-        for (int c = a0; c <= a1 && !found; ++c) {
-            const float cv = xs[c];
-            int less = (cv > 0.f) ? nzero : 0, eq = (cv == 0.f) ? nzero : 0;
-            for (int k = a0; k <= a1; ++k) { const float v = xs[k]; less += v < cv; eq += v == cv; }
-            if (less <= h && h < less + eq) { med = cv; found = true; }
-        }
-        y[t] = med;
+        y[t] = med_unkey(lo);
     }
 }
 

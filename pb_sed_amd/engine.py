@@ -398,12 +398,13 @@ def _features(fe, raw_fn, seq_dev, seq_host, n_frames):
     return augment_features(fe, x, seq_dev, seq_host, normalise=True)
 
 
-def features_from_audio(fe, audio, seq_dev, n_frames, seq_host=None):
+def features_from_audio(fe, audio, seq_dev, n_frames, seq_host=None, pad_front=320):
     tables = _tables(fe, audio.device)
     if seq_host is None:
         seq_host = seq_dev.cpu().numpy()
     return _features(fe, lambda mean, inv_std, clamp, stats: ops.logmel_fwd(
-        audio, tables, mean, inv_std, n_frames, seq_dev, eps=fe.eps, clamp=clamp, stats=stats), seq_dev, seq_host, n_frames)
+        audio, tables, mean, inv_std, n_frames, seq_dev, eps=fe.eps, clamp=clamp, stats=stats, pad_front=pad_front),
+        seq_dev, seq_host, n_frames)
 
 
 def augment_features(fe, x, seq_dev, seq_host=None, normalise=False):

@@ -8,13 +8,15 @@ that are bit-exact with the reference's numpy/scipy host code (tests/test_gpu_po
 reference's own golden vectors).  Only the final per-clip ``[(n,)T,K]`` arrays go to the host, keyed by
 ``example_id`` like the reference's result dict.
 
-Not carried over (SURVEY.md section 8 marks them out of scope for 10 s clips): ``max_segment_length`` /
-``merge_score_segments`` (utils/segment.py) and on-disk score storage.
+Long clips: ``max_segment_length`` / ``segment_overlap`` / ``merge_score_segments`` / ``score_segment_overlap`` split
+every batch into overlapping windows and merge the per-segment scores as the reference does
+(pb_sed/models/base/inference.py:121-128,185-197 with pb_sed/utils/segment.py).  Not carried over: on-disk score storage.
 """
 import numpy as np
 import torch
 
 from . import ops
+from .utils.segment import is_last_segment, merge_segments, segment_batch
 
 
 def _as_dev_scores(y, device):
@@ -101,8 +103,8 @@ def inference(model, method, dataset, device, max_segment_length=None, segment_o
               event_classes=None, score_storage_dir=None, rank=0, world_size=1):
     """Same contract as the reference's ``inference`` (inference.py:86-222).  ``rank``/``world_size``
     shard every batch over clips (config 5: no collective needed, results are keyed by example_id)."""
-    if max_segment_length is not None or merge_score_segments or score_storage_dir is not None:
-        raise NotImplementedError('segmenting / score storage are outside the MI355X hot path')
+    if score_storage_dir is not None:
+        raise NotImplementedError('on-disk score storage is outside the MI355X hot path')
     models = list(model) if isinstance(model, (list, tuple)) else [model]
     model_kwargs = {} if model_kwargs is None else model_kwargs
     kwargs = list(model_kwargs) if isinstance(model_kwargs, (list, tuple)) else len(models) * [model_kwargs]
@@ -118,19 +120,30 @@ def inference(model, method, dataset, device, max_segment_length=None, segment_o
             if world_size > 1:
                 from .trainer import shard_batch
                 batch = shard_batch(batch, rank, world_size)
-            batch = models[0].example_to_device(batch, device)
-            per_model, seq_len = [], None
-            for m, kw in zip(models, kwargs):
-                y, sl = getattr(m, method)(batch, **kw)
-                per_model.append(_as_dev_scores(y, device))
-                if seq_len is None:
-                    seq_len = np.asarray(sl)
-                else:
-                    assert (np.asarray(sl) == seq_len).all(), (seq_len, sl)
-            scores.update(postprocess_batch(per_model, seq_len, batch['example_id'], medfilt_length=medfilt_length,
-                                            stepfilt_length=stepfilt_length, apply_mask=apply_mask, masks=masks,
-                                            post_processing_fn=post_processing_fn))
+            segments = [batch] if max_segment_length is None else segment_batch(batch, max_segment_length, segment_overlap)
+            cache = {}
+            for segment in segments:
+                segment = models[0].example_to_device(segment, device)
+                per_model, seq_len = [], None
+                for m, kw in zip(models, kwargs):
+                    y, sl = getattr(m, method)(segment, **kw)
+                    per_model.append(_as_dev_scores(y, device))
+                    if seq_len is None:
+                        seq_len = np.asarray(sl)
+                    else:
+                        assert (np.asarray(sl) == seq_len).all(), (seq_len, sl)
+                seg_masks = masks
+                if masks is not None and len(segments) > 1:       # tags are keyed by clip, segments by clip + position
+                    seg_masks = {a: masks[a.split('_!segment!_')[0]] for a in segment['example_id']}
+                cache.update(postprocess_batch(per_model, seq_len, segment['example_id'], medfilt_length=medfilt_length,
+                                               stepfilt_length=stepfilt_length, apply_mask=apply_mask, masks=seg_masks,
+                                               post_processing_fn=post_processing_fn))
             ops.check_gru_sync()        # the scores are on the host already: a timed-out persistent scan raises here
+            if merge_score_segments and not is_last_segment(segments[-1]['example_id'][0]):
+                raise RuntimeError('a batch ended before its last segment')
+            if merge_score_segments:
+                cache = merge_segments(cache, segment_overlap if score_segment_overlap is None else score_segment_overlap)
+            scores.update(cache)
     if timestamps is not None or event_classes is not None:
         assert timestamps is not None and event_classes is not None
         return scores_to_dataframes(scores, timestamps, event_classes)
@@ -156,6 +169,24 @@ def sound_event_detection(models, dataset, device, model_kwargs=None, medfilt_le
                           apply_mask=False, masks=None, timestamps=None, event_classes=None, **kw):
     return inference(models, method, dataset, device, model_kwargs=model_kwargs, medfilt_length=medfilt_length,
                      apply_mask=apply_mask, masks=masks, timestamps=timestamps, event_classes=event_classes, **kw)
+
+
+def shift_and_widen_events(event_lists, pseudo_widening=0., onset_bias=None, offset_bias=None):
+    """Boundary correction applied to detected events before they are written out as pseudo labels
+    (pb_sed/experiments/strong_label_crnn/inference.py:177-184): onsets move earlier by ``pseudo_widening`` plus the
+    class' tuned onset bias (clamped at 0 s), offsets later by ``pseudo_widening`` minus its offset bias; events that
+    end up empty are dropped.  ``onset_bias`` / ``offset_bias``: {label: seconds} (missing labels: 0)."""
+    onset_bias, offset_bias = onset_bias or {}, offset_bias or {}
+    out = {}
+    for clip_id, events in event_lists.items():
+        kept = []
+        for onset, offset, label in events:
+            on = max(onset - pseudo_widening - onset_bias.get(label, 0), 0)
+            off = offset + pseudo_widening - offset_bias.get(label, 0)
+            if off > on:
+                kept.append((on, off, label))
+        out[clip_id] = kept
+    return out
 
 
 def scores_to_event_list(scores, thresholds, event_classes, timestamps, device='cuda'):

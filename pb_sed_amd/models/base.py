@@ -8,6 +8,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from ..configurable import Configurable
 from ..engine import flatten_parameters, seq_to_device
 
 
@@ -25,7 +26,7 @@ def _image_column(images, padding=2):
     return grid
 
 
-class SoundEventModel(nn.Module, abc.ABC):
+class SoundEventModel(nn.Module, Configurable, abc.ABC):
     def __init__(self, *, labelwise_metrics=(), label_mapping=None, test_labels=None):
         super().__init__()
         self.labelwise_metrics = labelwise_metrics
@@ -80,49 +81,61 @@ class SoundEventModel(nn.Module, abc.ABC):
             summary['images'][key] = _image_column(image.flip(2))
         return summary
 
+    def _class_names(self):
+        """(column selection or None, display name per selected column) from ``test_labels`` / ``label_mapping``."""
+        cols = self.test_labels
+        if cols is not None and isinstance(cols[0], str):
+            assert self.label_mapping is not None
+            cols = [self.label_mapping.index(name) for name in cols]
+        return cols, (lambda j: (self.label_mapping[c] if self.label_mapping is not None else c)
+                      if (c := (j if cols is None else cols[j])) is not None else j)
+
     def add_metrics_to_summary(self, summary, suffix):
-        """Validation metrics from the ``y_<suffix>`` / ``targets_<suffix>`` buffers (reference model.py:44-88)."""
-        from sklearn import metrics
+        """Validation metrics from the ``y_<suffix>`` / ``targets_<suffix>`` buffers (contract: the scalar keys of the
+        reference's pb_sed/models/base/model.py:44-88).  Expressed as a table: (aggregate key, label-wise key, per-class
+        values, aggregate) - the ranking metrics are only defined when every class has at least two positives."""
         from ..evaluation import instance_based
-        y = np.concatenate(summary['buffers'].pop(f'y_{suffix}'))
-        summary['scalars'][f'num_examples_{suffix}'] = len(y)
-        targets = np.concatenate(summary['buffers'].pop(f'targets_{suffix}'))
-        test_labels = self.test_labels
-        if test_labels is not None:
-            if isinstance(test_labels[0], str):
-                assert self.label_mapping is not None
-                test_labels = [self.label_mapping.index(label) for label in test_labels]
-            y, targets = y[..., test_labels], targets[..., test_labels]
-
-        def label_wise(key, values):
-            if key not in self.labelwise_metrics:
-                return
-            for event_class, value in enumerate(values):
-                if test_labels is not None:
-                    event_class = test_labels[event_class]
-                if self.label_mapping is not None:
-                    event_class = self.label_mapping[event_class]
-                summary['scalars'][f'z/{key}/{event_class}'] = value
-
-        _, f, _, _ = instance_based.get_best_fscore_thresholds(targets, y)
-        summary['scalars'][f'macro_fscore_{suffix}'] = f.mean()
-        label_wise(f'fscore_{suffix}', f)
-        _, er, _, _ = instance_based.get_best_er_thresholds(targets, y)
-        summary['scalars'][f'macro_error_rate_{suffix}'] = er.mean()
-        label_wise(f'error_rate_{suffix}', er)
-        lwlrap, per_class_lwlrap, _ = instance_based.lwlrap(targets, y)
-        summary['scalars'][f'lwlrap_{suffix}'] = lwlrap
-        label_wise(f'lwlrap_{suffix}', per_class_lwlrap)
+        scalars, buffers = summary['scalars'], summary['buffers']
+        scores = np.concatenate(buffers.pop(f'y_{suffix}'))
+        targets = np.concatenate(buffers.pop(f'targets_{suffix}'))
+        scalars[f'num_examples_{suffix}'] = len(scores)
+        cols, name_of = self._class_names()
+        if cols is not None:
+            scores, targets = scores[..., cols], targets[..., cols]
+        overall, per_class_lw, _ = instance_based.lwlrap(targets, scores)
+        rows = [
+            (f'macro_fscore_{suffix}', f'fscore_{suffix}', instance_based.get_best_fscore_thresholds(targets, scores)[1], None),
+            (f'macro_error_rate_{suffix}', f'error_rate_{suffix}', instance_based.get_best_er_thresholds(targets, scores)[1], None),
+            (f'lwlrap_{suffix}', f'lwlrap_{suffix}', per_class_lw, overall),
+        ]
         if (targets.sum(0) > 1).all():
-            ap = metrics.average_precision_score(targets, y, average=None)
-            summary['scalars'][f'map_{suffix}'] = np.mean(ap)
-            label_wise(f'ap_{suffix}', ap)
-            auc = metrics.roc_auc_score(targets, y, average=None)
-            summary['scalars'][f'mauc_{suffix}'] = np.mean(auc)
-            label_wise(f'auc_{suffix}', auc)
+            from sklearn import metrics
+            rows += [(f'map_{suffix}', f'ap_{suffix}', metrics.average_precision_score(targets, scores, average=None), None),
+                     (f'mauc_{suffix}', f'auc_{suffix}', metrics.roc_auc_score(targets, scores, average=None), None)]
+        for aggregate_key, labelwise_key, values, aggregate in rows:
+            scalars[aggregate_key] = np.mean(values) if aggregate is None else aggregate
+            if labelwise_key in self.labelwise_metrics:
+                scalars.update({f'z/{labelwise_key}/{name_of(j)}': v for j, v in enumerate(values)})
 
     # ---- helpers shared by both CRNNs
     def _seq(self, inputs, device):
         seq_host = np.array(inputs['seq_len'])
         seq_dev = seq_to_device(seq_host, device)
         return seq_host, seq_dev
+
+    def input_key(self, inputs):
+        return 'audio_data' if 'audio_data' in inputs else 'stft'
+
+    def features(self, inputs, x_in, seq_host, seq_dev):
+        """Normalised log-mel [B,1,F,T] of either input contract: the reference's ``'stft'`` [B,1,T,bins,2]
+        (pb_sed/models/weak_label/crnn.py:79-90) or the waveform ``'audio_data'`` [B,N] (fused STFT).  Segments cut out of
+        long clips (pb_sed_amd/utils/segment.py) carry ``'stft_pad_front'`` / ``'num_frames'``."""
+        from .. import engine
+        from ..modules import num_frames
+        fe = self.feature_extractor
+        if 'audio_data' in inputs or x_in.dim() == 2:
+            audio = x_in.reshape(x_in.shape[0], -1).to(torch.float32)
+            n_frames = int(inputs.get('num_frames', 0)) or num_frames(audio.shape[1])
+            return engine.features_from_audio(fe, audio, seq_dev, n_frames, seq_host,
+                                              pad_front=int(inputs.get('stft_pad_front', 320)))
+        return engine.features_from_stft(fe, x_in, seq_host, seq_dev)

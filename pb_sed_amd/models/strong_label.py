@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from .. import engine, ops
-from ..modules import SHALLOW, NormalizedLogMelExtractor, build_cnn, build_rnn, num_frames
+from ..modules import CNN, GRU, SHALLOW, NormalizedLogMelExtractor, build_cnn, build_rnn, num_frames
 from .base import SoundEventModel
 
 
@@ -77,15 +77,35 @@ class CRNN(SoundEventModel):
                         bidirectional=True)
         return cls(fe, cnn, rnn, tag_conditioning=tag_conditioning, **kw)
 
+    @classmethod
+    def finalize_dogmatic_config(cls, config):
+        """pb_sed/models/strong_label/crnn.py:155-198: sub-module factories, tag conditioning adds ``num_events``
+        constant input planes to the CNN and as many inputs to the GRU, which defaults to ONE bidirectional layer
+        (the experiment config asks for two; the caller's entry wins)."""
+        config['feature_extractor'] = {'factory': NormalizedLogMelExtractor}
+        config['cnn'] = {'factory': CNN}
+        config['rnn'] = {'factory': GRU}
+        fe, cnn, rnn = config['feature_extractor'], config['cnn'], config['rnn']
+        out_channels = rnn['output_net'].get('out_channels')
+        num_events = out_channels[-1] if out_channels else None
+        in_channels = 1 + fe['add_deltas'] + fe['add_delta_deltas'] + cnn['positional_encoding']
+        if config['tag_conditioning'] and num_events is not None:
+            cnn['conditional_dims'] = num_events
+            in_channels += num_events
+        cnn['cnn_2d']['in_channels'] = in_channels
+        cnn['input_height'] = fe['number_of_filters']
+        CNN.finalize_dogmatic_config(cnn)
+        width = cnn['cnn_1d'].get('out_channels')
+        rnn['rnn'].update({'num_layers': 1, 'bias': True, 'dropout': 0., 'bidirectional': True})
+        if width is not None:
+            rnn['rnn']['input_size'] = width[-1] + (num_events if config['tag_conditioning'] and num_events else 0)
+        GRU.finalize_dogmatic_config(rnn)                 # head width follows bidirectional=True
+
     def forward(self, inputs):
-        key = 'audio_data' if 'audio_data' in inputs else 'stft'
+        key = self.input_key(inputs)
         x_in = inputs.pop(key) if self.training else inputs[key]
         seq_host, seq_dev = self._seq(inputs, x_in.device)
-        if key == 'audio_data':
-            audio = x_in.reshape(x_in.shape[0], -1).to(torch.float32)
-            x = engine.features_from_audio(self.feature_extractor, audio, seq_dev, num_frames(audio.shape[1]), seq_host)
-        else:
-            x = engine.features_from_stft(self.feature_extractor, x_in, seq_host, seq_dev)
+        x = self.features(inputs, x_in, seq_host, seq_dev)
         targets = (inputs['weak_targets'], inputs['strong_targets']) if 'strong_targets' in inputs else None
         tag = inputs['tag_condition'].to(torch.float32) if self.tag_conditioning else None
         self._net_params = [p for p in self.parameters()]
@@ -101,20 +121,48 @@ class CRNN(SoundEventModel):
             self.add_metrics_to_summary(summary, 'strong')
         return super().modify_summary(summary)
 
-    def review(self, inputs, outputs):
+    def review(self, inputs, outputs, defer_summary=False):
+        """Loss + validation buffers (pb_sed/models/strong_label/crnn.py:95-138).  The host side of the summary
+        (strong-label rate, strongly labelled clips, segment-wise maxima of scores and targets over
+        ``eval_segment_length`` frames) is produced by one launch and fetched with ONE pinned device->host copy;
+        ``defer_summary``: Trainer.step waits for it only after backward + Adam are enqueued."""
         y, seq_len_y, x, _, targets = outputs
         assert targets is not None
         strong_targets = targets[1].to(torch.float32)
         assert strong_targets.shape == y.shape, (strong_targets.shape, y.shape)
         seq_dev = engine.seq_to_device(seq_len_y, y.device)
         loss = _LossFunction.apply(y, strong_targets, seq_dev)
-        mask = (strong_targets > .99) | (strong_targets < .01)
-        return dict(
-            loss=loss,
-            scalars=dict(seq_len=np.mean(inputs['seq_len']), strong_label_rate=mask.float().mean().item()),
-            images=dict(features=x[:3], strong_targets=strong_targets[:3]),
-            buffers=dict(),
-        )
+        b, k, t = y.shape
+        seg = int(self.eval_segment_length)
+        s = t // seg
+        with torch.no_grad():
+            packed_dev = torch.empty(2 * b * s * k + 2 * b * k, device=y.device, dtype=torch.float32)
+            ops.bicrnn_review_summary(y.detach(), strong_targets, seq_dev, seg, packed_dev)
+            host = torch.empty(packed_dev.shape, dtype=packed_dev.dtype, pin_memory=True)
+            host.copy_(packed_dev, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record()
+        review = dict(loss=loss, scalars=dict(seq_len=np.mean(inputs['seq_len'])),
+                      images=dict(features=x[:3], strong_targets=strong_targets[:3]), buffers={})
+        seq = np.minimum(np.asarray(seq_len_y), t)
+
+        def finalize():
+            copied.synchronize()
+            packed = host.numpy()
+            n = b * s * k
+            y_seg, t_seg = packed[:n].reshape(b, s, k), packed[n:2 * n].reshape(b, s, k)
+            mask_mean, mask_cnt = packed[2 * n:2 * n + b * k].reshape(b, k), packed[2 * n + b * k:]
+            labelled = np.flatnonzero((mask_mean > .999).all(-1))
+            review['scalars']['strong_label_rate'] = float(mask_cnt.sum()) / (b * k * t)
+            pick = lambda a: (np.concatenate([a[i, :seq[i] // seg] for i in labelled]) if len(labelled)
+                              else np.zeros((0, k), np.float32))
+            review['buffers'].update(y_strong=pick(y_seg), targets_strong=pick(t_seg))
+            return review
+
+        if defer_summary:
+            review['_finalize'] = finalize
+            return review
+        return finalize()
 
     def tagging(self, inputs):
         y, seq_len_y, *_ = self.forward(inputs)

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .. import engine, ops
-from ..modules import (SHALLOW, NormalizedLogMelExtractor, build_cnn, build_rnn, num_frames)
+from ..modules import (CNN, GRU, SHALLOW, NormalizedLogMelExtractor, build_cnn, build_rnn, num_frames)
 from .base import SoundEventModel
 
 
@@ -114,14 +114,26 @@ class CRNN(SoundEventModel):
         bwd = build_rnn(c, hidden_size, num_layers, num_events, hidden_size, reverse=True) if rnn_bwd else None
         return cls(fe, cnn, fwd, bwd, **kw)
 
-    # ------------------------------------------------------------------ forward / review
-    def _features(self, inputs, seq_host, seq_dev):
-        if 'audio_data' in inputs:
-            audio = inputs['audio_data']
-            audio = audio.reshape(audio.shape[0], -1).to(torch.float32)
-            return engine.features_from_audio(self.feature_extractor, audio, seq_dev, num_frames(audio.shape[1]), seq_host)
-        return engine.features_from_stft(self.feature_extractor, inputs['stft'], seq_host, seq_dev)
+    @classmethod
+    def finalize_dogmatic_config(cls, config):
+        """Completes a (partial) model config the way the reference does (pb_sed/models/weak_label/crnn.py:304-340):
+        default factories of the three sub-modules, CNN input channels / height from the feature extractor, GRU input
+        width from the 1-D stack, and ``rnn_bwd`` = a copy of ``rnn_fwd`` with ``reverse=True`` unless it is None."""
+        config['feature_extractor'] = {'factory': NormalizedLogMelExtractor}
+        config['cnn'] = {'factory': CNN}
+        config['rnn_fwd'] = {'factory': GRU}
+        config['rnn_bwd'] = {}
+        fe, cnn = config['feature_extractor'], config['cnn']
+        cnn['cnn_2d']['in_channels'] = 1 + fe['add_deltas'] + fe['add_delta_deltas'] + cnn['positional_encoding']
+        cnn['input_height'] = fe['number_of_filters']
+        CNN.finalize_dogmatic_config(cnn)                 # the 1-D stack's width depends on the height set just now
+        width = cnn['cnn_1d'].get('out_channels')
+        if width is not None:
+            config['rnn_fwd']['rnn']['input_size'] = width[-1]
+        if config.get('rnn_bwd') is not None:
+            config['rnn_bwd'].update(config['rnn_fwd'].to_dict(), reverse=True)
 
+    # ------------------------------------------------------------------ forward / review
     def _net(self, x, seq_host, seq_dev):
         self._net_params = [p for p in self.parameters()]
         engine.flatten_parameters(self)
@@ -132,10 +144,10 @@ class CRNN(SoundEventModel):
         return self.minimum_score + (1 - 2 * self.minimum_score) * torch.sigmoid(y)
 
     def forward(self, inputs):
-        key = 'audio_data' if 'audio_data' in inputs else 'stft'
+        key = self.input_key(inputs)
         x_in = inputs.pop(key) if self.training else inputs[key]
         seq_host, seq_dev = self._seq(inputs, x_in.device)
-        x = self._features({key: x_in}, seq_host, seq_dev)
+        x = self.features(inputs, x_in, seq_host, seq_dev)
         targets = self.read_targets(inputs) if 'weak_targets' in inputs else None
         h, y_fwd, *rest = self._net(x, seq_host, seq_dev)
         y_bwd = rest[0] if rest else None
@@ -216,45 +228,51 @@ class CRNN(SoundEventModel):
         return torch.minimum(y_fwd * m, y_bwd * m), seq_len_y
 
     def sound_event_detection(self, inputs, window_length, window_shift=1):
-        window_length = np.array(window_length, dtype=int)
-        key = 'audio_data' if 'audio_data' in inputs else 'stft'
+        """Windowed SED (pb_sed/models/weak_label/crnn.py:241-302): for every window position the clip-level tagging
+        score of the window (forward GRU's last + backward GRU's first output, halved).  ``window_length``: scalar, per
+        class [K] or per variant and class [n, K] / [n, 1]; result [B, (n,) K, T'] with T' = ceil(T / window_shift).
+
+        The CNN runs once on the whole clip; per distinct window length the windows of ALL positions and clips are
+        gathered by one index op into a [n_windows * B, C, length] batch of short sequences and scanned together; the
+        scores are then routed to the (variant, class) slots that asked for that length."""
+        lengths = np.array(window_length, dtype=int)
+        if lengths.ndim > 2:
+            raise ValueError('window_length.ndim must not be greater than 2.')
+        key = self.input_key(inputs)
         seq_host, seq_dev = self._seq(inputs, inputs[key].device)
-        x = self._features(inputs, seq_host, seq_dev)
+        x = self.features(inputs, inputs[key], seq_host, seq_dev)
         with torch.no_grad():
             h = self._net(x, seq_host, seq_dev)[0]
-        if window_length.ndim == 0:
-            return self._single_window_length_sed(h, seq_host, int(window_length), window_shift)
-        y = None
-        for win_len in np.unique(window_length.flatten()):
-            yi, seq_len_y = self._single_window_length_sed(h, seq_host, int(win_len), window_shift)
-            b, k, t = yi.shape
-            if window_length.ndim == 1:
-                assert window_length.shape[0] in [1, k], window_length.shape
-            elif window_length.ndim == 2:
-                assert window_length.shape[1] in [1, k], window_length.shape
-                window_length = np.broadcast_to(window_length, (window_length.shape[0], k))
-                yi = yi[:, None]
-            else:
-                raise ValueError('window_length.ndim must not be greater than 2.')
-            if y is None:
-                y = torch.zeros((b, *window_length.shape, t), device=yi.device)
-            y += (torch.from_numpy(window_length.copy()).to(yi.device) == win_len)[..., None] * yi
-        return y, seq_len_y
+        per_length = {int(n): self._window_scores(h, int(n), window_shift) for n in np.unique(lengths)}
+        seq_len_y = 1 + (np.asarray(seq_host) - 1) // window_shift
+        if lengths.ndim == 0:
+            return per_length[int(lengths)], seq_len_y
+        k = next(iter(per_length.values())).shape[1]
+        assert lengths.shape[-1] in (1, k), lengths.shape
+        slots = np.broadcast_to(lengths, lengths.shape[:-1] + (k,)) if lengths.ndim == 2 else lengths
+        out = None
+        for n, y in per_length.items():                       # y [B, K, T']
+            chosen = torch.from_numpy(np.ascontiguousarray(slots == n)).to(y.device)[..., None]     # [(n,) K or 1, 1]
+            part = chosen * (y[:, None] if lengths.ndim == 2 else y)
+            out = part if out is None else out + part
+        return out, seq_len_y
 
-    def _single_window_length_sed(self, h, seq_len, window_length, window_shift):
-        b, f, t = h.shape
-        if window_length > window_shift:
-            p = window_length - window_shift
-            h = torch.nn.functional.pad(h, (p // 2, p - p // 2))
-        h = torch.nn.functional.pad(h, (0, window_shift - 1))
-        wins = [h[..., i:i + window_length] for i in np.arange(0, t, window_shift)]
-        n = len(wins)
-        hw = torch.cat(wins, dim=0).contiguous()
+    def _window_scores(self, h, window_length, window_shift):
+        """[B, C, T] -> [B, K, ceil(T / shift)]: tagging score of the window that the reference's padding rule centres
+        on each shift position ('both' padding of length - shift, then shift - 1 at the end)."""
+        b, c, t = h.shape
+        lead = max(window_length - window_shift, 0) // 2
+        starts = torch.arange(0, t, window_shift, device=h.device)                      # window n covers [s - lead, +length)
+        idx = starts[:, None] - lead + torch.arange(window_length, device=h.device)[None]     # [n, length]
+        inside = (idx >= 0) & (idx < t)
+        hw = h[:, :, idx.clamp(0, t - 1)] * inside                                       # [B, C, n, length], zero padding
+        n = starts.numel()
+        hw = hw.permute(2, 0, 1, 3).reshape(n * b, c, window_length).contiguous()        # '(n b) c l'
         seq_host = np.full(n * b, window_length)
         seq_dev = torch.full((n * b,), window_length, dtype=torch.int32, device=h.device)
         with torch.no_grad():
             ys = _HeadsFunction.apply(self, hw, seq_host, seq_dev)
-        y = ys[0][..., -1].reshape(n, b, -1).permute(1, 2, 0)
+        y = ys[0][..., -1]
         if self.rnn_bwd is not None:
-            y = (y + ys[1][..., 0].reshape(n, b, -1).permute(1, 2, 0)) / 2
-        return y, 1 + (np.asarray(seq_len) - 1) // window_shift
+            y = (y + ys[1][..., 0]) / 2
+        return y.reshape(n, b, -1).permute(1, 2, 0)

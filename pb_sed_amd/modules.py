@@ -37,11 +37,58 @@ def num_frames(n_samples, shift=320, window_length=960):
     return max(int(math.ceil((n_samples + pad - window_length) / shift)) + 1, 1)
 
 
+class LogTruncatedNormal:
+    """paderbox.utils.random_utils.LogTruncatedNormal restated: exp(N(loc, scale) truncated to loc +- truncation)."""
+
+    def __init__(self, loc=0., scale=1., truncation=3., seed=None):
+        self.loc, self.scale, self.truncation = loc, scale, truncation
+        self._rng = np.random.RandomState(seed)
+
+    def __call__(self, shape=()):
+        from scipy.stats import truncnorm
+        a = self.truncation / self.scale
+        return np.exp(truncnorm(-a, a, loc=self.loc, scale=self.scale).rvs(shape, random_state=self._rng))
+
+
+class TruncatedExponential:
+    """paderbox.utils.random_utils.TruncatedExponential restated: Exp(scale) redrawn / clipped below ``truncation``."""
+
+    def __init__(self, loc=0., scale=1., truncation=3., seed=None):
+        self.loc, self.scale, self.truncation = loc, scale, truncation
+        self._rng = np.random.RandomState(seed)
+
+    def __call__(self, shape=()):
+        from scipy.stats import truncexpon
+        return truncexpon(self.truncation / self.scale, loc=self.loc, scale=self.scale).rvs(shape, random_state=self._rng)
+
+
+class MelWarping:
+    """paderbox.transform.module_fbank.MelWarping restated (vocal-tract-length style piecewise-linear warping of the mel
+    filters' centre frequencies, one draw per clip; reference config pb_sed/experiments/weak_label_crnn/training.py:195-208):
+    f -> alpha f below the boundary frequency b = ratio * f_max * min(alpha, 1) / alpha, and linearly on to f_max above it."""
+
+    def __init__(self, warp_factor_sampling_fn, boundary_frequency_ratio_sampling_fn, highest_frequency):
+        self.warp_factor_sampling_fn = warp_factor_sampling_fn
+        self.boundary_frequency_ratio_sampling_fn = boundary_frequency_ratio_sampling_fn
+        self.highest_frequency = highest_frequency
+
+    def __call__(self, f, n=1):
+        """f: [P] frequencies in Hz -> [n, P] warped frequencies."""
+        f = np.asarray(f, dtype=np.float64)[None]
+        alpha = np.asarray(self.warp_factor_sampling_fn((n,)), dtype=np.float64)[:, None]
+        ratio = np.minimum(np.asarray(self.boundary_frequency_ratio_sampling_fn((n,)), dtype=np.float64), 1.)[:, None]
+        hi = self.highest_frequency
+        b = ratio * hi * np.minimum(alpha, 1.) / alpha
+        upper = hi - (hi - alpha * b) / np.maximum(hi - b, 1e-9) * (hi - f)
+        return np.where(f <= b, alpha * f, upper)
+
+
 class NormalizedLogMelExtractor(nn.Module):
     """Front-end description (STFT 1024/960/320 Blackman -> mel -> log -> global norm -> clamp)."""
 
     def __init__(self, sample_rate=16000, stft_size=1024, number_of_filters=128, lowest_frequency=50.,
                  highest_frequency=None, eps=1e-18, clamp=6.0, shift=320, window_length=960,
+                 add_deltas=False, add_delta_deltas=False,
                  n_time_masks=0, max_masked_time_steps=70, max_masked_time_rate=.2,
                  n_frequency_masks=0, max_masked_frequency_bands=20, max_masked_frequency_rate=.2,
                  max_noise_scale=0., frequency_warping_fn=None, augmentation_seed=0, norm_eps=1e-5):
@@ -49,8 +96,12 @@ class NormalizedLogMelExtractor(nn.Module):
         (pb_sed/experiments/weak_label_crnn/training.py:194-216); all default to off (as in the reference's class
         defaults), training scripts switch them on.  They act in training mode only."""
         super().__init__()
-        if frequency_warping_fn is not None:
-            raise NotImplementedError('mel warping (MelWarping, training.py:194-208) is not built: SURVEY.md 8(f) f2')
+        if add_deltas or add_delta_deltas:
+            raise NotImplementedError('delta features are not used by the reference configurations')
+        self.add_deltas, self.add_delta_deltas = False, False
+        self.frequency_warping_fn = frequency_warping_fn
+        self.lowest_frequency = lowest_frequency
+        self.highest_frequency = sample_rate / 2 if highest_frequency is None else highest_frequency
         if n_time_masks > 1 or n_frequency_masks > 1:
             raise NotImplementedError('one time mask and one frequency mask per clip (the reference configuration)')
         self.n_time_masks, self.max_masked_time_steps, self.max_masked_time_rate = n_time_masks, max_masked_time_steps, max_masked_time_rate
@@ -155,13 +206,30 @@ class ConvLayer(nn.Module):
 class _CNN(nn.Module):
     ndim = None
 
-    def __init__(self, in_channels, out_channels, kernel_size, pool_size=1, norm='batch', eps=1e-3,
-                 pre_activation=False, output_layer=True, input_layer=True):
+    def __init__(self, in_channels, out_channels, kernel_size, pool_size=1, norm='batch', eps=None,
+                 pre_activation=False, output_layer=True, input_layer=True, norm_kwargs=None, activation_fn='relu',
+                 dropout=0., residual_connections=None, dense_connections=False, pad_type='both', dilation=1, stride=1,
+                 gated=False, pool_type='max', pool_stride=None):
+        """Constructor fields of padertorch's CNN2d / CNN1d as the reference configs give them
+        (pb_sed/experiments/weak_label_crnn/training.py:218-242); what the HIP kernels do not implement is refused."""
         super().__init__()
+        if eps is None:
+            eps = (norm_kwargs or {}).get('eps', 1e-3)
+        unsupported = dict(activation_fn=(activation_fn, 'relu'), dropout=(dropout, 0.), dense_connections=(dense_connections, False),
+                           pad_type=(pad_type, 'both'), dilation=(dilation, 1), stride=(stride, 1), gated=(gated, False),
+                           pool_type=(pool_type, 'max'), pool_stride=(pool_stride, None), norm=(norm, 'batch'))
+        for name, (got, want) in unsupported.items():
+            if got != want and not (name == 'norm' and got is None):
+                raise NotImplementedError(f'{type(self).__name__}({name}={got!r}): the MI355X kernels implement {name}={want!r}')
+        if residual_connections is not None and any(r is not None for r in residual_connections):
+            raise NotImplementedError('residual connections (the reference\'s "deep" net_config) are not built: SURVEY.md 8(f) f4')
+        self.norm_kind, self.eps, self.pre_activation = norm, eps, pre_activation
+        self.output_layer, self.input_layer = output_layer, input_layer
         n = len(out_channels)
         ks = kernel_size if isinstance(kernel_size, (list, tuple)) else n * [kernel_size]
         ps = pool_size if isinstance(pool_size, list) and len(pool_size) == n else n * [pool_size]
         self.in_channels, self.out_channels = in_channels, list(out_channels)
+        self.kernel_sizes, self.pool_sizes = list(ks), list(ps)
         convs, cin = [], in_channels
         for i, cout in enumerate(out_channels):
             if pre_activation:
@@ -189,29 +257,66 @@ class CNN1d(_CNN):
     ndim = 1
 
 
+def _pooled_height(height, pool_sizes):
+    for p in pool_sizes:
+        height //= (p[0] if isinstance(p, (tuple, list)) else p)
+    return height
+
+
 class CNN(nn.Module):
-    def __init__(self, cnn_2d, cnn_1d, input_height=128, conditional_dims=0):
+    """padertorch's hybrid CNN (CNN2d -> 'b c f t -> b (c f) t' -> CNN1d) as a parameter container."""
+
+    def __init__(self, cnn_2d, cnn_1d, input_height=128, positional_encoding=False, conditional_dims=0):
         super().__init__()
+        if positional_encoding:
+            raise NotImplementedError('positional_encoding is not used by the reference configurations')
         self.cnn_2d, self.cnn_1d = cnn_2d, cnn_1d
-        self.input_height, self.conditional_dims = input_height, conditional_dims
+        self.input_height, self.conditional_dims, self.positional_encoding = input_height, conditional_dims, False
+
+    @classmethod
+    def finalize_dogmatic_config(cls, config):
+        """hybrid CNN rule: the 1-D stack's input width is the 2-D stack's last channel count times the frequency
+        axis left after the (f, 1) pools (pb_sed/models/weak_label/crnn.py:326-330 sets in_channels / input_height)."""
+        config['cnn_2d'] = {'factory': CNN2d}
+        config['cnn_1d'] = {'factory': CNN1d, 'input_layer': False}     # SURVEY.md A.4 choice (ii): the 1-D stack's first conv has a pre-norm
+        c2 = config['cnn_2d']
+        if c2.get('out_channels') is not None and config.get('input_height') is not None:
+            n = len(c2['out_channels'])
+            ps = c2.get('pool_size', 1)
+            ps = ps if isinstance(ps, list) and len(ps) == n else n * [ps]
+            config['cnn_1d']['in_channels'] = c2['out_channels'][-1] * _pooled_height(config['input_height'], ps)
 
 
 class GRU(nn.Module):
-    """padertorch GRU wrapper mirror: ``rnn`` (torch.nn.GRU parameter names) + ``output_net``."""
+    """padertorch GRU wrapper mirror: ``rnn`` (a torch.nn.GRU used purely as the parameter container: names, shapes,
+    U(+-1/sqrt(H)) init - its forward is never called, the scans run in csrc/gru_stack.hip) + ``output_net`` (CNN1d) +
+    the ``reverse`` flag (pb_sed/models/weak_label/crnn.py:338-340)."""
 
-    def __init__(self, input_size, hidden_size, num_layers=1, bidirectional=False, reverse=False,
-                 output_net=None):
+    def __init__(self, rnn, output_net=None, reverse=False):
         super().__init__()
-        # torch.nn.GRU is used as the parameter container (names, shapes, U(+-1/sqrt(H)) init);
-        # its forward is never called - the scan runs in pb_sed_amd/csrc/gru.hip.
-        self.rnn = nn.GRU(input_size, hidden_size, num_layers, bias=True, batch_first=True, dropout=0.,
-                          bidirectional=bidirectional)
-        self.output_net = output_net
-        self.reverse = reverse
-        self.input_size, self.hidden_size = input_size, hidden_size
-        self.num_layers, self.bidirectional = num_layers, bidirectional
-        if hidden_size % 64:
+        if not isinstance(rnn, nn.GRU):
+            raise NotImplementedError(f'recurrent part must be a torch.nn.GRU, got {type(rnn).__name__}')
+        if not rnn.bias or not rnn.batch_first or rnn.dropout:
+            raise NotImplementedError('torch.nn.GRU(bias=True, batch_first=True, dropout=0) is what the kernels implement')
+        self.rnn, self.output_net, self.reverse = rnn, output_net, reverse
+        if rnn.hidden_size % 64:
             raise NotImplementedError('GRU hidden size must be a multiple of 64')
+
+    input_size = property(lambda self: self.rnn.input_size)
+    hidden_size = property(lambda self: self.rnn.hidden_size)
+    num_layers = property(lambda self: self.rnn.num_layers)
+    bidirectional = property(lambda self: self.rnn.bidirectional)
+
+    @classmethod
+    def finalize_dogmatic_config(cls, config):
+        config['rnn'] = {'factory': nn.GRU}
+        config['output_net'] = {'factory': CNN1d}
+        rnn = config['rnn']
+        for k, v in dict(bias=True, batch_first=True, dropout=0., bidirectional=False, num_layers=1).items():
+            if rnn.get(k) is None:
+                rnn[k] = v
+        if rnn.get('hidden_size') is not None:
+            config['output_net']['in_channels'] = rnn['hidden_size'] * (2 if rnn.get('bidirectional') else 1)
 
 
 SHALLOW = dict(
@@ -233,7 +338,7 @@ def build_cnn(in_channels, out_channels_2d, pool_sizes_2d, kernel_size_2d, out_c
         f //= (p[0] if isinstance(p, (tuple, list)) else p)
     cnn_1d = CNN1d(out_channels_2d[-1] * f, out_channels_1d, kernel_size_1d, 1, eps=eps,
                    pre_activation=True, output_layer=False, input_layer=False)
-    return CNN(cnn_2d, cnn_1d, input_height, conditional_dims)
+    return CNN(cnn_2d, cnn_1d, input_height, conditional_dims=conditional_dims)
 
 
 def build_rnn(input_size, hidden_size, num_layers, num_events, head_hidden, bidirectional=False,
@@ -241,4 +346,5 @@ def build_rnn(input_size, hidden_size, num_layers, num_events, head_hidden, bidi
     dirs = 2 if bidirectional else 1
     output_net = CNN1d(hidden_size * dirs, [head_hidden, num_events], 1, 1, eps=eps, pre_activation=False,
                        output_layer=True)
-    return GRU(input_size, hidden_size, num_layers, bidirectional, reverse, output_net)
+    rnn = nn.GRU(input_size, hidden_size, num_layers, bias=True, batch_first=True, dropout=0., bidirectional=bidirectional)
+    return GRU(rnn, output_net, reverse)

@@ -544,6 +544,16 @@ def bicrnn_loss(logit, strong_targets, seq_len, want_grad=True, inputs_are_score
     return loss, y, d
 
 
+def bicrnn_review_summary(y, strong_targets, seq_len, segment_length, packed):
+    """Fills ``packed`` (float32 [2*B*S*K + 2*B*K], S = T // segment_length) with y_seg | t_seg | mask_mean | mask_cnt."""
+    b, k, t = y.shape
+    s = t // segment_length
+    n = b * s * k
+    assert packed.numel() == 2 * n + 2 * b * k
+    call('pbsed_bicrnn_review_summary', ptr(y.contiguous()), ptr(strong_targets.contiguous()), ptr(seq_len), ptr(packed[:n]),
+         ptr(packed[n:2 * n]), ptr(packed[2 * n:2 * n + b * k]), ptr(packed[2 * n + b * k:]), b, k, t, int(segment_length), stream())
+
+
 class LogMelTables:
     """Device tables for the fused front-end (window, twiddles, sparse mel filters)."""
 
@@ -569,7 +579,7 @@ class LogMelTables:
         self.one = torch.ones(self.n_filters, device=device)
 
 
-def logmel_fwd(wav, tables, mean, inv_std, n_frames, seq_len=None, eps=1e-18, clamp=6.0, stats=None):
+def logmel_fwd(wav, tables, mean, inv_std, n_frames, seq_len=None, eps=1e-18, clamp=6.0, stats=None, pad_front=320):
     """wav [B, N] f32 (device) -> normalised, clamped, masked log-mel [B, 1, F, T].  ``stats``: see
     feature_norm_stats (then pass mean = inv_std = None, clamp = None to get the raw log-mel)."""
     _lib.require_gpu(wav)
@@ -578,7 +588,7 @@ def logmel_fwd(wav, tables, mean, inv_std, n_frames, seq_len=None, eps=1e-18, cl
     call('pbsed_logmel_fwd', ptr(wav.contiguous()), b, n, n_frames, ptr(seq_len), ptr(tables.window),
          ptr(tables.twiddle), ptr(tables.start), ptr(tables.len), ptr(tables.off), ptr(tables.w),
          tables.n_filters, ptr(tables.zero if mean is None else mean), ptr(tables.one if inv_std is None else inv_std),
-         float(eps), float(clamp if clamp is not None else 3e38), ptr(out), ptr(stats), stream(),
+         float(eps), float(clamp if clamp is not None else 3e38), ptr(out), ptr(stats), int(pad_front), stream(),
          nbytes=b * (n * 4 + tables.n_filters * n_frames * 4))
     return out
 

@@ -52,11 +52,12 @@ class GradSync:
 
 
 def shard_batch(batch, rank, world):
-    """Rank r takes clips [r*B/world, (r+1)*B/world) of a global batch."""
+    """Rank r takes a contiguous run of clips of a global batch: B/world each; a remainder (a ragged last
+    inference batch) goes one clip each to the first B % world ranks, so a rank's share may be empty."""
     n = len(batch['seq_len'])
-    assert n % world == 0, (n, world)
-    per = n // world
-    sl = slice(rank * per, (rank + 1) * per)
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    sl = slice(start, start + base + (1 if rank < rem else 0))
     out = {}
     for k, v in batch.items():
         if isinstance(v, (torch.Tensor, np.ndarray)) and len(v) == n:

@@ -92,6 +92,39 @@ def _segment_axis(x, length, shift, axis=-1, end='cut', pad_mode=None):
     return np.moveaxis(out, (0, 1), (axis, axis + 1))
 
 
+class _Segmenter:
+    """padertorch.data.segment.Segmenter restated for the one way the reference uses it (utils/segment.py:26-31:
+    fixed length / shift along one axis, zero padding so that the tail is covered, 'example_id' copied): a list of
+    dicts with the segmented arrays + 'segment_start' / 'segment_stop'."""
+
+    def __init__(self, length, shift, include_keys, copy_keys=(), axis=-1, mode='constant', padding=True):
+        self.length, self.shift, self.include_keys, self.copy_keys, self.axis = length, shift, include_keys, copy_keys, axis
+
+    def __call__(self, example):
+        t = np.asarray(example[self.include_keys[0]]).shape[self.axis]
+        n = max(-(-(t - self.length) // self.shift), 0) + 1
+        out = []
+        for i in range(n):
+            a, b = i * self.shift, i * self.shift + self.length
+            seg = {'segment_start': a, 'segment_stop': b}
+            for k in self.include_keys:
+                x = example[k]
+                is_t = isinstance(x, torch.Tensor)
+                x = np.asarray(x)
+                piece = np.take(x, np.arange(a, min(b, t)), axis=self.axis)
+                if b > t:
+                    pad = [(0, 0)] * x.ndim
+                    pad[self.axis] = (0, b - t)
+                    piece = np.pad(piece, pad)
+                seg[k] = torch.from_numpy(piece) if is_t else piece
+            for k in self.copy_keys:
+                seg[k] = example[k]
+            out.append(seg)
+        return out
+
+
+import padertorch.data.segment as pt_segment                   # noqa: E402
+pt_segment.Segmenter = _Segmenter
 padertorch.Model = _Model
 pt_mask.compute_mask = compute_mask
 for _n in ('TakeLast', 'Mean', 'Sum', 'Max'):
@@ -186,12 +219,12 @@ def gen_fbcrnn_loss():
 def gen_bicrnn_loss():
     rng = np.random.default_rng(12)
     cases = {}
-    for n, (b, k, t) in {'a': (4, 10, 50), 'b': (3, 5, 21)}.items():
+    for n, (b, k, t, seg) in {'a': (4, 10, 50, 1), 'b': (3, 5, 21, 1), 'c': (5, 10, 50, 3), 'd': (4, 6, 37, 4)}.items():
         seq_len = np.sort(rng.integers(t // 2, t + 1, b))[::-1].copy()
         seq_len[0] = t
         weak, st = make_targets(rng, b, k, t, seq_len, unlabeled_rows=(b - 1,))
         y = torch.tensor(rng.uniform(.001, .999, (b, k, t)).astype(np.float32), requires_grad=True)
-        m = RefBiCRNN(None, None, None, tag_conditioning=True)
+        m = RefBiCRNN(None, None, None, tag_conditioning=True, eval_segment_length=seg)
         review = m.review({'seq_len': seq_len.tolist()},
                           (y, seq_len, torch.zeros(b, 1, 4, t), seq_len,
                            (torch.tensor(weak), torch.tensor(st))))
@@ -200,7 +233,9 @@ def gen_bicrnn_loss():
                       f'{n}/strong_targets': st, f'{n}/loss': review['loss'].detach().numpy(),
                       f'{n}/grad_y': y.grad.numpy(),
                       f'{n}/y_strong': review['buffers']['y_strong'],
-                      f'{n}/targets_strong': review['buffers']['targets_strong']})
+                      f'{n}/targets_strong': review['buffers']['targets_strong'],
+                      f'{n}/eval_segment_length': np.int64(seg),
+                      f'{n}/strong_label_rate': np.float64(review['scalars']['strong_label_rate'])})
     np.savez_compressed(os.path.join(OUT, 'ref_bicrnn_loss.npz'), **cases)
     print('ref_bicrnn_loss', {k: float(v) for k, v in cases.items() if k.endswith('/loss')})
 
@@ -262,6 +297,15 @@ def gen_filters():
     s1 = np.array([0, 2, 4, 10, 6])
     cases['steplen_1d'] = s1
     cases['filtering_bnd_1d'] = ref_inf.filtering(x.copy(), ref_inf.boundariesfilt, s1)
+    # long rows / long filters: the reference tunes median filters up to 301 frames on 10 s clips
+    # (pb_sed/experiments/strong_label_crnn/tuning.py:64)
+    rng2 = np.random.default_rng(141)
+    xl = rng2.random((2, 3, 500)).astype(np.float32)
+    xl[0, 0, 100:300] = np.round(xl[0, 0, 100:300] * 4) / 4            # many ties
+    xl[1, 2, :40] = 0.
+    cases['x_long'] = xl
+    for n in (5, 151, 301):
+        cases[f'medfilt_long_{n}'] = ref_filters.medfilt(xl.copy(), n, axis=-1)
     np.savez_compressed(os.path.join(OUT, 'ref_filters.npz'), **cases)
     print('ref_filters', {k: (v.dtype.name, v.shape) for k, v in cases.items()})
 
@@ -320,6 +364,58 @@ def gen_inference():
     dump('tagging', ref_inf.tagging(models, dataset(), None))
     np.savez_compressed(os.path.join(OUT, 'ref_inference.npz'), **cases)
     print('ref_inference', {k: v.shape for k, v in cases.items()})
+
+
+class _FakeSegModel(_FakeModel):
+    """Scores are a fixed function of the (segment of the) input itself, so segmenting the input segments the scores."""
+
+    def __init__(self, gain):
+        self.gain = gain
+
+    def sound_event_detection(self, batch):
+        x = torch.as_tensor(batch['stft'])                     # [B, 1, T, K, 2]
+        return (x[:, 0, :, :, 0] * self.gain + x[:, 0, :, :, 1]).transpose(1, 2), np.array(batch['seq_len'])
+
+
+def gen_segments():
+    """pb_sed/utils/segment.py (segment_batch, merge_segments) and the segmenting branch of
+    pb_sed/models/base/inference.py:121-128,185-197."""
+    import pb_sed.utils.segment as ref_seg
+    rng = np.random.default_rng(18)
+    b, k, t = 3, 4, 50
+    seq_len = [50, 47, 41]
+    stft = rng.random((b, 1, t, k, 2)).astype(np.float32)
+    ids = ['a', 'b', 'c']
+    cases = dict(stft=stft, seq_len=np.array(seq_len), ids=np.array(ids))
+    for max_len, overlap in ((12, 2), (20, 5), (16, 0), (64, 4)):
+        segs = ref_seg.segment_batch({'example_id': list(ids), 'stft': stft.copy(), 'seq_len': list(seq_len)}, max_len, overlap)
+        tag = f'seg_{max_len}_{overlap}'
+        cases[f'{tag}/n'] = np.int64(len(segs))
+        for i, sgm in enumerate(segs):
+            cases[f'{tag}/{i}/stft'] = np.asarray(sgm['stft'])
+            cases[f'{tag}/{i}/seq_len'] = np.array(sgm['seq_len'])
+            cases[f'{tag}/{i}/ids'] = np.array(sgm['example_id'])
+        # merge of per-segment score arrays [T_seg, K] (and a 3-d variant [n, T_seg, K])
+        if len(segs) > 1:
+            out2 = {aid: np.asarray(sgm['stft'])[j, 0, :sl, :, 0] for sgm in segs
+                    for j, (aid, sl) in enumerate(zip(sgm['example_id'], sgm['seq_len']))}
+            merged = ref_seg.merge_segments(out2, overlap)
+            for a in ids:
+                cases[f'{tag}/merged/{a}'] = merged[a]
+            out3 = {aid: np.stack([v, 2 * v]) for aid, v in out2.items()}
+            merged3 = ref_seg.merge_segments(out3, overlap)
+            for a in ids:
+                cases[f'{tag}/merged3/{a}'] = merged3[a]
+    # the driver with segmenting + merging (and a median filter applied per segment, as the reference does)
+    models = [_FakeSegModel(1.), _FakeSegModel(.5)]
+    for max_len, overlap, med in ((12, 2, 1), (20, 6, 3)):
+        ds = [{'example_id': list(ids), 'stft': torch.tensor(stft), 'seq_len': list(seq_len), 'weak_targets': 0}]
+        out = ref_inf.sound_event_detection(models, ds, None, medfilt_length=med, max_segment_length=max_len,
+                                            segment_overlap=overlap, merge_score_segments=True)
+        for a in ids:
+            cases[f'driver_{max_len}_{overlap}_{med}/{a}'] = out[a]
+    np.savez_compressed(os.path.join(OUT, 'ref_segments.npz'), **cases)
+    print('ref_segments', len(cases), 'arrays')
 
 
 def gen_instance_based():
@@ -407,6 +503,7 @@ if __name__ == '__main__':
     gen_fbcrnn_heads()
     gen_filters()
     gen_inference()
+    gen_segments()
     gen_instance_based()
     gen_summary_metrics()
     assert not os.path.exists('/root/reference/pb_sed/__pycache__'), 'bytecode written to reference'

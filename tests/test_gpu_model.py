@@ -233,7 +233,9 @@ def test_fbcrnn_conv_precision_modes(precision, tol):
     assert (out[0].cpu() - out_ref[0]).abs().max() < tol
     assert (out[1].cpu() - out_ref[1]).abs().max() < tol
     refp = dict(ref.named_parameters())
-    gtol = 2e-3 if precision == 'bf16x3' else 4e-1      # plain bf16 gradients: sanity bound only
+    # bf16x3: the fp32 class (both sides are fp32 implementations of a graph with ReLU / argmax switches, see
+    # test_gpu_configs._rounding_sensitivity); plain bf16 gradients: sanity bound only
+    gtol = 5e-3 if precision == 'bf16x3' else 4e-1
     for name, p in model.named_parameters():
         g = refp[name].grad
         if g.norm() < 1e-6:
@@ -327,6 +329,7 @@ def test_fbcrnn_full_size_properties():
     from pb_sed_amd.models import weak_label
     torch.manual_seed(0)
     model = weak_label.CRNN.build(num_events=10).to(DEV).train()
+    model.feature_extractor.freeze_stats = True                   # same normalisation in every run below
     b = 32
     wav, seq, weak, bnd, t = synth_batch(b, 160000, 10, ragged=True)
     seq[:4] = t                                                   # several full-length clips to permute among
@@ -339,7 +342,7 @@ def test_fbcrnn_full_size_properties():
         _, flat_grad = model.flat_parameters()
         flat_grad.zero_()
         for m_ in model.modules():                                # same running statistics before every run
-            if hasattr(m_, 'running_mean'):
+            if hasattr(m_, 'running_mean') and m_ is not model.feature_extractor:
                 m_.running_mean.zero_(), m_.running_power.fill_(1.)
         out = model(dict(inputs))
         rev = model.review(inputs, out)
@@ -403,6 +406,7 @@ def test_fbcrnn_forward_is_reproducible():
     from pb_sed_amd.models import weak_label
     torch.manual_seed(0)
     model = weak_label.CRNN.build(num_events=10).to(DEV).train()
+    model.feature_extractor.freeze_stats = True                   # cumulative feature statistics would differ run to run
     wav, seq, weak, bnd, t = synth_batch(16, 160000, 10, ragged=True)
     order = np.argsort(-seq, kind='stable')
     wav, seq, weak, bnd = wav[order], seq[order], weak[order], bnd[order]
@@ -413,7 +417,7 @@ def test_fbcrnn_forward_is_reproducible():
         _, flat_grad = model.flat_parameters()
         flat_grad.zero_()
         for m_ in model.modules():
-            if hasattr(m_, 'running_mean'):
+            if hasattr(m_, 'running_mean') and m_ is not model.feature_extractor:
                 m_.running_mean.zero_(), m_.running_power.fill_(1.)
         out = model(dict(inputs))
         rev = model.review(inputs, out)

@@ -506,3 +506,30 @@ def test_logmel_augmentation_vs_oracle():
     out2 = ops.augment_logmel(y.to(DEV).contiguous(), torch.from_numpy(masks).to(DEV),
                               torch.as_tensor(seq, dtype=torch.int32).to(DEV))
     close(out2, ofe.augment(y, seq, masks), atol=0, rtol=0, name='augment_logmel masks only')
+
+
+@pytest.mark.parametrize('name', ['a', 'b', 'c', 'd'])
+def test_bicrnn_review_buffers_vs_reference_golden(golden, name):
+    """strong_label.CRNN.review (pb_sed/models/strong_label/crnn.py:95-138) executed by the reference on seeded inputs:
+    loss, strong_label_rate and the y_strong / targets_strong validation buffers (segment-wise maxima over
+    eval_segment_length = 1, 3, 4 frames of the strongly labelled clips)."""
+    from pb_sed_amd.models import strong_label
+    g = golden('ref_bicrnn_loss.npz')
+    seg = int(g[f'{name}/eval_segment_length'])
+    model = strong_label.CRNN(None, None, None, tag_conditioning=True, eval_segment_length=seg)
+    y = torch.as_tensor(g[f'{name}/y']).to(DEV).requires_grad_(True)
+    st = torch.as_tensor(g[f'{name}/strong_targets']).to(DEV)
+    seq = g[f'{name}/seq_len']
+    b, k, t = y.shape
+    review = model.review({'seq_len': seq.tolist()}, (y, seq, torch.zeros(b, 1, 4, t, device=DEV), seq, (None, st)))
+    assert review['loss'].item() == pytest.approx(float(g[f'{name}/loss']), rel=2e-5)
+    assert review['scalars']['strong_label_rate'] == pytest.approx(float(g[f'{name}/strong_label_rate']), abs=1e-7)
+    np.testing.assert_array_equal(review['buffers']['y_strong'], g[f'{name}/y_strong'])
+    np.testing.assert_array_equal(review['buffers']['targets_strong'], g[f'{name}/targets_strong'])
+    review['loss'].backward()
+    close(y.grad, g[f'{name}/grad_y'], atol=1e-7, rtol=2e-4, name='dL/dy')
+    # summary path: modify_summary turns the buffers into *_strong metrics (needs >= 1 strongly labelled clip)
+    summary = dict(scalars={k_: [v] for k_, v in review['scalars'].items()}, images={},
+                   buffers={k_: [v] for k_, v in review['buffers'].items()})
+    model.modify_summary(summary)
+    assert 'macro_fscore_strong' in summary['scalars'] and summary['scalars']['num_examples_strong'] == len(g[f'{name}/y_strong'])

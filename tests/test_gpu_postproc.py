@@ -125,3 +125,83 @@ def test_inference_driver_end_to_end_vs_oracle():
     for a in ids:
         assert sed[a].shape == ref[a].shape
         np.testing.assert_allclose(sed[a], ref[a], atol=1e-4)
+
+
+def test_medfilt_long_filters_bit_exact(golden):
+    """Median filters up to 301 frames on 500-frame rows (the reference's tuning range,
+    pb_sed/experiments/strong_label_crnn/tuning.py:64) incl. rows with ties and zero runs: the bisection-select kernel
+    (O(32 n) per output) against the reference's scipy medfilt, bit for bit."""
+    from pb_sed_amd import ops
+    g = golden('ref_filters.npz')
+    x = dev(g['x_long'])
+    for n in (5, 151, 301):
+        np.testing.assert_array_equal(ops.medfilt(x, n).cpu().numpy(), g[f'medfilt_long_{n}'])
+    neg = dev(-g['x_long'] + .25)                       # negative values and sign changes: compare with scipy directly
+    from scipy import signal
+    want = np.stack([signal.medfilt(r, 31) for r in neg.cpu().numpy().reshape(-1, 500)]).reshape(neg.shape)
+    np.testing.assert_array_equal(ops.medfilt(neg, 31).cpu().numpy(), want)
+
+
+class _StftScoreModel:
+    """Fake model of tests/golden/gen_golden.py::_FakeSegModel: scores are a fixed function of the input segment."""
+
+    def __init__(self, gain):
+        self.gain = gain
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def example_to_device(self, ex, device=None):
+        return {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in ex.items()}
+
+    def sound_event_detection(self, batch):
+        x = batch['stft']
+        return (x[:, 0, :, :, 0] * self.gain + x[:, 0, :, :, 1]).transpose(1, 2), np.array(batch['seq_len'])
+
+
+def test_inference_driver_segments_and_merges_like_the_reference(golden):
+    """pb_sed/models/base/inference.py:121-128,185-197 + pb_sed/utils/segment.py: the reference's own driver was run with
+    max_segment_length / segment_overlap / merge_score_segments on a fake model; same inputs through the build's driver."""
+    from pb_sed_amd import inference as inf
+    g = golden('ref_segments.npz')
+    ids, seq = g['ids'].tolist(), g['seq_len'].tolist()
+    models = [_StftScoreModel(1.), _StftScoreModel(.5)]
+    for max_len, overlap, med in ((12, 2, 1), (20, 6, 3)):
+        ds = [{'example_id': list(ids), 'stft': torch.tensor(g['stft']), 'seq_len': list(seq), 'weak_targets': 0}]
+        out = inf.sound_event_detection(models, ds, DEV, medfilt_length=med, max_segment_length=max_len,
+                                        segment_overlap=overlap, merge_score_segments=True)
+        assert sorted(out) == sorted(ids)
+        for a in ids:
+            np.testing.assert_array_equal(out[a], g[f'driver_{max_len}_{overlap}_{med}/{a}'])
+    # without merging the per-segment entries are returned under the reference's segment ids
+    ds = [{'example_id': list(ids), 'stft': torch.tensor(g['stft']), 'seq_len': list(seq)}]
+    out = inf.sound_event_detection(models, ds, DEV, max_segment_length=12, segment_overlap=2)
+    assert 'a_!segment!_0_5' in out and len(out) == 15
+
+
+def test_audio_segments_give_the_features_of_the_whole_clip():
+    """Segmenting the waveform (fused front-end input) must be indistinguishable from segmenting the reference's STFT:
+    features of every audio segment == the matching frame range of the whole clip's features, bit for bit."""
+    from pb_sed_amd.models import weak_label
+    from pb_sed_amd.utils.segment import segment_batch
+    from tests.test_gpu_model import TINY
+    torch.manual_seed(0)
+    model = weak_label.CRNN.build(num_events=10, hidden_size=64, net=TINY).to(DEV).eval()
+    n = 16000 * 5 + 321
+    wav = torch.randn(3, n, device=DEV)
+    with torch.no_grad():
+        from pb_sed_amd.modules import num_frames
+        t = num_frames(n)
+        seq = [t, t - 11, t - 51]
+        full = model({'audio_data': wav, 'seq_len': seq})[3]
+        segs = segment_batch({'audio_data': wav, 'seq_len': seq, 'example_id': ['a', 'b', 'c']}, 64, 6)
+        assert len(segs) >= 4
+        for s in segs:
+            x = model(dict(s))[3]
+            a = s['segment_start']
+            for j, sl in enumerate(s['seq_len']):
+                sl = max(sl, 0)
+                assert torch.equal(x[j, :, :, :sl], full[j, :, :, a:a + sl]), (a, j)

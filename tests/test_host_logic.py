@@ -1,0 +1,201 @@
+"""CPU-side checks of the host logic around the kernels: config plumbing of the model API, long-clip segmenting against
+vectors produced by the reference's own code, event boundary correction, batch sharding."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _reference_style_updates(num_events=10, width=1):
+    """The model part of the reference's experiment config (pb_sed/experiments/weak_label_crnn/training.py:186-262)."""
+    return {
+        'feature_extractor': {'sample_rate': 16000, 'stft_size': 1024, 'number_of_filters': 128,
+                              'n_time_masks': 1, 'max_masked_time_steps': 70, 'max_masked_time_rate': .2,
+                              'n_frequency_masks': 1, 'max_masked_frequency_bands': 20, 'max_masked_frequency_rate': .2,
+                              'max_noise_scale': .2},
+        'cnn': {
+            'cnn_2d': {'out_channels': [16 * width, 16 * width, 32 * width, 32 * width, 64 * width, 64 * width, 128 * width,
+                                        128 * width, min(256 * width, 512)],
+                       'pool_size': 4 * [1, (2, 1)] + [1], 'kernel_size': 3, 'residual_connections': None, 'norm': 'batch',
+                       'norm_kwargs': {'eps': 1e-3}, 'activation_fn': 'relu', 'pre_activation': True, 'dropout': .0,
+                       'output_layer': False},
+            'cnn_1d': {'out_channels': 5 * [256 * width], 'kernel_size': [1, 3, 3, 3, 1], 'residual_connections': None,
+                       'norm': 'batch', 'norm_kwargs': {'eps': 1e-3}, 'activation_fn': 'relu', 'pre_activation': True,
+                       'dropout': .0, 'output_layer': False},
+        },
+        'rnn_fwd': {'rnn': {'hidden_size': 256 * width, 'num_layers': 2, 'dropout': .0},
+                    'output_net': {'out_channels': [256 * width, num_events], 'kernel_size': 1, 'norm': 'batch',
+                                   'norm_kwargs': {'eps': 1e-3}, 'activation_fn': 'relu', 'dropout': .0}},
+        'labelwise_metrics': ('fscore_weak',), 'strong_fwd_bwd_loss_weight': 1.,
+    }
+
+
+def test_fbcrnn_config_is_completed_like_the_reference_does():
+    """weak_label/crnn.py:304-340: in_channels / input_height from the extractor, the 1-D stack's width from the pooled
+    height, GRU input width, rnn_bwd = rnn_fwd with reverse=True; the caller's entries win over derived ones."""
+    from pb_sed_amd.models import weak_label
+    cfg = weak_label.CRNN.get_config(_reference_style_updates())
+    assert cfg['cnn']['cnn_2d']['in_channels'] == 1 and cfg['cnn']['input_height'] == 128
+    assert cfg['cnn']['cnn_1d']['in_channels'] == 256 * 8
+    assert cfg['rnn_fwd']['rnn']['input_size'] == 256 and cfg['rnn_fwd']['output_net']['in_channels'] == 256
+    assert cfg['rnn_fwd']['reverse'] is False and cfg['rnn_bwd']['reverse'] is True
+    assert cfg['rnn_bwd']['rnn']['hidden_size'] == 256 and cfg['rnn_bwd']['rnn']['num_layers'] == 2
+    assert cfg['rnn_bwd']['output_net']['out_channels'] == [256, 10]
+    assert cfg['minimum_score'] == 1e-5 and cfg['strong_fwd_bwd_loss_weight'] == 1.
+    model = weak_label.CRNN.from_config(cfg)
+    built = weak_label.CRNN.build()
+    assert [k for k in model.state_dict()] == [k for k in built.state_dict()]
+    assert sum(p.numel() for p in model.parameters()) == 3493188
+    assert model.rnn_bwd.reverse and not model.rnn_fwd.reverse and model.labelwise_metrics == ('fscore_weak',)
+    # rnn_bwd=None survives (the user's value wins over the derived copy)
+    upd = _reference_style_updates()
+    upd['rnn_bwd'] = None
+    assert weak_label.CRNN.from_config(weak_label.CRNN.get_config(upd)).rnn_bwd is None
+
+
+def test_bicrnn_config_tag_conditioning_and_gru_defaults():
+    """strong_label/crnn.py:155-198: tag conditioning adds num_events planes / GRU inputs; the GRU defaults to one
+    bidirectional layer and the experiment's explicit num_layers=2 wins (training.py:246-251)."""
+    from pb_sed_amd.models import strong_label
+    upd = _reference_style_updates()
+    upd = {'feature_extractor': upd['feature_extractor'], 'cnn': upd['cnn'],
+           'rnn': {'rnn': {'hidden_size': 256, 'num_layers': 2, 'dropout': 0.}, 'output_net': upd['rnn_fwd']['output_net']},
+           'tag_conditioning': True}
+    cfg = strong_label.CRNN.get_config(upd)
+    assert cfg['cnn']['cnn_2d']['in_channels'] == 11 and cfg['cnn']['conditional_dims'] == 10
+    assert cfg['rnn']['rnn']['input_size'] == 266 and cfg['rnn']['rnn']['bidirectional'] is True
+    assert cfg['rnn']['rnn']['num_layers'] == 2 and cfg['rnn']['output_net']['in_channels'] == 512
+    model = strong_label.CRNN.from_config(cfg)
+    assert sum(p.numel() for p in model.parameters()) == 3899866
+    del upd['rnn']['rnn']['num_layers']
+    assert strong_label.CRNN.get_config(upd)['rnn']['rnn']['num_layers'] == 1
+    upd['tag_conditioning'] = False
+    cfg = strong_label.CRNN.get_config(upd)
+    assert cfg['cnn']['cnn_2d']['in_channels'] == 1 and cfg['rnn']['rnn']['input_size'] == 256
+
+
+def test_from_storage_dir_round_trip(tmp_path):
+    """experiments/weak_label_crnn/inference.py:407-413: CRNN.from_storage_dir(dir, config_name='1/config.json',
+    checkpoint_name=...) with the config under trainer.model and the state_dict under ['model'] of the checkpoint;
+    factories stored as the REFERENCE's import paths resolve to the build's classes."""
+    from pb_sed_amd.configurable import _jsonable
+    from pb_sed_amd.models import weak_label
+    torch.manual_seed(0)
+    cfg = weak_label.CRNN.get_config(_reference_style_updates())
+    model = weak_label.CRNN.from_config(cfg)
+    with torch.no_grad():
+        model.feature_extractor.running_mean.normal_(-7, 1)
+        model.feature_extractor.running_power.copy_(model.feature_extractor.running_mean ** 2 + 4.)
+    js = _jsonable(cfg)
+    js['factory'] = 'pb_sed.models.weak_label.crnn.CRNN'
+    js['feature_extractor']['factory'] = 'padertorch.contrib.je.modules.features.NormalizedLogMelExtractor'
+    js['cnn']['factory'] = 'padertorch.contrib.je.modules.hybrid.CNN'
+    js['cnn']['cnn_2d']['factory'] = 'padertorch.contrib.je.modules.conv.CNN2d'
+    js['cnn']['cnn_1d']['factory'] = 'padertorch.contrib.je.modules.conv.CNN1d'
+    for r in ('rnn_fwd', 'rnn_bwd'):
+        js[r]['factory'] = 'padertorch.contrib.je.modules.rnn.GRU'
+        js[r]['rnn']['factory'] = 'torch.nn.modules.rnn.GRU'
+        js[r]['output_net']['factory'] = 'padertorch.contrib.je.modules.conv.CNN1d'
+    os.makedirs(tmp_path / '1')
+    os.makedirs(tmp_path / 'checkpoints')
+    json.dump({'trainer': {'model': js, 'optimizer': {'lr': 5e-4}}, 'batch_size': 32}, open(tmp_path / '1' / 'config.json', 'w'))
+    sd = dict(model.state_dict())
+    # the reference's extractor keeps its statistics under norm.* with padertorch's broadcast shape
+    for k in ('running_mean', 'running_power', 'num_tracked_values'):
+        v = sd.pop(f'feature_extractor.{k}')
+        sd[f'feature_extractor.norm.{k}'] = v.reshape(1, 1, -1, 1)
+    sd.pop('feature_extractor.mean'), sd.pop('feature_extractor.inv_std')
+    torch.save({'model': sd, 'iteration': 1234}, tmp_path / 'checkpoints' / 'ckpt_best_macro_fscore_weak.pth')
+    loaded = weak_label.CRNN.from_storage_dir(str(tmp_path), config_name='1/config.json',
+                                              checkpoint_name='ckpt_best_macro_fscore_weak.pth')
+    for (k, a), (_, b) in zip(model.state_dict().items(), loaded.state_dict().items()):
+        if k in ('feature_extractor.mean', 'feature_extractor.inv_std'):
+            continue
+        assert torch.equal(a, b), k
+    fe = loaded.feature_extractor
+    assert torch.allclose(fe.mean, fe.running_mean)
+    assert torch.allclose(fe.inv_std, 1 / torch.sqrt(fe.running_power - fe.running_mean ** 2 + 1e-5))
+
+
+def test_unsupported_reference_options_fail_loudly():
+    from pb_sed_amd import modules
+    with pytest.raises(NotImplementedError, match='dropout'):
+        modules.CNN2d(1, [16], 3, dropout=.1)
+    with pytest.raises(NotImplementedError, match='activation_fn'):
+        modules.CNN1d(4, [16], 1, activation_fn='leaky_relu')
+
+
+def test_segment_batch_and_merge_vs_reference_vectors(golden):
+    """pb_sed/utils/segment.py executed by tests/golden/gen_golden.py (under a restated padertorch Segmenter): segment
+    ids / lengths / trimmed inputs and the merged outputs for several (max_length, overlap) pairs."""
+    from pb_sed_amd.utils import segment as sg
+    g = golden('ref_segments.npz')
+    stft, seq, ids = g['stft'], g['seq_len'].tolist(), g['ids'].tolist()
+    for max_len, overlap in ((12, 2), (20, 5), (16, 0), (64, 4)):
+        tag = f'seg_{max_len}_{overlap}'
+        segs = sg.segment_batch({'example_id': ids, 'stft': stft, 'seq_len': seq}, max_len, overlap)
+        assert len(segs) == int(g[f'{tag}/n'])
+        for i, s in enumerate(segs):
+            np.testing.assert_array_equal(np.asarray(s['stft']), g[f'{tag}/{i}/stft'])
+            assert s['seq_len'] == g[f'{tag}/{i}/seq_len'].tolist()
+            assert s['example_id'] == g[f'{tag}/{i}/ids'].tolist()
+        if len(segs) > 1:
+            out2 = {aid: np.asarray(s['stft'])[j, 0, :sl, :, 0] for s in segs
+                    for j, (aid, sl) in enumerate(zip(s['example_id'], s['seq_len']))}
+            merged = sg.merge_segments(out2, overlap)
+            merged3 = sg.merge_segments({a: np.stack([v, 2 * v]) for a, v in out2.items()}, overlap)
+            for a in ids:
+                np.testing.assert_array_equal(merged[a], g[f'{tag}/merged/{a}'])
+                np.testing.assert_array_equal(merged3[a], g[f'{tag}/merged3/{a}'])
+
+
+def test_audio_segments_cover_exactly_the_frames_of_the_stft_segments():
+    """The waveform form of segment_batch: a slice plus its 'stft_pad_front' must frame to the same samples as frames
+    [start, start + T_seg) of the whole clip (frame t covers samples [320 t - 320, 320 t + 640))."""
+    from pb_sed_amd.modules import num_frames
+    from pb_sed_amd.utils import segment as sg
+    n = 16000 * 4 + 77
+    audio = torch.arange(2 * n, dtype=torch.float32).reshape(2, n)
+    t = num_frames(n)
+    segs = sg.segment_batch({'example_id': ['a', 'b'], 'audio_data': audio, 'seq_len': [t, t - 30]}, 64, 8)
+    assert len(segs) > 2
+    padded = torch.nn.functional.pad(audio, (320, 960))
+    for s in segs:
+        x = torch.nn.functional.pad(s['audio_data'], (s['stft_pad_front'], 960))
+        for j in (0, s['num_frames'] - 1):
+            g = s['segment_start'] + j
+            assert torch.equal(x[:, 320 * j:320 * j + 960], padded[:, 320 * g:320 * g + 960]), (s['segment_start'], j)
+
+
+def test_shift_and_widen_events():
+    """experiments/strong_label_crnn/inference.py:177-184."""
+    from pb_sed_amd.inference import shift_and_widen_events
+    ev = {'a': [(0.1, 0.5, 'dog'), (2.0, 2.1, 'cat'), (3.0, 3.2, 'dog')], 'b': []}
+    out = shift_and_widen_events(ev, pseudo_widening=.1, onset_bias={'dog': .15}, offset_bias={'dog': -.05, 'cat': .4})
+    assert out['b'] == []
+    assert out['a'][0] == (0., pytest.approx(0.65), 'dog')          # onset clamped at 0
+    assert all(lbl != 'cat' for *_, lbl in out['a'])                 # 2.0-.1 .. 2.1+.1-.4 is empty
+    assert out['a'][1] == (pytest.approx(2.75), pytest.approx(3.35), 'dog')
+    assert shift_and_widen_events(ev) == {'a': ev['a'], 'b': []}
+
+
+def test_shard_batch_with_remainder():
+    from pb_sed_amd.trainer import shard_batch
+    batch = {'audio_data': torch.arange(7)[:, None], 'seq_len': list(range(7)), 'example_id': list('abcdefg'), 'meta': 1}
+    got = [shard_batch(batch, r, 3) for r in range(3)]
+    assert [len(s['seq_len']) for s in got] == [3, 2, 2]
+    assert sum((s['example_id'] for s in got), []) == list('abcdefg')
+    assert torch.equal(torch.cat([s['audio_data'] for s in got]), batch['audio_data']) and got[1]['meta'] == 1
+    assert [len(shard_batch(batch, r, 8)['seq_len']) for r in range(8)] == [1] * 7 + [0]
+
+
+def test_mel_warping_is_monotone_and_fixes_the_band_edge():
+    from pb_sed_amd.modules import LogTruncatedNormal, MelWarping, TruncatedExponential
+    w = MelWarping(LogTruncatedNormal(scale=.08, truncation=np.log(1.3), seed=1), TruncatedExponential(scale=.5, truncation=5., seed=2), 8000.)
+    f = np.linspace(50., 8000., 130)
+    out = w(f, 16)
+    assert out.shape == (16, 130) and (np.diff(out, axis=-1) > 0).all()
+    np.testing.assert_allclose(out[:, -1], 8000., rtol=1e-9)
+    assert (np.abs(out[:, 1] / f[1] - 1) < .3 + 1e-9).all() and np.ptp(out[:, 10]) > 0
