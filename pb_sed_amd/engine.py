@@ -123,14 +123,14 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32'):
     """Run a conv stack.  Returns (y, ctx) - ctx is what stack_backward needs.  ``precision``: 'f32' |
     'bf16' | 'bf16x3' operand format of the forward / data-gradient MFMAs (weight gradients are always fp32)."""
     ctx = []
-    st_in = None
+    st_in, st_frozen = None, False
     for j, L in enumerate(layers):
         c = L.conv
         nxt = layers[j + 1] if j + 1 < len(layers) else None
         next_norm = nxt.in_norm if nxt is not None else None
+        # frozen statistics (cnn_2d.freeze(n, freeze_norm_stats=True), pb_sed/experiments/weak_label_crnn/training.py:343-350):
+        # the layer normalises with its running statistics in training too and they are not updated
         batch_stats = training and next_norm is not None and not next_norm.freeze_stats
-        if training and next_norm is not None and next_norm.freeze_stats:
-            raise NotImplementedError('training through frozen norm statistics')
         per_cf = bool(batch_stats and c.ndim == 2 and nxt.conv.ndim == 1)
         if c.ndim == 1 and x.dim() == 4:
             x = x.flatten(1, 2)                       # 'b c f t -> b (c f) t' is a view in this layout
@@ -140,7 +140,8 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32'):
             x, pc, pc.fwd(pr), bias=c.conv.bias.detach(),
             scale=None if st_in is None else st_in.scale, shift=None if st_in is None else st_in.shift,
             relu=True, seq_len=seq_dev, pool=c.pool_f, want_stats=batch_stats, stats_per_cf=per_cf, precision=pr)
-        ctx.append((x, st_in, pc, idx, pr))
+        ctx.append((x, st_in, pc, idx, pr, st_frozen))
+        st_frozen = bool(training and next_norm is not None and next_norm.freeze_stats)
         if next_norm is None:
             st_in = None
         elif batch_stats:
@@ -155,9 +156,18 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32'):
 def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_done=None):
     """Backward of stack_forward; accumulates parameter grads, returns grad wrt the stack input.
     ``on_layer_done(j)`` fires once every gradient owned by layers >= j is final."""
+    def trainable(j):
+        mods = [layers[j].conv.conv] + ([layers[j].in_norm] if layers[j].in_norm is not None else [])
+        return any(p.requires_grad for m in mods for p in m.parameters())
+
+    lowest = min((j for j in range(len(layers)) if trainable(j)), default=len(layers))
     for j in reversed(range(len(layers))):
-        L, (x, st_in, pc, idx, pr) = layers[j], ctx[j]
+        L, (x, st_in, pc, idx, pr, frozen) = layers[j], ctx[j]
         c = L.conv
+        if j < lowest and not need_input_grad:                # nothing below needs a gradient (frozen front layers)
+            if on_layer_done is not None:
+                on_layer_done(0)
+            return None
         g = g.contiguous()
         dw, db = _grad(c.conv.weight), _grad(c.conv.bias)
         if dw is not None:
@@ -176,8 +186,9 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
                                           bn=(x, st_in.mean, st_in.invstd, st_in.scale, st_in.shift), precision=pr)
             rows = 1 if x.dim() == 3 else x.shape[2]
             norm = L.in_norm
-            g = ops.bn_backward(dz, x, st_in, stats, _count(seq_host, x.shape[-1], rows),
-                                _grad(norm.gamma), _grad(norm.beta), seq_dev)
+            # frozen statistics are constants: no mean / variance terms in the input gradient (count = inf drops them)
+            count = float('inf') if frozen else _count(seq_host, x.shape[-1], rows)
+            g = ops.bn_backward(dz, x, st_in, stats, count, _grad(norm.gamma), _grad(norm.beta), seq_dev)
         else:
             g, _ = ops.conv_bwd_data(g, pc, wd, x.shape, idx, None, precision=pr)
         if on_layer_done is not None:
