@@ -234,6 +234,20 @@ int pbsed_adam_step(float* p, const float* g, float* m, float* v, size_t n, floa
                     const int* skip_flags, int n_flags, void* stream);
 int pbsed_memset_async(void* p, int value, size_t bytes, void* stream);
 
+/* ---- data-parallel gradient exchange (new in the build: the reference is single-device,
+ * pb_sed/experiments/weak_label_crnn/training.py:284).  RCCL over xGMI, one communicator per process /
+ * GPU.  The communicator owns one extra HIP stream: pbsed_allreduce_begin orders an in-place fp32 sum-all-reduce of
+ * buf[0..n) after everything already enqueued on `producer_stream` and runs it on the communicator's stream (it overlaps
+ * what the producer stream does next); pbsed_allreduce_finish makes `consumer_stream` wait for every collective begun
+ * since the last finish.  Nothing blocks the host.  The unique id (pbsed_comm_id_bytes() host bytes, made on rank 0) is
+ * distributed by the caller. */
+int pbsed_comm_id_bytes(void);
+int pbsed_comm_unique_id(void* out /*host*/);
+int pbsed_comm_create(const void* unique_id /*host*/, int rank, int world, void** comm /*host, out*/);
+int pbsed_comm_destroy(void* comm);
+int pbsed_allreduce_begin(void* comm, float* buf, size_t n, void* producer_stream);
+int pbsed_allreduce_finish(void* comm, void* consumer_stream);
+
 #ifdef __cplusplus
 }
 #endif

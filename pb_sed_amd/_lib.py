@@ -68,8 +68,14 @@ SIGNATURES = {
     'pbsed_grad_sumsq': [_v, SZ, _v, _v],
     'pbsed_adam_step': [_v, _v, _v, _v, SZ, F32, F32, F32, F32, I, F32, F32, _v, _v, _v, I, _v],
     'pbsed_memset_async': [_v, I, SZ, _v],
+    'pbsed_comm_id_bytes': [],
+    'pbsed_comm_unique_id': [_v],
+    'pbsed_comm_create': [_v, I, I, _pp],
+    'pbsed_comm_destroy': [_v],
+    'pbsed_allreduce_begin': [_v, _v, SZ, _v],
+    'pbsed_allreduce_finish': [_v, _v],
 }
-_NON_STATUS = {'pbsed_last_error': C.c_char_p, 'pbsed_version': C.c_int, 'pbsed_conv_pack_dims': None,
+_NON_STATUS = {'pbsed_last_error': C.c_char_p, 'pbsed_version': C.c_int, 'pbsed_comm_id_bytes': C.c_int, 'pbsed_conv_pack_dims': None,
                'pbsed_conv_pack_dims_bf16': None, 'pbsed_conv_pack_dims_wino': None}
 
 _lib = None

@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value"
 mkdir -p build
 pids=()
-for f in api conv conv_bf16 conv_wino conv_wgrad gru gru_stack gru_wgrad misc logmel postproc; do
+for f in api conv conv_bf16 conv_wino conv_wgrad gru gru_stack gru_wgrad misc logmel postproc collective; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || \
      [ pbsed_internal.h -nt build/$f.o ] || [ fft512.h -nt build/$f.o ] || [ conv_epilogue.h -nt build/$f.o ] || [ pack_elems.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &
@@ -14,5 +14,5 @@ for f in api conv conv_bf16 conv_wino conv_wgrad gru gru_stack gru_wgrad misc lo
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC build/*.o -o ../libpbsed_mi355.so
+$HIPCC --offload-arch=gfx950 -shared -fPIC build/*.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -o ../libpbsed_mi355.so
 echo "built $(cd .. && pwd)/libpbsed_mi355.so"

@@ -433,6 +433,13 @@ def _granule_scan(nch, nlayers, b, h, t, device=None):
             and nch * nlayers * t * b * h * 4 < 2 ** 32)
 
 
+def _per_chain(nch, nlayers, b, h, t, dev):
+    """More than 32 clips per GPU: all chains together need more co-resident workgroups than the device has CUs, one
+    chain at a time fits (batch 64: 192 of 256) - run the persistent scans chain by chain instead of falling back to
+    one launch per time step."""
+    return nch > 1 and not _granule_scan(nch, nlayers, b, h, t, dev) and _granule_scan(1, nlayers, b, h, t, dev)
+
+
 def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=True):
     """Layer-wavefront scan of unidirectional stacks.  gi0: per chain [T,B,3H]; weight lists are indexed
     [chain*nlayers + layer] (w_ih/b_ih entries of layer 0 may be None).  Returns (hs, save) lists."""
@@ -440,6 +447,14 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
     t, b, g = gi0[0].shape
     h = g // 3
     dev = gi0[0].device
+    if _per_chain(nch, nlayers, b, h, t, dev):
+        hs, sv = [], []
+        for c in range(nch):
+            sl = slice(c * nlayers, (c + 1) * nlayers)
+            hc, sc = gru_stack_fwd(gi0[c:c + 1], w_ih[sl], b_ih[sl], w_hh[sl], b_hh[sl], reverse[c:c + 1], seq_len, nlayers, save)
+            hs += hc
+            sv += sc if save else []
+        return hs, (sv if save else None)
     n = nch * nlayers
     hs = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
     gran = _granule_scan(nch, nlayers, b, h, t, dev)
@@ -468,6 +483,14 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
     nch = len(dy_top)
     t, b, h = hs[0].shape
     dev = hs[0].device
+    if _per_chain(nch, nlayers, b, h, t, dev):
+        dgi, dgh = [], []
+        for c in range(nch):
+            sl = slice(c * nlayers, (c + 1) * nlayers)
+            a, g_ = gru_stack_bwd(w_hh_t[sl], w_ih_up_t[sl], hs[sl], save[sl], dy_top[c:c + 1], reverse[c:c + 1], seq_len, nlayers)
+            dgi += a
+            dgh += g_
+        return dgi, dgh
     n = nch * nlayers
     dgi = [torch.empty((t, b, 3 * h), device=dev, dtype=torch.float32) for _ in range(n)]
     dgh = [torch.empty((t, b, 3 * h), device=dev, dtype=torch.float32) for _ in range(n)]

@@ -51,6 +51,60 @@ class GradSync:
         return 1.0 / self.world
 
 
+class LibraryGradSync:
+    """Same interface as GradSync, but the collective is the library's own (``pbsed_allreduce_begin`` /
+    ``pbsed_allreduce_finish`` in include/pbsed.h: RCCL on a library-owned stream, event-fenced against the compute
+    stream, no torch.distributed call on the data path).  The RCCL unique id is made on rank 0 and handed to the other
+    ranks through whatever process group / store is initialised (a 128-byte control message, once)."""
+
+    def __init__(self, flat_grad, buckets, rank=None, world=None, unique_id=None):
+        import ctypes as C
+        from . import _lib
+        self.flat_grad, self.buckets = flat_grad, list(buckets)
+        if world is None:
+            world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+            rank = dist.get_rank() if world > 1 else 0
+        self.world, self.rank = world, rank
+        lib = _lib.lib()
+        n = lib.pbsed_comm_id_bytes()
+        if unique_id is None:
+            buf = C.create_string_buffer(n)
+            if rank == 0:
+                _lib.call('pbsed_comm_unique_id', buf)
+            box = [bytes(buf.raw)]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            unique_id = box[0]
+        assert len(unique_id) == n
+        handle = C.c_void_p()
+        with torch.cuda.device(flat_grad.device):
+            _lib.call('pbsed_comm_create', C.c_char_p(unique_id), rank, world, C.byref(handle))
+        self._comm, self._done = handle, set()
+
+    def bucket_ready(self, i):
+        from . import _lib
+        if i in self._done:
+            return
+        self._done.add(i)
+        a, b = self.buckets[i]
+        if b > a and self.world > 1:
+            _lib.call('pbsed_allreduce_begin', self._comm, self.flat_grad.data_ptr() + 4 * a, b - a, _lib.stream())
+
+    def finish(self):
+        from . import _lib
+        for i in range(len(self.buckets)):
+            self.bucket_ready(i)
+        _lib.call('pbsed_allreduce_finish', self._comm, _lib.stream())
+        self._done = set()
+        return 1.0 / self.world
+
+    def close(self):
+        from . import _lib
+        if self._comm is not None:
+            _lib.call('pbsed_comm_destroy', self._comm)
+            self._comm = None
+
+
 def shard_batch(batch, rank, world):
     """Rank r takes a contiguous run of clips of a global batch: B/world each; a remainder (a ragged last
     inference batch) goes one clip each to the first B % world ranks, so a rank's share may be empty."""
@@ -119,7 +173,9 @@ def load_init_checkpoint(model, state_dict):
     return sorted(picked)
 
 class Trainer:
-    def __init__(self, model, lr=5e-4, gradient_clipping=1e10, betas=(.9, .999), eps=1e-8):
+    def __init__(self, model, lr=5e-4, gradient_clipping=1e10, betas=(.9, .999), eps=1e-8, allreduce=None):
+        """``allreduce``: 'torch' (torch.distributed all_reduce on the initialised process group: "nccl" = RCCL on
+        ROCm; default) or 'library' (the C-ABI's own RCCL communicator, LibraryGradSync); env PBSED_ALLREDUCE."""
         self.model = model
         self.lr, self.clip, self.betas, self.eps = lr, gradient_clipping, betas, eps
         self.flat_param, self.flat_grad = model.flat_parameters()
@@ -129,7 +185,10 @@ class Trainer:
         self.grad_norm = torch.zeros((), dtype=torch.float32, device=self.flat_param.device)
         self.iteration = 0
         self.bucket_names, buckets = param_buckets(model)
-        self.sync = GradSync(self.flat_grad, buckets)
+        import os
+        allreduce = allreduce or os.environ.get('PBSED_ALLREDUCE', 'torch')
+        self.sync = (LibraryGradSync if allreduce == 'library' else GradSync)(self.flat_grad, buckets)
+        self.allreduce = allreduce
         model._grad_hook = self._on_grads_ready
         self._defer = 'defer_summary' in inspect.signature(model.review).parameters
         self._flags_host = torch.zeros(ops.GRU_FLAG_WORDS, dtype=torch.int32).pin_memory() if self.flat_param.is_cuda else None

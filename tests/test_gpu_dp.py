@@ -1,0 +1,137 @@
+"""Data-parallel training on the GPU path.  The box has ONE MI355X, so two ranks share it: the process
+group is gloo (RCCL refuses two ranks on one device), the tensors are device tensors, the kernels are the HIP path.
+
+* both ranks stay bit-identical through three Trainer steps (bucket hooks fired from autograd's thread, asynchronous
+  all-reduce of flat-gradient slices, averaged Adam);
+* 1 rank x 16 clips == 2 ranks x 8 clips: with statistics that do not depend on the batch (frozen norm / feature
+  statistics) and equal per-rank loss-weight sums the averaged gradient IS the single-rank gradient; with batch
+  statistics it is not (per-replica batch norm, a documented semantic of the build - the reference has no DP);
+* the library's own RCCL entry points (pbsed_comm_* / pbsed_allreduce_*) at world size 1: identity, ordered against the
+  compute stream, usable as the Trainer's gradient sync.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NET = dict(out_channels_2d=[16, 32, 64], pool_sizes_2d=[1, (2, 1), (2, 1)], kernel_size_2d=3,
+           out_channels_1d=[64, 64], kernel_size_1d=[3, 1])
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _batch(b, seed=7, t=100):
+    g = torch.Generator().manual_seed(seed)
+    weak = (torch.rand(b, 10, generator=g) < .3).float()
+    weak[:, 0] = 1
+    bnd = torch.zeros(b, 10, t)
+    bnd[:, 0, 10:40] = 1
+    return {'audio_data': torch.randn(b, 32000, generator=g), 'seq_len': [t] * b, 'weak_targets': weak, 'boundary_targets': bnd}
+
+
+def _to(batch, dev):
+    return {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+
+
+def _model(frozen):
+    from pb_sed_amd.models import weak_label
+    from pb_sed_amd.modules import Normalization
+    torch.manual_seed(0)
+    model = weak_label.CRNN.build(num_events=10, hidden_size=64, num_layers=2, net=NET).to('cuda:0')
+    if frozen:                                   # statistics independent of the batch: clips become independent
+        model.feature_extractor.freeze_stats = True
+        g = torch.Generator().manual_seed(1)
+        for m in model.modules():
+            if isinstance(m, Normalization):
+                m.freeze_stats = True
+                with torch.no_grad():
+                    m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * .1)
+                    m.running_power.copy_(torch.rand(m.running_power.shape, generator=g) + .8)
+    return model
+
+
+def _worker(rank, world, port, out_dir, frozen):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from pb_sed_amd.trainer import Trainer, shard_batch
+    model = _model(frozen)
+    trainer = Trainer(model, lr=1e-3, gradient_clipping=5.)
+    mine = shard_batch(_to(_batch(16), 'cuda:0'), rank, world)
+    rows = []
+    for step in range(3):
+        rev = trainer.step(mine)
+        torch.cuda.synchronize()
+        if step == 0:
+            # the reduced gradient of the first step (Adam divides by world): compare with the single-rank run
+            torch.save((trainer.flat_grad / world).cpu(), os.path.join(out_dir, f'grad{int(frozen)}_{rank}.pt'))
+        rows.append((float(rev['loss'].item()), float(trainer.flat_param.double().sum().item()),
+                     float(trainer.flat_param.double().abs().sum().item())))
+    torch.save(rows, os.path.join(out_dir, f'rows{int(frozen)}_{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('frozen', [True, False])
+def test_two_ranks_on_one_gpu(tmp_path, frozen):
+    import torch.multiprocessing as mp
+    from pb_sed_amd.trainer import Trainer
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), frozen), nprocs=2, join=True)
+    rows = [torch.load(tmp_path / f'rows{int(frozen)}_{r}.pt') for r in range(2)]
+    for step in range(3):
+        (l0, s0, a0), (l1, s1, a1) = rows[0][step], rows[1][step]
+        assert np.isfinite(l0) and np.isfinite(l1)
+        assert s0 == s1 and a0 == a1, f'step {step}: ranks diverged (all-reduce / averaged Adam not symmetric)'
+    g0, g1 = (torch.load(tmp_path / f'grad{int(frozen)}_{r}.pt') for r in range(2))
+    assert torch.equal(g0, g1)
+    # single rank, all 16 clips
+    model = _model(frozen)
+    trainer = Trainer(model, lr=1e-3, gradient_clipping=5.)
+    batch = _to(_batch(16), 'cuda:0')
+    # equal per-rank weight sums are what makes "average of per-rank gradients" the global gradient
+    w = ((batch['weak_targets'] < .01) | (batch['weak_targets'] > .99)).float().sum(-1)
+    assert w[:8].sum() == w[8:].sum()
+    trainer.step(batch)
+    torch.cuda.synchronize()
+    single = trainer.flat_grad.cpu()
+    rel = ((g0 - single).norm() / single.norm()).item()
+    print(f'frozen statistics={frozen}: |avg of 2x8 - 1x16| / |1x16| = {rel:.2e}')
+    if frozen:
+        assert rel < 2e-5, 'with batch-independent statistics DP must reproduce the single-rank gradient'
+    else:
+        assert 1e-4 < rel < .5, 'per-replica batch norm: the DP gradient differs from the single-rank one (documented)'
+
+
+def test_library_allreduce_world1_and_trainer_sync():
+    import ctypes as C
+    from pb_sed_amd import _lib
+    from pb_sed_amd.trainer import LibraryGradSync, Trainer
+    x = torch.randn(1 << 20, device='cuda:0')
+    want = (x * 3 + 1).clone()
+    sync = LibraryGradSync(x, [(0, 1 << 19), (1 << 19, 1 << 20)], rank=0, world=1)
+    # world 1 skips the collective in bucket_ready; drive the entry points directly: a 1-rank sum is the identity, and
+    # it must be ordered AFTER the producer stream's pending work and BEFORE the consumer's next kernel
+    x.mul_(3)
+    _lib.call('pbsed_allreduce_begin', sync._comm, x.data_ptr(), x.numel(), _lib.stream())
+    _lib.call('pbsed_allreduce_finish', sync._comm, _lib.stream())
+    x.add_(1)
+    torch.cuda.synchronize()
+    assert torch.equal(x, want)
+    assert sync.finish() == 1.0
+    sync.close()
+    model = _model(False)
+    trainer = Trainer(model, lr=1e-3, allreduce='library')
+    assert isinstance(trainer.sync, LibraryGradSync)
+    rev = trainer.step(_to(_batch(4), 'cuda:0'))
+    assert np.isfinite(rev['loss'].item())
+    trainer.sync.close()
