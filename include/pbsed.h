@@ -39,8 +39,12 @@ int pbsed_version(void);
 int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, const int* seq_len_frames,
                      const float* window, const float* twiddle, const int* mel_start, const int* mel_len,
                      const int* mel_off, const float* mel_w, int F, const float* mean, const float* inv_std,
-                     float eps, float clampv, float* out, double* stats, int pad_front, void* stream);
-/* `pad_front`: zero samples assumed before wav[0]; frame t covers samples [320 t - pad_front, +960).  320 is the
+                     float eps, float clampv, float* out, double* stats, int pad_front, const float* mel_pts,
+                     void* stream);
+/* `mel_pts` (both front-end entry points): NULL = the static sparse filterbank; else [B][F+2] fractional STFT-bin
+ * positions of each clip's (warped) triangular filters - filter m spans mel_pts[b][m] .. [m+2] with its peak at [m+1],
+ * unit sum: the per-example MelWarping of the training config (pb_sed/experiments/weak_label_crnn/training.py:195-208).
+ * `pad_front`: zero samples assumed before wav[0]; frame t covers samples [320 t - pad_front, +960).  320 is the
  * reference's 'half' fading (provider.py:315-323); 0 for a slice cut out of the middle of a long clip.
  * `stats` (both front-end entry points): NULL, or [PBSED_STAT_SLOTS][F][2] zeroed doubles that receive the per-mel sum
  * and sum of squares of the values written for frames < seq_len - the training-mode statistics pass of the feature
@@ -52,7 +56,7 @@ int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, const int* s
 int pbsed_logmel_from_stft(const float* stft, int B, int T, int bins, const int* seq_len_frames,
                            const int* mel_start, const int* mel_len, const int* mel_off, const float* mel_w,
                            int F, const float* mean, const float* inv_std, float eps, float clampv,
-                           float* out, double* stats, void* stream);
+                           float* out, double* stats, const float* mel_pts, void* stream);
 /* Cumulative statistics of NormalizedLogMelExtractor's Normalization(statistics_axis='bt', momentum=None) (config
  * pb_sed/experiments/weak_label_crnn/training.py:190-217): running_mean / running_power [F] over all `num_tracked`
  * valid (clip, frame) positions so far are advanced by this batch's `count` positions with sums `stats`; mean and

@@ -134,9 +134,19 @@ class LogMelExtractor(torch.nn.Module):
         self.inv_std.copy_(1. / torch.sqrt((pw - mu * mu).clamp_min(0.) + self.norm_eps))
 
     @torch.no_grad()
-    def forward(self, x, seq_len=None, targets=None):
+    def forward(self, x, seq_len=None, targets=None, mel_points=None):
+        """``mel_points`` [B, F+2]: per-clip fractional bin positions of warped filters (training-time MelWarping,
+        training.py:195-208) - filter m of clip b is the unit-sum triangle over points m, m+1, m+2 (get_fbanks above)."""
         power = (x.to(self.fbanks.dtype) ** 2).sum(-1)          # [B,1,T,bins] (f32; f64 if .double())
-        mel = power @ self.fbanks.T                               # [B,1,T,F]
+        if mel_points is not None:
+            p = torch.as_tensor(np.asarray(mel_points), dtype=torch.float64)
+            k = torch.arange(power.shape[-1], dtype=torch.float64)[None, None]
+            lo, c, hi = p[:, :-2, None], p[:, 1:-1, None], p[:, 2:, None]
+            fb = torch.minimum((k - lo) / (c - lo), (hi - k) / (hi - c)).clamp_min(0.)
+            fb = (fb / fb.sum(-1, keepdim=True)).to(power.dtype)            # [B,F,bins]
+            mel = torch.einsum('bctk,bfk->bctf', power, fb)
+        else:
+            mel = power @ self.fbanks.T                           # [B,1,T,F]
         logmel = torch.log(mel + self.eps).transpose(-1, -2)     # [B,1,F,T]
         if self.training and not self.freeze_stats:
             self._track(logmel, seq_len)

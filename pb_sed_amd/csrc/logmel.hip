@@ -32,6 +32,7 @@ struct LogmelArgs {
     double* stats;           // optional [PBSED_STAT_SLOTS][F][2]: masked sum / sum of squares of the written values
     int B, N, T, F;
     float eps, clampv;
+    const float* mel_pts;    // optional [B][F+2]: per-clip fractional bin positions of the (warped) filter edges / centres
     int pad_front;           // zero samples assumed in front of wav[0] (320 = the reference's 'half' fading; 0 for a slice
                              // cut out of the middle of a clip, pb_sed_amd/utils/segment.py)
 };
@@ -50,6 +51,31 @@ __device__ __forceinline__ void logmel_tile_stats(const float* tile, double* sta
         atomicAdd(dst + 2 * m, (double)s);
         atomicAdd(dst + 2 * m + 1, (double)q);
     }
+}
+
+// One mel value from a power-spectrum row.  Static filterbank: sparse rows of the packed table.  Per-clip warped
+// filterbank (training-time MelWarping, pb_sed/experiments/weak_label_crnn/training.py:195-208): filter m is the
+// triangle over the fractional bin positions pts[m] < pts[m+1] < pts[m+2] of THIS clip, normalised to unit sum
+// (paderbox get_fbanks semantics), its weights computed on the fly - no per-clip table is ever materialised.
+__device__ __forceinline__ float mel_from_power(const float* P, int m, int bins, const int* mel_start, const int* mel_len,
+                                                const int* mel_off, const float* mel_w, const float* pts) {
+    float s = 0.f;
+    if (pts) {
+        const float lo = pts[m], c = pts[m + 1], hi = pts[m + 2];
+        const float il = 1.f / (c - lo), ih = 1.f / (hi - c);
+        const int k0 = max((int)ceilf(lo), 0), k1 = min((int)floorf(hi), bins - 1);
+        float wsum = 0.f;
+        for (int k = k0; k <= k1; ++k) {
+            const float w = fmaxf(fminf(((float)k - lo) * il, (hi - (float)k) * ih), 0.f);
+            wsum += w;
+            s = fmaf(P[k], w, s);
+        }
+        return wsum > 0.f ? s / wsum : 0.f;
+    }
+    const int st = mel_start[m], ln = mel_len[m];
+    const float* w = mel_w + mel_off[m];
+    for (int i = 0; i < ln; ++i) s = fmaf(P[st + i], w[i], s);
+    return s;
 }
 
 __global__ __launch_bounds__(256) void logmel_kernel(LogmelArgs a) {
@@ -99,11 +125,9 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelArgs a) {
         float* P = reinterpret_cast<float*>(A);                 // [513] power spectrum
         for (int k = lane; k <= 512; k += 64) P[k] = rfft1024_power(Bf, tw, k);
         __syncthreads();
+        const float* pts = a.mel_pts ? a.mel_pts + (size_t)b * (a.F + 2) : nullptr;
         for (int m = lane; m < a.F; m += 64) {
-            const int st = a.mel_start[m], ln = a.mel_len[m];
-            const float* w = a.mel_w + a.mel_off[m];
-            float s = 0.f;
-            for (int i = 0; i < ln; ++i) s = fmaf(P[st + i], w[i], s);
+            const float s = mel_from_power(P, m, 513, a.mel_start, a.mel_len, a.mel_off, a.mel_w, pts);
             float v = (logf(s + a.eps) - a.mean[m]) * a.inv_std[m];
             v = fminf(fmaxf(v, -a.clampv), a.clampv);
             tile[m * (LM_FR + 1) + fl] = (t < sl) ? v : 0.f;
@@ -135,6 +159,7 @@ struct LogmelStftArgs {
     double* stats;           // optional, as LogmelArgs::stats
     int B, T, F, bins;
     float eps, clampv;
+    const float* mel_pts;    // optional, as LogmelArgs::mel_pts
 };
 
 __global__ __launch_bounds__(256) void logmel_from_stft_kernel(LogmelStftArgs a) {
@@ -159,11 +184,8 @@ __global__ __launch_bounds__(256) void logmel_from_stft_kernel(LogmelStftArgs a)
         const int fl = i % LM_FR, m = i / LM_FR;                  // 16 consecutive lanes share a filter (broadcast weights)
         float v = 0.f;
         if (fl < nfr) {
-            const int st = a.mel_start[m], ln = a.mel_len[m];
-            const float* w = a.mel_w + a.mel_off[m];
-            const float* p = P + fl * PS + st;
-            float s = 0.f;
-            for (int j = 0; j < ln; ++j) s = fmaf(p[j], w[j], s);
+            const float s = mel_from_power(P + fl * PS, m, a.bins, a.mel_start, a.mel_len, a.mel_off, a.mel_w,
+                                           a.mel_pts ? a.mel_pts + (size_t)b * (a.F + 2) : nullptr);
             v = (logf(s + a.eps) - a.mean[m]) * a.inv_std[m];
             v = fminf(fmaxf(v, -a.clampv), a.clampv);
             if (t0 + fl >= sl) v = 0.f;
@@ -260,11 +282,11 @@ extern "C" int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, c
                                 const float* window, const float* twiddle, const int* mel_start,
                                 const int* mel_len, const int* mel_off, const float* mel_w, int F,
                                 const float* mean, const float* inv_std, float eps, float clampv,
-                                float* out, double* stats, int pad_front, void* stream) {
+                                float* out, double* stats, int pad_front, const float* mel_pts, void* stream) {
     if (pad_front < 0 || pad_front > LM_WIN) { set_error("logmel: pad_front %d", pad_front); return PBSED_E_ARG; }
     if (F > LM_NMEL_MAX * 4 || F < 1 || T < 1) { set_error("logmel: bad F=%d T=%d", F, T); return PBSED_E_ARG; }
     LogmelArgs a{wav, window, twiddle, mel_start, mel_len, mel_off, mel_w, mean, inv_std, seq_len_frames,
-                 out, stats, B, n_samples, T, F, eps, clampv, pad_front};
+                 out, stats, B, n_samples, T, F, eps, clampv, mel_pts, pad_front};
     const int nTt = (T + LM_FR - 1) / LM_FR;
     const size_t lds = ((LM_FR - 1) * LM_SHIFT + LM_WIN + LM_WIN) * sizeof(float) + 1024 * sizeof(cpx) +
                        4 * 2 * 512 * sizeof(cpx) + (size_t)F * (LM_FR + 1) * sizeof(float);
@@ -276,11 +298,11 @@ extern "C" int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, c
 extern "C" int pbsed_logmel_from_stft(const float* stft, int B, int T, int bins, const int* seq_len_frames,
                                       const int* mel_start, const int* mel_len, const int* mel_off, const float* mel_w,
                                       int F, const float* mean, const float* inv_std, float eps, float clampv,
-                                      float* out, double* stats, void* stream) {
+                                      float* out, double* stats, const float* mel_pts, void* stream) {
     if (F < 1 || T < 1 || bins < 2 || B < 1) { set_error("logmel_from_stft: bad B=%d T=%d bins=%d F=%d", B, T, bins, F); return PBSED_E_ARG; }
     const size_t lds = ((size_t)LM_FR * (bins + 1) + (size_t)F * (LM_FR + 1)) * sizeof(float);
     if (lds > 160 * 1024) { set_error("logmel_from_stft: %d bins x %d filters need %zu B of LDS", bins, F, lds); return PBSED_E_UNSUPPORTED; }
-    LogmelStftArgs a{stft, mel_start, mel_len, mel_off, mel_w, mean, inv_std, seq_len_frames, out, stats, B, T, F, bins, eps, clampv};
+    LogmelStftArgs a{stft, mel_start, mel_len, mel_off, mel_w, mean, inv_std, seq_len_frames, out, stats, B, T, F, bins, eps, clampv, mel_pts};
     PBSED_DYN_LDS_ONCE(logmel_from_stft_kernel, lds);
     const int nTt = (T + LM_FR - 1) / LM_FR;
     hipLaunchKernelGGL(logmel_from_stft_kernel, dim3(B * nTt), dim3(256), lds, (hipStream_t)stream, a);

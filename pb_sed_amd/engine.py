@@ -397,13 +397,17 @@ def _features(fe, raw_fn, seq_dev, seq_host, n_frames):
     """Shared driver of both front-end entry points.  Eval / frozen statistics: ONE fused launch (normalised, clamped,
     masked).  Training with statistics tracking (the reference's NormalizedLogMelExtractor default): raw
     log-mel + per-mel sums in the same launch -> cumulative statistics update -> normalise / clamp (+ augmentation) in
-    place.  ``raw_fn(mean, inv_std, clamp, stats)`` launches the front-end kernel."""
+    place.  ``raw_fn(mean, inv_std, clamp, stats, mel_points)`` launches the front-end kernel."""
     track = fe.training and not fe.freeze_stats
+    pts = None
+    if fe.training and fe.frequency_warping_fn is not None:       # per-clip mel warping: filters built inside the kernel
+        fe.last_mel_points = fe.sample_mel_points(len(seq_host))
+        pts = torch.from_numpy(fe.last_mel_points).to(seq_dev.device)
     if not track:
-        x = raw_fn(fe.mean, fe.inv_std, fe.clamp, None)
+        x = raw_fn(fe.mean, fe.inv_std, fe.clamp, None, pts)
         return augment_features(fe, x, seq_dev, seq_host) if (fe.training and fe.augments) else x
     stats = ops.feature_norm_stats(fe.number_of_filters, seq_dev.device)
-    x = raw_fn(None, None, None, stats)
+    x = raw_fn(None, None, None, stats, pts)
     count = float(np.minimum(np.asarray(seq_host), n_frames).sum())
     ops.feature_norm_update(stats, count, fe)
     return augment_features(fe, x, seq_dev, seq_host, normalise=True)
@@ -413,9 +417,9 @@ def features_from_audio(fe, audio, seq_dev, n_frames, seq_host=None, pad_front=3
     tables = _tables(fe, audio.device)
     if seq_host is None:
         seq_host = seq_dev.cpu().numpy()
-    return _features(fe, lambda mean, inv_std, clamp, stats: ops.logmel_fwd(
-        audio, tables, mean, inv_std, n_frames, seq_dev, eps=fe.eps, clamp=clamp, stats=stats, pad_front=pad_front),
-        seq_dev, seq_host, n_frames)
+    return _features(fe, lambda mean, inv_std, clamp, stats, pts: ops.logmel_fwd(
+        audio, tables, mean, inv_std, n_frames, seq_dev, eps=fe.eps, clamp=clamp, stats=stats, pad_front=pad_front,
+        mel_points=pts), seq_dev, seq_host, n_frames)
 
 
 def augment_features(fe, x, seq_dev, seq_host=None, normalise=False):
@@ -439,5 +443,6 @@ def features_from_stft(fe, stft, seq_host, seq_dev=None):
     tables = _tables(fe, stft.device)
     if seq_dev is None:
         seq_dev = seq_to_device(seq_host, stft.device)
-    return _features(fe, lambda mean, inv_std, clamp, stats: ops.logmel_from_stft(
-        stft, tables, mean, inv_std, seq_dev, eps=fe.eps, clamp=clamp, stats=stats), seq_dev, seq_host, stft.shape[2])
+    return _features(fe, lambda mean, inv_std, clamp, stats, pts: ops.logmel_from_stft(
+        stft, tables, mean, inv_std, seq_dev, eps=fe.eps, clamp=clamp, stats=stats, mel_points=pts),
+        seq_dev, seq_host, stft.shape[2])

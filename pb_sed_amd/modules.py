@@ -127,6 +127,13 @@ class NormalizedLogMelExtractor(nn.Module):
         self.freeze_stats = False
         self._tables = None
 
+    def sample_mel_points(self, batch_size):
+        """Per-clip fractional STFT-bin positions [B, F + 2] of the warped filter edges / centres (training only): the
+        HTK-mel spaced points lowest..highest frequency, pushed through ``frequency_warping_fn`` (one draw per clip)."""
+        pts_hz = mel2hz(np.linspace(hz2mel(self.lowest_frequency), hz2mel(self.highest_frequency), self.number_of_filters + 2))
+        warped = self.frequency_warping_fn(pts_hz, batch_size)
+        return (np.asarray(warped, dtype=np.float64) / self.sample_rate * self.stft_size).astype(np.float32)
+
     def set_statistics(self, mean, std):
         """Fixed normalisation statistics (e.g. from a data-set pass); training stops tracking."""
         with torch.no_grad():

@@ -602,7 +602,8 @@ class LogMelTables:
         self.one = torch.ones(self.n_filters, device=device)
 
 
-def logmel_fwd(wav, tables, mean, inv_std, n_frames, seq_len=None, eps=1e-18, clamp=6.0, stats=None, pad_front=320):
+def logmel_fwd(wav, tables, mean, inv_std, n_frames, seq_len=None, eps=1e-18, clamp=6.0, stats=None, pad_front=320,
+               mel_points=None):
     """wav [B, N] f32 (device) -> normalised, clamped, masked log-mel [B, 1, F, T].  ``stats``: see
     feature_norm_stats (then pass mean = inv_std = None, clamp = None to get the raw log-mel)."""
     _lib.require_gpu(wav)
@@ -611,12 +612,12 @@ def logmel_fwd(wav, tables, mean, inv_std, n_frames, seq_len=None, eps=1e-18, cl
     call('pbsed_logmel_fwd', ptr(wav.contiguous()), b, n, n_frames, ptr(seq_len), ptr(tables.window),
          ptr(tables.twiddle), ptr(tables.start), ptr(tables.len), ptr(tables.off), ptr(tables.w),
          tables.n_filters, ptr(tables.zero if mean is None else mean), ptr(tables.one if inv_std is None else inv_std),
-         float(eps), float(clamp if clamp is not None else 3e38), ptr(out), ptr(stats), int(pad_front), stream(),
+         float(eps), float(clamp if clamp is not None else 3e38), ptr(out), ptr(stats), int(pad_front), ptr(mel_points), stream(),
          nbytes=b * (n * 4 + tables.n_filters * n_frames * 4))
     return out
 
 
-def logmel_from_stft(stft, tables, mean, inv_std, seq_len=None, eps=1e-18, clamp=6.0, stats=None):
+def logmel_from_stft(stft, tables, mean, inv_std, seq_len=None, eps=1e-18, clamp=6.0, stats=None, mel_points=None):
     """stft [B, 1, T, bins, 2] f32 (the reference's ``inputs['stft']``) -> normalised, clamped, masked log-mel [B, 1, F, T]."""
     _lib.require_gpu(stft)
     b, c, t, bins, two = stft.shape
@@ -626,7 +627,7 @@ def logmel_from_stft(stft, tables, mean, inv_std, seq_len=None, eps=1e-18, clamp
     call('pbsed_logmel_from_stft', ptr(x), b, t, bins, ptr(seq_len), ptr(tables.start), ptr(tables.len), ptr(tables.off),
          ptr(tables.w), tables.n_filters, ptr(tables.zero if mean is None else mean),
          ptr(tables.one if inv_std is None else inv_std), float(eps), float(clamp if clamp is not None else 3e38),
-         ptr(out), ptr(stats), stream(), nbytes=b * t * (bins * 8 + tables.n_filters * 4))
+         ptr(out), ptr(stats), ptr(mel_points), stream(), nbytes=b * t * (bins * 8 + tables.n_filters * 4))
     return out
 
 

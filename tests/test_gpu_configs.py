@@ -475,3 +475,32 @@ def test_gru_stack_t500_h256_vs_torch(b):
         for l in range(2):
             db = dgh[ci * 2 + l].sum((0, 1)).cpu()
             rel_close(db, getattr(g, f'bias_hh_l{l}').grad, 2e-4, f'chain {ci} layer {l} db_hh')
+
+
+def test_mel_warping_training_front_end():
+    """The reference's training front-end incl. per-example MelWarping (pb_sed/experiments/weak_label_crnn/training.py:
+    195-208): the kernel builds every clip's warped triangular filters on the fly from its warped edge positions; same
+    positions through the oracle's dense per-clip filterbank.  Both input contracts; eval mode does not warp."""
+    from oracle import frontend as ofe
+    from pb_sed_amd import engine
+    from pb_sed_amd.modules import LogTruncatedNormal, MelWarping, NormalizedLogMelExtractor, TruncatedExponential
+    warp = MelWarping(LogTruncatedNormal(scale=.08, truncation=np.log(1.3), seed=3),
+                      TruncatedExponential(scale=.5, truncation=5., seed=4), highest_frequency=8000.)
+    fe = NormalizedLogMelExtractor(frequency_warping_fn=warp).to(DEV).train()
+    fe_ref = ofe.LogMelExtractor().train()
+    wav, seq, *_ = synth_batch(6, 16000 * 2 + 50, 10, seed=80)
+    stft = ofe.stft(wav)
+    seq_dev = engine.seq_to_device(seq, DEV)
+    x = engine.features_from_audio(fe, wav.to(DEV), seq_dev, stft.shape[2], seq)
+    pts = fe.last_mel_points
+    assert pts.shape == (6, 130) and np.ptp(pts[:, 60]) > .5             # clips are warped differently
+    x_ref, _ = fe_ref(stft, seq_len=seq, mel_points=pts)
+    rel_close(x, x_ref, 1e-4, 'warped features (waveform input)')
+    fe2 = NormalizedLogMelExtractor(frequency_warping_fn=warp).to(DEV).train()
+    fe_ref2 = ofe.LogMelExtractor().train()
+    x2 = engine.features_from_stft(fe2, stft.to(DEV), seq, seq_dev)
+    x2_ref, _ = fe_ref2(stft, seq_len=seq, mel_points=fe2.last_mel_points)
+    rel_close(x2, x2_ref, 1e-4, 'warped features (stft input)')
+    fe.eval(), fe_ref.eval()
+    rel_close(engine.features_from_audio(fe, wav.to(DEV), seq_dev, stft.shape[2], seq), fe_ref(stft, seq_len=seq)[0], 1e-4,
+              'eval: static filterbank')
