@@ -35,10 +35,10 @@ int pbsed_version(void);
 /* ---- fused front-end.  Replaces the CPU STFT (pb_sed/data_preparation/provider.py:315-323, called at
  * pb_sed/data_preparation/transform.py:53) + NormalizedLogMelExtractor (pb_sed/models/weak_label/crnn.py:86-90).
  * wav [B, n_samples] -> out [B, 1, F, T];  window[960], twiddle[1024][2], sparse mel filters
- * (mel_start/mel_len/mel_off [F], mel_w flat), mean/inv_std [F]; seq_len_frames [B] or NULL. */
+ * (mel_start/mel_len/mel_off [F], mel_w flat with mel_w_count <= 1152 entries), mean/inv_std [F]; seq_len_frames [B] or NULL. */
 int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, const int* seq_len_frames,
                      const float* window, const float* twiddle, const int* mel_start, const int* mel_len,
-                     const int* mel_off, const float* mel_w, int F, const float* mean, const float* inv_std,
+                     const int* mel_off, const float* mel_w, int mel_w_count, int F, const float* mean, const float* inv_std,
                      float eps, float clampv, float* out, double* stats, int pad_front, const float* mel_pts,
                      void* stream);
 /* `mel_pts` (both front-end entry points): NULL = the static sparse filterbank; else [B][F+2] fractional STFT-bin
@@ -55,7 +55,7 @@ int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, const int* s
  * (x - mean) * inv_std -> clamp -> frames >= seq_len zeroed -> out [B, 1, F, T].  Same tables as pbsed_logmel_fwd. */
 int pbsed_logmel_from_stft(const float* stft, int B, int T, int bins, const int* seq_len_frames,
                            const int* mel_start, const int* mel_len, const int* mel_off, const float* mel_w,
-                           int F, const float* mean, const float* inv_std, float eps, float clampv,
+                           int mel_w_count, int F, const float* mean, const float* inv_std, float eps, float clampv,
                            float* out, double* stats, const float* mel_pts, void* stream);
 /* Cumulative statistics of NormalizedLogMelExtractor's Normalization(statistics_axis='bt', momentum=None) (config
  * pb_sed/experiments/weak_label_crnn/training.py:190-217): running_mean / running_power [F] over all `num_tracked`

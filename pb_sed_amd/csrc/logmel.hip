@@ -16,6 +16,7 @@
 namespace pbsed {
 
 constexpr int LM_SHIFT = 320, LM_WIN = 960, LM_FR = 16, LM_NMEL_MAX = 128;
+constexpr int LM_MW_MAX = 1152;      // packed non-zero filter weights staged in LDS (128 HTK-mel filters over 513 bins: ~1030); sized so that two blocks share a CU (79.3 KB each)
 
 struct LogmelArgs {
     const float* wav;        // [B][N]
@@ -57,25 +58,34 @@ __device__ __forceinline__ void logmel_tile_stats(const float* tile, double* sta
 // filterbank (training-time MelWarping, pb_sed/experiments/weak_label_crnn/training.py:195-208): filter m is the
 // triangle over the fractional bin positions pts[m] < pts[m+1] < pts[m+2] of THIS clip, normalised to unit sum
 // (paderbox get_fbanks semantics), its weights computed on the fly - no per-clip table is ever materialised.
+__device__ __forceinline__ float mel_triangle(const float* P, int bins, float lo, float c, float hi) {
+    const float il = 1.f / (c - lo), ih = 1.f / (hi - c);
+    const int k0 = max((int)ceilf(lo), 0), k1 = min((int)floorf(hi), bins - 1);
+    float s = 0.f, wsum = 0.f;
+    for (int k = k0; k <= k1; ++k) {
+        const float w = fmaxf(fminf(((float)k - lo) * il, (hi - (float)k) * ih), 0.f);
+        wsum += w;
+        s = fmaf(P[k], w, s);
+    }
+    return wsum > 0.f ? s / wsum : 0.f;
+}
+
 __device__ __forceinline__ float mel_from_power(const float* P, int m, int bins, const int* mel_start, const int* mel_len,
                                                 const int* mel_off, const float* mel_w, const float* pts) {
     float s = 0.f;
-    if (pts) {
-        const float lo = pts[m], c = pts[m + 1], hi = pts[m + 2];
-        const float il = 1.f / (c - lo), ih = 1.f / (hi - c);
-        const int k0 = max((int)ceilf(lo), 0), k1 = min((int)floorf(hi), bins - 1);
-        float wsum = 0.f;
-        for (int k = k0; k <= k1; ++k) {
-            const float w = fmaxf(fminf(((float)k - lo) * il, (hi - (float)k) * ih), 0.f);
-            wsum += w;
-            s = fmaf(P[k], w, s);
-        }
-        return wsum > 0.f ? s / wsum : 0.f;
-    }
+    if (pts) return mel_triangle(P, bins, pts[m], pts[m + 1], pts[m + 2]);
     const int st = mel_start[m], ln = mel_len[m];
     const float* w = mel_w + mel_off[m];
     for (int i = 0; i < ln; ++i) s = fmaf(P[st + i], w[i], s);
     return s;
+}
+
+// A wave's FFT buffers, power row and output-tile columns are private to it: between the phases of one frame only the
+// wave's own LDS traffic has to be ordered (the LDS unit executes one wave's ds_* instructions in issue order), so the
+// per-frame loop needs no block-wide barrier - the four waves of a block drift apart and hide each other's latencies.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 __global__ __launch_bounds__(256) void logmel_kernel(LogmelArgs a) {
@@ -86,6 +96,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelArgs a) {
     cpx* tw = reinterpret_cast<cpx*>(win + LM_WIN);               // [1024]
     cpx* bufs = tw + 1024;                                        // [4 waves][2][512]
     float* tile = reinterpret_cast<float*>(bufs + 4 * 2 * 512);   // [F][LM_FR+1]
+    float* mw = tile + a.F * (LM_FR + 1);                         // packed filter weights (static filterbank)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nTt = (a.T + LM_FR - 1) / LM_FR;
@@ -96,13 +107,32 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelArgs a) {
         const long n = s0 + i;
         samp[i] = (n >= 0 && n < a.N) ? wav[n] : 0.f;
     }
+    const int n_mw = a.mel_pts ? 0 : a.mel_off[a.F - 1] + a.mel_len[a.F - 1];
+    for (int i = tid; i < n_mw; i += 256) mw[i] = a.mel_w[i];
     for (int i = tid; i < LM_WIN; i += 256) win[i] = a.window[i];
-    for (int i = tid; i < 1024; i += 256) tw[i] = cpx{a.twiddle[2 * i], a.twiddle[2 * i + 1]};
+    for (int i = tid; i < 1024; i += 256) {
+        const float2 w = reinterpret_cast<const float2*>(a.twiddle)[i];
+        tw[i] = cpx{w.x, w.y};
+    }
     __syncthreads();
 
     cpx* A = bufs + wave * 1024;
     cpx* Bf = A + 512;
     const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
+    // per-lane filter descriptors (filters m = lane, lane + 64, ...) stay in registers for all frames of the block
+    constexpr int MPL = LM_NMEL_MAX * 4 / 64;
+    int f_st[MPL], f_ln[MPL], f_off[MPL];
+    float f_mean[MPL], f_is[MPL], f_lo[MPL], f_c[MPL], f_hi[MPL];
+    const float* pts = a.mel_pts ? a.mel_pts + (size_t)b * (a.F + 2) : nullptr;
+#pragma unroll
+    for (int i = 0; i < MPL; ++i) {
+        const int m = lane + 64 * i;
+        if (m < a.F) {
+            f_mean[i] = a.mean[m]; f_is[i] = a.inv_std[m];
+            if (pts) { f_lo[i] = pts[m]; f_c[i] = pts[m + 1]; f_hi[i] = pts[m + 2]; }
+            else { f_st[i] = a.mel_start[m]; f_ln[i] = a.mel_len[m]; f_off[i] = a.mel_off[m]; }
+        }
+    }
     for (int fi = 0; fi < LM_FR / 4; ++fi) {
         const int fl = wave * (LM_FR / 4) + fi;
         const int t = t0 + fl;
@@ -115,25 +145,35 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelArgs a) {
             if (2 * n < LM_WIN) v = cpx{x[2 * n] * win[2 * n], x[2 * n + 1] * win[2 * n + 1]};
             A[n] = v;
         }
-        __syncthreads();
+        wave_lds_sync();
         fft512_pass<1>(A, Bf, tw, lane);
-        __syncthreads();
+        wave_lds_sync();
         fft512_pass<8>(Bf, A, tw, lane);
-        __syncthreads();
+        wave_lds_sync();
         fft512_pass<64>(A, Bf, tw, lane);
-        __syncthreads();
+        wave_lds_sync();
         float* P = reinterpret_cast<float*>(A);                 // [513] power spectrum
         for (int k = lane; k <= 512; k += 64) P[k] = rfft1024_power(Bf, tw, k);
-        __syncthreads();
-        const float* pts = a.mel_pts ? a.mel_pts + (size_t)b * (a.F + 2) : nullptr;
-        for (int m = lane; m < a.F; m += 64) {
-            const float s = mel_from_power(P, m, 513, a.mel_start, a.mel_len, a.mel_off, a.mel_w, pts);
-            float v = (logf(s + a.eps) - a.mean[m]) * a.inv_std[m];
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < MPL; ++i) {
+            const int m = lane + 64 * i;
+            if (m >= a.F) break;
+            float s = 0.f;
+            if (pts) {
+                s = mel_triangle(P, 513, f_lo[i], f_c[i], f_hi[i]);
+            } else {
+                const float* p = P + f_st[i];
+                const float* w = mw + f_off[i];
+                for (int j = 0; j < f_ln[i]; ++j) s = fmaf(p[j], w[j], s);
+            }
+            float v = (logf(s + a.eps) - f_mean[i]) * f_is[i];
             v = fminf(fmaxf(v, -a.clampv), a.clampv);
             tile[m * (LM_FR + 1) + fl] = (t < sl) ? v : 0.f;
         }
-        __syncthreads();
+        wave_lds_sync();
     }
+    __syncthreads();
     if (a.stats) logmel_tile_stats(tile, a.stats, a.F, tid);
     for (int i = tid; i < a.F * LM_FR; i += 256) {
         const int m = i / LM_FR, fl = i % LM_FR;
@@ -167,7 +207,10 @@ __global__ __launch_bounds__(256) void logmel_from_stft_kernel(LogmelStftArgs a)
     const int PS = a.bins + 1;                                    // odd row stride: frames land in different banks
     float* P = smem;                                              // [LM_FR][PS]
     float* tile = P + LM_FR * PS;                                 // [F][LM_FR+1]
+    float* mw = tile + a.F * (LM_FR + 1);                         // packed filter weights (static filterbank)
     const int tid = threadIdx.x;
+    const int n_mw = a.mel_pts ? 0 : a.mel_off[a.F - 1] + a.mel_len[a.F - 1];
+    for (int i = tid; i < n_mw; i += 256) mw[i] = a.mel_w[i];
     const int nTt = (a.T + LM_FR - 1) / LM_FR;
     const int b = blockIdx.x / nTt, t0 = (blockIdx.x % nTt) * LM_FR;
     const int nfr = min(LM_FR, a.T - t0);
@@ -184,7 +227,7 @@ __global__ __launch_bounds__(256) void logmel_from_stft_kernel(LogmelStftArgs a)
         const int fl = i % LM_FR, m = i / LM_FR;                  // 16 consecutive lanes share a filter (broadcast weights)
         float v = 0.f;
         if (fl < nfr) {
-            const float s = mel_from_power(P + fl * PS, m, a.bins, a.mel_start, a.mel_len, a.mel_off, a.mel_w,
+            const float s = mel_from_power(P + fl * PS, m, a.bins, a.mel_start, a.mel_len, a.mel_off, mw,
                                            a.mel_pts ? a.mel_pts + (size_t)b * (a.F + 2) : nullptr);
             v = (logf(s + a.eps) - a.mean[m]) * a.inv_std[m];
             v = fminf(fmaxf(v, -a.clampv), a.clampv);
@@ -280,16 +323,17 @@ extern "C" int pbsed_augment_logmel(float* x, const float* noise, const float* n
 
 extern "C" int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, const int* seq_len_frames,
                                 const float* window, const float* twiddle, const int* mel_start,
-                                const int* mel_len, const int* mel_off, const float* mel_w, int F,
+                                const int* mel_len, const int* mel_off, const float* mel_w, int mel_w_count, int F,
                                 const float* mean, const float* inv_std, float eps, float clampv,
                                 float* out, double* stats, int pad_front, const float* mel_pts, void* stream) {
     if (pad_front < 0 || pad_front > LM_WIN) { set_error("logmel: pad_front %d", pad_front); return PBSED_E_ARG; }
     if (F > LM_NMEL_MAX * 4 || F < 1 || T < 1) { set_error("logmel: bad F=%d T=%d", F, T); return PBSED_E_ARG; }
+    if (mel_w_count > LM_MW_MAX || mel_w_count < 0) { set_error("logmel: %d packed filter weights (max %d)", mel_w_count, LM_MW_MAX); return PBSED_E_UNSUPPORTED; }
     LogmelArgs a{wav, window, twiddle, mel_start, mel_len, mel_off, mel_w, mean, inv_std, seq_len_frames,
                  out, stats, B, n_samples, T, F, eps, clampv, mel_pts, pad_front};
     const int nTt = (T + LM_FR - 1) / LM_FR;
     const size_t lds = ((LM_FR - 1) * LM_SHIFT + LM_WIN + LM_WIN) * sizeof(float) + 1024 * sizeof(cpx) +
-                       4 * 2 * 512 * sizeof(cpx) + (size_t)F * (LM_FR + 1) * sizeof(float);
+                       4 * 2 * 512 * sizeof(cpx) + (size_t)F * (LM_FR + 1) * sizeof(float) + LM_MW_MAX * sizeof(float);
     PBSED_DYN_LDS_ONCE(logmel_kernel, lds);
     hipLaunchKernelGGL(logmel_kernel, dim3(B * nTt), dim3(256), lds, (hipStream_t)stream, a);
     return check_launch("logmel_fwd");
@@ -297,10 +341,11 @@ extern "C" int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, c
 
 extern "C" int pbsed_logmel_from_stft(const float* stft, int B, int T, int bins, const int* seq_len_frames,
                                       const int* mel_start, const int* mel_len, const int* mel_off, const float* mel_w,
-                                      int F, const float* mean, const float* inv_std, float eps, float clampv,
+                                      int mel_w_count, int F, const float* mean, const float* inv_std, float eps, float clampv,
                                       float* out, double* stats, const float* mel_pts, void* stream) {
     if (F < 1 || T < 1 || bins < 2 || B < 1) { set_error("logmel_from_stft: bad B=%d T=%d bins=%d F=%d", B, T, bins, F); return PBSED_E_ARG; }
-    const size_t lds = ((size_t)LM_FR * (bins + 1) + (size_t)F * (LM_FR + 1)) * sizeof(float);
+    if (mel_w_count > LM_MW_MAX || mel_w_count < 0) { set_error("logmel_from_stft: %d packed filter weights (max %d)", mel_w_count, LM_MW_MAX); return PBSED_E_UNSUPPORTED; }
+    const size_t lds = ((size_t)LM_FR * (bins + 1) + (size_t)F * (LM_FR + 1) + LM_MW_MAX) * sizeof(float);
     if (lds > 160 * 1024) { set_error("logmel_from_stft: %d bins x %d filters need %zu B of LDS", bins, F, lds); return PBSED_E_UNSUPPORTED; }
     LogmelStftArgs a{stft, mel_start, mel_len, mel_off, mel_w, mean, inv_std, seq_len_frames, out, stats, B, T, F, bins, eps, clampv, mel_pts};
     PBSED_DYN_LDS_ONCE(logmel_from_stft_kernel, lds);

@@ -610,7 +610,7 @@ def logmel_fwd(wav, tables, mean, inv_std, n_frames, seq_len=None, eps=1e-18, cl
     b, n = wav.shape
     out = torch.empty((b, 1, tables.n_filters, n_frames), device=wav.device, dtype=torch.float32)
     call('pbsed_logmel_fwd', ptr(wav.contiguous()), b, n, n_frames, ptr(seq_len), ptr(tables.window),
-         ptr(tables.twiddle), ptr(tables.start), ptr(tables.len), ptr(tables.off), ptr(tables.w),
+         ptr(tables.twiddle), ptr(tables.start), ptr(tables.len), ptr(tables.off), ptr(tables.w), tables.w.numel(),
          tables.n_filters, ptr(tables.zero if mean is None else mean), ptr(tables.one if inv_std is None else inv_std),
          float(eps), float(clamp if clamp is not None else 3e38), ptr(out), ptr(stats), int(pad_front), ptr(mel_points), stream(),
          nbytes=b * (n * 4 + tables.n_filters * n_frames * 4))
@@ -625,7 +625,7 @@ def logmel_from_stft(stft, tables, mean, inv_std, seq_len=None, eps=1e-18, clamp
     x = stft.to(torch.float32).contiguous()
     out = torch.empty((b, 1, tables.n_filters, t), device=stft.device, dtype=torch.float32)
     call('pbsed_logmel_from_stft', ptr(x), b, t, bins, ptr(seq_len), ptr(tables.start), ptr(tables.len), ptr(tables.off),
-         ptr(tables.w), tables.n_filters, ptr(tables.zero if mean is None else mean),
+         ptr(tables.w), tables.w.numel(), tables.n_filters, ptr(tables.zero if mean is None else mean),
          ptr(tables.one if inv_std is None else inv_std), float(eps), float(clamp if clamp is not None else 3e38),
          ptr(out), ptr(stats), ptr(mel_points), stream(), nbytes=b * t * (bins * 8 + tables.n_filters * 4))
     return out
