@@ -69,6 +69,45 @@ with open(os.path.join(out, f'{tag}_pmc_hbm_traffic.csv'), 'w') as fh:
                     round((2 * fe + wr) * 1024 / 1e6, 2)])
 print('wrote', f'profiles/{tag}_pmc_hbm_traffic.csv')
 
+# SQ / TCC counter passes (collected WITH the persistent GRU scans on): per kernel template, averages per dispatch
+for name, fname in (('prof_sq', 'pmc_sq'), ('prof_tcc', 'pmc_tcc')):
+    files = glob.glob(os.path.join(go, name, '*', '*_counter_collection.csv'))
+    if not files:
+        continue
+    agg = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(files[0])):
+        if 'rocclr' in r['Kernel_Name']:
+            continue
+        key = (r['Kernel_Name'][:110], r['Grid_Size'], r['Workgroup_Size'])
+        agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
+        agg[key]['dur_us'].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    counters = sorted({c for v in agg.values() for c in v if c != 'dur_us'})
+    with open(os.path.join(out, f'{tag}_{fname}.csv'), 'w') as fh:
+        w = csv.writer(fh)
+        extra = (['wait_any_frac', 'wait_inst_frac', 'active_frac'] if fname == 'pmc_sq' else ['l2_hit_rate'])
+        w.writerow(['kernel', 'grid_threads', 'wg', 'dispatches', 'avg_us(pmc run)'] + counters + extra)
+        for (k, g, wg), v in sorted(agg.items(), key=lambda kv: -sum(kv[1]['dur_us'])):
+            n = len(v[counters[0]])
+            if sum(v['dur_us']) / max(len(counters), 1) < 200.:
+                continue
+            avg = {c: sum(v[c]) / max(len(v[c]), 1) for c in counters}
+            if fname == 'pmc_sq':
+                wc = max(avg.get('SQ_WAVE_CYCLES', 0.), 1.)
+                ex = [round(avg.get('SQ_WAIT_ANY', 0.) / wc, 3), round(avg.get('SQ_WAIT_INST_ANY', 0.) / wc, 3),
+                      round(avg.get('SQ_ACTIVE_INST_ANY', 0.) / wc, 3)]
+            else:
+                ex = [round(avg.get('TCC_HIT_sum', 0.) / max(avg.get('TCC_HIT_sum', 0.) + avg.get('TCC_MISS_sum', 0.), 1.), 3)]
+            w.writerow([k, g, wg, n, round(sum(v['dur_us']) / len(v['dur_us']), 1)] + [round(avg[c], 1) for c in counters] + ex)
+    print('wrote', f'profiles/{tag}_{fname}.csv')
+for cfg in ('c3', 'c5'):
+    stc = glob.glob(os.path.join(go, f'prof_stats_{cfg}', '*', '*_kernel_stats.csv'))
+    if stc:
+        shutil.copy(stc[0], os.path.join(out, f'{tag}_{cfg}_kernel_stats.csv'))
+        print('wrote', f'profiles/{tag}_{cfg}_kernel_stats.csv')
+    bjc = os.path.join(go, f'prof_stats_bench_{cfg}.json')
+    if os.path.exists(bjc):
+        shutil.copy(bjc, os.path.join(out, f'{tag}_{cfg}_bench_under_rocprof.json'))
+
 # HBM bytes per launch of the layers bench.py may name as its roofline kernel (bench.py copies the value into
 # `roofline.traffic`); keyed by bench.py's "<entry point> <layer tag>", matched to (kernel template, 3-D grid).
 import json

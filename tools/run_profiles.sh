@@ -1,9 +1,10 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for profiles/ on the GPU box (run through gpurun from the repo root):
-#   1. kernel trace + stats of the default bench command (per-kernel durations)
-#   2./3. PMC passes (FETCH_SIZE, WRITE_SIZE) in their own runs, counters only (MI355X_MICROARCH.md HBM section).
-# The PMC passes use the launch-per-step GRU scans: counter collection serialises dispatches and the persistent
-# scans are not what the HBM-traffic numbers are for.
+#   1. kernel trace + stats of the default bench command (c2) and of --config c3 / c5 (per-kernel durations)
+#   2./3. PMC passes (FETCH_SIZE, WRITE_SIZE) of c2 in their own runs, counters only (MI355X_MICROARCH.md HBM section);
+#         these use the launch-per-step GRU scans (the HBM numbers are for the conv kernels).
+#   4. SQ / TCC counters WITH the persistent scans on (what the scan kernels themselves do): bounded by `timeout`, the
+#      scans' own bounded spin turns a scan that cannot make progress under counter collection into an error, not a hang.
 set -x
 REPO=$(pwd)
 export TMPDIR=/tmp
@@ -11,9 +12,19 @@ mkdir -p gpurun_out
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_stats -- \
     python $REPO/bench.py --no-cpu-baseline --steps 5 --warmup 3 > $REPO/gpurun_out/prof_stats_bench.json 2> $REPO/gpurun_out/prof_stats.log
+for cfg in c3 c5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_stats_$cfg -- \
+      python $REPO/bench.py --config $cfg --no-cpu-baseline --steps 5 --warmup 3 > $REPO/gpurun_out/prof_stats_bench_$cfg.json 2> $REPO/gpurun_out/prof_stats_$cfg.log
+done
 PBSED_GRU_PERSIST=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $REPO/gpurun_out/prof_fetch -- \
     python $REPO/bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $REPO/gpurun_out/prof_fetch.log
 PBSED_GRU_PERSIST=0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $REPO/gpurun_out/prof_write -- \
     python $REPO/bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $REPO/gpurun_out/prof_write.log
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv \
+    -d $REPO/gpurun_out/prof_sq -- python $REPO/bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $REPO/gpurun_out/prof_sq.log
+echo "sq pass rc=$?" >> $REPO/gpurun_out/prof_sq.log
+timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv \
+    -d $REPO/gpurun_out/prof_tcc -- python $REPO/bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $REPO/gpurun_out/prof_tcc.log
+echo "tcc pass rc=$?" >> $REPO/gpurun_out/prof_tcc.log
 cd $REPO
-ls gpurun_out/prof_stats/* | head; tail -2 gpurun_out/prof_stats.log
+ls gpurun_out/prof_stats/* | head; tail -2 gpurun_out/prof_stats.log; tail -3 gpurun_out/prof_sq.log; tail -3 gpurun_out/prof_tcc.log
