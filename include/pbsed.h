@@ -167,7 +167,8 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
 /* Persistent forward scan (one launch for the whole scan; needs nchains*(2*nlayers-1)*(H/16)*ceil(B/16) <= #CUs
  * co-resident workgroups) exchanging h_t (and the projected inputs of layers > 0) between workgroups as 4-byte words
  * = the fp32 value with its mantissa LSB replaced by the call's parity bit (the exchanged quantity is defined as the
- * truncated value).  granules: device uint32 workspace of nchains*T*B*H*(nlayers + 3*(nlayers-1)) words, ZERO before
+ * truncated value).  granules: device uint32 workspace of nchains*T*Bp*H*(nlayers + 3*(nlayers-1)) words (Bp = B rounded up to 16:
+ * the exchanged states are stored as [T][batch tile][H/16][16 rows][16 units] tiles), ZERO before
  * its first use; epoch: odd on the first use of a workspace, parity flipped on every further call with it.
  * err_flag: device uint32, non-zero afterwards if a hand-off timed out (re-zero the workspace then).
  * `save` rows are [5][H] (factors of dh_t, see gru_stack.hip). */

@@ -293,10 +293,12 @@ struct PollPacer {
 };
 
 // One wave polls the words of its K range [k0, k0 + 16*NL) for 16 batch rows with 16-byte write-through-visible
-// (sc1) buffer loads: lane (lq, lr) reads, per load n, the four words k0 + n*16 + lq*4 + {0..3} of row lr, so one
-// instruction fetches whole 64-byte row segments and nothing is fetched twice.  All loads of a step are issued
+// (sc1) buffer loads: lane (lq, lr) reads, per load n, the four words k0 + n*16 + lq*4 + {0..3} of row lr.  The exchange
+// arrays are TILE-MAJOR - [T][batch tile][H/16 producers][16 rows][16 units] - so one load instruction covers exactly the
+// contiguous 1 KB tile one producer block published (8 whole 128-byte lines instead of 16 half lines of a row-major
+// [T][B][H] array) and a producer's 256 publishing threads write one contiguous 1 KB; nothing is fetched twice.  All loads of a step are issued
 // before any tag is looked at (one fabric round trip per step); out[n] = the four (tag-cleared) values.
-template <int NL>
+template <int NL, int STEP = 1024>
 __device__ __forceinline__ int poll_batch(float4 (&out)[NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned parity,
                                           bool valid, unsigned* err_flag) {
     u32x4_t q[NL];
@@ -307,7 +309,7 @@ __device__ __forceinline__ int poll_batch(float4 (&out)[NL], __amdgpu_buffer_rsr
         bool ok = true;
         if (valid) {
 #pragma unroll
-            for (int n = 0; n < NL; ++n) q[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + n * 64, 0, /*aux = sc1*/ 16);
+            for (int n = 0; n < NL; ++n) q[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + n * STEP, 0, /*aux = sc1*/ 16);
             unsigned all1 = 1u, any1 = 0u;
 #pragma unroll
             for (int n = 0; n < NL; ++n) {
@@ -411,12 +413,14 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
     const bool is_mfma = wave >= 0;               // GW: waves 0..3 of the block only run the gate phase
     const int j0 = role.bx * 16, b0 = role.by * 16, B = a.B;
     const bool rev = a.reverse[chain] != 0;
-    const size_t per_cl = (size_t)a.T * B * H;
+    const int Bp = (B + 15) / 16 * 16;                       // the tile-major h array holds whole batch tiles
+    const size_t per_cl = (size_t)a.T * Bp * H, per_cl_b = (size_t)a.T * B * H;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(gran_h_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 4), 0x00020000);
     const unsigned parity = epoch & 1u;
-    gu32* g_own = (gu32*)gran_h_ + (size_t)(chain * a.nlayers + layer) * per_cl;                       // ring: h_t
-    gu32* g_gi = (gu32*)gran_gi_ + (size_t)(chain * (a.nlayers - 1) + (layer > 0 ? layer - 1 : 0)) * per_cl * 3;  // [T][B][3][H]
+    // ring: h_t, tile-major; this block's tile of step t starts at g_own + t * Bp * H
+    gu32* g_own = (gu32*)gran_h_ + (size_t)(chain * a.nlayers + layer) * per_cl + ((size_t)role.by * (H / 16) + role.bx) * 256;
+    gu32* g_gi = (gu32*)gran_gi_ + (size_t)(chain * (a.nlayers - 1) + (layer > 0 ? layer - 1 : 0)) * per_cl_b * 3;  // [T][B][3][H]
     const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
     const bool bv = tid < 256 && b < B;
     const bool rowv = (b0 + lr) < B;
@@ -436,7 +440,8 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
     }
     // a projection reads h_t of the layer below, a ring its own h_{t-1}
     const unsigned cl_src = chain * a.nlayers + (is_proj ? layer - 1 : layer);
-    const unsigned voff0 = (unsigned)((((size_t)cl_src * a.T * B + b0 + lr) * H + k0 + lq * 4) * 4);
+    const unsigned voff0 = (unsigned)(((size_t)cl_src * per_cl + (size_t)role.by * 16 * H + (k0 / 16) * 256 + lr * 16 + lq * 4) * 4);
+    const unsigned step_t = (unsigned)(Bp * H * 4);           // bytes per time step of one (chain, layer)
     float h_reg = 0.f;
     const PollPacer pacer{(GW || threadIdx.x >= 256) ? a.poll_delay : a.poll_delay_gate};
     if (tid == 0) s_err = 0;
@@ -464,7 +469,7 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
         const bool contract = (is_proj || has_prev) && is_mfma;
         if (contract) {
             pacer.wait();
-            poll_batch<NL>(x, rsrc, voff0 + (unsigned)(is_proj ? t : tp) * (unsigned)(B * H * 4), parity, rowv, err_flag);
+            poll_batch<NL>(x, rsrc, voff0 + (unsigned)(is_proj ? t : tp) * step_t, parity, rowv, err_flag);
         }
         // requests issued behind the poll (loads return in order, anything older would hold the poll back):
         // next step's input projection (first layer) / this step's projected input granules (other rings)
@@ -522,7 +527,7 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
                 const float hp = h_reg;
                 const float h = tag_clear((t < sl) ? (1.f - z) * n + z * hp : 0.f);    // the state IS the truncated value
                 h_reg = h;
-                publish(g_own + tb * H + j, h, parity);
+                publish(g_own + (size_t)t * Bp * H + bb * 16 + u, h, parity);
                 L.hs[tb * H + j] = h;
                 if (L.save) {
                     // what BPTT multiplies dh_t with: d(r,z,n pre-activations)/dh, d(gh_n)/dh and z (granule save format)
@@ -572,12 +577,13 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
     const bool is_mfma = wave >= 0;
     const int j0 = role.bx * 16, b0 = role.by * 16, B = a.B;
     const bool rev = a.reverse[chain] != 0;
-    const size_t per_cl = (size_t)a.T * B * H;
+    const int Bp = (B + 15) / 16 * 16;
+    const size_t per_cl = (size_t)a.T * Bp * H, per_cl_b = (size_t)a.T * B * H;     // dh: tile-major (poll_batch); dy: [T][B][H]
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(gran_dh_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 4), 0x00020000);
     const unsigned parity = epoch & 1u;
-    gu32* g_own = (gu32*)gran_dh_ + (size_t)(chain * a.nlayers + layer) * per_cl;
-    gu32* g_dy = (gu32*)gran_dy_ + (size_t)(chain * (a.nlayers - 1) + (layer < top ? layer : 0)) * per_cl;
+    gu32* g_own = (gu32*)gran_dh_ + (size_t)(chain * a.nlayers + layer) * per_cl + ((size_t)role.by * (H / 16) + role.bx) * 256;
+    gu32* g_dy = (gu32*)gran_dy_ + (size_t)(chain * (a.nlayers - 1) + (layer < top ? layer : 0)) * per_cl_b;
     const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
     const bool bv = tid < 256 && b < B;
     const bool rowv = (b0 + lr) < B;
@@ -595,7 +601,8 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
             for (int g = 0; g < 3; ++g) wv[n][g] = *reinterpret_cast<const float4*>(W + g * H + n * 16);
     }
     const unsigned cl_src = chain * a.nlayers + (is_proj ? layer + 1 : layer);
-    const unsigned voff0 = (unsigned)((((size_t)cl_src * a.T * B + b0 + lr) * H + k0 + lq * 4) * 4);
+    const unsigned voff0 = (unsigned)(((size_t)cl_src * per_cl + (size_t)role.by * 16 * H + (k0 / 16) * 256 + lr * 16 + lq * 4) * 4);
+    const unsigned step_t = (unsigned)(Bp * H * 4);
     float dhz_prev = 0.f;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const PollPacer pacer{(GW || threadIdx.x >= 256) ? a.poll_delay : a.poll_delay_gate};
@@ -651,7 +658,7 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         const bool contract = (is_proj || has_next) && is_mfma;
         if (contract) {
             pacer.wait();
-            poll_batch<NL>(dh4, rsrc, voff0 + (unsigned)(is_proj ? t : tn) * (unsigned)(B * H * 4), parity, rowv, err_flag);
+            poll_batch<NL>(dh4, rsrc, voff0 + (unsigned)(is_proj ? t : tn) * step_t, parity, rowv, err_flag);
         }
         unsigned qd[1] = {0};                         // behind the poll: loads return in order
         if (!is_proj && layer < top && bv)
@@ -700,7 +707,7 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
                     dhzv = dh * z;
                 }
                 dhz_prev = dhzv;
-                publish(g_own + tb * H + j, dh, parity);
+                publish(g_own + (size_t)t * Bp * H + bb * 16 + u, dh, parity);
                 float* dgi = L.dgi + tb * G;
                 float* dgh = L.dgh + tb * G;
                 dgi[j] = dr; dgi[H + j] = dz; dgi[2 * H + j] = dn;
@@ -803,7 +810,7 @@ static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid) {
 
 // PBSED_GRU_POLL_DELAYS="fwd,fwd_gate,bwd,bwd_gate" overrides the measured defaults (PollPacer).
 static void granule_poll_delays(bool bwd, GruStackArgs& a) {
-    static int d[4] = {26, 6, 20, 0};
+    static int d[4] = {25, 6, 16, 0};     // measured with the tile-major exchange arrays (tools/sweep_poll_delays.sh): forward 23 is over a cliff (1.20 ms, 22: 1.44), 24 1.12, 25 1.13, 28 1.22 ms
     static const bool parsed = [] {
         if (const char* e = getenv("PBSED_GRU_POLL_DELAYS")) sscanf(e, "%d,%d,%d,%d", &d[0], &d[1], &d[2], &d[3]);
         return true;
@@ -821,7 +828,7 @@ static bool granule_ring_xcd(bool bwd) {
 }
 
 // Granule-exchange persistent forward scan (see gru_granule_fwd_kernel).  granules: device uint32 workspace of
-// nchains*T*B*H*(nlayers + 3*(nlayers-1)) words (h_t of every layer, then the projected inputs of layers > 0) that
+// nchains*T*Bp*H*(nlayers + 3*(nlayers-1)) words, Bp = B rounded up to 16 (h_t of every layer, then the projected inputs of layers > 0) that
 // must be ZERO before its first use; `epoch` must be odd on the first use of a workspace and change parity with
 // every call that uses it (the words of the previous call then never match); same T, B, H for the life of a
 // workspace.  err_flag: device uint32 (0 on entry; non-zero after a hand-off timed out: re-zero the workspace).
@@ -832,7 +839,8 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
                                 void* stream) {
     if (int e = stack_check(nchains, nlayers, B, H, T)) return e;
     if (epoch == 0 || !granules || !err_flag) { set_error("gru_stack_fwd_granule: need workspace and epoch != 0"); return PBSED_E_ARG; }
-    if ((size_t)nchains * nlayers * T * B * H * 4 >= (1ull << 32)) { set_error("gru_stack_fwd_granule: workspace over 4 GiB"); return PBSED_E_ARG; }
+    const size_t Bp = (size_t)(B + 15) / 16 * 16;            // the exchanged states are stored in whole 16-row batch tiles
+    if ((size_t)nchains * nlayers * T * Bp * H * 4 >= (1ull << 32)) { set_error("gru_stack_fwd_granule: workspace over 4 GiB"); return PBSED_E_ARG; }
     GruStackArgs a{};
     for (int c = 0; c < nchains; ++c) {
         a.reverse[c] = reverse[c];
@@ -849,7 +857,7 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
     granule_poll_delays(false, a);
     dim3 grid(H / 16, (B + 15) / 16, ngroups);
     if (granule_ring_xcd(false)) granule_xcd_grid(a, H, &grid);
-    unsigned* gran_gi = granules + (size_t)nchains * nlayers * T * B * H;
+    unsigned* gran_gi = granules + (size_t)nchains * nlayers * T * Bp * H;
     hipStream_t s = (hipStream_t)stream;
     // PBSED_GRU_GW: bit 0 forward / bit 1 BPTT scan with dedicated gate waves (default both; 1.35 -> 1.21 ms and
     // 1.65 -> 1.49 ms at B = 32, H = 256, T = 500)
@@ -874,7 +882,7 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
     return check_launch("gru_stack_fwd_granule");
 }
 
-// Granule-exchange persistent BPTT.  granules: device uint32 workspace of nchains*T*B*H*(2*nlayers-1) words
+// Granule-exchange persistent BPTT.  granules: device uint32 workspace of nchains*T*Bp*H*(2*nlayers-1) words (Bp as above)
 // (dh_t of every layer, then dy_t of the layers below the top), zero before first use, epoch parity as above.
 int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
                                 const float* const* hs, const float* const* save, const float* const* dy_top,
@@ -883,7 +891,8 @@ int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_
                                 void* stream) {
     if (int e = stack_check(nchains, nlayers, B, H, T)) return e;
     if (epoch == 0 || !granules || !err_flag) { set_error("gru_stack_bwd_granule: need workspace and epoch != 0"); return PBSED_E_ARG; }
-    if ((size_t)nchains * nlayers * T * B * H * 4 >= (1ull << 32)) { set_error("gru_stack_bwd_granule: workspace over 4 GiB"); return PBSED_E_ARG; }
+    const size_t Bp = (size_t)(B + 15) / 16 * 16;
+    if ((size_t)nchains * nlayers * T * Bp * H * 4 >= (1ull << 32)) { set_error("gru_stack_bwd_granule: workspace over 4 GiB"); return PBSED_E_ARG; }
     GruStackArgs a{};
     for (int c = 0; c < nchains; ++c) {
         a.reverse[c] = reverse[c];
@@ -901,7 +910,7 @@ int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_
     granule_poll_delays(true, a);
     dim3 grid(H / 16, (B + 15) / 16, ngroups);
     if (granule_ring_xcd(true)) granule_xcd_grid(a, H, &grid);
-    unsigned* gran_dy = granules + (size_t)nchains * nlayers * T * B * H;
+    unsigned* gran_dy = granules + (size_t)nchains * nlayers * T * Bp * H;
     hipStream_t s = (hipStream_t)stream;
     // PBSED_GRU_GW: bit 0 forward / bit 1 BPTT scan with dedicated gate waves (default both; 1.35 -> 1.21 ms and
     // 1.65 -> 1.49 ms at B = 32, H = 256, T = 500)

@@ -430,7 +430,7 @@ def _granule_scan(nch, nlayers, b, h, t, device=None):
     if dev not in _CU_COUNT:
         _CU_COUNT[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
     return (os.environ.get('PBSED_GRU_PERSIST', '2') == '2' and blocks <= _CU_COUNT[dev] * 7 // 8
-            and nch * nlayers * t * b * h * 4 < 2 ** 32)
+            and nch * nlayers * t * ((b + 15) // 16 * 16) * h * 4 < 2 ** 32)
 
 
 def _per_chain(nch, nlayers, b, h, t, dev):
@@ -464,7 +464,7 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
         key = (str(dev), n, t, b, h)
         gw = _GRANULE_WS.get(key)
         if gw is None:
-            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * b * h * (nlayers + 3 * (nlayers - 1)), dtype=torch.int32, device=dev), 0]
+            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (nlayers + 3 * (nlayers - 1)), dtype=torch.int32, device=dev), 0]
         ws = _gru_err_flag(dev)
         call('pbsed_gru_stack_fwd_granule', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih),
              _lib.ptr_array(b_ih), _lib.ptr_array(w_hh), _lib.ptr_array(b_hh), _lib.ptr_array(hs),
@@ -499,7 +499,7 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
         key = (str(dev), 'bwd', n, t, b, h)
         gw = _GRANULE_WS.get(key)
         if gw is None:
-            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * b * h * (2 * nlayers - 1), dtype=torch.int32, device=dev), 0]
+            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (2 * nlayers - 1), dtype=torch.int32, device=dev), 0]
         ws = _gru_err_flag(dev)
         call('pbsed_gru_stack_bwd_granule', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t),
              _lib.ptr_array(hs), _lib.ptr_array(save), _lib.ptr_array(dy_top), _lib.ptr_array(dgi), _lib.ptr_array(dgh),
