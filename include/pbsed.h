@@ -102,7 +102,8 @@ typedef struct {
     const float* src;       /* [Cout, Cin, KH, KW] weights */
     float* dst;             /* packed copy (sizes from pbsed_conv_pack_dims / pbsed_conv_pack_dims_wino) */
     int Cout, Cin, KH, KW, InP, OutP;
-    int mode;               /* 0 / 1: direct forward / data-gradient layout, 2 / 3: Winograd forward / data-gradient */
+    int mode;               /* 0 / 1: direct forward / data-gradient layout, 2 / 3: Winograd forward / data-gradient,
+                             * 4 / 5: bf16 (nsplit 1) forward / data-gradient layout of pbsed_pack_conv_weights_bf16 (dst: uint16) */
     int pad_;
 } pbsed_pack_desc;
 int pbsed_pack_conv_weights_batched(const pbsed_pack_desc* descs /*device*/, int n, void* stream);

@@ -24,14 +24,37 @@ struct PackDesc {
     const float* src;
     float* dst;
     int Cout, Cin, KH, KW, InP, OutP;
-    int mode;      // 0/1: direct forward / data-gradient layout, 2/3: Winograd forward / data-gradient layout
+    int mode;      // 0/1: direct forward / data-gradient layout, 2/3: Winograd forward / data-gradient layout,
+                   // 4/5: bf16 [tap][OutP][InP] forward / data-gradient layout (dst holds uint16)
     int pad_;
 };
 
+__device__ __forceinline__ unsigned short f2bf_rne(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
 __global__ void pack_batched_kernel(const PackDesc* __restrict__ descs) {
     const PackDesc d = descs[blockIdx.y];
-    const bool wino = d.mode >= 2;
     const int KK = d.KH * d.KW;
+    if (d.mode >= 4) {                                   // csrc/conv_bf16.hip layout: [tap][OutP][InP], input channels innermost
+        const size_t total = (size_t)KK * d.OutP * d.InP;
+        unsigned short* dst = reinterpret_cast<unsigned short*>(d.dst);
+        const int dgrad = d.mode & 1;
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const int ci = i % d.InP, co = (i / d.InP) % d.OutP, kk = i / ((size_t)d.InP * d.OutP);
+            float v = 0.f;
+            if (!dgrad) {
+                if (co < d.Cout && ci < d.Cin) v = d.src[((size_t)co * d.Cin + ci) * KK + kk];
+            } else if (co < d.Cin && ci < d.Cout) {
+                v = d.src[((size_t)ci * d.Cin + co) * KK + (KK - 1 - kk)];
+            }
+            dst[i] = f2bf_rne(v);
+        }
+        return;
+    }
+    const bool wino = d.mode >= 2;
     const size_t total = (size_t)(wino ? 18 : KK) * d.InP * d.OutP;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
         d.dst[i] = wino ? pack_wino_elem(d.src, i, d.Cout, d.Cin, d.InP, d.OutP, d.mode & 1)

@@ -481,3 +481,32 @@ def test_fbcrnn_finetuning_with_frozen_layers_and_norm_statistics():
     for name, buf in model.named_buffers():
         if 'running' in name:
             rel_close(buf, refb[name], 1e-4, name)
+
+
+def test_bf16_weight_copies_follow_the_optimiser():
+    """conv_precision='bf16': the bf16 weight copies are refreshed by the same one-launch re-pack as the fp32 / Winograd
+    ones after the fused Adam changed the parameters in place - after two steps every registered copy must equal a fresh
+    pack of the current parameter (a stale copy would silently train on old weights)."""
+    import ctypes as C
+    from pb_sed_amd import _lib, ops
+    from pb_sed_amd.models import strong_label
+    from pb_sed_amd.trainer import Trainer
+    torch.manual_seed(0)
+    net = dict(out_channels_2d=[16, 32, 64], pool_sizes_2d=[1, (2, 1), (2, 1)], kernel_size_2d=3,
+               out_channels_1d=[64, 64], kernel_size_1d=[3, 1])
+    model = strong_label.CRNN.build(num_events=10, hidden_size=64, num_layers=1, net=net, tag_conditioning=True).to(DEV)
+    model.conv_precision = 'bf16'
+    trainer = Trainer(model, lr=1e-2)
+    wav, seq, weak, strong, t = synth_batch(4, 16000, 10, seed=3)
+    batch = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV), 'strong_targets': strong.to(DEV),
+             'tag_condition': (weak > .99).float().to(DEV)}
+    for _ in range(2):
+        trainer.step(batch)
+    entries = [e for e in ops._PACKS.values() if e.mode in (4, 5) and e.owner() is not None]
+    assert len(entries) >= 4
+    for e in entries:
+        cout, cin, kh, kw, inp, outp = e.dims
+        fresh = torch.empty_like(e.dst)
+        w = e.owner().detach().reshape(cout, cin, kh, kw).contiguous()
+        _lib.call('pbsed_pack_conv_weights_bf16', w.data_ptr(), fresh.data_ptr(), cout, cin, kh, kw, e.mode & 1, 1, _lib.stream())
+        assert torch.equal(fresh, e.dst), (e.dims, e.mode)
