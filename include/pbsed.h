@@ -93,6 +93,10 @@ int pbsed_conv_bwd_data(const float* g, const float* wd_packed, const unsigned c
 int pbsed_conv_bwd_weight(const float* x, const float* scale, const float* shift, int relu,
                           const int* seq_len, const float* g, const unsigned char* unpool_idx, float* dw,
                           float* db, int B, int Cin, int Cout, int F, int T, int KH, int KW, void* stream);
+/* bf16-MFMA operands (rounded while staged), fp32 accumulation / gradients; < 32 channels: the fp32 kernels. */
+int pbsed_conv_bwd_weight_bf16(const float* x, const float* scale, const float* shift, int relu,
+                          const int* seq_len, const float* g, const unsigned char* unpool_idx, float* dw,
+                          float* db, int B, int Cin, int Cout, int F, int T, int KH, int KW, void* stream);
 
 /* bf16-MFMA variants (same contracts; activations stay fp32 in HBM, operands are converted while staging, fp32
  * accumulate).  nsplit = 1: plain bf16 compute (BASELINE.json config 3).  nsplit = 3: exact 3-way bf16 split of both

@@ -37,6 +37,7 @@ SIGNATURES = {
     'pbsed_conv_fwd_bf16': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, I, I, I, _v],
     'pbsed_conv_bwd_data_bf16': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, _v, I, I, I, I, I, I, I, I, _v],
     'pbsed_conv_bwd_weight': [_v, _v, _v, I, _v, _v, _v, _v, _v, I, I, I, I, I, I, I, _v],
+    'pbsed_conv_bwd_weight_bf16': [_v, _v, _v, I, _v, _v, _v, _v, _v, I, I, I, I, I, I, I, _v],
     'pbsed_bn_finalize': [_v, F64, _v, _v, F32, F32, _v, _v, _v, _v, _v, _v, I, _v],
     'pbsed_bn_eval_params': [_v, _v, F32, _v, _v, _v, _v, _v, _v, I, _v],
     'pbsed_bn_bwd': [_v, _v, _v, F64, _v, _v, _v, _v, _v, _v, I, I, I, I, _v],

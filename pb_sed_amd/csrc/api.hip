@@ -83,6 +83,18 @@ int pbsed_conv_bwd_weight(const float* x, const float* scale, const float* shift
     return conv_wgrad_launch(a, KH, KW, (hipStream_t)stream);
 }
 
+// Same contract with bf16-MFMA operands (x after its prologue and dY are rounded to bf16 while staged; products are
+// accumulated, reduced and returned in fp32).  Layers with fewer than 32 input or output channels run the fp32 kernels.
+int pbsed_conv_bwd_weight_bf16(const float* x, const float* scale, const float* shift, int relu,
+                               const int* seq_len, const float* g, const unsigned char* unpool_idx, float* dw,
+                               float* db, int B, int Cin, int Cout, int F, int T, int KH, int KW, void* stream) {
+    ConvWgradArgs a{};
+    a.x = x; a.scale = scale; a.shift = shift; a.relu = relu; a.seq_len = seq_len; a.g = g;
+    a.unpool_idx = unpool_idx; a.dw = dw; a.db = db;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.F = F; a.T = T; a.bf16 = 1;
+    return conv_wgrad_launch(a, KH, KW, (hipStream_t)stream);
+}
+
 int pbsed_memset_async(void* p, int value, size_t bytes, void* stream) {
     hipError_t e = hipMemsetAsync(p, value, bytes, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return PBSED_E_HIP; }

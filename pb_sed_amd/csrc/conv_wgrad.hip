@@ -586,12 +586,270 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(ConvWgradArgs a
     }
 }
 
+
+// ============================================================================================
+// Weight gradient on bf16 MFMA (v_mfma_f32_16x16x32_bf16) - the compute dtype of BASELINE.json config 3.
+// dW[cout][cin][kh][kw] = sum over (b, f, t) of dY[b][cout][f][t] * prologue(x)[b][cin][f+kh-1][t+kw-1]:
+// M = cout (A = dY), N = cin (B = x), K = 32 CONSECUTIVE t of one row per MFMA.  With time as the contraction index
+// both operands are read the way they lie in memory (T innermost) - no transposition anywhere: the tiles are staged as
+// bf16 [channel][row][t] images and a lane's 8 k-values are one aligned 16-byte LDS read.  The kw = 0 / 2 operands are
+// the centre operand shifted by one element: built in registers from the centre read plus the two neighbouring
+// elements (five v_alignbit per row), so the x tile is stored once.  Block = 64 cout x 32 cin, wave = (16 cin, 32 cout),
+// all KH*KW taps in its accumulators; loader / chunk walk / slotted LDS-transposed atomic reduction as conv_wgrad_kernel
+// (fp32 accumulation, fp32 gradients).
+// ============================================================================================
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned wg_pack(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(wg_f32x2{lo, hi}, wg_bf16x2));
+}
+__device__ __forceinline__ f32x4 wg_mfma(u32x4_t a, u32x4_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_bf16x8, a), __builtin_bit_cast(wg_bf16x8, b), c, 0, 0, 0);
+}
+constexpr int pad8mod64(int n) { return ((n + 55) / 64) * 64 + 8; }      // halfs: plane stride = 16 bytes mod 128
+
+template <int KH, int KW, int MH>
+struct WgradB16Cfg {
+    // MH groups of 32 output channels per block (two waves each: the two 16-channel halves of the 32-channel cin tile).
+    // 3x3: MH = 4 (128 cout x 32 cin, 512 threads): the kernel is bound by the bytes a block pulls per MFMA, and the
+    // wider cout tile halves the re-reads of x (measured at 64: no faster than the fp32 Winograd kernel).
+    static constexpr int FT = (KH == 3) ? 2 : 1, TT = (KH == 3) ? 64 : 128;
+    static constexpr int KK = KH * KW, NT = MH * 128;
+    static constexpr int COUT_T = MH * 32, CIN_T = 32;
+    static constexpr int HALO = (KW > 1) ? 8 : 0;                          // elements; keeps the centre read 16-byte aligned
+    static constexpr int ROWS = FT + KH - 1, ROW = TT + 2 * HALO, QR = ROW / 4;
+    static constexpr int PLANE_Y = pad8mod64(FT * TT), PLANE_A = pad8mod64(ROWS * ROW);    // halfs
+    static constexpr int YQ = COUT_T * FT * (TT / 4), AQ = CIN_T * ROWS * QR;
+    static constexpr int Y_PER_T = (YQ + NT - 1) / NT, A_PER_T = (AQ + NT - 1) / NT;
+    static constexpr int OUT_ROW = CIN_T * KK + 1;
+    static constexpr int OUT_ROWS = 64;                                    // the LDS transpose of the result runs 64 cout rows at a time
+    static constexpr int LDS_FLOATS = cmax((COUT_T * PLANE_Y + CIN_T * PLANE_A) / 2 + 2 * CIN_T, OUT_ROWS * OUT_ROW);
+};
+
+template <int KH, int KW, int MH>
+__global__ __launch_bounds__(MH * 128) void conv_wgrad_bf16_kernel(ConvWgradArgs a) {
+    using C = WgradB16Cfg<KH, KW, MH>;
+    constexpr int FT = C::FT, TT = C::TT, KK = C::KK, NT = C::NT;
+    constexpr int PADH = (KH - 1) / 2, PADW = (KW - 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* dy_s = reinterpret_cast<unsigned short*>(smem);              // [COUT_T][PLANE_Y]
+    unsigned short* a_s = dy_s + C::COUT_T * C::PLANE_Y;                           // [CIN_T][PLANE_A]
+    float* sc_s = reinterpret_cast<float*>(a_s + C::CIN_T * C::PLANE_A);           // [CIN_T] scale, [CIN_T] shift
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = wave & 1, mh = wave >> 1;                                        // cin sub-tile / cout half of this wave
+    const int lq = lane >> 4, lr = lane & 15;
+    const int cin0 = blockIdx.y * C::CIN_T, cout0 = blockIdx.z * C::COUT_T;
+    const int nTt = (a.T + TT - 1) / TT, nFt = (a.F + FT - 1) / FT;
+    const int nChunks = a.B * nFt * nTt;
+    const bool pro = a.scale != nullptr;
+    const bool do_bias = (a.db != nullptr) && (blockIdx.y == 0) && g == 0;
+    const bool unpool = a.unpool_idx != nullptr;
+    const int Fg = unpool ? a.F / 2 : a.F;
+    const bool vec = (a.T & 3) == 0;
+    if (tid < C::CIN_T) {
+        const int cin = cin0 + tid;
+        sc_s[tid] = (pro && cin < a.Cin) ? a.scale[cin] : 0.f;
+        sc_s[C::CIN_T + tid] = (pro && cin < a.Cin) ? a.shift[cin] : 0.f;
+    }
+
+    f32x4 acc[2][KK], accb[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KK; ++i) acc[m][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    u32x4_t ry[C::Y_PER_T], ra[C::A_PER_T];
+    unsigned ryi[C::Y_PER_T];
+    int r_ym[C::Y_PER_T], r_am[C::A_PER_T];
+    constexpr unsigned OOB = 0x20000000u;            // element offset beyond every clip (x 4 = 2^31 bytes)
+    const unsigned gclip = (unsigned)(a.Cout * Fg * a.T), xclip = (unsigned)(a.Cin * a.F * a.T);
+
+    auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
+        const int ct = chunk % nTt, c1 = chunk / nTt, cf = c1 % nFt, b = c1 / nFt;
+        const int t0 = ct * TT, f0 = cf * FT;
+        const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
+        const int tlim = pro ? sl : a.T;
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.g) + (size_t)b * gclip, 0, gclip * 4u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
+            unpool ? const_cast<uint8_t*>(a.unpool_idx) + (size_t)b * gclip : nullptr, 0, unpool ? gclip : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.x) + (size_t)b * xclip, 0, xclip * 4u, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < C::Y_PER_T; ++i) {
+            const int q = tid + i * NT;
+            const int cl = q / (FT * (TT / 4)), rem = q % (FT * (TT / 4));
+            const int fl = rem / (TT / 4), qc = rem % (TT / 4);
+            const int f = f0 + fl, tq = t0 + 4 * qc, cout = cout0 + cl;
+            const bool ok = q < C::YQ && cout < a.Cout && f < a.F && tq < a.T;
+            const unsigned off = ok ? (unsigned)((cout * Fg + (unpool ? (f >> 1) : f)) * a.T + tq) : OOB;
+            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, off * 4u, 0, 0);
+            if (unpool) {
+                if (vec) {
+                    ryi[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, off, 0, 0);
+                } else {
+                    unsigned w = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_i, off + e, 0, 0) << (8 * e);
+                    ryi[i] = w;
+                }
+            }
+            r_ym[i] = (ok ? min(a.T - tq, 4) : 0) | ((f & 1) << 8);
+        }
+#pragma unroll
+        for (int i = 0; i < C::A_PER_T; ++i) {
+            const int q = tid + i * NT;
+            const int cl = q / (C::ROWS * C::QR), rem = q % (C::ROWS * C::QR);
+            const int r = rem / C::QR, qc = rem % C::QR;
+            const int f = f0 - PADH + r, tq = t0 - C::HALO + 4 * qc, cin = cin0 + cl;
+            const bool ok = q < C::AQ && cin < a.Cin && f >= 0 && f < a.F && tq >= 0 && tq < a.T;
+            const unsigned off = ok ? (unsigned)((cin * a.F + f) * a.T + tq) : OOB;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off * 4u, 0, 0);
+            r_am[i] = ok ? min(max(tlim - tq, 0), 4) : 0;
+        }
+    };
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < C::Y_PER_T; ++i) {
+            const int q = tid + i * NT;
+            if (q < C::YQ) {
+                const int cl = q / (FT * (TT / 4)), rem = q % (FT * (TT / 4));
+                float v[4] = {__uint_as_float(ry[i].x), __uint_as_float(ry[i].y), __uint_as_float(ry[i].z), __uint_as_float(ry[i].w)};
+                const int n_ok = r_ym[i] & 7;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = e < n_ok ? v[e] : 0.f;
+                if (unpool) {
+                    const int par = r_ym[i] >> 8;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (int)((ryi[i] >> (8 * e)) & 0xffu) == par ? v[e] : 0.f;
+                }
+                uint2 o;
+                o.x = wg_pack(v[0], v[1]); o.y = wg_pack(v[2], v[3]);
+                *reinterpret_cast<uint2*>(dy_s + cl * C::PLANE_Y + rem * 4) = o;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::A_PER_T; ++i) {
+            const int q = tid + i * NT;
+            if (q < C::AQ) {
+                const int cl = q / (C::ROWS * C::QR), rem = q % (C::ROWS * C::QR);
+                float v[4] = {__uint_as_float(ra[i].x), __uint_as_float(ra[i].y), __uint_as_float(ra[i].z), __uint_as_float(ra[i].w)};
+                if (pro) {
+                    const float sc = sc_s[cl], sh = sc_s[C::CIN_T + cl];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = fmaf(v[e], sc, sh);
+                        if (a.relu) v[e] = fmaxf(v[e], 0.f);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = e < r_am[i] ? v[e] : 0.f;        // zero padding is post-activation
+                uint2 o;
+                o.x = wg_pack(v[0], v[1]); o.y = wg_pack(v[2], v[3]);
+                *reinterpret_cast<uint2*>(a_s + cl * C::PLANE_A + rem * 4) = o;
+            }
+        }
+    };
+
+    const u32x4_t ones = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    int chunk = blockIdx.x;
+    if (chunk < nChunks) load_chunk(chunk);
+    for (; chunk < nChunks; chunk += gridDim.x) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (chunk + (int)gridDim.x < nChunks) load_chunk(chunk + gridDim.x);      // in flight during the MFMAs below
+#pragma unroll
+        for (int fl = 0; fl < FT; ++fl) {
+#pragma unroll
+            for (int ks = 0; ks < TT / 32; ++ks) {
+                u32x4_t af[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    af[m] = *reinterpret_cast<const u32x4_t*>(dy_s + ((mh * 2 + m) * 16 + lr) * C::PLANE_Y + fl * TT + ks * 32 + lq * 8);
+#pragma unroll
+                for (int kh = 0; kh < KH; ++kh) {
+                    const unsigned short* row = a_s + (g * 16 + lr) * C::PLANE_A + (fl + kh) * C::ROW + C::HALO + ks * 32 + lq * 8;
+                    const u32x4_t c = *reinterpret_cast<const u32x4_t*>(row);
+                    if (KW == 1) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) acc[m][kh] = wg_mfma(af[m], c, acc[m][kh]);
+                    } else {
+                        const unsigned xm1 = row[-1], x8 = row[8];
+                        const unsigned s1 = __builtin_amdgcn_alignbit(c.y, c.x, 16), s2 = __builtin_amdgcn_alignbit(c.z, c.y, 16),
+                                       s3 = __builtin_amdgcn_alignbit(c.w, c.z, 16);
+                        const u32x4_t left = u32x4_t{(c.x << 16) | xm1, s1, s2, s3};                    // x[t-1 .. t+6]
+                        const u32x4_t right = u32x4_t{s1, s2, s3, (x8 << 16) | (c.w >> 16)};           // x[t+1 .. t+8]
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            acc[m][kh * KW + 0] = wg_mfma(af[m], left, acc[m][kh * KW + 0]);
+                            acc[m][kh * KW + 1] = wg_mfma(af[m], c, acc[m][kh * KW + 1]);
+                            acc[m][kh * KW + 2] = wg_mfma(af[m], right, acc[m][kh * KW + 2]);
+                        }
+                    }
+                }
+                if (do_bias) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) accb[m] = wg_mfma(af[m], ones, accb[m]);
+                }
+            }
+        }
+    }
+
+    // ---- reduce: transpose the block's partial dW through LDS, then row-contiguous atomics (as conv_wgrad_kernel)
+    __syncthreads();
+    float* out_s = smem;                             // [OUT_ROWS][OUT_ROW]
+    const int ncol = min(C::CIN_T, a.Cin - cin0) * KK;
+    const int slot = a.nslots > 1 ? (int)(blockIdx.x % a.nslots) : 0;
+    float* dwp = a.dw + (size_t)slot * a.slot_w;
+#pragma unroll 1
+    for (int part = 0; part < C::COUT_T / C::OUT_ROWS; ++part) {
+        if (part > 0) __syncthreads();
+        if ((mh * 32) / C::OUT_ROWS == part) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        out_s[((mh * 32) % C::OUT_ROWS + m * 16 + lq * 4 + r) * C::OUT_ROW + (g * 16 + lr) * KK + kk] = acc[m][kk][r];
+        }
+        __syncthreads();
+        for (int row = wave; row < C::OUT_ROWS; row += NT / 64) {
+            const int cout = cout0 + part * C::OUT_ROWS + row;
+            if (cout >= a.Cout) break;
+            float* dst = dwp + ((size_t)cout * a.Cin + cin0) * KK;
+            for (int col = lane; col < ncol; col += 64) atomicAdd(dst + col, out_s[row * C::OUT_ROW + col]);
+        }
+    }
+    if (do_bias && lr == 0) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cout = cout0 + (mh * 2 + m) * 16 + lq * 4 + r;
+                if (cout < a.Cout) atomicAdd(&a.db[(size_t)slot * a.slot_b + cout], accb[m][r]);
+            }
+    }
+}
+
 int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     if (a.unpool_idx && (a.F % 2)) { set_error("conv_wgrad: unpool needs even F"); return PBSED_E_ARG; }
     // the loaders address one clip with 32-bit element offsets (buffer loads; 2^29 elements marks "out of range")
     if ((size_t)a.Cin * a.F * a.T >= (1ull << 28) || (size_t)a.Cout * a.F * a.T >= (1ull << 28)) {
         set_error("conv_wgrad: one clip of x / dy must stay below 1 GiB (Cin=%d Cout=%d F=%d T=%d)", a.Cin, a.Cout, a.F, a.T);
         return PBSED_E_ARG;
+    }
+    if (a.bf16 && a.Cin >= 32 && a.Cout >= 32) {       // bf16-MFMA operands (config 3); few-channel layers stay on the fp32 kernels
+        if (KH == 3 && KW == 3) {
+            if (a.Cout > 64) return launch_wgrad_cfg<WgradB16Cfg<3, 3, 4>>(conv_wgrad_bf16_kernel<3, 3, 4>, a, s);
+            return launch_wgrad_cfg<WgradB16Cfg<3, 3, 2>>(conv_wgrad_bf16_kernel<3, 3, 2>, a, s);
+        }
+        if (KH == 1 && KW == 3) return launch_wgrad_cfg<WgradB16Cfg<1, 3, 2>>(conv_wgrad_bf16_kernel<1, 3, 2>, a, s);
+        if (KH == 1 && KW == 1) return launch_wgrad_cfg<WgradB16Cfg<1, 1, 2>>(conv_wgrad_bf16_kernel<1, 1, 2>, a, s);
     }
     // Configurations measured on MI355X at B=32, T=500: one per channel regime.
     if (KH == 3 && KW == 3) {

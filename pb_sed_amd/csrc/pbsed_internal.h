@@ -39,6 +39,7 @@ struct ConvWgradArgs {
     float* db;              // [Cout] (+=) or null
     int B, Cin, Cout, F, T;
     int relu;
+    int bf16;               // bf16-MFMA operands (fp32 accumulation and gradients) where the shape allows
     int nslots;             // > 1: dw/db point at nslots partial copies (stride slot_w / slot_b floats), block x -> x % nslots
     int slot_w, slot_b;
 };

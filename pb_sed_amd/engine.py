@@ -174,7 +174,7 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
             ops.conv_bwd_weight(x, g, pc, dw, db,
                                 scale=None if st_in is None else st_in.scale,
                                 shift=None if st_in is None else st_in.shift,
-                                relu=True, seq_len=seq_dev, unpool_idx=idx)
+                                relu=True, seq_len=seq_dev, unpool_idx=idx, precision='bf16' if pr == 'bf16' else 'f32')
         if j == 0 and not need_input_grad:
             if on_layer_done is not None:
                 on_layer_done(0)
@@ -370,7 +370,8 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
                         x_tbc[ch.widx] = ops.bct_to_tbc(x_w[ch.widx])
                     _wgrad_job(jobs, dgi[i], x_tbc[ch.widx], 0, _grad(w_ih), _grad(ch.p('bias_ih', l)))
                 else:                                # e.g. 266 = 256 + 10 tag-conditioned inputs: not a float4 multiple
-                    ops.conv_bwd_weight(x_w[ch.widx], dgi_b, pcs[i], _grad(w_ih), _grad(ch.p('bias_ih', l)))
+                    ops.conv_bwd_weight(x_w[ch.widx], dgi_b, pcs[i], _grad(w_ih), _grad(ch.p('bias_ih', l)),
+                                        precision='bf16' if _prec(precision, pcs[i].cin) == 'bf16' else 'f32')
             pr = _prec(precision, pcs[i].cin)
             dx, _ = ops.conv_bwd_data(dgi_b, pcs[i], pcs[i].dgrad(pr), x_w[ch.widx].shape, precision=pr)
             dx_w[ch.widx] = dx if dx_w[ch.widx] is None else dx_w[ch.widx].add_(dx)

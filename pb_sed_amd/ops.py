@@ -258,9 +258,15 @@ def conv_bwd_data(g, pc, wd, x_shape, unpool_idx=None, seq_len=None, bn=None, re
 
 
 def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, seq_len=None,
-                    unpool_idx=None):
-    """dw (+=), db (+=): gradients of the conv parameters (buffers must be pre-zeroed/accumulating)."""
+                    unpool_idx=None, precision='f32'):
+    """dw (+=), db (+=): gradients of the conv parameters (buffers must be pre-zeroed/accumulating).  ``precision``
+    'bf16': bf16-MFMA operands, fp32 accumulation (layers with >= 32 input and output channels)."""
     b, cin, f, t = _dims4(x)
+    if precision == 'bf16' and cin >= 32 and pc.cout >= 32:
+        call('pbsed_conv_bwd_weight_bf16', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(g),
+             ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream(),
+             tag=_conv_tag(b, cin, pc, f, t) + ' bf16', flops=_conv_flops(b, cin, pc, f, t))
+        return
     # the library runs its Winograd-F(4,3) weight-gradient kernel for these shapes (conv_wgrad.hip dispatch)
     wino = pc.kh == 3 and pc.kw == 3 and pc.cout >= 64 and cin >= 16 and os.environ.get('PBSED_WGRAD_WINO', '1') != '0'
     call('pbsed_conv_bwd_weight', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(g),

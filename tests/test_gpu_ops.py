@@ -384,6 +384,65 @@ def test_conv_bf16_mfma_vs_torch(case, precision):
         close(g, xr.grad, name=f'conv_dgrad {precision}', **tol)
 
 
+WGRAD_BF16_CASES = [
+    dict(cin=32, cout=32, f=8, t=70, k=(3, 3), pool=False, pro=True),
+    dict(cin=64, cout=128, f=6, t=133, k=(3, 3), pool=True, pro=True),          # un-pooled dY, odd T (scalar idx loads)
+    dict(cin=40, cout=72, f=4, t=96, k=(3, 3), pool=False, pro=False),          # channel counts off the 32 / 64 tiles
+    dict(cin=128, cout=128, f=4, t=64, k=(3, 3), pool=True, pro=True),
+    dict(cin=64, cout=48, f=1, t=200, k=(1, 3), pool=False, pro=True),
+    dict(cin=96, cout=256, f=1, t=130, k=(1, 1), pool=False, pro=True),
+    dict(cin=266, cout=64, f=1, t=77, k=(1, 1), pool=False, pro=False),
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_BF16_CASES, ids=lambda c: f"{c['cin']}x{c['cout']}k{c['k'][0]}{c['k'][1]}p{int(c['pool'])}{'pro' if c['pro'] else ''}")
+def test_conv_wgrad_bf16_vs_torch(case):
+    """Weight / bias gradient on bf16 MFMA (time as the contraction index, shifted kw operands built in registers):
+    against the float64 reference at the bf16 tolerance, and against the fp32 kernel of the same entry point."""
+    from pb_sed_amd import ops
+    torch.manual_seed(0)
+    b, cin, cout, f, t, k, pool, pro = 3, case['cin'], case['cout'], case['f'], case['t'], case['k'], case['pool'], case['pro']
+    x = torch.randn(b, cin, f, t, dtype=torch.float64)
+    w = (torch.randn(cout, cin, *k, dtype=torch.float64) / np.sqrt(cin * k[0] * k[1])).requires_grad_()
+    bias = torch.randn(cout, dtype=torch.float64).requires_grad_()
+    seq = np.array([t, max(t - 9, 1), max(t // 2, 1)])
+    scale = (torch.rand(cin, dtype=torch.float64) + .5) if pro else None
+    shift = torch.randn(cin, dtype=torch.float64) * .3 if pro else None
+    dx = lambda a: None if a is None else a.float().to(DEV).contiguous()
+    seq_dev = torch.as_tensor(seq, dtype=torch.int32).to(DEV)
+    wd = w.detach().float().to(DEV)
+    pc = ops.PackedConv(wd)
+    xd = dx(x)
+    y_full = _conv_ref(x, w, bias, scale, shift, seq, k, False)          # un-pooled conv output
+    idx = None
+    if pool:
+        # the gradient is routed through the argmax the (fp32) forward pass took: a near-tie decided differently in
+        # float64 would move one position's gradient to the other row (2 % of max |dW| in this size) without either
+        # weight-gradient kernel being wrong
+        _, idx, _ = ops.conv_fwd(xd, pc, pc.fwd(), bias=dx(bias.detach()), scale=dx(scale), shift=dx(shift), relu=True,
+                                 seq_len=seq_dev, pool=True)
+        gy = torch.randn(b, cout, f // 2, t, dtype=torch.float64)
+        rows = torch.arange(f)[None, None, :, None]
+        g_full = gy.repeat_interleave(2, dim=2) * (idx.cpu().long().repeat_interleave(2, dim=2) == rows % 2)
+    else:
+        gy = torch.randn_like(y_full)
+        g_full = gy
+    y_full.backward(g_full)
+    out = {}
+    for precision in ('bf16', 'f32'):
+        dw, db = torch.zeros_like(wd), torch.zeros(cout, device=DEV)
+        ops.conv_bwd_weight(xd, dx(gy), pc, dw, db, scale=dx(scale), shift=dx(shift), relu=True, seq_len=seq_dev,
+                            unpool_idx=idx, precision=precision)
+        out[precision] = (dw, db)
+    scale_w = w.grad.abs().max().item()
+    err = (out['bf16'][0].cpu().double() - w.grad).abs().max().item() / scale_w
+    err32 = (out['f32'][0].cpu().double() - w.grad).abs().max().item() / scale_w
+    assert err32 < 1e-3 and err < 2e-2, (err, err32)                 # bf16 operands: 2^-9 relative rounding, sqrt(N) growth
+    l2 = ((out['bf16'][0].cpu().double() - w.grad).norm() / w.grad.norm()).item()
+    assert l2 < 6e-3, l2
+    close(out['bf16'][1], bias.grad, atol=.25, rtol=2e-2, name='conv_bgrad bf16')      # sums of bf16-rounded dY
+
+
 @pytest.mark.parametrize('t,b,g,k', [(23, 5, 192, 24), (30, 32, 768, 256), (17, 19, 384, 128), (9, 3, 12, 8)])
 def test_gru_wgrad_vs_torch(t, b, g, k):
     """Batched time-major weight/bias gradient GEMM (with the h_{t-1} / h_{t+1} row shift) vs fp64 einsum."""
