@@ -429,6 +429,49 @@ def check_gru_sync():
 _CU_COUNT = {}
 
 
+class ScanWatch:
+    """Slow-down guard of the persistent scans.  They assume one workgroup per CU on <= 7/8 of the device; if something
+    else holds CUs while a scan runs (a collective on another stream, a second process on the device) the scan does not
+    fail - its hand-offs just get slower.  Every ``every``-th scan call is bracketed by events; ``check()`` (called by
+    Trainer.step, no host sync: only completed events are read) compares the newest duration with the running median of
+    its kind and warns when it is more than ``factor`` times slower."""
+
+    def __init__(self, every=16, factor=1.6):
+        self.every, self.factor = every, factor
+        self.calls, self.pending, self.history, self.warned = 0, [], {}, 0
+
+    def bracket(self, kind):
+        self.calls += 1
+        if self.calls % self.every:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.pending.append((kind, e0, e1))
+        return e1
+
+    def check(self):
+        import warnings
+        still = []
+        for kind, e0, e1 in self.pending:
+            if not e1.query():
+                still.append((kind, e0, e1))
+                continue
+            ms = e0.elapsed_time(e1)
+            hist = self.history.setdefault(kind, [])
+            if len(hist) >= 4:
+                med = sorted(hist)[len(hist) // 2]
+                if ms > self.factor * med:
+                    self.warned += 1
+                    warnings.warn(f'persistent GRU scan {kind}: {ms:.2f} ms against a median of {med:.2f} ms - another stream or '
+                                  f'process is holding compute units (PBSED_GRU_PERSIST=0 selects the launch-per-step scans)')
+            hist.append(ms)
+            del hist[:-32]
+        self.pending = still
+
+
+scan_watch = ScanWatch()
+
+
 def _granule_scan(nch, nlayers, b, h, t, device=None):
     """Persistent granule-exchange scans need every workgroup co-resident (one per CU): a ring per (chain, layer)
     plus a projection group per layer boundary, each H/16 x ceil(B/16) blocks, on at most 7/8 of the device's CUs
@@ -474,11 +517,14 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
         if gw is None:
             gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (nlayers + 3 * (nlayers - 1)), dtype=torch.int32, device=dev), 0]
         ws = _gru_err_flag(dev)
+        watch_end = scan_watch.bracket(('fwd', nch, nlayers, b, h, t)) if scan_watch is not None else None
         call('pbsed_gru_stack_fwd_granule', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih),
              _lib.ptr_array(b_ih), _lib.ptr_array(w_hh), _lib.ptr_array(b_hh), _lib.ptr_array(hs),
              _lib.ptr_array(sv) if save else None, _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]),
              gw[1] + 1, ptr(ws), stream(), tag=f'{nch}x{nlayers} B{b} H{h} T{t}',
              flops=2. * nch * (2 * nlayers - 1) * t * b * 3 * h * h)        # recurrent + layer-boundary projection products
+        if watch_end is not None:
+            watch_end.record()
         gw[1] += 1                                   # parity flips per launched call: the previous call's words never match
         return hs, sv
     call('pbsed_gru_stack_fwd', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih), _lib.ptr_array(b_ih),
@@ -509,10 +555,13 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
         if gw is None:
             gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (2 * nlayers - 1), dtype=torch.int32, device=dev), 0]
         ws = _gru_err_flag(dev)
+        watch_end = scan_watch.bracket(('bwd', nch, nlayers, b, h, t)) if scan_watch is not None else None
         call('pbsed_gru_stack_bwd_granule', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t),
              _lib.ptr_array(hs), _lib.ptr_array(save), _lib.ptr_array(dy_top), _lib.ptr_array(dgi), _lib.ptr_array(dgh),
              _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]), gw[1] + 1, ptr(ws), stream(),
              tag=f'{nch}x{nlayers} B{b} H{h} T{t}', flops=2. * nch * (2 * nlayers - 1) * t * b * 3 * h * h)
+        if watch_end is not None:
+            watch_end.record()
         gw[1] += 1
         return dgi, dgh
     dhz = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]

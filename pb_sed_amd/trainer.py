@@ -231,6 +231,8 @@ class Trainer:
             checked = torch.cuda.Event()
             checked.record()
             flags[1] = 0
+        if ops.scan_watch is not None:
+            ops.scan_watch.check()               # completed event pairs only: a scan slowed down by CU contention warns
         self.last_enqueue_s = time.perf_counter() - t_start
         finalize = review.pop('_finalize', None)
         if finalize is not None:

@@ -135,3 +135,21 @@ def test_library_allreduce_world1_and_trainer_sync():
     rev = trainer.step(_to(_batch(4), 'cuda:0'))
     assert np.isfinite(rev['loss'].item())
     trainer.sync.close()
+
+
+def test_scan_watch_flags_a_slowed_down_persistent_scan():
+    """The persistent scans do not fail when something else holds compute units, they get slower; the guard brackets
+    every n-th scan with events and warns when one takes much longer than the median of its kind."""
+    import warnings
+    from pb_sed_amd import ops
+    watch = ops.ScanWatch(every=1, factor=1.6)
+    for i in range(6):                                  # synthetic history through the same code path
+        e1 = watch.bracket(('fwd', 2, 2, 32, 256, 500))
+        torch.cuda._sleep(2_000_000 if i < 5 else 20_000_000)
+        e1.record()
+    torch.cuda.synchronize()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        watch.check()
+    assert watch.warned == 1 and any('holding compute units' in str(w.message) for w in caught)
+    assert not watch.pending
