@@ -86,6 +86,18 @@ int pbsed_conv_fwd(const float* x, const float* w_packed, const float* bias, con
                    const float* shift, int relu, const int* seq_len, float* y, unsigned char* pool_idx,
                    double* stats, int stats_per_cf, int B, int Cin, int Cout, int F, int T, int KH, int KW,
                    int pool, void* stream);
+/* Residual connections ('deep' net_config, pb_sed/experiments/weak_label_crnn/training.py:170-183; padertorch's skip
+ * path restated, parity unpinned).  pbsed_conv_fwd_res: pbsed_conv_fwd whose (biased, pooled) output gets `residual`
+ * [B,Cout,Fo,T] added before the store and before the statistics.  A skip that crosses a (2,1) pool is max-pooled with
+ * pbsed_pool21_fwd (x as n_out row pairs of length T -> y, idx) and its gradient routed back with pbsed_pool21_bwd_add
+ * (dx[argmax row] += g); pbsed_add_inplace: a += b. */
+int pbsed_conv_fwd_res(const float* x, const float* w_packed, const float* bias, const float* scale,
+                       const float* shift, int relu, const int* seq_len, float* y, unsigned char* pool_idx,
+                       double* stats, int stats_per_cf, int B, int Cin, int Cout, int F, int T, int KH, int KW,
+                       int pool, const float* residual, void* stream);
+int pbsed_pool21_fwd(const float* x, float* y, unsigned char* idx, size_t n_out, int T, void* stream);
+int pbsed_pool21_bwd_add(const float* g, const unsigned char* idx, float* dx, size_t n_out, int T, void* stream);
+int pbsed_add_inplace(float* a, const float* b, size_t n, void* stream);
 int pbsed_conv_bwd_data(const float* g, const float* wd_packed, const unsigned char* unpool_idx,
                         const int* seq_len, float* dz, const float* bx, const float* bmean,
                         const float* binvstd, const float* bscale, const float* bshift, int relu,

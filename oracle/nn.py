@@ -162,7 +162,11 @@ class _CNN(nn.Module):
     ndim = None
 
     def __init__(self, in_channels, out_channels, kernel_size, pool_size=1, norm='batch',
-                 eps=1e-3, pre_activation=False, output_layer=True, input_layer=True):
+                 eps=1e-3, pre_activation=False, output_layer=True, input_layer=True, residual_connections=None):
+        """``residual_connections[i] = j``: the input of layer i is added to the input of layer j (the reference's 'deep'
+        net_config, pb_sed/experiments/weak_label_crnn/training.py:170-183).  padertorch's skip path restated - parity
+        unpinned: in between lying max-pools are applied to the skip, then a 1x1 conv (with bias) if the channel counts
+        differ; with pre-activation layers both ends are the raw tensors in front of norm + ReLU."""
         super().__init__()
         n = len(out_channels)
         ks = kernel_size if isinstance(kernel_size, (list, tuple)) else n * [kernel_size]
@@ -180,9 +184,31 @@ class _CNN(nn.Module):
             convs.append(_ConvLayer(self.ndim, cin, cout, ks[i], ps[i], pre, post, eps))
             cin = cout
         self.convs = nn.ModuleList(convs)
+        res = list(residual_connections) if residual_connections is not None else n * [None]
+        self.residual_connections = [r[0] if isinstance(r, (list, tuple)) else r for r in res]
+        cins = [in_channels] + list(out_channels[:-1])
+        self.skip_convs = nn.ModuleDict()
+        for src, dst in enumerate(self.residual_connections):
+            if dst is not None and cins[src] != cins[dst]:
+                conv = (nn.Conv2d if self.ndim == 2 else nn.Conv1d)(cins[src], cins[dst], 1)
+                nn.init.xavier_uniform_(conv.weight)
+                nn.init.zeros_(conv.bias)
+                self.skip_convs[f'{src}_{dst}'] = conv
 
     def forward(self, x, seq_len=None):
-        for conv in self.convs:
+        inputs = []
+        for j, conv in enumerate(self.convs):
+            for src, dst in enumerate(self.residual_connections):
+                if dst == j:
+                    r = inputs[src]
+                    for k in range(src, dst):
+                        if self.convs[k].pool != 1:
+                            r = F.max_pool2d(r, self.convs[k].pool) if self.ndim == 2 else F.max_pool1d(r, self.convs[k].pool)
+                    key = f'{src}_{dst}'
+                    if key in self.skip_convs:
+                        r = self.skip_convs[key](r)
+                    x = x + r
+            inputs.append(x)
             x = conv(x, seq_len)
         return x, seq_len
 

@@ -26,6 +26,10 @@ SIGNATURES = {
     'pbsed_conv_pack_dims': [I, I, I, I, I, _i, _i],
     'pbsed_pack_conv_weights': [_v, _v, I, I, I, I, I, _v],
     'pbsed_conv_fwd': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, I, I, _v],
+    'pbsed_conv_fwd_res': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, I, I, _v, _v],
+    'pbsed_pool21_fwd': [_v, _v, _v, SZ, I, _v],
+    'pbsed_pool21_bwd_add': [_v, _v, _v, SZ, I, _v],
+    'pbsed_add_inplace': [_v, _v, SZ, _v],
     'pbsed_conv_bwd_data': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, _v, I, I, I, I, I, I, I, _v],
     'pbsed_pack_conv_weights_batched': [_v, I, _v],
     'pbsed_conv_pack_dims_wino': [I, I, I, _i, _i],

@@ -51,6 +51,23 @@ int pbsed_conv_fwd(const float* x, const float* w_packed, const float* bias, con
     return conv_fwd_launch(a, KH, KW, pool, 0, (hipStream_t)stream);
 }
 
+// pbsed_conv_fwd + a residual connection ending at this layer: `residual` [B, Cout, Fo, T] is added to the (biased,
+// pooled) output before it is stored and before the statistics are taken, so the next layer's batch norm sees the sum.
+int pbsed_conv_fwd_res(const float* x, const float* w_packed, const float* bias, const float* scale,
+                       const float* shift, int relu, const int* seq_len, float* y, unsigned char* pool_idx,
+                       double* stats, int stats_per_cf, int B, int Cin, int Cout, int F, int T, int KH, int KW,
+                       int pool, const float* residual, void* stream) {
+    ConvFwdArgs a{};
+    a.x = x; a.wp = w_packed; a.bias = bias; a.scale = scale; a.shift = shift; a.seq_len = seq_len;
+    a.y = y; a.pool_idx = pool_idx; a.stats = stats; a.stats_cf = stats_per_cf; a.relu = relu; a.res = residual;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.F = F; a.T = T;
+    int ck, ct;
+    conv_fwd_tile_dims(KH, KW, Cin, Cout, &ck, &ct);
+    a.CinP = (Cin + ck - 1) / ck * ck;
+    a.CoutP = (Cout + ct - 1) / ct * ct;
+    return conv_fwd_launch(a, KH, KW, pool, 0, (hipStream_t)stream);
+}
+
 // Data gradient.  g: grad wrt the forward conv's output [B,Cout,Fo,T] (pooled if unpool_idx);
 // wd_packed: pack_conv_weights(dgrad=1).  Output dz [B,Cin,F,T]: if bx != null the result is already
 // pushed back through mask -> ReLU -> BN-apply of the layer's prologue (dz wrt BN output) and

@@ -271,6 +271,11 @@ int conv_fwd_launch(const ConvFwdArgs& a, int KH, int KW, int pool, int dgrad, h
         if (ct == 16) CFG(16, 4, 128, 3, 3, 8);
         if (ct == 32) CFG(32, 4, 64, 3, 3, 8);
         if (ct == 64) CFG(64, 4, 64, 3, 3, 8);
+    } else if (KH == 1 && KW == 1 && pool) {
+        // 1x1 conv of a 2-D tensor followed by the (2,1) pool (the 'deep' net configuration,
+        // pb_sed/experiments/weak_label_crnn/training.py:170-183): two frequency rows per tile
+        if (ct == 16) return launch_cfg<16, 2, 64, 1, 1, 16, true, false>(a, s);
+        return launch_cfg<128, 2, 64, 1, 1, 16, true, false>(a, s);
     } else if (KH == 1 && !pool) {
 #define CFG1(CT, KW_, CK_)                                                            \
     do {                                                                              \

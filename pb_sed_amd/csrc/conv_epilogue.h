@@ -28,6 +28,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvFwdArgs& a, f32x4 (&acc)
     const bool want_idx = POOL && a.pool_idx != nullptr;
     const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(
         want_idx ? a.pool_idx + (size_t)b * clip : nullptr, 0, want_idx ? clip : 0u, 0x00020000);
+    const bool has_res = !DGRAD && a.res != nullptr;              // residual connection ending at this layer's output
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+        has_res ? const_cast<float*>(a.res) + (size_t)b * clip : nullptr, 0, has_res ? clip * 4u : 0u, 0x00020000);
     const bool bnb = DGRAD && a.bx != nullptr;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
         bnb ? const_cast<float*>(a.bx) + (size_t)b * clip : nullptr, 0, bnb ? clip * 4u : 0u, 0x00020000);
@@ -84,6 +87,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvFwdArgs& a, f32x4 (&acc)
                     } else {
                         v = acc[m][fo_l * NTT + j][r] + bias;
                     }
+                    if (has_res) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_r, off, 0, 0));   // out of range: + 0
                     if (DGRAD) {
                         if (bnb) {
                             // backward through mask -> ReLU -> BN-apply of the layer's prologue:

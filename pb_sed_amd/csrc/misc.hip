@@ -497,6 +497,31 @@ __global__ __launch_bounds__(256) void bicrnn_review_summary_kernel(const float*
     }
 }
 
+
+// Skip path of a residual connection that crosses a (2,1) frequency pool (the 'deep' net configuration): max over row
+// pairs + argmax byte forward; backward routes the gradient to the argmax row and ADDS it to dx (the main path's
+// gradient is already there).  x [R, 2, T] rows pairs flattened over (b, c, f/2).
+__global__ void pool21_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx, size_t n, int T) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / T;
+        const int t = i % T;
+        const float v0 = x[(2 * row) * T + t], v1 = x[(2 * row + 1) * T + t];
+        const bool second = v1 > v0;
+        y[i] = second ? v1 : v0;
+        idx[i] = (unsigned char)second;
+    }
+}
+__global__ void pool21_bwd_add_kernel(const float* __restrict__ g, const unsigned char* __restrict__ idx, float* __restrict__ dx, size_t n, int T) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / T;
+        const int t = i % T;
+        dx[(2 * row + idx[i]) * T + t] += g[i];
+    }
+}
+__global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] += b[i];
+}
+
 }  // namespace pbsed
 
 using namespace pbsed;
@@ -618,6 +643,21 @@ int pbsed_bicrnn_review_summary(const float* y, const float* strong_targets, con
     hipLaunchKernelGGL(bicrnn_review_summary_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, y, strong_targets, seq_len,
                        y_seg, t_seg, mask_mean, mask_cnt, B, K, T, segment_length);
     return check_launch("bicrnn_review_summary");
+}
+
+int pbsed_pool21_fwd(const float* x, float* y, unsigned char* idx, size_t n_out, int T, void* stream) {
+    hipLaunchKernelGGL(pool21_fwd_kernel, dim3(nblocks(n_out)), dim3(256), 0, (hipStream_t)stream, x, y, idx, n_out, T);
+    return check_launch("pool21_fwd");
+}
+
+int pbsed_pool21_bwd_add(const float* g, const unsigned char* idx, float* dx, size_t n_out, int T, void* stream) {
+    hipLaunchKernelGGL(pool21_bwd_add_kernel, dim3(nblocks(n_out)), dim3(256), 0, (hipStream_t)stream, g, idx, dx, n_out, T);
+    return check_launch("pool21_bwd_add");
+}
+
+int pbsed_add_inplace(float* a, const float* b, size_t n, void* stream) {
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, n);
+    return check_launch("add_inplace");
 }
 
 int pbsed_squash_fwd(const float* x, float* y, size_t n, float eps, void* stream) {

@@ -24,6 +24,7 @@ struct ConvFwdArgs {
     const float* bscale;    // [Cout] gamma*invstd
     const float* bshift;    // [Cout]
     int B, Cin, Cout, F, T, CinP, CoutP;
+    const float* res;       // forward: residual added to the (pooled) output before the statistics, [B, Cout, Fo, T], or null
     int stats_cf;           // statistics per (cout, f) instead of per cout
     int relu;               // prologue applies ReLU
 };

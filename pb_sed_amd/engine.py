@@ -84,15 +84,24 @@ def _grad(p):
 class LayerDesc:
     def __init__(self, conv, in_norm):
         self.conv, self.in_norm = conv, in_norm
+        self.skips_in = []          # residual connections ending at this layer's INPUT: (source layer index, skip conv | None)
 
 
 def describe_stack(cnns):
-    """Flatten one or more _CNN modules into [conv + the norm applied (with ReLU) to its input]."""
+    """Flatten one or more _CNN modules into [conv + the norm applied (with ReLU) to its input] (+ the residual
+    connections of each stack, re-indexed to the flattened layer list)."""
     convs = [c for cnn in cnns for c in cnn.convs]
     layers = []
     for j, c in enumerate(convs):
         in_norm = c.norm if c.pre else (convs[j - 1].norm if j > 0 and convs[j - 1].post else None)
         layers.append(LayerDesc(c, in_norm))
+    base = 0
+    for cnn in cnns:
+        for src, dst in enumerate(getattr(cnn, 'residual_connections', None) or []):
+            if dst is not None:
+                key = f'{src}_{dst}'
+                layers[base + dst].skips_in.append((base + src, cnn.skip_convs[key] if key in cnn.skip_convs else None))
+        base += len(cnn.convs)
     if convs[-1].post:
         raise NotImplementedError('a trailing post-activation norm (output_layer=False without '
                                   'pre_activation) has no consumer conv to fuse into')
@@ -136,11 +145,21 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32'):
             x = x.flatten(1, 2)                       # 'b c f t -> b (c f) t' is a view in this layout
         pc = PackedConv(c.conv.weight)
         pr = _prec(precision, pc.cin, pc)
+        # residual connections ending at the NEXT layer's input = this conv's output: their sum rides in this launch's
+        # epilogue (added before the store and before the statistics of the next layer's norm)
+        res, skip_ctx = None, []
+        for src, skip_conv in (nxt.skips_in if nxt is not None else []):
+            r, sctx = _skip_forward(layers, ctx, src, j + 1, skip_conv)
+            res = r if res is None else ops.add_inplace(res, r)
+            skip_ctx.append((src, skip_conv, sctx))
+        if res is not None:
+            pr = 'f32'                       # the residual add lives in the fp32 direct kernels' epilogue
         y, idx, stats = ops.conv_fwd(
             x, pc, pc.fwd(pr), bias=c.conv.bias.detach(),
             scale=None if st_in is None else st_in.scale, shift=None if st_in is None else st_in.shift,
-            relu=True, seq_len=seq_dev, pool=c.pool_f, want_stats=batch_stats, stats_per_cf=per_cf, precision=pr)
-        ctx.append((x, st_in, pc, idx, pr, st_frozen))
+            relu=True, seq_len=seq_dev, pool=c.pool_f, want_stats=batch_stats, stats_per_cf=per_cf, precision=pr,
+            residual=res)
+        ctx.append((x, st_in, pc, idx, pr, st_frozen, skip_ctx))
         st_frozen = bool(training and next_norm is not None and next_norm.freeze_stats)
         if next_norm is None:
             st_in = None
@@ -153,6 +172,38 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32'):
     return x, ctx
 
 
+def _skip_forward(layers, ctx, src, dst, skip_conv):
+    """Skip path x_src -> shape of x_dst: the (2,1) pools of the layers in between, then the 1x1 skip conv (if any)."""
+    r = ctx[src][0]
+    pools = []
+    for k in range(src, dst):
+        if layers[k].conv.pool_f:
+            r, pidx = ops.pool21_fwd(r)
+            pools.append(pidx)
+    pcs = None
+    r_in = r
+    if skip_conv is not None:
+        pcs = PackedConv(skip_conv.weight)
+        r, _, _ = ops.conv_fwd(r_in, pcs, pcs.fwd('f32'), bias=skip_conv.bias.detach(), seq_len=None)
+    elif r is ctx[src][0]:
+        r = r.clone()                    # summed in place with other residuals / never alias a saved activation
+    return r, (pools, pcs, r_in)
+
+
+def _skip_backward(ctx, src, skip_conv, sctx, g):
+    """Gradient of the skip path: returns dL/dx_src contributed by the residual whose sum has gradient ``g``."""
+    pools, pcs, r_in = sctx
+    if skip_conv is not None:
+        dw, db = _grad(skip_conv.weight), _grad(skip_conv.bias)
+        if dw is not None:
+            ops.conv_bwd_weight(r_in, g, pcs, dw, db, relu=False)
+        g, _ = ops.conv_bwd_data(g, pcs, pcs.dgrad('f32'), r_in.shape)
+    for pidx in reversed(pools):
+        full = torch.zeros((*pidx.shape[:2], pidx.shape[2] * 2, pidx.shape[3]), device=g.device, dtype=torch.float32)
+        g = ops.pool21_bwd_add(g, pidx, full)
+    return g
+
+
 def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_done=None):
     """Backward of stack_forward; accumulates parameter grads, returns grad wrt the stack input.
     ``on_layer_done(j)`` fires once every gradient owned by layers >= j is final."""
@@ -161,9 +212,14 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
         return any(p.requires_grad for m in mods for p in m.parameters())
 
     lowest = min((j for j in range(len(layers)) if trainable(j)), default=len(layers))
+    pending = {}                                 # source layer -> gradient arriving over residual connections
     for j in reversed(range(len(layers))):
-        L, (x, st_in, pc, idx, pr, frozen) = layers[j], ctx[j]
+        L, (x, st_in, pc, idx, pr, frozen, skip_ctx) = layers[j], ctx[j]
         c = L.conv
+        # g = dL/d(output of conv j) = dL/d(input of layer j+1): the residuals summed into it take the same gradient
+        for src, skip_conv, sctx in skip_ctx:
+            gs = _skip_backward(ctx, src, skip_conv, sctx, g.contiguous())
+            pending[src] = gs if src not in pending else ops.add_inplace(pending[src], gs)
         if j < lowest and not need_input_grad:                # nothing below needs a gradient (frozen front layers)
             if on_layer_done is not None:
                 on_layer_done(0)
@@ -191,6 +247,8 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
             g = ops.bn_backward(dz, x, st_in, stats, count, _grad(norm.gamma), _grad(norm.beta), seq_dev)
         else:
             g, _ = ops.conv_bwd_data(g, pc, wd, x.shape, idx, None, precision=pr)
+        if j in pending:                         # x_j also feeds a residual connection
+            g = ops.add_inplace(g, pending.pop(j))
         if on_layer_done is not None:
             on_layer_done(j)        # layer j's in_norm belongs to it or to j-1's tail: both done now
     return g

@@ -210,6 +210,39 @@ class ConvLayer(nn.Module):
             raise NotImplementedError('kernel sizes 1 and 3 only (reference shallow config)')
 
 
+def plan_residuals(ndim, residual_connections, in_channels, out_channels, pool_sizes, pre_activation):
+    """Residual connections of padertorch's CNNs as the reference's 'deep' net_config uses them
+    (pb_sed/experiments/weak_label_crnn/training.py:170-183): ``residual_connections[i] = j`` adds the INPUT of layer i
+    to the INPUT of layer j > i (pre-activation: both are the raw tensors in front of the layers' norm + ReLU).  Restated
+    semantics, parity unpinned (padertorch is absent): where the two tensors differ the skip path applies, in this order,
+    every (2,1) max-pool of the layers in between and a bias-carrying 1x1 convolution when the channel counts differ.
+    Returns (per-layer destination or None, ModuleDict of the skip convolutions keyed '<src>_<dst>')."""
+    n = len(out_channels)
+    if residual_connections is None or all(r is None for r in residual_connections):
+        return [None] * n, nn.ModuleDict()
+    if not pre_activation:
+        raise NotImplementedError('residual connections are built for pre-activation stacks (the reference configuration)')
+    assert len(residual_connections) == n, (len(residual_connections), n)
+    cin = [in_channels] + list(out_channels[:-1])                 # channels of the input of layer i
+    skips = nn.ModuleDict()
+    for src, dst in enumerate(residual_connections):
+        if dst is None:
+            continue
+        if isinstance(dst, (list, tuple)):
+            if len(dst) != 1:
+                raise NotImplementedError('one destination per residual connection (the reference configuration)')
+            dst = dst[0]
+        if not (src < dst < n) or src == 0:
+            raise NotImplementedError(f'residual connection {src} -> {dst}: destinations are later layers of the same stack, '
+                                      'sources are layers behind the first')
+        if cin[src] != cin[dst]:
+            conv = (nn.Conv2d if ndim == 2 else nn.Conv1d)(cin[src], cin[dst], 1)
+            nn.init.xavier_uniform_(conv.weight)
+            nn.init.zeros_(conv.bias)
+            skips[f'{src}_{dst}'] = conv
+    return [None if d is None else (d[0] if isinstance(d, (list, tuple)) else d) for d in residual_connections], skips
+
+
 class _CNN(nn.Module):
     ndim = None
 
@@ -228,8 +261,6 @@ class _CNN(nn.Module):
         for name, (got, want) in unsupported.items():
             if got != want and not (name == 'norm' and got is None):
                 raise NotImplementedError(f'{type(self).__name__}({name}={got!r}): the MI355X kernels implement {name}={want!r}')
-        if residual_connections is not None and any(r is not None for r in residual_connections):
-            raise NotImplementedError('residual connections (the reference\'s "deep" net_config) are not built: SURVEY.md 8(f) f4')
         self.norm_kind, self.eps, self.pre_activation = norm, eps, pre_activation
         self.output_layer, self.input_layer = output_layer, input_layer
         n = len(out_channels)
@@ -246,6 +277,8 @@ class _CNN(nn.Module):
             convs.append(ConvLayer(self.ndim, cin, cout, ks[i], ps[i], pre, post, eps))
             cin = cout
         self.convs = nn.ModuleList(convs)
+        self.residual_connections, self.skip_convs = plan_residuals(
+            self.ndim, residual_connections, in_channels, self.out_channels, ps, pre_activation)
 
     def freeze(self, num_layers=None, freeze_norm_stats=True):
         layers = self.convs if num_layers is None else self.convs[:num_layers]
@@ -326,6 +359,16 @@ class GRU(nn.Module):
             config['output_net']['in_channels'] = rnn['hidden_size'] * (2 if rnn.get('bidirectional') else 1)
 
 
+DEEP = dict(            # net_config == 'deep', width 2 (pb_sed/experiments/weak_label_crnn/training.py:170-183)
+    out_channels_2d=4 * [32] + 4 * [64] + 4 * [128] + 4 * [256] + [512, 512],
+    pool_sizes_2d=4 * [1, 1, 1, (2, 1)] + [1, 1],
+    kernel_size_2d=9 * [3, 1],
+    residual_connections_2d=[None, None, 4, None, 6, None, 8, None, 10, None, 12, None, 14, None, 16, None, None, None],
+    out_channels_1d=8 * [512],
+    kernel_size_1d=[1] + 3 * [3, 1] + [1],
+    residual_connections_1d=[None, 3, None, 5, None, 7, None, None],
+)
+
 SHALLOW = dict(
     out_channels_2d=[16, 16, 32, 32, 64, 64, 128, 128, 256],
     pool_sizes_2d=4 * [1, (2, 1)] + [1],
@@ -336,15 +379,15 @@ SHALLOW = dict(
 
 
 def build_cnn(in_channels, out_channels_2d, pool_sizes_2d, kernel_size_2d, out_channels_1d, kernel_size_1d,
-              input_height, conditional_dims=0, eps=1e-3):
+              input_height, conditional_dims=0, eps=1e-3, residual_connections_2d=None, residual_connections_1d=None):
     cnn_2d = CNN2d(in_channels + conditional_dims, out_channels_2d, kernel_size_2d, pool_sizes_2d, eps=eps,
-                   pre_activation=True, output_layer=False, input_layer=True)
+                   pre_activation=True, output_layer=False, input_layer=True, residual_connections=residual_connections_2d)
     f = input_height
     ps = pool_sizes_2d if isinstance(pool_sizes_2d, list) else len(out_channels_2d) * [pool_sizes_2d]
     for p in ps:
         f //= (p[0] if isinstance(p, (tuple, list)) else p)
     cnn_1d = CNN1d(out_channels_2d[-1] * f, out_channels_1d, kernel_size_1d, 1, eps=eps,
-                   pre_activation=True, output_layer=False, input_layer=False)
+                   pre_activation=True, output_layer=False, input_layer=False, residual_connections=residual_connections_1d)
     return CNN(cnn_2d, cnn_1d, input_height, conditional_dims=conditional_dims)
 
 

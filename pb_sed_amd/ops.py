@@ -200,9 +200,10 @@ def _zero_stats(c, device):
 
 
 def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=None, pool=False,
-             want_stats=False, stats_per_cf=False, precision='f32'):
-    """y = conv(prologue(x)) [+pool].  Returns (y, pool_idx|None, stats|None).  ``wp`` must have been packed with
-    the same ``precision`` ('f32' | 'bf16' | 'bf16x3')."""
+             want_stats=False, stats_per_cf=False, precision='f32', residual=None):
+    """y = conv(prologue(x)) [+pool] [+residual].  Returns (y, pool_idx|None, stats|None).  ``wp`` must have been packed
+    with the same ``precision`` ('f32' | 'bf16' | 'bf16x3').  ``residual`` [like y]: added before the store and the
+    statistics (fp32 direct kernels only)."""
     _lib.require_gpu(x)
     b, cin, f, t = _dims4(x)
     assert cin == pc.cin, (cin, pc.cin)
@@ -213,6 +214,7 @@ def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=No
     stats = None
     if want_stats:
         stats = _zero_stats(pc.cout * fo if stats_per_cf else pc.cout, x.device)
+    assert residual is None or precision == 'f32', 'a residual add needs the fp32 direct kernel'
     if precision == 'wino':
         call('pbsed_conv_fwd_wino', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
              ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, int(pool), stream(),
@@ -223,6 +225,12 @@ def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=No
              ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, pc.kh, pc.kw, int(pool),
              NSPLIT[precision], stream(), tag=_conv_tag(b, cin, pc, f, t) + ' ' + precision,
              flops=_conv_flops(b, cin, pc, f, t))
+        return y, idx, stats
+    if residual is not None:
+        assert residual.shape == y.shape and residual.is_contiguous(), (residual.shape, y.shape)
+        call('pbsed_conv_fwd_res', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
+             ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, pc.kh, pc.kw,
+             int(pool), ptr(residual), stream(), tag=_conv_tag(b, cin, pc, f, t) + ' +res', flops=_conv_flops(b, cin, pc, f, t))
         return y, idx, stats
     call('pbsed_conv_fwd', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
          ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, pc.kh, pc.kw,
@@ -272,6 +280,28 @@ def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, se
     call('pbsed_conv_bwd_weight', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(g),
          ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream(),
          tag=_conv_tag(b, cin, pc, f, t) + (' wino' if wino else ''), flops=_conv_flops(b, cin, pc, f, t))
+
+
+def pool21_fwd(x):
+    """(2,1) max-pool of [B,C,F,T] over frequency-row pairs -> (y [B,C,F/2,T], argmax bytes)."""
+    b, c, f, t = x.shape
+    assert f % 2 == 0 and x.is_contiguous()
+    y = torch.empty((b, c, f // 2, t), device=x.device, dtype=torch.float32)
+    idx = torch.empty(y.shape, device=x.device, dtype=torch.uint8)
+    call('pbsed_pool21_fwd', ptr(x), ptr(y), ptr(idx), y.numel(), t, stream())
+    return y, idx
+
+
+def pool21_bwd_add(g, idx, dx):
+    """dx[argmax row] += g (dx [B,C,F,T], g / idx [B,C,F/2,T])."""
+    call('pbsed_pool21_bwd_add', ptr(g.contiguous()), ptr(idx), ptr(dx), g.numel(), g.shape[-1], stream())
+    return dx
+
+
+def add_inplace(a, b):
+    assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+    call('pbsed_add_inplace', ptr(a), ptr(b), a.numel(), stream())
+    return a
 
 
 class BNState:

@@ -521,3 +521,79 @@ def test_mel_warping_training_front_end():
     fe.eval(), fe_ref.eval()
     rel_close(engine.features_from_audio(fe, wav.to(DEV), seq_dev, stft.shape[2], seq), fe_ref(stft, seq_len=seq)[0], 1e-4,
               'eval: static filterbank')
+
+
+# ------------------------------------------------------------------------------------------------ 'deep' net_config (f4)
+MINI_DEEP = dict(        # the structure of net_config == 'deep' (training.py:170-183) at a size the CPU oracle finishes in seconds:
+    out_channels_2d=[16, 16, 16, 16, 32, 32, 32, 32, 48, 48],          # 3x3 / 1x1 alternating, pools on 1x1 layers,
+    pool_sizes_2d=2 * [1, 1, 1, (2, 1)] + [1, 1],                       # residuals across a pool (2 -> 4), across a
+    kernel_size_2d=5 * [3, 1],                                          # channel change (4 -> 6) and both (6 -> 8)
+    residual_connections_2d=[None, None, 4, None, 6, None, 8, None, None, None],
+    out_channels_1d=6 * [64],
+    kernel_size_1d=[1, 3, 1, 3, 1, 1],
+    residual_connections_1d=[None, 3, None, 5, None, None],
+)
+
+
+def test_f4_residual_net_train_step_vs_oracle():
+    """Residual connections + 1x1 conv2d layers with (2,1) pools (the 'deep' net_config): one FBCRNN train step on a
+    small net with every skip variant (identity, across a pool, across a channel change, both; 2-D and 1-D stacks)
+    against the oracle's restatement - scores, loss, every parameter gradient incl. the skip convolutions', running
+    statistics.  (padertorch's skip path is restated, parity unpinned: both sides implement the SAME stated rule.)"""
+    from oracle import frontend as ofe, models as om
+    from pb_sed_amd.models import weak_label
+    torch.manual_seed(0)
+    kw = dict(num_events=10, number_of_filters=128, hidden_size=64, num_layers=2, net=MINI_DEEP)
+    ref = om.FBCRNN.build(**kw)
+    _randomise(ref, 4)
+    model = weak_label.CRNN.build(**kw)
+    assert any('skip_convs' in k for k in model.state_dict())
+    _copy_weights(model, ref)
+    model.to(DEV).train()
+    ref64 = copy.deepcopy(ref).double().train()
+    wav, seq, weak, bnd, t = synth_batch(5, 16000 * 2, 10, seed=12)
+    ref.train()
+    inp_ref = {'stft': ofe.stft(wav), 'seq_len': seq.tolist(), 'weak_targets': weak, 'boundary_targets': bnd}
+    out_ref = ref(inp_ref)
+    rev_ref = ref.review(inp_ref, out_ref)
+    rev_ref['loss'].backward()
+    in64 = {'stft': ofe.stft(wav).double(), 'seq_len': seq.tolist(), 'weak_targets': weak.double(), 'boundary_targets': bnd.double()}
+    ref64.review(in64, ref64(in64))['loss'].backward()
+    inp = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV), 'boundary_targets': bnd.to(DEV)}
+    state0 = {n: b.detach().clone() for n, b in model.named_buffers()}
+    out, rev, grads = _train_step(model, inp)
+    buffers = {n: b.detach().clone() for n, b in model.named_buffers()}
+    assert (out[0].cpu() - out_ref[0]).abs().max() < 1e-4 and (out[1].cpu() - out_ref[1]).abs().max() < 1e-4
+    assert rev['loss'].item() == pytest.approx(rev_ref['loss'].item(), rel=1e-4)
+    model.load_state_dict(state0, strict=False)
+    bad = _grad_table(grads, ref64, ref, _rounding_sensitivity(model, inp, grads))
+    assert not bad, '\n'.join(bad)
+    refb = dict(ref.named_buffers())
+    for name, buf in buffers.items():
+        if 'running' in name:
+            rel_close(buf.double(), refb[name].double(), 1e-4, name)
+
+
+def test_f4_deep_config_full_size_properties():
+    """The reference's 'deep' net_config at its real width (18 conv2d layers up to 512 channels, 8 conv1d layers, GRU
+    2 x 512; training.py:170-183) at batch 8, T = 500: finite loss and gradients, every parameter incl. the skip
+    convolutions receives a gradient, permuting clips permutes the scores."""
+    from pb_sed_amd.models import weak_label
+    from pb_sed_amd.modules import DEEP
+    torch.manual_seed(0)
+    model = weak_label.CRNN.build(num_events=10, hidden_size=512, net=DEEP).to(DEV).train()
+    model.feature_extractor.freeze_stats = True
+    assert sum(p.numel() for p in model.parameters()) > 15e6
+    wav, seq, weak, bnd, t = synth_batch(8, 160000, 10, ragged=False, seed=13)
+    inp = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV), 'boundary_targets': bnd.to(DEV)}
+    state = {n: b.detach().clone() for n, b in model.named_buffers()}
+    out, rev, grads = _train_step(model, inp)
+    assert np.isfinite(rev['loss'].item()) and all(torch.isfinite(g).all() for g in grads.values())
+    dead = [n for n, g in grads.items() if not g.any() and not n.endswith('conv.bias')]
+    assert not dead, dead
+    perm = torch.tensor([3, 2, 1, 0, 7, 6, 5, 4])
+    model.load_state_dict(state, strict=False)
+    inp2 = {k: (v[perm.to(v.device)] if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
+    out2, rev2, _ = _train_step(model, inp2)
+    assert (out2[0] - out[0][perm.to(DEV)]).abs().max().item() < 1e-4
+    assert rev2['loss'].item() == pytest.approx(rev['loss'].item(), rel=1e-4)
