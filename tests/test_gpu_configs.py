@@ -597,3 +597,27 @@ def test_f4_deep_config_full_size_properties():
     out2, rev2, _ = _train_step(model, inp2)
     assert (out2[0] - out[0][perm.to(DEV)]).abs().max().item() < 1e-4
     assert rev2['loss'].item() == pytest.approx(rev['loss'].item(), rel=1e-4)
+
+
+def test_f1_windowed_sed_full_size_vs_oracle():
+    """FBCRNN windowed SED (weak_label/crnn.py:241-302) on the full 'shallow' net with 10 s clips: every window of every
+    clip becomes a short sequence of the GRUs (500 windows x 4 clips x 2 lengths = 4000 sequences per call, far more than
+    the persistent scans' 32 - the launch-per-step stack kernels with a wide batch); per-class lengths and a shift > 1."""
+    from oracle import frontend as ofe, models as om
+    from pb_sed_amd.models import weak_label
+    torch.manual_seed(6)
+    ref = om.FBCRNN.build(num_events=10)
+    _randomise(ref, 6)
+    model = weak_label.CRNN.build(num_events=10)
+    _copy_weights(model, ref)
+    ref.eval(), model.to(DEV).eval()
+    wav, seq, *_ = _sorted_batch(4, 160000, seed=61)
+    inp_ref = {'stft': ofe.stft(wav), 'seq_len': seq.tolist()}
+    inp = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist()}
+    with torch.no_grad():
+        for kwargs in (dict(window_length=[11, 25] * 5, window_shift=1), dict(window_length=40, window_shift=4)):
+            y_ref, sl_ref = ref.sound_event_detection(dict(inp_ref), **kwargs)
+            y, sl = model.sound_event_detection(dict(inp), **kwargs)
+            np.testing.assert_array_equal(sl, sl_ref)
+            assert y.shape == y_ref.shape
+            assert (y.cpu() - y_ref).abs().max().item() < 1e-4, kwargs
