@@ -72,6 +72,21 @@ int pbsed_augment_logmel(float* x, const float* noise, const float* noise_scale,
                          const int* seq_len, const float* mean, const float* inv_std, float clampv,
                          int B, int F, int T, void* stream);
 
+/* ---- data front-end.  Scale + superposition mixing of resident waveforms
+ * (pb_sed/data_preparation/mix.py:67-155, provider.py:195-215): out [B, n_out] = per clip the sum, in list order, of its
+ * components comps[first[b] .. first[b+1]) - slices pool[src_off .. +length) placed at `start`, times `gain` (fp32), times
+ * the raised-cosine fade of `fade_len` samples at the ends flagged fade_in / fade_out (float64, as numpy does).
+ * Target encoding (pb_sed/data_preparation/transform.py:56-124): events of clip b = events[ev_first[b] .. ev_first[b+1])
+ * (class, start frame, stop frame, type 0 weak / 1 boundaries / 2 strong) -> weak [B,K], boundary / strong [B,K,T]
+ * (either may be NULL) with the reference's 0.5 conventions for unlabeled clips and weakly present classes. */
+typedef struct { long long src_off; int length, start; float gain; int fade_in, fade_out; int pad_; } pbsed_mix_comp;
+typedef struct { int cls, start, stop, type; } pbsed_target_event;
+int pbsed_mix_clips(const float* pool, const pbsed_mix_comp* comps /*device*/, const int* first /*device [B+1]*/, float* out,
+                    int B, int n_out, int fade_len, void* stream);
+int pbsed_encode_targets(const pbsed_target_event* events /*device*/, const int* ev_first /*device [B+1]*/,
+                         const int* unlabeled /*device [B]*/, const int* seq_len /*device [B]*/, float* weak, float* boundary,
+                         float* strong, int B, int K, int T, void* stream);
+
 /* ---- convolutions (CNN2d 3x3 / CNN1d k=1,3 / GRU input projections / heads): the `self.cnn(...)`,
  * `self.rnn_*` op sites pb_sed/models/weak_label/crnn.py:93,61-67; layer list
  * pb_sed/experiments/weak_label_crnn/training.py:159-169,218-260. */

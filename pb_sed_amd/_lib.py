@@ -23,6 +23,8 @@ I, F32, F64, SZ = C.c_int, C.c_float, C.c_double, C.c_size_t
 SIGNATURES = {
     'pbsed_last_error': [],
     'pbsed_version': [],
+    'pbsed_mix_clips': [_v, _v, _v, _v, I, I, I, _v],
+    'pbsed_encode_targets': [_v, _v, _v, _v, _v, _v, _v, I, I, I, _v],
     'pbsed_conv_pack_dims': [I, I, I, I, I, _i, _i],
     'pbsed_pack_conv_weights': [_v, _v, I, I, I, I, I, _v],
     'pbsed_conv_fwd': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, I, I, _v],

@@ -522,6 +522,82 @@ __global__ void add_inplace_kernel(float* __restrict__ a, const float* __restric
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] += b[i];
 }
 
+
+// ---- data front-end pieces.
+// Scale + superposition mixing (pb_sed/data_preparation/mix.py:67-155, provider.py:195-215): output clip b is the sum of its
+// components in list order; a component is a slice of the resident waveform pool, multiplied by its gain in fp32 (numpy:
+// float32 array * python float), by the raised-cosine fade in float64 where it does not touch the mixture's edge
+// (float32 array *= float64 array) and accumulated in fp32 - bit-exact with the reference on float32 audio.
+struct MixComp { long long src_off; int length, start; float gain; int fade_in, fade_out; int pad_; };
+__global__ void mix_clips_kernel(const float* __restrict__ pool, const MixComp* __restrict__ comps,
+                                 const int* __restrict__ first /*[B+1]*/, float* __restrict__ out, int n_out, int fade_len) {
+    const int b = blockIdx.y;
+    const int c0 = first[b], c1 = first[b + 1];
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < n_out; n += gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int c = c0; c < c1; ++c) {
+            const MixComp m = comps[c];
+            const int i = n - m.start;
+            if (i < 0 || i >= m.length) continue;
+            float v = pool[m.src_off + i] * m.gain;
+            if (fade_len > 0) {
+                if (m.fade_in && i < fade_len)          // raised_cos[::-1][i] = raised_cos[fade_len - 1 - i]
+                    v = (float)((double)v * (0.5 + cos(M_PI * (double)(fade_len - i) / (double)(fade_len + 1)) / 2.0));
+                if (m.fade_out && i >= m.length - fade_len)
+                    v = (float)((double)v * (0.5 + cos(M_PI * (double)(i - (m.length - fade_len) + 1) / (double)(fade_len + 1)) / 2.0));
+            }
+            acc += v;
+        }
+        out[(size_t)b * n_out + n] = acc;
+    }
+}
+
+// Target encoding (pb_sed/data_preparation/transform.py:56-124): events (class, start frame, stop frame, label type
+// 0 = weak / 1 = boundaries / 2 = strong) of each clip -> weak targets [B,K], boundary targets [B,K,T] (first onset ..
+// last offset of the class' boundary / strong events), strong targets [B,K,T] (each strong event); classes that are only
+// weakly present get 0.5 where any of their events is active, unlabeled clips 0.5 wherever the target is not 1; frames
+// >= seq_len[b] stay 0 (collation padding).  One block per (clip, class).
+struct TargetEvent { int cls, start, stop, type; };
+__global__ __launch_bounds__(256) void encode_targets_kernel(const TargetEvent* __restrict__ ev, const int* __restrict__ ev_first /*[B+1]*/,
+                                                             const int* __restrict__ unlabeled, const int* __restrict__ seq_len,
+                                                             float* __restrict__ weak, float* __restrict__ bnd, float* __restrict__ strong,
+                                                             int K, int T) {
+    const int b = blockIdx.x / K, k = blockIdx.x % K;
+    const int e0 = ev_first[b], e1 = ev_first[b + 1], sl = min(seq_len[b], T);
+    const bool unl = unlabeled[b] != 0;
+    int lo = 0x7fffffff, hi = -1;
+    bool present = false;
+    for (int e = e0; e < e1; ++e) {
+        const TargetEvent v = ev[e];
+        if (v.cls != k) continue;
+        present = true;
+        if (v.type >= 1) { lo = min(lo, v.start); hi = max(hi, v.stop); }
+    }
+    if (threadIdx.x == 0) {
+        const float w = present ? 1.f : 0.f;
+        weak[b * K + k] = unl ? w + (1.f - w) * .5f : w;
+    }
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        float fb = 0.f, fs = 0.f;
+        if (t < sl) {
+            bool overall = false, st = false;
+            for (int e = e0; e < e1; ++e) {
+                const TargetEvent v = ev[e];
+                if (v.cls != k || t < v.start || t >= v.stop) continue;
+                overall = true;
+                st = st || v.type == 2;
+            }
+            const float half = unl ? .5f : (overall ? .5f : 0.f);
+            fb = (t >= lo && t < hi) ? 1.f : 0.f;
+            fb += (1.f - fb) * half;
+            fs = st ? 1.f : 0.f;
+            fs += (1.f - fs) * half;
+        }
+        if (bnd) bnd[((size_t)b * K + k) * T + t] = fb;
+        if (strong) strong[((size_t)b * K + k) * T + t] = fs;
+    }
+}
+
 }  // namespace pbsed
 
 using namespace pbsed;
@@ -658,6 +734,23 @@ int pbsed_pool21_bwd_add(const float* g, const unsigned char* idx, float* dx, si
 int pbsed_add_inplace(float* a, const float* b, size_t n, void* stream) {
     hipLaunchKernelGGL(add_inplace_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, n);
     return check_launch("add_inplace");
+}
+
+int pbsed_mix_clips(const float* pool, const void* comps, const int* first, float* out, int B, int n_out, int fade_len,
+                    void* stream) {
+    if (B < 1 || n_out < 1 || fade_len < 0) { set_error("mix_clips: bad B=%d n_out=%d fade=%d", B, n_out, fade_len); return PBSED_E_ARG; }
+    const int gx = (n_out + 255) / 256 < 1024 ? (n_out + 255) / 256 : 1024;
+    hipLaunchKernelGGL(mix_clips_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, pool, (const MixComp*)comps, first, out,
+                       n_out, fade_len);
+    return check_launch("mix_clips");
+}
+
+int pbsed_encode_targets(const void* events, const int* ev_first, const int* unlabeled, const int* seq_len, float* weak,
+                         float* boundary, float* strong, int B, int K, int T, void* stream) {
+    if (B < 1 || K < 1 || T < 1 || !weak) { set_error("encode_targets: bad B=%d K=%d T=%d", B, K, T); return PBSED_E_ARG; }
+    hipLaunchKernelGGL(encode_targets_kernel, dim3(B * K), dim3(256), 0, (hipStream_t)stream, (const TargetEvent*)events, ev_first,
+                       unlabeled, seq_len, weak, boundary, strong, K, T);
+    return check_launch("encode_targets");
 }
 
 int pbsed_squash_fwd(const float* x, float* y, size_t n, float eps, void* stream) {

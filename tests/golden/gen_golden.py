@@ -418,6 +418,124 @@ def gen_segments():
     print('ref_segments', len(cases), 'arrays')
 
 
+class _ShimSTFT:
+    """Stands in for padertorch's STFT inside Transform.__call__ (transform.py:53): a dummy 'stft' of the right length and
+    the sample -> frame alignment rule of pb_sed_amd.data.samples_to_frames (third-party behaviour, restated)."""
+
+    def __init__(self, shift=320, window_length=960):
+        self.shift, self.window_length = shift, window_length
+
+    def __call__(self, example):
+        from pb_sed_amd.data import samples_to_frames
+        from pb_sed_amd.modules import num_frames
+        example = dict(example)
+        t = num_frames(example['audio_data'].shape[-1], self.shift, self.window_length)
+        example['stft'] = np.zeros((1, t, 3, 2), np.float32)
+        example['events_start_frames'], example['events_stop_frames'] = samples_to_frames(
+            example['events_start_samples'], example['events_stop_samples'], self.shift)
+        return example
+
+
+class _ShimLabelEncoder:
+    """MultiHotAlignmentEncoder restated: encode(label) -> index; encode_alignment([(start, stop, idx)], seq_len) ->
+    [seq_len, K] multi-hot; __call__(example) -> {'events': alignment of all events with their frames}."""
+    label_key = 'events'
+
+    def __init__(self, labels):
+        self.label_mapping = {l: i for i, l in enumerate(labels)}
+
+    def encode(self, label):
+        return self.label_mapping[label]
+
+    def encode_alignment(self, labels, seq_len):
+        out = np.zeros((seq_len, len(self.label_mapping)), np.float32)
+        for start, stop, idx in labels:
+            out[max(start, 0):stop, idx] = 1
+        return out
+
+    def __call__(self, example):
+        labels = [(a, o, self.encode(l)) for l, a, o in zip(example['events'], example['events_start_frames'], example['events_stop_frames'])]
+        return {'events': self.encode_alignment(labels, example['stft'].shape[1])}
+
+
+def gen_data_front_end():
+    """pb_sed/data_preparation/mix.py SuperposeEvents (seeded np.random) and transform.py Transform.__call__ (under the
+    STFT / label-encoder shims above) on float32 waveforms."""
+    import pb_sed.data_preparation.mix as ref_mix
+    import pb_sed.data_preparation.transform as ref_tr
+    rng = np.random.default_rng(19)
+    labels = ['alarm', 'dog', 'dishes', 'speech', 'water']
+    cases = dict(labels=np.array(labels))
+
+    def example(i, n, events, unlabeled=None, weak_only=False):
+        ex = {'example_id': f'ex{i}', 'dataset': f'ds{i % 2}', 'audio_data': rng.standard_normal((1, n)).astype(np.float32)}
+        if events is not None:
+            ex['events'] = [e[0] for e in events]
+            if not weak_only:
+                ex['events_start_samples'] = [e[1] for e in events]
+                ex['events_stop_samples'] = [e[2] for e in events]
+                ex['label_types'] = [e[3] for e in events]
+        if unlabeled is not None:
+            ex['unlabeled'] = unlabeled
+        return ex
+
+    exs = [
+        example(0, 16000, [('dog', 2000, 9000, 'strong'), ('dog', 12000, 15000, 'strong'), ('speech', 0, 16000, 'weak')]),
+        example(1, 12345, [('alarm', 100, 6000, 'boundaries'), ('alarm', 7000, 12000, 'boundaries'), ('water', 3000, 4000, 'strong')]),
+        example(2, 20000, [('dishes',), ('speech',)], weak_only=True),
+        example(3, 9000, None),
+        example(4, 16000, [('dog', 640, 3200, 'strong'), ('water', 0, 16000, 'weak')], unlabeled=True),
+    ]
+    for i, ex in enumerate(exs):
+        cases[f'ex{i}/audio'] = ex['audio_data']
+    # ---- mixing
+    mixes = {'m01': ([0, 1], dict(min_overlap=.5, fade_length=0)), 'm203': ([2, 0, 3], dict(min_overlap=.25, fade_length=200)),
+             'm41': ([4, 1], dict(min_overlap=1., max_length_in_samples=24000, fade_length=64))}
+    for name, (idx, kw) in mixes.items():
+        np.random.seed(hash(name) % 1000 if False else sum(map(ord, name)))
+        out = ref_mix.SuperposeEvents(**kw)([{k: (v.copy() if isinstance(v, np.ndarray) else list(v) if isinstance(v, list) else v)
+                                              for k, v in exs[i].items()} for i in idx])
+        cases[f'{name}/idx'] = np.array(idx)
+        cases[f'{name}/kw'] = np.array(repr(kw))
+        cases[f'{name}/seed'] = np.int64(sum(map(ord, name)))
+        cases[f'{name}/audio'] = out['audio_data']
+        cases[f'{name}/events'] = np.array(out['events'])
+        cases[f'{name}/start'] = np.array(out['events_start_samples'], dtype=np.int64)
+        cases[f'{name}/stop'] = np.array(out['events_stop_samples'], dtype=np.int64)
+        cases[f'{name}/label_types'] = np.array(out['label_types'])
+        cases[f'{name}/unlabeled'] = np.bool_(out['unlabeled'])
+        cases[f'{name}/example_id'] = np.array(out['example_id'])
+    # ---- target encoding (incl. a mixture)
+    enc = _ShimLabelEncoder(labels)
+    tr = ref_tr.Transform.__new__(ref_tr.Transform)
+    tr.stft, tr.label_encoder = _ShimSTFT(), enc
+    tr.provide_boundary_targets = tr.provide_strong_targets = True
+    tr.pop_audio_data, tr.anchor_sampling_fn, tr.anchor_shift_sampling_fn = True, None, None
+    np.random.seed(7)
+    mixed = ref_mix.SuperposeEvents(min_overlap=.5)([dict(exs[0]), dict(exs[1])])
+    for name, ex in [(f'ex{i}', exs[i]) for i in range(5)] + [('mix', mixed)]:
+        ex = {k: (list(v) if isinstance(v, list) else v) for k, v in ex.items()}
+        out = tr(dict(ex))
+        cases[f'targets/{name}/weak'] = out['weak_targets']
+        cases[f'targets/{name}/boundary'] = out['boundary_targets']
+        cases[f'targets/{name}/strong'] = out['strong_targets']
+        cases[f'targets/{name}/seq_len'] = np.int64(out['seq_len'])
+    cases['targets/mix/start'] = np.array(mixed['events_start_samples'], dtype=np.int64)
+    cases['targets/mix/stop'] = np.array(mixed['events_stop_samples'], dtype=np.int64)
+    cases['targets/mix/events'] = np.array(mixed['events'])
+    cases['targets/mix/label_types'] = np.array(mixed['label_types'])
+    cases['targets/mix/n'] = np.int64(mixed['audio_data'].shape[1])
+    for i, ex in enumerate(exs):
+        e = ref_mix.add_label_types({k: (list(v) if isinstance(v, list) else v) for k, v in ex.items()})
+        cases[f'ex{i}/events'] = np.array(e['events'], dtype='<U16')
+        cases[f'ex{i}/start'] = np.array(e['events_start_samples'], dtype=np.int64)
+        cases[f'ex{i}/stop'] = np.array(e['events_stop_samples'], dtype=np.int64)
+        cases[f'ex{i}/label_types'] = np.array(e['label_types'], dtype='<U16')
+        cases[f'ex{i}/unlabeled'] = np.bool_(e['unlabeled'])
+    np.savez_compressed(os.path.join(OUT, 'ref_data_front_end.npz'), **cases)
+    print('ref_data_front_end', len(cases), 'arrays')
+
+
 def gen_instance_based():
     """Validation metrics (pb_sed/evaluation/instance_based.py, pure numpy): threshold searches on score matrices with
     ties, the rate constraints, binary-decision metrics and lwlrap."""
@@ -504,6 +622,7 @@ if __name__ == '__main__':
     gen_filters()
     gen_inference()
     gen_segments()
+    gen_data_front_end()
     gen_instance_based()
     gen_summary_metrics()
     assert not os.path.exists('/root/reference/pb_sed/__pycache__'), 'bytecode written to reference'

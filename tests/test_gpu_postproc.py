@@ -205,3 +205,60 @@ def test_audio_segments_give_the_features_of_the_whole_clip():
             for j, sl in enumerate(s['seq_len']):
                 sl = max(sl, 0)
                 assert torch.equal(x[j, :, :, :sl], full[j, :, :, a:a + sl]), (a, j)
+
+
+def _golden_examples(g, device=None):
+    exs = []
+    for i in range(5):
+        audio = torch.as_tensor(g[f'ex{i}/audio'])
+        ex = {'example_id': f'ex{i}', 'dataset': f'ds{i % 2}', 'audio_data': audio if device is None else audio.to(device),
+              'events': [str(v) for v in g[f'ex{i}/events']], 'events_start_samples': g[f'ex{i}/start'].tolist(),
+              'events_stop_samples': g[f'ex{i}/stop'].tolist(), 'label_types': [str(v) for v in g[f'ex{i}/label_types']],
+              'unlabeled': bool(g[f'ex{i}/unlabeled'])}
+        exs.append(ex)
+    return exs
+
+
+def test_superpose_events_matches_the_reference(golden):
+    """pb_sed/data_preparation/mix.py::SuperposeEvents executed by the reference on seeded float32 clips: the build draws
+    the offsets with the same np.random calls, shifts the event boundaries the same way and mixes on the device in one
+    launch - audio bit-exact without fades, within one float32 ulp where the float64 raised-cosine fade is applied."""
+    from pb_sed_amd.data import SuperposeEvents
+    g = golden('ref_data_front_end.npz')
+    exs = _golden_examples(g, DEV)
+    for name in ('m01', 'm203', 'm41'):
+        kw = eval(str(g[f'{name}/kw']))
+        np.random.seed(int(g[f'{name}/seed']))
+        out = SuperposeEvents(**kw)([dict(exs[i]) for i in g[f'{name}/idx']])
+        assert out['example_id'] == str(g[f'{name}/example_id']) and out['unlabeled'] == bool(g[f'{name}/unlabeled'])
+        assert out['events'] == [str(v) for v in g[f'{name}/events']]
+        assert out['events_start_samples'] == g[f'{name}/start'].tolist() and out['events_stop_samples'] == g[f'{name}/stop'].tolist()
+        assert out['label_types'] == [str(v) for v in g[f'{name}/label_types']]
+        got, want = out['audio_data'].cpu().numpy(), g[f'{name}/audio']
+        assert got.shape == want.shape and out['seq_len'] == want.shape[1]
+        if kw.get('fade_length', 0) == 0:
+            np.testing.assert_array_equal(got, want)
+        else:
+            np.testing.assert_allclose(got, want, rtol=2.5e-7, atol=1e-9)
+            assert (got == want).mean() > .999
+
+
+def test_target_encoding_bit_exact_vs_the_reference(golden):
+    """pb_sed/data_preparation/transform.py:56-124 executed by the reference (under an STFT / label-encoder shim):
+    strongly, boundary-, weakly and un-labelled clips, an unlabeled clip with events, and a mixture - weak, boundary and
+    strong targets of a ragged batch in one launch, bit for bit."""
+    from pb_sed_amd.data import encode_targets
+    g = golden('ref_data_front_end.npz')
+    labels = {str(l): i for i, l in enumerate(g['labels'])}
+    exs = _golden_examples(g)
+    exs.append({'audio_data': torch.zeros(1, int(g['targets/mix/n'])), 'events': [str(v) for v in g['targets/mix/events']],
+                'events_start_samples': g['targets/mix/start'].tolist(), 'events_stop_samples': g['targets/mix/stop'].tolist(),
+                'label_types': [str(v) for v in g['targets/mix/label_types']], 'unlabeled': False})
+    names = [f'ex{i}' for i in range(5)] + ['mix']
+    seq = [int(g[f'targets/{n}/seq_len']) for n in names]
+    weak, bnd, strong = encode_targets(exs, labels, max(seq), DEV, seq_len=seq)
+    for i, n in enumerate(names):
+        np.testing.assert_array_equal(weak[i].cpu().numpy(), g[f'targets/{n}/weak'])
+        np.testing.assert_array_equal(bnd[i, :, :seq[i]].cpu().numpy(), g[f'targets/{n}/boundary'])
+        np.testing.assert_array_equal(strong[i, :, :seq[i]].cpu().numpy(), g[f'targets/{n}/strong'])
+        assert not bnd[i, :, seq[i]:].any() and not strong[i, :, seq[i]:].any()
