@@ -199,3 +199,22 @@ def test_mel_warping_is_monotone_and_fixes_the_band_edge():
     assert out.shape == (16, 130) and (np.diff(out, axis=-1) > 0).all()
     np.testing.assert_allclose(out[:, -1], 8000., rtol=1e-9)
     assert (np.abs(out[:, 1] / f[1] - 1) < .3 + 1e-9).all() and np.ptp(out[:, 10]) > 0
+
+
+def test_superpose_placement_draws_match_the_reference(golden):
+    """Host half of SuperposeEvents (mix.py:95-117): with the reference's seed the same offsets are drawn, i.e. the
+    shifted event boundaries equal the reference's (the device half - the mixing - is in tests/test_gpu_postproc.py)."""
+    from pb_sed_amd.data import SuperposeEvents, add_label_types, samples_to_frames
+    g = golden('ref_data_front_end.npz')
+    for name in ('m01', 'm203', 'm41'):
+        kw = eval(str(g[f'{name}/kw']))
+        idx = g[f'{name}/idx']
+        np.random.seed(int(g[f'{name}/seed']))
+        starts, stops = SuperposeEvents(**kw).place([g[f'ex{i}/audio'].shape[1] for i in idx])
+        shifted = [int(v + s) for i, s in zip(idx, starts) for v in g[f'ex{i}/start']]
+        assert shifted == g[f'{name}/start'].tolist()
+        assert int(stops.max()) == g[f'{name}/audio'].shape[1]
+    ex = add_label_types({'audio_data': np.zeros((1, 1000)), 'events': ['a']})
+    assert ex['events_stop_samples'] == [1000] and ex['label_types'] == ['weak'] and ex['unlabeled'] is False
+    assert add_label_types({'audio_data': np.zeros((1, 10))})['unlabeled'] is True
+    assert samples_to_frames([0, 319, 320, 641], [320, 321, 640, 641]) == ([0, 0, 1, 2], [1, 2, 2, 3])
