@@ -199,6 +199,29 @@ class Trainer:
         if name in self.bucket_names:
             self.sync.bucket_ready(self.bucket_names.index(name))
 
+    def sync_buffers(self, mode='mean'):
+        """Data-parallel replicas keep their own batch-norm / feature running statistics (no SyncBN).  Before a checkpoint
+        or a validation pass make them agree: ``mode='mean'`` averages every floating-point buffer over the ranks
+        (``num_tracked_values`` counters are summed), ``'rank0'`` broadcasts rank 0's.  No-op without a process group."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        world = dist.get_world_size()
+        for name, buf in self.model.named_buffers():
+            if not buf.is_floating_point():
+                continue
+            if mode == 'rank0':
+                dist.broadcast(buf, src=0)
+            elif name.endswith('num_tracked_values'):
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                buf.div_(world)
+        fe = getattr(self.model, 'feature_extractor', None)
+        if fe is not None and mode == 'mean':           # derived buffers follow the merged statistics
+            with torch.no_grad():
+                fe.mean.copy_(fe.running_mean)
+                fe.inv_std.copy_(1. / torch.sqrt((fe.running_power - fe.running_mean ** 2).clamp_min(0.) + fe.norm_eps))
+
     def step(self, batch):
         """One optimisation step.  Returns the review dict (loss is a device scalar, no host sync)."""
         t_start = time.perf_counter()

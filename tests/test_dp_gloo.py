@@ -58,6 +58,42 @@ def test_gradsync_and_sharding_world2(tmp_path):
         assert open(tmp_path / f'ok{r}').read() == 'True'
 
 
+def _buffer_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pb_sed_amd.modules import NormalizedLogMelExtractor, Normalization
+    from pb_sed_amd.trainer import Trainer
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.feature_extractor = NormalizedLogMelExtractor(number_of_filters=8)
+            self.norm = Normalization(4)
+    m = M()
+    with torch.no_grad():
+        m.norm.running_mean.fill_(float(rank + 1))
+        m.feature_extractor.running_mean.fill_(float(rank))
+        m.feature_extractor.running_power.fill_(float(rank) ** 2 + 4.)
+        m.feature_extractor.num_tracked_values.fill_(100. * (rank + 1))
+    t = Trainer.__new__(Trainer)
+    t.model = m
+    t.sync_buffers()
+    ok = torch.allclose(m.norm.running_mean, torch.full((4,), 1.5)) and m.feature_extractor.num_tracked_values.item() == 300.
+    ok = ok and torch.allclose(m.feature_extractor.mean, torch.full((8,), .5))
+    ok = ok and torch.allclose(m.feature_extractor.inv_std, 1. / torch.sqrt(torch.full((8,), 4.5 - .25 + 1e-5)))
+    with open(os.path.join(out_dir, f'buf{rank}'), 'w') as f:
+        f.write(str(bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_sync_buffers_world2(tmp_path):
+    """Per-replica running statistics are averaged (tracked-value counters summed) before a checkpoint."""
+    mp.spawn(_buffer_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f'buf{r}').read() == 'True'
+
+
 def test_gradsync_single_process_is_noop():
     from pb_sed_amd.trainer import GradSync
     g = torch.ones(10)
