@@ -41,6 +41,15 @@ int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, const int* s
                      const int* mel_off, const float* mel_w, int mel_w_count, int F, const float* mean, const float* inv_std,
                      float eps, float clampv, float* out, double* stats, int pad_front, const float* mel_pts,
                      void* stream);
+/* The same front-end with an explicit first-sample index per frame, frame_pos [B][T] int32 (windows reaching outside
+ * [0, n_samples) read zeros): the time-warped STFT of the training pipeline (TimeWarpedSTFT at
+ * pb_sed/data_preparation/transform.py:36-45 with the samplers of provider.py:329-338) computed on the GPU - the host
+ * draws the warp and hands over where each frame starts, see pb_sed_amd/data.py::TimeWarp. */
+int pbsed_logmel_fwd_frames(const float* wav, int B, int n_samples, int T, const int* seq_len_frames, const int* frame_pos,
+                            const float* window, const float* twiddle, const int* mel_start, const int* mel_len,
+                            const int* mel_off, const float* mel_w, int mel_w_count, int F, const float* mean,
+                            const float* inv_std, float eps, float clampv, float* out, double* stats, const float* mel_pts,
+                            void* stream);
 /* `mel_pts` (both front-end entry points): NULL = the static sparse filterbank; else [B][F+2] fractional STFT-bin
  * positions of each clip's (warped) triangular filters - filter m spans mel_pts[b][m] .. [m+2] with its peak at [m+1],
  * unit sum: the per-example MelWarping of the training config (pb_sed/experiments/weak_label_crnn/training.py:195-208).

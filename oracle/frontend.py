@@ -35,10 +35,20 @@ def num_frames(n_samples, shift=SHIFT, window_length=WINDOW_LENGTH):
     return max(int(math.ceil((n_samples + pad - window_length) / shift)) + 1, 1)
 
 
-def stft(wav, shift=SHIFT, window_length=WINDOW_LENGTH, size=FFT_SIZE):
-    """wav [B, N] float -> [B, 1, T, size//2+1, 2] float32 (re, im), float64 inside like numpy."""
+def stft(wav, shift=SHIFT, window_length=WINDOW_LENGTH, size=FFT_SIZE, frame_pos=None):
+    """wav [B, N] float -> [B, 1, T, size//2+1, 2] float32 (re, im), float64 inside like numpy.
+    ``frame_pos`` [B, T] ints: first sample of every frame's window (samples outside the clip are zeros) - time-warped
+    framing; None: the base STFT's regular grid."""
     wav = torch.as_tensor(wav, dtype=torch.float64)
     b, n = wav.shape
+    if frame_pos is not None:
+        pos = torch.as_tensor(np.asarray(frame_pos), dtype=torch.long)
+        idx = pos[:, :, None] + torch.arange(window_length)[None, None]          # [B, T, wl]
+        ok = (idx >= 0) & (idx < n)
+        frames = torch.gather(wav, 1, idx.clamp(0, n - 1).reshape(b, -1)).reshape(idx.shape) * ok
+        win = torch.from_numpy(blackman_periodic(window_length))
+        spec = torch.fft.rfft(frames * win, n=size, dim=-1)
+        return torch.stack([spec.real, spec.imag], dim=-1).to(torch.float32)[:, None]
     pad_front = (window_length - shift) // 2
     pad_back = int(math.ceil((window_length - shift) / 2))
     t = num_frames(n, shift, window_length)

@@ -51,6 +51,7 @@ SIGNATURES = {
     'pbsed_bn_bwd_apply': [_v, _v, _v, _v, _v, _v, _v, _v, I, I, I, I, _v],
     'pbsed_augment_logmel': [_v, _v, _v, _v, _v, _v, _v, F32, I, I, I, _v],
     'pbsed_logmel_fwd': [_v, I, I, I, _v, _v, _v, _v, _v, _v, _v, I, I, _v, _v, F32, F32, _v, _v, I, _v, _v],
+    'pbsed_logmel_fwd_frames': [_v, I, I, I, _v, _v, _v, _v, _v, _v, _v, _v, I, I, _v, _v, F32, F32, _v, _v, _v, _v],
     'pbsed_logmel_from_stft': [_v, I, I, I, _v, _v, _v, _v, _v, I, I, _v, _v, F32, F32, _v, _v, _v, _v],
     'pbsed_feature_norm_update': [_v, F64, _v, _v, _v, F32, _v, _v, I, _v],
     'pbsed_bct_to_tbc': [_v, _v, I, I, I, _v],

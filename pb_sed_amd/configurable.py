@@ -37,6 +37,7 @@ def _reference_factories():
         'paderbox.transform.module_fbank.MelWarping': modules.MelWarping,
         'paderbox.utils.random_utils.LogTruncatedNormal': modules.LogTruncatedNormal,
         'paderbox.utils.random_utils.TruncatedExponential': modules.TruncatedExponential,
+        'paderbox.utils.random_utils.Uniform': modules.Uniform,
         'torch.nn.modules.rnn.GRU': torch.nn.GRU,
         'torch.nn.GRU': torch.nn.GRU,
     }

@@ -36,6 +36,9 @@ struct LogmelArgs {
     const float* mel_pts;    // optional [B][F+2]: per-clip fractional bin positions of the (warped) filter edges / centres
     int pad_front;           // zero samples assumed in front of wav[0] (320 = the reference's 'half' fading; 0 for a slice
                              // cut out of the middle of a clip, pb_sed_amd/utils/segment.py)
+    const int* frame_pos;    // optional [B][T]: first sample of every frame's window (may lie outside [0, N): zeros) - the
+                             // time-warped STFT of the training pipeline (pb_sed/data_preparation/transform.py:36-45);
+                             // null: frame t starts at 320 t - pad_front
 };
 
 // Per-mel sums of one block's output tile (frames past seq_len hold 0 and add nothing) into one of the slot copies.
@@ -103,9 +106,12 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelArgs a) {
     const int b = blockIdx.x / nTt, t0 = (blockIdx.x % nTt) * LM_FR;
     const long s0 = (long)t0 * LM_SHIFT - a.pad_front;
     const float* wav = a.wav + (size_t)b * a.N;
-    for (int i = tid; i < NS_SAMP; i += 256) {
-        const long n = s0 + i;
-        samp[i] = (n >= 0 && n < a.N) ? wav[n] : 0.f;
+    const int* fpos = a.frame_pos ? a.frame_pos + (size_t)b * a.T : nullptr;
+    if (!fpos) {
+        for (int i = tid; i < NS_SAMP; i += 256) {
+            const long n = s0 + i;
+            samp[i] = (n >= 0 && n < a.N) ? wav[n] : 0.f;
+        }
     }
     const int n_mw = a.mel_pts ? 0 : a.mel_off[a.F - 1] + a.mel_len[a.F - 1];
     for (int i = tid; i < n_mw; i += 256) mw[i] = a.mel_w[i];
@@ -138,12 +144,28 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelArgs a) {
         const int t = t0 + fl;
         const float* x = samp + fl * LM_SHIFT;
         // pack windowed real frame (zero padded 960 -> 1024) as 512 complex
+        if (fpos) {
+            // warped framing: the windows of neighbouring frames start at arbitrary samples, so each wave reads its frame
+            // straight from the clip (L2-resident: every sample is touched by ~3 frames)
+            const long s = t < a.T ? (long)fpos[t] : (long)a.N;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int n = lane + r * 64;
-            cpx v = cpx{0.f, 0.f};
-            if (2 * n < LM_WIN) v = cpx{x[2 * n] * win[2 * n], x[2 * n + 1] * win[2 * n + 1]};
-            A[n] = v;
+            for (int r = 0; r < 8; ++r) {
+                const int n = lane + r * 64;
+                cpx v = cpx{0.f, 0.f};
+                if (2 * n < LM_WIN) {
+                    const long i0 = s + 2 * n, i1 = i0 + 1;
+                    v = cpx{(i0 >= 0 && i0 < a.N ? wav[i0] : 0.f) * win[2 * n], (i1 >= 0 && i1 < a.N ? wav[i1] : 0.f) * win[2 * n + 1]};
+                }
+                A[n] = v;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int n = lane + r * 64;
+                cpx v = cpx{0.f, 0.f};
+                if (2 * n < LM_WIN) v = cpx{x[2 * n] * win[2 * n], x[2 * n + 1] * win[2 * n + 1]};
+                A[n] = v;
+            }
         }
         wave_lds_sync();
         fft512_pass<1>(A, Bf, tw, lane);
@@ -321,22 +343,41 @@ extern "C" int pbsed_augment_logmel(float* x, const float* noise, const float* n
     return check_launch("augment_logmel");
 }
 
-extern "C" int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, const int* seq_len_frames,
-                                const float* window, const float* twiddle, const int* mel_start,
-                                const int* mel_len, const int* mel_off, const float* mel_w, int mel_w_count, int F,
-                                const float* mean, const float* inv_std, float eps, float clampv,
-                                float* out, double* stats, int pad_front, const float* mel_pts, void* stream) {
+static int logmel_launch(const float* wav, int B, int n_samples, int T, const int* seq_len_frames,
+                         const float* window, const float* twiddle, const int* mel_start,
+                         const int* mel_len, const int* mel_off, const float* mel_w, int mel_w_count, int F,
+                         const float* mean, const float* inv_std, float eps, float clampv,
+                         float* out, double* stats, int pad_front, const int* frame_pos, const float* mel_pts, void* stream) {
     if (pad_front < 0 || pad_front > LM_WIN) { set_error("logmel: pad_front %d", pad_front); return PBSED_E_ARG; }
     if (F > LM_NMEL_MAX * 4 || F < 1 || T < 1) { set_error("logmel: bad F=%d T=%d", F, T); return PBSED_E_ARG; }
     if (mel_w_count > LM_MW_MAX || mel_w_count < 0) { set_error("logmel: %d packed filter weights (max %d)", mel_w_count, LM_MW_MAX); return PBSED_E_UNSUPPORTED; }
     LogmelArgs a{wav, window, twiddle, mel_start, mel_len, mel_off, mel_w, mean, inv_std, seq_len_frames,
-                 out, stats, B, n_samples, T, F, eps, clampv, mel_pts, pad_front};
+                 out, stats, B, n_samples, T, F, eps, clampv, mel_pts, pad_front, frame_pos};
     const int nTt = (T + LM_FR - 1) / LM_FR;
     const size_t lds = ((LM_FR - 1) * LM_SHIFT + LM_WIN + LM_WIN) * sizeof(float) + 1024 * sizeof(cpx) +
                        4 * 2 * 512 * sizeof(cpx) + (size_t)F * (LM_FR + 1) * sizeof(float) + LM_MW_MAX * sizeof(float);
     PBSED_DYN_LDS_ONCE(logmel_kernel, lds);
     hipLaunchKernelGGL(logmel_kernel, dim3(B * nTt), dim3(256), lds, (hipStream_t)stream, a);
     return check_launch("logmel_fwd");
+}
+
+extern "C" int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, const int* seq_len_frames,
+                                const float* window, const float* twiddle, const int* mel_start,
+                                const int* mel_len, const int* mel_off, const float* mel_w, int mel_w_count, int F,
+                                const float* mean, const float* inv_std, float eps, float clampv,
+                                float* out, double* stats, int pad_front, const float* mel_pts, void* stream) {
+    return logmel_launch(wav, B, n_samples, T, seq_len_frames, window, twiddle, mel_start, mel_len, mel_off, mel_w, mel_w_count,
+                         F, mean, inv_std, eps, clampv, out, stats, pad_front, nullptr, mel_pts, stream);
+}
+
+extern "C" int pbsed_logmel_fwd_frames(const float* wav, int B, int n_samples, int T, const int* seq_len_frames,
+                                       const int* frame_pos, const float* window, const float* twiddle, const int* mel_start,
+                                       const int* mel_len, const int* mel_off, const float* mel_w, int mel_w_count, int F,
+                                       const float* mean, const float* inv_std, float eps, float clampv,
+                                       float* out, double* stats, const float* mel_pts, void* stream) {
+    if (!frame_pos) { set_error("logmel_fwd_frames: frame_pos is null"); return PBSED_E_ARG; }
+    return logmel_launch(wav, B, n_samples, T, seq_len_frames, window, twiddle, mel_start, mel_len, mel_off, mel_w, mel_w_count,
+                         F, mean, inv_std, eps, clampv, out, stats, 0, frame_pos, mel_pts, stream);
 }
 
 extern "C" int pbsed_logmel_from_stft(const float* stft, int B, int T, int bins, const int* seq_len_frames,

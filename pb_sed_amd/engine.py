@@ -472,13 +472,14 @@ def _features(fe, raw_fn, seq_dev, seq_host, n_frames):
     return augment_features(fe, x, seq_dev, seq_host, normalise=True)
 
 
-def features_from_audio(fe, audio, seq_dev, n_frames, seq_host=None, pad_front=320):
+def features_from_audio(fe, audio, seq_dev, n_frames, seq_host=None, pad_front=320, frame_pos=None):
+    """``frame_pos`` [B, n_frames] int32: time-warped framing (pb_sed_amd/data.py::TimeWarp)."""
     tables = _tables(fe, audio.device)
     if seq_host is None:
         seq_host = seq_dev.cpu().numpy()
     return _features(fe, lambda mean, inv_std, clamp, stats, pts: ops.logmel_fwd(
         audio, tables, mean, inv_std, n_frames, seq_dev, eps=fe.eps, clamp=clamp, stats=stats, pad_front=pad_front,
-        mel_points=pts), seq_dev, seq_host, n_frames)
+        mel_points=pts, frame_pos=frame_pos), seq_dev, seq_host, n_frames)
 
 
 def augment_features(fe, x, seq_dev, seq_host=None, normalise=False):

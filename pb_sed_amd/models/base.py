@@ -129,13 +129,17 @@ class SoundEventModel(nn.Module, Configurable, abc.ABC):
     def features(self, inputs, x_in, seq_host, seq_dev):
         """Normalised log-mel [B,1,F,T] of either input contract: the reference's ``'stft'`` [B,1,T,bins,2]
         (pb_sed/models/weak_label/crnn.py:79-90) or the waveform ``'audio_data'`` [B,N] (fused STFT).  Segments cut out of
-        long clips (pb_sed_amd/utils/segment.py) carry ``'stft_pad_front'`` / ``'num_frames'``."""
+        long clips (pb_sed_amd/utils/segment.py) carry ``'stft_pad_front'`` / ``'num_frames'``; ``'frame_pos'`` [B,T] selects
+        time-warped framing of the waveform (pb_sed_amd/data.py::TimeWarp)."""
         from .. import engine
         from ..modules import num_frames
         fe = self.feature_extractor
         if 'audio_data' in inputs or x_in.dim() == 2:
             audio = x_in.reshape(x_in.shape[0], -1).to(torch.float32)
             n_frames = int(inputs.get('num_frames', 0)) or num_frames(audio.shape[1])
+            frame_pos = inputs.get('frame_pos')                  # time-warped framing drawn by data.TimeWarp
+            if frame_pos is not None:
+                frame_pos = torch.as_tensor(frame_pos, dtype=torch.int32).to(audio.device).contiguous()
             return engine.features_from_audio(fe, audio, seq_dev, n_frames, seq_host,
-                                              pad_front=int(inputs.get('stft_pad_front', 320)))
+                                              pad_front=int(inputs.get('stft_pad_front', 320)), frame_pos=frame_pos)
         return engine.features_from_stft(fe, x_in, seq_host, seq_dev)

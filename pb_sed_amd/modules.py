@@ -62,6 +62,17 @@ class TruncatedExponential:
         return truncexpon(self.truncation / self.scale, loc=self.loc, scale=self.scale).rvs(shape, random_state=self._rng)
 
 
+class Uniform:
+    """paderbox.utils.random_utils.Uniform restated: U(low, high)."""
+
+    def __init__(self, low=0., high=1., seed=None):
+        self.low, self.high = low, high
+        self._rng = np.random.RandomState(seed)
+
+    def __call__(self, shape=()):
+        return self._rng.uniform(self.low, self.high, shape)
+
+
 class MelWarping:
     """paderbox.transform.module_fbank.MelWarping restated (vocal-tract-length style piecewise-linear warping of the mel
     filters' centre frequencies, one draw per clip; reference config pb_sed/experiments/weak_label_crnn/training.py:195-208):

@@ -690,12 +690,22 @@ class LogMelTables:
 
 
 def logmel_fwd(wav, tables, mean, inv_std, n_frames, seq_len=None, eps=1e-18, clamp=6.0, stats=None, pad_front=320,
-               mel_points=None):
+               mel_points=None, frame_pos=None):
     """wav [B, N] f32 (device) -> normalised, clamped, masked log-mel [B, 1, F, T].  ``stats``: see
-    feature_norm_stats (then pass mean = inv_std = None, clamp = None to get the raw log-mel)."""
+    feature_norm_stats (then pass mean = inv_std = None, clamp = None to get the raw log-mel).  ``frame_pos`` [B, T] int32
+    (device): first sample of every frame's window (time-warped framing, pb_sed_amd/data.py::TimeWarp) instead of
+    320 t - pad_front."""
     _lib.require_gpu(wav)
     b, n = wav.shape
     out = torch.empty((b, 1, tables.n_filters, n_frames), device=wav.device, dtype=torch.float32)
+    if frame_pos is not None:
+        assert frame_pos.shape == (b, n_frames) and frame_pos.dtype == torch.int32 and frame_pos.is_contiguous(), frame_pos.shape
+        call('pbsed_logmel_fwd_frames', ptr(wav.contiguous()), b, n, n_frames, ptr(seq_len), ptr(frame_pos), ptr(tables.window),
+             ptr(tables.twiddle), ptr(tables.start), ptr(tables.len), ptr(tables.off), ptr(tables.w), tables.w.numel(),
+             tables.n_filters, ptr(tables.zero if mean is None else mean), ptr(tables.one if inv_std is None else inv_std),
+             float(eps), float(clamp if clamp is not None else 3e38), ptr(out), ptr(stats), ptr(mel_points), stream(),
+             nbytes=b * (n * 4 + tables.n_filters * n_frames * 4))
+        return out
     call('pbsed_logmel_fwd', ptr(wav.contiguous()), b, n, n_frames, ptr(seq_len), ptr(tables.window),
          ptr(tables.twiddle), ptr(tables.start), ptr(tables.len), ptr(tables.off), ptr(tables.w), tables.w.numel(),
          tables.n_filters, ptr(tables.zero if mean is None else mean), ptr(tables.one if inv_std is None else inv_std),

@@ -621,3 +621,36 @@ def test_f1_windowed_sed_full_size_vs_oracle():
             np.testing.assert_array_equal(sl, sl_ref)
             assert y.shape == y_ref.shape
             assert (y.cpu() - y_ref).abs().max().item() < 1e-4, kwargs
+
+
+def test_fbcrnn_trains_on_time_warped_frames():
+    """inputs['frame_pos'] (data.TimeWarp) through the model: features equal the oracle's at the same frame positions, and a
+    training step with warped framing + warped targets runs (finite loss, all gradients set)."""
+    from oracle import frontend as ofe
+    from pb_sed_amd import data, modules
+    from pb_sed_amd.models import weak_label
+    torch.manual_seed(0)
+    b, n, k = 4, 32000, 10
+    from tests.test_gpu_model import TINY
+    model = weak_label.CRNN.build(num_events=k, hidden_size=64, net=TINY).to(DEV)
+    t = modules.num_frames(n)
+    wav = torch.randn(b, n) * .1
+    exs = [{'audio_data': wav[i:i + 1].numpy(), 'events': ['c%d' % (i % 3)], 'events_start_samples': [4000 * i],
+            'events_stop_samples': [4000 * i + 12000]} for i in range(b)]
+    tw = data.TimeWarp(modules.Uniform(.4, .6, seed=5), modules.Uniform(-.1, .1, seed=6))
+    fp, warped = tw(exs, t)
+    mapping = {'c%d' % i: i for i in range(k)}
+    weak, bnd, strong = data.encode_targets(warped, mapping, t, DEV)
+    seq = [t] * b
+    inputs = {'audio_data': wav.to(DEV), 'seq_len': seq, 'frame_pos': fp, 'weak_targets': weak, 'boundary_targets': bnd}
+    model.eval()
+    feats = model.features(inputs, inputs['audio_data'], np.array(seq), torch.tensor(seq, dtype=torch.int32, device=DEV))
+    ext = ofe.LogMelExtractor().eval()
+    ext.mean.copy_(model.feature_extractor.mean.cpu()), ext.inv_std.copy_(model.feature_extractor.inv_std.cpu())
+    ref, _ = ext(ofe.stft(wav, frame_pos=fp), seq_len=np.array(seq))
+    assert (feats.cpu() - ref).abs().max() < 2e-4
+    model.train()
+    out = model(inputs)
+    review = model.review(inputs, out)
+    review['loss'].backward()
+    assert torch.isfinite(review['loss']) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())

@@ -42,6 +42,40 @@ def test_logmel_vs_oracle(n, b):
     close(out, ref, atol=2e-4, name='logmel')
 
 
+def test_logmel_time_warped_frames_vs_oracle():
+    """pbsed_logmel_fwd_frames: the front-end at explicit frame positions (time-warped STFT, data.TimeWarp).  The regular
+    grid reproduces pbsed_logmel_fwd bit for bit; warped positions (incl. windows hanging over both clip ends) match the
+    oracle's STFT taken at the same positions; statistics tracking and mel warping compose with it."""
+    from oracle import frontend as fe
+    from pb_sed_amd import data, modules, ops
+    from pb_sed_amd.modules import get_fbanks, num_frames
+    g = torch.Generator().manual_seed(4321)
+    b, n = 5, 48000
+    wav = torch.randn(b, n, generator=g)
+    wav = wav / wav.abs().max(-1, keepdim=True)[0]
+    t = num_frames(n)
+    seq = np.array([t, t - 3, t, t // 2, t - 1])
+    seq_dev = torch.as_tensor(seq, dtype=torch.int32).to(DEV)
+    ext = fe.LogMelExtractor().eval()
+    ext.mean.copy_(torch.linspace(-8, -4, 128))
+    ext.inv_std.copy_(torch.linspace(.3, .6, 128))
+    tables = ops.LogMelTables(get_fbanks(16000, 1024, 128), DEV)
+    mean, inv_std = ext.mean.to(DEV), ext.inv_std.to(DEV)
+    tw = data.TimeWarp(modules.Uniform(.4, .6, seed=3), modules.Uniform(-.1, .1, seed=4))
+    plain = ops.logmel_fwd(wav.to(DEV), tables, mean, inv_std, t, seq_dev)
+    grid = tw.frame_positions(n, t, np.full(b, .5), np.zeros(b))
+    same = ops.logmel_fwd(wav.to(DEV), tables, mean, inv_std, t, seq_dev, frame_pos=torch.from_numpy(grid).to(DEV))
+    assert torch.equal(plain, same)
+    a, s = tw.sample(b)
+    pos = tw.frame_positions(n, t, a, s)
+    pos[0, :3] -= 700                                                  # windows starting well before / ending after the clip
+    pos[1, -3:] += 900
+    ref, _ = ext(fe.stft(wav, frame_pos=pos), seq_len=seq)
+    out = ops.logmel_fwd(wav.to(DEV), tables, mean, inv_std, t, seq_dev, frame_pos=torch.from_numpy(pos).to(DEV))
+    close(out, ref, atol=2e-4, name='logmel warped frames')
+    assert (out - plain).abs().max() > .5                              # it is a different signal
+
+
 # ------------------------------------------------------------------------------------------ conv
 CONV_CASES = [
     # cin, cout, F, T, k(2d? tuple), pool, prologue, ragged

@@ -218,3 +218,80 @@ def test_superpose_placement_draws_match_the_reference(golden):
     assert ex['events_stop_samples'] == [1000] and ex['label_types'] == ['weak'] and ex['unlabeled'] is False
     assert add_label_types({'audio_data': np.zeros((1, 10))})['unlabeled'] is True
     assert samples_to_frames([0, 319, 320, 641], [320, 321, 640, 641]) == ([0, 0, 1, 2], [1, 2, 2, 3])
+
+
+def test_time_warp_maps_are_inverse_monotone_and_identity_without_shift():
+    """pb_sed_amd.data.TimeWarp (time-warped STFT of pb_sed/data_preparation/transform.py:36-45, samplers of
+    provider.py:329-338): no shift -> the base STFT's regular grid; the event map inverts the frame map; frames advance
+    monotonically and stay within the stretch factors the samplers allow."""
+    from pb_sed_amd import data, modules
+    tw = data.TimeWarp(modules.Uniform(.4, .6, seed=1), modules.Uniform(-.1, .1, seed=2))
+    n, t = 160000, modules.num_frames(160000)
+    pos = tw.frame_positions(n, t, np.array([.5, .4]), np.array([0., 0.]))
+    assert (pos == (np.arange(t) * 320 - 320)[None]).all()          # 'half' fading: frame t starts at 320 t - 320
+    a, s = tw.sample(64)
+    assert ((a >= .4) & (a <= .6)).all() and (np.abs(s) <= .1 + 1e-12).all()
+    pos = tw.frame_positions(n, t, a, s)
+    hop = np.diff(pos, axis=1)
+    assert (hop > 0).all() and hop.min() >= 320 * .4 / .7 - 1 and hop.max() <= 320 * .6 / .3 + 1
+    v = np.linspace(0, n, 57)
+    for i in range(8):
+        u = tw.warped_of(v, n, a[i], s[i])
+        assert (np.diff(u) > 0).all() and abs(u[0]) < 1e-9 and abs(u[-1] - n) < 1e-6
+        np.testing.assert_allclose(tw.source_of(u, n, a[i], s[i]), v, atol=1e-6)
+    # an event keeps covering the audio it labelled: the frames inside the warped event look at source samples inside it
+    ex = [{'audio_data': np.zeros((1, n)), 'events': ['x'], 'events_start_samples': [40000], 'events_stop_samples': [90000]}]
+    tw2 = data.TimeWarp(lambda shape: np.full(shape, .45), lambda shape: np.full(shape, .08))
+    fp, warped = tw2(ex, t)
+    (on,), (off,) = data.samples_to_frames(warped[0]['events_start_samples'], warped[0]['events_stop_samples'])
+    centre = fp[0, on + 1:off - 1] + 480
+    assert (centre >= 40000 - 320).all() and (centre <= 90000 + 320).all()
+    outside = np.r_[fp[0, :max(on - 2, 0)] + 480, fp[0, off + 2:] + 480]
+    assert ((outside < 40000) | (outside > 90000)).all()
+
+
+def test_dynamic_bucket_batcher_rules():
+    """pb_sed_amd.data.DynamicBucketBatcher (pb_sed/data_preparation/fetcher.py:38-51): padding bound, batch size, sort
+    order, every example exactly once, drop_incomplete, expiration, buffer limit, label diversity."""
+    from pb_sed_amd import data
+    rng = np.random.RandomState(0)
+    k = 5
+    exs = [{'example_id': i, 'seq_len': int(n), 'dataset': 'a' if i % 3 else 'b',
+            'weak_targets': np.eye(k)[rng.randint(k)]} for i, n in enumerate(rng.randint(100, 501, 400))]
+    batches = list(data.DynamicBucketBatcher(8, max_padding_rate=.05)(exs))
+    ids = [ex['example_id'] for b in batches for ex in b]
+    assert sorted(ids) == list(range(400))
+    for b in batches:
+        lens = [ex['seq_len'] for ex in b]
+        assert len(b) <= 8 and lens == sorted(lens, reverse=True)
+        assert min(lens) >= max(lens) * (1 - .05) - 1e-9
+    assert sum(len(b) == 8 for b in batches) >= 35
+    full = list(data.DynamicBucketBatcher(8, max_padding_rate=.05, drop_incomplete=True)(exs))
+    assert full and all(len(b) == 8 for b in full) and len(full) == sum(len(b) == 8 for b in batches)
+    # expiration closes a lonely bucket after that many further examples; the buffer limit bounds what waits
+    odd = [dict(exs[0], seq_len=5000, example_id=-1)] + exs[:50]
+    out = list(data.DynamicBucketBatcher(8, expiration=10)(odd))
+    first_small = next(i for i, b in enumerate(out) if b[0]['example_id'] == -1)
+    assert len(out[first_small]) == 1 and sum(len(b) for b in out[:first_small]) <= 10
+    waiting, longest = 0, 0
+    bb = data.DynamicBucketBatcher(8, max_padding_rate=.01, max_buffered_examples=20)
+    emitted = 0
+    for i, b in enumerate(bb(exs)):
+        emitted += len(b)
+    assert emitted == 400
+    # label diversity: every full batch covers at least 3 classes
+    div = list(data.DynamicBucketBatcher(8, max_padding_rate=.5, min_label_diversity=3, drop_incomplete=True)(exs))
+    assert div and all(len({int(np.argmax(ex['weak_targets'])) for ex in b}) >= 3 for b in div)
+    # examples per dataset
+    mix = list(data.DynamicBucketBatcher(8, max_padding_rate=.5, min_dataset_examples={'b': 2}, drop_incomplete=True)(exs))
+    assert mix and all(sum(ex['dataset'] == 'b' for ex in b) >= 2 for b in mix)
+
+
+def test_collate_pads_along_time():
+    from pb_sed_amd import data
+    batch = [{'example_id': 'a', 'seq_len': 7, 'audio_data': np.ones((1, 50), np.float32), 'stft': np.ones((1, 7, 3, 2), np.float32)},
+             {'example_id': 'b', 'seq_len': 5, 'audio_data': np.ones((1, 40), np.float32), 'stft': np.ones((1, 5, 3, 2), np.float32)}]
+    out = data.collate(batch)
+    assert out['example_id'] == ['a', 'b'] and out['seq_len'] == [7, 5]
+    assert out['audio_data'].shape == (2, 1, 50) and out['audio_data'][1, 0, 40:].abs().sum() == 0
+    assert out['stft'].shape == (2, 1, 7, 3, 2) and out['stft'][1, 0, 5:].abs().sum() == 0 and out['stft'][1, 0, :5].min() == 1
