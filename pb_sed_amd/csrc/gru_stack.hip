@@ -332,6 +332,44 @@ __device__ __forceinline__ int poll_batch(float4 (&out)[NL], __amdgpu_buffer_rsr
     return spin;
 }
 
+// bf16x3 operands of the recurrent product (X3 variants of the scans).  An fp32 value splits EXACTLY into three bf16 parts
+// by truncation (8 + 8 + 8 significant bits: hi = the upper half of its word, the remainders are exact differences); the
+// product a*b is then accumulated from the six part products whose weight is above 2^-24 of |a||b| on the bf16 MFMA
+// (16x16x32: the wave's whole K = 32 slice in one instruction, ~17 clocks, against eight 32-clock fp32 MFMAs) with fp32
+// accumulation, smallest terms first - fp32-class accuracy (the three dropped products are below the fp32 rounding of the sum).
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+struct Bf3 {
+    u32x4_t hi, mid, lo;          // 8 values each, packed in the order of the poll's words: (n = 0: x y z w), (n = 1: x y z w)
+};
+__device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const unsigned u0 = __float_as_uint(v0), u1 = __float_as_uint(v1);
+    hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                     // (u1 & 0xffff0000) | (u0 >> 16)
+    const float r0 = v0 - __uint_as_float(u0 & 0xffff0000u), r1 = v1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned m0 = __float_as_uint(r0), m1 = __float_as_uint(r1);
+    mid = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    const float l0 = r0 - __uint_as_float(m0 & 0xffff0000u), l1 = r1 - __uint_as_float(m1 & 0xffff0000u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+}
+__device__ __forceinline__ Bf3 split3x8(float4 a, float4 b) {
+    unsigned h[4], m[4], l[4];
+    split3_pair(a.x, a.y, h[0], m[0], l[0]);
+    split3_pair(a.z, a.w, h[1], m[1], l[1]);
+    split3_pair(b.x, b.y, h[2], m[2], l[2]);
+    split3_pair(b.z, b.w, h[3], m[3], l[3]);
+    return Bf3{u32x4_t{h[0], h[1], h[2], h[3]}, u32x4_t{m[0], m[1], m[2], m[3]}, u32x4_t{l[0], l[1], l[2], l[3]}};
+}
+__device__ __forceinline__ f32x4 mfma_b16(u32x4_t a, u32x4_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gbf16x8, a), __builtin_bit_cast(gbf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_x3(const Bf3& a, const Bf3& b, f32x4 c) {
+    c = mfma_b16(a.lo, b.hi, c);
+    c = mfma_b16(a.hi, b.lo, c);
+    c = mfma_b16(a.mid, b.mid, c);
+    c = mfma_b16(a.mid, b.hi, c);
+    c = mfma_b16(a.hi, b.mid, c);
+    return mfma_b16(a.hi, b.hi, c);
+}
+
 // Block roles of the granule scans.  Every (chain, layer) has a RING of H/16 x ceil(B/16) blocks that carries the
 // recurrence (h_{t-1} -> h_t, or dh_{t+1} -> dh_t) and, for every layer boundary, a group of the same size of
 // PROJECTION blocks that turn the neighbouring ring's step output into this ring's step input (forward:
@@ -399,7 +437,7 @@ __device__ __forceinline__ void wait_own_granules(unsigned (&q)[NQ], const gu32*
 // waves.  Vector memory operations of a wave complete in issue order, so a wave that publishes h_t with a write-through
 // store and then polls for step t + 1 waits for that store's acknowledgement (0.35 us/step) before its poll counts as
 // returned; with GW the polling waves never store and the publishing waves never poll on the critical path.
-template <int KB, int NW, bool GW>
+template <int KB, int NW, bool GW, bool X3 = false>
 __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsigned* gran_h_, unsigned* gran_gi_, unsigned epoch,
                                                      unsigned* err_flag, float (&red)[2][NW][3][64][4], int& s_err) {
     constexpr int H = KB * NW * 16, NL = KB;           // NL: 16-byte loads per lane (16 k each) of this wave's H/NW range
@@ -430,13 +468,27 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
     // every wave contracts its H/NW slice of K; within it a lane owns k = k0 + n*16 + lq*4 + {0..3} (the poll's
     // load pattern) and the weights follow the same order
     const int k0 = (is_mfma ? wave : 0) * NL * 16;
-    float4 wv[NL][3];
+    constexpr int NM = (NL + 1) / 2;                 // X3: bf16 MFMAs (K = 32 = two of the poll's loads) per product term
+    float4 wv[X3 ? 1 : NL][3];
+    Bf3 w3[X3 ? NM : 1][3];
     if (is_mfma) {
         const float* W = (is_proj ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * H + k0 + lq * 4;
+        if constexpr (X3) {
 #pragma unroll
-        for (int n = 0; n < NL; ++n)
+            for (int m = 0; m < NM; ++m)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) wv[n][g] = *reinterpret_cast<const float4*>(W + (size_t)g * H * H + n * 16);
+                for (int g = 0; g < 3; ++g) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(W + (size_t)g * H * H + (2 * m) * 16);
+                    const float4 w1 = 2 * m + 1 < NL ? *reinterpret_cast<const float4*>(W + (size_t)g * H * H + (2 * m + 1) * 16)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                    w3[m][g] = split3x8(w0, w1);
+                }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NL; ++n)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) wv[n][g] = *reinterpret_cast<const float4*>(W + (size_t)g * H * H + n * 16);
+        }
     }
     // a projection reads h_t of the layer below, a ring its own h_{t-1}
     const unsigned cl_src = chain * a.nlayers + (is_proj ? layer - 1 : layer);
@@ -481,15 +533,24 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
         }
         if (step + 1 < a.T) load_gi(step + 1);
         if (contract) {
+            if constexpr (X3) {
 #pragma unroll
-            for (int n = 0; n < NL; ++n)
+                for (int m = 0; m < NM; ++m) {
+                    const Bf3 xs = split3x8(x[2 * m], 2 * m + 1 < NL ? x[2 * m + 1] : make_float4(0.f, 0.f, 0.f, 0.f));
 #pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    acc[g] = mfma16(wv[n][g].x, x[n].x, acc[g]);
-                    acc[g] = mfma16(wv[n][g].y, x[n].y, acc[g]);
-                    acc[g] = mfma16(wv[n][g].z, x[n].z, acc[g]);
-                    acc[g] = mfma16(wv[n][g].w, x[n].w, acc[g]);
+                    for (int g = 0; g < 3; ++g) acc[g] = mfma_x3(w3[m][g], xs, acc[g]);
                 }
+            } else {
+#pragma unroll
+                for (int n = 0; n < NL; ++n)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        acc[g] = mfma16(wv[n][g].x, x[n].x, acc[g]);
+                        acc[g] = mfma16(wv[n][g].y, x[n].y, acc[g]);
+                        acc[g] = mfma16(wv[n][g].z, x[n].z, acc[g]);
+                        acc[g] = mfma16(wv[n][g].w, x[n].w, acc[g]);
+                    }
+            }
         }
         if (is_mfma) {
 #pragma unroll
@@ -550,19 +611,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     gru_granule_fwd_body<KB, NW, false>(a, gran_h_, gran_gi_, epoch, err_flag, red, s_err);
 }
 
-template <int KB, int NW>
+template <int KB, int NW, bool X3>
 __global__ __launch_bounds__((NW + 4) * 64) void gru_granule_fwd_gw_kernel(GruStackArgs a, unsigned* gran_h_, unsigned* gran_gi_,
                                                                          unsigned epoch, unsigned* err_flag) {
     __shared__ float red[2][NW][3][64][4];
     __shared__ int s_err;
-    gru_granule_fwd_body<KB, NW, true>(a, gran_h_, gran_gi_, epoch, err_flag, red, s_err);
+    gru_granule_fwd_body<KB, NW, true, X3>(a, gran_h_, gran_gi_, epoch, err_flag, red, s_err);
 }
 
 // Backward twin.  Rings publish dh_t (masked by the sequence length) of their 16 units as granules [T][B][H];
 // consumers rebuild the gate gradients they contract with as dh * (factor saved by the forward scan), the factors
 // being plain loads issued one step ahead.  Projection blocks turn dh_t of the layer above into dy_t of the layer
 // below (granules [T][B][H] as well); dh*z of a thread's own unit stays in a register.  Scan order = top layer first.
-template <int KB, int NW, bool GW>
+template <int KB, int NW, bool GW, bool X3 = false>
 __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsigned* gran_dh_, unsigned* gran_dy_, unsigned epoch,
                                                      unsigned* err_flag, float (&red)[2][NW][64][4], int& s_err) {
     constexpr int H = KB * NW * 16, G = 3 * H, NL = KB;     // NL: 16-byte loads per lane (16 units each)
@@ -592,13 +653,25 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
     // that layer's W_ih.  Every wave takes H/NW hidden units jj = k0 + n*16 + lq*4 + {0..3} (the poll's load pattern).
     const int k0 = (is_mfma ? wave : 0) * NL * 16;
     const GruStackLayer& X = is_proj ? a.lc[chain][layer + 1] : L;
-    float4 wv[NL][3];
+    constexpr int NM = (NL + 1) / 2;                 // X3: bf16 MFMAs per product term (see gru_granule_fwd_body)
+    float4 wv[X3 ? 1 : NL][3];
+    Bf3 w3[X3 ? NM : 1][3];
     if (is_mfma) {
         const float* W = (is_proj ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * G + k0 + lq * 4;
+        if constexpr (X3) {
 #pragma unroll
-        for (int n = 0; n < NL; ++n)
+            for (int m = 0; m < NM; ++m)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) wv[n][g] = *reinterpret_cast<const float4*>(W + g * H + n * 16);
+                for (int g = 0; g < 3; ++g)
+                    w3[m][g] = split3x8(*reinterpret_cast<const float4*>(W + g * H + (2 * m) * 16),
+                                        2 * m + 1 < NL ? *reinterpret_cast<const float4*>(W + g * H + (2 * m + 1) * 16)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f));
+        } else {
+#pragma unroll
+            for (int n = 0; n < NL; ++n)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) wv[n][g] = *reinterpret_cast<const float4*>(W + g * H + n * 16);
+        }
     }
     const unsigned cl_src = chain * a.nlayers + (is_proj ? layer + 1 : layer);
     const unsigned voff0 = (unsigned)(((size_t)cl_src * per_cl + (size_t)role.by * 16 * H + (k0 / 16) * 256 + lr * 16 + lq * 4) * 4);
@@ -664,7 +737,22 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         if (!is_proj && layer < top && bv)
             qd[0] = __hip_atomic_load(g_dy + tb * H + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (bstep + 1 < a.T) load_own(bstep + 1);
-        if (contract) {
+        if constexpr (X3) {
+            if (contract) {
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const int n0 = 2 * m, n1 = 2 * m + 1 < NL ? 2 * m + 1 : 2 * m;
+                    const float k1 = 2 * m + 1 < NL ? 1.f : 0.f;
+                    const float4 d0 = dh4[n0], d1 = make_float4(dh4[n1].x * k1, dh4[n1].y * k1, dh4[n1].z * k1, dh4[n1].w * k1);
+                    acc[0] = mfma_x3(w3[m][0], split3x8(make_float4(d0.x * pr[n0][0], d0.y * pr[n0][1], d0.z * pr[n0][2], d0.w * pr[n0][3]),
+                                                        make_float4(d1.x * pr[n1][0], d1.y * pr[n1][1], d1.z * pr[n1][2], d1.w * pr[n1][3])), acc[0]);
+                    acc[1] = mfma_x3(w3[m][1], split3x8(make_float4(d0.x * pz[n0][0], d0.y * pz[n0][1], d0.z * pz[n0][2], d0.w * pz[n0][3]),
+                                                        make_float4(d1.x * pz[n1][0], d1.y * pz[n1][1], d1.z * pz[n1][2], d1.w * pz[n1][3])), acc[1]);
+                    acc[2] = mfma_x3(w3[m][2], split3x8(make_float4(d0.x * pn[n0][0], d0.y * pn[n0][1], d0.z * pn[n0][2], d0.w * pn[n0][3]),
+                                                        make_float4(d1.x * pn[n1][0], d1.y * pn[n1][1], d1.z * pn[n1][2], d1.w * pn[n1][3])), acc[2]);
+                }
+            }
+        } else if (contract) {
 #pragma unroll
             for (int n = 0; n < NL; ++n) {
                 acc[0] = mfma16(wv[n][0].x, dh4[n].x * pr[n][0], acc[0]);
@@ -726,12 +814,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     gru_granule_bwd_body<KB, NW, false>(a, gran_dh_, gran_dy_, epoch, err_flag, red, s_err);
 }
 
-template <int KB, int NW>
+template <int KB, int NW, bool X3>
 __global__ __launch_bounds__((NW + 4) * 64) void gru_granule_bwd_gw_kernel(GruStackArgs a, unsigned* gran_dh_, unsigned* gran_dy_,
                                                                          unsigned epoch, unsigned* err_flag) {
     __shared__ float red[2][NW][64][4];
     __shared__ int s_err;
-    gru_granule_bwd_body<KB, NW, true>(a, gran_dh_, gran_dy_, epoch, err_flag, red, s_err);
+    gru_granule_bwd_body<KB, NW, true, X3>(a, gran_dh_, gran_dy_, epoch, err_flag, red, s_err);
 }
 
 }  // namespace pbsed
@@ -810,14 +898,21 @@ static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid) {
 
 // PBSED_GRU_POLL_DELAYS="fwd,fwd_gate,bwd,bwd_gate" overrides the measured defaults (PollPacer).
 static void granule_poll_delays(bool bwd, GruStackArgs& a) {
-    static int d[4] = {25, 6, 16, 0};     // measured with the tile-major exchange arrays (tools/sweep_poll_delays.sh): forward 23 is over a cliff (1.20 ms, 22: 1.44), 24 1.12, 25 1.13, 28 1.22 ms
+    // measured with the tile-major exchange arrays and bf16x3 products (tools/sweep_poll_delays.sh, B = 32, H = 256, T = 500).
+    // Two-layer stacks (FBCRNN): forward 21 1.28 ms, 23 0.99, 24 0.94, 25 0.97, 26 1.04, 27 1.10; BPTT 14 1.37, 16 1.35,
+    // 18..22 1.334, 24 1.36, 28 1.43.  One-layer scans (the BiGRU layers of the BiCRNN, two launches): forward 20 2.40,
+    // 22 1.82, 23 1.78, 24 1.80, 26 1.90; BPTT 8 2.48, 14..17 2.44, 20 2.51, 26 2.70.
+    static int d[4] = {24, 6, 20, 0}, d1[4] = {24, 6, 15, 0};
     static const bool parsed = [] {
-        if (const char* e = getenv("PBSED_GRU_POLL_DELAYS")) sscanf(e, "%d,%d,%d,%d", &d[0], &d[1], &d[2], &d[3]);
+        if (const char* e = getenv("PBSED_GRU_POLL_DELAYS"))
+            if (sscanf(e, "%d,%d,%d,%d", &d[0], &d[1], &d[2], &d[3]) == 4)
+                for (int i = 0; i < 4; ++i) d1[i] = d[i];
         return true;
     }();
     (void)parsed;
-    a.poll_delay = d[bwd ? 2 : 0];
-    a.poll_delay_gate = d[bwd ? 3 : 1];
+    const int* use = a.nlayers == 1 ? d1 : d;
+    a.poll_delay = use[bwd ? 2 : 0];
+    a.poll_delay_gate = use[bwd ? 3 : 1];
 }
 
 // Ring-per-XCD placement (granule_role) per scan direction: bit 0 = forward, bit 1 = BPTT.  Measured on MI355X with the
@@ -862,11 +957,17 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
     // PBSED_GRU_GW: bit 0 forward / bit 1 BPTT scan with dedicated gate waves (default both; 1.35 -> 1.21 ms and
     // 1.65 -> 1.49 ms at B = 32, H = 256, T = 500)
     static const int gw = [] { const char* e = getenv("PBSED_GRU_GW"); return e ? atoi(e) : 3; }();
+    // PBSED_GRU_X3: bit 0 = forward / bit 1 = BPTT scan with bf16x3 operands on the bf16 MFMA (see Bf3; default both:
+    // forward 1.13 -> 0.94 ms, BPTT 1.40 -> 1.33 ms at B = 32, H = 256, T = 500)
+    static const int x3 = [] { const char* e = getenv("PBSED_GRU_X3"); return e ? atoi(e) : 3; }();
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
     do {                                                                                                             \
-        if (gw & 1) {                                                                                                \
-            hipLaunchKernelGGL((gru_granule_fwd_gw_kernel<KB_, NW_>), grid, dim3((NW_ + 4) * 64), 0, s, a, granules,  \
-                               gran_gi, epoch, err_flag);                                                            \
+        if ((gw & 1) && (x3 & 1)) {                                                                                  \
+            hipLaunchKernelGGL((gru_granule_fwd_gw_kernel<KB_, NW_, true>), grid, dim3((NW_ + 4) * 64), 0, s, a,      \
+                               granules, gran_gi, epoch, err_flag);                                                  \
+        } else if (gw & 1) {                                                                                         \
+            hipLaunchKernelGGL((gru_granule_fwd_gw_kernel<KB_, NW_, false>), grid, dim3((NW_ + 4) * 64), 0, s, a,     \
+                               granules, gran_gi, epoch, err_flag);                                                  \
         } else {                                                                                                     \
             hipLaunchKernelGGL((gru_granule_fwd_kernel<KB_, NW_>), grid, dim3(NW_ * 64), 0, s, a, granules, gran_gi,  \
                                epoch, err_flag);                                                                     \
@@ -915,11 +1016,15 @@ int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_
     // PBSED_GRU_GW: bit 0 forward / bit 1 BPTT scan with dedicated gate waves (default both; 1.35 -> 1.21 ms and
     // 1.65 -> 1.49 ms at B = 32, H = 256, T = 500)
     static const int gw = [] { const char* e = getenv("PBSED_GRU_GW"); return e ? atoi(e) : 3; }();
+    static const int x3 = [] { const char* e = getenv("PBSED_GRU_X3"); return e ? atoi(e) : 3; }();     // bit 1 = BPTT scan
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
     do {                                                                                                             \
-        if (gw & 2) {                                                                                                \
-            hipLaunchKernelGGL((gru_granule_bwd_gw_kernel<KB_, NW_>), grid, dim3((NW_ + 4) * 64), 0, s, a, granules,  \
-                               gran_dy, epoch, err_flag);                                                            \
+        if ((gw & 2) && (x3 & 2) && KB_ < 4) {                                                                               \
+            hipLaunchKernelGGL((gru_granule_bwd_gw_kernel<KB_, NW_, true>), grid, dim3((NW_ + 4) * 64), 0, s, a,      \
+                               granules, gran_dy, epoch, err_flag);                                                  \
+        } else if (gw & 2) {                                                                                         \
+            hipLaunchKernelGGL((gru_granule_bwd_gw_kernel<KB_, NW_, false>), grid, dim3((NW_ + 4) * 64), 0, s, a,     \
+                               granules, gran_dy, epoch, err_flag);                                                  \
         } else {                                                                                                     \
             hipLaunchKernelGGL((gru_granule_bwd_kernel<KB_, NW_>), grid, dim3(NW_ * 64), 0, s, a, granules, gran_dy,  \
                                epoch, err_flag);                                                                     \
