@@ -253,13 +253,21 @@ def roofline_objects(agg, by_family, steps, batch, precision, gru_shape, kind):
                 continue
             ms = sum(r[0] for r in rows) / steps            # all scans of one step (FBCRNN: one launch; BiGRU: one per layer)
             fl = sum(r[2] * r[1] for r in rows) / steps
+            x3 = (int(os.environ.get('PBSED_GRU_X3', '3')) >> (key == 'bptt_scan')) & 1 and h < 512
+            tf = fl / (ms * 1e-3) / 1e12
             g[key] = {'ms_per_step': round(ms, 4), 'launches_per_step': round(sum(r[1] for r in rows) / steps, 2),
-                      'gflop_per_step': round(fl / 1e9, 2), 'achieved': round(fl / (ms * 1e-3) / 1e12, 2),
-                      'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_TFLOPS['f32'], 4),
+                      'gflop_per_step': round(fl / 1e9, 2), 'achieved': round(tf, 2),
+                      'frac': round(tf / PEAK_TFLOPS['f32'], 4),
+                      'operands': 'bf16x3 (exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMA products per fp32 product)' if x3 else 'f32',
+                      'executed': round(tf * (6 if x3 else 1), 2),
+                      'frac_executed': round(tf * 6 / PEAK_TFLOPS['bf16'] if x3 else tf / PEAK_TFLOPS['f32'], 4),
                       'us_per_time_step': round(ms * 1e3 / (t * sum(r[1] for r in rows) / steps), 3)}
         if g:
-            g.update(bound='mfma (fp32 operands); latency-bound in practice: T dependent steps with an inter-workgroup hand-off each',
-                     peak=PEAK_TFLOPS['f32'], unit='TFLOP/s', shape=dict(chains=nch, layers=nl, T=t, B=b, H=h))
+            g.update(bound='mfma; latency-bound in practice: T dependent steps with an inter-workgroup hand-off each',
+                     note='achieved / frac: fp32-equivalent flops of the recurrence + layer-boundary projections over the fp32-MFMA peak; '
+                          'executed / frac_executed: what the MFMA pipe actually ran (bf16x3 scans: 6 bf16 products each, over the bf16 peak)',
+                     peak=PEAK_TFLOPS['f32'], peak_executed=PEAK_TFLOPS['bf16'], unit='TFLOP/s',
+                     shape=dict(chains=nch, layers=nl, T=t, B=b, H=h))
             out['roofline_gru'] = g
     fe = [v for k, v in agg.items() if k[0] in ('pbsed_logmel_fwd', 'pbsed_logmel_from_stft')]
     if fe:

@@ -51,6 +51,50 @@ __device__ __forceinline__ double wave_sum64d(double v) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// bf16x3 operands (GRU scans, GRU weight gradients).  An fp32 value splits EXACTLY into three bf16 parts
+// by truncation (8 + 8 + 8 significant bits: hi = the upper half of its word, the remainders are exact differences); the
+// product a*b is then accumulated from the six part products whose weight is above 2^-24 of |a||b| on the bf16 MFMA
+// (16x16x32: the wave's whole K = 32 slice in one instruction, ~17 clocks, against eight 32-clock fp32 MFMAs) with fp32
+// accumulation, smallest terms first - fp32-class accuracy (the three dropped products are below the fp32 rounding of the sum).
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+struct Bf3 {
+    u32x4_t hi, mid, lo;          // 8 values each, packed in the order of the poll's words: (n = 0: x y z w), (n = 1: x y z w)
+};
+__device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const unsigned u0 = __float_as_uint(v0), u1 = __float_as_uint(v1);
+    hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                     // (u1 & 0xffff0000) | (u0 >> 16)
+    const float r0 = v0 - __uint_as_float(u0 & 0xffff0000u), r1 = v1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned m0 = __float_as_uint(r0), m1 = __float_as_uint(r1);
+    mid = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    const float l0 = r0 - __uint_as_float(m0 & 0xffff0000u), l1 = r1 - __uint_as_float(m1 & 0xffff0000u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+}
+__device__ __forceinline__ Bf3 split3x8(float4 a, float4 b) {
+    unsigned h[4], m[4], l[4];
+    split3_pair(a.x, a.y, h[0], m[0], l[0]);
+    split3_pair(a.z, a.w, h[1], m[1], l[1]);
+    split3_pair(b.x, b.y, h[2], m[2], l[2]);
+    split3_pair(b.z, b.w, h[3], m[3], l[3]);
+    return Bf3{u32x4_t{h[0], h[1], h[2], h[3]}, u32x4_t{m[0], m[1], m[2], m[3]}, u32x4_t{l[0], l[1], l[2], l[3]}};
+}
+typedef float pbsed_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pbsed_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16_rne(float lo, float hi) {          // v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(pbsed_f32x2{lo, hi}, pbsed_bf16x2));
+}
+__device__ __forceinline__ f32x4 mfma_b16(u32x4_t a, u32x4_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gbf16x8, a), __builtin_bit_cast(gbf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_x3(const Bf3& a, const Bf3& b, f32x4 c) {
+    c = mfma_b16(a.lo, b.hi, c);
+    c = mfma_b16(a.hi, b.lo, c);
+    c = mfma_b16(a.mid, b.mid, c);
+    c = mfma_b16(a.mid, b.hi, c);
+    c = mfma_b16(a.hi, b.mid, c);
+    return mfma_b16(a.hi, b.hi, c);
+}
+
+
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 

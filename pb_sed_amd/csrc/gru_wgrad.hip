@@ -28,6 +28,9 @@ struct GruWgradArgs {
     float* db[GW_MAX];
     int shift_rows[GW_MAX];    // shift * B
     int TB, G, K, nsplit, rows_per_split;
+    // bf16-MFMA kernel: GEMMs of different K share a launch; blockIdx.y enumerates the (GEMM, column tile) pairs
+    int Ks[GW_MAX];
+    unsigned char y_gemm[4 * GW_MAX], y_tile[4 * GW_MAX];
 };
 
 template <int BN>
@@ -130,22 +133,198 @@ __global__ __launch_bounds__(BN * 2) void gru_wgrad_kernel(GruWgradArgs a) {
     if (blockIdx.y == 0 && m0 + tid % GW_BM < a.G && a.db[gemm]) unsafeAtomicAdd(a.db[gemm] + m0 + tid % GW_BM, bsum);
 }
 
+// The same GEMMs on the bf16 MFMA (16x16x32).  NS = 3: every fp32 operand is split exactly into three bf16 parts while it
+// is staged (Bf3 in common.h) and the six part products above 2^-24 are accumulated - fp32-class gradients at up to 2.6x
+// the fp32-MFMA rate; NS = 1: plain bf16 operands (the bf16 training mode of BASELINE config 3), HBM-bound.
+// The contraction index (t, b) is the slow dimension of both operands, the MFMA wants 8 consecutive contraction values per
+// lane: a staging thread therefore fetches an 8-row x 4-column block (8 coalesced float4 rows), converts it, and writes
+// each column's 8 values as ONE 16-byte LDS row.  LDS rows are stored at pos(c) = (c % 4) * (W / 4) + c / 4 of the tile's W
+// columns, so that the four rows a thread writes per part are conflict-free and an MFMA tile = 16 consecutive rows
+// (= columns c with the same c % 4, stride 4); the output indices follow the same bijection.
+constexpr int GB_BM = 128, GB_BN = 256, GB_KC = 32, GB_KG = GB_KC / 8;
+
+template <int NS>
+__global__ __launch_bounds__(512) void gru_wgrad_b16_kernel(GruWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32x4_t smem_b16[];
+    u32x4_t* As = smem_b16;                              // [NS][KG][BM] 16-byte rows (8 bf16 along the contraction index)
+    u32x4_t* Bs = smem_b16 + NS * GB_KG * GB_BM;         // [NS][KG][BN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lq = lane >> 4, lr = lane & 15;
+    const int wm = wave >> 2, wn = wave & 3;             // 2 x 4 waves, 64 x 64 outputs each
+    const int gemm = a.y_gemm[blockIdx.y], split = blockIdx.z, K = a.Ks[gemm];
+    const int m0 = blockIdx.x * GB_BM, n0 = a.y_tile[blockIdx.y] * GB_BN;
+    const float* __restrict__ dg = a.dg[gemm];
+    const float* __restrict__ x = a.x[gemm];
+    const int shift = a.shift_rows[gemm];
+    const int r_begin = split * a.rows_per_split, r_end = min(a.TB, r_begin + a.rows_per_split);
+    if (r_begin >= r_end) return;
+
+    // staging items: waves 0..1 (threads 0..127) one (8-row group, 4 gate columns) block of dG each, waves 2..5 one of X;
+    // the role is wave-uniform, the loads are raw buffer loads whose out-of-range rows / columns read 0 without a branch
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool is_a = wave_u < 2, is_b = wave_u >= 2 && wave_u < 6;
+    const int it = is_a ? tid : tid - GB_KG * (GB_BM / 4);
+    const int wq = is_a ? GB_BM / 4 : GB_BN / 4;         // column quads of the tile
+    const int kg = it / wq, jq = it % wq;
+    const int col = (is_a ? m0 : n0) + 4 * jq;
+    const int ld = is_a ? a.G : K;                     // row length of the operand
+    const bool col_ok = (is_a || is_b) && col < ld;
+    const int shift_u = is_a ? 0 : shift;
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(is_a ? dg : x), 0, (is_a || is_b) ? (unsigned)((size_t)a.TB * ld * 4) : 0u, 0x00020000);
+    // two stages of operand rows are in flight in registers (rv0 / rv1): a stage's loads are issued two iterations before
+    // they are converted, so a CU keeps ~100 KB of requests outstanding - the launch is bound by the fetch of its operands
+    u32x4_t rv0[8], rv1[8];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](u32x4_t (&rv)[8], int r0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = r0 + kg * 8 + rr, rs = r + shift_u;
+            const bool ok = col_ok && r < r_end && rs >= 0 && rs < a.TB;
+            rv[rr] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? (unsigned)(((size_t)rs * ld + col) * 4) : OOB, 0, 0);
+        }
+    };
+    auto stage = [&](const u32x4_t (&rv)[8]) __attribute__((always_inline)) {
+        if (!(is_a || is_b)) return;
+        u32x4_t* dst = (is_a ? As : Bs) + (size_t)kg * (4 * wq) + jq;
+        const int part_stride = GB_KG * 4 * wq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v[8];
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) v[rr] = __uint_as_float(i == 0 ? rv[rr].x : i == 1 ? rv[rr].y : i == 2 ? rv[rr].z : rv[rr].w);
+            if (is_a) bsum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            if constexpr (NS == 3) {
+                const Bf3 p = split3x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+                dst[i * wq] = p.hi; dst[part_stride + i * wq] = p.mid; dst[2 * part_stride + i * wq] = p.lo;
+            } else {
+                dst[i * wq] = u32x4_t{pack_bf16_rne(v[0], v[1]), pack_bf16_rne(v[2], v[3]), pack_bf16_rne(v[4], v[5]), pack_bf16_rne(v[6], v[7])};
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&]() __attribute__((always_inline)) {
+        u32x4_t af[4][NS];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int p = 0; p < NS; ++p) af[mi][p] = As[(size_t)(p * GB_KG + lq) * GB_BM + wm * 64 + mi * 16 + lr];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            u32x4_t bf[NS];
+#pragma unroll
+            for (int p = 0; p < NS; ++p) bf[p] = Bs[(size_t)(p * GB_KG + lq) * GB_BN + wn * 64 + ni * 16 + lr];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                if constexpr (NS == 3) {
+                    acc[mi][ni] = mfma_x3(Bf3{af[mi][0], af[mi][1], af[mi][2]}, Bf3{bf[0], bf[1], bf[2]}, acc[mi][ni]);
+                } else {
+                    acc[mi][ni] = mfma_b16(af[mi][0], bf[0], acc[mi][ni]);
+                }
+            }
+        }
+    };
+
+    fetch(rv0, r_begin);
+    fetch(rv1, r_begin + GB_KC);                         // rows past r_end read as zeros
+    for (int r0 = r_begin; r0 < r_end; r0 += 2 * GB_KC) {
+        __syncthreads();                                 // the previous stage's fragments have been read
+        stage(rv0);
+        __syncthreads();
+        fetch(rv0, r0 + 2 * GB_KC);
+        compute();
+        if (r0 + GB_KC >= r_end) break;
+        __syncthreads();
+        stage(rv1);
+        __syncthreads();
+        fetch(rv1, r0 + 3 * GB_KC);
+        compute();
+    }
+
+    float* __restrict__ dw = a.dw[gemm];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int pb = wn * 64 + ni * 16 + lr;                           // LDS row of the X tile -> column k
+            const int k = n0 + 4 * (pb % (GB_BN / 4)) + pb / (GB_BN / 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pa = wm * 64 + mi * 16 + lq * 4 + r;               // LDS row of the dG tile -> gate row g
+                const int g = m0 + 4 * (pa % (GB_BM / 4)) + pa / (GB_BM / 4);
+                if (g < a.G && k < K) unsafeAtomicAdd(dw + (size_t)g * K + k, acc[mi][ni][r]);
+            }
+        }
+    if (a.y_tile[blockIdx.y] == 0 && is_a && a.db[gemm]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (col + i < a.G) unsafeAtomicAdd(a.db[gemm] + col + i, bsum[i]);
+    }
+}
+
 }  // namespace pbsed
 
 using namespace pbsed;
 
-extern "C" int pbsed_gru_wgrad(int n, const float* const* dg, const float* const* x, const int* shift, float* const* dw,
-                               float* const* db, int T, int B, int G, int K, void* stream) {
-    if (n < 1 || n > GW_MAX || T < 1 || B < 1 || G < 4 || K < 4 || (G & 3) || (K & 3)) {
-        set_error("gru_wgrad: need 1 <= n <= %d, G and K multiples of 4 (n=%d G=%d K=%d)", GW_MAX, n, G, K);
+static int gru_wgrad_launch(int n, const float* const* dg, const float* const* x, const int* shift, float* const* dw,
+                            float* const* db, int T, int B, int G, const int* Ks, int operands, void* stream) {
+    if (n < 1 || n > GW_MAX || T < 1 || B < 1 || G < 4 || (G & 3)) {
+        set_error("gru_wgrad: need 1 <= n <= %d, G a multiple of 4 (n=%d G=%d)", GW_MAX, n, G);
         return PBSED_E_ARG;
     }
+    if (operands != 0 && operands != 1 && operands != 3) { set_error("gru_wgrad: operands %d (0 = f32, 1 = bf16, 3 = bf16x3)", operands); return PBSED_E_ARG; }
     GruWgradArgs a{};
+    int kmax = 0;
     for (int i = 0; i < n; ++i) {
+        if (Ks[i] < 4 || (Ks[i] & 3)) { set_error("gru_wgrad: K must be a multiple of 4 (K[%d]=%d)", i, Ks[i]); return PBSED_E_ARG; }
+        if (!operands && Ks[i] != Ks[0]) { set_error("gru_wgrad: the fp32-MFMA kernel takes one K per launch"); return PBSED_E_UNSUPPORTED; }
         a.dg[i] = dg[i]; a.x[i] = x[i]; a.dw[i] = dw[i]; a.db[i] = db ? db[i] : nullptr;
         a.shift_rows[i] = shift[i] * B;
+        a.Ks[i] = Ks[i];
+        kmax = Ks[i] > kmax ? Ks[i] : kmax;
     }
+    const int K = Ks[0];
     a.TB = T * B; a.G = G; a.K = K;
+    hipStream_t s = (hipStream_t)stream;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    if (operands) {
+        if ((size_t)a.TB * (G > kmax ? G : kmax) * 4 >= (1ull << 31)) { set_error("gru_wgrad: an operand of %d x %d floats exceeds the 2 GiB the loaders address", a.TB, G > kmax ? G : kmax); return PBSED_E_ARG; }
+        int ny = 0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < (Ks[i] + GB_BN - 1) / GB_BN; ++j) {
+                if (ny >= 4 * GW_MAX) { set_error("gru_wgrad: more than %d column tiles in one launch", 4 * GW_MAX); return PBSED_E_ARG; }
+                a.y_gemm[ny] = (unsigned char)i; a.y_tile[ny] = (unsigned char)j; ++ny;
+            }
+        // one block per CU (8 waves with 64 accumulator registers each): split the (t, b) reduction to one residency round
+        dim3 grid((G + GB_BM - 1) / GB_BM, ny, 1);
+        const int tiles = grid.x * ny;
+        int nsplit = n_cu / tiles;
+        const int max_split = (a.TB + 4 * GB_KC - 1) / (4 * GB_KC);
+        if (nsplit > max_split) nsplit = max_split;
+        if (nsplit < 1) nsplit = 1;
+        a.rows_per_split = ((a.TB + nsplit - 1) / nsplit + GB_KC - 1) / GB_KC * GB_KC;
+        a.nsplit = (a.TB + a.rows_per_split - 1) / a.rows_per_split;
+        grid.z = a.nsplit;
+        const size_t lds = (size_t)operands * GB_KG * (GB_BM + GB_BN) * sizeof(u32x4_t);
+        if (operands == 3) {
+            PBSED_DYN_LDS_ONCE(gru_wgrad_b16_kernel<3>, lds);
+            hipLaunchKernelGGL((gru_wgrad_b16_kernel<3>), grid, dim3(512), lds, s, a);
+        } else {
+            PBSED_DYN_LDS_ONCE(gru_wgrad_b16_kernel<1>, lds);
+            hipLaunchKernelGGL((gru_wgrad_b16_kernel<1>), grid, dim3(512), lds, s, a);
+        }
+        return check_launch("gru_wgrad");
+    }
     const bool wide = K > 128;
     const int bn = wide ? 256 : 128;
     dim3 grid((G + GW_BM - 1) / GW_BM, (K + bn - 1) / bn, 1);
@@ -154,9 +333,7 @@ extern "C" int pbsed_gru_wgrad(int n, const float* const* dg, const float* const
     const int tiles = grid.x * grid.y * n;
     static int target = 0;
     if (target == 0) {
-        int occ = 0, dev = 0, n_cu = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        int occ = 0;
         const hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gru_wgrad_kernel<256>, 512, 0)
                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gru_wgrad_kernel<128>, 256, 0);
         if (e != hipSuccess || occ < 1) occ = 2;
@@ -169,8 +346,26 @@ extern "C" int pbsed_gru_wgrad(int n, const float* const* dg, const float* const
     a.rows_per_split = ((a.TB + nsplit - 1) / nsplit + GW_KC - 1) / GW_KC * GW_KC;
     a.nsplit = (a.TB + a.rows_per_split - 1) / a.rows_per_split;
     grid.z = n * a.nsplit;
-    hipStream_t s = (hipStream_t)stream;
     if (wide) hipLaunchKernelGGL((gru_wgrad_kernel<256>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((gru_wgrad_kernel<128>), grid, dim3(256), 0, s, a);
     return check_launch("gru_wgrad");
+}
+
+static int x3_default() {
+    static const int x3 = [] { const char* e = getenv("PBSED_GRU_WGRAD_X3"); return e ? atoi(e) : 1; }();
+    return x3 ? 3 : 0;
+}
+
+// PBSED_GRU_WGRAD_X3 (default 1): the fp32 entry points run the bf16x3 kernel (fp32-class results, see gru_wgrad_b16_kernel)
+extern "C" int pbsed_gru_wgrad(int n, const float* const* dg, const float* const* x, const int* shift, float* const* dw,
+                               float* const* db, int T, int B, int G, int K, void* stream) {
+    int Ks[GW_MAX];
+    for (int i = 0; i < GW_MAX; ++i) Ks[i] = K;
+    return gru_wgrad_launch(n, dg, x, shift, dw, db, T, B, G, Ks, x3_default(), stream);
+}
+
+extern "C" int pbsed_gru_wgrad_multi(int n, const float* const* dg, const float* const* x, const int* shift, float* const* dw,
+                                     float* const* db, int T, int B, int G, const int* K, int bf16, void* stream) {
+    if (!K) { set_error("gru_wgrad_multi: K is null"); return PBSED_E_ARG; }
+    return gru_wgrad_launch(n, dg, x, shift, dw, db, T, B, G, K, bf16 ? 1 : x3_default(), stream);
 }

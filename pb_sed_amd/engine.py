@@ -320,7 +320,7 @@ def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     w_ih_up_t = [ops.transpose2d(ch.p('weight_ih', l + 1).detach()) if l + 1 < nl else None for ch, l in idx]
     dgi, dgh = ops.gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, [ch.reverse for ch in chains], seq_dev, nl)
     dh = None
-    jobs = {}                                    # K -> (dg, x, shift, dw, db) lists of one batched weight-gradient launch
+    jobs = ([], [], [], [], [])                  # all weight gradients of the stacks: one launch
     h_tbc = None
     for ci, ch in enumerate(chains):
         for l in range(nl):
@@ -336,15 +336,14 @@ def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
                 pr = _prec(precision, pcs0[ci].cin)
                 dx, _ = ops.conv_bwd_data(ops.tbc_to_bct(dgi[i]), pcs0[ci], pcs0[ci].dgrad(pr), h.shape, precision=pr)
                 dh = dx if dh is None else dh.add_(dx)
-    for job in jobs.values():
-        for a in range(0, len(job[0]), 16):
-            ops.gru_wgrad(*[v[a:a + 16] for v in job])
+    if jobs[0]:
+        ops.gru_wgrad(*jobs, precision='bf16' if precision == 'bf16' else 'f32')
     return dh
 
 
 def _wgrad_job(jobs, dg, x, shift, dw, db):
-    job = jobs.setdefault(x.shape[2], ([], [], [], [], []))
-    for lst, v in zip(job, (dg, x, shift, dw, db)):
+    """``jobs``: (dg, x, shift, dw, db) lists of ONE batched weight-gradient launch (ops.gru_wgrad) per backward pass."""
+    for lst, v in zip(jobs, (dg, x, shift, dw, db)):
         lst.append(v)
 
 
@@ -403,6 +402,7 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
         layers, c = head_ctx[wi]
         d_out.append(stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True))
     dh_in = None
+    jobs = ([], [], [], [], [])                  # weight gradients of ALL layers: one launch after the last scan
     for l in reversed(range(num_layers)):
         x_w, pcs, hs, save = layer_ctx[l]
         dy = []
@@ -416,7 +416,7 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
         else:
             dgi, dgh = ops.gru_scan_bwd(w_hh_t, hs, save, dy, [ch.reverse for ch in chains], seq_dev)
         dx_w = [None for _ in wrappers]
-        jobs, x_tbc = {}, {}                       # batched time-major weight-gradient launches (ops.gru_wgrad)
+        x_tbc = {}                                 # the layer input once per wrapper, time-major
         for i, ch in enumerate(chains):
             w_hh, w_ih = ch.p('weight_hh', l), ch.p('weight_ih', l)
             dgi_b = ops.tbc_to_bct(dgi[i])
@@ -433,15 +433,14 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
             pr = _prec(precision, pcs[i].cin)
             dx, _ = ops.conv_bwd_data(dgi_b, pcs[i], pcs[i].dgrad(pr), x_w[ch.widx].shape, precision=pr)
             dx_w[ch.widx] = dx if dx_w[ch.widx] is None else dx_w[ch.widx].add_(dx)
-        for job in jobs.values():
-            for a in range(0, len(job[0]), 16):
-                ops.gru_wgrad(*[v[a:a + 16] for v in job])
         if l > 0:
             d_out = dx_w
         else:
             dh_in = dx_w[0]
             for d in dx_w[1:]:
                 dh_in = dh_in.add_(d)
+    if jobs[0]:
+        ops.gru_wgrad(*jobs, precision='bf16' if precision == 'bf16' else 'f32')
     return dh_in
 
 

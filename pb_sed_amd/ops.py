@@ -601,14 +601,24 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
     return dgi, dgh
 
 
-def gru_wgrad(dg, x, shift, dw, db):
-    """dw[i] += dg[i]^T x[i] (time shift shift[i] on x), db[i] += column sums of dg[i]; all time-major [T,B,*]."""
+def gru_wgrad(dg, x, shift, dw, db, precision='f32'):
+    """dw[i] += dg[i]^T x[i] (time shift shift[i] on x), db[i] += column sums of dg[i]; all time-major [T,B,*]; the x[i] may
+    differ in width (all weight gradients of a GRU backward pass go in one launch, at most 16 per launch).
+    'f32': fp32-class products (exact bf16x3 operand splits on the bf16 MFMA); 'bf16': plain bf16 operands."""
     t, b, g = dg[0].shape
-    k = x[0].shape[2]
-    assert all(d.shape == (t, b, g) and d.is_contiguous() for d in dg) and all(v.shape == (t, b, k) and v.is_contiguous() for v in x)
-    assert all(w.shape == (g, k) and w.is_contiguous() for w in dw)
-    call('pbsed_gru_wgrad', len(dg), _lib.ptr_array(dg), _lib.ptr_array(x), _lib.int_array(shift), _lib.ptr_array(dw),
-         _lib.ptr_array(db), t, b, g, k, stream(), flops=2. * len(dg) * t * b * g * k)
+    ks = [v.shape[2] for v in x]
+    assert all(d.shape == (t, b, g) and d.is_contiguous() for d in dg) and all(v.shape[:2] == (t, b) and v.is_contiguous() for v in x)
+    assert all(w.shape == (g, k) and w.is_contiguous() for w, k in zip(dw, ks))
+    if precision != 'bf16' and os.environ.get('PBSED_GRU_WGRAD_X3', '1') == '0' and len(set(ks)) > 1:
+        for k in sorted(set(ks)):                       # the fp32-MFMA kernel takes one input width per launch
+            sel = [i for i, v in enumerate(ks) if v == k]
+            gru_wgrad(*[[lst[i] for i in sel] for lst in (dg, x, shift, dw, db)], precision=precision)
+        return
+    for a in range(0, len(dg), 16):
+        sl = slice(a, a + 16)
+        call('pbsed_gru_wgrad_multi', len(dg[sl]), _lib.ptr_array(dg[sl]), _lib.ptr_array(x[sl]), _lib.int_array(shift[sl]),
+             _lib.ptr_array(dw[sl]), _lib.ptr_array(db[sl]), t, b, g, _lib.int_array(ks[sl]), int(precision == 'bf16'), stream(),
+             flops=2. * t * b * g * sum(ks[sl]))
 
 
 def squash_fwd(x, eps):

@@ -477,21 +477,25 @@ def test_conv_wgrad_bf16_vs_torch(case):
     close(out['bf16'][1], bias.grad, atol=.25, rtol=2e-2, name='conv_bgrad bf16')      # sums of bf16-rounded dY
 
 
-@pytest.mark.parametrize('t,b,g,k', [(23, 5, 192, 24), (30, 32, 768, 256), (17, 19, 384, 128), (9, 3, 12, 8)])
-def test_gru_wgrad_vs_torch(t, b, g, k):
-    """Batched time-major weight/bias gradient GEMM (with the h_{t-1} / h_{t+1} row shift) vs fp64 einsum."""
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+@pytest.mark.parametrize('t,b,g,k', [(23, 5, 192, 24), (30, 32, 768, 256), (17, 19, 384, 128), (9, 3, 12, 8), (500, 32, 768, 512)])
+def test_gru_wgrad_vs_torch(t, b, g, k, precision):
+    """Batched time-major weight/bias gradient GEMM (with the h_{t-1} / h_{t+1} row shift) vs fp64 einsum.  'f32' = exact
+    bf16x3 operand splits on the bf16 MFMA: held to the fp32 tolerance; 'bf16': operands rounded to bf16 (2^-9 each)."""
     from pb_sed_amd import ops
     torch.manual_seed(7)
     shifts = [0, -1, 1]
+    ks = [k, k, 2 * k]                                  # GEMMs of different input width share the launch
     dg = [torch.randn(t, b, g) for _ in shifts]
-    x = [torch.randn(t, b, k) for _ in shifts]
-    dw0 = [torch.randn(g, k) for _ in shifts]
+    x = [torch.randn(t, b, kk) for kk in ks]
+    dw0 = [torch.randn(g, kk) for kk in ks]
     db0 = [torch.randn(g) for _ in shifts]
     dw = [w.to(DEV) for w in dw0]
     db = [v.to(DEV) for v in db0[:2]] + [None]
-    ops.gru_wgrad([d.to(DEV) for d in dg], [v.to(DEV) for v in x], shifts, dw, db)
+    ops.gru_wgrad([d.to(DEV) for d in dg], [v.to(DEV) for v in x], shifts, dw, db, precision=precision)
+    tol = 2e-5 if precision == 'f32' else 2e-2
     for i, sh in enumerate(shifts):
-        xs = torch.zeros(t, b, k, dtype=torch.float64)
+        xs = torch.zeros(t, b, ks[i], dtype=torch.float64)
         if sh == 0:
             xs[:] = x[i]
         elif sh < 0:
@@ -499,7 +503,7 @@ def test_gru_wgrad_vs_torch(t, b, g, k):
         else:
             xs[:-1] = x[i][1:]
         ref = dw0[i].double() + torch.einsum('tbg,tbk->gk', dg[i].double(), xs)
-        close(dw[i], ref.float(), atol=2e-5 * (t * b) ** .5, rtol=1e-5, name=f'gru_wgrad dW shift {sh}')
+        close(dw[i], ref.float(), atol=tol * (t * b) ** .5, rtol=1e-5, name=f'gru_wgrad dW shift {sh}')
         if db[i] is not None:
             close(db[i], (db0[i].double() + dg[i].double().sum((0, 1))).float(), atol=2e-5 * (t * b) ** .5, rtol=1e-5,
                   name=f'gru_wgrad db shift {sh}')

@@ -23,7 +23,7 @@ def timed(fn, n=50):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for cin, cout, kw in ((256, 256, 1), (256, 256, 3), (2048, 256, 3), (256, 768, 1), (256, 10, 1)):
+for cin, cout, kw in ((256, 256, 1), (256, 256, 3), (2048, 256, 1), (256, 768, 1), (256, 10, 1)):
     w = torch.randn(cout, cin, kw, device=dev) * 0.05
     pc = ops.PackedConv(w)
     wp, wd = pc._pack(0), pc._pack(1)
@@ -42,6 +42,11 @@ for cin, cout, kw in ((256, 256, 1), (256, 256, 3), (2048, 256, 3), (256, 768, 1
     ]
     print(f'--- {cin}->{cout} k{kw}: {gf:.2f} GFLOP, ideal {gf / 157.3 * 1e3:.1f} us MFMA, '
           f'{(x.numel() + g.numel()) * 4 / 5e6:.1f} us HBM@5TB/s')
+    if cin >= 32 and cout >= 32:
+        for prec in ('bf16', 'bf16x3'):
+            wpb, wdb = pc._pack_bf16(0, ops.NSPLIT[prec]), pc._pack_bf16(1, ops.NSPLIT[prec])
+            rows += [(prec + ' +both', lambda wpb=wpb, prec=prec: ops.conv_fwd(x, pc, wpb, bias, sc, sh, True, seq_len=seq, want_stats=True, precision=prec)),
+                     (prec + ' dgrad+bn', lambda wdb=wdb, prec=prec: ops.conv_bwd_data(g, pc, wdb, x.shape, seq_len=seq, bn=(x, sh, sc, sc, sh), precision=prec))]
     for name, fn in rows:
         us = timed(fn)
-        print(f'{name:12s} {us:7.1f} us  {gf / us * 1e3:6.1f} TFLOP/s')
+        print(f'{name:16s} {us:7.1f} us  {gf / us * 1e3:6.1f} TFLOP/s')
