@@ -401,9 +401,53 @@ __device__ __forceinline__ void wait_own_granules(unsigned (&q)[NQ], const gu32*
 // waves.  Vector memory operations of a wave complete in issue order, so a wave that publishes h_t with a write-through
 // store and then polls for step t + 1 waits for that store's acknowledgement (0.35 us/step) before its poll counts as
 // returned; with GW the polling waves never store and the publishing waves never poll on the critical path.
-template <int KB, int NW, bool GW, bool X3 = false>
+// NB: 16-row batch tiles per block (1, or 2 for more than 32 clips: the rings of 64 clips then need 192 instead of 384
+// co-resident blocks and stay one launch; a block's two tiles share the W fragments, their polls are issued together).
+template <int NL, int NB>
+__device__ __forceinline__ void poll_tiles(float4 (&out)[NB][NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned tile_stride,
+                                           unsigned parity, const bool (&valid)[NB], unsigned* err_flag) {
+    u32x4_t q[NB][NL];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int n = 0; n < NL; ++n) q[nb][n] = u32x4_t{0u, 0u, 0u, 0u};
+    for (int spin = 0;; ++spin) {
+        unsigned all1 = 1u, any1 = 0u;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            if (valid[nb]) {
+#pragma unroll
+                for (int n = 0; n < NL; ++n)
+                    q[nb][n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + nb * tile_stride + n * 1024, 0, /*aux = sc1*/ 16);
+            }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            if (valid[nb]) {
+#pragma unroll
+                for (int n = 0; n < NL; ++n) {
+                    all1 &= q[nb][n].x & q[nb][n].y & q[nb][n].z & q[nb][n].w;
+                    any1 |= q[nb][n].x | q[nb][n].y | q[nb][n].z | q[nb][n].w;
+                }
+            }
+        const bool ok = parity ? (all1 & 1u) != 0u : (any1 & 1u) == 0u;
+        if (__all(ok)) break;
+        if (spin > (1 << 18)) {                     // bounded: raise the error flag and go on with garbage
+            __hip_atomic_store((gu32*)err_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        if (spin > 8) __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int n = 0; n < NL; ++n)
+            out[nb][n] = make_float4(__uint_as_float(q[nb][n].x & ~1u), __uint_as_float(q[nb][n].y & ~1u),
+                                     __uint_as_float(q[nb][n].z & ~1u), __uint_as_float(q[nb][n].w & ~1u));
+}
+
+template <int KB, int NW, bool GW, bool X3 = false, int NB = 1>
 __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsigned* gran_h_, unsigned* gran_gi_, unsigned epoch,
-                                                     unsigned* err_flag, float (&red)[2][NW][3][64][4], int& s_err) {
+                                                     unsigned* err_flag, float (&red)[2][NW][NB][3][64][4], int& s_err) {
     constexpr int H = KB * NW * 16, NL = KB;           // NL: 16-byte loads per lane (16 k each) of this wave's H/NW range
     constexpr int GWV = GW ? 4 : 0;
     const GranuleRole role = granule_role(a);
@@ -413,22 +457,28 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
     const GruStackLayer& L = a.lc[chain][layer];
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) - GWV, lq = lane >> 4, lr = lane & 15;
     const bool is_mfma = wave >= 0;               // GW: waves 0..3 of the block only run the gate phase
-    const int j0 = role.bx * 16, b0 = role.by * 16, B = a.B;
+    const int j0 = role.bx * 16, b0 = role.by * 16 * NB, B = a.B;
     const bool rev = a.reverse[chain] != 0;
     const int Bp = (B + 15) / 16 * 16;                       // the tile-major h array holds whole batch tiles
     const size_t per_cl = (size_t)a.T * Bp * H, per_cl_b = (size_t)a.T * B * H;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(gran_h_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 4), 0x00020000);
     const unsigned parity = epoch & 1u;
-    // ring: h_t, tile-major; this block's tile of step t starts at g_own + t * Bp * H
-    gu32* g_own = (gu32*)gran_h_ + (size_t)(chain * a.nlayers + layer) * per_cl + ((size_t)role.by * (H / 16) + role.bx) * 256;
+    // ring: h_t, tile-major; this block's first tile of step t starts at g_own + t * Bp * H, the next one H * 16 words on
+    gu32* g_own = (gu32*)gran_h_ + (size_t)(chain * a.nlayers + layer) * per_cl + ((size_t)role.by * NB * (H / 16) + role.bx) * 256;
     gu32* g_gi = (gu32*)gran_gi_ + (size_t)(chain * (a.nlayers - 1) + (layer > 0 ? layer - 1 : 0)) * per_cl_b * 3;  // [T][B][3][H]
-    const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
-    const bool bv = tid < 256 && b < B;
-    const bool rowv = (b0 + lr) < B;
+    const int u = tid & 15, bb = tid >> 4, j = j0 + u;
+    int b[NB], sl[NB];
+    bool bv[NB], rowv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        b[nb] = b0 + nb * 16 + bb;
+        bv[nb] = tid < 256 && b[nb] < B;
+        rowv[nb] = (b0 + nb * 16 + lr) < B;
+        sl[nb] = bv[nb] ? a.seq_len[b[nb]] : 0;
+    }
     const float* bias = is_proj ? L.b_ih : L.b_hh;
     const float bs_r = bias[j0 + u], bs_z = bias[H + j0 + u], bs_n = bias[2 * H + j0 + u];
-    const int sl = bv ? a.seq_len[b] : 0;
     // every wave contracts its H/NW slice of K; within it a lane owns k = k0 + n*16 + lq*4 + {0..3} (the poll's
     // load pattern) and the weights follow the same order
     const int k0 = (is_mfma ? wave : 0) * NL * 16;
@@ -456,17 +506,26 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
     }
     // a projection reads h_t of the layer below, a ring its own h_{t-1}
     const unsigned cl_src = chain * a.nlayers + (is_proj ? layer - 1 : layer);
-    const unsigned voff0 = (unsigned)(((size_t)cl_src * per_cl + (size_t)role.by * 16 * H + (k0 / 16) * 256 + lr * 16 + lq * 4) * 4);
+    const unsigned voff0 = (unsigned)(((size_t)cl_src * per_cl + (size_t)role.by * NB * 16 * H + (k0 / 16) * 256 + lr * 16 + lq * 4) * 4);
     const unsigned step_t = (unsigned)(Bp * H * 4);           // bytes per time step of one (chain, layer)
-    float h_reg = 0.f;
+    constexpr unsigned tile_bytes = 16u * H * 4u;            // one batch tile of one step
+    float h_reg[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) h_reg[nb] = 0.f;
     const PollPacer pacer{(GW || threadIdx.x >= 256) ? a.poll_delay : a.poll_delay_gate};
     if (tid == 0) s_err = 0;
     __syncthreads();
-    float gn_r = 0.f, gn_z = 0.f, gn_n = 0.f;
+    float gn_r[NB], gn_z[NB], gn_n[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) gn_r[nb] = gn_z[nb] = gn_n[nb] = 0.f;
     auto load_gi = [&](int st) {                    // first layer: input projection computed before the scan
-        if (bv && layer == 0) {
-            const float* gi = L.gi + ((size_t)(rev ? a.T - 1 - st : st) * B + b) * 3 * H;
-            gn_r = gi[j]; gn_z = gi[H + j]; gn_n = gi[2 * H + j];
+        if (layer == 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                if (bv[nb]) {
+                    const float* gi = L.gi + ((size_t)(rev ? a.T - 1 - st : st) * B + b[nb]) * 3 * H;
+                    gn_r[nb] = gi[j]; gn_z[nb] = gi[H + j]; gn_n[nb] = gi[2 * H + j];
+                }
         }
     };
     load_gi(0);
@@ -476,64 +535,81 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
         const int tp = rev ? t + 1 : t - 1;
         const bool has_prev = step > 0;
         const int par = step & 1;                     // `red` is double-buffered: one barrier per step
-        const size_t tb = (size_t)t * B + b;
-        float gi_r = gn_r, gi_z = gn_z, gi_n = gn_n;
+        float gi_r[NB], gi_z[NB], gi_n[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { gi_r[nb] = gn_r[nb]; gi_z[nb] = gn_z[nb]; gi_n[nb] = gn_n[nb]; }
         // another block's time-out is looked for every 32 steps only: the agent-scope load stalls its wave
         if (tid == 0 && (step & 31) == 31 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
-        f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        float4 x[NL];
+        f32x4 acc[NB][3];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[nb][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float4 x[NB][NL];
         const bool contract = (is_proj || has_prev) && is_mfma;
         if (contract) {
             pacer.wait();
-            poll_batch<NL>(x, rsrc, voff0 + (unsigned)(is_proj ? t : tp) * step_t, parity, rowv, err_flag);
+            poll_tiles<NL, NB>(x, rsrc, voff0 + (unsigned)(is_proj ? t : tp) * step_t, tile_bytes, parity, rowv, err_flag);
         }
         // requests issued behind the poll (loads return in order, anything older would hold the poll back):
         // next step's input projection (first layer) / this step's projected input granules (other rings)
-        unsigned qg[3] = {0, 0, 0};
-        const gu32* gp = g_gi + tb * 3 * H + j;
-        if (!is_proj && layer > 0 && bv) {
+        unsigned qg[NB][3];
 #pragma unroll
-            for (int g = 0; g < 3; ++g) qg[g] = __hip_atomic_load(gp + (size_t)g * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int nb = 0; nb < NB; ++nb) {
+            qg[nb][0] = qg[nb][1] = qg[nb][2] = 0u;
+            if (!is_proj && layer > 0 && bv[nb]) {
+                const gu32* gp = g_gi + ((size_t)t * B + b[nb]) * 3 * H + j;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) qg[nb][g] = __hip_atomic_load(gp + (size_t)g * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         if (step + 1 < a.T) load_gi(step + 1);
         if (contract) {
-            if constexpr (X3) {
 #pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    const Bf3 xs = split3x8(x[2 * m], 2 * m + 1 < NL ? x[2 * m + 1] : make_float4(0.f, 0.f, 0.f, 0.f));
+            for (int nb = 0; nb < NB; ++nb) {
+                if constexpr (X3) {
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) acc[g] = mfma_x3(w3[m][g], xs, acc[g]);
-                }
-            } else {
+                    for (int m = 0; m < NM; ++m) {
+                        const Bf3 xs = split3x8(x[nb][2 * m], 2 * m + 1 < NL ? x[nb][2 * m + 1] : make_float4(0.f, 0.f, 0.f, 0.f));
 #pragma unroll
-                for (int n = 0; n < NL; ++n)
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) {
-                        acc[g] = mfma16(wv[n][g].x, x[n].x, acc[g]);
-                        acc[g] = mfma16(wv[n][g].y, x[n].y, acc[g]);
-                        acc[g] = mfma16(wv[n][g].z, x[n].z, acc[g]);
-                        acc[g] = mfma16(wv[n][g].w, x[n].w, acc[g]);
+                        for (int g = 0; g < 3; ++g) acc[nb][g] = mfma_x3(w3[m][g], xs, acc[nb][g]);
                     }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NL; ++n)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            acc[nb][g] = mfma16(wv[n][g].x, x[nb][n].x, acc[nb][g]);
+                            acc[nb][g] = mfma16(wv[n][g].y, x[nb][n].y, acc[nb][g]);
+                            acc[nb][g] = mfma16(wv[n][g].z, x[nb][n].z, acc[nb][g]);
+                            acc[nb][g] = mfma16(wv[n][g].w, x[nb][n].w, acc[nb][g]);
+                        }
+                }
             }
         }
         if (is_mfma) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                red[par][wave][0][lane][r] = acc[0][r];
-                red[par][wave][1][lane][r] = acc[1][r];
-                red[par][wave][2][lane][r] = acc[2][r];
-            }
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    red[par][wave][nb][0][lane][r] = acc[nb][0][r];
+                    red[par][wave][nb][1][lane][r] = acc[nb][1][r];
+                    red[par][wave][nb][2][lane][r] = acc[nb][2][r];
+                }
         }
         __syncthreads();
         if (s_err) return;                            // some hand-off timed out
-        if (bv) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (!bv[nb]) continue;
+            const size_t tb = (size_t)t * B + b[nb];
             const int src = (u >> 2) * 16 + bb, reg = u & 3;
             float s[3] = {bs_r, bs_z, bs_n};
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                s[0] += red[par][w][0][src][reg];
-                s[1] += red[par][w][1][src][reg];
-                s[2] += red[par][w][2][src][reg];
+                s[0] += red[par][w][nb][0][src][reg];
+                s[1] += red[par][w][nb][1][src][reg];
+                s[2] += red[par][w][nb][2][src][reg];
             }
             if (is_proj) {
                 gu32* dst = g_gi + tb * 3 * H + j;
@@ -541,18 +617,18 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
                 for (int g = 0; g < 3; ++g) publish(dst + (size_t)g * H, tag_clear(s[g]), parity);
             } else {
                 if (layer > 0) {
-                    wait_own_granules<3>(qg, gp, (size_t)H, parity, err_flag);
-                    gi_r = __uint_as_float(qg[0] & ~1u); gi_z = __uint_as_float(qg[1] & ~1u);
-                    gi_n = __uint_as_float(qg[2] & ~1u);
+                    wait_own_granules<3>(qg[nb], g_gi + tb * 3 * H + j, (size_t)H, parity, err_flag);
+                    gi_r[nb] = __uint_as_float(qg[nb][0] & ~1u); gi_z[nb] = __uint_as_float(qg[nb][1] & ~1u);
+                    gi_n[nb] = __uint_as_float(qg[nb][2] & ~1u);
                 }
                 const float ghn = s[2];
-                const float r = 1.f / (1.f + expf(-(gi_r + s[0])));
-                const float z = 1.f / (1.f + expf(-(gi_z + s[1])));
-                const float n = tanhf(gi_n + r * ghn);
-                const float hp = h_reg;
-                const float h = tag_clear((t < sl) ? (1.f - z) * n + z * hp : 0.f);    // the state IS the truncated value
-                h_reg = h;
-                publish(g_own + (size_t)t * Bp * H + bb * 16 + u, h, parity);
+                const float r = 1.f / (1.f + expf(-(gi_r[nb] + s[0])));
+                const float z = 1.f / (1.f + expf(-(gi_z[nb] + s[1])));
+                const float n = tanhf(gi_n[nb] + r * ghn);
+                const float hp = h_reg[nb];
+                const float h = tag_clear((t < sl[nb]) ? (1.f - z) * n + z * hp : 0.f);    // the state IS the truncated value
+                h_reg[nb] = h;
+                publish(g_own + (size_t)t * Bp * H + (size_t)nb * (H / 16) * 256 + bb * 16 + u, h, parity);
                 L.hs[tb * H + j] = h;
                 if (L.save) {
                     // what BPTT multiplies dh_t with: d(r,z,n pre-activations)/dh, d(gh_n)/dh and z (granule save format)
@@ -570,17 +646,18 @@ template <int KB, int NW>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gru_granule_fwd_kernel(GruStackArgs a, unsigned* gran_h_,
                                                                  unsigned* gran_gi_, unsigned epoch,
                                                                  unsigned* err_flag) {
-    __shared__ float red[2][NW][3][64][4];
+    __shared__ float red[2][NW][1][3][64][4];
     __shared__ int s_err;
     gru_granule_fwd_body<KB, NW, false>(a, gran_h_, gran_gi_, epoch, err_flag, red, s_err);
 }
 
-template <int KB, int NW, bool X3>
+template <int KB, int NW, bool X3, int NB>
 __global__ __launch_bounds__((NW + 4) * 64) void gru_granule_fwd_gw_kernel(GruStackArgs a, unsigned* gran_h_, unsigned* gran_gi_,
                                                                          unsigned epoch, unsigned* err_flag) {
-    __shared__ float red[2][NW][3][64][4];
+    extern __shared__ __attribute__((aligned(16))) float red_dyn[];          // [2][NW][NB][3][64][4]: over 64 KB for NB = 2
     __shared__ int s_err;
-    gru_granule_fwd_body<KB, NW, true, X3>(a, gran_h_, gran_gi_, epoch, err_flag, red, s_err);
+    auto& red = *reinterpret_cast<float (*)[2][NW][NB][3][64][4]>(red_dyn);
+    gru_granule_fwd_body<KB, NW, true, X3, NB>(a, gran_h_, gran_gi_, epoch, err_flag, red, s_err);
 }
 
 // Backward twin.  Rings publish dh_t (masked by the sequence length) of their 16 units as granules [T][B][H];
@@ -841,7 +918,19 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
 // with one (12-wave, register-heavy) block per CU a ring pinned to an XCD can fill its 32 CUs and lock the projection
 // blocks of that XCD out (found by tests/sweeps/fuzz_gru.py: H = 512, B = 16).  The caller then keeps the 3-D grid, whose
 // blocks spread evenly over the XCDs.
-static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid) {
+static int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        if (cus < 8) cus = 8;
+    }
+    return cus;
+}
+
+// nb: 16-row batch tiles per block
+static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid, int nb = 1) {
     static int cus_per_xcd = 0;
     if (cus_per_xcd == 0) {
         int dev = 0;
@@ -850,7 +939,7 @@ static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid) {
                           ? prop.multiProcessorCount / 8 : 32;
         if (cus_per_xcd < 1) cus_per_xcd = 1;
     }
-    const int nby = (a.B + 15) / 16, nj = H / 16;
+    const int nby = (a.B + 16 * nb - 1) / (16 * nb), nj = H / 16;
     const int R = a.nchains * a.nlayers * nby, P = a.nchains * (a.nlayers - 1) * nby;
     const int slots = (R + 7) / 8 * nj + (P * nj + 7) / 8;
     if (slots > cus_per_xcd) return false;
@@ -861,20 +950,22 @@ static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid) {
 }
 
 // PBSED_GRU_POLL_DELAYS="fwd,fwd_gate,bwd,bwd_gate" overrides the measured defaults (PollPacer).
-static void granule_poll_delays(bool bwd, GruStackArgs& a) {
+static void granule_poll_delays(bool bwd, GruStackArgs& a, int nb = 1) {
     // measured with the tile-major exchange arrays and bf16x3 products (tools/sweep_poll_delays.sh, B = 32, H = 256, T = 500).
     // Two-layer stacks (FBCRNN): forward 21 1.28 ms, 23 0.99, 24 0.94, 25 0.97, 26 1.04, 27 1.10; BPTT 14 1.37, 16 1.35,
     // 18..22 1.334, 24 1.36, 28 1.43.  One-layer scans (the BiGRU layers of the BiCRNN, two launches): forward 20 2.40,
     // 22 1.82, 23 1.78, 24 1.80, 26 1.90; BPTT 8 2.48, 14..17 2.44, 20 2.51, 26 2.70.
-    static int d[4] = {24, 6, 20, 0}, d1[4] = {24, 6, 15, 0};
+    // Two batch tiles per block (forward, 64 clips, two-layer stacks): 24 2.25 ms, 36 1.93, 40 1.79, 44 1.77, 48 1.80, 64 1.88
+    // (the two per-chain launches it replaces: 1.90 ms).
+    static int d[4] = {24, 6, 20, 0}, d1[4] = {24, 6, 15, 0}, d2[4] = {44, 6, 20, 0};
     static const bool parsed = [] {
         if (const char* e = getenv("PBSED_GRU_POLL_DELAYS"))
             if (sscanf(e, "%d,%d,%d,%d", &d[0], &d[1], &d[2], &d[3]) == 4)
-                for (int i = 0; i < 4; ++i) d1[i] = d[i];
+                for (int i = 0; i < 4; ++i) d1[i] = d2[i] = d[i];
         return true;
     }();
     (void)parsed;
-    const int* use = a.nlayers == 1 ? d1 : d;
+    const int* use = nb == 2 ? d2 : a.nlayers == 1 ? d1 : d;
     a.poll_delay = use[bwd ? 2 : 0];
     a.poll_delay_gate = use[bwd ? 3 : 1];
 }
@@ -913,25 +1004,32 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
     }
     a.seq_len = seq_len; a.B = B; a.T = T; a.nchains = nchains; a.nlayers = nlayers;
     const int ngroups = nchains * (2 * nlayers - 1);     // rings + projection groups (see GranuleRole)
-    granule_poll_delays(false, a);
-    dim3 grid(H / 16, (B + 15) / 16, ngroups);
-    if (granule_ring_xcd(false)) granule_xcd_grid(a, H, &grid);
-    unsigned* gran_gi = granules + (size_t)nchains * nlayers * T * Bp * H;
-    hipStream_t s = (hipStream_t)stream;
     // PBSED_GRU_GW: bit 0 forward / bit 1 BPTT scan with dedicated gate waves (default both; 1.35 -> 1.21 ms and
     // 1.65 -> 1.49 ms at B = 32, H = 256, T = 500)
     static const int gw = [] { const char* e = getenv("PBSED_GRU_GW"); return e ? atoi(e) : 3; }();
     // PBSED_GRU_X3: bit 0 = forward / bit 1 = BPTT scan with bf16x3 operands on the bf16 MFMA (see Bf3; default both:
     // forward 1.13 -> 0.94 ms, BPTT 1.40 -> 1.33 ms at B = 32, H = 256, T = 500)
     static const int x3 = [] { const char* e = getenv("PBSED_GRU_X3"); return e ? atoi(e) : 3; }();
+    // every block has to be co-resident (one per CU, 7/8 of the device at most): past that, two batch tiles per block
+    const int nb = ((gw & 1) && ngroups * (H / 16) * ((B + 15) / 16) > device_cus() * 7 / 8) ? 2 : 1;
+    granule_poll_delays(false, a, nb);
+    dim3 grid(H / 16, (B + 16 * nb - 1) / (16 * nb), ngroups);
+    if (granule_ring_xcd(false)) granule_xcd_grid(a, H, &grid, nb);
+    unsigned* gran_gi = granules + (size_t)nchains * nlayers * T * Bp * H;
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_GW(KB_, NW_, X3_, NB_)                                                                                  \
+    do {                                                                                                             \
+        auto kern = gru_granule_fwd_gw_kernel<KB_, NW_, X3_, NB_>;                                                   \
+        const size_t lds = (size_t)2 * NW_ * NB_ * 3 * 64 * 4 * sizeof(float);                                       \
+        PBSED_DYN_LDS_ONCE(kern, lds);                                                                               \
+        hipLaunchKernelGGL(kern, grid, dim3((NW_ + 4) * 64), lds, s, a, granules, gran_gi, epoch, err_flag);         \
+    } while (0)
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
     do {                                                                                                             \
-        if ((gw & 1) && (x3 & 1)) {                                                                                  \
-            hipLaunchKernelGGL((gru_granule_fwd_gw_kernel<KB_, NW_, true>), grid, dim3((NW_ + 4) * 64), 0, s, a,      \
-                               granules, gran_gi, epoch, err_flag);                                                  \
+        if ((gw & 1) && nb == 2) {                                                                                   \
+            if ((x3 & 1) && KB_ < 4) LAUNCH_GW(KB_, NW_, true, 2); else LAUNCH_GW(KB_, NW_, false, 2);               \
         } else if (gw & 1) {                                                                                         \
-            hipLaunchKernelGGL((gru_granule_fwd_gw_kernel<KB_, NW_, false>), grid, dim3((NW_ + 4) * 64), 0, s, a,     \
-                               granules, gran_gi, epoch, err_flag);                                                  \
+            if (x3 & 1) LAUNCH_GW(KB_, NW_, true, 1); else LAUNCH_GW(KB_, NW_, false, 1);                            \
         } else {                                                                                                     \
             hipLaunchKernelGGL((gru_granule_fwd_kernel<KB_, NW_>), grid, dim3(NW_ * 64), 0, s, a, granules, gran_gi,  \
                                epoch, err_flag);                                                                     \
@@ -944,6 +1042,7 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
         default: LAUNCH_GRANULE(4, 8); break;
     }
 #undef LAUNCH_GRANULE
+#undef LAUNCH_GW
     return check_launch("gru_stack_fwd_granule");
 }
 

@@ -313,7 +313,12 @@ class BNState:
         self.c = c
 
 
+BN_EPOCH = [0]        # bumped whenever running statistics are written behind torch's back (bn_finalize in training mode)
+
+
 def bn_finalize(stats, count, norm, training_update=True):
+    if training_update:
+        BN_EPOCH[0] += 1
     st = BNState(stats.shape[1], stats.device)
     call('pbsed_bn_finalize', ptr(stats), float(count), ptr(norm.gamma.detach()), ptr(norm.beta.detach()),
          float(norm.eps), float(norm.momentum), ptr(norm.running_mean if training_update else None),
@@ -323,10 +328,22 @@ def bn_finalize(stats, count, norm, training_update=True):
 
 
 def bn_eval_params(norm):
+    """Per-channel (mean, invstd, scale, shift) of a norm layer applied with its running statistics.  Cached on the module
+    until a parameter / buffer changes (torch versions for in-place updates, PACK_EPOCH / BN_EPOCH for the library's own
+    writes): an inference loop derives them once, not once per batch and layer."""
+    tensors = (norm.gamma, norm.beta, norm.running_mean, norm.running_power)
+    key = (PACK_EPOCH[0], BN_EPOCH[0]) + tuple((t._version, t.data_ptr()) for t in tensors)
+    cached = getattr(norm, '_pbsed_eval', None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
     st = BNState(norm.gamma.numel(), norm.gamma.device)
     call('pbsed_bn_eval_params', ptr(norm.gamma.detach()), ptr(norm.beta.detach()), float(norm.eps),
          ptr(norm.running_mean), ptr(norm.running_power), ptr(st.mean), ptr(st.invstd), ptr(st.scale),
          ptr(st.shift), st.c, stream())
+    try:
+        norm._pbsed_eval = (key, st)
+    except AttributeError:
+        pass
     return st
 
 
@@ -502,23 +519,27 @@ class ScanWatch:
 scan_watch = ScanWatch()
 
 
-def _granule_scan(nch, nlayers, b, h, t, device=None):
+def _granule_scan(nch, nlayers, b, h, t, device=None, fwd=False):
     """Persistent granule-exchange scans need every workgroup co-resident (one per CU): a ring per (chain, layer)
     plus a projection group per layer boundary, each H/16 x ceil(B/16) blocks, on at most 7/8 of the device's CUs
-    (256 on an MI355X in SPX mode; a partitioned device falls back to the launch-per-step scans)."""
+    (256 on an MI355X in SPX mode; a partitioned device falls back to the launch-per-step scans).  The forward scan
+    switches to two batch tiles per block (H/16 x ceil(B/32)) when one tile per block does not fit (the library applies the
+    same rule)."""
     blocks = nch * (2 * nlayers - 1) * ((b + 15) // 16) * (h // 16)
     dev = torch.cuda.current_device() if device is None else device
     if dev not in _CU_COUNT:
         _CU_COUNT[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    if fwd and blocks > _CU_COUNT[dev] * 7 // 8 and int(os.environ.get('PBSED_GRU_GW', '3')) & 1:
+        blocks = nch * (2 * nlayers - 1) * ((b + 31) // 32) * (h // 16)
     return (os.environ.get('PBSED_GRU_PERSIST', '2') == '2' and blocks <= _CU_COUNT[dev] * 7 // 8
             and nch * nlayers * t * ((b + 15) // 16 * 16) * h * 4 < 2 ** 32)
 
 
-def _per_chain(nch, nlayers, b, h, t, dev):
+def _per_chain(nch, nlayers, b, h, t, dev, fwd=False):
     """More than 32 clips per GPU: all chains together need more co-resident workgroups than the device has CUs, one
     chain at a time fits (batch 64: 192 of 256) - run the persistent scans chain by chain instead of falling back to
     one launch per time step."""
-    return nch > 1 and not _granule_scan(nch, nlayers, b, h, t, dev) and _granule_scan(1, nlayers, b, h, t, dev)
+    return nch > 1 and not _granule_scan(nch, nlayers, b, h, t, dev, fwd) and _granule_scan(1, nlayers, b, h, t, dev, fwd)
 
 
 def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=True):
@@ -528,7 +549,10 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
     t, b, g = gi0[0].shape
     h = g // 3
     dev = gi0[0].device
-    if _per_chain(nch, nlayers, b, h, t, dev):
+    # two batch tiles per block (more than 32 clips in one launch) unless the saved factors are for a BPTT that has to take
+    # the launch-per-step kernels (other save format)
+    nb2 = (not save) or _granule_scan(nch, nlayers, b, h, t, dev) or _per_chain(nch, nlayers, b, h, t, dev)
+    if _per_chain(nch, nlayers, b, h, t, dev, fwd=nb2):
         hs, sv = [], []
         for c in range(nch):
             sl = slice(c * nlayers, (c + 1) * nlayers)
@@ -538,7 +562,7 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
         return hs, (sv if save else None)
     n = nch * nlayers
     hs = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
-    gran = _granule_scan(nch, nlayers, b, h, t, dev)
+    gran = _granule_scan(nch, nlayers, b, h, t, dev, fwd=nb2)
     # saved per step: (r, z, n, gh_n), or in granule mode the five factors BPTT multiplies dh_t with
     sv = [torch.empty((t, b, 5 if gran else 4, h), device=dev, dtype=torch.float32) for _ in range(n)] if save else None
     if gran:

@@ -12,7 +12,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(n_cases):
-    b = int(rng.choice([1, 2, 7, 15, 16, 17, 31, 32, 33, 48]))
+    b = int(rng.choice([1, 2, 7, 15, 16, 17, 31, 32, 33, 48, 49, 64, 65, 100, 128]))   # > 32: two batch tiles per block (forward) / chain by chain
     h = int(rng.choice([64, 128, 256, 512]))
     t = int(rng.choice([1, 2, 3, 9, 40, 130]))
     ragged = bool(rng.random() < .6) and t > 1

@@ -420,12 +420,12 @@ def test_feature_statistics_tracking():
 
 
 # ------------------------------------------------------------------------------------------------ GRU scan drift
-@pytest.mark.parametrize('b', [32, 64])
+@pytest.mark.parametrize('b', [32, 48, 64])
 def test_gru_stack_t500_h256_vs_torch(b):
     """The persistent scan hands h_t between workgroups as fp32 words whose mantissa LSB carries a parity tag (<= 1 ulp
     per step, csrc/gru_stack.hip): 2 chains x 2 layers, T = 500, H = 256 at batch 32 (and 64) against torch.nn.GRU on
-    the same inputs - forward states and the BPTT gradients.  Batch 64 runs the scans chain by chain (192 of 256 CUs
-    each): forward against nn.GRU, its BPTT against the batch-32 run of the same first 32 clips (clips are independent)."""
+    the same inputs - forward states and the BPTT gradients.  Batch 48 / 64: the forward scan handles two batch tiles per
+    block (one launch, 192 of 256 CUs; 48 leaves the last block half empty), the BPTT runs chain by chain: forward against nn.GRU, its BPTT against the batch-32 run of the same first 32 clips (clips are independent)."""
     from pb_sed_amd import ops
     torch.manual_seed(5)
     t, h = 500, 256
