@@ -246,6 +246,15 @@ int pbsed_gru_wgrad_multi(int n, const float* const* dg, const float* const* x, 
                           float* const* dw, float* const* db, int T, int B, int G, const int* K /*host*/, int bf16,
                           void* stream);
 
+/* Time-major projections around the scans: y [R, N] = bias [N] (or 0 if NULL) + sum_i x[i] [R, k[i]] @ w[i] [N, k[i]]^T
+ * with R = T*B rows in the scans' own [T][B][*] layout - the GRU input projection gi = W_ih x + b_ih of torch.nn.GRU
+ * (pb_sed/models/weak_label/crnn.py:61-67) and its data gradient dx = sum over chains of dgi @ W_ih (pass W_ih^T as w),
+ * without the [B,C,T] <-> [T,B,C] round trips of a convolution on the CNN layout.  x, w, k: host arrays of n_src <= 4
+ * entries; N and every k[i] multiples of 4.  bf16 = 0: exact three-way bf16 operand splits on the bf16 MFMA (fp32-class
+ * results); bf16 != 0: plain bf16 operands, fp32 accumulation. */
+int pbsed_tm_gemm(int n_src, const float* const* x, const float* const* w, const int* k /*host*/, const float* bias,
+                  float* y, int R, int N, int bf16, void* stream);
+
 /* ---- heads' squash + losses (pb_sed/models/weak_label/crnn.py:58-59,107-206;
  * pb_sed/models/strong_label/crnn.py:93,106-112) */
 int pbsed_squash_fwd(const float* x, float* y, size_t n, float eps, void* stream);

@@ -58,6 +58,7 @@ SIGNATURES = {
     'pbsed_tbc_to_bct': [_v, _v, I, I, I, I, _v],
     'pbsed_transpose2d': [_v, _v, I, I, _v],
     'pbsed_gru_wgrad': [I, _pp, _pp, _i, _pp, _pp, I, I, I, I, _v],
+    'pbsed_tm_gemm': [I, _pp, _pp, _i, _v, _v, I, I, I, _v],
     'pbsed_gru_wgrad_multi': [I, _pp, _pp, _i, _pp, _pp, I, I, I, _i, I, _v],
     'pbsed_gru_scan_fwd': [I, _pp, _pp, _pp, _pp, _pp, _i, _v, I, I, I, _v],
     'pbsed_gru_scan_bwd': [I, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _i, _v, I, I, I, _v],

@@ -957,7 +957,10 @@ static void granule_poll_delays(bool bwd, GruStackArgs& a, int nb = 1) {
     // 22 1.82, 23 1.78, 24 1.80, 26 1.90; BPTT 8 2.48, 14..17 2.44, 20 2.51, 26 2.70.
     // Two batch tiles per block (forward, 64 clips, two-layer stacks): 24 2.25 ms, 36 1.93, 40 1.79, 44 1.77, 48 1.80, 64 1.88
     // (the two per-chain launches it replaces: 1.90 ms).
-    static int d[4] = {24, 6, 20, 0}, d1[4] = {24, 6, 15, 0}, d2[4] = {44, 6, 20, 0};
+    // The forward optimum sits one unit behind a cliff whose position moves by a unit with what ran before the scan (24 was
+    // best with the convolution + transpose producing gi, 25 with the time-major projection: 24 1.05 ms, 25 0.97, 26 0.99): the
+    // default is the safe side.  A per-wave feedback on missed first polls was tried: the extra state alone costs 0.2 ms.
+    static int d[4] = {25, 6, 20, 0}, d1[4] = {24, 6, 15, 0}, d2[4] = {44, 6, 20, 0};
     static const bool parsed = [] {
         if (const char* e = getenv("PBSED_GRU_POLL_DELAYS"))
             if (sscanf(e, "%d,%d,%d,%d", &d[0], &d[1], &d[2], &d[3]) == 4)

@@ -287,12 +287,24 @@ def _heads_forward(wrappers, x_w, seq_dev, seq_host, training, precision='f32'):
     return logits, head_ctx
 
 
+def _gemm_prec(precision, k):
+    """Operand format of a time-major projection (ops.tm_gemm): plain bf16 in the bf16 training mode, else fp32-class."""
+    return 'bf16' if _prec(precision, k) == 'bf16' else 'f32'
+
+
 def _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training, precision='f32'):
-    """Unidirectional multi-layer stacks (FBCRNN): layer-wavefront scan, T + L - 1 launches."""
+    """Unidirectional multi-layer stacks (FBCRNN): layer-wavefront scan, T + L - 1 launches.  The input projections of the
+    first layer run time-major (ops.tm_gemm on h transposed once) when the input width allows 16-byte rows."""
     nl = wrappers[0].num_layers
     gi0, pcs0 = [], []
+    h_tbc = ops.bct_to_tbc(h) if h.shape[1] % 4 == 0 else None
     for ch in chains:
-        pc = PackedConv(ch.p('weight_ih', 0).unsqueeze(-1), owner=ch.p('weight_ih', 0))
+        w_ih = ch.p('weight_ih', 0)
+        if h_tbc is not None:
+            gi0.append(ops.tm_gemm([h_tbc], [w_ih.detach()], ch.p('bias_ih', 0).detach(), _gemm_prec(precision, w_ih.shape[1])))
+            pcs0.append(None)
+            continue
+        pc = PackedConv(w_ih.unsqueeze(-1), owner=w_ih)
         pr = _prec(precision, pc.cin)
         y, _, _ = ops.conv_fwd(h, pc, pc.fwd(pr), bias=ch.p('bias_ih', 0).detach(), seq_len=None, precision=pr)
         gi0.append(ops.bct_to_tbc(y))
@@ -305,11 +317,11 @@ def _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training, precisi
         [ch.reverse for ch in chains], seq_dev, nl, save=training)
     x_w = [ops.tbc_to_bct(hs[ci * nl + nl - 1]) for ci in range(len(chains))]     # one chain per wrapper
     logits, head_ctx = _heads_forward(wrappers, x_w, seq_dev, seq_host, training, precision)
-    return logits, ('stack', chains, (h, pcs0, hs, save, precision), head_ctx)
+    return logits, ('stack', chains, (h, pcs0, hs, save, precision, h_tbc if training else None), head_ctx)
 
 
 def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
-    _, chains, (h, pcs0, hs, save, precision), head_ctx = ctx
+    _, chains, (h, pcs0, hs, save, precision, h_tbc), head_ctx = ctx
     nl = wrappers[0].num_layers
     dy_top = []
     for wi, w in enumerate(wrappers):
@@ -321,7 +333,6 @@ def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     dgi, dgh = ops.gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, [ch.reverse for ch in chains], seq_dev, nl)
     dh = None
     jobs = ([], [], [], [], [])                  # all weight gradients of the stacks: one launch
-    h_tbc = None
     for ci, ch in enumerate(chains):
         for l in range(nl):
             i = ci * nl + l
@@ -332,10 +343,14 @@ def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
                 if l == 0 and h_tbc is None:
                     h_tbc = ops.bct_to_tbc(h)
                 _wgrad_job(jobs, dgi[i], h_tbc if l == 0 else hs[i - 1], 0, _grad(w_ih), _grad(ch.p('bias_ih', l)))
-            if l == 0:
+            if l == 0 and pcs0[ci] is not None:
                 pr = _prec(precision, pcs0[ci].cin)
                 dx, _ = ops.conv_bwd_data(ops.tbc_to_bct(dgi[i]), pcs0[ci], pcs0[ci].dgrad(pr), h.shape, precision=pr)
                 dh = dx if dh is None else dh.add_(dx)
+    if pcs0[0] is None:
+        # data gradient of the first layers' input projections, all chains in one time-major product: dh = sum_c dgi_c W_ih,c
+        w_t = [ops.transpose2d(ch.p('weight_ih', 0).detach()) for ch in chains]
+        dh = ops.tbc_to_bct(ops.tm_gemm([dgi[ci * nl] for ci in range(len(chains))], w_t, None, _gemm_prec(precision, w_t[0].shape[1])))
     if jobs[0]:
         ops.gru_wgrad(*jobs, precision='bf16' if precision == 'bf16' else 'f32')
     return dh
@@ -352,23 +367,39 @@ def _scan_as_stack(wrappers):
 
 
 def rnn_forward(wrappers, h, seq_dev, seq_host, training, precision='f32'):
-    """wrappers: list of modules.GRU sharing the input h [B,C,T].  Returns (logits per wrapper, ctx)."""
+    """wrappers: list of modules.GRU sharing the input h [B,C,T].  Returns (logits per wrapper, ctx).
+
+    Layer-by-layer path (bidirectional GRUs): every layer's input projection is a time-major product (ops.tm_gemm) - of the
+    transposed CNN output for the first layer, of the previous layer's scan outputs (one source per direction, nothing
+    concatenated) above it; input widths that are no multiple of 4 (tag-conditioned first layers) take the k = 1 convolution
+    on the CNN layout."""
     chains = _chains(wrappers)
     num_layers = wrappers[0].num_layers
     assert all(w.num_layers == num_layers for w in wrappers)
     if not any(w.bidirectional for w in wrappers) and wrappers[0].hidden_size in (64, 128, 256, 512) \
             and all(w.rnn.input_size == h.shape[1] for w in wrappers):
         return _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training, precision)
-    x_w = [h for _ in wrappers]                  # per-wrapper layer input [B, In, T]
-    layer_ctx = []
+    of_w = [[i for i, ch in enumerate(chains) if ch.widx == wi] for wi in range(len(wrappers))]
+    h_tbc = ops.bct_to_tbc(h) if h.shape[1] % 4 == 0 else None
+    src = [[h_tbc] if h_tbc is not None else None for _ in wrappers]      # per wrapper: time-major sources of the layer input
+    layer_ctx, hs = [], None
     for l in range(num_layers):
         gi, pcs = [], []
         for ch in chains:
             w_ih = ch.p('weight_ih', l)
+            xs = src[ch.widx]
+            if xs is not None:
+                if len(xs) == 1:
+                    ws = [w_ih.detach()]
+                else:                                  # one column block of W_ih per source
+                    edges = np.cumsum([0] + [x.shape[2] for x in xs])
+                    ws = [w_ih.detach()[:, edges[j]:edges[j + 1]].contiguous() for j in range(len(xs))]
+                gi.append(ops.tm_gemm(xs, ws, ch.p('bias_ih', l).detach(), _gemm_prec(precision, w_ih.shape[1])))
+                pcs.append(None)
+                continue
             pc = PackedConv(w_ih.unsqueeze(-1), owner=w_ih)
             pr = _prec(precision, pc.cin)
-            y, _, _ = ops.conv_fwd(x_w[ch.widx], pc, pc.fwd(pr), bias=ch.p('bias_ih', l).detach(),
-                                   seq_len=None, precision=pr)
+            y, _, _ = ops.conv_fwd(h, pc, pc.fwd(pr), bias=ch.p('bias_ih', l).detach(), seq_len=None, precision=pr)
             gi.append(ops.bct_to_tbc(y))
             pcs.append(pc)
         w_hh_l = [ch.p('weight_hh', l).detach() for ch in chains]
@@ -380,65 +411,80 @@ def rnn_forward(wrappers, h, seq_dev, seq_host, training, precision='f32'):
                                          save=training)
         else:
             hs, save = ops.gru_scan_fwd(gi, w_hh_l, b_hh_l, [ch.reverse for ch in chains], seq_dev, save=training)
-        hs_bct = [ops.tbc_to_bct(h_) for h_ in hs]
-        layer_ctx.append((list(x_w), pcs, hs, save))
-        x_w = []
-        for wi, w in enumerate(wrappers):
-            outs = [hs_bct[i] for i, ch in enumerate(chains) if ch.widx == wi]
-            x_w.append(outs[0] if len(outs) == 1 else torch.cat(outs, dim=1))
+        layer_ctx.append((src, pcs, hs, save))
+        src = [[hs[i] for i in of_w[wi]] for wi in range(len(wrappers))]
+    hs_bct = [ops.tbc_to_bct(h_) for h_ in hs]
+    x_w = []
+    for wi, w in enumerate(wrappers):
+        outs = [hs_bct[i] for i in of_w[wi]]
+        x_w.append(outs[0] if len(outs) == 1 else torch.cat(outs, dim=1))
     logits, head_ctx = _heads_forward(wrappers, x_w, seq_dev, seq_host, training, precision)
-    return logits, (chains, layer_ctx, head_ctx, precision)
+    return logits, (chains, layer_ctx, head_ctx, precision, h)
 
 
 def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     """Returns grad wrt the shared input h."""
     if ctx[0] == 'stack':
         return _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host)
-    chains, layer_ctx, head_ctx, precision = ctx
+    chains, layer_ctx, head_ctx, precision, h = ctx
     num_layers = wrappers[0].num_layers
     hid = wrappers[0].hidden_size
-    d_out = []                                   # per wrapper: grad wrt top-layer output [B, H*dirs, T]
+    of_w = [[i for i, ch in enumerate(chains) if ch.widx == wi] for wi in range(len(wrappers))]
+    dy = [None] * len(chains)                    # per chain: grad wrt its top-layer output, time-major [T,B,H]
     for wi, w in enumerate(wrappers):
         layers, c = head_ctx[wi]
-        d_out.append(stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True))
+        d_out = stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True)       # [B, H*dirs, T]
+        for k, i in enumerate(of_w[wi]):
+            dy[i] = ops.bct_to_tbc(d_out[:, k * hid:(k + 1) * hid].contiguous())
     dh_in = None
     jobs = ([], [], [], [], [])                  # weight gradients of ALL layers: one launch after the last scan
     for l in reversed(range(num_layers)):
-        x_w, pcs, hs, save = layer_ctx[l]
-        dy = []
-        for i, ch in enumerate(chains):
-            k = [j for j, c2 in enumerate(chains) if c2.widx == ch.widx].index(i)
-            dy.append(ops.bct_to_tbc(d_out[ch.widx][:, k * hid:(k + 1) * hid].contiguous()))
+        src, pcs, hs, save = layer_ctx[l]
         w_hh_t = [ops.transpose2d(ch.p('weight_hh', l).detach()) for ch in chains]
         if _scan_as_stack(wrappers):
             dgi, dgh = ops.gru_stack_bwd(w_hh_t, [None] * len(chains), hs, save, dy, [ch.reverse for ch in chains],
                                          seq_dev, 1)
         else:
             dgi, dgh = ops.gru_scan_bwd(w_hh_t, hs, save, dy, [ch.reverse for ch in chains], seq_dev)
-        dx_w = [None for _ in wrappers]
-        x_tbc = {}                                 # the layer input once per wrapper, time-major
+        x_cat = {}                                 # the layer input once per wrapper, time-major, for the weight gradients
+        dgi_bct = {}                               # conv-path first layers: dgi on the CNN layout, once per chain
+
+        def dgi_b(i):
+            if i not in dgi_bct:
+                dgi_bct[i] = ops.tbc_to_bct(dgi[i])
+            return dgi_bct[i]
         for i, ch in enumerate(chains):
             w_hh, w_ih = ch.p('weight_hh', l), ch.p('weight_ih', l)
-            dgi_b = ops.tbc_to_bct(dgi[i])
             if w_hh.requires_grad:
                 _wgrad_job(jobs, dgh[i], hs[i], 1 if ch.reverse else -1, _grad(w_hh), _grad(ch.p('bias_hh', l)))
             if w_ih.requires_grad:
-                if w_ih.shape[1] % 4 == 0:
-                    if ch.widx not in x_tbc:         # the layer input once per wrapper, time-major
-                        x_tbc[ch.widx] = ops.bct_to_tbc(x_w[ch.widx])
-                    _wgrad_job(jobs, dgi[i], x_tbc[ch.widx], 0, _grad(w_ih), _grad(ch.p('bias_ih', l)))
+                if pcs[i] is None:
+                    if ch.widx not in x_cat:
+                        xs = src[ch.widx]
+                        x_cat[ch.widx] = xs[0] if len(xs) == 1 else torch.cat(xs, dim=2)
+                    _wgrad_job(jobs, dgi[i], x_cat[ch.widx], 0, _grad(w_ih), _grad(ch.p('bias_ih', l)))
                 else:                                # e.g. 266 = 256 + 10 tag-conditioned inputs: not a float4 multiple
-                    ops.conv_bwd_weight(x_w[ch.widx], dgi_b, pcs[i], _grad(w_ih), _grad(ch.p('bias_ih', l)),
+                    ops.conv_bwd_weight(h, dgi_b(i), pcs[i], _grad(w_ih), _grad(ch.p('bias_ih', l)),
                                         precision='bf16' if _prec(precision, pcs[i].cin) == 'bf16' else 'f32')
-            pr = _prec(precision, pcs[i].cin)
-            dx, _ = ops.conv_bwd_data(dgi_b, pcs[i], pcs[i].dgrad(pr), x_w[ch.widx].shape, precision=pr)
-            dx_w[ch.widx] = dx if dx_w[ch.widx] is None else dx_w[ch.widx].add_(dx)
-        if l > 0:
-            d_out = dx_w
-        else:
-            dh_in = dx_w[0]
-            for d in dx_w[1:]:
-                dh_in = dh_in.add_(d)
+        # data gradient of the input projections: per wrapper, the sum over its chains of dgi W_ih
+        new_dy = [None] * len(chains)
+        for wi in range(len(wrappers)):
+            mine = of_w[wi]
+            if pcs[mine[0]] is None:
+                w_t = [ops.transpose2d(chains[i].p('weight_ih', l).detach()) for i in mine]       # [In, 3H]
+                gp = _gemm_prec(precision, w_t[0].shape[1])
+                if l > 0:                            # straight into the per-chain gradients of the layer below
+                    for k, i in enumerate(mine):
+                        new_dy[i] = ops.tm_gemm([dgi[j] for j in mine], [w[k * hid:(k + 1) * hid] for w in w_t], None, gp)
+                else:
+                    d = ops.tbc_to_bct(ops.tm_gemm([dgi[j] for j in mine], w_t, None, gp))
+                    dh_in = d if dh_in is None else dh_in.add_(d)
+            else:                                    # first layer on the CNN layout
+                for i in mine:
+                    pr = _prec(precision, pcs[i].cin)
+                    d, _ = ops.conv_bwd_data(dgi_b(i), pcs[i], pcs[i].dgrad(pr), h.shape, precision=pr)
+                    dh_in = d if dh_in is None else dh_in.add_(d)
+        dy = new_dy
     if jobs[0]:
         ops.gru_wgrad(*jobs, precision='bf16' if precision == 'bf16' else 'f32')
     return dh_in

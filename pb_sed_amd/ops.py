@@ -400,6 +400,21 @@ def transpose2d(x):
     return y
 
 
+def tm_gemm(xs, ws, bias=None, precision='f32'):
+    """Time-major projection: sum_i xs[i] [T,B,K_i] @ ws[i] [N,K_i]^T (+ bias [N]) -> [T,B,N].  'f32': fp32-class products
+    (exact bf16x3 operand splits on the bf16 MFMA); 'bf16': plain bf16 operands."""
+    t, b = xs[0].shape[:2]
+    n = ws[0].shape[0]
+    ks = [x.shape[2] for x in xs]
+    assert all(x.shape[:2] == (t, b) and x.is_contiguous() for x in xs)
+    assert all(w.shape == (n, k) and w.is_contiguous() for w, k in zip(ws, ks))
+    y = torch.empty((t, b, n), device=xs[0].device, dtype=torch.float32)
+    call('pbsed_tm_gemm', len(xs), _lib.ptr_array(xs), _lib.ptr_array(ws), _lib.int_array(ks), ptr(bias), ptr(y), t * b, n,
+         int(precision == 'bf16'), stream(), tag=f'{"+".join(map(str, ks))}->{n} R{t * b}' + (' bf16' if precision == 'bf16' else ''),
+         flops=2. * t * b * n * sum(ks))
+    return y
+
+
 def gru_scan_fwd(gi, w_hh, b_hh, reverse, seq_len, save=True):
     """gi: list of [T,B,3H] per chain.  Returns (hs list [T,B,H], save list [T,B,4,H]|None)."""
     n = len(gi)

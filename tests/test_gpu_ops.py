@@ -509,6 +509,26 @@ def test_gru_wgrad_vs_torch(t, b, g, k, precision):
                   name=f'gru_wgrad db shift {sh}')
 
 
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+@pytest.mark.parametrize('t,b,n,ks', [(23, 5, 192, [24]), (500, 32, 768, [256]), (40, 19, 256, [768, 768]), (9, 3, 12, [8, 36, 4]),
+                                      (130, 7, 768, [512]), (17, 4, 100, [260])])
+def test_tm_gemm_vs_torch(t, b, n, ks, precision):
+    """Time-major projection sum_i x_i @ w_i^T + bias against fp64 (row / output / k tails, several sources).  'f32' = exact
+    bf16x3 operand splits: fp32 tolerance; 'bf16': operands rounded to bf16."""
+    from pb_sed_amd import ops
+    torch.manual_seed(11)
+    xs = [torch.randn(t, b, k) for k in ks]
+    ws = [torch.randn(n, k) * .2 for k in ks]
+    bias = torch.randn(n)
+    ref = bias.double() + sum(x.double() @ w.double().T for x, w in zip(xs, ws))
+    out = ops.tm_gemm([x.to(DEV) for x in xs], [w.to(DEV) for w in ws], bias.to(DEV), precision=precision)
+    scale = sum(ks) ** .5 * .2
+    close(out, ref.float(), atol=(3e-6 if precision == 'f32' else 4e-2) * scale, rtol=1e-5, name=f'tm_gemm {precision}')
+    out0 = ops.tm_gemm([xs[0].to(DEV)], [ws[0].to(DEV)], None, precision=precision)
+    close(out0, (xs[0].double() @ ws[0].double().T).float(), atol=(3e-6 if precision == 'f32' else 4e-2) * ks[0] ** .5 * .2, rtol=1e-5,
+          name='tm_gemm without bias')
+
+
 WINO_CASES = [c for c in CONV_CASES if c['k'] == (3, 3) and c['cin'] >= 16] + [
     dict(cin=64, cout=64, f=8, t=70, k=(3, 3), pool=False, pro=False),
     dict(cin=32, cout=64, f=6, t=500, k=(3, 3), pool=True, pro=True),
