@@ -279,7 +279,7 @@ def roofline_objects(agg, by_family, steps, batch, precision, gru_shape, kind):
     return out
 
 
-EVENT_FILTER = lambda n: n.startswith(('pbsed_conv', 'pbsed_gru_stack', 'pbsed_gru_wgrad', 'pbsed_logmel'))
+EVENT_FILTER = lambda n: n.startswith(('pbsed_conv', 'pbsed_gru_stack', 'pbsed_gru_wgrad', 'pbsed_tm_gemm', 'pbsed_logmel'))
 
 
 def event_pass(step_fn, steps):
@@ -388,10 +388,15 @@ def bench_train(args, kind, world, rank, device):
                         'executed_tflop_per_step_in_bracketed_launches': round(exe_step / 1e12, 4),
                         'executed_tflops_per_gpu': round(exe_step / 1e12 / (ms_step * 1e-3), 2),
                         'frac_executed_of_fp32_mfma_peak': round(exe_step / 1e12 / (ms_step * 1e-3) / peak, 4),
-                        'frac_algorithmic_of_fp32_mfma_peak': round(train_tflop / (ms_step * 1e-3) / peak, 4)}
-    fwd_ms = sum(v for k, v in by_family.items() if k.startswith(('pbsed_conv_fwd', 'pbsed_gru_stack_fwd', 'pbsed_logmel')))
+                        'frac_algorithmic_of_fp32_mfma_peak': round(train_tflop / (ms_step * 1e-3) / peak, 4),
+                        'note': 'executed = fp32-equivalent products issued by the bracketed launches: a Winograd launch counts half of '
+                                'the direct products; bf16x3 launches (GRU scans, GRU weight gradients, time-major projections) count each '
+                                'fp32-equivalent product once although the bf16 pipe runs six part products for it'}
+    is_fwd = lambda name, tag: (name.startswith(('pbsed_conv_fwd', 'pbsed_gru_stack_fwd', 'pbsed_logmel'))
+                                or (name == 'pbsed_tm_gemm' and tag.endswith(' fwd')))      # the GRU input projections
+    fwd_ms = sum(ms for (name, tag), (ms, c, fl, by) in agg.items() if is_fwd(name, tag)) / ev_steps
     fwd_exe = sum(_executed(fl, tag) * c for (name, tag), (ms, c, fl, by) in agg.items()
-                  if name.startswith(('pbsed_conv_fwd', 'pbsed_gru_stack_fwd'))) / ev_steps
+                  if is_fwd(name, tag) and not name.startswith('pbsed_logmel')) / ev_steps
     out['forward_conv_gru'] = {'ms_per_step': round(fwd_ms, 3), 'algorithmic_tflop': round(fwd_tflop, 4),
                                'algorithmic_tflops': round(fwd_tflop / (fwd_ms * 1e-3), 2),
                                'executed_tflops': round(fwd_exe / 1e12 / (fwd_ms * 1e-3), 2),

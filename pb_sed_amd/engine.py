@@ -350,7 +350,7 @@ def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     if pcs0[0] is None:
         # data gradient of the first layers' input projections, all chains in one time-major product: dh = sum_c dgi_c W_ih,c
         w_t = [ops.transpose2d(ch.p('weight_ih', 0).detach()) for ch in chains]
-        dh = ops.tbc_to_bct(ops.tm_gemm([dgi[ci * nl] for ci in range(len(chains))], w_t, None, _gemm_prec(precision, w_t[0].shape[1])))
+        dh = ops.tbc_to_bct(ops.tm_gemm([dgi[ci * nl] for ci in range(len(chains))], w_t, None, _gemm_prec(precision, w_t[0].shape[1]), role='bwd'))
     if jobs[0]:
         ops.gru_wgrad(*jobs, precision='bf16' if precision == 'bf16' else 'f32')
     return dh
@@ -475,9 +475,9 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
                 gp = _gemm_prec(precision, w_t[0].shape[1])
                 if l > 0:                            # straight into the per-chain gradients of the layer below
                     for k, i in enumerate(mine):
-                        new_dy[i] = ops.tm_gemm([dgi[j] for j in mine], [w[k * hid:(k + 1) * hid] for w in w_t], None, gp)
+                        new_dy[i] = ops.tm_gemm([dgi[j] for j in mine], [w[k * hid:(k + 1) * hid] for w in w_t], None, gp, role='bwd')
                 else:
-                    d = ops.tbc_to_bct(ops.tm_gemm([dgi[j] for j in mine], w_t, None, gp))
+                    d = ops.tbc_to_bct(ops.tm_gemm([dgi[j] for j in mine], w_t, None, gp, role='bwd'))
                     dh_in = d if dh_in is None else dh_in.add_(d)
             else:                                    # first layer on the CNN layout
                 for i in mine:

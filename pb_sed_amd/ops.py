@@ -400,9 +400,10 @@ def transpose2d(x):
     return y
 
 
-def tm_gemm(xs, ws, bias=None, precision='f32'):
+def tm_gemm(xs, ws, bias=None, precision='f32', role='fwd'):
     """Time-major projection: sum_i xs[i] [T,B,K_i] @ ws[i] [N,K_i]^T (+ bias [N]) -> [T,B,N].  'f32': fp32-class products
-    (exact bf16x3 operand splits on the bf16 MFMA); 'bf16': plain bf16 operands."""
+    (exact bf16x3 operand splits on the bf16 MFMA); 'bf16': plain bf16 operands.  ``role`` ('fwd' | 'bwd') only labels the
+    launch for bench.py's forward / backward accounting."""
     t, b = xs[0].shape[:2]
     n = ws[0].shape[0]
     ks = [x.shape[2] for x in xs]
@@ -410,7 +411,7 @@ def tm_gemm(xs, ws, bias=None, precision='f32'):
     assert all(w.shape == (n, k) and w.is_contiguous() for w, k in zip(ws, ks))
     y = torch.empty((t, b, n), device=xs[0].device, dtype=torch.float32)
     call('pbsed_tm_gemm', len(xs), _lib.ptr_array(xs), _lib.ptr_array(ws), _lib.int_array(ks), ptr(bias), ptr(y), t * b, n,
-         int(precision == 'bf16'), stream(), tag=f'{"+".join(map(str, ks))}->{n} R{t * b}' + (' bf16' if precision == 'bf16' else ''),
+         int(precision == 'bf16'), stream(), tag=f'{"+".join(map(str, ks))}->{n} R{t * b}' + (' bf16' if precision == 'bf16' else '') + ' ' + role,
          flops=2. * t * b * n * sum(ks))
     return y
 
