@@ -128,11 +128,40 @@ def _prec(precision, cin, pc=None, dgrad=False):
     return 'f32'
 
 
-def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32'):
+class _StackCtx(list):
+    """ctx of stack_forward (one entry per layer) + the stack output in the scans' layout when the last layers ran time-major."""
+    tbc_out = None
+
+
+def _tm_start(layers, precision):
+    """First layer of the trailing run of layers that the time-major kernels take (csrc/tm_gemm.hip: Conv1d of kernel size 1
+    or 3 without pooling or residual connections, input widths in whole float4s); len(layers) if there is none.
+    Opt-in (PBSED_TM_STACK=1): measured on the headline step the forward / data-gradient launches gain 10-20 % over the
+    kernels on the CNN layout, but the weight gradients of these small matrices (256 x 256 x 3 over 16 000 rows) need a
+    40-fold split of the reduction to fill the device and drown in its atomics (0.46 ms against 0.10) - DESIGN.md section 4."""
+    j = len(layers)
+    if os.environ.get('PBSED_TM_STACK', '0') != '1' or precision not in ('f32', 'bf16', 'bf16x3'):
+        return j
+    while j > 0:
+        L = layers[j - 1]
+        w = L.conv.conv.weight
+        if not (L.conv.ndim == 1 and w.shape[2] in (1, 3) and not L.conv.pool_f and not L.skips_in and w.shape[1] % 4 == 0):
+            break
+        j -= 1
+    return j
+
+
+def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32', x_tbc=None):
     """Run a conv stack.  Returns (y, ctx) - ctx is what stack_backward needs.  ``precision``: 'f32' |
-    'bf16' | 'bf16x3' operand format of the forward / data-gradient MFMAs (weight gradients are always fp32)."""
-    ctx = []
+    'bf16' | 'bf16x3' operand format of the forward / data-gradient MFMAs (weight gradients are always fp32).
+    The trailing 1-D layers run on the scans' time-major layout (``x_tbc``: the stack input already in that layout, for
+    stacks that are 1-D throughout); ``ctx.tbc_out`` is then the output [T,B,C] next to the returned [B,C,T]."""
+    ctx = _StackCtx()
     st_in, st_frozen = None, False
+    j_tm = _tm_start(layers, precision)
+    x_t = rowmask = None
+    if x is None and j_tm > 0:                        # only the time-major form of the input was handed over
+        x = ops.tbc_to_bct(x_tbc)
     for j, L in enumerate(layers):
         c = L.conv
         nxt = layers[j + 1] if j + 1 < len(layers) else None
@@ -140,6 +169,25 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32'):
         # frozen statistics (cnn_2d.freeze(n, freeze_norm_stats=True), pb_sed/experiments/weak_label_crnn/training.py:343-350):
         # the layer normalises with its running statistics in training too and they are not updated
         batch_stats = training and next_norm is not None and not next_norm.freeze_stats
+        if j >= j_tm:
+            if x_t is None:                            # entering the time-major run
+                x_shape = None if x is None else tuple(x.shape)
+                x_t = x_tbc if (x_tbc is not None and j == 0) else ops.bct_to_tbc(x.flatten(1, 2) if x.dim() == 4 else x)
+                rowmask = ops.tm_rowmask(seq_dev, x_t.shape[0], x_t.shape[1])
+            tc = ops.TmConv(c.conv.weight, c.conv.bias)
+            assert tc.n4 == tc.cout or next_norm is None
+            gp = _gemm_prec(precision, tc.cin)
+            y_t, stats = ops.tm_conv_fwd(x_t, tc, st_in, rowmask, want_stats=batch_stats, precision=gp)
+            ctx.append(('tm', x_t, st_in, tc, gp, st_frozen, rowmask, x_shape if j == j_tm else None))
+            st_frozen = bool(training and next_norm is not None and next_norm.freeze_stats)
+            if next_norm is None:
+                st_in = None
+            elif batch_stats:
+                st_in = ops.bn_finalize(stats, _count(seq_host, x_t.shape[0], 1), next_norm)
+            else:
+                st_in = ops.bn_eval_params(next_norm)
+            x_t = y_t
+            continue
         per_cf = bool(batch_stats and c.ndim == 2 and nxt.conv.ndim == 1)
         if c.ndim == 1 and x.dim() == 4:
             x = x.flatten(1, 2)                       # 'b c f t -> b (c f) t' is a view in this layout
@@ -169,6 +217,13 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32'):
         else:
             st_in = ops.bn_eval_params(next_norm)
         x = y
+    if x_t is not None:                                # back to the CNN layout for the callers on it
+        cout = layers[-1].conv.conv.weight.shape[0]
+        x = ops.tbc_to_bct(x_t)
+        if x.shape[1] != cout:
+            x = x[:, :cout].contiguous()
+            x_t = None                                 # padded output channels: no [T,B,C] view of exactly C channels
+        ctx.tbc_out = x_t
     return x, ctx
 
 
@@ -204,18 +259,60 @@ def _skip_backward(ctx, src, skip_conv, sctx, g):
     return g
 
 
-def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_done=None):
+def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_done=None, g_tbc=None, want_tbc=False):
     """Backward of stack_forward; accumulates parameter grads, returns grad wrt the stack input.
-    ``on_layer_done(j)`` fires once every gradient owned by layers >= j is final."""
+    ``on_layer_done(j)`` fires once every gradient owned by layers >= j is final.  ``g_tbc``: the output gradient already in
+    the time-major layout [T,B,C] (instead of ``g``); ``want_tbc``: return the input gradient in that layout when the first
+    layer ran time-major."""
     def trainable(j):
         mods = [layers[j].conv.conv] + ([layers[j].in_norm] if layers[j].in_norm is not None else [])
         return any(p.requires_grad for m in mods for p in m.parameters())
 
     lowest = min((j for j in range(len(layers)) if trainable(j)), default=len(layers))
     pending = {}                                 # source layer -> gradient arriving over residual connections
+    g_t = None                                   # the gradient while it travels through the time-major layers
     for j in reversed(range(len(layers))):
-        L, (x, st_in, pc, idx, pr, frozen, skip_ctx) = layers[j], ctx[j]
+        L = layers[j]
         c = L.conv
+        if isinstance(ctx[j][0], str):               # a layer that ran time-major
+            _, x_t, st_in, tc, gp, frozen, rowmask, x_shape = ctx[j]
+            if g_t is None:                          # entering from the top
+                if g_tbc is not None and g_tbc.shape[2] == tc.n4:
+                    g_t = g_tbc
+                else:
+                    if g is None:
+                        g = ops.tbc_to_bct(g_tbc)
+                    if tc.n4 != tc.cout:
+                        g = torch.cat([g, g.new_zeros((g.shape[0], tc.n4 - tc.cout, g.shape[2]))], dim=1)
+                    g_t = ops.bct_to_tbc(g.contiguous())
+            if j < lowest and not need_input_grad:
+                if on_layer_done is not None:
+                    on_layer_done(0)
+                return None
+            dw, db = _grad(c.conv.weight), _grad(c.conv.bias)
+            if dw is not None:
+                ops.tm_conv_bwd_weight(x_t, g_t, tc, dw, db, st_in, rowmask, precision=gp)
+            if j == 0 and not need_input_grad:
+                if on_layer_done is not None:
+                    on_layer_done(0)
+                return None
+            if st_in is not None:
+                dz, stats = ops.tm_conv_bwd_data(g_t, tc, rowmask, bn=(x_t, st_in), precision=gp)
+                count = float('inf') if frozen else _count(seq_host, x_t.shape[0], 1)
+                norm = L.in_norm
+                g_t = ops.bn_backward_tm(dz, x_t, st_in, stats, count, _grad(norm.gamma), _grad(norm.beta), rowmask)
+            else:
+                g_t, _ = ops.tm_conv_bwd_data(g_t, tc, None, None, precision=gp)
+            if on_layer_done is not None:
+                on_layer_done(j)
+            if x_shape is not None or j == 0:        # leaving the time-major run
+                if j == 0 and want_tbc:
+                    return g_t
+                g = ops.tbc_to_bct(g_t)
+                if x_shape is not None:
+                    g = g.reshape(x_shape)
+            continue
+        x, st_in, pc, idx, pr, frozen, skip_ctx = ctx[j]
         # g = dL/d(output of conv j) = dL/d(input of layer j+1): the residuals summed into it take the same gradient
         for src, skip_conv, sctx in skip_ctx:
             gs = _skip_backward(ctx, src, skip_conv, sctx, g.contiguous())
@@ -277,11 +374,13 @@ def _chains(wrappers):
     return chains
 
 
-def _heads_forward(wrappers, x_w, seq_dev, seq_host, training, precision='f32'):
+def _heads_forward(wrappers, x_w, seq_dev, seq_host, training, precision='f32', x_tbc=None):
+    """``x_tbc``: per wrapper the head input in the scans' layout [T,B,C] (then ``x_w[wi]`` may be None)."""
     logits, head_ctx = [], []
     for wi, w in enumerate(wrappers):
         layers = describe_stack([w.output_net])
-        y, c = stack_forward(layers, x_w[wi], seq_dev, seq_host, training, precision)
+        y, c = stack_forward(layers, x_w[wi], seq_dev, seq_host, training, precision,
+                             x_tbc=None if x_tbc is None else x_tbc[wi])
         logits.append(y)
         head_ctx.append((layers, c))
     return logits, head_ctx
@@ -292,12 +391,13 @@ def _gemm_prec(precision, k):
     return 'bf16' if _prec(precision, k) == 'bf16' else 'f32'
 
 
-def _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training, precision='f32'):
+def _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training, precision='f32', h_tbc=None):
     """Unidirectional multi-layer stacks (FBCRNN): layer-wavefront scan, T + L - 1 launches.  The input projections of the
     first layer run time-major (ops.tm_gemm on h transposed once) when the input width allows 16-byte rows."""
     nl = wrappers[0].num_layers
     gi0, pcs0 = [], []
-    h_tbc = ops.bct_to_tbc(h) if h.shape[1] % 4 == 0 else None
+    if h_tbc is None and h.shape[1] % 4 == 0:
+        h_tbc = ops.bct_to_tbc(h)
     for ch in chains:
         w_ih = ch.p('weight_ih', 0)
         if h_tbc is not None:
@@ -315,8 +415,9 @@ def _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training, precisi
         [ch.p('bias_ih', l).detach() if l else None for ch, l in idx],
         [ch.p('weight_hh', l).detach() for ch, l in idx], [ch.p('bias_hh', l).detach() for ch, l in idx],
         [ch.reverse for ch in chains], seq_dev, nl, save=training)
-    x_w = [ops.tbc_to_bct(hs[ci * nl + nl - 1]) for ci in range(len(chains))]     # one chain per wrapper
-    logits, head_ctx = _heads_forward(wrappers, x_w, seq_dev, seq_host, training, precision)
+    # one chain per wrapper: the heads take the top layer's states in the scans' layout
+    top = [hs[ci * nl + nl - 1] for ci in range(len(chains))]
+    logits, head_ctx = _heads_forward(wrappers, [None] * len(chains), seq_dev, seq_host, training, precision, x_tbc=top)
     return logits, ('stack', chains, (h, pcs0, hs, save, precision, h_tbc if training else None), head_ctx)
 
 
@@ -326,7 +427,8 @@ def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     dy_top = []
     for wi, w in enumerate(wrappers):
         layers, c = head_ctx[wi]
-        dy_top.append(ops.bct_to_tbc(stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True)))
+        d = stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True, want_tbc=True)
+        dy_top.append(d if isinstance(c[0][0], str) else ops.bct_to_tbc(d))      # time-major heads hand back [T,B,H]
     idx = [(ch, l) for ch in chains for l in range(nl)]
     w_hh_t = [ops.transpose2d(ch.p('weight_hh', l).detach()) for ch, l in idx]
     w_ih_up_t = [ops.transpose2d(ch.p('weight_ih', l + 1).detach()) if l + 1 < nl else None for ch, l in idx]
@@ -366,8 +468,9 @@ def _scan_as_stack(wrappers):
     return wrappers[0].hidden_size in (64, 128, 256, 512)
 
 
-def rnn_forward(wrappers, h, seq_dev, seq_host, training, precision='f32'):
-    """wrappers: list of modules.GRU sharing the input h [B,C,T].  Returns (logits per wrapper, ctx).
+def rnn_forward(wrappers, h, seq_dev, seq_host, training, precision='f32', h_tbc=None):
+    """wrappers: list of modules.GRU sharing the input h [B,C,T] (``h_tbc``: the same in the scans' layout [T,B,C], if the
+    caller has it).  Returns (logits per wrapper, ctx).
 
     Layer-by-layer path (bidirectional GRUs): every layer's input projection is a time-major product (ops.tm_gemm) - of the
     transposed CNN output for the first layer, of the previous layer's scan outputs (one source per direction, nothing
@@ -378,9 +481,10 @@ def rnn_forward(wrappers, h, seq_dev, seq_host, training, precision='f32'):
     assert all(w.num_layers == num_layers for w in wrappers)
     if not any(w.bidirectional for w in wrappers) and wrappers[0].hidden_size in (64, 128, 256, 512) \
             and all(w.rnn.input_size == h.shape[1] for w in wrappers):
-        return _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training, precision)
+        return _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training, precision, h_tbc)
     of_w = [[i for i, ch in enumerate(chains) if ch.widx == wi] for wi in range(len(wrappers))]
-    h_tbc = ops.bct_to_tbc(h) if h.shape[1] % 4 == 0 else None
+    if h_tbc is None and h.shape[1] % 4 == 0:
+        h_tbc = ops.bct_to_tbc(h)
     src = [[h_tbc] if h_tbc is not None else None for _ in wrappers]      # per wrapper: time-major sources of the layer input
     layer_ctx, hs = [], None
     for l in range(num_layers):
@@ -413,12 +517,12 @@ def rnn_forward(wrappers, h, seq_dev, seq_host, training, precision='f32'):
             hs, save = ops.gru_scan_fwd(gi, w_hh_l, b_hh_l, [ch.reverse for ch in chains], seq_dev, save=training)
         layer_ctx.append((src, pcs, hs, save))
         src = [[hs[i] for i in of_w[wi]] for wi in range(len(wrappers))]
-    hs_bct = [ops.tbc_to_bct(h_) for h_ in hs]
-    x_w = []
+    # the heads take the top layer's states in the scans' layout (both directions side by side)
+    top = []
     for wi, w in enumerate(wrappers):
-        outs = [hs_bct[i] for i in of_w[wi]]
-        x_w.append(outs[0] if len(outs) == 1 else torch.cat(outs, dim=1))
-    logits, head_ctx = _heads_forward(wrappers, x_w, seq_dev, seq_host, training, precision)
+        outs = [hs[i] for i in of_w[wi]]
+        top.append(outs[0] if len(outs) == 1 else torch.cat(outs, dim=2))
+    logits, head_ctx = _heads_forward(wrappers, [None] * len(wrappers), seq_dev, seq_host, training, precision, x_tbc=top)
     return logits, (chains, layer_ctx, head_ctx, precision, h)
 
 
@@ -433,9 +537,12 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     dy = [None] * len(chains)                    # per chain: grad wrt its top-layer output, time-major [T,B,H]
     for wi, w in enumerate(wrappers):
         layers, c = head_ctx[wi]
-        d_out = stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True)       # [B, H*dirs, T]
+        d_out = stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True, want_tbc=True)
         for k, i in enumerate(of_w[wi]):
-            dy[i] = ops.bct_to_tbc(d_out[:, k * hid:(k + 1) * hid].contiguous())
+            if isinstance(c[0][0], str):             # time-major heads: [T, B, H*dirs]
+                dy[i] = d_out[:, :, k * hid:(k + 1) * hid].contiguous() if len(of_w[wi]) > 1 else d_out
+            else:                                    # [B, H*dirs, T]
+                dy[i] = ops.bct_to_tbc(d_out[:, k * hid:(k + 1) * hid].contiguous())
     dh_in = None
     jobs = ([], [], [], [], [])                  # weight gradients of ALL layers: one launch after the last scan
     for l in reversed(range(num_layers)):
