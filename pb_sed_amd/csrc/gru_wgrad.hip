@@ -39,6 +39,10 @@ struct GruWgradArgs {
     const float* rowmask;     // [TB] or null
     int relu;
     int ldg[GW_MAX], ldk[GW_MAX];
+    // many-way splits of small gradients: every (GEMM, split) writes its partial tile to its own slot [G][K_max] with plain
+    // stores and gru_wgrad_slot_reduce_kernel adds the slots up - instead of nsplit atomics per gradient element
+    float* slots;
+    int slot_kmax;
 };
 
 template <int BN>
@@ -151,7 +155,8 @@ __global__ __launch_bounds__(BN * 2) void gru_wgrad_kernel(GruWgradArgs a) {
 // (= columns c with the same c % 4, stride 4); the output indices follow the same bijection.
 constexpr int GB_BM = 128, GB_BN = 256, GB_KC = 32, GB_KG = GB_KC / 8;
 
-template <int NS>
+// EXT: the convolution form (prologue of X, sequence mask) - compiled out of the GRU launches.
+template <int NS, bool EXT>
 __global__ __launch_bounds__(512) void gru_wgrad_b16_kernel(GruWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4_t smem_b16[];
     u32x4_t* As = smem_b16;                              // [NS][KG][BM] 16-byte rows (8 bf16 along the contraction index)
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(512) void gru_wgrad_b16_kernel(GruWgradArgs a) {
     u32x4_t rv0[8], rv1[8];
     unsigned rm0 = 0u, rm1 = 0u;                         // X rows: bit rr = row rr of the stage is inside the tensor and the sequence
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool masked = is_b && a.scale[gemm] != nullptr;      // without a prologue the rows are taken as they are
+    const bool masked = EXT && is_b && a.scale[gemm] != nullptr;      // without a prologue the rows are taken as they are
     auto fetch = [&](u32x4_t (&rv)[8], unsigned& rmk, int r0) __attribute__((always_inline)) {
         rmk = 0u;
 #pragma unroll
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(512) void gru_wgrad_b16_kernel(GruWgradArgs a) {
             if (masked && ok && (!a.rowmask || a.rowmask[rs] != 0.f)) rmk |= 1u << rr;
         }
     };
-    const bool pro = is_b && a.scale[gemm] != nullptr;
+    const bool pro = EXT && is_b && a.scale[gemm] != nullptr;
     float4 psc = make_float4(0.f, 0.f, 0.f, 0.f), psh = psc;
     if (pro && col_ok) { psc = *reinterpret_cast<const float4*>(a.scale[gemm] + col); psh = *reinterpret_cast<const float4*>(a.shift[gemm] + col); }
     auto stage = [&](const u32x4_t (&rv)[8], unsigned rmk) __attribute__((always_inline)) {
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(512) void gru_wgrad_b16_kernel(GruWgradArgs a) {
             float v[8];
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) v[rr] = __uint_as_float(i == 0 ? rv[rr].x : i == 1 ? rv[rr].y : i == 2 ? rv[rr].z : rv[rr].w);
-            if (pro) {
+            if (EXT && pro) {
                 const float sc = i == 0 ? psc.x : i == 1 ? psc.y : i == 2 ? psc.z : psc.w;
                 const float sh = i == 0 ? psh.x : i == 1 ? psh.y : i == 2 ? psh.z : psh.w;
 #pragma unroll
@@ -272,6 +277,7 @@ __global__ __launch_bounds__(512) void gru_wgrad_b16_kernel(GruWgradArgs a) {
     }
 
     float* __restrict__ dw = a.dw[gemm];
+    float* __restrict__ slot = a.slots ? a.slots + ((size_t)gemm * a.nsplit + split) * a.G * a.slot_kmax : nullptr;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -282,7 +288,10 @@ __global__ __launch_bounds__(512) void gru_wgrad_b16_kernel(GruWgradArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int pa = wm * 64 + mi * 16 + lq * 4 + r;               // LDS row of the dG tile -> gate row g
                 const int g = m0 + 4 * (pa % (GB_BM / 4)) + pa / (GB_BM / 4);
-                if (g < a.G && k < K) unsafeAtomicAdd(dw + (size_t)g * a.ldg[gemm] + (size_t)k * a.ldk[gemm], acc[mi][ni][r]);
+                if (g < a.G && k < K) {
+                    if (slot) slot[(size_t)g * a.slot_kmax + k] = acc[mi][ni][r];
+                    else unsafeAtomicAdd(dw + (size_t)g * a.ldg[gemm] + (size_t)k * a.ldk[gemm], acc[mi][ni][r]);
+                }
             }
         }
     if (a.y_tile[blockIdx.y] == 0 && is_a && a.db[gemm]) {
@@ -292,9 +301,37 @@ __global__ __launch_bounds__(512) void gru_wgrad_b16_kernel(GruWgradArgs a) {
     }
 }
 
+__global__ void gru_wgrad_slot_reduce_kernel(GruWgradArgs a, int n) {
+    const int gemm = blockIdx.y, K = a.Ks[gemm];
+    const size_t total = (size_t)a.G * K;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i / K), k = (int)(i % K);
+        const float* p = a.slots + (size_t)gemm * a.nsplit * a.G * a.slot_kmax + (size_t)g * a.slot_kmax + k;
+        float v = 0.f;
+        for (int sp = 0; sp < a.nsplit; ++sp) v += p[(size_t)sp * a.G * a.slot_kmax];
+        a.dw[gemm][(size_t)g * a.ldg[gemm] + (size_t)k * a.ldk[gemm]] += v;
+    }
+}
+
 }  // namespace pbsed
 
 using namespace pbsed;
+
+// device scratch of the slot mode, grown on demand, one per device ordinal (one stream per device at a time, as for the
+// convolution weight gradients' slots)
+static float* gru_wgrad_scratch(size_t floats) {
+    static float* buf[64] = {nullptr};
+    static size_t cap[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    dev &= 63;
+    if (cap[dev] < floats) {
+        if (buf[dev]) { (void)hipDeviceSynchronize(); (void)hipFree(buf[dev]); buf[dev] = nullptr; cap[dev] = 0; }
+        if (hipMalloc(&buf[dev], floats * sizeof(float)) != hipSuccess) return nullptr;
+        cap[dev] = floats;
+    }
+    return buf[dev];
+}
 
 struct GwExt {                 // 1-D convolution layers: prologue of X and the strides of dw
     const float* scale; const float* shift; const float* rowmask;
@@ -350,13 +387,28 @@ static int gru_wgrad_launch(int n, const float* const* dg, const float* const* x
         a.rows_per_split = ((a.TB + nsplit - 1) / nsplit + GB_KC - 1) / GB_KC * GB_KC;
         a.nsplit = (a.TB + a.rows_per_split - 1) / a.rows_per_split;
         grid.z = a.nsplit;
+        // more than 8 partial sums per gradient element: slots + one reduction pass instead of atomics (a [256 x 256] x 3-tap
+        // convolution gradient over 16 000 rows: 42 splits, 0.46 ms with atomics)
+        static const int slot_min = [] { const char* e = getenv("PBSED_GRU_WGRAD_SLOT_MIN"); return e ? atoi(e) : 8; }();
+        a.slots = nullptr;
+        if (a.nsplit > slot_min && slot_min > 0) {
+            a.slot_kmax = kmax;
+            const size_t need = (size_t)n * a.nsplit * G * kmax;
+            if (need * sizeof(float) <= (1ull << 30)) a.slots = gru_wgrad_scratch(need);
+        }
         const size_t lds = (size_t)operands * GB_KG * (GB_BM + GB_BN) * sizeof(u32x4_t);
-        if (operands == 3) {
-            PBSED_DYN_LDS_ONCE(gru_wgrad_b16_kernel<3>, lds);
-            hipLaunchKernelGGL((gru_wgrad_b16_kernel<3>), grid, dim3(512), lds, s, a);
-        } else {
-            PBSED_DYN_LDS_ONCE(gru_wgrad_b16_kernel<1>, lds);
-            hipLaunchKernelGGL((gru_wgrad_b16_kernel<1>), grid, dim3(512), lds, s, a);
+#define GW_GO(NS_, EXT_)                                                                          \
+    do {                                                                                          \
+        PBSED_DYN_LDS_ONCE((gru_wgrad_b16_kernel<NS_, EXT_>), lds);                               \
+        hipLaunchKernelGGL((gru_wgrad_b16_kernel<NS_, EXT_>), grid, dim3(512), lds, s, a);        \
+    } while (0)
+        if (operands == 3) { if (ext) GW_GO(3, true); else GW_GO(3, false); }
+        else { if (ext) GW_GO(1, true); else GW_GO(1, false); }
+#undef GW_GO
+        if (a.slots) {
+            const size_t per = (size_t)G * kmax;
+            hipLaunchKernelGGL(gru_wgrad_slot_reduce_kernel, dim3((unsigned)((per + 255) / 256 < 1024 ? (per + 255) / 256 : 1024), n),
+                               dim3(256), 0, s, a, n);
         }
         return check_launch("gru_wgrad");
     }
