@@ -248,19 +248,22 @@ def roofline_objects(agg, by_family, steps, batch, precision, gru_shape, kind):
         nch, nl, t, b, h = gru_shape
         g = {}
         for key, fam in (('forward_scan', 'pbsed_gru_stack_fwd_granule'), ('bptt_scan', 'pbsed_gru_stack_bwd_granule')):
-            rows = [v for k, v in agg.items() if k[0] == fam]
+            rows = [v for k, v in agg.items() if k[0] in (fam, fam + '_bf16')]
             if not rows:
                 continue
+            plain_bf16 = any(k[0] == fam + '_bf16' for k in agg)      # the bf16 training mode: one bf16 product per product
             ms = sum(r[0] for r in rows) / steps            # all scans of one step (FBCRNN: one launch; BiGRU: one per layer)
             fl = sum(r[2] * r[1] for r in rows) / steps
-            x3 = (int(os.environ.get('PBSED_GRU_X3', '3')) >> (key == 'bptt_scan')) & 1 and h < 512
+            x3 = (int(os.environ.get('PBSED_GRU_X3', '3')) >> (key == 'bptt_scan')) & 1 and h < 512 and not plain_bf16
             tf = fl / (ms * 1e-3) / 1e12
             g[key] = {'ms_per_step': round(ms, 4), 'launches_per_step': round(sum(r[1] for r in rows) / steps, 2),
                       'gflop_per_step': round(fl / 1e9, 2), 'achieved': round(tf, 2),
                       'frac': round(tf / PEAK_TFLOPS['f32'], 4),
-                      'operands': 'bf16x3 (exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMA products per fp32 product)' if x3 else 'f32',
+                      'operands': ('bf16 (operands of the recurrent / projection products rounded to bf16; fp32 state and accumulation)'
+                                   if plain_bf16 else
+                                   'bf16x3 (exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMA products per fp32 product)' if x3 else 'f32'),
                       'executed': round(tf * (6 if x3 else 1), 2),
-                      'frac_executed': round(tf * 6 / PEAK_TFLOPS['bf16'] if x3 else tf / PEAK_TFLOPS['f32'], 4),
+                      'frac_executed': round(tf * (6 if x3 else 1) / PEAK_TFLOPS['bf16'] if (x3 or plain_bf16) else tf / PEAK_TFLOPS['f32'], 4),
                       'us_per_time_step': round(ms * 1e3 / (t * sum(r[1] for r in rows) / steps), 3)}
         if g:
             g.update(bound='mfma; latency-bound in practice: T dependent steps with an inter-workgroup hand-off each',

@@ -229,6 +229,19 @@ int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_
                                 float* const* dgi, float* const* dgh, const int* reverse /*host*/, const int* seq_len,
                                 int B, int H, int T, unsigned int* granules, unsigned int epoch,
                                 unsigned int* err_flag, void* stream);
+/* The same scans with plain bf16 operands of the recurrent / layer-boundary products (weights and h_{t-1} / gate gradients
+ * rounded to bf16 for the MFMA; fp32 accumulation, state, gate maths and outputs): the bf16 training mode
+ * (BASELINE.json configs[2]).  Same arguments, workspaces and save format as the fp32-class entry points. */
+int pbsed_gru_stack_fwd_granule_bf16(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
+                                     const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
+                                     float* const* hs, float* const* save, const int* reverse /*host*/, const int* seq_len,
+                                     int B, int H, int T, unsigned int* granules, unsigned int epoch,
+                                     unsigned int* err_flag, void* stream);
+int pbsed_gru_stack_bwd_granule_bf16(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
+                                     const float* const* hs, const float* const* save, const float* const* dy_top,
+                                     float* const* dgi, float* const* dgh, const int* reverse /*host*/, const int* seq_len,
+                                     int B, int H, int T, unsigned int* granules, unsigned int epoch,
+                                     unsigned int* err_flag, void* stream);
 int pbsed_bct_to_tbc(const float* src, float* dst, int B, int C, int T, void* stream);
 int pbsed_tbc_to_bct(const float* src, float* dst, int B, int C, int T, int shift, void* stream);
 int pbsed_transpose2d(const float* src, float* dst, int R, int C, void* stream);

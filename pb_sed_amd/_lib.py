@@ -69,7 +69,9 @@ SIGNATURES = {
     'pbsed_gru_scan_bwd': [I, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _i, _v, I, I, I, _v],
     'pbsed_gru_stack_fwd': [I, I, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _i, _v, I, I, I, _v],
     'pbsed_gru_stack_bwd_granule': [I, I, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _i, _v, I, I, I, _v, C.c_uint, _v, _v],
+    'pbsed_gru_stack_bwd_granule_bf16': [I, I, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _i, _v, I, I, I, _v, C.c_uint, _v, _v],
     'pbsed_gru_stack_fwd_granule': [I, I, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _i, _v, I, I, I, _v, C.c_uint, _v, _v],
+    'pbsed_gru_stack_fwd_granule_bf16': [I, I, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _i, _v, I, I, I, _v, C.c_uint, _v, _v],
     'pbsed_gru_stack_bwd': [I, I, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _pp, _i, _v, I, I, I, _v],
     'pbsed_fbcrnn_loss': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, I, I, F32, F32, I, F32, I, _v, _v],
     'pbsed_bicrnn_loss': [_v, _v, _v, _v, _v, _v, _v, I, I, I, I, _v],

@@ -85,6 +85,23 @@ __device__ __forceinline__ unsigned pack_bf16_rne(float lo, float hi) {         
 __device__ __forceinline__ f32x4 mfma_b16(u32x4_t a, u32x4_t b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gbf16x8, a), __builtin_bit_cast(gbf16x8, b), c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mfma_x3(const Bf3& a, const Bf3& b, f32x4 c);
+// Operand of a bf16-MFMA product in one of two formats: XS = 3 the exact three-way split (fp32-class), XS = 1 one part
+// rounded to nearest even (plain bf16 operands, the bf16 training mode); XS = 0: placeholder of the fp32-MFMA code paths.
+template <int XS> struct BfOp {};
+template <> struct BfOp<3> { Bf3 v; };
+template <> struct BfOp<1> { u32x4_t v; };
+template <int XS> __device__ __forceinline__ BfOp<XS> make_op(float4 a, float4 b) {
+    BfOp<XS> r;
+    if constexpr (XS == 3) r.v = split3x8(a, b);
+    if constexpr (XS == 1) r.v = u32x4_t{pack_bf16_rne(a.x, a.y), pack_bf16_rne(a.z, a.w), pack_bf16_rne(b.x, b.y), pack_bf16_rne(b.z, b.w)};
+    return r;
+}
+template <int XS> __device__ __forceinline__ f32x4 mfma_op(const BfOp<XS>& a, const BfOp<XS>& b, f32x4 c) {
+    if constexpr (XS == 3) return mfma_x3(a.v, b.v, c);
+    else if constexpr (XS == 1) return mfma_b16(a.v, b.v, c);
+    else return c;
+}
 __device__ __forceinline__ f32x4 mfma_x3(const Bf3& a, const Bf3& b, f32x4 c) {
     c = mfma_b16(a.lo, b.hi, c);
     c = mfma_b16(a.hi, b.lo, c);

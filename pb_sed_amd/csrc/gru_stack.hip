@@ -445,7 +445,7 @@ __device__ __forceinline__ void poll_tiles(float4 (&out)[NB][NL], __amdgpu_buffe
                                      __uint_as_float(q[nb][n].z & ~1u), __uint_as_float(q[nb][n].w & ~1u));
 }
 
-template <int KB, int NW, bool GW, bool X3 = false, int NB = 1>
+template <int KB, int NW, bool GW, int XS = 0, int NB = 1>
 __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsigned* gran_h_, unsigned* gran_gi_, unsigned epoch,
                                                      unsigned* err_flag, float (&red)[2][NW][NB][3][64][4], int& s_err) {
     constexpr int H = KB * NW * 16, NL = KB;           // NL: 16-byte loads per lane (16 k each) of this wave's H/NW range
@@ -483,11 +483,11 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
     // load pattern) and the weights follow the same order
     const int k0 = (is_mfma ? wave : 0) * NL * 16;
     constexpr int NM = (NL + 1) / 2;                 // X3: bf16 MFMAs (K = 32 = two of the poll's loads) per product term
-    float4 wv[X3 ? 1 : NL][3];
-    Bf3 w3[X3 ? NM : 1][3];
+    float4 wv[XS ? 1 : NL][3];
+    BfOp<XS> w3[XS ? NM : 1][3];
     if (is_mfma) {
         const float* W = (is_proj ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * H + k0 + lq * 4;
-        if constexpr (X3) {
+        if constexpr (XS > 0) {
 #pragma unroll
             for (int m = 0; m < NM; ++m)
 #pragma unroll
@@ -495,7 +495,7 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
                     const float4 w0 = *reinterpret_cast<const float4*>(W + (size_t)g * H * H + (2 * m) * 16);
                     const float4 w1 = 2 * m + 1 < NL ? *reinterpret_cast<const float4*>(W + (size_t)g * H * H + (2 * m + 1) * 16)
                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-                    w3[m][g] = split3x8(w0, w1);
+                    w3[m][g] = make_op<XS>(w0, w1);
                 }
         } else {
 #pragma unroll
@@ -567,12 +567,12 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
         if (contract) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                if constexpr (X3) {
+                if constexpr (XS > 0) {
 #pragma unroll
                     for (int m = 0; m < NM; ++m) {
-                        const Bf3 xs = split3x8(x[nb][2 * m], 2 * m + 1 < NL ? x[nb][2 * m + 1] : make_float4(0.f, 0.f, 0.f, 0.f));
+                        const BfOp<XS> xs = make_op<XS>(x[nb][2 * m], 2 * m + 1 < NL ? x[nb][2 * m + 1] : make_float4(0.f, 0.f, 0.f, 0.f));
 #pragma unroll
-                        for (int g = 0; g < 3; ++g) acc[nb][g] = mfma_x3(w3[m][g], xs, acc[nb][g]);
+                        for (int g = 0; g < 3; ++g) acc[nb][g] = mfma_op<XS>(w3[m][g], xs, acc[nb][g]);
                     }
                 } else {
 #pragma unroll
@@ -651,20 +651,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     gru_granule_fwd_body<KB, NW, false>(a, gran_h_, gran_gi_, epoch, err_flag, red, s_err);
 }
 
-template <int KB, int NW, bool X3, int NB>
+template <int KB, int NW, int XS, int NB>
 __global__ __launch_bounds__((NW + 4) * 64) void gru_granule_fwd_gw_kernel(GruStackArgs a, unsigned* gran_h_, unsigned* gran_gi_,
                                                                          unsigned epoch, unsigned* err_flag) {
     extern __shared__ __attribute__((aligned(16))) float red_dyn[];          // [2][NW][NB][3][64][4]: over 64 KB for NB = 2
     __shared__ int s_err;
     auto& red = *reinterpret_cast<float (*)[2][NW][NB][3][64][4]>(red_dyn);
-    gru_granule_fwd_body<KB, NW, true, X3, NB>(a, gran_h_, gran_gi_, epoch, err_flag, red, s_err);
+    gru_granule_fwd_body<KB, NW, true, XS, NB>(a, gran_h_, gran_gi_, epoch, err_flag, red, s_err);
 }
 
 // Backward twin.  Rings publish dh_t (masked by the sequence length) of their 16 units as granules [T][B][H];
 // consumers rebuild the gate gradients they contract with as dh * (factor saved by the forward scan), the factors
 // being plain loads issued one step ahead.  Projection blocks turn dh_t of the layer above into dy_t of the layer
 // below (granules [T][B][H] as well); dh*z of a thread's own unit stays in a register.  Scan order = top layer first.
-template <int KB, int NW, bool GW, bool X3 = false>
+template <int KB, int NW, bool GW, int XS = 0>
 __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsigned* gran_dh_, unsigned* gran_dy_, unsigned epoch,
                                                      unsigned* err_flag, float (&red)[2][NW][64][4], int& s_err) {
     constexpr int H = KB * NW * 16, G = 3 * H, NL = KB;     // NL: 16-byte loads per lane (16 units each)
@@ -695,16 +695,16 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
     const int k0 = (is_mfma ? wave : 0) * NL * 16;
     const GruStackLayer& X = is_proj ? a.lc[chain][layer + 1] : L;
     constexpr int NM = (NL + 1) / 2;                 // X3: bf16 MFMAs per product term (see gru_granule_fwd_body)
-    float4 wv[X3 ? 1 : NL][3];
-    Bf3 w3[X3 ? NM : 1][3];
+    float4 wv[XS ? 1 : NL][3];
+    BfOp<XS> w3[XS ? NM : 1][3];
     if (is_mfma) {
         const float* W = (is_proj ? L.w_ih : L.w_hh) + (size_t)(j0 + lr) * G + k0 + lq * 4;
-        if constexpr (X3) {
+        if constexpr (XS > 0) {
 #pragma unroll
             for (int m = 0; m < NM; ++m)
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
-                    w3[m][g] = split3x8(*reinterpret_cast<const float4*>(W + g * H + (2 * m) * 16),
+                    w3[m][g] = make_op<XS>(*reinterpret_cast<const float4*>(W + g * H + (2 * m) * 16),
                                         2 * m + 1 < NL ? *reinterpret_cast<const float4*>(W + g * H + (2 * m + 1) * 16)
                                                        : make_float4(0.f, 0.f, 0.f, 0.f));
         } else {
@@ -778,18 +778,18 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         if (!is_proj && layer < top && bv)
             qd[0] = __hip_atomic_load(g_dy + tb * H + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (bstep + 1 < a.T) load_own(bstep + 1);
-        if constexpr (X3) {
+        if constexpr (XS > 0) {
             if (contract) {
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
                     const int n0 = 2 * m, n1 = 2 * m + 1 < NL ? 2 * m + 1 : 2 * m;
                     const float k1 = 2 * m + 1 < NL ? 1.f : 0.f;
                     const float4 d0 = dh4[n0], d1 = make_float4(dh4[n1].x * k1, dh4[n1].y * k1, dh4[n1].z * k1, dh4[n1].w * k1);
-                    acc[0] = mfma_x3(w3[m][0], split3x8(make_float4(d0.x * pr[n0][0], d0.y * pr[n0][1], d0.z * pr[n0][2], d0.w * pr[n0][3]),
+                    acc[0] = mfma_op<XS>(w3[m][0], make_op<XS>(make_float4(d0.x * pr[n0][0], d0.y * pr[n0][1], d0.z * pr[n0][2], d0.w * pr[n0][3]),
                                                         make_float4(d1.x * pr[n1][0], d1.y * pr[n1][1], d1.z * pr[n1][2], d1.w * pr[n1][3])), acc[0]);
-                    acc[1] = mfma_x3(w3[m][1], split3x8(make_float4(d0.x * pz[n0][0], d0.y * pz[n0][1], d0.z * pz[n0][2], d0.w * pz[n0][3]),
+                    acc[1] = mfma_op<XS>(w3[m][1], make_op<XS>(make_float4(d0.x * pz[n0][0], d0.y * pz[n0][1], d0.z * pz[n0][2], d0.w * pz[n0][3]),
                                                         make_float4(d1.x * pz[n1][0], d1.y * pz[n1][1], d1.z * pz[n1][2], d1.w * pz[n1][3])), acc[1]);
-                    acc[2] = mfma_x3(w3[m][2], split3x8(make_float4(d0.x * pn[n0][0], d0.y * pn[n0][1], d0.z * pn[n0][2], d0.w * pn[n0][3]),
+                    acc[2] = mfma_op<XS>(w3[m][2], make_op<XS>(make_float4(d0.x * pn[n0][0], d0.y * pn[n0][1], d0.z * pn[n0][2], d0.w * pn[n0][3]),
                                                         make_float4(d1.x * pn[n1][0], d1.y * pn[n1][1], d1.z * pn[n1][2], d1.w * pn[n1][3])), acc[2]);
                 }
             }
@@ -855,12 +855,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     gru_granule_bwd_body<KB, NW, false>(a, gran_dh_, gran_dy_, epoch, err_flag, red, s_err);
 }
 
-template <int KB, int NW, bool X3>
+template <int KB, int NW, int XS>
 __global__ __launch_bounds__((NW + 4) * 64) void gru_granule_bwd_gw_kernel(GruStackArgs a, unsigned* gran_dh_, unsigned* gran_dy_,
                                                                          unsigned epoch, unsigned* err_flag) {
     __shared__ float red[2][NW][64][4];
     __shared__ int s_err;
-    gru_granule_bwd_body<KB, NW, true, X3>(a, gran_dh_, gran_dy_, epoch, err_flag, red, s_err);
+    gru_granule_bwd_body<KB, NW, true, XS>(a, gran_dh_, gran_dy_, epoch, err_flag, red, s_err);
 }
 
 }  // namespace pbsed
@@ -985,11 +985,15 @@ static bool granule_ring_xcd(bool bwd) {
 // must be ZERO before its first use; `epoch` must be odd on the first use of a workspace and change parity with
 // every call that uses it (the words of the previous call then never match); same T, B, H for the life of a
 // workspace.  err_flag: device uint32 (0 on entry; non-zero after a hand-off timed out: re-zero the workspace).
-int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
-                                const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
-                                float* const* hs, float* const* save, const int* reverse, const int* seq_len, int B,
-                                int H, int T, unsigned int* granules, unsigned int epoch, unsigned int* err_flag,
-                                void* stream) {
+}  // extern "C"
+
+// bf16: plain bf16 operands of the recurrent / projection products (fp32 state, accumulation and gate maths) - the scans of
+// the bf16 training mode (BASELINE.json configs[2]); else fp32-class products (bf16x3, or the fp32 MFMA with PBSED_GRU_X3=0).
+static int gru_stack_fwd_granule_impl(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
+                                      const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
+                                      float* const* hs, float* const* save, const int* reverse, const int* seq_len, int B,
+                                      int H, int T, unsigned int* granules, unsigned int epoch, unsigned int* err_flag,
+                                      int bf16, void* stream) {
     if (int e = stack_check(nchains, nlayers, B, H, T)) return e;
     if (epoch == 0 || !granules || !err_flag) { set_error("gru_stack_fwd_granule: need workspace and epoch != 0"); return PBSED_E_ARG; }
     const size_t Bp = (size_t)(B + 15) / 16 * 16;            // the exchanged states are stored in whole 16-row batch tiles
@@ -1030,9 +1034,11 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
     do {                                                                                                             \
         if ((gw & 1) && nb == 2) {                                                                                   \
-            if ((x3 & 1) && KB_ < 4) LAUNCH_GW(KB_, NW_, true, 2); else LAUNCH_GW(KB_, NW_, false, 2);               \
+            if (bf16 && KB_ < 4) LAUNCH_GW(KB_, NW_, 1, 2);                                                          \
+            else if ((x3 & 1) && KB_ < 4) LAUNCH_GW(KB_, NW_, 3, 2);                                                 \
+            else LAUNCH_GW(KB_, NW_, 0, 2);                                                                          \
         } else if (gw & 1) {                                                                                         \
-            if (x3 & 1) LAUNCH_GW(KB_, NW_, true, 1); else LAUNCH_GW(KB_, NW_, false, 1);                            \
+            if (bf16) LAUNCH_GW(KB_, NW_, 1, 1); else if (x3 & 1) LAUNCH_GW(KB_, NW_, 3, 1); else LAUNCH_GW(KB_, NW_, 0, 1);  \
         } else {                                                                                                     \
             hipLaunchKernelGGL((gru_granule_fwd_kernel<KB_, NW_>), grid, dim3(NW_ * 64), 0, s, a, granules, gran_gi,  \
                                epoch, err_flag);                                                                     \
@@ -1049,13 +1055,14 @@ int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi
     return check_launch("gru_stack_fwd_granule");
 }
 
+
 // Granule-exchange persistent BPTT.  granules: device uint32 workspace of nchains*T*Bp*H*(2*nlayers-1) words (Bp as above)
 // (dh_t of every layer, then dy_t of the layers below the top), zero before first use, epoch parity as above.
-int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
-                                const float* const* hs, const float* const* save, const float* const* dy_top,
-                                float* const* dgi, float* const* dgh, const int* reverse, const int* seq_len, int B, int H,
-                                int T, unsigned int* granules, unsigned int epoch, unsigned int* err_flag,
-                                void* stream) {
+static int gru_stack_bwd_granule_impl(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
+                                      const float* const* hs, const float* const* save, const float* const* dy_top,
+                                      float* const* dgi, float* const* dgh, const int* reverse, const int* seq_len, int B, int H,
+                                      int T, unsigned int* granules, unsigned int epoch, unsigned int* err_flag, int bf16,
+                                      void* stream) {
     if (int e = stack_check(nchains, nlayers, B, H, T)) return e;
     if (epoch == 0 || !granules || !err_flag) { set_error("gru_stack_bwd_granule: need workspace and epoch != 0"); return PBSED_E_ARG; }
     const size_t Bp = (size_t)(B + 15) / 16 * 16;
@@ -1085,11 +1092,14 @@ int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_
     static const int x3 = [] { const char* e = getenv("PBSED_GRU_X3"); return e ? atoi(e) : 3; }();     // bit 1 = BPTT scan
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
     do {                                                                                                             \
-        if ((gw & 2) && (x3 & 2) && KB_ < 4) {                                                                               \
-            hipLaunchKernelGGL((gru_granule_bwd_gw_kernel<KB_, NW_, true>), grid, dim3((NW_ + 4) * 64), 0, s, a,      \
+        if ((gw & 2) && bf16 && KB_ < 4) {                                                                           \
+            hipLaunchKernelGGL((gru_granule_bwd_gw_kernel<KB_, NW_, 1>), grid, dim3((NW_ + 4) * 64), 0, s, a,         \
+                               granules, gran_dy, epoch, err_flag);                                                  \
+        } else if ((gw & 2) && (x3 & 2) && KB_ < 4) {                                                                \
+            hipLaunchKernelGGL((gru_granule_bwd_gw_kernel<KB_, NW_, 3>), grid, dim3((NW_ + 4) * 64), 0, s, a,         \
                                granules, gran_dy, epoch, err_flag);                                                  \
         } else if (gw & 2) {                                                                                         \
-            hipLaunchKernelGGL((gru_granule_bwd_gw_kernel<KB_, NW_, false>), grid, dim3((NW_ + 4) * 64), 0, s, a,     \
+            hipLaunchKernelGGL((gru_granule_bwd_gw_kernel<KB_, NW_, 0>), grid, dim3((NW_ + 4) * 64), 0, s, a,         \
                                granules, gran_dy, epoch, err_flag);                                                  \
         } else {                                                                                                     \
             hipLaunchKernelGGL((gru_granule_bwd_kernel<KB_, NW_>), grid, dim3(NW_ * 64), 0, s, a, granules, gran_dy,  \
@@ -1104,6 +1114,44 @@ int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_
     }
 #undef LAUNCH_GRANULE
     return check_launch("gru_stack_bwd_granule");
+}
+
+extern "C" {
+
+int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
+                                const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
+                                float* const* hs, float* const* save, const int* reverse, const int* seq_len, int B,
+                                int H, int T, unsigned int* granules, unsigned int epoch, unsigned int* err_flag,
+                                void* stream) {
+    return gru_stack_fwd_granule_impl(nchains, nlayers, gi0, w_ih, b_ih, w_hh, b_hh, hs, save, reverse, seq_len, B, H, T, granules,
+                                      epoch, err_flag, 0, stream);
+}
+
+int pbsed_gru_stack_fwd_granule_bf16(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
+                                     const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
+                                     float* const* hs, float* const* save, const int* reverse, const int* seq_len, int B,
+                                     int H, int T, unsigned int* granules, unsigned int epoch, unsigned int* err_flag,
+                                     void* stream) {
+    return gru_stack_fwd_granule_impl(nchains, nlayers, gi0, w_ih, b_ih, w_hh, b_hh, hs, save, reverse, seq_len, B, H, T, granules,
+                                      epoch, err_flag, 1, stream);
+}
+
+int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
+                                const float* const* hs, const float* const* save, const float* const* dy_top,
+                                float* const* dgi, float* const* dgh, const int* reverse, const int* seq_len, int B, int H,
+                                int T, unsigned int* granules, unsigned int epoch, unsigned int* err_flag,
+                                void* stream) {
+    return gru_stack_bwd_granule_impl(nchains, nlayers, w_hh_t, w_ih_up_t, hs, save, dy_top, dgi, dgh, reverse, seq_len, B, H, T,
+                                      granules, epoch, err_flag, 0, stream);
+}
+
+int pbsed_gru_stack_bwd_granule_bf16(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
+                                     const float* const* hs, const float* const* save, const float* const* dy_top,
+                                     float* const* dgi, float* const* dgh, const int* reverse, const int* seq_len, int B, int H,
+                                     int T, unsigned int* granules, unsigned int epoch, unsigned int* err_flag,
+                                     void* stream) {
+    return gru_stack_bwd_granule_impl(nchains, nlayers, w_hh_t, w_ih_up_t, hs, save, dy_top, dgi, dgh, reverse, seq_len, B, H, T,
+                                      granules, epoch, err_flag, 1, stream);
 }
 
 // BPTT of the same stacks.  w_hh_t[i] = W_hh^T [H][3H]; w_ih_up_t[i] = (W_ih of layer l+1)^T [H][3H] (ignored

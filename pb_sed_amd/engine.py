@@ -414,7 +414,7 @@ def _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training, precisi
         gi0, [ch.p('weight_ih', l).detach() if l else None for ch, l in idx],
         [ch.p('bias_ih', l).detach() if l else None for ch, l in idx],
         [ch.p('weight_hh', l).detach() for ch, l in idx], [ch.p('bias_hh', l).detach() for ch, l in idx],
-        [ch.reverse for ch in chains], seq_dev, nl, save=training)
+        [ch.reverse for ch in chains], seq_dev, nl, save=training, precision='bf16' if precision == 'bf16' else 'f32')
     # one chain per wrapper: the heads take the top layer's states in the scans' layout
     top = [hs[ci * nl + nl - 1] for ci in range(len(chains))]
     logits, head_ctx = _heads_forward(wrappers, [None] * len(chains), seq_dev, seq_host, training, precision, x_tbc=top)
@@ -432,7 +432,8 @@ def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     idx = [(ch, l) for ch in chains for l in range(nl)]
     w_hh_t = [ops.transpose2d(ch.p('weight_hh', l).detach()) for ch, l in idx]
     w_ih_up_t = [ops.transpose2d(ch.p('weight_ih', l + 1).detach()) if l + 1 < nl else None for ch, l in idx]
-    dgi, dgh = ops.gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, [ch.reverse for ch in chains], seq_dev, nl)
+    dgi, dgh = ops.gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, [ch.reverse for ch in chains], seq_dev, nl,
+                                 precision='bf16' if precision == 'bf16' else 'f32')
     dh = None
     jobs = ([], [], [], [], [])                  # all weight gradients of the stacks: one launch
     for ci, ch in enumerate(chains):
@@ -512,7 +513,7 @@ def rnn_forward(wrappers, h, seq_dev, seq_host, training, precision='f32', h_tbc
             # one layer of a (bi)directional GRU = len(chains) independent one-layer stacks: persistent scan
             none = [None] * len(chains)
             hs, save = ops.gru_stack_fwd(gi, none, none, w_hh_l, b_hh_l, [ch.reverse for ch in chains], seq_dev, 1,
-                                         save=training)
+                                         save=training, precision='bf16' if precision == 'bf16' else 'f32')
         else:
             hs, save = ops.gru_scan_fwd(gi, w_hh_l, b_hh_l, [ch.reverse for ch in chains], seq_dev, save=training)
         layer_ctx.append((src, pcs, hs, save))
@@ -550,7 +551,7 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
         w_hh_t = [ops.transpose2d(ch.p('weight_hh', l).detach()) for ch in chains]
         if _scan_as_stack(wrappers):
             dgi, dgh = ops.gru_stack_bwd(w_hh_t, [None] * len(chains), hs, save, dy, [ch.reverse for ch in chains],
-                                         seq_dev, 1)
+                                         seq_dev, 1, precision='bf16' if precision == 'bf16' else 'f32')
         else:
             dgi, dgh = ops.gru_scan_bwd(w_hh_t, hs, save, dy, [ch.reverse for ch in chains], seq_dev)
         x_cat = {}                                 # the layer input once per wrapper, time-major, for the weight gradients

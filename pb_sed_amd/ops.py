@@ -663,7 +663,7 @@ def _per_chain(nch, nlayers, b, h, t, dev, fwd=False):
     return nch > 1 and not _granule_scan(nch, nlayers, b, h, t, dev, fwd) and _granule_scan(1, nlayers, b, h, t, dev, fwd)
 
 
-def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=True):
+def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=True, precision='f32'):
     """Layer-wavefront scan of unidirectional stacks.  gi0: per chain [T,B,3H]; weight lists are indexed
     [chain*nlayers + layer] (w_ih/b_ih entries of layer 0 may be None).  Returns (hs, save) lists."""
     nch = len(gi0)
@@ -677,7 +677,7 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
         hs, sv = [], []
         for c in range(nch):
             sl = slice(c * nlayers, (c + 1) * nlayers)
-            hc, sc = gru_stack_fwd(gi0[c:c + 1], w_ih[sl], b_ih[sl], w_hh[sl], b_hh[sl], reverse[c:c + 1], seq_len, nlayers, save)
+            hc, sc = gru_stack_fwd(gi0[c:c + 1], w_ih[sl], b_ih[sl], w_hh[sl], b_hh[sl], reverse[c:c + 1], seq_len, nlayers, save, precision)
             hs += hc
             sv += sc if save else []
         return hs, (sv if save else None)
@@ -693,7 +693,7 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
             gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (nlayers + 3 * (nlayers - 1)), dtype=torch.int32, device=dev), 0]
         ws = _gru_err_flag(dev)
         watch_end = scan_watch.bracket(('fwd', nch, nlayers, b, h, t)) if scan_watch is not None else None
-        call('pbsed_gru_stack_fwd_granule', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih),
+        call('pbsed_gru_stack_fwd_granule_bf16' if precision == 'bf16' else 'pbsed_gru_stack_fwd_granule', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih),
              _lib.ptr_array(b_ih), _lib.ptr_array(w_hh), _lib.ptr_array(b_hh), _lib.ptr_array(hs),
              _lib.ptr_array(sv) if save else None, _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]),
              gw[1] + 1, ptr(ws), stream(), tag=f'{nch}x{nlayers} B{b} H{h} T{t}',
@@ -708,7 +708,7 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
     return hs, sv
 
 
-def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers):
+def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers, precision='f32'):
     nch = len(dy_top)
     t, b, h = hs[0].shape
     dev = hs[0].device
@@ -716,7 +716,7 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
         dgi, dgh = [], []
         for c in range(nch):
             sl = slice(c * nlayers, (c + 1) * nlayers)
-            a, g_ = gru_stack_bwd(w_hh_t[sl], w_ih_up_t[sl], hs[sl], save[sl], dy_top[c:c + 1], reverse[c:c + 1], seq_len, nlayers)
+            a, g_ = gru_stack_bwd(w_hh_t[sl], w_ih_up_t[sl], hs[sl], save[sl], dy_top[c:c + 1], reverse[c:c + 1], seq_len, nlayers, precision)
             dgi += a
             dgh += g_
         return dgi, dgh
@@ -731,7 +731,7 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
             gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (2 * nlayers - 1), dtype=torch.int32, device=dev), 0]
         ws = _gru_err_flag(dev)
         watch_end = scan_watch.bracket(('bwd', nch, nlayers, b, h, t)) if scan_watch is not None else None
-        call('pbsed_gru_stack_bwd_granule', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t),
+        call('pbsed_gru_stack_bwd_granule_bf16' if precision == 'bf16' else 'pbsed_gru_stack_bwd_granule', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t),
              _lib.ptr_array(hs), _lib.ptr_array(save), _lib.ptr_array(dy_top), _lib.ptr_array(dgi), _lib.ptr_array(dgh),
              _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]), gw[1] + 1, ptr(ws), stream(),
              tag=f'{nch}x{nlayers} B{b} H{h} T{t}', flops=2. * nch * (2 * nlayers - 1) * t * b * 3 * h * h)

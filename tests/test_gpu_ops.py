@@ -718,3 +718,36 @@ def test_tm_conv_layer_vs_torch(cin, cout, kw, t, b, pro, precision):
     ops.tm_conv_bwd_weight(x_t, g_t, tc, dw, db, st, rowmask, precision=precision)
     close(dw, wr.grad.float(), atol=(3e-2 if lo else 3e-5) * n ** .5, rtol=tol, name='tm conv dw')
     close(db, br.grad.float(), atol=1e-4 * n ** .5, rtol=1e-4, name='tm conv db')
+
+
+@pytest.mark.parametrize('b,h,t,nl', [(7, 128, 130, 2), (32, 256, 500, 1), (40, 64, 33, 2)])
+def test_gru_scans_with_bf16_operands_stay_close_to_the_fp32_scans(b, h, t, nl):
+    """pbsed_gru_stack_{fwd,bwd}_granule_bf16 (plain bf16 operands of the recurrent / projection products, the bf16 training
+    mode): states and BPTT gradients against the fp32-class scans on the same inputs - bf16 rounding of W and h (2^-9 each)
+    through T dependent steps; the tolerance is that of the bf16 convolutions."""
+    from pb_sed_amd import ops
+    torch.manual_seed(9)
+    nch = 2
+    seq = torch.as_tensor(np.sort(np.random.RandomState(2).randint(t // 2, t + 1, b))[::-1].copy(), dtype=torch.int32).to(DEV)
+    gi0 = [torch.randn(t, b, 3 * h, device=DEV) * .5 for _ in range(nch)]
+    mk = lambda *s: torch.randn(*s, device=DEV) * h ** -.5
+    idx = [(c, l) for c in range(nch) for l in range(nl)]
+    w_ih = [mk(3 * h, h) if l else None for c, l in idx]
+    b_ih = [mk(3 * h) if l else None for c, l in idx]
+    w_hh = [mk(3 * h, h) for _ in idx]
+    b_hh = [mk(3 * h) for _ in idx]
+    dy = [torch.randn(t, b, h, device=DEV) * (torch.arange(t, device=DEV)[:, None, None] < seq[None, :, None]) for _ in range(nch)]
+    out = {}
+    for prec in ('f32', 'bf16'):
+        hs, save = ops.gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, [False, True], seq, nl, save=True, precision=prec)
+        w_hh_t = [ops.transpose2d(w) for w in w_hh]
+        w_up = [ops.transpose2d(w_ih[c * nl + l + 1]) if l + 1 < nl else None for c, l in idx]
+        dgi, dgh = ops.gru_stack_bwd(w_hh_t, w_up, hs, save, dy, [False, True], seq, nl, precision=prec)
+        ops.check_gru_sync()
+        out[prec] = (hs, dgi, dgh)
+    for a, r in zip(out['bf16'][0], out['f32'][0]):
+        assert (a - r).abs().max().item() < 3e-2
+    for k in (1, 2):
+        for a, r in zip(out['bf16'][k], out['f32'][k]):
+            assert ((a - r).norm() / r.norm().clamp_min(1e-6)).item() < 5e-2
+    assert (out['bf16'][0][0] - out['f32'][0][0]).abs().max().item() > 0      # it is the other kernel
