@@ -480,10 +480,12 @@ def rnn_forward(wrappers, h, seq_dev, seq_host, training, precision='f32', h_tbc
     chains = _chains(wrappers)
     num_layers = wrappers[0].num_layers
     assert all(w.num_layers == num_layers for w in wrappers)
-    if not any(w.bidirectional for w in wrappers) and wrappers[0].hidden_size in (64, 128, 256, 512) \
+    if h is not None and not any(w.bidirectional for w in wrappers) and wrappers[0].hidden_size in (64, 128, 256, 512) \
             and all(w.rnn.input_size == h.shape[1] for w in wrappers):
         return _stack_rnn_forward(wrappers, chains, h, seq_dev, seq_host, training, precision, h_tbc)
     of_w = [[i for i, ch in enumerate(chains) if ch.widx == wi] for wi in range(len(wrappers))]
+    # ``h_tbc`` may carry zero channels behind the input_size real ones (widths like 266 = 256 + 10 tags padded to whole
+    # float4s): the first layer's weights are padded with zero columns to match
     if h_tbc is None and h.shape[1] % 4 == 0:
         h_tbc = ops.bct_to_tbc(h)
     src = [[h_tbc] if h_tbc is not None else None for _ in wrappers]      # per wrapper: time-major sources of the layer input
@@ -496,6 +498,8 @@ def rnn_forward(wrappers, h, seq_dev, seq_host, training, precision='f32', h_tbc
             if xs is not None:
                 if len(xs) == 1:
                     ws = [w_ih.detach()]
+                    if xs[0].shape[2] != w_ih.shape[1]:          # zero-padded input channels
+                        ws = [torch.cat([ws[0], ws[0].new_zeros((w_ih.shape[0], xs[0].shape[2] - w_ih.shape[1]))], dim=1)]
                 else:                                  # one column block of W_ih per source
                     edges = np.cumsum([0] + [x.shape[2] for x in xs])
                     ws = [w_ih.detach()[:, edges[j]:edges[j + 1]].contiguous() for j in range(len(xs))]
@@ -546,6 +550,7 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
                 dy[i] = ops.bct_to_tbc(d_out[:, k * hid:(k + 1) * hid].contiguous())
     dh_in = None
     jobs = ([], [], [], [], [])                  # weight gradients of ALL layers: one launch after the last scan
+    padded = []                                  # (gradient of a zero-padded W_ih, the parameter's gradient)
     for l in reversed(range(num_layers)):
         src, pcs, hs, save = layer_ctx[l]
         w_hh_t = [ops.transpose2d(ch.p('weight_hh', l).detach()) for ch in chains]
@@ -570,7 +575,12 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
                     if ch.widx not in x_cat:
                         xs = src[ch.widx]
                         x_cat[ch.widx] = xs[0] if len(xs) == 1 else torch.cat(xs, dim=2)
-                    _wgrad_job(jobs, dgi[i], x_cat[ch.widx], 0, _grad(w_ih), _grad(ch.p('bias_ih', l)))
+                    dw = _grad(w_ih)
+                    if x_cat[ch.widx].shape[2] != w_ih.shape[1]:     # zero-padded input channels: gradient of the padded matrix
+                        dw_pad = dw.new_zeros((w_ih.shape[0], x_cat[ch.widx].shape[2]))
+                        padded.append((dw_pad, dw))
+                        dw = dw_pad
+                    _wgrad_job(jobs, dgi[i], x_cat[ch.widx], 0, dw, _grad(ch.p('bias_ih', l)))
                 else:                                # e.g. 266 = 256 + 10 tag-conditioned inputs: not a float4 multiple
                     ops.conv_bwd_weight(h, dgi_b(i), pcs[i], _grad(w_ih), _grad(ch.p('bias_ih', l)),
                                         precision='bf16' if _prec(precision, pcs[i].cin) == 'bf16' else 'f32')
@@ -580,6 +590,9 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
             mine = of_w[wi]
             if pcs[mine[0]] is None:
                 w_t = [ops.transpose2d(chains[i].p('weight_ih', l).detach()) for i in mine]       # [In, 3H]
+                k_in = src[wi][0].shape[2] if len(src[wi]) == 1 else w_t[0].shape[0]
+                if k_in != w_t[0].shape[0]:               # zero-padded input channels: zero rows
+                    w_t = [torch.cat([w, w.new_zeros((k_in - w.shape[0], w.shape[1]))]) for w in w_t]
                 gp = _gemm_prec(precision, w_t[0].shape[1])
                 if l > 0:                            # straight into the per-chain gradients of the layer below
                     for k, i in enumerate(mine):
@@ -595,6 +608,8 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
         dy = new_dy
     if jobs[0]:
         ops.gru_wgrad(*jobs, precision='bf16' if precision == 'bf16' else 'f32')
+    for dw_pad, dw in padded:
+        dw.add_(dw_pad[:, :dw.shape[1]])
     return dh_in
 
 

@@ -17,9 +17,19 @@ class _NetFunction(torch.autograd.Function):
         layers = engine.describe_stack([model.cnn.cnn_2d, model.cnn.cnn_1d])
         h, cnn_ctx = engine.stack_forward(layers, x, seq_dev, seq_host, training, model.conv_precision)
         n_h = h.shape[1]
+        h_tbc = None
         if tag is not None:
-            h = torch.cat([h, tag.reshape(h.shape[0], -1, 1).to(h.dtype).expand(-1, -1, h.shape[-1])], dim=1).contiguous()
-        logits, rnn_ctx = engine.rnn_forward([model.rnn], h, seq_dev, seq_host, training, model.conv_precision)
+            # the GRU input in the scans' layout [T, B, C + K (+ zero channels up to whole float4s)]: the tags are appended
+            # there, so the first layer's projections run time-major like the others (the padded width is the engine's affair)
+            b, _, t = h.shape
+            k = tag.shape[1]
+            hc = cnn_ctx.tbc_out if cnn_ctx.tbc_out is not None else ops.bct_to_tbc(h)
+            parts = [hc, tag.to(h.dtype).reshape(1, b, k).expand(t, b, k)]
+            if (n_h + k) % 4:
+                parts.append(h.new_zeros((t, b, 4 - (n_h + k) % 4)))
+            h_tbc = torch.cat(parts, dim=2)
+            h = None
+        logits, rnn_ctx = engine.rnn_forward([model.rnn], h, seq_dev, seq_host, training, model.conv_precision, h_tbc=h_tbc)
         if model.keep_logits:
             model.last_logits = [logits[0].detach().clone()]
         y = ops.squash_fwd(logits[0], 0.)
