@@ -201,17 +201,20 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
-template <int FT, int TT, int KH, int KW, bool POOL>
-struct ConvB2Cfg : ConvBCfg<FT, TT, KH, KW, 1, POOL> {
-    using B = ConvBCfg<FT, TT, KH, KW, 1, POOL>;
+// NS = 1: plain bf16 operands; NS = 3: exact three-way splits (Bf3 in common.h: the input is split while it is staged, the
+// weights arrive split from the pack), six part products per product - fp32-class results on the bf16 MFMA.
+template <int NS, int FT, int TT, int KH, int KW, bool POOL>
+struct ConvB2Cfg : ConvBCfg<FT, TT, KH, KW, NS, POOL> {
+    using B = ConvBCfg<FT, TT, KH, KW, NS, POOL>;
+    static constexpr int IN_PART = B::IN_HALFS / NS, W_PART = B::W_HALFS / NS;
     static constexpr int QR = B::ROW / 4;
     static constexpr int IN_ITEMS2 = (CB_CK / 8) * B::ROWS * QR, IN_PER_T2 = (IN_ITEMS2 + 255) / 256;
     static constexpr int W_ITEMS2 = KW * CB_COUT_T * (CB_CK / 8), W_PER_T2 = (W_ITEMS2 + 255) / 256;
 };
 
-template <int FT, int TT, int KH, int KW, bool POOL, bool DGRAD>
+template <int NS, int FT, int TT, int KH, int KW, bool POOL, bool DGRAD>
 __global__ __launch_bounds__(256) void conv_bf16v2_kernel(ConvFwdArgs a, const unsigned short* __restrict__ wpb) {
-    using C = ConvB2Cfg<FT, TT, KH, KW, POOL>;
+    using C = ConvB2Cfg<NS, FT, TT, KH, KW, POOL>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned short* in_s = reinterpret_cast<unsigned short*>(smem_raw);            // [ROWS][ROW][CKP]
     unsigned short* w_s = in_s + C::IN_HALFS;                                       // [KW][64][CKP]
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256) void conv_bf16v2_kernel(ConvFwdArgs a, const u
     const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
         unpool ? const_cast<uint8_t*>(a.unpool_idx) + (size_t)b * clip_elems : nullptr, 0, unpool ? clip_elems : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short*>(wpb), 0, (unsigned)(C::KK * a.CinP * a.CoutP) * 2u, 0x00020000);
+        const_cast<unsigned short*>(wpb), 0, (unsigned)(NS * C::KK * a.CinP * a.CoutP) * 2u, 0x00020000);
     const unsigned cstride = (unsigned)(Fsrc * a.T) * 4u;           // bytes between channels of one clip
     const unsigned step_x = cstride * CB_CK;
 
@@ -275,7 +278,8 @@ __global__ __launch_bounds__(256) void conv_bf16v2_kernel(ConvFwdArgs a, const u
         q_m[i] = (ok ? min(max(tlim - tq, 0), 4) : 0) | ((f & 1) << 8) | (it < C::IN_ITEMS2 ? 0x1000 : 0);
         q_c[i] = oc * 8;
     }
-    u32x4_t rw[C::W_PER_T2];
+    u32x4_t rw[NS][C::W_PER_T2];
+    const unsigned w_part_step = (unsigned)((size_t)C::KK * a.CoutP * a.CinP * 2);      // bytes between the parts of the packed weights
     unsigned w_voff[C::W_PER_T2];
     int w_lds[C::W_PER_T2];
 #pragma unroll
@@ -339,25 +343,39 @@ __global__ __launch_bounds__(256) void conv_bf16v2_kernel(ConvFwdArgs a, const u
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                u32x4_t o;
                 const bool keep = k < n_ok;                           // zero padding is post-activation
-                o.x = keep ? pack_bf16(v[0][k], v[1][k]) : 0u;
-                o.y = keep ? pack_bf16(v[2][k], v[3][k]) : 0u;
-                o.z = keep ? pack_bf16(v[4][k], v[5][k]) : 0u;
-                o.w = keep ? pack_bf16(v[6][k], v[7][k]) : 0u;
-                *reinterpret_cast<u32x4_t*>(in_s + q_lds[i] + k * CB_CKP) = o;
+                if constexpr (NS == 3) {
+                    const float z = keep ? 1.f : 0.f;
+                    const Bf3 p = split3x8(make_float4(v[0][k] * z, v[1][k] * z, v[2][k] * z, v[3][k] * z),
+                                           make_float4(v[4][k] * z, v[5][k] * z, v[6][k] * z, v[7][k] * z));
+                    *reinterpret_cast<u32x4_t*>(in_s + q_lds[i] + k * CB_CKP) = p.hi;
+                    *reinterpret_cast<u32x4_t*>(in_s + C::IN_PART + q_lds[i] + k * CB_CKP) = p.mid;
+                    *reinterpret_cast<u32x4_t*>(in_s + 2 * C::IN_PART + q_lds[i] + k * CB_CKP) = p.lo;
+                } else {
+                    u32x4_t o;
+                    o.x = keep ? pack_bf16(v[0][k], v[1][k]) : 0u;
+                    o.y = keep ? pack_bf16(v[2][k], v[3][k]) : 0u;
+                    o.z = keep ? pack_bf16(v[4][k], v[5][k]) : 0u;
+                    o.w = keep ? pack_bf16(v[6][k], v[7][k]) : 0u;
+                    *reinterpret_cast<u32x4_t*>(in_s + q_lds[i] + k * CB_CKP) = o;
+                }
             }
         }
     };
     auto load_w = [&](int c0, int kh) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < C::W_PER_T2; ++i)
-            rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_voff[i] + (unsigned)kh * w_kh_step + (unsigned)c0 * 2u, 0, 0);
+        for (int p = 0; p < NS; ++p)
+#pragma unroll
+            for (int i = 0; i < C::W_PER_T2; ++i)
+                rw[p][i] = __builtin_amdgcn_raw_buffer_load_b128(
+                    rs_w, w_voff[i] == OOB ? OOB : w_voff[i] + (unsigned)p * w_part_step + (unsigned)kh * w_kh_step + (unsigned)c0 * 2u, 0, 0);
     };
     auto store_w = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < C::W_PER_T2; ++i)
-            if (tid + i * 256 < C::W_ITEMS2) *reinterpret_cast<u32x4_t*>(w_s + w_lds[i]) = rw[i];
+        for (int p = 0; p < NS; ++p)
+#pragma unroll
+            for (int i = 0; i < C::W_PER_T2; ++i)
+                if (tid + i * 256 < C::W_ITEMS2) *reinterpret_cast<u32x4_t*>(w_s + p * C::W_PART + w_lds[i]) = rw[p][i];
     };
 
     load_in();
@@ -376,17 +394,25 @@ __global__ __launch_bounds__(256) void conv_bf16v2_kernel(ConvFwdArgs a, const u
             if (kh == 0 && c0 + CB_CK < a.CinP) load_in();
 #pragma unroll
             for (int kw = 0; kw < KW; ++kw) {
-                us8 af[C::MTW];
+                u32x4_t af[C::MTW][NS];
 #pragma unroll
                 for (int m = 0; m < C::MTW; ++m)
-                    af[m] = *reinterpret_cast<const us8*>(w_s + ((size_t)(kw * CB_COUT_T + (wm * C::MTW + m) * 16 + lr)) * CB_CKP + lq * 8);
+#pragma unroll
+                    for (int p = 0; p < NS; ++p)
+                        af[m][p] = *reinterpret_cast<const u32x4_t*>(w_s + p * C::W_PART + ((size_t)(kw * CB_COUT_T + (wm * C::MTW + m) * 16 + lr)) * CB_CKP + lq * 8);
 #pragma unroll
                 for (int n = 0; n < C::NTW; ++n) {
                     const int fl = n / C::NTT, tt = wn * C::NTT + n % C::NTT;
-                    const us8 bfr = *reinterpret_cast<const us8*>(
-                        in_s + ((size_t)((fl + kh) * C::ROW + tt * 16 + lr + kw + (C::HALO - PADW))) * CB_CKP + lq * 8);
+                    u32x4_t bfr[NS];
 #pragma unroll
-                    for (int m = 0; m < C::MTW; ++m) acc[m][n] = mfma_bf16(af[m], bfr, acc[m][n]);
+                    for (int p = 0; p < NS; ++p)
+                        bfr[p] = *reinterpret_cast<const u32x4_t*>(
+                            in_s + p * C::IN_PART + ((size_t)((fl + kh) * C::ROW + tt * 16 + lr + kw + (C::HALO - PADW))) * CB_CKP + lq * 8);
+#pragma unroll
+                    for (int m = 0; m < C::MTW; ++m) {
+                        if constexpr (NS == 3) acc[m][n] = mfma_x3(Bf3{af[m][0], af[m][1], af[m][2]}, Bf3{bfr[0], bfr[1], bfr[2]}, acc[m][n]);
+                        else acc[m][n] = mfma_b16(af[m][0], bfr[0], acc[m][n]);
+                    }
                 }
             }
         }
@@ -394,9 +420,9 @@ __global__ __launch_bounds__(256) void conv_bf16v2_kernel(ConvFwdArgs a, const u
     conv_epilogue<CB_COUT_T, FT, TT, C::MTW, C::NTT, C::WN, POOL, DGRAD>(a, acc, st_s, b, f0, t0, cout0, sl, wm, wn, lq, lr, tid);
 }
 
-template <int FT, int TT, int KH, int KW, bool POOL, bool DGRAD>
+template <int NS, int FT, int TT, int KH, int KW, bool POOL, bool DGRAD>
 static int launch_b2(const ConvFwdArgs& a, const unsigned short* wpb, hipStream_t s) {
-    using C = ConvB2Cfg<FT, TT, KH, KW, POOL>;
+    using C = ConvB2Cfg<NS, FT, TT, KH, KW, POOL>;
     if ((size_t)a.Cout * a.F * a.T * 4 >= (1ull << 29) || (size_t)a.Cin * a.F * a.T * 4 >= (1ull << 30)) {
         set_error("conv_bf16: one clip of the input / output must stay below 1 GiB / 512 MiB (Cin=%d Cout=%d F=%d T=%d)", a.Cin, a.Cout, a.F, a.T);
         return PBSED_E_ARG;
@@ -405,7 +431,7 @@ static int launch_b2(const ConvFwdArgs& a, const unsigned short* wpb, hipStream_
     dim3 grid(nTt * nFt * a.B, a.CoutP / CB_COUT_T);
     const size_t lds = C::LDS_BYTES + (size_t)2 * a.CinP * sizeof(float);
     if (lds > 160 * 1024) { set_error("conv_bf16: %d input channels need %zu B of LDS", a.Cin, lds); return PBSED_E_UNSUPPORTED; }
-    auto kern = conv_bf16v2_kernel<FT, TT, KH, KW, POOL, DGRAD>;
+    auto kern = conv_bf16v2_kernel<NS, FT, TT, KH, KW, POOL, DGRAD>;
     PBSED_DYN_LDS_ONCE(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, wpb);
     return check_launch("conv_bf16v2");
@@ -446,17 +472,18 @@ static int launch_b(const ConvFwdArgs& a, const unsigned short* wpb, hipStream_t
     return check_launch("conv_bf16");
 }
 
+template <int NS>
 static int dispatch_b2(const ConvFwdArgs& a, const unsigned short* wpb, int KH, int KW, int pool, int dgrad, hipStream_t s) {
 #define CB2(FT_, TT_, KH_, KW_)                                                   \
     do {                                                                          \
-        if (dgrad) return launch_b2<FT_, TT_, KH_, KW_, false, true>(a, wpb, s);  \
-        if (pool) return launch_b2<FT_, TT_, KH_, KW_, true, false>(a, wpb, s);   \
-        return launch_b2<FT_, TT_, KH_, KW_, false, false>(a, wpb, s);            \
+        if (dgrad) return launch_b2<NS, FT_, TT_, KH_, KW_, false, true>(a, wpb, s);  \
+        if (pool) return launch_b2<NS, FT_, TT_, KH_, KW_, true, false>(a, wpb, s);   \
+        return launch_b2<NS, FT_, TT_, KH_, KW_, false, false>(a, wpb, s);            \
     } while (0)
 #define CB21(TT_, KW_)                                                            \
     do {                                                                          \
-        if (dgrad) return launch_b2<1, TT_, 1, KW_, false, true>(a, wpb, s);      \
-        return launch_b2<1, TT_, 1, KW_, false, false>(a, wpb, s);                \
+        if (dgrad) return launch_b2<NS, 1, TT_, 1, KW_, false, true>(a, wpb, s);      \
+        return launch_b2<NS, 1, TT_, 1, KW_, false, false>(a, wpb, s);                \
     } while (0)
     if (KH == 3 && KW == 3) CB2(4, 64, 3, 3);
     if (KH == 1 && KW == 3 && !pool) CB21(128, 3);
@@ -470,7 +497,9 @@ static int dispatch_b2(const ConvFwdArgs& a, const unsigned short* wpb, int KH, 
 template <int NSPLIT>
 static int dispatch_b(const ConvFwdArgs& a, const unsigned short* wpb, int KH, int KW, int pool, int dgrad, hipStream_t s) {
     static const bool v1 = getenv("PBSED_BF16_V1") ? atoi(getenv("PBSED_BF16_V1")) != 0 : false;
-    if (NSPLIT == 1 && !v1) return dispatch_b2(a, wpb, KH, KW, pool, dgrad, s);
+    // PBSED_BF16X3_V2 (default 1): the three-part (fp32-class) format runs the pipelined kernel too
+    static const bool x3v2 = getenv("PBSED_BF16X3_V2") ? atoi(getenv("PBSED_BF16X3_V2")) != 0 : true;
+    if (!v1 && (NSPLIT == 1 || x3v2)) return dispatch_b2<NSPLIT>(a, wpb, KH, KW, pool, dgrad, s);
 #define CB(FT_, TT_, KH_, KW_)                                                             \
     do {                                                                                   \
         if (dgrad) return launch_b<FT_, TT_, KH_, KW_, NSPLIT, false, true>(a, wpb, s);    \

@@ -50,7 +50,15 @@ __global__ void pack_batched_kernel(const PackDesc* __restrict__ descs) {
             } else if (co < d.Cin && ci < d.Cout) {
                 v = d.src[((size_t)ci * d.Cin + co) * KK + (KK - 1 - kk)];
             }
-            dst[i] = f2bf_rne(v);
+            if (d.mode >= 6) {                             // three exact-ish parts [part][tap][OutP][InP] (bf16x3 operands)
+                const unsigned short h0 = f2bf_rne(v);
+                float r = v - __uint_as_float((unsigned)h0 << 16);
+                const unsigned short h1 = f2bf_rne(r);
+                r -= __uint_as_float((unsigned)h1 << 16);
+                dst[i] = h0; dst[total + i] = h1; dst[2 * total + i] = f2bf_rne(r);
+            } else {
+                dst[i] = f2bf_rne(v);
+            }
         }
         return;
     }

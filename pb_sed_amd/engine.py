@@ -121,6 +121,11 @@ def _prec(precision, cin, pc=None, dgrad=False):
     >= 32 channels into >= 64 output channels of the launch (a data gradient produces the layer's cin)."""
     if precision != 'f32':
         return precision if cin >= 32 else 'f32'
+    # Conv1d layers of the fp32 path: the pipelined bf16-MFMA kernel with exact three-way operand splits (fp32-class results,
+    # csrc/conv_bf16.hip NS = 3) is ahead of the fp32-MFMA kernel there (256->256 k = 3: 66 -> 44 us, k = 1: 31 -> 25 us)
+    if pc is not None and pc.weight.dim() == 3 and pc.cin >= 32 and pc.cout >= 32 \
+            and os.environ.get('PBSED_CONV1D_X3', '1') != '0':
+        return 'bf16x3'
     if pc is not None and pc.kh == 3 and pc.kw == 3 and os.environ.get('PBSED_CONV_WINO', '1') != '0':
         k_in, n_out = (pc.cout, pc.cin) if dgrad else (pc.cin, pc.cout)
         if k_in >= 32 and n_out >= 64:

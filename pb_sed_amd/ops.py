@@ -139,8 +139,11 @@ class PackedConv:
         call('pbsed_pack_conv_weights_bf16', ptr(w), ptr(wp), self.cout, self.cin, self.kh, self.kw, dgrad, nsplit,
              stream())
         cache[ck] = wp
-        if nsplit == 1:          # plain bf16 copies join the one-launch refresh after every optimiser step
-            _register_pack(self.owner, self.weight, wp, (self.cout, self.cin, self.kh, self.kw, inp.value, outp.value), 4 + dgrad, ck)
+        # the bf16 copies (one part, or the three parts of the fp32-class format) join the one-launch refresh after every
+        # optimiser step
+        if nsplit in (1, 3):
+            _register_pack(self.owner, self.weight, wp, (self.cout, self.cin, self.kh, self.kw, inp.value, outp.value),
+                           (4 if nsplit == 1 else 6) + dgrad, ck)
         return wp
 
     def _pack_wino(self, dgrad):

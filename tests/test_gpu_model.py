@@ -235,7 +235,8 @@ def test_fbcrnn_conv_precision_modes(precision, tol):
     refp = dict(ref.named_parameters())
     # bf16x3: the fp32 class (both sides are fp32 implementations of a graph with ReLU / argmax switches, see
     # test_gpu_configs._rounding_sensitivity); plain bf16 gradients: sanity bound only
-    gtol = 5e-3 if precision == 'bf16x3' else 4e-1
+    # (the first layer's weight gradient collects every downstream switch: 4e-3 ... 6e-3 between equivalent fp32-class kernels)
+    gtol = 8e-3 if precision == 'bf16x3' else 4e-1
     for name, p in model.named_parameters():
         g = refp[name].grad
         if g.norm() < 1e-6:

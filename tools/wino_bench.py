@@ -18,7 +18,7 @@ for cin, cout, f in [(128, 128, 16), (128, 256, 8), (64, 64, 32), (64, 128, 16),
     sc, sh = torch.rand(cin, device=dev) + .5, torch.randn(cin, device=dev) * .3
     seq = torch.full((b,), t, dtype=torch.int32, device=dev)
     res = []
-    for prec in ('f32', 'wino'):
+    for prec in ('f32', 'wino', 'bf16x3'):
         wp = pc.fwd(prec); wd = pc.dgrad(prec)
         ms = tm(lambda: ops.conv_fwd(x, pc, wp, scale=sc, shift=sh, seq_len=seq, want_stats=True, precision=prec))
         g = torch.randn(b, cout, f, t, device=dev)
@@ -26,7 +26,7 @@ for cin, cout, f in [(128, 128, 16), (128, 256, 8), (64, 64, 32), (64, 128, 16),
         res.append((ms, msd))
     fl = 2 * b * cout * cin * 9 * f * t / 1e9
     print(f'{cin}->{cout} F{f}: fwd direct {res[0][0]:.3f} ms ({fl/res[0][0]:.0f} TF)  wino {res[1][0]:.3f} ms ({fl/res[1][0]:.0f} TF eff) x{res[0][0]/res[1][0]:.2f} | '
-          f'dgrad direct {res[0][1]:.3f}  wino {res[1][1]:.3f} x{res[0][1]/res[1][1]:.2f}')
+          f'dgrad direct {res[0][1]:.3f}  wino {res[1][1]:.3f} x{res[0][1]/res[1][1]:.2f} | bf16x3 fwd {res[2][0]:.3f} dgrad {res[2][1]:.3f}')
 
 # rounding error of both kernels against an fp64 convolution (small batch)
 import torch.nn.functional as F
@@ -37,7 +37,7 @@ for cin, cout, f in [(128, 128, 16), (64, 64, 32)]:
     w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** .5
     ref = F.conv2d(F.pad(x.double(), (1, 1, 1, 1)), w.double())
     pc = ops.PackedConv(w.to(dev))
-    for prec in ('f32', 'wino'):
+    for prec in ('f32', 'wino', 'bf16x3'):
         y, _, _ = ops.conv_fwd(x.to(dev), pc, pc.fwd(prec), precision=prec)
         e = (y.cpu().double() - ref).abs()
         print(f'{cin}->{cout} {prec}: max abs err {e.max():.2e}  rms err {e.pow(2).mean().sqrt():.2e}  (output rms {ref.pow(2).mean().sqrt():.2f})')
