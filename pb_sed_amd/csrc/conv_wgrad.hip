@@ -609,7 +609,9 @@ __device__ __forceinline__ f32x4 wg_mfma(u32x4_t a, u32x4_t b, f32x4 c) {
 }
 constexpr int pad8mod64(int n) { return ((n + 55) / 64) * 64 + 8; }      // halfs: plane stride = 16 bytes mod 128
 
-template <int KH, int KW, int MH>
+// NS = 1: plain bf16 operands; NS = 3: exact three-way splits of dY and x (Bf3 in common.h), six part products per product:
+// fp32-class gradients - the Conv1d layers of the fp32 path.
+template <int KH, int KW, int MH, int NS = 1>
 struct WgradB16Cfg {
     // MH groups of 32 output channels per block (two waves each: the two 16-channel halves of the 32-channel cin tile).
     // 3x3: MH = 4 (128 cout x 32 cin, 512 threads): the kernel is bound by the bytes a block pulls per MFMA, and the
@@ -624,18 +626,19 @@ struct WgradB16Cfg {
     static constexpr int Y_PER_T = (YQ + NT - 1) / NT, A_PER_T = (AQ + NT - 1) / NT;
     static constexpr int OUT_ROW = CIN_T * KK + 1;
     static constexpr int OUT_ROWS = 64;                                    // the LDS transpose of the result runs 64 cout rows at a time
-    static constexpr int LDS_FLOATS = cmax((COUT_T * PLANE_Y + CIN_T * PLANE_A) / 2 + 2 * CIN_T, OUT_ROWS * OUT_ROW);
+    static constexpr int LDS_FLOATS = cmax(NS * (COUT_T * PLANE_Y + CIN_T * PLANE_A) / 2 + 2 * CIN_T, OUT_ROWS * OUT_ROW);
 };
 
-template <int KH, int KW, int MH>
+template <int KH, int KW, int MH, int NS = 1>
 __global__ __launch_bounds__(MH * 128) void conv_wgrad_bf16_kernel(ConvWgradArgs a) {
-    using C = WgradB16Cfg<KH, KW, MH>;
+    using C = WgradB16Cfg<KH, KW, MH, NS>;
+    constexpr int Y_PART = C::COUT_T * C::PLANE_Y, A_PART = C::CIN_T * C::PLANE_A;       // halfs per operand part
     constexpr int FT = C::FT, TT = C::TT, KK = C::KK, NT = C::NT;
     constexpr int PADH = (KH - 1) / 2, PADW = (KW - 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned short* dy_s = reinterpret_cast<unsigned short*>(smem);              // [COUT_T][PLANE_Y]
-    unsigned short* a_s = dy_s + C::COUT_T * C::PLANE_Y;                           // [CIN_T][PLANE_A]
-    float* sc_s = reinterpret_cast<float*>(a_s + C::CIN_T * C::PLANE_A);           // [CIN_T] scale, [CIN_T] shift
+    unsigned short* dy_s = reinterpret_cast<unsigned short*>(smem);              // [NS][COUT_T][PLANE_Y]
+    unsigned short* a_s = dy_s + NS * Y_PART;                                      // [NS][CIN_T][PLANE_A]
+    float* sc_s = reinterpret_cast<float*>(a_s + NS * A_PART);                     // [CIN_T] scale, [CIN_T] shift
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = wave & 1, mh = wave >> 1;                                        // cin sub-tile / cout half of this wave
@@ -726,9 +729,18 @@ __global__ __launch_bounds__(MH * 128) void conv_wgrad_bf16_kernel(ConvWgradArgs
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (int)((ryi[i] >> (8 * e)) & 0xffu) == par ? v[e] : 0.f;
                 }
-                uint2 o;
-                o.x = wg_pack(v[0], v[1]); o.y = wg_pack(v[2], v[3]);
-                *reinterpret_cast<uint2*>(dy_s + cl * C::PLANE_Y + rem * 4) = o;
+                if constexpr (NS == 3) {
+                    unsigned h0, m0, l0, h1, m1, l1;
+                    split3_pair(v[0], v[1], h0, m0, l0);
+                    split3_pair(v[2], v[3], h1, m1, l1);
+                    *reinterpret_cast<uint2*>(dy_s + cl * C::PLANE_Y + rem * 4) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(dy_s + Y_PART + cl * C::PLANE_Y + rem * 4) = make_uint2(m0, m1);
+                    *reinterpret_cast<uint2*>(dy_s + 2 * Y_PART + cl * C::PLANE_Y + rem * 4) = make_uint2(l0, l1);
+                } else {
+                    uint2 o;
+                    o.x = wg_pack(v[0], v[1]); o.y = wg_pack(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(dy_s + cl * C::PLANE_Y + rem * 4) = o;
+                }
             }
         }
 #pragma unroll
@@ -747,9 +759,18 @@ __global__ __launch_bounds__(MH * 128) void conv_wgrad_bf16_kernel(ConvWgradArgs
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = e < r_am[i] ? v[e] : 0.f;        // zero padding is post-activation
-                uint2 o;
-                o.x = wg_pack(v[0], v[1]); o.y = wg_pack(v[2], v[3]);
-                *reinterpret_cast<uint2*>(a_s + cl * C::PLANE_A + rem * 4) = o;
+                if constexpr (NS == 3) {
+                    unsigned h0, m0, l0, h1, m1, l1;
+                    split3_pair(v[0], v[1], h0, m0, l0);
+                    split3_pair(v[2], v[3], h1, m1, l1);
+                    *reinterpret_cast<uint2*>(a_s + cl * C::PLANE_A + rem * 4) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(a_s + A_PART + cl * C::PLANE_A + rem * 4) = make_uint2(m0, m1);
+                    *reinterpret_cast<uint2*>(a_s + 2 * A_PART + cl * C::PLANE_A + rem * 4) = make_uint2(l0, l1);
+                } else {
+                    uint2 o;
+                    o.x = wg_pack(v[0], v[1]); o.y = wg_pack(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(a_s + cl * C::PLANE_A + rem * 4) = o;
+                }
             }
         }
     };
@@ -766,34 +787,48 @@ __global__ __launch_bounds__(MH * 128) void conv_wgrad_bf16_kernel(ConvWgradArgs
         for (int fl = 0; fl < FT; ++fl) {
 #pragma unroll
             for (int ks = 0; ks < TT / 32; ++ks) {
-                u32x4_t af[2];
+                u32x4_t af[2][NS];
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
-                    af[m] = *reinterpret_cast<const u32x4_t*>(dy_s + ((mh * 2 + m) * 16 + lr) * C::PLANE_Y + fl * TT + ks * 32 + lq * 8);
+#pragma unroll
+                    for (int p = 0; p < NS; ++p)
+                        af[m][p] = *reinterpret_cast<const u32x4_t*>(dy_s + p * Y_PART + ((mh * 2 + m) * 16 + lr) * C::PLANE_Y + fl * TT + ks * 32 + lq * 8);
+                auto prod = [&](const u32x4_t (&A)[NS], const u32x4_t (&Bq)[NS], f32x4 c) __attribute__((always_inline)) {
+                    if constexpr (NS == 3) return mfma_x3(Bf3{A[0], A[1], A[2]}, Bf3{Bq[0], Bq[1], Bq[2]}, c);
+                    else return wg_mfma(A[0], Bq[0], c);
+                };
 #pragma unroll
                 for (int kh = 0; kh < KH; ++kh) {
-                    const unsigned short* row = a_s + (g * 16 + lr) * C::PLANE_A + (fl + kh) * C::ROW + C::HALO + ks * 32 + lq * 8;
-                    const u32x4_t c = *reinterpret_cast<const u32x4_t*>(row);
+                    u32x4_t c[NS], left[NS], right[NS];
+#pragma unroll
+                    for (int p = 0; p < NS; ++p) {
+                        const unsigned short* row = a_s + p * A_PART + (g * 16 + lr) * C::PLANE_A + (fl + kh) * C::ROW + C::HALO + ks * 32 + lq * 8;
+                        c[p] = *reinterpret_cast<const u32x4_t*>(row);
+                        if (KW > 1) {
+                            const unsigned xm1 = row[-1], x8 = row[8];
+                            const unsigned s1 = __builtin_amdgcn_alignbit(c[p].y, c[p].x, 16), s2 = __builtin_amdgcn_alignbit(c[p].z, c[p].y, 16),
+                                           s3 = __builtin_amdgcn_alignbit(c[p].w, c[p].z, 16);
+                            left[p] = u32x4_t{(c[p].x << 16) | xm1, s1, s2, s3};                    // x[t-1 .. t+6]
+                            right[p] = u32x4_t{s1, s2, s3, (x8 << 16) | (c[p].w >> 16)};           // x[t+1 .. t+8]
+                        }
+                    }
                     if (KW == 1) {
 #pragma unroll
-                        for (int m = 0; m < 2; ++m) acc[m][kh] = wg_mfma(af[m], c, acc[m][kh]);
+                        for (int m = 0; m < 2; ++m) acc[m][kh] = prod(af[m], c, acc[m][kh]);
                     } else {
-                        const unsigned xm1 = row[-1], x8 = row[8];
-                        const unsigned s1 = __builtin_amdgcn_alignbit(c.y, c.x, 16), s2 = __builtin_amdgcn_alignbit(c.z, c.y, 16),
-                                       s3 = __builtin_amdgcn_alignbit(c.w, c.z, 16);
-                        const u32x4_t left = u32x4_t{(c.x << 16) | xm1, s1, s2, s3};                    // x[t-1 .. t+6]
-                        const u32x4_t right = u32x4_t{s1, s2, s3, (x8 << 16) | (c.w >> 16)};           // x[t+1 .. t+8]
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
-                            acc[m][kh * KW + 0] = wg_mfma(af[m], left, acc[m][kh * KW + 0]);
-                            acc[m][kh * KW + 1] = wg_mfma(af[m], c, acc[m][kh * KW + 1]);
-                            acc[m][kh * KW + 2] = wg_mfma(af[m], right, acc[m][kh * KW + 2]);
+                            acc[m][kh * KW + 0] = prod(af[m], left, acc[m][kh * KW + 0]);
+                            acc[m][kh * KW + 1] = prod(af[m], c, acc[m][kh * KW + 1]);
+                            acc[m][kh * KW + 2] = prod(af[m], right, acc[m][kh * KW + 2]);
                         }
                     }
                 }
                 if (do_bias) {
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) accb[m] = wg_mfma(af[m], ones, accb[m]);
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int p = 0; p < NS; ++p) accb[m] = wg_mfma(af[m][NS - 1 - p], ones, accb[m]);
                 }
             }
         }
@@ -842,6 +877,13 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     if ((size_t)a.Cin * a.F * a.T >= (1ull << 28) || (size_t)a.Cout * a.F * a.T >= (1ull << 28)) {
         set_error("conv_wgrad: one clip of x / dy must stay below 1 GiB (Cin=%d Cout=%d F=%d T=%d)", a.Cin, a.Cout, a.F, a.T);
         return PBSED_E_ARG;
+    }
+    // Conv1d layers of the fp32 path (F = 1 rows): the same kernel with exact three-way operand splits - fp32-class gradients
+    // (256->256 k = 3: 100 us on the fp32-MFMA kernel); very wide inputs stay on the fp32 kernel's 128-wide cin tiles
+    static const bool x3_1d = getenv("PBSED_CONV1D_X3") ? atoi(getenv("PBSED_CONV1D_X3")) != 0 : true;
+    if (!a.bf16 && x3_1d && KH == 1 && a.F == 1 && !a.unpool_idx && a.Cin >= 32 && a.Cout >= 32 && a.Cin < 1024) {
+        if (KW == 3) return launch_wgrad_cfg<WgradB16Cfg<1, 3, 2, 3>>(conv_wgrad_bf16_kernel<1, 3, 2, 3>, a, s);
+        if (KW == 1) return launch_wgrad_cfg<WgradB16Cfg<1, 1, 2, 3>>(conv_wgrad_bf16_kernel<1, 1, 2, 3>, a, s);
     }
     if (a.bf16 && a.Cin >= 32 && a.Cout >= 32) {       // bf16-MFMA operands (config 3); few-channel layers stay on the fp32 kernels
         if (KH == 3 && KW == 3) {
