@@ -37,7 +37,20 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}      # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA, f32 / bf16 operands
 PEAK_HBM_GBS = 8000.0
 XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7
-FWD_GFLOP = {'c2': 11.82, 'c3': 12.34}            # forward per clip (train step = 3x)
+FWD_GFLOP = {'c2': 11.82, 'c3': 12.34}
+# what 'dtype' means in detail (the value itself stays the plain type name)
+ARITHMETIC_NOTE = {
+    'f32': 'fp32 storage, accumulation, state and results throughout.  3x3 conv layers: fp32 MFMA (Winograd F(4,3) along t where '
+           'MFMA-bound).  GRU scans, GRU weight gradients, the projections around the scans and the Conv1d layers form their '
+           'products on the bf16 MFMA from EXACT three-way bf16 splits of both fp32 operands (x = hi + mid + lo, 8 + 8 + 8 '
+           'significant bits; the six part products above 2^-24 accumulated in fp32): fp32-class results - rms error vs fp64 '
+           '5.0e-7 against 5.9e-7 of the fp32-MFMA kernel on the same layer - held to the same 1e-4 logit / gradient parity '
+           'tests; PBSED_GRU_X3=0 PBSED_GRU_WGRAD_X3=0 PBSED_CONV1D_X3=0 select the fp32-MFMA forms of the scans, GRU weight '
+           'gradients and Conv1d layers',
+    'bf16': 'bf16 MFMA operands (rounded to nearest even while staged) in every conv / projection / scan / weight-gradient '
+            'product with >= 32 channels; fp32 accumulation, BN, GRU state, losses, master weights and optimiser',
+    'bf16x3': 'every conv product from exact three-way bf16 operand splits on the bf16 MFMA (fp32-class); the rest as f32',
+}            # forward per clip (train step = 3x)
 
 
 # ------------------------------------------------------------------------------------------------ synthetic data
@@ -375,6 +388,7 @@ def bench_train(args, kind, world, rank, device):
         'dtype': {'f32': 'f32', 'bf16': 'bf16 (MFMA operands of conv / projection / head launches; fp32 accumulate, BN, GRU state, '
                                         'master weights)',
                   'bf16x3': 'bf16x3 (fp32 operands split into 3 bf16 terms, fp32 accumulate)'}[precision],
+        'arithmetic': ARITHMETIC_NOTE[precision],
         'data': 'synthetic (randn waveforms, random-init weights, 2 distinct resident batches in rotation)',
         'config': {'workload': what + '; full train step incl. fused log-mel front-end, loss, backward, grad-norm clip, Adam'
                                       + (', RCCL grad all-reduce' if world > 1 else ''),
@@ -494,6 +508,7 @@ def bench_inference(args, world, rank, device):
         'value': round(total / (dt / args.steps), 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': precision,
+        'arithmetic': ARITHMETIC_NOTE[precision],
         'data': 'synthetic (randn waveforms, random-init weights, 2 distinct resident batches in rotation)',
         'config': {'workload': 'strong_label_crnn_inference: 2 FBCRNN taggers -> tags -> 3 tag-conditioned BiCRNN detectors, '
                                'ensemble mean, 3 per-class median-filter variants, tag masking, event lists on the host '
