@@ -294,6 +294,10 @@ int pbsed_tm_conv_bwd_weight(const float* x, const float* g, int n_taps, const f
 int pbsed_bn_bwd_tm(float* dz, const float* x, const double* sums, double count, const float* mean, const float* invstd,
                     const float* scale, float* dgamma, float* dbeta, const float* rowmask, float* scratch, int R, int C,
                     void* stream);
+/* masked per-channel sums (sum x, sum x^2 over frames < seq_len) of a network input x [B, C, S, T] into stats
+ * [PBSED_STAT_SLOTS][C][2] (zeroed doubles): batch statistics of a FIRST layer that has its own pre-activation norm
+ * (padertorch CNN input_layer=False; every other norm gets its statistics from the producing convolution's epilogue). */
+int pbsed_channel_stats(const float* x, const int* seq_len, double* stats, int B, int C, int S, int T, void* stream);
 int pbsed_tm_rowmask(const int* seq_len, float* mask, int T, int B, void* stream);
 
 /* ---- heads' squash + losses (pb_sed/models/weak_label/crnn.py:58-59,107-206;

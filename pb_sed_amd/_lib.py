@@ -63,6 +63,7 @@ SIGNATURES = {
     'pbsed_tm_conv_bwd_weight': [_v, _v, I, _v, _v, I, _v, _v, _v, I, I, I, I, I, _v],
     'pbsed_bn_bwd_tm': [_v, _v, _v, F64, _v, _v, _v, _v, _v, _v, _v, I, I, _v],
     'pbsed_tm_rowmask': [_v, _v, I, I, _v],
+    'pbsed_channel_stats': [_v, _v, _v, I, I, I, I, _v],
     'pbsed_tm_gemm': [I, _pp, _pp, _i, _v, _v, I, I, I, _v],
     'pbsed_gru_wgrad_multi': [I, _pp, _pp, _i, _pp, _pp, I, I, I, _i, I, _v],
     'pbsed_gru_scan_fwd': [I, _pp, _pp, _pp, _pp, _pp, _i, _v, I, I, I, _v],

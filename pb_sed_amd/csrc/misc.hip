@@ -249,6 +249,29 @@ __global__ __launch_bounds__(256) void bn_bwd_tm_apply_kernel(float* __restrict_
     }
 }
 
+// Masked per-channel sums (sum x, sum x^2 over t < seq_len[b]) of a network INPUT [B, C, S, T] - the batch statistics of a
+// first layer that carries its own pre-activation norm (padertorch CNN with input_layer=False; SURVEY.md A.4 variant (i)).
+// Everywhere else the statistics come out of the producing convolution's epilogue.
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, const int* __restrict__ seq_len,
+                                                            double* __restrict__ stats, int C, int S, int T) {
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int sl = seq_len ? min(seq_len[b], T) : T;
+    const float* p = x + ((size_t)b * C + c) * S * T;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = tid; i < S * T; i += 256) {
+        const float v = (i % T) < sl ? p[i] : 0.f;
+        s1 += v; s2 = fmaf(v, v, s2);
+    }
+    __shared__ float red[2][4];
+    s1 = wave_sum64(s1); s2 = wave_sum64(s2);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid < 2) {
+        const float v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+        atomicAdd(&stats[((size_t)(b & (PBSED_STAT_SLOTS - 1)) * C + c) * 2 + tid], (double)v);
+    }
+}
+
 // rowmask[t * B + b] = t < seq_len[b] ? 1 : 0
 __global__ void tm_rowmask_kernel(const int* __restrict__ seq_len, float* __restrict__ mask, int T, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -754,6 +777,12 @@ int pbsed_bn_bwd_tm(float* dz, const float* x, const double* sums, double count,
     hipLaunchKernelGGL(bn_bwd_tm_apply_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, dz, x, scratch, mean,
                        invstd, scale, rowmask, (size_t)R, C);
     return check_launch("bn_bwd_tm");
+}
+
+int pbsed_channel_stats(const float* x, const int* seq_len, double* stats, int B, int C, int S, int T, void* stream) {
+    if (B < 1 || B > 65535 || C < 1) { set_error("channel_stats: bad B=%d C=%d", B, C); return PBSED_E_ARG; }
+    hipLaunchKernelGGL(channel_stats_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, seq_len, stats, C, S, T);
+    return check_launch("channel_stats");
 }
 
 int pbsed_tm_rowmask(const int* seq_len, float* mask, int T, int B, void* stream) {

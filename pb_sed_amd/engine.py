@@ -105,8 +105,6 @@ def describe_stack(cnns):
     if convs[-1].post:
         raise NotImplementedError('a trailing post-activation norm (output_layer=False without '
                                   'pre_activation) has no consumer conv to fuse into')
-    if layers[0].in_norm is not None:
-        raise NotImplementedError('first layer with a pre-activation norm needs input statistics')
     return layers
 
 
@@ -165,8 +163,20 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32', x_tbc
     st_in, st_frozen = None, False
     j_tm = _tm_start(layers, precision)
     x_t = rowmask = None
-    if x is None and j_tm > 0:                        # only the time-major form of the input was handed over
+    if x is None and (j_tm > 0 or layers[0].in_norm is not None):       # only the time-major form of the input was handed over
         x = ops.tbc_to_bct(x_tbc)
+    if layers[0].in_norm is not None:
+        # a first layer with its own pre-activation norm (padertorch input_layer=False, SURVEY.md A.4 variant (i)): the batch
+        # statistics of the stack input come from a reduction of their own, every other norm gets them from a conv epilogue
+        n0 = layers[0].in_norm
+        if j_tm == 0:
+            raise NotImplementedError('a first layer with its own norm runs on the CNN layout (PBSED_TM_STACK=0)')
+        st_frozen = bool(training and n0.freeze_stats)
+        if training and not n0.freeze_stats:
+            rows = x.shape[2] if x.dim() == 4 else 1
+            st_in = ops.bn_finalize(ops.channel_stats(x, seq_dev), _count(seq_host, x.shape[-1], rows), n0)
+        else:
+            st_in = ops.bn_eval_params(n0)
     for j, L in enumerate(layers):
         c = L.conv
         nxt = layers[j + 1] if j + 1 < len(layers) else None
@@ -333,7 +343,9 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
                                 scale=None if st_in is None else st_in.scale,
                                 shift=None if st_in is None else st_in.shift,
                                 relu=True, seq_len=seq_dev, unpool_idx=idx, precision='bf16' if pr == 'bf16' else 'f32')
-        if j == 0 and not need_input_grad:
+        norm0 = L.in_norm if (j == 0 and st_in is not None) else None
+        norm0_grads = norm0 is not None and any(p.requires_grad for p in norm0.parameters())
+        if j == 0 and not need_input_grad and not norm0_grads:
             if on_layer_done is not None:
                 on_layer_done(0)
             return None

@@ -390,15 +390,18 @@ SHALLOW = dict(
 
 
 def build_cnn(in_channels, out_channels_2d, pool_sizes_2d, kernel_size_2d, out_channels_1d, kernel_size_1d,
-              input_height, conditional_dims=0, eps=1e-3, residual_connections_2d=None, residual_connections_1d=None):
+              input_height, conditional_dims=0, eps=1e-3, residual_connections_2d=None, residual_connections_1d=None,
+              input_layer_2d=True, input_layer_1d=False):
+    """``input_layer_2d`` / ``input_layer_1d``: padertorch's ``input_layer`` of the two stacks (True = the stack's first layer has no
+    pre-activation norm + ReLU) - the defaults are SURVEY.md A.4's reading, the other variants are flags."""
     cnn_2d = CNN2d(in_channels + conditional_dims, out_channels_2d, kernel_size_2d, pool_sizes_2d, eps=eps,
-                   pre_activation=True, output_layer=False, input_layer=True, residual_connections=residual_connections_2d)
+                   pre_activation=True, output_layer=False, input_layer=input_layer_2d, residual_connections=residual_connections_2d)
     f = input_height
     ps = pool_sizes_2d if isinstance(pool_sizes_2d, list) else len(out_channels_2d) * [pool_sizes_2d]
     for p in ps:
         f //= (p[0] if isinstance(p, (tuple, list)) else p)
     cnn_1d = CNN1d(out_channels_2d[-1] * f, out_channels_1d, kernel_size_1d, 1, eps=eps,
-                   pre_activation=True, output_layer=False, input_layer=False, residual_connections=residual_connections_1d)
+                   pre_activation=True, output_layer=False, input_layer=input_layer_1d, residual_connections=residual_connections_1d)
     return CNN(cnn_2d, cnn_1d, input_height, conditional_dims=conditional_dims)
 
 

@@ -330,6 +330,14 @@ def bn_finalize(stats, count, norm, training_update=True):
     return st
 
 
+def channel_stats(x, seq_len):
+    """Masked per-channel (sum, sum of squares) of a stack input [B,C,(S,)T] -> stats for bn_finalize."""
+    b, c, s, t = _dims4(x)
+    stats = _zero_stats(c, x.device)
+    call('pbsed_channel_stats', ptr(x), ptr(seq_len), ptr(stats), b, c, s, t, stream())
+    return stats
+
+
 def bn_eval_params(norm):
     """Per-channel (mean, invstd, scale, shift) of a norm layer applied with its running statistics.  Cached on the module
     until a parameter / buffer changes (torch versions for in-place updates, PACK_EPOCH / BN_EPOCH for the library's own
