@@ -317,14 +317,42 @@ def print_table(agg, steps):
 
 
 # ------------------------------------------------------------------------------------------------ train configs
-def bench_train(args, kind, world, rank, device):
+def _timed_steps(trainer, batches, steps, world, device):
+    """Exactly `steps` train steps between barrier + synchronize pairs; max over ranks.  Returns (seconds, enqueue s, review)."""
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    enq, review = 0., None
+    t0 = time.perf_counter()
+    for i in range(steps):
+        review = trainer.step(batches[i % 2])
+        enq += trainer.last_enqueue_s
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    return dt, enq, review
+
+
+def bench_train(args, kind, world, rank, device, sustained_steps=0):
     import torch.distributed as dist
     from pb_sed_amd import _lib, ops
     from pb_sed_amd.models import strong_label, weak_label
     from pb_sed_amd.trainer import Trainer
     torch.manual_seed(0)
-    precision = args.conv_precision or ('f32' if kind == 'c2' else 'bf16')
-    model = (weak_label.CRNN.build() if kind == 'c2' else strong_label.CRNN.build(tag_conditioning=True)).to(device)
+    precision = args.conv_precision or ('bf16' if kind == 'c3' else 'f32')
+    if kind == 'deep':
+        from pb_sed_amd.modules import DEEP
+        model = weak_label.CRNN.build(num_events=10, hidden_size=512, net=DEEP).to(device)
+    else:
+        model = (weak_label.CRNN.build() if kind == 'c2' else strong_label.CRNN.build(tag_conditioning=True)).to(device)
     model.conv_precision = precision
     n_params = sum(p.numel() for p in model.parameters())
     trainer = Trainer(model, lr=5e-4, gradient_clipping=1e10)
@@ -337,27 +365,23 @@ def bench_train(args, kind, world, rank, device):
         torch.cuda.synchronize()
         if rank == 0:
             print(f'[bench] warm-up step {i}: {(time.perf_counter() - t_w) * 1e3:.1f} ms', file=sys.stderr, flush=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    calls0, enq, trainer.sync_events = _lib.n_calls, 0., []
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        review = trainer.step(batches[i % 2])
-        enq += trainer.last_enqueue_s
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    calls0, trainer.sync_events = _lib.n_calls, []
+    dt, enq, review = _timed_steps(trainer, batches, args.steps, world, device)
     calls = (_lib.n_calls - calls0) / max(args.steps, 1)
     sync_events, trainer.sync_events = trainer.sync_events, None
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
     loss = float(review['loss'].item())
+    sustained = None
+    if sustained_steps:
+        # the headline's K steps are a fraction of a second; a second, long region shows what the clocks settle at
+        chunks, n_chunk = [], max(sustained_steps // 10, 1)
+        for _ in range(10):
+            dt_c, _, _ = _timed_steps(trainer, batches, n_chunk, world, device)
+            chunks.append(args.batch * world * n_chunk / dt_c)
+        sustained = {'clips_per_s': round(10 * n_chunk * args.batch * world / sum(args.batch * world * n_chunk / c for c in chunks), 2),
+                     'steps': 10 * n_chunk, 'clips_per_s_median_of_10_chunks': round(float(np.median(chunks)), 2),
+                     'clips_per_s_min_max_of_chunks': [round(min(chunks), 2), round(max(chunks), 2)],
+                     'note': f'10 back-to-back timed regions of {n_chunk} steps each after the headline region, same bracket '
+                             '(barrier + synchronize, max over ranks); clips_per_s = all clips / total time'}
     exposed_ms = (sum(a.elapsed_time(b) for a, b in sync_events) / max(args.steps, 1)) if sync_events else None
     ev_steps = min(max(args.steps, 1), 10)
     events = event_pass(lambda i: trainer.step(batches[i % 2]), ev_steps)
@@ -377,11 +401,14 @@ def bench_train(args, kind, world, rank, device):
     ms_step = dt / args.steps * 1e3
     clips = args.batch * world
     what = {'c2': 'FBCRNN weak_label_crnn.training batch 32/GPU fp32, 10 s 16 kHz clips (BASELINE.json configs[1])',
-            'c3': 'tag-conditioned strong_label BiCRNN training batch 32/GPU bf16, 10 s 16 kHz clips (BASELINE.json configs[2])'}[kind]
-    gru_shape = (2, 2, 500, args.batch, 256) if kind == 'c2' else (2, 1, 500, args.batch, 256)
+            'c3': 'tag-conditioned strong_label BiCRNN training batch 32/GPU bf16, 10 s 16 kHz clips (BASELINE.json configs[2])',
+            'deep': "FBCRNN weak_label_crnn.training with net_config 'deep' (width 2: 18 conv2d layers up to 512 channels with "
+                    'residual connections, 8 conv1d layers, GRU 2 x 512; training.py:170-183), batch 32/GPU fp32, 10 s 16 kHz clips'}[kind]
+    gru_shape = {'c2': (2, 2, 500, args.batch, 256), 'c3': (2, 1, 500, args.batch, 256), 'deep': (2, 2, 500, args.batch, 512)}[kind]
     out = {
         'metric': {'c2': '10s@16kHz clips/sec (train step) FBCRNN batch32',
-                   'c3': '10s@16kHz clips/sec (train step) tag-conditioned BiCRNN batch32 bf16'}[kind],
+                   'c3': '10s@16kHz clips/sec (train step) tag-conditioned BiCRNN batch32 bf16',
+                   'deep': "10s@16kHz clips/sec (train step) FBCRNN net_config 'deep' width 2 batch32"}[kind],
         'value': round(clips / (dt / args.steps), 2), 'unit': 'clips/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -397,9 +424,17 @@ def bench_train(args, kind, world, rank, device):
     rf = roofline_objects(agg, by_family, ev_steps, args.batch, precision, gru_shape, kind)
     exe_step = rf.pop('_exe_step_flop')
     out.update(rf)
-    train_tflop = 3 * FWD_GFLOP[kind] * args.batch / 1e3
-    fwd_tflop = FWD_GFLOP[kind] * args.batch / 1e3
-    peak = PEAK_TFLOPS['f32']            # whole-step figures are priced against the fp32 peak (GRU, wgrad and BN stay fp32)
+    is_fwd = lambda name, tag: (name.startswith(('pbsed_conv_fwd', 'pbsed_gru_stack_fwd', 'pbsed_logmel'))
+                                or (name == 'pbsed_tm_gemm' and tag.endswith(' fwd')))      # the GRU input projections
+    fwd_ms = sum(ms for (name, tag), (ms, c, fl, by) in agg.items() if is_fwd(name, tag)) / ev_steps
+    fwd_exe = sum(_executed(fl, tag) * c for (name, tag), (ms, c, fl, by) in agg.items()
+                  if is_fwd(name, tag) and not name.startswith('pbsed_logmel')) / ev_steps
+    fwd_alg = sum(fl * c for (name, tag), (ms, c, fl, by) in agg.items()
+                  if is_fwd(name, tag) and not name.startswith('pbsed_logmel')) / ev_steps
+    # BASELINE.md section 2 for the two named configs; any other net: 2*MACs of the bracketed forward launches
+    fwd_tflop = FWD_GFLOP[kind] * args.batch / 1e3 if kind in FWD_GFLOP else fwd_alg / 1e12
+    train_tflop = 3 * fwd_tflop
+    peak = PEAK_TFLOPS['f32']
     out['step_mfma'] = {'algorithmic_tflop_per_step': round(train_tflop, 4),
                         'algorithmic_tflops_per_gpu': round(train_tflop / (ms_step * 1e-3), 2),
                         'executed_tflop_per_step_in_bracketed_launches': round(exe_step / 1e12, 4),
@@ -407,18 +442,24 @@ def bench_train(args, kind, world, rank, device):
                         'frac_executed_of_fp32_mfma_peak': round(exe_step / 1e12 / (ms_step * 1e-3) / peak, 4),
                         'frac_algorithmic_of_fp32_mfma_peak': round(train_tflop / (ms_step * 1e-3) / peak, 4),
                         'note': 'executed = fp32-equivalent products issued by the bracketed launches: a Winograd launch counts half of '
-                                'the direct products; bf16x3 launches (GRU scans, GRU weight gradients, time-major projections) count each '
-                                'fp32-equivalent product once although the bf16 pipe runs six part products for it'}
-    is_fwd = lambda name, tag: (name.startswith(('pbsed_conv_fwd', 'pbsed_gru_stack_fwd', 'pbsed_logmel'))
-                                or (name == 'pbsed_tm_gemm' and tag.endswith(' fwd')))      # the GRU input projections
-    fwd_ms = sum(ms for (name, tag), (ms, c, fl, by) in agg.items() if is_fwd(name, tag)) / ev_steps
-    fwd_exe = sum(_executed(fl, tag) * c for (name, tag), (ms, c, fl, by) in agg.items()
-                  if is_fwd(name, tag) and not name.startswith('pbsed_logmel')) / ev_steps
+                                'the direct products; bf16x3 launches count each fp32-equivalent product once although the bf16 pipe '
+                                'runs six part products for it'}
     out['forward_conv_gru'] = {'ms_per_step': round(fwd_ms, 3), 'algorithmic_tflop': round(fwd_tflop, 4),
                                'algorithmic_tflops': round(fwd_tflop / (fwd_ms * 1e-3), 2),
                                'executed_tflops': round(fwd_exe / 1e12 / (fwd_ms * 1e-3), 2),
                                'frac_executed_of_fp32_mfma_peak': round(fwd_exe / 1e12 / (fwd_ms * 1e-3) / peak, 4),
                                'frac_algorithmic_of_fp32_mfma_peak': round(fwd_tflop / (fwd_ms * 1e-3) / peak, 4)}
+    if precision == 'bf16':
+        # a bf16 line is priced against the bf16 peak first; the fp32-peak fractions above are kept for comparison with c2 only
+        pb = PEAK_TFLOPS['bf16']
+        out['step_mfma']['frac_algorithmic_of_bf16_mfma_peak'] = round(train_tflop / (ms_step * 1e-3) / pb, 4)
+        out['step_mfma']['frac_executed_of_bf16_mfma_peak'] = round(exe_step / 1e12 / (ms_step * 1e-3) / pb, 4)
+        out['forward_conv_gru']['frac_algorithmic_of_bf16_mfma_peak'] = round(fwd_tflop / (fwd_ms * 1e-3) / pb, 4)
+        out['forward_conv_gru']['frac_executed_of_bf16_mfma_peak'] = round(fwd_exe / 1e12 / (fwd_ms * 1e-3) / pb, 4)
+        out['step_mfma']['honest_reading'] = ('dtype is bf16: the step runs at the frac_*_of_bf16_mfma_peak fractions of what the chip '
+                                              'can do with bf16 operands; it is latency / HBM / fp32-kernel bound, see ms_per_step_by_entry_point')
+    if sustained is not None:
+        out['sustained'] = sustained
     out['ms_per_step_by_entry_point'] = {k: round(v, 3) for k, v in sorted(by_family.items(), key=lambda kv: -kv[1])}
     out['host'] = {'enqueue_ms_per_step': round(enq / args.steps * 1e3, 3), 'c_abi_calls_per_step': round(calls, 1),
                    'note': 'host time of a step up to (not including) the wait for its deferred review summary'}
@@ -530,32 +571,104 @@ def bench_inference(args, world, rank, device):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command as N ranks (one per GPU) under
+    torch.distributed.run on 127.0.0.1 and hand its exit code back.  stdout of the ranks passes through, so rank 0's JSON
+    line is this process' JSON line."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f'[bench] --gpus {n} without WORLD_SIZE: launching {n} ranks: {" ".join(cmd)}', file=sys.stderr, flush=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rendezvous_check(world, rank, device, backend):
+    """Every rank contributes rank + 1 to a sum-all-reduce: the collective backend really spans `world` ranks."""
+    import torch.distributed as dist
+    t = torch.tensor([float(rank + 1)], device=device if backend == 'nccl' else 'cpu')
+    dist.all_reduce(t)
+    got, want = t.item(), world * (world + 1) / 2
+    assert dist.get_world_size() == world and got == want, (dist.get_world_size(), world, got, want)
+    return {'backend': 'nccl (RCCL)' if backend == 'nccl' else backend, 'ranks_seen': dist.get_world_size(),
+            'allreduce_check': got}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=32, help='clips per GPU (c5: total clips, default 64)')
-    ap.add_argument('--config', default='c2', choices=['c2', 'c3', 'c5'])
+    ap.add_argument('--config', default='c2', choices=['c2', 'c3', 'c5', 'deep'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--headline-only', action='store_true',
+                    help='default run: skip the sustained figure and the other_configs (c3, c5, deep) legs')
+    ap.add_argument('--sustained-steps', type=int, default=500)
     ap.add_argument('--conv-precision', default=None, choices=['f32', 'bf16', 'bf16x3'],
-                    help="operand format of the conv MFMAs; default: f32 (c2, c5), bf16 (c3)")
+                    help="operand format of the conv MFMAs; default: f32 (c2, c5, deep), bf16 (c3)")
+    ap.add_argument('--rendezvous-only', default=None, choices=['gloo', 'nccl'],
+                    help='launch / rendezvous / all-reduce check only, no GPU work (tests/test_dp_gloo.py drives it with gloo on CPU)')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
 
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if args.rendezvous_only:
+        dist.init_process_group(args.rendezvous_only)
+        info = rendezvous_check(world, rank, f'cuda:{local_rank}', args.rendezvous_only)
+        if rank == 0:
+            print(json.dumps({'rendezvous': info, 'n_gpus': world}))
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     device = f'cuda:{local_rank}'
+    rendezvous = None
     if world > 1:
         dist.init_process_group('nccl', device_id=torch.device(device))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    out = bench_inference(args, world, rank, device) if args.config == 'c5' else bench_train(args, args.config, world, rank, device)
+        rendezvous = rendezvous_check(world, rank, device, 'nccl')
+        if rank == 0:
+            print(f'[bench] RCCL spans {world} ranks: {rendezvous}', file=sys.stderr, flush=True)
+    full = args.config == 'c2' and not args.headline_only and args.conv_precision is None and args.batch == 32
+    out = run_config(args, args.config, world, rank, device, sustained_steps=args.sustained_steps if full else 0)
+    if full:
+        # the driver runs the default command only: carry the sustained figure and the other BASELINE configs on the same line
+        others = {}
+        for kind in ('c3', 'c5', 'deep'):
+            sub = argparse.Namespace(**vars(args))
+            sub.steps, sub.warmup, sub.no_cpu_baseline = (10, 3, True) if kind == 'c5' else (20, 5, True)
+            try:
+                res = run_config(sub, kind, world, rank, device)
+            except Exception as e:                       # a leg that fails must not take the headline with it
+                res = {'error': f'{type(e).__name__}: {e}'}
+            if rank == 0:
+                others[kind] = res
+        if rank == 0:
+            out['other_configs'] = others
     if rank == 0:
+        if rendezvous is not None:
+            out['rendezvous'] = rendezvous
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_config(args, kind, world, rank, device, sustained_steps=0):
+    if kind == 'c5':
+        return bench_inference(args, world, rank, device)
+    return bench_train(args, kind, world, rank, device, sustained_steps=sustained_steps)
 
 
 if __name__ == '__main__':

@@ -125,20 +125,24 @@ int check_launch(const char* what);
         }                                                                       \
     } while (0)
 
-// One-time kernel setup (opt-in to > 48 KB of dynamic LDS) is per DEVICE, not per process: a bit per device ordinal
-// in a per-call-site mask, so a process driving several GPUs through the C-ABI sets the attribute on each of them.
+// Kernel setup (opt-in to > 48 KB of dynamic LDS) is per DEVICE and per SIZE: a call site remembers, per device ordinal,
+// the largest size it has set, and re-issues the attribute when a later launch needs more (the front-end kernels' LDS
+// grows with the number of filters / bins), so a process driving several GPUs or several configurations stays correct.
 #define PBSED_DYN_LDS_ONCE(kern, bytes)                                                                         \
     do {                                                                                                        \
-        static unsigned long long pbsed_mask_ = 0ull;                                                           \
+        static unsigned pbsed_set_[64] = {0};                                                                   \
         int pbsed_dev_ = 0;                                                                                     \
         PBSED_HIP_TRY(hipGetDevice(&pbsed_dev_), "hipGetDevice");                                                \
-        const unsigned long long pbsed_bit_ = 1ull << (pbsed_dev_ & 63);                                        \
-        if (!(__atomic_load_n(&pbsed_mask_, __ATOMIC_ACQUIRE) & pbsed_bit_)) {                                  \
-            if ((size_t)(bytes) > 48 * 1024)                                                                    \
-                PBSED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                          \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)),    \
-                              "hipFuncSetAttribute");                                                           \
-            __atomic_fetch_or(&pbsed_mask_, pbsed_bit_, __ATOMIC_RELEASE);                                      \
+        unsigned* pbsed_slot_ = &pbsed_set_[pbsed_dev_ & 63];                                                   \
+        const unsigned pbsed_need_ = (unsigned)(bytes);                                                         \
+        if (pbsed_need_ > 48u * 1024u && __atomic_load_n(pbsed_slot_, __ATOMIC_ACQUIRE) < pbsed_need_) {        \
+            PBSED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)pbsed_need_),    \
+                          "hipFuncSetAttribute");                                                               \
+            unsigned pbsed_old_ = __atomic_load_n(pbsed_slot_, __ATOMIC_ACQUIRE);                               \
+            while (pbsed_old_ < pbsed_need_ &&                                                                  \
+                   !__atomic_compare_exchange_n(pbsed_slot_, &pbsed_old_, pbsed_need_, false, __ATOMIC_RELEASE, \
+                                                __ATOMIC_ACQUIRE)) {}                                           \
         }                                                                                                       \
     } while (0)
 

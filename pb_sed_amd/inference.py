@@ -120,6 +120,8 @@ def inference(model, method, dataset, device, max_segment_length=None, segment_o
             if world_size > 1:
                 from .trainer import shard_batch
                 batch = shard_batch(batch, rank, world_size)
+                if not len(batch['seq_len']):            # a ragged last batch with fewer clips than ranks: nothing for this rank
+                    continue
             segments = [batch] if max_segment_length is None else segment_batch(batch, max_segment_length, segment_overlap)
             cache = {}
             for segment in segments:

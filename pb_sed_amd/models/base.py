@@ -134,7 +134,7 @@ class SoundEventModel(nn.Module, Configurable, abc.ABC):
         from .. import engine
         from ..modules import num_frames
         fe = self.feature_extractor
-        if 'audio_data' in inputs or x_in.dim() == 2:
+        if 'audio_data' in inputs or x_in.dim() != 5:      # a waveform: [B,N], or [B,1,N] from data.collate; stft is [B,1,T,bins,2]
             audio = x_in.reshape(x_in.shape[0], -1).to(torch.float32)
             n_frames = int(inputs.get('num_frames', 0)) or num_frames(audio.shape[1])
             frame_pos = inputs.get('frame_pos')                  # time-warped framing drawn by data.TimeWarp

@@ -201,6 +201,18 @@ class Normalization(nn.Module):
         self.register_buffer('running_power', torch.ones(num_channels))
         self.freeze_stats = False
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """Accept a padertorch-written checkpoint: its Normalization keeps gamma / beta / running statistics in the
+        broadcast shape of the normalised tensor ([1,C,1,1] / [1,C,1]) and a ``num_tracked_values`` counter this build has
+        no use for (momentum statistics).  Flatten the former, drop the latter (pb_sed/experiments/weak_label_crnn/
+        inference.py:407-413 loads such checkpoints through ``from_storage_dir``)."""
+        state_dict.pop(prefix + 'num_tracked_values', None)
+        for name in ('gamma', 'beta', 'running_mean', 'running_power'):
+            v = state_dict.get(prefix + name)
+            if v is not None and v.dim() != 1 and v.numel() == self.num_channels:
+                state_dict[prefix + name] = v.reshape(-1)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
 
 class ConvLayer(nn.Module):
     def __init__(self, ndim, cin, cout, k, pool=1, pre=False, post=False, eps=1e-3):

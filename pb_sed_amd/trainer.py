@@ -201,24 +201,60 @@ class Trainer:
 
     def sync_buffers(self, mode='mean'):
         """Data-parallel replicas keep their own batch-norm / feature running statistics (no SyncBN).  Before a checkpoint
-        or a validation pass make them agree: ``mode='mean'`` averages every floating-point buffer over the ranks
-        (``num_tracked_values`` counters are summed), ``'rank0'`` broadcasts rank 0's.  No-op without a process group."""
+        or a validation pass make them agree.  ``mode='mean'``: momentum statistics (batch norm) are averaged over the
+        ranks; CUMULATIVE statistics (a module with a ``num_tracked_values`` counter: the feature extractor) are merged
+        with their counts as weights - every rank contributes what it tracked SINCE the last merge (count delta and the
+        matching sum deltas), so the call is idempotent: calling it twice in a row, or before every checkpoint, neither
+        inflates the counter nor re-weights old data.  The replicas are assumed identical before the first call (they are
+        built / loaded identically) unless their counters say otherwise (then each rank's whole history is its delta).
+        ``'rank0'`` broadcasts rank 0's buffers.  No-op without a process group."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         world = dist.get_world_size()
-        for name, buf in self.model.named_buffers():
-            if not buf.is_floating_point():
-                continue
-            if mode == 'rank0':
-                dist.broadcast(buf, src=0)
-            elif name.endswith('num_tracked_values'):
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-            else:
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-                buf.div_(world)
-        fe = getattr(self.model, 'feature_extractor', None)
-        if fe is not None and mode == 'mean':           # derived buffers follow the merged statistics
-            with torch.no_grad():
+        synced = self.__dict__.setdefault('_synced_stats', {})
+        buffers = dict(self.model.named_buffers())
+        counted = {n[:-len('num_tracked_values')] for n in buffers if n.endswith('num_tracked_values')}
+        with torch.no_grad():
+            for name, buf in buffers.items():
+                prefix = name[:len(name) - len(name.rpartition('.')[2])]
+                if not buf.is_floating_point():
+                    continue
+                if mode == 'rank0':
+                    dist.broadcast(buf, src=0)
+                elif prefix in counted:
+                    continue                                 # merged below, count-weighted
+                else:
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                    buf.div_(world)
+            for prefix in sorted(counted):
+                cnt = buffers[prefix + 'num_tracked_values']
+                stats = [buffers[prefix + k] for k in ('running_mean', 'running_power') if prefix + k in buffers]
+                if mode != 'rank0':
+                    n = cnt.double().reshape(-1)[:1]
+                    base = synced.get(prefix)
+                    if base is None:
+                        # never merged: equal counters = identical replicas (baseline = that common state, nothing new);
+                        # different counters = independent histories (baseline empty)
+                        lo, hi = n.clone(), n.clone()
+                        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+                        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                        same = bool(lo.item() == hi.item())
+                        base = (n.clone() if same else torch.zeros_like(n),
+                                [s.double().clone() if same else torch.zeros_like(s, dtype=torch.float64) for s in stats])
+                    base_n, base_stats = base
+                    delta_n = n - base_n
+                    sums = [s.double() * n - bs * base_n for s, bs in zip(stats, base_stats)]
+                    dist.all_reduce(delta_n, op=dist.ReduceOp.SUM)
+                    for x in sums:
+                        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+                    total = base_n + delta_n
+                    if total.item() > 0:
+                        for s, bs, x in zip(stats, base_stats, sums):
+                            s.copy_(((bs * base_n + x) / total).to(s.dtype))
+                    cnt.copy_(total.to(cnt.dtype).reshape(cnt.shape) if cnt.numel() == 1 else total.to(cnt.dtype).expand_as(cnt))
+                synced[prefix] = (cnt.double().reshape(-1)[:1].clone(), [s.double().clone() for s in stats])
+            fe = getattr(self.model, 'feature_extractor', None)
+            if fe is not None:                              # derived buffers follow the merged statistics
                 fe.mean.copy_(fe.running_mean)
                 fe.inv_std.copy_(1. / torch.sqrt((fe.running_power - fe.running_mean ** 2).clamp_min(0.) + fe.norm_eps))
 

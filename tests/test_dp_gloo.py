@@ -78,10 +78,31 @@ def _buffer_worker(rank, world, port, out_dir):
         m.feature_extractor.num_tracked_values.fill_(100. * (rank + 1))
     t = Trainer.__new__(Trainer)
     t.model = m
+    fe = m.feature_extractor
     t.sync_buffers()
-    ok = torch.allclose(m.norm.running_mean, torch.full((4,), 1.5)) and m.feature_extractor.num_tracked_values.item() == 300.
-    ok = ok and torch.allclose(m.feature_extractor.mean, torch.full((8,), .5))
-    ok = ok and torch.allclose(m.feature_extractor.inv_std, 1. / torch.sqrt(torch.full((8,), 4.5 - .25 + 1e-5)))
+    # batch-norm (momentum) statistics: plain average; cumulative ones: count-weighted (100 frames of mean 0, 200 of mean 1)
+    ok = torch.allclose(m.norm.running_mean, torch.full((4,), 1.5)) and fe.num_tracked_values.item() == 300.
+    ok = ok and torch.allclose(fe.running_mean, torch.full((8,), 200. / 300.))
+    ok = ok and torch.allclose(fe.running_power, torch.full((8,), (100. * 4. + 200. * 5.) / 300.))
+    ok = ok and torch.allclose(fe.mean, fe.running_mean)
+    ok = ok and torch.allclose(fe.inv_std, 1. / torch.sqrt(fe.running_power - fe.running_mean ** 2 + 1e-5))
+    snap = [fe.running_mean.clone(), fe.running_power.clone()]
+    t.sync_buffers()                                  # idempotent: a second call must not inflate the counter
+    t.sync_buffers()
+    ok = ok and fe.num_tracked_values.item() == 300. and torch.allclose(fe.running_mean, snap[0], atol=1e-7) \
+        and torch.allclose(fe.running_power, snap[1], atol=1e-6)
+    # each rank then tracks more frames: rank r adds 60 * (r + 1) frames with mean 3 / power 10 (cumulative update)
+    with torch.no_grad():
+        add = 60. * (rank + 1)
+        n0 = fe.num_tracked_values.item()
+        fe.running_mean.copy_((fe.running_mean * n0 + 3. * add) / (n0 + add))
+        fe.running_power.copy_((fe.running_power * n0 + 10. * add) / (n0 + add))
+        fe.num_tracked_values.fill_(n0 + add)
+    t.sync_buffers()
+    tot = 300. + 60. + 120.
+    ok = ok and fe.num_tracked_values.item() == tot
+    ok = ok and torch.allclose(fe.running_mean, (snap[0] * 300. + 3. * 180.) / tot, atol=1e-6)
+    ok = ok and torch.allclose(fe.running_power, (snap[1] * 300. + 10. * 180.) / tot, atol=1e-5)
     with open(os.path.join(out_dir, f'buf{rank}'), 'w') as f:
         f.write(str(bool(ok)))
     dist.destroy_process_group()
@@ -100,3 +121,18 @@ def test_gradsync_single_process_is_noop():
     s = GradSync(g, [(0, 10)])
     s.bucket_ready(0)
     assert s.finish() == 1.0 and torch.equal(g, torch.ones(10))
+
+
+def test_bench_self_launches_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the driver invokes --gpus 1) must spawn its
+    own ranks instead of asserting; --rendezvous-only gloo stops after the process-group check (no GPU here)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rendezvous-only', 'gloo'],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout                     # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['rendezvous']['ranks_seen'] == 2 and out['rendezvous']['allreduce_check'] == 3.0

@@ -410,6 +410,28 @@ def test_fbcrnn_training_augmentation_in_the_loop():
     assert np.isfinite(rev['loss'].item())
 
 
+def test_training_mode_accepts_collated_waveforms_with_a_channel_axis():
+    """data.collate of reference-style examples gives audio [B,1,N]; forward() pops the input key in training mode
+    (pb_sed/models/weak_label/crnn.py:79-83), so the routing must not depend on the key being present."""
+    from pb_sed_amd.models import weak_label
+    torch.manual_seed(0)
+    model = weak_label.CRNN.build(num_events=10, hidden_size=64, num_layers=2, net=TINY).to(DEV)
+    model.feature_extractor.freeze_stats = True
+    wav, seq, weak, bnd, t = synth_batch(3, 16000, 10)
+    base = {'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV), 'boundary_targets': bnd.to(DEV)}
+    outs = {}
+    for mode in ('eval', 'train'):
+        getattr(model, mode)()
+        for name, audio in (('flat', wav), ('chan', wav[:, None])):
+            inputs = dict(base, audio_data=audio.to(DEV))
+            out = model(inputs)
+            assert ('audio_data' in inputs) == (mode == 'eval')          # train mode pops the key, as the reference does
+            outs[mode, name] = out[3].detach().clone()
+            if mode == 'train':
+                model.review(dict(base), out)['loss'].backward()
+        assert torch.equal(outs[mode, 'flat'], outs[mode, 'chan'])
+
+
 def test_fbcrnn_forward_is_reproducible():
     """Same batch, same state, several runs: scores are bitwise identical (block-level BN statistics are summed in a
     fixed order, the cross-block sums are f64) and the flat gradient agrees to fp32-atomics noise."""

@@ -107,6 +107,13 @@ def test_from_storage_dir_round_trip(tmp_path):
         v = sd.pop(f'feature_extractor.{k}')
         sd[f'feature_extractor.norm.{k}'] = v.reshape(1, 1, -1, 1)
     sd.pop('feature_extractor.mean'), sd.pop('feature_extractor.inv_std')
+    # ... and so do its batch norms: gamma / beta / statistics broadcast-shaped ([1,C,1,1] in CNN2d, [1,C,1] in CNN1d)
+    # plus a num_tracked_values counter the build does not keep
+    for k in [k for k in sd if '.norm.' in k and not k.startswith('feature_extractor.')]:
+        lead = k.rsplit('.norm.', 1)[0] + '.norm.'
+        sd[k] = sd[k].reshape((1, -1, 1, 1) if '.cnn_2d.' in k else (1, -1, 1))
+        sd[lead + 'num_tracked_values'] = torch.zeros(1)
+    assert any(k.endswith('.norm.num_tracked_values') and 'cnn_2d' in k for k in sd)
     torch.save({'model': sd, 'iteration': 1234}, tmp_path / 'checkpoints' / 'ckpt_best_macro_fscore_weak.pth')
     loaded = weak_label.CRNN.from_storage_dir(str(tmp_path), config_name='1/config.json',
                                               checkpoint_name='ckpt_best_macro_fscore_weak.pth')
@@ -189,6 +196,29 @@ def test_shard_batch_with_remainder():
     assert sum((s['example_id'] for s in got), []) == list('abcdefg')
     assert torch.equal(torch.cat([s['audio_data'] for s in got]), batch['audio_data']) and got[1]['meta'] == 1
     assert [len(shard_batch(batch, r, 8)['seq_len']) for r in range(8)] == [1] * 7 + [0]
+
+
+def test_sharded_inference_skips_an_empty_share():
+    """A ragged last batch with fewer clips than ranks: the rank whose share is empty neither segments nor launches
+    (pb_sed_amd/inference.py; the reference has no sharding)."""
+    from pb_sed_amd.inference import inference
+
+    class Untouchable:
+        def to(self, device):
+            return self
+
+        def eval(self):
+            return self
+
+        def tagging(self, *a, **k):
+            raise AssertionError('the model must not run on an empty share')
+
+        example_to_device = tagging
+
+    batch = {'audio_data': torch.zeros(2, 16000), 'seq_len': [50, 50], 'example_id': ['a', 'b']}
+    for seg in (None, 20):
+        assert inference(Untouchable(), 'tagging', [batch], 'cpu', max_segment_length=seg, merge_score_segments=seg is not None,
+                         rank=2, world_size=3) == {}
 
 
 def test_mel_warping_is_monotone_and_fixes_the_band_edge():
