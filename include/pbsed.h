@@ -143,7 +143,8 @@ typedef struct {
     float* dst;             /* packed copy (sizes from pbsed_conv_pack_dims / pbsed_conv_pack_dims_wino) */
     int Cout, Cin, KH, KW, InP, OutP;
     int mode;               /* 0 / 1: direct forward / data-gradient layout, 2 / 3: Winograd forward / data-gradient,
-                             * 4 / 5: bf16 (nsplit 1) forward / data-gradient layout of pbsed_pack_conv_weights_bf16 (dst: uint16) */
+                             * 4 / 5: bf16 (nsplit 1) forward / data-gradient layout of pbsed_pack_conv_weights_bf16 (dst: uint16),
+                             * 6 / 7: its three-part (nsplit 3) form, 8 / 9: pbsed_pack_conv_weights_winox3 forward / data gradient */
     int pad_;
 } pbsed_pack_desc;
 int pbsed_pack_conv_weights_batched(const pbsed_pack_desc* descs /*device*/, int n, void* stream);
@@ -159,6 +160,20 @@ int pbsed_conv_bwd_data_wino(const float* g, const float* ud_packed, const unsig
                              const int* seq_len, float* dz, const float* bx, const float* bmean, const float* binvstd,
                              const float* bscale, const float* bshift, int relu, double* stats, int B, int Cin,
                              int Cout, int F, int T, void* stream);
+/* The same 3x3 Winograd F(4,3) convolutions on the bf16 MFMA with exact three-way bf16 splits of both transformed operands
+ * (csrc/conv_winox3.hip; fp32-class results: six part products above 2^-24 accumulated in fp32).  Replaces the
+ * MFMA-bound 3x3 Conv2d + Normalization + ReLU (+ pool) sites of pb_sed/models/weak_label/crnn.py:93 (config
+ * pb_sed/experiments/weak_label_crnn/training.py:159-169,218-229).  u_packed_x3: uint16
+ * [in_padded/32][6][3][out_padded/16][3 parts][64 lanes][8] from pbsed_pack_conv_weights_winox3 (pbsed_pack_desc modes 8 / 9). */
+void pbsed_conv_pack_dims_winox3(int Cin, int Cout, int dgrad, int* in_padded /*host*/, int* out_padded /*host*/);
+int pbsed_pack_conv_weights_winox3(const float* w, unsigned short* u_packed_x3, int Cout, int Cin, int dgrad, void* stream);
+int pbsed_conv_fwd_winox3(const float* x, const unsigned short* u_packed_x3, const float* bias, const float* scale,
+                          const float* shift, int relu, const int* seq_len, float* y, unsigned char* pool_idx,
+                          double* stats, int stats_per_cf, int B, int Cin, int Cout, int F, int T, int pool, void* stream);
+int pbsed_conv_bwd_data_winox3(const float* g, const unsigned short* ud_packed_x3, const unsigned char* unpool_idx,
+                               const int* seq_len, float* dz, const float* bx, const float* bmean, const float* binvstd,
+                               const float* bscale, const float* bshift, int relu, double* stats, int B, int Cin,
+                               int Cout, int F, int T, void* stream);
 void pbsed_conv_pack_dims_bf16(int Cin, int Cout, int dgrad, int* in_padded /*host*/, int* out_padded /*host*/);
 int pbsed_pack_conv_weights_bf16(const float* w, unsigned short* w_packed_bf16, int Cout, int Cin, int KH, int KW,
                                  int dgrad, int nsplit, void* stream);
@@ -299,6 +314,15 @@ int pbsed_bn_bwd_tm(float* dz, const float* x, const double* sums, double count,
  * (padertorch CNN input_layer=False; every other norm gets its statistics from the producing convolution's epilogue). */
 int pbsed_channel_stats(const float* x, const int* seq_len, double* stats, int B, int C, int S, int T, void* stream);
 int pbsed_tm_rowmask(const int* seq_len, float* mask, int T, int B, void* stream);
+/* A norm + ReLU that CLOSES a stack (padertorch pre-activation CNN1d / CNN2d with a final norm + activation behind the last
+ * conv; SURVEY.md A.4 variant (iii) of pb_sed/experiments/weak_label_crnn/training.py:218-242): y = mask * relu(x * scale[c] +
+ * shift[c]) on [B, C, S, T]; backward writes dz = dy * mask * relu'(z) and the (sum dz, sum dz * xhat) partial sums
+ * [PBSED_STAT_SLOTS][C][2] (zeroed doubles) that pbsed_bn_bwd then turns into the gradient wrt x, dgamma and dbeta. */
+int pbsed_bn_relu_fwd(const float* x, const float* scale, const float* shift, const int* seq_len, float* y, int relu, int B,
+                      int C, int S, int T, void* stream);
+int pbsed_bn_relu_bwd(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
+                      const float* invstd, const int* seq_len, float* dz, double* stats, int relu, int B, int C, int S, int T,
+                      void* stream);
 
 /* ---- heads' squash + losses (pb_sed/models/weak_label/crnn.py:58-59,107-206;
  * pb_sed/models/strong_label/crnn.py:93,106-112) */

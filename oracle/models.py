@@ -75,7 +75,7 @@ def _feature_extractor(cfg):
 
 def build_cnn(in_channels, out_channels_2d, pool_sizes_2d, kernel_size_2d, out_channels_1d,
               kernel_size_1d, input_height, conditional_dims=0, eps=1e-3, residual_connections_2d=None,
-              residual_connections_1d=None, input_layer_2d=True, input_layer_1d=False):
+              residual_connections_1d=None, input_layer_2d=True, input_layer_1d=False, final_norm_1d=False):
     cnn_2d = CNN2d(in_channels + conditional_dims, out_channels_2d, kernel_size_2d, pool_sizes_2d,
                    eps=eps, pre_activation=True, output_layer=False, input_layer=input_layer_2d,
                    residual_connections=residual_connections_2d)
@@ -84,7 +84,7 @@ def build_cnn(in_channels, out_channels_2d, pool_sizes_2d, kernel_size_2d, out_c
         f //= (p[0] if isinstance(p, (tuple, list)) else p)
     cnn_1d = CNN1d(out_channels_2d[-1] * f, out_channels_1d, kernel_size_1d, 1, eps=eps,
                    pre_activation=True, output_layer=False, input_layer=input_layer_1d,
-                   residual_connections=residual_connections_1d)
+                   residual_connections=residual_connections_1d, final_norm=final_norm_1d)
     return CNN(cnn_2d, cnn_1d, input_height, conditional_dims)
 
 

@@ -162,8 +162,10 @@ class _CNN(nn.Module):
     ndim = None
 
     def __init__(self, in_channels, out_channels, kernel_size, pool_size=1, norm='batch',
-                 eps=1e-3, pre_activation=False, output_layer=True, input_layer=True, residual_connections=None):
-        """``residual_connections[i] = j``: the input of layer i is added to the input of layer j (the reference's 'deep'
+                 eps=1e-3, pre_activation=False, output_layer=True, input_layer=True, residual_connections=None,
+                 final_norm=False):
+        """``final_norm``: SURVEY.md A.4 reading (iii) - a pre-activation stack closes with a norm + ReLU behind its last conv.
+        ``residual_connections[i] = j``: the input of layer i is added to the input of layer j (the reference's 'deep'
         net_config, pb_sed/experiments/weak_label_crnn/training.py:170-183).  padertorch's skip path restated - parity
         unpinned: in between lying max-pools are applied to the skip, then a 1x1 conv (with bias) if the channel counts
         differ; with pre-activation layers both ends are the raw tensors in front of norm + ReLU."""
@@ -184,6 +186,7 @@ class _CNN(nn.Module):
             convs.append(_ConvLayer(self.ndim, cin, cout, ks[i], ps[i], pre, post, eps))
             cin = cout
         self.convs = nn.ModuleList(convs)
+        self.out_norm = Normalization(cin, eps=eps) if final_norm else None
         res = list(residual_connections) if residual_connections is not None else n * [None]
         self.residual_connections = [r[0] if isinstance(r, (list, tuple)) else r for r in res]
         cins = [in_channels] + list(out_channels[:-1])
@@ -210,6 +213,8 @@ class _CNN(nn.Module):
                     x = x + r
             inputs.append(x)
             x = conv(x, seq_len)
+        if self.out_norm is not None:
+            x = F.relu(self.out_norm(x, seq_len))
         return x, seq_len
 
     def freeze(self, num_layers=None, freeze_norm_stats=True):

@@ -38,6 +38,10 @@ SIGNATURES = {
     'pbsed_pack_conv_weights_wino': [_v, _v, I, I, I, _v],
     'pbsed_conv_fwd_wino': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, _v],
     'pbsed_conv_bwd_data_wino': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, _v, I, I, I, I, I, _v],
+    'pbsed_conv_pack_dims_winox3': [I, I, I, _i, _i],
+    'pbsed_pack_conv_weights_winox3': [_v, _v, I, I, I, _v],
+    'pbsed_conv_fwd_winox3': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, _v],
+    'pbsed_conv_bwd_data_winox3': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, _v, I, I, I, I, I, _v],
     'pbsed_conv_pack_dims_bf16': [I, I, I, _i, _i],
     'pbsed_pack_conv_weights_bf16': [_v, _v, I, I, I, I, I, I, _v],
     'pbsed_conv_fwd_bf16': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, I, I, I, _v],
@@ -63,6 +67,8 @@ SIGNATURES = {
     'pbsed_tm_conv_bwd_weight': [_v, _v, I, _v, _v, I, _v, _v, _v, I, I, I, I, I, _v],
     'pbsed_bn_bwd_tm': [_v, _v, _v, F64, _v, _v, _v, _v, _v, _v, _v, I, I, _v],
     'pbsed_tm_rowmask': [_v, _v, I, I, _v],
+    'pbsed_bn_relu_fwd': [_v, _v, _v, _v, _v, I, I, I, I, I, _v],
+    'pbsed_bn_relu_bwd': [_v, _v, _v, _v, _v, _v, _v, _v, _v, I, I, I, I, I, _v],
     'pbsed_channel_stats': [_v, _v, _v, I, I, I, I, _v],
     'pbsed_tm_gemm': [I, _pp, _pp, _i, _v, _v, I, I, I, _v],
     'pbsed_gru_wgrad_multi': [I, _pp, _pp, _i, _pp, _pp, I, I, I, _i, I, _v],
@@ -94,7 +100,7 @@ SIGNATURES = {
     'pbsed_allreduce_finish': [_v, _v],
 }
 _NON_STATUS = {'pbsed_last_error': C.c_char_p, 'pbsed_version': C.c_int, 'pbsed_comm_id_bytes': C.c_int, 'pbsed_conv_pack_dims': None,
-               'pbsed_conv_pack_dims_bf16': None, 'pbsed_conv_pack_dims_wino': None}
+               'pbsed_conv_pack_dims_bf16': None, 'pbsed_conv_pack_dims_wino': None, 'pbsed_conv_pack_dims_winox3': None}
 
 _lib = None
 

@@ -611,12 +611,12 @@ constexpr int pad8mod64(int n) { return ((n + 55) / 64) * 64 + 8; }      // half
 
 // NS = 1: plain bf16 operands; NS = 3: exact three-way splits of dY and x (Bf3 in common.h), six part products per product:
 // fp32-class gradients - the Conv1d layers of the fp32 path.
-template <int KH, int KW, int MH, int NS = 1>
+template <int KH, int KW, int MH, int NS = 1, int FT_ = 0>
 struct WgradB16Cfg {
     // MH groups of 32 output channels per block (two waves each: the two 16-channel halves of the 32-channel cin tile).
     // 3x3: MH = 4 (128 cout x 32 cin, 512 threads): the kernel is bound by the bytes a block pulls per MFMA, and the
     // wider cout tile halves the re-reads of x (measured at 64: no faster than the fp32 Winograd kernel).
-    static constexpr int FT = (KH == 3) ? 2 : 1, TT = (KH == 3) ? 64 : 128;
+    static constexpr int FT = FT_ ? FT_ : (KH == 3) ? 2 : 1, TT = (KH == 3) ? 64 : 128;
     static constexpr int KK = KH * KW, NT = MH * 128;
     static constexpr int COUT_T = MH * 32, CIN_T = 32;
     static constexpr int HALO = (KW > 1) ? 8 : 0;                          // elements; keeps the centre read 16-byte aligned
@@ -629,9 +629,9 @@ struct WgradB16Cfg {
     static constexpr int LDS_FLOATS = cmax(NS * (COUT_T * PLANE_Y + CIN_T * PLANE_A) / 2 + 2 * CIN_T, OUT_ROWS * OUT_ROW);
 };
 
-template <int KH, int KW, int MH, int NS = 1>
+template <int KH, int KW, int MH, int NS = 1, int FT_ = 0>
 __global__ __launch_bounds__(MH * 128) void conv_wgrad_bf16_kernel(ConvWgradArgs a) {
-    using C = WgradB16Cfg<KH, KW, MH, NS>;
+    using C = WgradB16Cfg<KH, KW, MH, NS, FT_>;
     constexpr int Y_PART = C::COUT_T * C::PLANE_Y, A_PART = C::CIN_T * C::PLANE_A;       // halfs per operand part
     constexpr int FT = C::FT, TT = C::TT, KK = C::KK, NT = C::NT;
     constexpr int PADH = (KH - 1) / 2, PADW = (KW - 1) / 2;
@@ -884,6 +884,14 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     if (!a.bf16 && x3_1d && KH == 1 && a.F == 1 && !a.unpool_idx && a.Cin >= 32 && a.Cout >= 32 && a.Cin < 1024) {
         if (KW == 3) return launch_wgrad_cfg<WgradB16Cfg<1, 3, 2, 3>>(conv_wgrad_bf16_kernel<1, 3, 2, 3>, a, s);
         if (KW == 1) return launch_wgrad_cfg<WgradB16Cfg<1, 1, 2, 3>>(conv_wgrad_bf16_kernel<1, 1, 2, 3>, a, s);
+    }
+    // 3x3 layers of the fp32 path on the same kernel with exact three-way operand splits (fp32-class gradients, 6 bf16 MFMA
+    // products per product): far fewer operand bytes per MFMA than the Winograd form, whose transformed operands are 6/4 as
+    // large per part (PBSED_WGRAD_X3: 0 = off, 1 = 128-cout blocks one row tall above 64 channels, 2 = 64-cout blocks)
+    static const int x3_2d = getenv("PBSED_WGRAD_X3") ? atoi(getenv("PBSED_WGRAD_X3")) : 0;
+    if (!a.bf16 && x3_2d && KH == 3 && KW == 3 && a.Cin >= 32 && a.Cout >= 32) {
+        if (x3_2d == 1 && a.Cout > 64) return launch_wgrad_cfg<WgradB16Cfg<3, 3, 4, 3, 1>>(conv_wgrad_bf16_kernel<3, 3, 4, 3, 1>, a, s);
+        return launch_wgrad_cfg<WgradB16Cfg<3, 3, 2, 3>>(conv_wgrad_bf16_kernel<3, 3, 2, 3>, a, s);
     }
     if (a.bf16 && a.Cin >= 32 && a.Cout >= 32) {       // bf16-MFMA operands (config 3); few-channel layers stay on the fp32 kernels
         if (KH == 3 && KW == 3) {

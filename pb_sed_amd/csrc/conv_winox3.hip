@@ -1,0 +1,542 @@
+// 3x3 convolution forward / data gradient in the Winograd F(4,3) domain on the bf16 MFMA with EXACT three-way bf16
+// operand splits (fp32-class results) for gfx950.  Same op sites and contract as conv_wino.hip (pb_sed/models/weak_label/
+// crnn.py:93; the MFMA-bound 3x3 layers of pb_sed/experiments/weak_label_crnn/training.py:159-169), same tensors, same
+// prologue / epilogue fusions.  What changes is where the multiplications run: conv_wino.hip issues them on the fp32 MFMA,
+// which shares the SIMD's pipe with the VALU and runs at 1/16 of the bf16 rate; here every transformed operand is split
+// exactly into three bf16 parts (x = hi + mid + lo by truncation, 8 + 8 + 8 significant bits) and the six part products above
+// 2^-24 are accumulated in fp32 on v_mfma_f32_16x16x32_bf16 (Bf3 / mfma_x3 in common.h): 6/16 of the fp32 pipe time, and
+// the staging VALU no longer competes with the MFMAs.
+//
+//   M_xi[cout, (row f, tile i)] = sum_{kh, cin} U_xi[kh][cout, cin] * V_xi[cin, (row f + kh - 1, tile i)],   y = A^T M
+//
+// Block = 512 threads = 4 CONSUMER waves + 4 PRODUCER waves (one of each per SIMD), tile = 64 cout x 4 rows x 64 t:
+//  * consumer wave w owns 16 cout x 4 rows x 16 tiles and all 6 transform points (96 accumulator registers), so the output
+//    transform is register arithmetic as in conv_wino.hip.  Its A operands - the transformed, pre-split weights U - are NOT
+//    staged: the pack writes them in fragment order ([chunk][xi][kh][cout tile][part][lane] x 16 B) and the wave streams its
+//    own 1 KB pieces from L2 straight into a register ring of three transform points (loads issued two points = 144 MFMAs
+//    ahead; one point ahead the wave drains its whole request queue at every point boundary: 67 % of the MFMA peak).
+//    U is 108 B per weight pair; through LDS it would have cost 221 KB of writes per 32-channel chunk for two reads each.
+//  * producer waves turn the raw input into V: global load (BN-apply + ReLU + mask prologue, un-pool for pooled data
+//    gradients) -> B^T d -> three bf16 parts -> LDS image [xi][halo row][tile][32 cin] per part (64-byte positions,
+//    XOR-swizzled 16-byte groups: a B fragment is one conflict-free ds_read_b128 per part).  The image of a 32-channel
+//    chunk is built in two halves (xi 0..2, xi 3..5; 54 KB each, double-buffered): while the consumers multiply one half
+//    the producers build the other, one block barrier per half.  VALU work beside bf16 MFMAs of another wave overlaps
+//    (tools/micro/x3_stream.hip: 89 % of the MFMA peak from one wave per SIMD, 75 % with a producer beside it, 67 % with
+//    the U stream from a 2 MB footprint).
+// Blocks are PERSISTENT (one per CU) and walk a list of (cout tile, spatial tile) items; the producers run ahead through
+// the chunk stream of all of a block's tiles, so a tile's first half image is built during the previous tile's last phase
+// and epilogue.  Items are numbered so that an XCD works on one cout tile (item % 8 = XCD): its L2 holds that tile's U only.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "pack_elems.h"
+#include "pbsed_internal.h"
+
+namespace pbsed {
+
+constexpr int WX_CT = 64;                               // cout per block (16 per consumer wave)
+constexpr int WX_CK = 32;                               // cin per chunk = K of one MFMA
+constexpr int WX_FT = 4, WX_TT = 64, WX_ROWS = WX_FT + 2;
+constexpr int WX_PART = 3 * WX_ROWS * 16 * 64;          // bytes of one part of a half image: [xi 3][row 6][tile 16][32 cin bf16]
+constexpr int WX_HALF = 3 * WX_PART;                    // 55 296
+constexpr int WX_V_BYTES = 2 * WX_HALF;
+constexpr int WX_RING = 2;                              // U register ring in transform points (3 kh x 3 parts x 16 B per lane each)
+
+template <bool POOL>
+struct WxCfg {
+    static constexpr int FO_T = POOL ? WX_FT / 2 : WX_FT;
+    static constexpr size_t LDS_BYTES = (size_t)WX_V_BYTES;
+};
+
+__global__ void winox3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ up, int Cout, int Cin, int InP,
+                                   int OutP, int dgrad) {
+    const size_t total = (size_t)18 * InP * OutP * 3;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        up[i] = pack_winox3_elem(w, i, Cout, Cin, InP, OutP, dgrad);
+}
+
+template <bool POOL, bool DGRAD, bool UNPOOL>
+__global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt, int nSp, int xcd_map, int nWork) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // uniform: buffer-load scalar offsets and role branches depend on it
+    const bool consumer = wave < 4;
+    const int lq = lane >> 4, lr = lane & 15;
+
+    // PERSISTENT blocks: block p works on items p, p + gridDim, p + 2 gridDim .. of the (cout tile, spatial tile) list.
+    // xcd_map: item -> XCD = item % 8 (gridDim is a multiple of 8), and an XCD keeps ONE cout tile: its L2 holds that tile's U.
+    const int nTt = (a.T + WX_TT - 1) / WX_TT, nFt = (a.F + WX_FT - 1) / WX_FT;
+    auto item = [&](int k, int& ct, int& sp) __attribute__((always_inline)) {
+        const int w = (int)blockIdx.x + k * (int)gridDim.x;
+        if (xcd_map) {
+            const int xcd = w & 7, slot = w >> 3, per = 8 / nCt;
+            ct = xcd % nCt;
+            sp = slot * per + xcd / nCt;
+        } else {
+            ct = w % nCt;
+            sp = w / nCt;
+        }
+        return w < nWork && sp < nSp;
+    };
+    int nT = 0;                                       // valid items of this block (sp grows with k: the invalid ones are at the end)
+    {
+        int ct_, sp_;
+        while (item(nT, ct_, sp_)) ++nT;
+    }
+    if (nT == 0) return;
+    const bool pro = a.scale != nullptr;
+    constexpr bool unpool = DGRAD && UNPOOL;
+    const int Fsrc = unpool ? a.F / 2 : a.F;
+    const int nChunks = a.CinP / WX_CK;
+    const int G = nT * nChunks;                       // the block's stream of 32-channel chunks over all of its tiles
+
+    if (!consumer) {
+        // ================================================================ PRODUCER: x -> V (three bf16 parts) in LDS
+        // Item = (cin, halo row, tile): the tile's four inputs are ONE aligned 16-byte load (16 lanes = 16 tiles = 256
+        // contiguous bytes of a row), the two inputs it shares with its neighbours (d0 = x[4i-1], d5 = x[4i+4]) come from the
+        // neighbouring lanes by DPP after the prologue; only the row's first / last tile loads its outer element itself.
+        // A thread's 12 items: rows j % 6, cin = (j / 6) * 16 + producer wave * 4 + lane / 16.
+        // The producers run through the chunk stream of ALL tiles of the block: the first half image of the next tile is
+        // built while the consumers are still in the last phase / the epilogue of the current one.
+        const int pw = wave - 4, tile = lr, cl = lq;
+        constexpr unsigned OOB = 0x80000000u;
+        const unsigned clip_elems = (unsigned)(a.Cin * Fsrc * a.T);
+        const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.scale), 0, pro ? (unsigned)a.Cin * 4u : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.shift), 0, pro ? (unsigned)a.Cin * 4u : 0u, 0x00020000);
+        const bool edge_lane = tile == 0 || tile == 15;
+        const int ic0 = pw * 4 + cl;                             // cin of items 0..5; items 6..11: + 16
+        const unsigned row_elems = (unsigned)a.T;
+        const unsigned chan_step = (unsigned)(Fsrc * a.T);
+        const unsigned lds_t = (unsigned)(tile * 64 + (ic0 & 7) * 2);
+        const unsigned swz0 = (unsigned)((((ic0 >> 3) ^ ((-(tile >> 2)) & 3)) & 3) * 16);
+
+        // state of the tile the NEXT load_chunk reads from (set when the stream enters a tile) ...
+        int ld_k = 0, ld_ch = 0, ld_f0 = 0, ld_t0 = 0, ld_b = 0;
+        // ... and of the tile whose raw registers finish_inputs turns into inputs (the chunk loaded last)
+        int fi_f0 = 0, fi_nok = 0;
+        bool fi_edge_ok = false;
+
+        unsigned rin[12][4], redge[12], ridx[12], ridx_e[12];
+        unsigned rsc[2] = {0u, 0u}, rsh[2] = {0u, 0u};
+        float d[12][6];
+
+        auto load_chunk = [&]() __attribute__((always_inline)) {
+            if (ld_ch == 0) {                                      // entering tile ld_k
+                int ct, sp;
+                item(ld_k, ct, sp);
+                ld_t0 = (sp % nTt) * WX_TT;
+                ld_f0 = ((sp / nTt) % nFt) * WX_FT;
+                ld_b = sp / (nTt * nFt);
+            }
+            const int f0 = ld_f0, t0 = ld_t0;
+            const int sl = a.seq_len ? min(a.seq_len[ld_b], a.T) : a.T;
+            const int tlim = pro ? sl : a.T;                       // Normalization re-masks its output (y*mask)
+            const int tq = t0 + 4 * tile;                          // first output column of the tile = its input d1
+            const int t_edge = tile == 0 ? t0 - 1 : t0 + 64;      // the outer element this lane loads itself (tiles 0 and 15)
+            fi_f0 = f0;
+            fi_nok = min(max(tlim - tq, 0), 4);                    // d1..d4 inside [0, tlim)  (zero padding is post-activation)
+            fi_edge_ok = edge_lane && t_edge >= 0 && t_edge < tlim;
+            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a.x) + (size_t)ld_b * clip_elems, 0, clip_elems * 4u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
+                unpool ? const_cast<uint8_t*>(a.unpool_idx) + (size_t)ld_b * clip_elems : nullptr, 0, unpool ? clip_elems : 0u, 0x00020000);
+            const unsigned voff_c = (unsigned)(ld_ch * WX_CK + ic0) * 4u;
+            const unsigned chunk_elem0 = (unsigned)(ld_ch * WX_CK + ic0) * chan_step;
+            if (pro) {
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg) {
+                    rsc[cg] = __builtin_amdgcn_raw_buffer_load_b32(rs_sc, voff_c + cg * 64u, 0, 0);
+                    rsh[cg] = __builtin_amdgcn_raw_buffer_load_b32(rs_sh, voff_c + cg * 64u, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int ir = j % 6, cg = j / 6;
+                const int fin = f0 - 1 + ir;
+                const bool row_ok = fin >= 0 && fin < a.F;
+                const unsigned row0 = chunk_elem0 + (unsigned)cg * 16u * chan_step + (unsigned)(unpool ? (fin >> 1) : fin) * row_elems;
+                const unsigned e1 = row_ok ? row0 + (unsigned)tq : (OOB >> 2);           // element index of d1
+                const unsigned ee = (row_ok && edge_lane) ? row0 + (unsigned)t_edge : (OOB >> 2);
+                const u32x4_t xv = __builtin_amdgcn_raw_buffer_load_b128(rs_x, e1 * 4u, 0, 0);
+                rin[j][0] = xv.x; rin[j][1] = xv.y; rin[j][2] = xv.z; rin[j][3] = xv.w;
+                if (unpool) ridx[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, e1 >= (OOB >> 2) ? OOB : e1, 0, 0);
+                redge[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, ee * 4u, 0, 0);
+                if (unpool) ridx_e[j] = __builtin_amdgcn_raw_buffer_load_b8(rs_i, ee >= (OOB >> 2) ? OOB : ee, 0, 0);
+            }
+            if (++ld_ch == nChunks) { ld_ch = 0; ++ld_k; }
+        };
+        // raw registers -> the six post-activation inputs of every item
+        auto finish_inputs = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int ir = j % 6, cg = j / 6;
+                const int fin = fi_f0 - 1 + ir;
+                const int par = fin & 1;
+                const float sc = __uint_as_float(rsc[cg]), sh = __uint_as_float(rsh[cg]);
+                float v[4], ve = __uint_as_float(redge[j]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float u = __uint_as_float(rin[j][k]);
+                    if (unpool) u = (int)((ridx[j] >> (8 * k)) & 0xffu) != par ? 0.f : u;
+                    if (pro) {
+                        u = fmaf(u, sc, sh);
+                        if (a.relu) u = fmaxf(u, 0.f);
+                    }
+                    v[k] = k < fi_nok ? u : 0.f;
+                }
+                if (unpool) ve = (int)(ridx_e[j] & 0xffu) != par ? 0.f : ve;
+                if (pro) {
+                    ve = fmaf(ve, sc, sh);
+                    if (a.relu) ve = fmaxf(ve, 0.f);
+                }
+                ve = fi_edge_ok ? ve : 0.f;
+                // d0 = the left neighbour's last input, d5 = the right neighbour's first one
+                const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[3]), 0x111, 0xf, 0xf, true));    // row_shr:1
+                const float right = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[0]), 0x101, 0xf, 0xf, true));   // row_shl:1
+                const bool live = fin >= 0 && fin < a.F;          // a halo row outside the plane is zero AFTER the activation
+                d[j][0] = live ? (tile == 0 ? ve : left) : 0.f;
+                d[j][1] = live ? v[0] : 0.f; d[j][2] = live ? v[1] : 0.f; d[j][3] = live ? v[2] : 0.f; d[j][4] = live ? v[3] : 0.f;
+                d[j][5] = live ? (tile == 15 ? ve : right) : 0.f;
+            }
+        };
+        // V of three transform points -> LDS half image `half` (0: xi 0..2, 1: xi 3..5)
+        auto store_half = [&](auto half_c) __attribute__((always_inline)) {
+            constexpr int HALF = decltype(half_c)::value;
+            unsigned char* base = smem_raw + HALF * WX_HALF + lds_t;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int ir = j % 6, cg = j / 6;
+                const float d0 = d[j][0], d1 = d[j][1], d2 = d[j][2], d3 = d[j][3], d4 = d[j][4], d5 = d[j][5];
+                float v[3];
+                if (HALF == 0) {
+                    v[0] = 4.f * d0 - 5.f * d2 + d4;
+                    v[1] = -4.f * (d1 + d2) + d3 + d4;
+                    v[2] = 4.f * (d1 - d2) - d3 + d4;
+                } else {
+                    v[0] = -2.f * d1 - d2 + 2.f * d3 + d4;
+                    v[1] = 2.f * d1 - d2 - 2.f * d3 + d4;
+                    v[2] = 4.f * d1 - 5.f * d3 + d5;
+                }
+                unsigned char* pj = base + (cg ? (swz0 ^ 32u) : swz0) + ir * 1024;
+#pragma unroll
+                for (int xl = 0; xl < 3; ++xl) {
+                    const unsigned u0 = __float_as_uint(v[xl]);
+                    const float r1 = v[xl] - __uint_as_float(u0 & 0xffff0000u);
+                    const unsigned u1 = __float_as_uint(r1);
+                    const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+                    unsigned char* p = pj + xl * (WX_ROWS * 16 * 64);
+                    *reinterpret_cast<unsigned short*>(p) = (unsigned short)(u0 >> 16);
+                    *reinterpret_cast<unsigned short*>(p + WX_PART) = (unsigned short)(u1 >> 16);
+                    *reinterpret_cast<unsigned short*>(p + 2 * WX_PART) = (unsigned short)(__float_as_uint(r2) >> 16);
+                }
+            }
+        };
+
+        load_chunk();
+        finish_inputs();
+        if (G > 1) load_chunk();
+        store_half(std::integral_constant<int, 0>{});
+        __syncthreads();
+        for (int g = 0; g < G; ++g) {
+            store_half(std::integral_constant<int, 1>{});              // consumers: xi 0..2 of chunk g
+            __syncthreads();
+            if (g + 1 < G) {                                            // consumers: xi 3..5 of chunk g (then, at a tile's end, its epilogue)
+                finish_inputs();
+                if (g + 2 < G) load_chunk();
+                store_half(std::integral_constant<int, 0>{});
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ================================================================ CONSUMER: U from L2, V from LDS, MFMAs, epilogue
+    const int MT = a.CoutP / 16;
+    const size_t u_bytes = (size_t)18 * a.CinP * a.CoutP * 3 * 2;
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (unsigned)u_bytes, 0x00020000);
+    const unsigned voff_u = (unsigned)lane * 16u;
+    const unsigned step_bytes = (unsigned)MT * 3072u;               // one (xi, kh) step of all cout tiles
+    const unsigned point_bytes = 3u * step_bytes;
+    const unsigned v_lane = (unsigned)(lr * 64 + (((lq ^ ((-(lr >> 2)) & 3)) & 3) * 16));
+
+    u32x4_t A[WX_RING][3][3];                                        // [ring slot][kh][part]
+    auto load_A = [&](int slot, unsigned soff) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                A[slot][kh][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u, soff + kh * step_bytes + p * 1024u, 0);
+    };
+    int ct, sp;
+    item(0, ct, sp);
+    unsigned u_base = (unsigned)(ct * (WX_CT / 16) + wave) * 3072u;  // point 0 of chunk 0, this wave's cout tile
+    static_assert(WX_RING == 2, "the ring holds the current point and the next one");
+    load_A(0, u_base);
+
+    f32x4 acc[6][4];
+    __syncthreads();                                                 // half 0 of the first chunk is staged
+    for (int k = 0; k < nT; ++k) {
+        const int t0 = (sp % nTt) * WX_TT;
+        const int f0 = ((sp / nTt) % nFt) * WX_FT;
+        const int b = sp / (nTt * nFt);
+        const int cout0 = ct * WX_CT;
+        const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
+        int ct_n = ct, sp_n = sp;
+        const bool more = k + 1 < nT && item(k + 1, ct_n, sp_n);
+        const unsigned u_base_n = more ? (unsigned)(ct_n * (WX_CT / 16) + wave) * 3072u : 0xC0000000u;   // past the end: reads 0
+#pragma unroll
+        for (int x = 0; x < 6; ++x)
+#pragma unroll
+            for (int fl = 0; fl < 4; ++fl) acc[x][fl] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ch = 0; ch < nChunks; ++ch) {
+            const unsigned soff_u = u_base + (unsigned)ch * 6u * point_bytes;
+            const unsigned soff_next = ch + 1 < nChunks ? soff_u + 6u * point_bytes : u_base_n;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const unsigned char* vb = smem_raw + half * WX_HALF + v_lane;
+                u32x4_t Bf[2][3];                                        // V fragments of two halo rows: the next row's reads are
+                auto read_B = [&](int xl, int h, u32x4_t (&dst)[3]) __attribute__((always_inline)) {   // in flight during a row's MFMAs
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        dst[p] = *reinterpret_cast<const u32x4_t*>(vb + p * WX_PART + (xl * WX_ROWS + h) * 1024);
+                };
+                read_B(0, 0, Bf[0]);
+#pragma unroll
+                for (int xl = 0; xl < 3; ++xl) {
+                    const int x = half * 3 + xl;
+                    // U of the next point into the slot the previous point left
+                    load_A((x + 1) % WX_RING, x + 1 < 6 ? soff_u + (unsigned)(x + 1) * point_bytes : soff_next);
+#pragma unroll
+                    for (int h = 0; h < WX_ROWS; ++h) {
+                        const int cur = (xl * WX_ROWS + h) & 1;
+                        if (h + 1 < WX_ROWS) read_B(xl, h + 1, Bf[cur ^ 1]);
+                        else if (xl + 1 < 3) read_B(xl + 1, 0, Bf[cur ^ 1]);
+                        // six part products, smallest first, round-robin over the (row, kh) sets of this halo row
+#pragma unroll
+                        for (int pp = 0; pp < 6; ++pp) {
+                            const int pa = pp == 0 ? 2 : pp == 1 ? 0 : pp == 2 ? 1 : pp == 3 ? 1 : 0;     // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+                            const int pb = pp == 0 ? 0 : pp == 1 ? 2 : pp == 2 ? 1 : pp == 3 ? 0 : pp == 4 ? 1 : 0;
+#pragma unroll
+                            for (int kh = 0; kh < 3; ++kh) {
+                                const int fl = h - kh;
+                                if (fl >= 0 && fl < WX_FT) acc[x][fl] = mfma_b16(A[x % WX_RING][kh][pa], Bf[cur][pb], acc[x][fl]);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+
+        // ---- epilogue of this tile (the producers are already staging the next one): A^T M in registers, then bias / pool /
+        // statistics / BN-ReLU backward as in conv_wino.hip on 4 consecutive t per lane:
+        //   t = t0 + 4*lr + e,  cout = cout0 + 16*wave + lq*4 + r,  f = f0 + fl.
+        // A wave owns its 16 channels alone, so the statistics need no cross-wave pass: one lane per (channel[, row]) adds them.
+        constexpr unsigned OOB_C = 0x80000000u, OOB_T = 0x20000000u;
+        constexpr int FO_T = POOL ? WX_FT / 2 : WX_FT;
+        const int Fo = POOL ? a.F / 2 : a.F;
+        const int tb = t0 + 4 * lr;
+        const unsigned oclip = (unsigned)(a.Cout * Fo * a.T);
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)b * oclip, 0, oclip * 4u, 0x00020000);
+        const bool want_idx = POOL && a.pool_idx != nullptr;
+        const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(
+            want_idx ? a.pool_idx + (size_t)b * oclip : nullptr, 0, want_idx ? oclip : 0u, 0x00020000);
+        const bool bnb = DGRAD && a.bx != nullptr;
+        const __amdgpu_buffer_rsrc_t rs_bx = __builtin_amdgcn_make_buffer_rsrc(
+            bnb ? const_cast<float*>(a.bx) + (size_t)b * oclip : nullptr, 0, bnb ? oclip * 4u : 0u, 0x00020000);
+        const unsigned tcol = tb < a.T ? (unsigned)tb * 4u : OOB_T;
+        const int n_seq = min(max(sl - tb, 0), 4);                    // elements of the quad inside the sequence
+        const int slot = (int)(sp & (PBSED_STAT_SLOTS - 1));
+        constexpr int NFO = POOL ? 1 : 2;                             // output rows per row pair
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cout = cout0 + wave * 16 + lq * 4 + r;
+            const bool cv = cout < a.Cout;
+            const float bias = (a.bias && cv) ? a.bias[cout] : 0.f;
+            const unsigned coff = cv ? (unsigned)(cout * Fo * a.T) * 4u : OOB_C;
+            float bsc = 0.f, bsh = 0.f, bmu = 0.f, bis = 0.f;
+            if (bnb && cv) { bsc = a.bscale[cout]; bsh = a.bshift[cout]; bmu = a.bmean[cout]; bis = a.binvstd[cout]; }
+            float c1 = 0.f, c2 = 0.f;                                   // per-channel statistics over the block's rows
+#pragma unroll
+            for (int rp = 0; rp < 2; ++rp) {                            // row pairs (0,1), (2,3): one pool window each
+                unsigned roff[NFO];
+                bool orow_ok[NFO];
+                int fo_of[NFO];
+#pragma unroll
+                for (int fo_l = 0; fo_l < NFO; ++fo_l) {
+                    const int fo = POOL ? f0 / 2 + rp : f0 + rp * 2 + fo_l;
+                    fo_of[fo_l] = fo;
+                    orow_ok[fo_l] = fo < Fo;
+                    roff[fo_l] = orow_ok[fo_l] ? (unsigned)(fo * a.T) * 4u : OOB_T;
+                }
+                u32x4_t xq[NFO];
+                if (bnb) {
+#pragma unroll
+                    for (int fo_l = 0; fo_l < NFO; ++fo_l) xq[fo_l] = __builtin_amdgcn_raw_buffer_load_b128(rs_bx, coff + roff[fo_l] + tcol, 0, 0);
+                }
+                float y[2][4];
+#pragma unroll
+                for (int fl = 0; fl < 2; ++fl) {
+                    const int f = rp * 2 + fl;
+                    const float m0 = acc[0][f][r], m1 = acc[1][f][r], m2 = acc[2][f][r], m3 = acc[3][f][r], m4 = acc[4][f][r],
+                                m5 = acc[5][f][r];
+                    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                    y[fl][0] = m0 + s12 + s34 + bias;
+                    y[fl][1] = d12 + 2.f * d34 + bias;
+                    y[fl][2] = s12 + 4.f * s34 + bias;
+                    y[fl][3] = d12 + 8.f * d34 + m5 + bias;
+                }
+#pragma unroll
+                for (int fo_l = 0; fo_l < NFO; ++fo_l) {
+                    float v[4];
+                    unsigned pbytes = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (POOL) {
+                            const bool second = y[1][e] > y[0][e];
+                            v[e] = second ? y[1][e] : y[0][e];
+                            pbytes |= (unsigned)second << (8 * e);
+                        } else {
+                            v[e] = y[fo_l][e];
+                        }
+                    }
+                    const int n_cnt = orow_ok[fo_l] ? n_seq : 0;           // padded channels produce exact zeros
+                    float s1 = 0.f, s2 = 0.f;
+                    if (DGRAD) {
+                        if (bnb) {
+                            // backward through mask -> ReLU -> BN-apply of the layer's prologue, with the BN-backward sums
+                            const u32x4_t x4 = xq[fo_l];
+                            const float xv[4] = {__uint_as_float(x4.x), __uint_as_float(x4.y), __uint_as_float(x4.z), __uint_as_float(x4.w)};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float z = fmaf(xv[e], bsc, bsh);
+                                const bool keep = e < n_cnt && (!a.relu || z > 0.f);
+                                v[e] = keep ? v[e] : 0.f;
+                                s1 += v[e]; s2 = fmaf(v[e], (xv[e] - bmu) * bis, s2);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float vm = e < n_cnt ? v[e] : 0.f;
+                            s1 += vm; s2 = fmaf(vm, vm, s2);
+                        }
+                    }
+                    const unsigned off = coff + roff[fo_l] + tcol;
+                    const u32x4_t q = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(q, rs_y, off, 0, 0);
+                    if (want_idx) __builtin_amdgcn_raw_buffer_store_b32(pbytes, rs_p, off >> 2, 0, 0);
+                    if (a.stats && a.stats_cf) {                         // statistics per (channel, output row)
+                        s1 = wave_sum16(s1);
+                        s2 = wave_sum16(s2);
+                        if (lr == 0 && cv && orow_ok[fo_l]) {
+                            double* dst = a.stats + ((size_t)slot * a.Cout * Fo + (size_t)cout * Fo + fo_of[fo_l]) * 2;
+                            atomicAdd(dst, (double)s1);
+                            atomicAdd(dst + 1, (double)s2);
+                        }
+                    }
+                    c1 += s1; c2 += s2;
+                }
+            }
+            if (a.stats && !a.stats_cf) {
+                c1 = wave_sum16(c1);
+                c2 = wave_sum16(c2);
+                if (lr == 0 && cv) {
+                    double* dst = a.stats + ((size_t)slot * a.Cout + cout) * 2;
+                    atomicAdd(dst, (double)c1);
+                    atomicAdd(dst + 1, (double)c2);
+                }
+            }
+        }
+        (void)FO_T;
+        ct = ct_n; sp = sp_n; u_base = u_base_n;
+    }
+}
+
+template <bool POOL, bool DGRAD, bool UNPOOL>
+static int launch_winox3(const ConvFwdArgs& a, hipStream_t s) {
+    using C = WxCfg<POOL>;
+    // the loaders address one clip with 32-bit byte offsets (buffer loads; 2^31 marks "out of range")
+    if ((size_t)a.Cin * a.F * a.T * 4 >= (1ull << 30) || (size_t)a.Cout * a.F * a.T * 4 >= (1ull << 29)) {
+        set_error("conv_winox3: one clip of the input / output must stay below 1 GiB / 512 MiB (Cin=%d Cout=%d F=%d T=%d)", a.Cin,
+                  a.Cout, a.F, a.T);
+        return PBSED_E_ARG;
+    }
+    if ((size_t)18 * a.CinP * a.CoutP * 6 >= (1ull << 31)) { set_error("conv_winox3: packed weights exceed 2 GiB"); return PBSED_E_ARG; }
+    const int nTt = (a.T + WX_TT - 1) / WX_TT, nFt = (a.F + WX_FT - 1) / WX_FT;
+    const int nSp = nTt * nFt * a.B, nCt = a.CoutP / WX_CT;
+    const int xcd_map = (nCt <= 8 && 8 % nCt == 0) ? 1 : 0;
+    const int per = xcd_map ? 8 / nCt : 1;
+    const int nWork = xcd_map ? (nSp + per - 1) / per * 8 : nSp * nCt;
+    if (a.T & 3) { set_error("conv_winox3: T = %d is not a multiple of 4 (rows must be 16-byte aligned; use the fp32 Winograd kernel)", a.T); return PBSED_E_UNSUPPORTED; }
+    // persistent blocks, one per CU (110 KB of LDS each), a multiple of 8 so that an item's XCD is its block's XCD
+    static int n_cu_dev[64] = {0};
+    int dev = 0;
+    PBSED_HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
+    int& n_cu = n_cu_dev[dev & 63];
+    if (n_cu == 0) {
+        hipDeviceProp_t prop;
+        n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    int blocks = n_cu / 8 * 8;
+    if (blocks < 8) blocks = 8;
+    if (blocks > nWork) blocks = (nWork + 7) / 8 * 8;
+    auto kern = conv_winox3_kernel<POOL, DGRAD, UNPOOL>;
+    PBSED_DYN_LDS_ONCE(kern, C::LDS_BYTES);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), C::LDS_BYTES, s, a, nCt, nSp, xcd_map, nWork);
+    return check_launch("conv_winox3");
+}
+
+}  // namespace pbsed
+
+using namespace pbsed;
+
+extern "C" {
+
+void pbsed_conv_pack_dims_winox3(int Cin, int Cout, int dgrad, int* InP, int* OutP) {
+    const int in = dgrad ? Cout : Cin, out = dgrad ? Cin : Cout;
+    *InP = (in + WX_CK - 1) / WX_CK * WX_CK;
+    *OutP = (out + WX_CT - 1) / WX_CT * WX_CT;
+}
+
+// up: uint16 [InP/32][xi 6][kh 3][OutP/16][part 3][lane 64][8]
+int pbsed_pack_conv_weights_winox3(const float* w, unsigned short* up, int Cout, int Cin, int dgrad, void* stream) {
+    int InP, OutP;
+    pbsed_conv_pack_dims_winox3(Cin, Cout, dgrad, &InP, &OutP);
+    const size_t total = (size_t)18 * InP * OutP * 3;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(winox3_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, up, Cout, Cin, InP, OutP, dgrad);
+    return check_launch("pack_conv_weights_winox3");
+}
+
+int pbsed_conv_fwd_winox3(const float* x, const unsigned short* u_packed, const float* bias, const float* scale,
+                          const float* shift, int relu, const int* seq_len, float* y, unsigned char* pool_idx, double* stats,
+                          int stats_per_cf, int B, int Cin, int Cout, int F, int T, int pool, void* stream) {
+    if (pool && (F % 2)) { set_error("conv_fwd_winox3: pool needs even F"); return PBSED_E_ARG; }
+    ConvFwdArgs a{};
+    a.x = x; a.wp = reinterpret_cast<const float*>(u_packed); a.bias = bias; a.scale = scale; a.shift = shift; a.seq_len = seq_len;
+    a.y = y; a.pool_idx = pool_idx; a.stats = stats; a.stats_cf = stats_per_cf; a.relu = relu;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.F = F; a.T = T;
+    pbsed_conv_pack_dims_winox3(Cin, Cout, 0, &a.CinP, &a.CoutP);
+    return pool ? launch_winox3<true, false, false>(a, (hipStream_t)stream) : launch_winox3<false, false, false>(a, (hipStream_t)stream);
+}
+
+int pbsed_conv_bwd_data_winox3(const float* g, const unsigned short* ud_packed, const unsigned char* unpool_idx,
+                               const int* seq_len, float* dz, const float* bx, const float* bmean, const float* binvstd,
+                               const float* bscale, const float* bshift, int relu, double* stats, int B, int Cin, int Cout,
+                               int F, int T, void* stream) {
+    if (unpool_idx && (F % 2)) { set_error("conv_bwd_data_winox3: unpool needs even F"); return PBSED_E_ARG; }
+    ConvFwdArgs a{};
+    a.x = g; a.wp = reinterpret_cast<const float*>(ud_packed); a.seq_len = seq_len; a.y = dz; a.unpool_idx = unpool_idx;
+    a.bx = bx; a.bmean = bmean; a.binvstd = binvstd; a.bscale = bscale; a.bshift = bshift;
+    a.relu = relu; a.stats = bx ? stats : nullptr;
+    a.B = B; a.Cin = Cout; a.Cout = Cin; a.F = F; a.T = T;      // roles swapped
+    pbsed_conv_pack_dims_winox3(Cin, Cout, 1, &a.CinP, &a.CoutP);
+    return unpool_idx ? launch_winox3<false, true, true>(a, (hipStream_t)stream) : launch_winox3<false, true, false>(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -25,7 +25,8 @@ struct PackDesc {
     float* dst;
     int Cout, Cin, KH, KW, InP, OutP;
     int mode;      // 0/1: direct forward / data-gradient layout, 2/3: Winograd forward / data-gradient layout,
-                   // 4/5: bf16 [tap][OutP][InP] forward / data-gradient layout (dst holds uint16)
+                   // 4/5: bf16 [tap][OutP][InP] forward / data-gradient layout (dst holds uint16), 6/7: its three-part form,
+                   // 8/9: bf16x3 Winograd fragment layout forward / data gradient (csrc/conv_winox3.hip)
     int pad_;
 };
 
@@ -38,6 +39,13 @@ __device__ __forceinline__ unsigned short f2bf_rne(float x) {
 __global__ void pack_batched_kernel(const PackDesc* __restrict__ descs) {
     const PackDesc d = descs[blockIdx.y];
     const int KK = d.KH * d.KW;
+    if (d.mode >= 8) {                                   // csrc/conv_winox3.hip: fragment-ordered three-part Winograd weights
+        const size_t total = (size_t)18 * d.InP * d.OutP * 3;
+        unsigned short* dst = reinterpret_cast<unsigned short*>(d.dst);
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+            dst[i] = pack_winox3_elem(d.src, i, d.Cout, d.Cin, d.InP, d.OutP, d.mode & 1);
+        return;
+    }
     if (d.mode >= 4) {                                   // csrc/conv_bf16.hip layout: [tap][OutP][InP], input channels innermost
         const size_t total = (size_t)KK * d.OutP * d.InP;
         unsigned short* dst = reinterpret_cast<unsigned short*>(d.dst);
@@ -261,6 +269,54 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
     for (int i = tid; i < S * T; i += 256) {
         const float v = (i % T) < sl ? p[i] : 0.f;
         s1 += v; s2 = fmaf(v, v, s2);
+    }
+    __shared__ float red[2][4];
+    s1 = wave_sum64(s1); s2 = wave_sum64(s2);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid < 2) {
+        const float v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+        atomicAdd(&stats[((size_t)(b & (PBSED_STAT_SLOTS - 1)) * C + c) * 2 + tid], (double)v);
+    }
+}
+
+// A norm + ReLU that CLOSES a stack (padertorch pre-activation CNN whose last conv is followed by the stack's final norm and
+// activation; SURVEY.md A.4 variant (iii)): there is no consumer conv whose loader could apply it, so it is a launch of its
+// own.  Forward: y = mask * relu(x * scale[c] + shift[c]) (the batch statistics behind scale / shift came out of the
+// producing conv's epilogue as everywhere else).
+__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const int* __restrict__ seq_len,
+                                                          float* __restrict__ y, int C, int S, int T, int relu) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int sl = seq_len ? min(seq_len[b], T) : T;
+    const size_t base = ((size_t)b * C + c) * S * T;
+    const float sc = scale[c], sh = shift[c];
+    for (int i = threadIdx.x; i < S * T; i += 256) {
+        float z = fmaf(x[base + i], sc, sh);
+        if (relu) z = fmaxf(z, 0.f);
+        y[base + i] = (i % T) < sl ? z : 0.f;
+    }
+}
+
+// Backward of the same: dz = dy * mask * relu'(z) written out, and the (sum dz, sum dz * xhat) partial sums BN backward needs
+// (the quantities a data-gradient epilogue produces for every other norm) into stats [PBSED_STAT_SLOTS][C][2].
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const int* __restrict__ seq_len, float* __restrict__ dz,
+                                                          double* __restrict__ stats, int C, int S, int T, int relu) {
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int sl = seq_len ? min(seq_len[b], T) : T;
+    const size_t base = ((size_t)b * C + c) * S * T;
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = tid; i < S * T; i += 256) {
+        const float xv = x[base + i];
+        const float z = fmaf(xv, sc, sh);
+        const bool keep = (i % T) < sl && (!relu || z > 0.f);
+        const float g = keep ? dy[base + i] : 0.f;
+        dz[base + i] = g;
+        s1 += g; s2 = fmaf(g, (xv - mu) * is, s2);
     }
     __shared__ float red[2][4];
     s1 = wave_sum64(s1); s2 = wave_sum64(s2);
@@ -783,6 +839,22 @@ int pbsed_channel_stats(const float* x, const int* seq_len, double* stats, int B
     if (B < 1 || B > 65535 || C < 1) { set_error("channel_stats: bad B=%d C=%d", B, C); return PBSED_E_ARG; }
     hipLaunchKernelGGL(channel_stats_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, seq_len, stats, C, S, T);
     return check_launch("channel_stats");
+}
+
+int pbsed_bn_relu_fwd(const float* x, const float* scale, const float* shift, const int* seq_len, float* y, int relu, int B,
+                      int C, int S, int T, void* stream) {
+    if (B < 1 || B > 65535 || C < 1) { set_error("bn_relu_fwd: bad B=%d C=%d", B, C); return PBSED_E_ARG; }
+    hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, scale, shift, seq_len, y, C, S, T, relu);
+    return check_launch("bn_relu_fwd");
+}
+
+int pbsed_bn_relu_bwd(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
+                      const float* invstd, const int* seq_len, float* dz, double* stats, int relu, int B, int C, int S, int T,
+                      void* stream) {
+    if (B < 1 || B > 65535 || C < 1) { set_error("bn_relu_bwd: bad B=%d C=%d", B, C); return PBSED_E_ARG; }
+    hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, dy, x, scale, shift, mean, invstd,
+                       seq_len, dz, stats, C, S, T, relu);
+    return check_launch("bn_relu_bwd");
 }
 
 int pbsed_tm_rowmask(const int* seq_len, float* mask, int T, int B, void* stream) {

@@ -38,4 +38,29 @@ __device__ __forceinline__ float pack_wino_elem(const float* __restrict__ w, siz
     }
 }
 
+// bf16x3 Winograd layout (csrc/conv_winox3.hip): halfwords [InP/32][xi 6][kh 3][OutP/16][part 3][lane 64][8] - the 16 bytes
+// a lane holds of an MFMA A fragment (row = cout tile * 16 + (lane & 15), k = chunk * 32 + (lane >> 4) * 8 + j) contiguous,
+// one 1 KB piece per (point, kernel row, cout tile, part).  U is formed in fp32 exactly as pack_wino_elem does and split by
+// truncation into three bf16 parts (hi + mid + lo == U exactly).
+__device__ __forceinline__ unsigned short pack_winox3_elem(const float* __restrict__ w, size_t i, int Cout, int Cin, int InP,
+                                                           int OutP, int dgrad) {
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    size_t r = i >> 9;
+    const int part = (int)(r % 3); r /= 3;
+    const int MT = OutP / 16;
+    const int mt = (int)(r % MT); r /= MT;
+    const int kh = (int)(r % 3); r /= 3;
+    const int xi = (int)(r % 6);
+    const int c = (int)(r / 6);
+    const int o = mt * 16 + (lane & 15), ii = c * 32 + (lane >> 4) * 8 + j;
+    const float u = pack_wino_elem(w, ((size_t)(kh * 6 + xi) * InP + ii) * OutP + o, Cout, Cin, InP, OutP, dgrad);
+    const unsigned b0 = __float_as_uint(u);
+    if (part == 0) return (unsigned short)(b0 >> 16);
+    const float r1 = u - __uint_as_float(b0 & 0xffff0000u);
+    const unsigned b1 = __float_as_uint(r1);
+    if (part == 1) return (unsigned short)(b1 >> 16);
+    const float r2 = r1 - __uint_as_float(b1 & 0xffff0000u);
+    return (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
 }  // namespace pbsed

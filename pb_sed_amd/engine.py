@@ -82,6 +82,8 @@ def _grad(p):
 
 # ------------------------------------------------------------------------------------- conv stacks
 class LayerDesc:
+    out_norm = None                 # last layer of a stack that closes with its own norm + ReLU (SURVEY.md A.4 reading (iii))
+
     def __init__(self, conv, in_norm):
         self.conv, self.in_norm = conv, in_norm
         self.skips_in = []          # residual connections ending at this layer's INPUT: (source layer index, skip conv | None)
@@ -105,6 +107,12 @@ def describe_stack(cnns):
     if convs[-1].post:
         raise NotImplementedError('a trailing post-activation norm (output_layer=False without '
                                   'pre_activation) has no consumer conv to fuse into')
+    for k, cnn in enumerate(cnns):
+        if getattr(cnn, 'out_norm', None) is not None:
+            if k != len(cnns) - 1:
+                raise NotImplementedError('a closing norm + ReLU is built for the LAST stack of a chain (the next stack\'s '
+                                          'first layer would normalise again)')
+            layers[-1].out_norm = cnn.out_norm            # its own launch: pbsed_bn_relu_fwd / pbsed_bn_relu_bwd
     return layers
 
 
@@ -127,13 +135,16 @@ def _prec(precision, cin, pc=None, dgrad=False):
     if pc is not None and pc.kh == 3 and pc.kw == 3 and os.environ.get('PBSED_CONV_WINO', '1') != '0':
         k_in, n_out = (pc.cout, pc.cin) if dgrad else (pc.cin, pc.cout)
         if k_in >= 32 and n_out >= 64:
-            return 'wino'
+            # bf16x3 Winograd (csrc/conv_winox3.hip: the same transform-domain products from exact three-way bf16 splits on
+            # the bf16 MFMA) where it is ahead of the fp32-MFMA Winograd kernel; PBSED_CONV_WINOX3=0 keeps the latter
+            return 'winox3' if os.environ.get('PBSED_CONV_WINOX3', '1') != '0' else 'wino'
     return 'f32'
 
 
 class _StackCtx(list):
     """ctx of stack_forward (one entry per layer) + the stack output in the scans' layout when the last layers ran time-major."""
     tbc_out = None
+    final = None                # (raw output of the last conv, BN state, frozen) of a stack that closes with norm + ReLU
 
 
 def _tm_start(layers, precision):
@@ -162,6 +173,8 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32', x_tbc
     ctx = _StackCtx()
     st_in, st_frozen = None, False
     j_tm = _tm_start(layers, precision)
+    if layers[-1].out_norm is not None:
+        j_tm = len(layers)                             # the closing norm + ReLU runs on the CNN layout
     x_t = rowmask = None
     if x is None and (j_tm > 0 or layers[0].in_norm is not None):       # only the time-major form of the input was handed over
         x = ops.tbc_to_bct(x_tbc)
@@ -180,7 +193,7 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32', x_tbc
     for j, L in enumerate(layers):
         c = L.conv
         nxt = layers[j + 1] if j + 1 < len(layers) else None
-        next_norm = nxt.in_norm if nxt is not None else None
+        next_norm = nxt.in_norm if nxt is not None else L.out_norm
         # frozen statistics (cnn_2d.freeze(n, freeze_norm_stats=True), pb_sed/experiments/weak_label_crnn/training.py:343-350):
         # the layer normalises with its running statistics in training too and they are not updated
         batch_stats = training and next_norm is not None and not next_norm.freeze_stats
@@ -232,6 +245,10 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32', x_tbc
         else:
             st_in = ops.bn_eval_params(next_norm)
         x = y
+    if layers[-1].out_norm is not None:
+        # the stack's closing norm + ReLU (st_in / st_frozen are the last conv's "next norm" state): a launch of its own
+        ctx.final = (x, st_in, st_frozen)
+        x = ops.bn_relu_fwd(x, st_in, seq_dev)
     if x_t is not None:                                # back to the CNN layout for the callers on it
         cout = layers[-1].conv.conv.weight.shape[0]
         x = ops.tbc_to_bct(x_t)
@@ -284,6 +301,16 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
         return any(p.requires_grad for m in mods for p in m.parameters())
 
     lowest = min((j for j in range(len(layers)) if trainable(j)), default=len(layers))
+    if ctx.final is not None:                    # backward through the closing ReLU + norm first
+        x_raw, st_f, frozen_f = ctx.final
+        norm_f = layers[-1].out_norm
+        if g is None:
+            g = ops.tbc_to_bct(g_tbc)
+            g_tbc = None
+        dz, stats_f = ops.bn_relu_bwd(g, x_raw, st_f, seq_dev)
+        rows = 1 if x_raw.dim() == 3 else x_raw.shape[2]
+        count = float('inf') if frozen_f else _count(seq_host, x_raw.shape[-1], rows)
+        g = ops.bn_backward(dz, x_raw, st_f, stats_f, count, _grad(norm_f.gamma), _grad(norm_f.beta), seq_dev)
     pending = {}                                 # source layer -> gradient arriving over residual connections
     g_t = None                                   # the gradient while it travels through the time-major layers
     for j in reversed(range(len(layers))):
@@ -349,7 +376,7 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
             if on_layer_done is not None:
                 on_layer_done(0)
             return None
-        pr = _prec('f32' if pr == 'wino' else pr, pc.cin, pc, dgrad=True)
+        pr = _prec('f32' if pr in ('wino', 'winox3') else pr, pc.cin, pc, dgrad=True)
         wd = pc.dgrad(pr)
         if st_in is not None:
             dz, stats = ops.conv_bwd_data(g, pc, wd, x.shape, idx, seq_dev,

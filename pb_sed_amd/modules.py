@@ -272,9 +272,11 @@ class _CNN(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, pool_size=1, norm='batch', eps=None,
                  pre_activation=False, output_layer=True, input_layer=True, norm_kwargs=None, activation_fn='relu',
                  dropout=0., residual_connections=None, dense_connections=False, pad_type='both', dilation=1, stride=1,
-                 gated=False, pool_type='max', pool_stride=None):
+                 gated=False, pool_type='max', pool_stride=None, final_norm=False):
         """Constructor fields of padertorch's CNN2d / CNN1d as the reference configs give them
-        (pb_sed/experiments/weak_label_crnn/training.py:218-242); what the HIP kernels do not implement is refused."""
+        (pb_sed/experiments/weak_label_crnn/training.py:218-242); what the HIP kernels do not implement is refused.
+        ``final_norm`` (not a padertorch field): SURVEY.md A.4 reading (iii) of ``pre_activation=True, output_layer=False`` -
+        the stack closes with a norm + ReLU of its own behind the last conv (``out_norm``)."""
         super().__init__()
         if eps is None:
             eps = (norm_kwargs or {}).get('eps', 1e-3)
@@ -300,6 +302,9 @@ class _CNN(nn.Module):
             convs.append(ConvLayer(self.ndim, cin, cout, ks[i], ps[i], pre, post, eps))
             cin = cout
         self.convs = nn.ModuleList(convs)
+        if final_norm and not (pre_activation and norm is not None):
+            raise NotImplementedError('final_norm closes a pre-activation stack with batch norm')
+        self.out_norm = Normalization(cin, eps=eps) if final_norm else None
         self.residual_connections, self.skip_convs = plan_residuals(
             self.ndim, residual_connections, in_channels, self.out_channels, ps, pre_activation)
 
@@ -403,9 +408,10 @@ SHALLOW = dict(
 
 def build_cnn(in_channels, out_channels_2d, pool_sizes_2d, kernel_size_2d, out_channels_1d, kernel_size_1d,
               input_height, conditional_dims=0, eps=1e-3, residual_connections_2d=None, residual_connections_1d=None,
-              input_layer_2d=True, input_layer_1d=False):
+              input_layer_2d=True, input_layer_1d=False, final_norm_1d=False):
     """``input_layer_2d`` / ``input_layer_1d``: padertorch's ``input_layer`` of the two stacks (True = the stack's first layer has no
-    pre-activation norm + ReLU) - the defaults are SURVEY.md A.4's reading, the other variants are flags."""
+    pre-activation norm + ReLU) - the defaults are SURVEY.md A.4's reading, the other variants are flags; ``final_norm_1d``:
+    reading (iii), the 1-D stack closes with its own norm + ReLU behind the last conv."""
     cnn_2d = CNN2d(in_channels + conditional_dims, out_channels_2d, kernel_size_2d, pool_sizes_2d, eps=eps,
                    pre_activation=True, output_layer=False, input_layer=input_layer_2d, residual_connections=residual_connections_2d)
     f = input_height
@@ -413,7 +419,8 @@ def build_cnn(in_channels, out_channels_2d, pool_sizes_2d, kernel_size_2d, out_c
     for p in ps:
         f //= (p[0] if isinstance(p, (tuple, list)) else p)
     cnn_1d = CNN1d(out_channels_2d[-1] * f, out_channels_1d, kernel_size_1d, 1, eps=eps,
-                   pre_activation=True, output_layer=False, input_layer=input_layer_1d, residual_connections=residual_connections_1d)
+                   pre_activation=True, output_layer=False, input_layer=input_layer_1d, residual_connections=residual_connections_1d,
+                   final_norm=final_norm_1d)
     return CNN(cnn_2d, cnn_1d, input_height, conditional_dims=conditional_dims)
 
 

@@ -168,12 +168,39 @@ class PackedConv:
         _register_pack(self.owner, self.weight, up, (self.cout, self.cin, 3, 3, inp.value, outp.value), 2 + dgrad, ck)
         return up
 
+    def _pack_winox3(self, dgrad):
+        """Fragment-ordered three-part Winograd weights of csrc/conv_winox3.hip (uint16)."""
+        assert self.kh == 3 and self.kw == 3
+        key = (self.owner._version, PACK_EPOCH[0], self.owner.data_ptr())
+        cache = getattr(self.owner, '_pbsed_pack', None)
+        if cache is None or cache.get('key') != key:
+            cache = {'key': key}
+            try:
+                self.owner._pbsed_pack = cache
+            except AttributeError:
+                pass
+        ck = ('winox3', dgrad)
+        if ck in cache:
+            return cache[ck]
+        inp, outp = C.c_int(), C.c_int()
+        _lib.lib().pbsed_conv_pack_dims_winox3(self.cin, self.cout, dgrad, C.byref(inp), C.byref(outp))
+        up = torch.empty(18 * inp.value * outp.value * 3, device=self.weight.device, dtype=torch.int16)
+        w = self.weight.detach().contiguous()
+        call('pbsed_pack_conv_weights_winox3', ptr(w), ptr(up), self.cout, self.cin, dgrad, stream())
+        cache[ck] = up
+        _register_pack(self.owner, self.weight, up, (self.cout, self.cin, 3, 3, inp.value, outp.value), 8 + dgrad, ck)
+        return up
+
     def fwd(self, precision='f32'):
+        if precision == 'winox3':
+            return self._pack_winox3(0)
         if precision == 'wino':
             return self._pack_wino(0)
         return self._pack(0) if precision == 'f32' else self._pack_bf16(0, NSPLIT[precision])
 
     def dgrad(self, precision='f32'):
+        if precision == 'winox3':
+            return self._pack_winox3(1)
         if precision == 'wino':
             return self._pack_wino(1)
         return self._pack(1) if precision == 'f32' else self._pack_bf16(1, NSPLIT[precision])
@@ -218,10 +245,12 @@ def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=No
     if want_stats:
         stats = _zero_stats(pc.cout * fo if stats_per_cf else pc.cout, x.device)
     assert residual is None or precision == 'f32', 'a residual add needs the fp32 direct kernel'
-    if precision == 'wino':
-        call('pbsed_conv_fwd_wino', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
+    if precision == 'winox3' and t % 4:               # the bf16x3 kernel needs 16-byte aligned rows: same result from the fp32 form
+        precision, wp = 'wino', pc.fwd('wino')
+    if precision in ('wino', 'winox3'):
+        call('pbsed_conv_fwd_' + precision, ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
              ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, int(pool), stream(),
-             tag=_conv_tag(b, cin, pc, f, t) + ' wino', flops=_conv_flops(b, cin, pc, f, t))
+             tag=_conv_tag(b, cin, pc, f, t) + ' ' + precision, flops=_conv_flops(b, cin, pc, f, t))
         return y, idx, stats
     if precision != 'f32':
         call('pbsed_conv_fwd_bf16', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
@@ -251,10 +280,12 @@ def conv_bwd_data(g, pc, wd, x_shape, unpool_idx=None, seq_len=None, bn=None, re
     if bn is not None:
         bx, bmean, binv, bsc, bsh = bn
         stats = _zero_stats(cin, g.device)
-    if precision == 'wino':
-        call('pbsed_conv_bwd_data_wino', ptr(g), ptr(wd), ptr(unpool_idx), ptr(seq_len), ptr(dz), ptr(bx),
+    if precision == 'winox3' and t % 4:
+        precision, wd = 'wino', pc.dgrad('wino')
+    if precision in ('wino', 'winox3'):
+        call('pbsed_conv_bwd_data_' + precision, ptr(g), ptr(wd), ptr(unpool_idx), ptr(seq_len), ptr(dz), ptr(bx),
              ptr(bmean), ptr(binv), ptr(bsc), ptr(bsh), int(relu), ptr(stats), b, cin, pc.cout, f, t, stream(),
-             tag=_conv_tag(b, cin, pc, f, t) + ' wino', flops=_conv_flops(b, cin, pc, f, t))
+             tag=_conv_tag(b, cin, pc, f, t) + ' ' + precision, flops=_conv_flops(b, cin, pc, f, t))
         return dz, stats
     if precision != 'f32':
         call('pbsed_conv_bwd_data_bf16', ptr(g), ptr(wd), ptr(unpool_idx), ptr(seq_len), ptr(dz), ptr(bx),
@@ -336,6 +367,24 @@ def channel_stats(x, seq_len):
     stats = _zero_stats(c, x.device)
     call('pbsed_channel_stats', ptr(x), ptr(seq_len), ptr(stats), b, c, s, t, stream())
     return stats
+
+
+def bn_relu_fwd(x, st, seq_len, relu=True):
+    """mask * relu(x * scale + shift): a norm + activation that closes a stack (no consumer conv to fuse into)."""
+    b, c, s_, t = _dims4(x)
+    y = torch.empty_like(x)
+    call('pbsed_bn_relu_fwd', ptr(x), ptr(st.scale), ptr(st.shift), ptr(seq_len), ptr(y), int(relu), b, c, s_, t, stream())
+    return y
+
+
+def bn_relu_bwd(dy, x, st, seq_len, relu=True):
+    """Backward of bn_relu_fwd up to the norm's input statistics: returns (dz, partial sums for bn_backward)."""
+    b, c, s_, t = _dims4(x)
+    dz = torch.empty_like(x)
+    stats = _zero_stats(c, x.device)
+    call('pbsed_bn_relu_bwd', ptr(dy.contiguous()), ptr(x), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(seq_len),
+         ptr(dz), ptr(stats), int(relu), b, c, s_, t, stream())
+    return dz, stats
 
 
 def bn_eval_params(norm):

@@ -51,12 +51,14 @@ def _copy_weights(dst, src):
     assert not missing and not unexpected
 
 
-@pytest.mark.parametrize('cfg', ['tiny_ragged', 'tiny_full', 'shallow_b2', 'tiny_prenorm_first_layer', 'tiny_no_prenorm_1d'])
+@pytest.mark.parametrize('cfg', ['tiny_ragged', 'tiny_full', 'shallow_b2', 'tiny_prenorm_first_layer', 'tiny_no_prenorm_1d',
+                                 'tiny_final_norm_1d'])
 def test_fbcrnn_train_step_parity(cfg):
     """``tiny_prenorm_first_layer`` / ``tiny_no_prenorm_1d``: the other readings of padertorch's ``input_layer`` (SURVEY.md
     A.4 (i), (ii)) - CNN2d's first layer WITH its own pre-activation norm (statistics of the network input from
     pbsed_channel_stats, its gamma / beta gradients through a data-gradient launch of the first layer), CNN1d's first layer
-    WITHOUT one - are flags of the builders, not NotImplementedErrors."""
+    WITHOUT one - and reading (iii), ``tiny_final_norm_1d``: a norm + ReLU behind the last CNN1d conv (pbsed_bn_relu_fwd /
+    pbsed_bn_relu_bwd, a launch of its own) - are flags of the builders, not NotImplementedErrors."""
     from oracle import frontend as ofe, models as om
     from pb_sed_amd.models import weak_label
     torch.manual_seed(0)
@@ -66,6 +68,8 @@ def test_fbcrnn_train_step_parity(cfg):
             net['input_layer_2d'] = False
         if cfg == 'tiny_no_prenorm_1d':
             net['input_layer_1d'] = True
+        if cfg == 'tiny_final_norm_1d':            # A.4 reading (iii): the 1-D stack closes with its own norm + ReLU
+            net['final_norm_1d'] = True
         kw = dict(num_events=10, number_of_filters=128, hidden_size=64, num_layers=2, net=net)
         b, n = 5, 16000 * 2
     else:

@@ -536,8 +536,9 @@ WINO_CASES = [c for c in CONV_CASES if c['k'] == (3, 3) and c['cin'] >= 16] + [
 ]
 
 
+@pytest.mark.parametrize('prec', ['wino', 'winox3'])
 @pytest.mark.parametrize('case', WINO_CASES, ids=lambda c: f"{c['cin']}x{c['cout']}f{c['f']}t{c['t']}p{int(c['pool'])}{'pro' if c['pro'] else ''}")
-def test_conv_winograd_vs_torch(case):
+def test_conv_winograd_vs_torch(case, prec):
     """3x3 conv with the time axis in the Winograd F(4,3) domain: forward (prologue, bias, pool + argmax, statistics)
     and data gradient (plain and through the pool argmax) at the fp32 tolerances of the direct kernels."""
     from pb_sed_amd import ops
@@ -557,8 +558,8 @@ def test_conv_winograd_vs_torch(case):
     seq_dev = torch.as_tensor(seq, dtype=torch.int32).to(DEV)
     pc = ops.PackedConv(dx(w))
     xd = dx(x)
-    y, idx, stats = ops.conv_fwd(xd, pc, pc.fwd('wino'), bias=dx(bias), scale=dx(scale), shift=dx(shift), relu=True,
-                                 seq_len=seq_dev, pool=pool, want_stats=True, precision='wino')
+    y, idx, stats = ops.conv_fwd(xd, pc, pc.fwd(prec), bias=dx(bias), scale=dx(scale), shift=dx(shift), relu=True,
+                                 seq_len=seq_dev, pool=pool, want_stats=True, precision=prec)
     close(y, y_ref, name='conv_fwd wino')
     m = (torch.arange(t)[None] < torch.as_tensor(seq)[:, None]).double()[:, None, None, :]
     yd = y_ref.detach()
@@ -570,7 +571,7 @@ def test_conv_winograd_vs_torch(case):
         valid = (torch.arange(t, device=DEV)[None] < seq_dev[:, None])[:, None, None, :]     # masked frames tie exactly
         assert ((idx != idx_d) & valid).float().mean().item() < 2e-3      # near-ties of the pooled rows may resolve differently
     if not pro:
-        g, _ = ops.conv_bwd_data(dx(gy), pc, pc.dgrad('wino'), xd.shape, idx, None, precision='wino')
+        g, _ = ops.conv_bwd_data(dx(gy), pc, pc.dgrad(prec), xd.shape, idx, None, precision=prec)
         close(g, xr.grad, atol=2e-4, rtol=1e-3, name='conv_dgrad wino')
 
 
@@ -592,12 +593,13 @@ def test_conv_winograd_dgrad_bn_epilogue_matches_direct(cin, cout, f, t, pool):
     scale, shift = gamma * invstd, beta - mean * gamma * invstd
     pc = ops.PackedConv(w)
     out = {}
-    for prec in ('f32', 'wino'):
+    for prec in ('f32', 'wino', 'winox3'):
         dz, st = ops.conv_bwd_data(g, pc, pc.dgrad(prec), x.shape, idx, seq, bn=(x, mean, invstd, scale, shift),
                                    precision=prec)
         out[prec] = (dz, st.sum(0))
-    close(out['wino'][0], out['f32'][0], atol=2e-5, rtol=1e-4, name='dz wino vs direct')
-    close(out['wino'][1], out['f32'][1], atol=2e-3, rtol=1e-4, name='bn-backward sums wino vs direct')
+    for prec in ('wino', 'winox3'):
+        close(out[prec][0], out['f32'][0], atol=2e-5, rtol=1e-4, name=f'dz {prec} vs direct')
+        close(out[prec][1], out['f32'][1], atol=2e-3, rtol=1e-4, name=f'bn-backward sums {prec} vs direct')
 
 
 def test_logmel_augmentation_vs_oracle():
