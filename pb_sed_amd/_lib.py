@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpbsed_mi355.so')
+LIB_PATH = os.environ.get('PBSED_LIB') or os.path.join(_HERE, 'libpbsed_mi355.so')     # PBSED_LIB: a tools/ build variant
 
 _f = C.POINTER(C.c_float)
 _d = C.POINTER(C.c_double)

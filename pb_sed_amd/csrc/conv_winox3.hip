@@ -41,6 +41,9 @@ constexpr int WX_FT = 4, WX_TT = 64, WX_ROWS = WX_FT + 2;
 constexpr int WX_PART = 3 * WX_ROWS * 16 * 64;          // bytes of one part of a half image: [xi 3][row 6][tile 16][32 cin bf16]
 constexpr int WX_HALF = 3 * WX_PART;                    // 55 296
 constexpr int WX_V_BYTES = 2 * WX_HALF;
+#ifndef WX_DBG
+#define WX_DBG 0            // ablation switches of tools/winox3_ablation.sh (never set in the product build)
+#endif
 constexpr int WX_RING = 2;                              // U register ring in transform points (3 kh x 3 parts x 16 B per lane each)
 
 template <bool POOL>
@@ -70,10 +73,14 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
     const int nTt = (a.T + WX_TT - 1) / WX_TT, nFt = (a.F + WX_FT - 1) / WX_FT;
     auto item = [&](int k, int& ct, int& sp) __attribute__((always_inline)) {
         const int w = (int)blockIdx.x + k * (int)gridDim.x;
-        if (xcd_map) {
+        if (xcd_map == 1) {                        // an XCD keeps one cout tile (its L2 holds that tile's U only)
             const int xcd = w & 7, slot = w >> 3, per = 8 / nCt;
             ct = xcd % nCt;
             sp = slot * per + xcd / nCt;
+        } else if (xcd_map == 2) {                 // the cout tiles of a spatial tile run side by side on ONE XCD: x is fetched from
+            const int xcd = w & 7, l = w >> 3;     // HBM once and found in that XCD's L2 by the others (and so are the halo rows of
+            ct = l % nCt;                          // the row tile above / below when the row has 8 column tiles)
+            sp = (l / nCt) * 8 + xcd;
         } else {
             ct = w % nCt;
             sp = w / nCt;
@@ -94,13 +101,16 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
 
     if (!consumer) {
         // ================================================================ PRODUCER: x -> V (three bf16 parts) in LDS
-        // Item = (cin, halo row, tile): the tile's four inputs are ONE aligned 16-byte load (16 lanes = 16 tiles = 256
-        // contiguous bytes of a row), the two inputs it shares with its neighbours (d0 = x[4i-1], d5 = x[4i+4]) come from the
-        // neighbouring lanes by DPP after the prologue; only the row's first / last tile loads its outer element itself.
-        // A thread's 12 items: rows j % 6, cin = (j / 6) * 16 + producer wave * 4 + lane / 16.
+        // Item = (4 consecutive cin, halo row, tile): a tile's four inputs are ONE aligned 16-byte load per channel (16 lanes =
+        // 16 tiles = 256 contiguous bytes of a row), the two inputs it shares with its neighbours (d0 = x[4i-1], d5 = x[4i+4])
+        // come from the neighbouring lanes by DPP after the prologue; only the row's first / last tile loads its outer
+        // element itself.  Four channels per item make every LDS store an 8-byte one (4 cin x bf16 of one transform point and
+        // part): 27 stores per thread and half image instead of 108 two-byte ones.
+        // A thread's 3 items: cin group q >> 1 (channels 4 (q >> 1) .. + 3), rows 2 j + (q & 1), q = producer wave * 4 + lane / 16.
         // The producers run through the chunk stream of ALL tiles of the block: the first half image of the next tile is
         // built while the consumers are still in the last phase / the epilogue of the current one.
-        const int pw = wave - 4, tile = lr, cl = lq;
+        const int pw = wave - 4, tile = lr;
+        const int q = pw * 4 + lq, cgp = q >> 1, rsel = q & 1;
         constexpr unsigned OOB = 0x80000000u;
         const unsigned clip_elems = (unsigned)(a.Cin * Fsrc * a.T);
         const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(
@@ -108,23 +118,29 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
         const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.shift), 0, pro ? (unsigned)a.Cin * 4u : 0u, 0x00020000);
         const bool edge_lane = tile == 0 || tile == 15;
-        const int ic0 = pw * 4 + cl;                             // cin of items 0..5; items 6..11: + 16
         const unsigned row_elems = (unsigned)a.T;
         const unsigned chan_step = (unsigned)(Fsrc * a.T);
-        const unsigned lds_t = (unsigned)(tile * 64 + (ic0 & 7) * 2);
-        const unsigned swz0 = (unsigned)((((ic0 >> 3) ^ ((-(tile >> 2)) & 3)) & 3) * 16);
+        // LDS byte offset of this thread's 8-byte slot in a (point, row) plane: tile position, swizzled k-group, half
+        const unsigned lds_t = (unsigned)(tile * 64 + ((((cgp >> 1) ^ ((-(tile >> 2)) & 3)) & 3) * 16) + (cgp & 1) * 8 + rsel * 1024);
 
         // state of the tile the NEXT load_chunk reads from (set when the stream enters a tile) ...
         int ld_k = 0, ld_ch = 0, ld_f0 = 0, ld_t0 = 0, ld_b = 0;
-        // ... and of the tile whose raw registers finish_inputs turns into inputs (the chunk loaded last)
-        int fi_f0 = 0, fi_nok = 0;
-        bool fi_edge_ok = false;
+        // ... and of the tile a raw buffer's registers belong to.  Two raw buffers = two chunks in flight: the loads of chunk
+        // g + 2 are issued as soon as chunk g's second half image is stored and have a period and a half to arrive (with one
+        // buffer and the inputs kept in registers between the two halves the loads had one period - about the HBM latency
+        // under load - and the whole block ran at the speed of its loads).  The post-activation inputs are not kept: each
+        // half image rebuilds them from the raw registers (prologue + two DPP moves per channel).
+        constexpr int NB = 2;
+        int fi_f0[NB], fi_nok[NB];
+        bool fi_edge_ok[NB];
 
-        unsigned rin[12][4], redge[12], ridx[12], ridx_e[12];
-        unsigned rsc[2] = {0u, 0u}, rsh[2] = {0u, 0u};
-        float d[12][6];
+        unsigned rin[NB][3][4][4], redge[NB][3][4], ridx[NB][3][4], ridx_e[NB][3][4];
+        u32x4_t rsc[NB], rsh[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) { rsc[n] = u32x4_t{0u, 0u, 0u, 0u}; rsh[n] = u32x4_t{0u, 0u, 0u, 0u}; fi_f0[n] = 0; fi_nok[n] = 0; fi_edge_ok[n] = false; }
 
-        auto load_chunk = [&]() __attribute__((always_inline)) {
+        auto load_chunk = [&](auto buf_c) __attribute__((always_inline)) {
+            constexpr int BUF = decltype(buf_c)::value;
             if (ld_ch == 0) {                                      // entering tile ld_k
                 int ct, sp;
                 item(ld_k, ct, sp);
@@ -137,119 +153,136 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
             const int tlim = pro ? sl : a.T;                       // Normalization re-masks its output (y*mask)
             const int tq = t0 + 4 * tile;                          // first output column of the tile = its input d1
             const int t_edge = tile == 0 ? t0 - 1 : t0 + 64;      // the outer element this lane loads itself (tiles 0 and 15)
-            fi_f0 = f0;
-            fi_nok = min(max(tlim - tq, 0), 4);                    // d1..d4 inside [0, tlim)  (zero padding is post-activation)
-            fi_edge_ok = edge_lane && t_edge >= 0 && t_edge < tlim;
+            fi_f0[BUF] = f0;
+            fi_nok[BUF] = min(max(tlim - tq, 0), 4);               // d1..d4 inside [0, tlim)  (zero padding is post-activation)
+            fi_edge_ok[BUF] = edge_lane && t_edge >= 0 && t_edge < tlim;
             const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(a.x) + (size_t)ld_b * clip_elems, 0, clip_elems * 4u, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
                 unpool ? const_cast<uint8_t*>(a.unpool_idx) + (size_t)ld_b * clip_elems : nullptr, 0, unpool ? clip_elems : 0u, 0x00020000);
-            const unsigned voff_c = (unsigned)(ld_ch * WX_CK + ic0) * 4u;
-            const unsigned chunk_elem0 = (unsigned)(ld_ch * WX_CK + ic0) * chan_step;
-            if (pro) {
-#pragma unroll
-                for (int cg = 0; cg < 2; ++cg) {
-                    rsc[cg] = __builtin_amdgcn_raw_buffer_load_b32(rs_sc, voff_c + cg * 64u, 0, 0);
-                    rsh[cg] = __builtin_amdgcn_raw_buffer_load_b32(rs_sh, voff_c + cg * 64u, 0, 0);
-                }
+            const unsigned cin0 = (unsigned)(ld_ch * WX_CK + 4 * cgp);
+            if (pro) {                                             // four consecutive channels: one 16-byte load each (Cin % 4 == 0 is not
+                rsc[BUF].x = __builtin_amdgcn_raw_buffer_load_b32(rs_sc, cin0 * 4u, 0, 0);          // required: element loads, range-checked)
+                rsc[BUF].y = __builtin_amdgcn_raw_buffer_load_b32(rs_sc, cin0 * 4u + 4u, 0, 0);
+                rsc[BUF].z = __builtin_amdgcn_raw_buffer_load_b32(rs_sc, cin0 * 4u + 8u, 0, 0);
+                rsc[BUF].w = __builtin_amdgcn_raw_buffer_load_b32(rs_sc, cin0 * 4u + 12u, 0, 0);
+                rsh[BUF].x = __builtin_amdgcn_raw_buffer_load_b32(rs_sh, cin0 * 4u, 0, 0);
+                rsh[BUF].y = __builtin_amdgcn_raw_buffer_load_b32(rs_sh, cin0 * 4u + 4u, 0, 0);
+                rsh[BUF].z = __builtin_amdgcn_raw_buffer_load_b32(rs_sh, cin0 * 4u + 8u, 0, 0);
+                rsh[BUF].w = __builtin_amdgcn_raw_buffer_load_b32(rs_sh, cin0 * 4u + 12u, 0, 0);
             }
 #pragma unroll
-            for (int j = 0; j < 12; ++j) {
-                const int ir = j % 6, cg = j / 6;
-                const int fin = f0 - 1 + ir;
+            for (int j = 0; j < 3; ++j) {
+                const int fin = f0 - 1 + 2 * j + rsel;
                 const bool row_ok = fin >= 0 && fin < a.F;
-                const unsigned row0 = chunk_elem0 + (unsigned)cg * 16u * chan_step + (unsigned)(unpool ? (fin >> 1) : fin) * row_elems;
-                const unsigned e1 = row_ok ? row0 + (unsigned)tq : (OOB >> 2);           // element index of d1
-                const unsigned ee = (row_ok && edge_lane) ? row0 + (unsigned)t_edge : (OOB >> 2);
-                const u32x4_t xv = __builtin_amdgcn_raw_buffer_load_b128(rs_x, e1 * 4u, 0, 0);
-                rin[j][0] = xv.x; rin[j][1] = xv.y; rin[j][2] = xv.z; rin[j][3] = xv.w;
-                if (unpool) ridx[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, e1 >= (OOB >> 2) ? OOB : e1, 0, 0);
-                redge[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, ee * 4u, 0, 0);
-                if (unpool) ridx_e[j] = __builtin_amdgcn_raw_buffer_load_b8(rs_i, ee >= (OOB >> 2) ? OOB : ee, 0, 0);
+                const unsigned row0 = cin0 * chan_step + (unsigned)(unpool ? (fin >> 1) : fin) * row_elems;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned e1 = row_ok ? row0 + (unsigned)c * chan_step + (unsigned)tq : (OOB >> 2);           // element index of d1
+                    const unsigned ee = (row_ok && edge_lane) ? row0 + (unsigned)c * chan_step + (unsigned)t_edge : (OOB >> 2);
+                    const u32x4_t xv = __builtin_amdgcn_raw_buffer_load_b128(rs_x, e1 * 4u, 0, 0);
+                    rin[BUF][j][c][0] = xv.x; rin[BUF][j][c][1] = xv.y; rin[BUF][j][c][2] = xv.z; rin[BUF][j][c][3] = xv.w;
+                    if (unpool) ridx[BUF][j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, e1 >= (OOB >> 2) ? OOB : e1, 0, 0);
+                    redge[BUF][j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, ee * 4u, 0, 0);
+                    if (unpool) ridx_e[BUF][j][c] = __builtin_amdgcn_raw_buffer_load_b8(rs_i, ee >= (OOB >> 2) ? OOB : ee, 0, 0);
+                }
             }
             if (++ld_ch == nChunks) { ld_ch = 0; ++ld_k; }
         };
-        // raw registers -> the six post-activation inputs of every item
-        auto finish_inputs = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < 12; ++j) {
-                const int ir = j % 6, cg = j / 6;
-                const int fin = fi_f0 - 1 + ir;
-                const int par = fin & 1;
-                const float sc = __uint_as_float(rsc[cg]), sh = __uint_as_float(rsh[cg]);
-                float v[4], ve = __uint_as_float(redge[j]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float u = __uint_as_float(rin[j][k]);
-                    if (unpool) u = (int)((ridx[j] >> (8 * k)) & 0xffu) != par ? 0.f : u;
-                    if (pro) {
-                        u = fmaf(u, sc, sh);
-                        if (a.relu) u = fmaxf(u, 0.f);
-                    }
-                    v[k] = k < fi_nok ? u : 0.f;
-                }
-                if (unpool) ve = (int)(ridx_e[j] & 0xffu) != par ? 0.f : ve;
-                if (pro) {
-                    ve = fmaf(ve, sc, sh);
-                    if (a.relu) ve = fmaxf(ve, 0.f);
-                }
-                ve = fi_edge_ok ? ve : 0.f;
-                // d0 = the left neighbour's last input, d5 = the right neighbour's first one
-                const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[3]), 0x111, 0xf, 0xf, true));    // row_shr:1
-                const float right = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[0]), 0x101, 0xf, 0xf, true));   // row_shl:1
-                const bool live = fin >= 0 && fin < a.F;          // a halo row outside the plane is zero AFTER the activation
-                d[j][0] = live ? (tile == 0 ? ve : left) : 0.f;
-                d[j][1] = live ? v[0] : 0.f; d[j][2] = live ? v[1] : 0.f; d[j][3] = live ? v[2] : 0.f; d[j][4] = live ? v[3] : 0.f;
-                d[j][5] = live ? (tile == 15 ? ve : right) : 0.f;
-            }
-        };
-        // V of three transform points -> LDS half image `half` (0: xi 0..2, 1: xi 3..5)
-        auto store_half = [&](auto half_c) __attribute__((always_inline)) {
-            constexpr int HALF = decltype(half_c)::value;
+        // raw registers of buffer BUF -> post-activation inputs -> V of three transform points -> LDS half image HALF
+        // (0: xi 0..2, 1: xi 3..5)
+        auto store_half = [&](auto half_c, auto buf_c) __attribute__((always_inline)) {
+            constexpr int HALF = decltype(half_c)::value, BUF = decltype(buf_c)::value;
+            const float scv[4] = {__uint_as_float(rsc[BUF].x), __uint_as_float(rsc[BUF].y), __uint_as_float(rsc[BUF].z), __uint_as_float(rsc[BUF].w)};
+            const float shv[4] = {__uint_as_float(rsh[BUF].x), __uint_as_float(rsh[BUF].y), __uint_as_float(rsh[BUF].z), __uint_as_float(rsh[BUF].w)};
             unsigned char* base = smem_raw + HALF * WX_HALF + lds_t;
 #pragma unroll
-            for (int j = 0; j < 12; ++j) {
-                const int ir = j % 6, cg = j / 6;
-                const float d0 = d[j][0], d1 = d[j][1], d2 = d[j][2], d3 = d[j][3], d4 = d[j][4], d5 = d[j][5];
-                float v[3];
-                if (HALF == 0) {
-                    v[0] = 4.f * d0 - 5.f * d2 + d4;
-                    v[1] = -4.f * (d1 + d2) + d3 + d4;
-                    v[2] = 4.f * (d1 - d2) - d3 + d4;
-                } else {
-                    v[0] = -2.f * d1 - d2 + 2.f * d3 + d4;
-                    v[1] = 2.f * d1 - d2 - 2.f * d3 + d4;
-                    v[2] = 4.f * d1 - 5.f * d3 + d5;
+            for (int j = 0; j < 3; ++j) {
+                const int fin = fi_f0[BUF] - 1 + 2 * j + rsel;
+                const int par = fin & 1;
+                const bool live = fin >= 0 && fin < a.F;          // a halo row outside the plane is zero AFTER the activation
+                float d[4][6];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float sc = scv[c], sh = shv[c];
+                    float v[4], ve = __uint_as_float(redge[BUF][j][c]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float u = __uint_as_float(rin[BUF][j][c][k]);
+                        if (unpool) u = (int)((ridx[BUF][j][c] >> (8 * k)) & 0xffu) != par ? 0.f : u;
+                        if (pro) {
+                            u = fmaf(u, sc, sh);
+                            if (a.relu) u = fmaxf(u, 0.f);
+                        }
+                        v[k] = (live && k < fi_nok[BUF]) ? u : 0.f;
+                    }
+                    if (unpool) ve = (int)(ridx_e[BUF][j][c] & 0xffu) != par ? 0.f : ve;
+                    if (pro) {
+                        ve = fmaf(ve, sc, sh);
+                        if (a.relu) ve = fmaxf(ve, 0.f);
+                    }
+                    ve = (live && fi_edge_ok[BUF]) ? ve : 0.f;
+                    // d0 = the left neighbour's last input, d5 = the right neighbour's first one
+                    const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[3]), 0x111, 0xf, 0xf, true));    // row_shr:1
+                    const float right = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[0]), 0x101, 0xf, 0xf, true));   // row_shl:1
+                    d[c][0] = tile == 0 ? ve : left;
+                    d[c][1] = v[0]; d[c][2] = v[1]; d[c][3] = v[2]; d[c][4] = v[3];
+                    d[c][5] = tile == 15 ? ve : right;
                 }
-                unsigned char* pj = base + (cg ? (swz0 ^ 32u) : swz0) + ir * 1024;
+                unsigned char* pj = base + j * 2048;
 #pragma unroll
                 for (int xl = 0; xl < 3; ++xl) {
-                    const unsigned u0 = __float_as_uint(v[xl]);
-                    const float r1 = v[xl] - __uint_as_float(u0 & 0xffff0000u);
-                    const unsigned u1 = __float_as_uint(r1);
-                    const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+                    unsigned hi[4], mid[4], lo[4];                      // bit patterns; the bf16 part is the upper half
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float d0 = d[c][0], d1 = d[c][1], d2 = d[c][2], d3 = d[c][3], d4 = d[c][4], d5 = d[c][5];
+                        const int x = HALF * 3 + xl;
+                        const float v = x == 0 ? 4.f * d0 - 5.f * d2 + d4
+                                      : x == 1 ? -4.f * (d1 + d2) + d3 + d4
+                                      : x == 2 ? 4.f * (d1 - d2) - d3 + d4
+                                      : x == 3 ? -2.f * d1 - d2 + 2.f * d3 + d4
+                                      : x == 4 ? 2.f * d1 - d2 - 2.f * d3 + d4
+                                               : 4.f * d1 - 5.f * d3 + d5;
+                        const unsigned u0 = __float_as_uint(v);
+                        const float r1 = v - __uint_as_float(u0 & 0xffff0000u);
+                        const unsigned u1 = __float_as_uint(r1);
+                        const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+                        hi[c] = u0; mid[c] = u1; lo[c] = __float_as_uint(r2);
+                    }
+                    // upper halves of (c0, c1) and (c2, c3) -> two dwords, channel c0 in the low half (v_perm_b32)
                     unsigned char* p = pj + xl * (WX_ROWS * 16 * 64);
-                    *reinterpret_cast<unsigned short*>(p) = (unsigned short)(u0 >> 16);
-                    *reinterpret_cast<unsigned short*>(p + WX_PART) = (unsigned short)(u1 >> 16);
-                    *reinterpret_cast<unsigned short*>(p + 2 * WX_PART) = (unsigned short)(__float_as_uint(r2) >> 16);
+                    *reinterpret_cast<uint2*>(p) = make_uint2(__builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u),
+                                                              __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u));
+                    *reinterpret_cast<uint2*>(p + WX_PART) = make_uint2(__builtin_amdgcn_perm(mid[1], mid[0], 0x07060302u),
+                                                                        __builtin_amdgcn_perm(mid[3], mid[2], 0x07060302u));
+                    *reinterpret_cast<uint2*>(p + 2 * WX_PART) = make_uint2(__builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u),
+                                                                            __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u));
                 }
             }
         };
 
-        load_chunk();
-        finish_inputs();
-        if (G > 1) load_chunk();
-        store_half(std::integral_constant<int, 0>{});
+        constexpr bool P_LD = !(WX_DBG & 1), P_ST = !(WX_DBG & 2);
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        // chunk c of the stream lives in raw buffer c % 2
+        if (P_LD) load_chunk(I0{});
+        if (G > 1 && P_LD) load_chunk(I1{});
+        if (P_ST) store_half(I0{}, I0{});
         __syncthreads();
-        for (int g = 0; g < G; ++g) {
-            store_half(std::integral_constant<int, 1>{});              // consumers: xi 0..2 of chunk g
+        // one chunk of the stream: second half image of chunk g (raw buffer CUR), its buffer re-loaded with chunk g + 2, then -
+        // while the consumers multiply that half - the first half image of chunk g + 1 from the other buffer
+        auto step = [&](int g, auto cur_c, auto nxt_c) __attribute__((always_inline)) {
+            using CUR = decltype(cur_c);
+            using NXT = decltype(nxt_c);
+            if (P_ST) store_half(I1{}, CUR{});                          // consumers: xi 0..2 of chunk g
+            if (g + 2 < G && P_LD) load_chunk(CUR{});
             __syncthreads();
-            if (g + 1 < G) {                                            // consumers: xi 3..5 of chunk g (then, at a tile's end, its epilogue)
-                finish_inputs();
-                if (g + 2 < G) load_chunk();
-                store_half(std::integral_constant<int, 0>{});
-            }
+            if (g + 1 < G && P_ST) store_half(I0{}, NXT{});             // consumers: xi 3..5 of chunk g (then, at a tile's end, its epilogue)
             __syncthreads();
+        };
+        for (int g = 0; g < G; g += 2) {
+            step(g, I0{}, I1{});
+            if (g + 1 < G) step(g + 1, I1{}, I0{});
         }
         return;
     }
@@ -309,7 +342,8 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
                 for (int xl = 0; xl < 3; ++xl) {
                     const int x = half * 3 + xl;
                     // U of the next point into the slot the previous point left
-                    load_A((x + 1) % WX_RING, x + 1 < 6 ? soff_u + (unsigned)(x + 1) * point_bytes : soff_next);
+                    if (!(WX_DBG & 4)) load_A((x + 1) % WX_RING, x + 1 < 6 ? soff_u + (unsigned)(x + 1) * point_bytes : soff_next);
+                    if (WX_DBG & 8) continue;
 #pragma unroll
                     for (int h = 0; h < WX_ROWS; ++h) {
                         const int cur = (xl * WX_ROWS + h) & 1;
@@ -469,9 +503,12 @@ static int launch_winox3(const ConvFwdArgs& a, hipStream_t s) {
     if ((size_t)18 * a.CinP * a.CoutP * 6 >= (1ull << 31)) { set_error("conv_winox3: packed weights exceed 2 GiB"); return PBSED_E_ARG; }
     const int nTt = (a.T + WX_TT - 1) / WX_TT, nFt = (a.F + WX_FT - 1) / WX_FT;
     const int nSp = nTt * nFt * a.B, nCt = a.CoutP / WX_CT;
-    const int xcd_map = (nCt <= 8 && 8 % nCt == 0) ? 1 : 0;
-    const int per = xcd_map ? 8 / nCt : 1;
-    const int nWork = xcd_map ? (nSp + per - 1) / per * 8 : nSp * nCt;
+    static const int map_env = getenv("PBSED_WX_MAP") ? atoi(getenv("PBSED_WX_MAP")) : 2;
+    int xcd_map = map_env, nWork;
+    if (xcd_map == 1 && !(nCt <= 8 && 8 % nCt == 0)) xcd_map = 0;
+    if (xcd_map == 1) nWork = (nSp + 8 / nCt - 1) / (8 / nCt) * 8;
+    else if (xcd_map == 2) nWork = (nSp + 7) / 8 * 8 * nCt;
+    else nWork = nSp * nCt;
     if (a.T & 3) { set_error("conv_winox3: T = %d is not a multiple of 4 (rows must be 16-byte aligned; use the fp32 Winograd kernel)", a.T); return PBSED_E_UNSUPPORTED; }
     // persistent blocks, one per CU (110 KB of LDS each), a multiple of 8 so that an item's XCD is its block's XCD
     static int n_cu_dev[64] = {0};
