@@ -12,6 +12,8 @@
 // atomics into the [Cout,Cin,KH,KW] gradient (the bias gradient is one extra MFMA against ones).
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "common.h"
 #include "pbsed_internal.h"
 
@@ -339,6 +341,9 @@ static int launch_wgrad_cfg(Kern kern, const ConvWgradArgs& a_in, hipStream_t s)
     const int cap = (slot_ok ? slot_cap : 1024) / (gy * gz);                              // atomics-per-address cap
     if (split > cap) split = cap > 0 ? cap : 1;
     if (split > nChunks) split = nChunks;
+    if constexpr (C::FT == 1 && C::TT == 32 && C::NT == 512) {        // column-walking kernels split over (clip, column) units
+        if (split > a.B * nTt) split = a.B * nTt;
+    }
     dim3 grid(split, gy, gz);
     float* scratch = (slot_ok && split >= 4 * WGRAD_SLOTS) ? wgrad_slot_scratch() : nullptr;
     if (scratch) {
@@ -815,6 +820,20 @@ __global__ __launch_bounds__(MH * 128) void conv_wgrad_bf16_kernel(ConvWgradArgs
                     if (KW == 1) {
 #pragma unroll
                         for (int m = 0; m < 2; ++m) acc[m][kh] = prod(af[m], c, acc[m][kh]);
+                    } else if constexpr (NS == 3) {
+                        // the six part products of the six (m, kw) accumulators of this kernel row round-robin, smallest
+                        // first: consecutive MFMAs never wait for each other's accumulator
+#pragma unroll
+                        for (int pp = 0; pp < 6; ++pp) {
+                            const int pa = pp == 0 ? 2 : pp == 1 ? 0 : pp == 2 ? 1 : pp == 3 ? 1 : 0;     // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+                            const int pb = pp == 0 ? 0 : pp == 1 ? 2 : pp == 2 ? 1 : pp == 3 ? 0 : pp == 4 ? 1 : 0;
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) {
+                                acc[m][kh * KW + 0] = wg_mfma(af[m][pa], left[pb], acc[m][kh * KW + 0]);
+                                acc[m][kh * KW + 1] = wg_mfma(af[m][pa], c[pb], acc[m][kh * KW + 1]);
+                                acc[m][kh * KW + 2] = wg_mfma(af[m][pa], right[pb], acc[m][kh * KW + 2]);
+                            }
+                        }
                     } else {
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
@@ -871,6 +890,367 @@ __global__ __launch_bounds__(MH * 128) void conv_wgrad_bf16_kernel(ConvWgradArgs
     }
 }
 
+// ============================================================================================
+// 3x3 weight gradient of the fp32 path on the bf16 MFMA with exact three-way operand splits, PRODUCER / CONSUMER form.
+// Same arithmetic as conv_wgrad_bf16_kernel<3, 3, *, 3> (M = cout, N = cin, K = 32 consecutive t of one row; six part products
+// per product, fp32 accumulation: fp32-class gradients), but the staging no longer alternates with the MFMAs: four producer
+// waves build the three-part LDS images one step ahead (global loads two steps ahead; un-pool / BN-apply + ReLU + mask;
+// splits; 8-byte LDS stores) while four consumer waves - one per SIMD, 32 cout x 32 cin x 9 taps = 144 accumulator registers
+// each - multiply; one block barrier per step.
+// A block walks COLUMNS: for a fixed (clip, 32-t range) the steps run down the rows f = 0 .. F-1, so an x row is loaded and
+// split ONCE and used by the three kernel rows of three consecutive steps (ring of four row slots + one all-zero slot for
+// the rows above / below the plane); dY of a step is double-buffered.  What a step pulls from L2 is then 128 dY rows + 32 x
+// rows of 128 / 192 bytes instead of 128 + 96: these scattered 16-byte-per-lane loads cost the CU's texture path ~60 clocks
+// each whatever they hit (an ablation that re-reads one cached chunk is no faster), which is what bounded the
+// chunk-at-a-time form of this kernel.
+// Operand images are t-innermost as in the bf16 kernel: dY rows are 64 bytes with XOR-swizzled 16-byte groups, x rows
+// [cin][48 t] with a 112-byte channel stride (16 bytes mod 128), so every fragment is one conflict-free ds_read_b128 per
+// part; the kw = 0 / 2 operands are the centre operand shifted by one element in registers - the two elements a shift pulls
+// in from outside the lane's 8 (x[8j - 1], x[8j + 8]) sit packed in one dword of a small side array with an odd dword
+// stride per channel (read straight from the row image they are 8-way bank conflicts: every channel row starts on the
+// same 4 banks).
+// Why not the Winograd form here: its operands are 6/4 as large per part and are read once per transform point and kernel
+// row - at bf16x3 rates that kernel is bound by LDS bytes, this one by the MFMA pipe.
+// ============================================================================================
+#ifndef WGPC_DBG
+#define WGPC_DBG 0          // ablation switches of tools/kernel_ablation.sh (never set in the product build)
+#endif
+template <int WM, int WN>
+struct WgradPcCfg {
+    static constexpr int FT = 1, TT = 32, KK = 9, NT = 512;
+    static constexpr int COUT_T = WM * 32, CIN_T = WN * 32;
+    static constexpr int XCH = 112;                                      // bytes: channel stride of an x row slot (48 t + 16)
+    static constexpr int DY_PART = COUT_T * 64, X_PART = CIN_T * XCH;   // bytes per operand part
+    static constexpr int XB_CH = 20, XB_PART = CIN_T * XB_CH;            // boundary words: per channel 4 dwords {x[8j - 1], x[8j + 8]} (+ 1 pad:
+    static constexpr int DY_STAGE = 3 * DY_PART, X_SLOT = 3 * (X_PART + XB_PART);   // odd dword stride = conflict-free 4-byte reads)
+    static constexpr int X_BASE = 2 * DY_STAGE;                         // LDS: dY stage 0, dY stage 1, x slots 0..3, zero slot
+    static constexpr int LDS_MAIN = X_BASE + 5 * X_SLOT;
+    static constexpr int DY_ITEMS = COUT_T * 8, X_ITEMS = CIN_T * 12;    // 4-element quads per step
+    static constexpr int DY_PER_T = (DY_ITEMS + 255) / 256, X_PER_T = (X_ITEMS + 255) / 256;
+    static constexpr int OUT_ROW = CIN_T * KK + 1, OUT_ROWS = 64;
+    static constexpr int LDS_FLOATS = cmax((LDS_MAIN + 3) / 4, OUT_ROWS * OUT_ROW);
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
+    using C = WgradPcCfg<WM, WN>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    const int lq = lane >> 4, lr = lane & 15;
+    const int cin0 = blockIdx.y * C::CIN_T, cout0 = blockIdx.z * C::COUT_T;
+    const int nTt = (a.T + C::TT - 1) / C::TT;
+    const int nCols = a.B * nTt;                                         // columns = (clip, 32-t range); the launcher's chunks = columns x rows
+    const bool pro = a.scale != nullptr;
+    const bool unpool = a.unpool_idx != nullptr;
+    const int Fg = unpool ? a.F / 2 : a.F;
+    const int wmi = wave / WN, wni = wave % WN;                          // consumer wave -> (32-cout group, 32-cin group)
+    const bool do_bias = (a.db != nullptr) && (blockIdx.y == 0) && wni == 0;
+    // columns of this block: blockIdx.x, + gridDim.x, ..; its steps run through them row by row
+    int nColMine = 0;
+    if ((int)blockIdx.x < nCols) nColMine = (nCols - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+    const int nSteps = nColMine * a.F;
+
+    f32x4 acc[2][2][9], accb[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[m][n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // the all-zero x slot (rows above / below the plane)
+    for (int i = tid; i < C::X_SLOT / 16; i += 512)
+        reinterpret_cast<u32x4_t*>(lds + C::X_BASE + 4 * C::X_SLOT)[i] = u32x4_t{0u, 0u, 0u, 0u};
+
+    if (!consumer && nSteps > 0) {
+        // ================================================================ PRODUCER
+        const int pt = tid - 256;
+        constexpr unsigned OOB = 0x20000000u;            // element offset beyond every clip (x 4 = 2^31 bytes)
+        const unsigned gclip = (unsigned)(a.Cout * Fg * a.T), xclip = (unsigned)(a.Cin * a.F * a.T);
+        const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.scale), 0, pro ? (unsigned)a.Cin * 4u : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.shift), 0, pro ? (unsigned)a.Cin * 4u : 0u, 0x00020000);
+        // per-thread item constants (computed once: the step loop only adds a uniform offset and selects, no divisions and no
+        // divergent branches): dY item i = (cout row, quad of 8), x item i = (cin, quad of 12)
+        int y_q[C::DY_PER_T], y_valid[C::DY_PER_T];
+        unsigned y_lds[C::DY_PER_T], y_base[C::DY_PER_T];
+#pragma unroll
+        for (int i = 0; i < C::DY_PER_T; ++i) {
+            const int it = pt + i * 256, cl = it >> 3;
+            y_q[i] = it & 7;
+            const int row = cl & 15;
+            y_lds[i] = (unsigned)(cl * 64 + ((((y_q[i] >> 1) ^ ((-(row >> 2)) & 3)) & 3) * 16) + (y_q[i] & 1) * 8);
+            y_valid[i] = (it < C::DY_ITEMS) & (cout0 + cl < a.Cout);
+            y_base[i] = (unsigned)((cout0 + cl) * Fg * a.T + 4 * y_q[i]);
+        }
+        int x_q[C::X_PER_T], x_valid[C::X_PER_T], x_item[C::X_PER_T];
+        unsigned x_lds[C::X_PER_T], x_bnd[C::X_PER_T];
+        int x_base[C::X_PER_T];
+        float x_sc[C::X_PER_T], x_sh[C::X_PER_T];
+#pragma unroll
+        for (int i = 0; i < C::X_PER_T; ++i) {
+            const int it = pt + i * 256, cl = it / 12;
+            x_q[i] = it % 12;
+            x_lds[i] = (unsigned)(cl * C::XCH + x_q[i] * 8);
+            x_bnd[i] = (unsigned)(cl * C::XB_CH);
+            x_item[i] = it < C::X_ITEMS;
+            x_valid[i] = x_item[i] & (cin0 + cl < a.Cin);
+            x_base[i] = (cin0 + cl) * a.F * a.T + 4 * x_q[i] - 8;
+            const bool ok = x_valid[i] && pro;
+            x_sc[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_sc, ok ? (unsigned)(cin0 + cl) * 4u : 0x80000000u, 0, 0));
+            x_sh[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_sh, ok ? (unsigned)(cin0 + cl) * 4u : 0x80000000u, 0, 0));
+        }
+        constexpr int NB = 2;                              // raw register sets = steps whose loads are in flight
+        u32x4_t ry[NB][C::DY_PER_T], rx[NB][C::X_PER_T];
+        unsigned ryi[NB][C::DY_PER_T];
+        int ry_n[NB][C::DY_PER_T], rx_n[NB][C::X_PER_T], r_par[NB];
+
+        // step S of the block = (column S / F of its list, row S % F).  Raw set S % 2 holds what is staged DURING step S - 1 ..
+        // the dY tile of step S and the x row of step S + 1 (x row g lives in ring slot g % 4; rows 0 and 1 of the stream are
+        // staged in the prologue): load_pair(S) issues the loads of {dY of step S, x row of step S + 1}.
+        auto locate = [&](int S, int& b, int& f, int& t0) __attribute__((always_inline)) {
+            const int col = (int)blockIdx.x + (S / a.F) * (int)gridDim.x;
+            f = S % a.F; b = col / nTt; t0 = (col % nTt) * C::TT;
+        };
+        auto load_dy = [&](int S, auto buf_c) __attribute__((always_inline)) {
+            constexpr int BUF = decltype(buf_c)::value;
+            int b, f, t0;
+            locate(S, b, f, t0);
+            const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a.g) + (size_t)b * gclip, 0, gclip * 4u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
+                unpool ? const_cast<uint8_t*>(a.unpool_idx) + (size_t)b * gclip : nullptr, 0, unpool ? gclip : 0u, 0x00020000);
+            r_par[BUF] = f & 1;
+            const unsigned y_row = (unsigned)((unpool ? (f >> 1) : f) * a.T + t0);
+#pragma unroll
+            for (int i = 0; i < C::DY_PER_T; ++i) {
+                const int tq = t0 + 4 * y_q[i];
+                // branch-free selects (as ?: the compiler forks into two load sites that must wait for each other)
+                const unsigned ok = (unsigned)-(y_valid[i] & (tq < a.T));
+                const unsigned off = ((y_base[i] + y_row) & ok) | (OOB & ~ok);
+                ry[BUF][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, off * 4u, 0, 0);
+                if (unpool) ryi[BUF][i] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, off, 0, 0);
+                ry_n[BUF][i] = (int)((unsigned)min(a.T - tq, 4) & ok);
+            }
+        };
+        auto load_x = [&](int S, auto buf_c) __attribute__((always_inline)) {       // the x row of step S (its centre row f)
+            constexpr int BUF = decltype(buf_c)::value;
+            int b, f, t0;
+            locate(S, b, f, t0);
+            const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
+            const int tlim = pro ? sl : a.T;
+            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a.x) + (size_t)b * xclip, 0, xclip * 4u, 0x00020000);
+            const int x_row = f * a.T + t0;
+#pragma unroll
+            for (int i = 0; i < C::X_PER_T; ++i) {
+                const int tq = t0 - 8 + 4 * x_q[i];
+                const unsigned ok = (unsigned)-(x_valid[i] & (tq >= 0) & (tq < a.T));
+                const unsigned off = ((unsigned)(x_base[i] + x_row) & ok) | (OOB & ~ok);
+                rx[BUF][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off * 4u, 0, 0);
+                rx_n[BUF][i] = (int)((unsigned)min(max(tlim - tq, 0), 4) & ok);
+            }
+        };
+        auto put = [&](unsigned char* p, int part_bytes, const float (&v)[4]) __attribute__((always_inline)) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            split3_pair(v[0], v[1], h0, m0, l0);
+            split3_pair(v[2], v[3], h1, m1, l1);
+            *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(p + part_bytes) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(p + 2 * part_bytes) = make_uint2(l0, l1);
+        };
+        auto store_dy = [&](int stage, auto buf_c) __attribute__((always_inline)) {
+            constexpr int BUF = decltype(buf_c)::value;
+            unsigned char* dy_s = lds + stage * C::DY_STAGE;
+#pragma unroll
+            for (int i = 0; i < C::DY_PER_T; ++i) {
+                if (C::DY_ITEMS % 256 == 0 || pt + i * 256 < C::DY_ITEMS) {
+                    const u32x4_t r = ry[BUF][i];
+                    float v[4] = {__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bool keep = e < ry_n[BUF][i];
+                        if (unpool) keep = keep && (int)((ryi[BUF][i] >> (8 * e)) & 0xffu) == r_par[BUF];
+                        v[e] = keep ? v[e] : 0.f;
+                    }
+                    put(dy_s + y_lds[i], C::DY_PART, v);
+                }
+            }
+        };
+        auto store_x = [&](int slot, auto buf_c) __attribute__((always_inline)) {
+            constexpr int BUF = decltype(buf_c)::value;
+            unsigned char* x_s = lds + C::X_BASE + slot * C::X_SLOT;
+#pragma unroll
+            for (int i = 0; i < C::X_PER_T; ++i) {
+                if (x_item[i]) {
+                    const u32x4_t r = rx[BUF][i];
+                    float v[4] = {__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (pro) {
+                            v[e] = fmaf(v[e], x_sc[i], x_sh[i]);
+                            if (a.relu) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        v[e] = e < rx_n[BUF][i] ? v[e] : 0.f;            // zero padding is post-activation
+                    }
+                    put(x_s + x_lds[i], C::X_PART, v);
+                    // boundary words: quad 1 + 2 j ends with x[8 j - 1] (low half of word j), quad 4 + 2 j starts with x[8 j + 8]
+                    // (high half of word j); relative to the row image the centre starts at element 8
+                    const int q = x_q[i];
+                    const bool lo_w = (q & 1) && q <= 7, hi_w = !(q & 1) && q >= 4 && q <= 10;
+                    if (lo_w || hi_w) {
+                        const float bv = lo_w ? v[3] : v[0];
+                        const int j = lo_w ? (q - 1) >> 1 : (q - 4) >> 1;
+                        const unsigned u0 = __float_as_uint(bv);
+                        const float r1 = bv - __uint_as_float(u0 & 0xffff0000u);
+                        const unsigned u1 = __float_as_uint(r1);
+                        const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+                        unsigned char* pb = x_s + 3 * C::X_PART + x_bnd[i] + j * 4 + (hi_w ? 2 : 0);
+                        *reinterpret_cast<unsigned short*>(pb) = (unsigned short)(u0 >> 16);
+                        *reinterpret_cast<unsigned short*>(pb + C::XB_PART) = (unsigned short)(u1 >> 16);
+                        *reinterpret_cast<unsigned short*>(pb + 2 * C::XB_PART) = (unsigned short)(__float_as_uint(r2) >> 16);
+                    }
+                }
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        constexpr bool P_LD = !(WGPC_DBG & 1), P_ST = !(WGPC_DBG & 2);
+        // prologue: x rows 0 and 1, dY of step 0 staged; the loads of {dY 1, x row 2} in flight
+        if (P_LD) { load_dy(0, I0{}); load_x(0, I0{}); }
+        if (nSteps > 1 && P_LD) load_x(1, I1{});
+        if (P_ST) { store_dy(0, I0{}); store_x(0, I0{}); }
+        if (nSteps > 1 && P_ST) store_x(1, I1{});
+        if (nSteps > 1 && P_LD) load_dy(1, I1{});
+        if (nSteps > 2 && P_LD) load_x(2, I1{});
+        if (nSteps > 2 && P_LD) load_dy(2, I0{});
+        if (nSteps > 3 && P_LD) load_x(3, I0{});
+        __syncthreads();
+        // during step S (consumers: dY stage S % 2, x rows S - 1, S, S + 1): stage dY of step S + 1 and x row S + 2 from raw set
+        // (S + 1) % 2, then re-load that set with {dY of step S + 3, x row S + 4}
+        auto stage_step = [&](int S, auto buf_c) __attribute__((always_inline)) {
+            using BUF = decltype(buf_c);
+            if (S + 1 < nSteps && P_ST) store_dy((S + 1) & 1, BUF{});
+            if (S + 2 < nSteps && P_ST) store_x((S + 2) & 3, BUF{});
+            if (S + 3 < nSteps && P_LD) load_dy(S + 3, BUF{});
+            if (S + 4 < nSteps && P_LD) load_x(S + 4, BUF{});
+            __syncthreads();
+        };
+        for (int S = 0; S < nSteps; S += 2) {
+            stage_step(S, I1{});
+            if (S + 1 < nSteps) stage_step(S + 1, I0{});
+        }
+    } else if (nSteps > 0) {
+        // ================================================================ CONSUMER
+        const u32x4_t ones = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+        const unsigned a_lane = (unsigned)(lr * 64 + (((lq ^ ((-(lr >> 2)) & 3)) & 3) * 16));     // dY fragment: row lr, t group lq
+        const unsigned b_lane = (unsigned)(lr * C::XCH + 16 + lq * 16);                            // x fragment: cin lr, t = 8 lq .. + 7 of the centre
+        const unsigned bnd_lane = (unsigned)(lr * C::XB_CH + lq * 4);                              // its boundary word
+        auto step = [&](int S) __attribute__((always_inline)) {
+            const int f = S % a.F;
+            const unsigned char* dy_s = lds + (S & 1) * C::DY_STAGE;
+            // x rows f - 1, f, f + 1 of this column: ring slots (S - 1, S, S + 1) % 4, the zero slot outside the plane
+            unsigned xoff[3];
+            xoff[0] = (unsigned)(C::X_BASE + (f > 0 ? ((S - 1) & 3) : 4) * C::X_SLOT);
+            xoff[1] = (unsigned)(C::X_BASE + (S & 3) * C::X_SLOT);
+            xoff[2] = (unsigned)(C::X_BASE + (f + 1 < a.F ? ((S + 1) & 3) : 4) * C::X_SLOT);
+            u32x4_t af[2][3];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[m][p] = *reinterpret_cast<const u32x4_t*>(dy_s + p * C::DY_PART + ((wmi * 2 + m) * 16) * 64 + a_lane);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const unsigned char* x_s = lds + xoff[kh];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    u32x4_t c[3], left[3], right[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const unsigned char* row = x_s + p * C::X_PART + ((wni * 2 + n) * 16) * C::XCH + b_lane;
+                        c[p] = *reinterpret_cast<const u32x4_t*>(row);
+                        // {x[t - 1] (low half), x[t + 8] (high half)} of this lane's 8-element group
+                        const unsigned w = *reinterpret_cast<const unsigned*>(x_s + 3 * C::X_PART + p * C::XB_PART +
+                                                                                 ((wni * 2 + n) * 16) * C::XB_CH + bnd_lane);
+                        const unsigned s1 = __builtin_amdgcn_alignbit(c[p].y, c[p].x, 16), s2 = __builtin_amdgcn_alignbit(c[p].z, c[p].y, 16),
+                                       s3 = __builtin_amdgcn_alignbit(c[p].w, c[p].z, 16);
+                        left[p] = u32x4_t{__builtin_amdgcn_perm(c[p].x, w, 0x05040100u), s1, s2, s3};     // x[t-1 .. t+6]
+                        right[p] = u32x4_t{s1, s2, s3, __builtin_amdgcn_perm(w, c[p].w, 0x07060302u)};    // x[t+1 .. t+8]
+                    }
+                    // six part products of the six (m, kw) accumulators round-robin, smallest first
+#pragma unroll
+                    for (int pp = 0; pp < 6; ++pp) {
+                        const int pa = pp == 0 ? 2 : pp == 1 ? 0 : pp == 2 ? 1 : pp == 3 ? 1 : 0;     // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+                        const int pb = pp == 0 ? 0 : pp == 1 ? 2 : pp == 2 ? 1 : pp == 3 ? 0 : pp == 4 ? 1 : 0;
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            acc[m][n][kh * 3 + 0] = wg_mfma(af[m][pa], left[pb], acc[m][n][kh * 3 + 0]);
+                            acc[m][n][kh * 3 + 1] = wg_mfma(af[m][pa], c[pb], acc[m][n][kh * 3 + 1]);
+                            acc[m][n][kh * 3 + 2] = wg_mfma(af[m][pa], right[pb], acc[m][n][kh * 3 + 2]);
+                        }
+                    }
+                }
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) accb[m] = wg_mfma(af[m][2 - p], ones, accb[m]);
+            }
+        };
+        __syncthreads();                                                 // the prologue's images are in place
+        for (int S = 0; S < nSteps; ++S) {
+            if (!(WGPC_DBG & 8)) step(S);
+            __syncthreads();
+        }
+    }
+
+    // ---- reduce: transpose the block's partial dW through LDS, then row-contiguous atomics (as conv_wgrad_bf16_kernel)
+    __syncthreads();
+    float* out_s = smem;                             // [OUT_ROWS][OUT_ROW]
+    const int ncol = min(C::CIN_T, a.Cin - cin0) * 9;
+    const int slot = a.nslots > 1 ? (int)(blockIdx.x % a.nslots) : 0;
+    float* dwp = a.dw + (size_t)slot * a.slot_w;
+#pragma unroll 1
+    for (int part = 0; part < (C::COUT_T + C::OUT_ROWS - 1) / C::OUT_ROWS; ++part) {
+        if (part > 0) __syncthreads();
+        if (consumer && (wmi * 32) / C::OUT_ROWS == part) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int kk = 0; kk < 9; ++kk)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            out_s[((wmi * 32) % C::OUT_ROWS + m * 16 + lq * 4 + r) * C::OUT_ROW + ((wni * 2 + n) * 16 + lr) * 9 + kk] = acc[m][n][kk][r];
+        }
+        __syncthreads();
+        for (int row = wave; row < C::OUT_ROWS; row += 8) {
+            const int cout = cout0 + part * C::OUT_ROWS + row;
+            if (cout >= a.Cout || part * C::OUT_ROWS + row >= C::COUT_T) break;
+            float* dst = dwp + ((size_t)cout * a.Cin + cin0) * 9;
+            for (int col = lane; col < ncol; col += 64) atomicAdd(dst + col, out_s[row * C::OUT_ROW + col]);
+        }
+    }
+    if (consumer && do_bias && lr == 0) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cout = cout0 + (wmi * 2 + m) * 16 + lq * 4 + r;
+                if (cout < a.Cout) atomicAdd(&a.db[(size_t)slot * a.slot_b + cout], accb[m][r]);
+            }
+    }
+}
+
 int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     if (a.unpool_idx && (a.F % 2)) { set_error("conv_wgrad: unpool needs even F"); return PBSED_E_ARG; }
     // the loaders address one clip with 32-bit element offsets (buffer loads; 2^29 elements marks "out of range")
@@ -889,8 +1269,21 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     // products per product): far fewer operand bytes per MFMA than the Winograd form, whose transformed operands are 6/4 as
     // large per part (PBSED_WGRAD_X3: 0 = off, 1 = 128-cout blocks one row tall above 64 channels, 2 = 64-cout blocks)
     static const int x3_2d = getenv("PBSED_WGRAD_X3") ? atoi(getenv("PBSED_WGRAD_X3")) : 0;
+    // producer / consumer column-walking form (default for the layers with >= 64 input and output channels, where it is ahead
+    // of the fp32 Winograd kernel: 128->128 0.374 vs 0.432 ms, 128->256 0.357 vs 0.419, 64->128 0.220 vs 0.240, 64->64 0.243 vs
+    // 0.258): 64 cout x 64 cin blocks; PBSED_WGRAD_PC=0 switches it off, PBSED_WGRAD_X3=4 forces it (128 x 32 blocks) from 32
+    // channels on
+    static const bool pc_on = getenv("PBSED_WGRAD_PC") ? atoi(getenv("PBSED_WGRAD_PC")) != 0 : true;
+    if (!a.bf16 && KH == 3 && KW == 3 && (a.T & 3) == 0) {
+        if (pc_on && x3_2d == 0 && a.Cin >= 64 && a.Cout >= 64) return launch_wgrad_cfg<WgradPcCfg<2, 2>>(conv_wgrad_pc_kernel<2, 2>, a, s);
+        if (x3_2d >= 4 && a.Cin >= 32 && a.Cout >= 32) {
+            if ((a.Cout <= 64 || x3_2d == 5) && a.Cin >= 64) return launch_wgrad_cfg<WgradPcCfg<2, 2>>(conv_wgrad_pc_kernel<2, 2>, a, s);
+            return launch_wgrad_cfg<WgradPcCfg<4, 1>>(conv_wgrad_pc_kernel<4, 1>, a, s);
+        }
+    }
     if (!a.bf16 && x3_2d && KH == 3 && KW == 3 && a.Cin >= 32 && a.Cout >= 32) {
         if (x3_2d == 1 && a.Cout > 64) return launch_wgrad_cfg<WgradB16Cfg<3, 3, 4, 3, 1>>(conv_wgrad_bf16_kernel<3, 3, 4, 3, 1>, a, s);
+        if (x3_2d == 3) return launch_wgrad_cfg<WgradB16Cfg<3, 3, 2, 3, 1>>(conv_wgrad_bf16_kernel<3, 3, 2, 3, 1>, a, s);   // 75 KB: two blocks per CU
         return launch_wgrad_cfg<WgradB16Cfg<3, 3, 2, 3>>(conv_wgrad_bf16_kernel<3, 3, 2, 3>, a, s);
     }
     if (a.bf16 && a.Cin >= 32 && a.Cout >= 32) {       // bf16-MFMA operands (config 3); few-channel layers stay on the fp32 kernels

@@ -42,7 +42,7 @@ constexpr int WX_PART = 3 * WX_ROWS * 16 * 64;          // bytes of one part of 
 constexpr int WX_HALF = 3 * WX_PART;                    // 55 296
 constexpr int WX_V_BYTES = 2 * WX_HALF;
 #ifndef WX_DBG
-#define WX_DBG 0            // ablation switches of tools/winox3_ablation.sh (never set in the product build)
+#define WX_DBG 0            // ablation switches of tools/kernel_ablation.sh (never set in the product build)
 #endif
 constexpr int WX_RING = 2;                              // U register ring in transform points (3 kh x 3 parts x 16 B per lane each)
 
@@ -81,6 +81,12 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
             const int xcd = w & 7, l = w >> 3;     // HBM once and found in that XCD's L2 by the others (and so are the halo rows of
             ct = l % nCt;                          // the row tile above / below when the row has 8 column tiles)
             sp = (l / nCt) * 8 + xcd;
+        } else if (xcd_map == 3) {                 // an XCD takes whole CLIPS (b % 8 = XCD) and all cout tiles of a spatial tile side
+            const int xcd = w & 7, l = w >> 3;     // by side: the cache lines neighbouring column tiles share, the halo rows of the row
+            ct = l % nCt;                          // tiles above / below and x for the other cout tiles are all found in that XCD's L2
+            const int spl = l / nCt, per = nTt * nFt;
+            const int b = (spl / per) * 8 + xcd;
+            sp = b < a.B ? b * per + spl % per : nSp;
         } else {
             ct = w % nCt;
             sp = w / nCt;
@@ -503,10 +509,12 @@ static int launch_winox3(const ConvFwdArgs& a, hipStream_t s) {
     if ((size_t)18 * a.CinP * a.CoutP * 6 >= (1ull << 31)) { set_error("conv_winox3: packed weights exceed 2 GiB"); return PBSED_E_ARG; }
     const int nTt = (a.T + WX_TT - 1) / WX_TT, nFt = (a.F + WX_FT - 1) / WX_FT;
     const int nSp = nTt * nFt * a.B, nCt = a.CoutP / WX_CT;
-    static const int map_env = getenv("PBSED_WX_MAP") ? atoi(getenv("PBSED_WX_MAP")) : 2;
+    static const int map_env = getenv("PBSED_WX_MAP") ? atoi(getenv("PBSED_WX_MAP")) : 3;
     int xcd_map = map_env, nWork;
     if (xcd_map == 1 && !(nCt <= 8 && 8 % nCt == 0)) xcd_map = 0;
+    if (xcd_map == 3 && a.B < 8) xcd_map = 2;
     if (xcd_map == 1) nWork = (nSp + 8 / nCt - 1) / (8 / nCt) * 8;
+    else if (xcd_map == 3) nWork = (a.B + 7) / 8 * nTt * nFt * nCt * 8;
     else if (xcd_map == 2) nWork = (nSp + 7) / 8 * 8 * nCt;
     else nWork = nSp * nCt;
     if (a.T & 3) { set_error("conv_winox3: T = %d is not a multiple of 4 (rows must be 16-byte aligned; use the fp32 Winograd kernel)", a.T); return PBSED_E_UNSUPPORTED; }

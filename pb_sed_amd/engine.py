@@ -686,6 +686,9 @@ def _features(fe, raw_fn, seq_dev, seq_host, n_frames):
 
 def features_from_audio(fe, audio, seq_dev, n_frames, seq_host=None, pad_front=320, frame_pos=None):
     """``frame_pos`` [B, n_frames] int32: time-warped framing (pb_sed_amd/data.py::TimeWarp)."""
+    if not getattr(fe, 'fused_waveform_frontend', True):
+        raise NotImplementedError(f'the fused waveform front-end is built for STFT 1024 / 960 / 320, not {fe.stft_size} / '
+                                  f"{fe.window_length} / {fe.shift}: hand the model inputs['stft'] (pbsed_logmel_from_stft)")
     tables = _tables(fe, audio.device)
     if seq_host is None:
         seq_host = seq_dev.cpu().numpy()

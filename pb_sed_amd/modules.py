@@ -119,9 +119,10 @@ class NormalizedLogMelExtractor(nn.Module):
         self.n_frequency_masks, self.max_masked_frequency_bands = n_frequency_masks, max_masked_frequency_bands
         self.max_masked_frequency_rate, self.max_noise_scale = max_masked_frequency_rate, max_noise_scale
         self._rng = np.random.RandomState(augmentation_seed)
-        if (stft_size, shift, window_length) != (1024, 320, 960):
-            raise NotImplementedError('the fused HIP front-end is built for STFT 1024/960/320 '
-                                      '(pb_sed/data_preparation/provider.py:315-323)')
+        # any STFT geometry runs through the reference's own input contract (inputs['stft'] -> pbsed_logmel_from_stft, generic in
+        # bins / filters: e.g. the doctest models of pb_sed/models/weak_label/crnn.py:16-34 with stft_size 512); the fused
+        # WAVEFORM front-end is built for the experiments' 1024 / 960 / 320 (pb_sed/data_preparation/provider.py:315-323)
+        self.fused_waveform_frontend = (stft_size, shift, window_length) == (1024, 320, 960)
         self.sample_rate, self.stft_size, self.number_of_filters = sample_rate, stft_size, number_of_filters
         self.shift, self.window_length, self.eps, self.clamp = shift, window_length, eps, clamp
         fb = get_fbanks(sample_rate, stft_size, number_of_filters, lowest_frequency, highest_frequency)

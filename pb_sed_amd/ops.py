@@ -309,11 +309,15 @@ def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, se
              ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream(),
              tag=_conv_tag(b, cin, pc, f, t) + ' bf16', flops=_conv_flops(b, cin, pc, f, t))
         return
-    # the library runs its Winograd-F(4,3) weight-gradient kernel for these shapes (conv_wgrad.hip dispatch)
-    wino = pc.kh == 3 and pc.kw == 3 and pc.cout >= 64 and cin >= 16 and os.environ.get('PBSED_WGRAD_WINO', '1') != '0'
+    # which kernel the library picks for these shapes (conv_wgrad.hip dispatch), for the bench's tags: the producer / consumer
+    # bf16x3 kernel from 64 channels on, the Winograd-F(4,3) fp32 kernel for the other 3x3 layers with >= 64 output channels
+    k33 = pc.kh == 3 and pc.kw == 3
+    x3pc = (k33 and cin >= 64 and pc.cout >= 64 and t % 4 == 0 and os.environ.get('PBSED_WGRAD_PC', '1') != '0'
+            and os.environ.get('PBSED_WGRAD_X3', '0') == '0')
+    wino = k33 and not x3pc and pc.cout >= 64 and cin >= 16 and os.environ.get('PBSED_WGRAD_WINO', '1') != '0'
     call('pbsed_conv_bwd_weight', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(g),
          ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream(),
-         tag=_conv_tag(b, cin, pc, f, t) + (' wino' if wino else ''), flops=_conv_flops(b, cin, pc, f, t))
+         tag=_conv_tag(b, cin, pc, f, t) + (' x3pc' if x3pc else ' wino' if wino else ''), flops=_conv_flops(b, cin, pc, f, t))
 
 
 def pool21_fwd(x):

@@ -66,14 +66,16 @@ def _train_step(model, inp):
 
 def _rounding_sensitivity(model, inp, grads):
     """How far rounding-level input changes move each gradient tensor of the HIP path itself: the step is repeated with
-    the waveform scaled by 1 +- 2^-21 and 1 + 2^-20 (the exact gradient moves by ~1e-6 relative) and the largest
+    the waveform scaled by 1 +- 2^-21, 1 +- 2^-20 and 1 +- 3 * 2^-22 (the exact gradient moves by ~1e-6 relative) and the largest
     per-tensor max-abs difference relative to the tensor's max is returned.  At this size that is NOT ~1e-6: a conv layer
     has 8..130 M pre-activations, a rounding-level change puts a few of them on the other side of their ReLU (or flips a
     pool argmax), each flip switches one position's contribution on or off and moves the layer's gradient by
     ~sqrt(flips / positions).  No fp32 implementation can be pinned below this floor, the CPU oracle included."""
     state = {n: b.detach().clone() for n, b in model.named_buffers()}
     noise = {n: 0. for n in grads}
-    for f in (1 + 2. ** -21, 1 - 2. ** -21, 1 + 2. ** -20):
+    # six rounding-level scalings (three left the maximum to chance: a tensor dominated by one flip was measured at
+    # 2.7e-3 in one run and 1.1e-2 in the next with an UNCHANGED 1.1e-2 error against float64)
+    for f in (1 + 2. ** -21, 1 - 2. ** -21, 1 + 2. ** -20, 1 - 2. ** -20, 1 + 3 * 2. ** -22, 1 - 3 * 2. ** -22):
         model.load_state_dict(state, strict=False)
         _, _, g = _train_step(model, dict(inp, audio_data=inp['audio_data'] * f))
         for n in g:
@@ -84,7 +86,21 @@ def _rounding_sensitivity(model, inp, grads):
     return noise
 
 
-def _grad_table(grads, ref64, ref32, noise, tol=2e-3):
+def _record(tag, **fields):
+    """Append one JSON line of measured parity figures to PBSED_PARITY_OUT (default gpurun_out/parity.jsonl): what the gates
+    below saw, kept so that they can be audited without a GPU (tools/parity_report.py turns it into profiles/parity_rNN.json)."""
+    import json
+    import os
+    path = os.environ.get('PBSED_PARITY_OUT', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'parity.jsonl'))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, 'a') as f:
+            f.write(json.dumps(dict(test=tag, **fields)) + '\n')
+    except OSError:
+        pass
+
+
+def _grad_table(grads, ref64, ref32, noise, tol=2e-3, tag=None):
     """Per-tensor max-abs gradient error relative to the tensor's max against the float64 oracle (no L2 averaging).
     A tensor passes at ``tol``, or at 3x the rounding sensitivity of the HIP path on that tensor (see
     _rounding_sensitivity), or at 2x what stock fp32 PyTorch on the CPU reaches on the same tensor against float64 -
@@ -105,6 +121,12 @@ def _grad_table(grads, ref64, ref32, noise, tol=2e-3):
     for err, name, err32, nz in rows[:8]:
         print(f'  {name:40s} err {err:.2e}   rounding sensitivity {nz:.2e}   fp32 CPU oracle {err32:.2e}')
     print(f'  {sum(1 for r in rows if r[0] <= tol)} of {len(rows)} tensors within {tol:g} outright')
+    if tag is None:
+        import inspect
+        tag = next((fr.function for fr in inspect.stack() if fr.function.startswith('test_')), 'unknown')
+    _record(tag, kind='per-tensor gradient error vs the float64 oracle (max-abs / tensor max)', tol=tol, tensors=len(rows),
+            within_tol_outright=sum(1 for r in rows if r[0] <= tol), failed=len(bad),
+            worst=[dict(name=n, err=e, fp32_cpu_oracle_err=e32, rounding_sensitivity=nz) for e, n, e32, nz in rows[:12]])
     return bad
 
 
@@ -215,6 +237,9 @@ def test_c3_bicrnn_shallow_b8(precision):
     e_g = ((g - g64).norm() / g64.norm()).item()
     print(f'{precision}: logits {e_logit:.2e} (|cpu32-cpu64| {((cap.out.double() - cap64.out) * m).abs().max():.2e}) '
           f'scores {e_score:.2e} loss {e_loss:.2e} grad(L2) {e_g:.2e}')
+    _record(f'test_c3_bicrnn_shallow_b8[{precision}]', kind='full-width tag-conditioned BiCRNN, B = 8, vs the CPU oracle',
+            logits_max_abs=e_logit, cpu32_vs_cpu64_logits=((cap.out.double() - cap64.out) * m).abs().max().item(),
+            scores_max_abs=e_score, loss_rel=e_loss, grad_rel_l2=e_g)
     if precision == 'f32':
         assert e_logit < 1e-4 and e_score < 2.5e-5 and e_loss < 2e-5
         bad = _grad_table(grads, ref64, ref, _rounding_sensitivity(model, inp, grads))
@@ -654,3 +679,87 @@ def test_fbcrnn_trains_on_time_warped_frames():
     review = model.review(inputs, out)
     review['loss'].backward()
     assert torch.isfinite(review['loss']) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def _doctest_oracle(kind):
+    """The oracle's classes assembled the way the doctest configs come out of ``get_config`` (post-activation batch-norm stacks
+    with padertorch's defaults as this build restates them: every conv but a stack's last followed by norm + ReLU)."""
+    from oracle import models as om, nn as onn
+    fe = om.LogMelExtractor(16000, 512, 80)
+    cd = 10 if kind == 'strong' else 0
+    cnn_2d = onn.CNN2d(1 + cd, [32, 32, 32], 3, 1, pre_activation=False, output_layer=True)
+    cnn_1d = onn.CNN1d(32 * 80, [32, 32], 3, 1, pre_activation=False, output_layer=True, input_layer=False)
+    cnn = onn.CNN(cnn_2d, cnn_1d, 80, cd)
+    head = lambda width: onn.CNN1d(width, [32, 10], 1, 1, pre_activation=False, output_layer=True)
+    if kind == 'weak':
+        return om.FBCRNN(fe, cnn, onn.GRU(32, 64, 1, False, False, head(64)), onn.GRU(32, 64, 1, False, True, head(64)))
+    return om.BiCRNN(fe, cnn, onn.GRU(32 + cd, 64, 2, True, False, head(128)), tag_conditioning=True)
+
+
+@pytest.mark.parametrize('kind', ['weak', 'strong'])
+def test_reference_doctest_configurations(kind):
+    """The only model configurations the reference itself pins (shapes): the doctests of pb_sed/models/weak_label/crnn.py:16-34
+    (stft 512, 80 mel filters, 3 x 32-channel CNN2d, 2 x 32 CNN1d, GRU 64: [4,1,15,257,2] -> [4,10,15]) and
+    pb_sed/models/strong_label/crnn.py:15-43 (tag-conditioned bi-GRU 2 x 64: [4,1,5,257,2] -> [4,10,5]), built with
+    ``CRNN.get_config`` / ``from_config`` exactly as the doctest does and run through the HIP path by the reference's own
+    input contract ``inputs['stft']``: shapes as the doctest asserts, scores / loss / every gradient against the oracle."""
+    from pb_sed_amd.models import strong_label, weak_label
+    from pb_sed_amd.modules import CNN, GRU
+    torch.manual_seed(0)
+    common = {'cnn': {'factory': CNN, 'cnn_2d': {'out_channels': [32, 32, 32], 'kernel_size': 3},
+                      'cnn_1d': {'out_channels': [32, 32], 'kernel_size': 3}},
+              'feature_extractor': {'sample_rate': 16000, 'stft_size': 512, 'number_of_filters': 80}}
+    if kind == 'weak':
+        cls, t = weak_label.CRNN, 15
+        config = cls.get_config({**common, 'rnn_fwd': {'factory': GRU, 'rnn': {'hidden_size': 64},
+                                                       'output_net': {'out_channels': [32, 10], 'kernel_size': 1}}})
+        np.random.seed(3)
+        stft = torch.tensor(np.random.randn(4, 1, 15, 257, 2), dtype=torch.float32)
+        seq = [15, 14, 13, 12]
+        weak = (torch.rand(4, 10) < .3).float()
+        weak[:, 0] = 1
+        bnd = torch.zeros(4, 10, t)
+        bnd[:, 0, 3:9] = 1
+        targets = {'weak_targets': weak, 'boundary_targets': bnd * weak[..., None]}
+    else:
+        cls, t = strong_label.CRNN, 5
+        config = cls.get_config({**common, 'tag_conditioning': True,
+                                 'rnn': {'factory': GRU, 'rnn': {'bidirectional': True, 'hidden_size': 64, 'num_layers': 2},
+                                         'output_net': {'out_channels': [32, 10], 'kernel_size': 1}}})
+        stft = torch.randn(4, 1, 5, 257, 2)
+        seq = [5, 4, 3, 2]
+        weak = (torch.rand(4, 10) < .4).float()
+        strong = (torch.rand(4, 10, t) < .5).float() * weak[..., None]
+        targets = {'weak_targets': weak, 'strong_targets': strong, 'tag_condition': weak.clone()}
+    model = cls.from_config(config)
+    if kind == 'strong':
+        assert model.rnn.output_net.in_channels == 128                  # the value the doctest prints
+    ref = _doctest_oracle(kind)
+    _randomise(ref, 21)
+    _copy_weights(model, ref)
+    model.to(DEV).train()
+    ref.train()
+    ref64 = copy.deepcopy(ref).double().train()
+    inp_ref = {'stft': stft, 'seq_len': seq, **targets}
+    out_ref = ref(dict(inp_ref))
+    rev_ref = ref.review(inp_ref, out_ref)
+    rev_ref['loss'].backward()
+    in64 = {k: (v.double() if isinstance(v, torch.Tensor) else v) for k, v in inp_ref.items()}
+    ref64.review(in64, ref64(dict(in64)))['loss'].backward()
+    inputs = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in inp_ref.items()}
+    model.flat_parameters()[1].zero_()
+    outputs = model({**inputs})
+    assert outputs[0].shape == torch.Size([4, 10, t])                   # the doctests' own assertion
+    review = model.review(inputs, outputs)
+    review['loss'].backward()
+    torch.cuda.synchronize()
+    n_out = 2 if kind == 'weak' else 1
+    for i in range(n_out):
+        assert (outputs[i].cpu() - out_ref[i]).abs().max().item() < 1e-4, i
+    assert review['loss'].item() == pytest.approx(rev_ref['loss'].item(), rel=1e-4)
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    bad = _grad_table(grads, ref64, ref, {n: 0. for n in grads}, tag=f'test_reference_doctest_configurations[{kind}]')
+    assert not bad, '\n'.join(bad)
+    # the waveform contract needs the experiments' STFT geometry and says so
+    with pytest.raises(NotImplementedError, match='1024'):
+        model({'audio_data': torch.randn(4, 4800, device=DEV), 'seq_len': seq})
