@@ -230,8 +230,14 @@ def _aggregate(events, steps):
 
 
 def _executed(flops, tag):
-    """flops a launch issues on the MFMA pipe: the Winograd-F(4,3) kernels need 18 products per 4 outputs instead of 36."""
-    return flops / 2 if tag.endswith('wino') else flops
+    """fp32-equivalent flops a launch issues on the MFMA pipe: the Winograd-F(4,3) kernels (fp32 'wino' and bf16x3 'winox3')
+    need 18 products per 4 outputs instead of 36."""
+    return flops / 2 if tag.endswith(('wino', 'winox3')) else flops
+
+
+def _x3(name, tag):
+    """launches whose products are formed from exact three-way bf16 splits on the bf16 MFMA (6 part products each)"""
+    return tag.endswith(('winox3', 'x3pc', 'bf16x3')) or name in ('pbsed_gru_wgrad_multi', 'pbsed_tm_gemm')
 
 
 def roofline_objects(agg, by_family, steps, batch, precision, gru_shape, kind):
@@ -240,20 +246,26 @@ def roofline_objects(agg, by_family, steps, batch, precision, gru_shape, kind):
     (dname, dtag), (tot_ms, cnt, flops, _) = max(conv.items(), key=lambda kv: kv[1][0])
     avg_ms = tot_ms / cnt
     bf16_launch = precision == 'bf16' and ('bf16' in dtag or dname.endswith('_bf16'))
-    peak = PEAK_TFLOPS['bf16' if bf16_launch else 'f32']
+    x3_launch = precision != 'bf16' and _x3(dname, dtag)
+    # the ceiling a launch is priced against: the dense MFMA peak of its operand type; bf16x3 launches run six bf16 part
+    # products per fp32-equivalent product, so their fp32-equivalent ceiling is the bf16 peak / 6
+    peak = PEAK_TFLOPS['bf16'] if bf16_launch else PEAK_TFLOPS['bf16'] / 6 if x3_launch else PEAK_TFLOPS['f32']
     alg = flops / (avg_ms * 1e-3) / 1e12
     exe = _executed(flops, dtag) / (avg_ms * 1e-3) / 1e12
     traffic, source = pmc_traffic(f'{dname} {dtag}')
+    wino = dtag.endswith(('wino', 'winox3'))
     out['roofline'] = {
-        'bound': 'mfma', 'achieved': round(exe, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(exe / peak, 4),
+        'bound': 'mfma', 'achieved': round(exe, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(exe / peak, 4),
         'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': source,
         'kernel': f'{dname} {dtag}', 'avg_ms': round(avg_ms, 4), 'launches': cnt, 'flops_per_launch': flops,
         'flops_executed_per_launch': _executed(flops, dtag),
         'achieved_algorithmic': round(alg, 2), 'frac_algorithmic': round(alg / peak, 4),
-        'operands': 'bf16' if bf16_launch else 'f32',
-        'note': ('achieved / frac = flops EXECUTED on the MFMA pipe over the dense peak of the operand type (utilisation, <= 1); '
-                 'achieved_algorithmic = 2*MACs of the direct convolution over the same time'
-                 + ('; this launch is a Winograd-F(4,3) kernel and executes half of the direct products' if dtag.endswith('wino') else ''))}
+        'frac_of_fp32_mfma_peak': round(exe / PEAK_TFLOPS['f32'], 4),
+        'operands': 'bf16' if bf16_launch else 'bf16x3 (exact three-way bf16 splits of fp32 operands, 6 bf16 MFMA products per product)' if x3_launch else 'f32',
+        'note': ('achieved / frac = fp32-equivalent flops EXECUTED on the MFMA pipe over the ceiling of the operand type (utilisation, <= 1'
+                 + ('; bf16x3: the pipe runs 6 bf16 products per counted product, ceiling = 2500 / 6 TFLOP/s' if x3_launch else '')
+                 + '); achieved_algorithmic = 2*MACs of the direct convolution over the same time'
+                 + ('; this launch is a Winograd-F(4,3) kernel and executes half of the direct products' if wino else ''))}
     # whole step / forward: algorithmic and executed (sum over the bracketed launches)
     exe_step = sum(_executed(fl, tag) * c for (name, tag), (ms, c, fl, by) in agg.items()) / steps
     out['_exe_step_flop'] = exe_step

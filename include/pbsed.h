@@ -7,9 +7,11 @@
  *     retains them; `stream` is a hipStream_t (NULL = default stream); every call is asynchronous.
  *   - activations use the reference layouts: 2-D [B, C, F, T], 1-D [B, C, T] (passed as F = 1);
  *     GRU scan buffers are time-major [T, B, *].
- *   - one-time kernel attributes are set per device ordinal, so one process may drive several GPUs; calls for ONE
- *     device must come from one host thread / stream at a time (scratch such as the weight-gradient partial slots
- *     and the persistent-scan workspaces is per device, not per stream).
+ *   - nothing is process-wide: kernel attributes, CU counts and occupancy figures are cached per device ordinal, so one
+ *     process may drive several GPUs.  The only memory the library owns is the partial-sum scratch of the weight-gradient
+ *     kernels (convolution slots, GRU slots): per DEVICE by default - then calls for one device must come from one stream
+ *     at a time - or the caller's own per (device, stream) after pbsed_set_scratch().  The persistent-scan workspaces and
+ *     every other buffer are arguments.
  *   - every function returns 0 on success or a negative PBSED_E_* code; pbsed_last_error() returns the
  *     thread-local message.  No C++ exception crosses the boundary.
  */
@@ -31,6 +33,11 @@ extern "C" {
 
 const char* pbsed_last_error(void);
 int pbsed_version(void);
+/* Caller-owned scratch for (current device, stream): pbsed_conv_bwd_weight* and pbsed_gru_wgrad* take their partial-sum slots
+ * from it instead of the library's per-device buffer (several streams of one device may then run them concurrently).
+ * scratch = NULL removes the registration; pbsed_scratch_bytes() covers every launch of the reference networks. */
+size_t pbsed_scratch_bytes(void);
+int pbsed_set_scratch(void* scratch /*device*/, size_t bytes, void* stream);
 
 /* ---- fused front-end.  Replaces the CPU STFT (pb_sed/data_preparation/provider.py:315-323, called at
  * pb_sed/data_preparation/transform.py:53) + NormalizedLogMelExtractor (pb_sed/models/weak_label/crnn.py:86-90).
@@ -220,6 +227,20 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
                         const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
                         float* const* hs, float* const* save, const int* reverse /*host*/, const int* seq_len,
                         int B, int H, int T, void* stream);
+/* Blocks of the persistent ("granule") scan kernel of this shape that can be co-resident on the CURRENT device: occupancy API
+ * of that kernel instantiation x CUs, at most one block per CU.  A scan launches nchains * (2 nlayers - 1) * (H / 16) *
+ * ceil(B / (16 * tiles_per_block)) blocks that poll each other's words; run the granule entry points only when that count is
+ * within the capacity (the callers here keep it within 7/8 of it) and pbsed_gru_stack_fwd / _bwd (one launch per time step)
+ * otherwise.  The granule entry points check the same bound and return PBSED_E_UNSUPPORTED rather than launch a scan that
+ * could never finish. */
+int pbsed_gru_granule_capacity(int H, int bwd, int bf16, int tiles_per_block);
+/* First-poll delays of the persistent scans on the current device, in units of 64 clocks, per scan kind (0: two-layer stacks,
+ * 1: one-layer scans, 2: forward with two batch tiles per block): {forward, forward gate waves, BPTT, BPTT gate waves}.  A wave
+ * sleeps this long before its first poll of a time step (polling before the data can be there loads the fabric); the forward
+ * optimum is sharp and depends on clocks and on what ran before the scan, so callers measure it in place (pb_sed_amd/ops.py
+ * does at the first scan of every shape) instead of relying on the built-in defaults. */
+int pbsed_gru_get_poll_delays(int kind, int* out4 /*host*/);
+int pbsed_gru_set_poll_delays(int kind, int fwd, int fwd_gate, int bwd, int bwd_gate);
 /* Persistent forward scan (one launch for the whole scan; needs nchains*(2*nlayers-1)*(H/16)*ceil(B/16) <= #CUs
  * co-resident workgroups) exchanging h_t (and the projected inputs of layers > 0) between workgroups as 4-byte words
  * = the fp32 value with its mantissa LSB replaced by the call's parity bit (the exchanged quantity is defined as the

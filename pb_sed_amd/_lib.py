@@ -91,6 +91,11 @@ SIGNATURES = {
     'pbsed_event_frames': [_v, _v, _v, _v, _v, I, I, I, _v],
     'pbsed_grad_sumsq': [_v, SZ, _v, _v],
     'pbsed_adam_step': [_v, _v, _v, _v, SZ, F32, F32, F32, F32, I, F32, F32, _v, _v, _v, I, _v],
+    'pbsed_gru_granule_capacity': [I, I, I, I],
+    'pbsed_gru_get_poll_delays': [I, _v],
+    'pbsed_gru_set_poll_delays': [I, I, I, I, I],
+    'pbsed_set_scratch': [_v, SZ, _v],
+    'pbsed_scratch_bytes': [],
     'pbsed_memset_async': [_v, I, SZ, _v],
     'pbsed_comm_id_bytes': [],
     'pbsed_comm_unique_id': [_v],
@@ -99,7 +104,7 @@ SIGNATURES = {
     'pbsed_allreduce_begin': [_v, _v, SZ, _v],
     'pbsed_allreduce_finish': [_v, _v],
 }
-_NON_STATUS = {'pbsed_last_error': C.c_char_p, 'pbsed_version': C.c_int, 'pbsed_comm_id_bytes': C.c_int, 'pbsed_conv_pack_dims': None,
+_NON_STATUS = {'pbsed_gru_granule_capacity': C.c_int, 'pbsed_scratch_bytes': C.c_size_t, 'pbsed_last_error': C.c_char_p, 'pbsed_version': C.c_int, 'pbsed_comm_id_bytes': C.c_int, 'pbsed_conv_pack_dims': None,
                'pbsed_conv_pack_dims_bf16': None, 'pbsed_conv_pack_dims_wino': None, 'pbsed_conv_pack_dims_winox3': None}
 
 _lib = None

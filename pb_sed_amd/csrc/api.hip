@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <pthread.h>
 
 #include "common.h"
 #include "pbsed_internal.h"
@@ -26,6 +27,63 @@ int check_launch(const char* what) {
     return PBSED_OK;
 }
 
+// ---- per-DEVICE facts and per-(device, stream) scratch: nothing process-wide that a second device or stream could trip over
+int device_cus() {
+    static int cus[64] = {0};                        // indexed by device ordinal; written once with the same value by whoever is first
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int& c = cus[dev & 63];
+    if (c == 0) {
+        hipDeviceProp_t prop;
+        const int n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+        c = n < 8 ? 8 : n;
+    }
+    return c;
+}
+
+namespace {
+struct ScratchSlot {
+    int dev;
+    hipStream_t stream;
+    float* ptr;
+    size_t floats;
+    bool owned;            // library-owned fallback (per device, stream = any)
+};
+constexpr int kScratchSlots = 64;
+ScratchSlot g_scratch[kScratchSlots] = {};
+int g_scratch_n = 0;
+pthread_mutex_t g_scratch_mu = PTHREAD_MUTEX_INITIALIZER;
+}  // namespace
+
+// Scratch for the partial-sum slots of the weight-gradient kernels on (current device, stream): the caller's registered
+// buffer (pbsed_set_scratch) when it is large enough, otherwise a library-owned buffer per DEVICE, grown on demand (then
+// calls for that device must come from one stream at a time - the documented default).
+float* scratch_for(hipStream_t stream, size_t floats) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    pthread_mutex_lock(&g_scratch_mu);
+    ScratchSlot* own = nullptr;
+    float* out = nullptr;
+    for (int i = 0; i < g_scratch_n; ++i) {
+        ScratchSlot& e = g_scratch[i];
+        if (e.dev != dev) continue;
+        if (!e.owned && e.stream == stream && e.floats >= floats) { out = e.ptr; break; }
+        if (e.owned) own = &e;
+    }
+    if (!out) {
+        if (!own && g_scratch_n < kScratchSlots) { own = &g_scratch[g_scratch_n++]; *own = ScratchSlot{dev, nullptr, nullptr, 0, true}; }
+        if (own) {
+            if (own->floats < floats) {
+                if (own->ptr) { (void)hipDeviceSynchronize(); (void)hipFree(own->ptr); own->ptr = nullptr; own->floats = 0; }
+                if (hipMalloc(&own->ptr, floats * sizeof(float)) == hipSuccess) own->floats = floats;
+            }
+            out = own->floats >= floats ? own->ptr : nullptr;
+        }
+    }
+    pthread_mutex_unlock(&g_scratch_mu);
+    return out;
+}
+
 }  // namespace pbsed
 
 using namespace pbsed;
@@ -33,6 +91,28 @@ using namespace pbsed;
 extern "C" {
 
 const char* pbsed_last_error(void) { return g_err; }
+
+// Caller-owned scratch for (current device, `stream`): the weight-gradient kernels (conv and GRU) put their partial-sum
+// slots there instead of into the library's per-device buffer, so several streams of one device can run them concurrently.
+// scratch = NULL removes the registration.  pbsed_scratch_bytes() is large enough for every launch of the reference nets.
+size_t pbsed_scratch_bytes(void) { return (size_t)64 << 20; }
+
+int pbsed_set_scratch(void* scratch, size_t bytes, void* stream) {
+    int dev = 0;
+    PBSED_HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
+    pthread_mutex_lock(&g_scratch_mu);
+    int hit = -1;
+    for (int i = 0; i < g_scratch_n; ++i)
+        if (!g_scratch[i].owned && g_scratch[i].dev == dev && g_scratch[i].stream == (hipStream_t)stream) hit = i;
+    int rc = PBSED_OK;
+    if (hit < 0 && scratch) {
+        if (g_scratch_n < kScratchSlots) hit = g_scratch_n++;
+        else { set_error("pbsed_set_scratch: registration table full (%d)", kScratchSlots); rc = PBSED_E_ARG; }
+    }
+    if (hit >= 0) g_scratch[hit] = ScratchSlot{dev, (hipStream_t)stream, scratch ? (float*)scratch : nullptr, scratch ? bytes / sizeof(float) : 0, false};
+    pthread_mutex_unlock(&g_scratch_mu);
+    return rc;
+}
 
 int pbsed_version(void) { return 1; }
 

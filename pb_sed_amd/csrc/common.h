@@ -114,6 +114,8 @@ __device__ __forceinline__ f32x4 mfma_x3(const Bf3& a, const Bf3& b, f32x4 c) {
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+int device_cus();                                             // CUs of the CURRENT device (cached per device ordinal)
+float* scratch_for(hipStream_t stream, size_t floats);        // partial-sum scratch of (current device, stream); api.hip
 
 // runtime calls in front of a launch (attributes, memsets): report a failure like a failed launch
 #define PBSED_HIP_TRY(expr, what)                                               \

@@ -298,13 +298,7 @@ __global__ void wgrad_slot_reduce_kernel(const float* __restrict__ part, float* 
     if (i < nw) dw[i] += v; else if (db) db[i - nw] += v;
 }
 
-static float* wgrad_slot_scratch() {
-    static float* buf[16] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!buf[dev] && hipMalloc(&buf[dev], sizeof(float) * WGRAD_SLOTS * WGRAD_SLOT_MAX) != hipSuccess) buf[dev] = nullptr;
-    return buf[dev];
-}
+static float* wgrad_slot_scratch(hipStream_t s) { return scratch_for(s, (size_t)WGRAD_SLOTS * WGRAD_SLOT_MAX); }
 
 // Shared launcher: K-split so that the grid is (close to) an integer number of full residency rounds (blocks per CU
 // from the occupancy query, n_cu * occ resident slots, one or two rounds depending on how much K there is), slotted
@@ -323,9 +317,8 @@ static int launch_wgrad_cfg(Kern kern, const ConvWgradArgs& a_in, hipStream_t s)
     PBSED_HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
     int& slots = slots_dev[dev & 63];
     if (slots == 0) {
-        int occ = 0, n_cu = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        int occ = 0;
+        const int n_cu = device_cus();
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, C::NT, lds) != hipSuccess || occ < 1) occ = 2;
         slots = n_cu * occ;
     }
@@ -345,7 +338,7 @@ static int launch_wgrad_cfg(Kern kern, const ConvWgradArgs& a_in, hipStream_t s)
         if (split > a.B * nTt) split = a.B * nTt;
     }
     dim3 grid(split, gy, gz);
-    float* scratch = (slot_ok && split >= 4 * WGRAD_SLOTS) ? wgrad_slot_scratch() : nullptr;
+    float* scratch = (slot_ok && split >= 4 * WGRAD_SLOTS) ? wgrad_slot_scratch(s) : nullptr;
     if (scratch) {
         const int stride = (nw + nb + 63) / 64 * 64;
         PBSED_HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(float) * WGRAD_SLOTS * stride, s), "hipMemsetAsync");

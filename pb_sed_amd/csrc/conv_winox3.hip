@@ -519,15 +519,7 @@ static int launch_winox3(const ConvFwdArgs& a, hipStream_t s) {
     else nWork = nSp * nCt;
     if (a.T & 3) { set_error("conv_winox3: T = %d is not a multiple of 4 (rows must be 16-byte aligned; use the fp32 Winograd kernel)", a.T); return PBSED_E_UNSUPPORTED; }
     // persistent blocks, one per CU (110 KB of LDS each), a multiple of 8 so that an item's XCD is its block's XCD
-    static int n_cu_dev[64] = {0};
-    int dev = 0;
-    PBSED_HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
-    int& n_cu = n_cu_dev[dev & 63];
-    if (n_cu == 0) {
-        hipDeviceProp_t prop;
-        n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
-    }
-    int blocks = n_cu / 8 * 8;
+    int blocks = device_cus() / 8 * 8;
     if (blocks < 8) blocks = 8;
     if (blocks > nWork) blocks = (nWork + 7) / 8 * 8;
     auto kern = conv_winox3_kernel<POOL, DGRAD, UNPOOL>;

@@ -918,27 +918,9 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
 // with one (12-wave, register-heavy) block per CU a ring pinned to an XCD can fill its 32 CUs and lock the projection
 // blocks of that XCD out (found by tests/sweeps/fuzz_gru.py: H = 512, B = 16).  The caller then keeps the 3-D grid, whose
 // blocks spread evenly over the XCDs.
-static int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        if (cus < 8) cus = 8;
-    }
-    return cus;
-}
-
 // nb: 16-row batch tiles per block
 static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid, int nb = 1) {
-    static int cus_per_xcd = 0;
-    if (cus_per_xcd == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus_per_xcd = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                          ? prop.multiProcessorCount / 8 : 32;
-        if (cus_per_xcd < 1) cus_per_xcd = 1;
-    }
+    const int cus_per_xcd = device_cus() / 8;           // per device ordinal (common.h)
     const int nby = (a.B + 16 * nb - 1) / (16 * nb), nj = H / 16;
     const int R = a.nchains * a.nlayers * nby, P = a.nchains * (a.nlayers - 1) * nby;
     const int slots = (R + 7) / 8 * nj + (P * nj + 7) / 8;
@@ -949,7 +931,31 @@ static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid, int nb = 1) {
     return true;
 }
 
-// PBSED_GRU_POLL_DELAYS="fwd,fwd_gate,bwd,bwd_gate" overrides the measured defaults (PollPacer).
+// First-poll delays per DEVICE and scan kind (0: two-layer stacks, 1: one-layer scans, 2: two batch tiles per block), in
+// 64-clock units: {forward, forward gate waves, BPTT, BPTT gate waves}.  The defaults are the measured optima below;
+// PBSED_GRU_POLL_DELAYS="fwd,fwd_gate,bwd,bwd_gate" overrides them, and pbsed_gru_set_poll_delays lets the caller install what it
+// measured on ITS device in ITS step (pb_sed_amd/ops.py tunes them at the first scan of every shape: the forward optimum is
+// sharp and moves by a unit with clocks and with what ran before the scan, so a value baked in here can detune).
+static int* granule_delay_table(int kind) {
+    static int tab[64][3][4];
+    static bool init[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (!init[dev]) {
+        const int def[3][4] = {{25, 6, 20, 0}, {24, 6, 15, 0}, {44, 6, 20, 0}};
+        int e4[4];
+        const char* e = getenv("PBSED_GRU_POLL_DELAYS");
+        const bool over = e && sscanf(e, "%d,%d,%d,%d", &e4[0], &e4[1], &e4[2], &e4[3]) == 4;
+        for (int k = 0; k < 3; ++k)
+            for (int i = 0; i < 4; ++i) tab[dev][k][i] = over ? e4[i] : def[k][i];
+        init[dev] = true;
+    }
+    return tab[dev][kind];
+}
+
+static int granule_capacity(bool bwd, int H, int bf16, int nb);       // co-resident blocks of the scan kernel (below)
+
 static void granule_poll_delays(bool bwd, GruStackArgs& a, int nb = 1) {
     // measured with the tile-major exchange arrays and bf16x3 products (tools/sweep_poll_delays.sh, B = 32, H = 256, T = 500).
     // Two-layer stacks (FBCRNN): forward 21 1.28 ms, 23 0.99, 24 0.94, 25 0.97, 26 1.04, 27 1.10; BPTT 14 1.37, 16 1.35,
@@ -960,15 +966,7 @@ static void granule_poll_delays(bool bwd, GruStackArgs& a, int nb = 1) {
     // The forward optimum sits one unit behind a cliff whose position moves by a unit with what ran before the scan (24 was
     // best with the convolution + transpose producing gi, 25 with the time-major projection: 24 1.05 ms, 25 0.97, 26 0.99): the
     // default is the safe side.  A per-wave feedback on missed first polls was tried: the extra state alone costs 0.2 ms.
-    static int d[4] = {25, 6, 20, 0}, d1[4] = {24, 6, 15, 0}, d2[4] = {44, 6, 20, 0};
-    static const bool parsed = [] {
-        if (const char* e = getenv("PBSED_GRU_POLL_DELAYS"))
-            if (sscanf(e, "%d,%d,%d,%d", &d[0], &d[1], &d[2], &d[3]) == 4)
-                for (int i = 0; i < 4; ++i) d1[i] = d2[i] = d[i];
-        return true;
-    }();
-    (void)parsed;
-    const int* use = nb == 2 ? d2 : a.nlayers == 1 ? d1 : d;
+    int* use = granule_delay_table(nb == 2 ? 2 : a.nlayers == 1 ? 1 : 0);
     a.poll_delay = use[bwd ? 2 : 0];
     a.poll_delay_gate = use[bwd ? 3 : 1];
 }
@@ -1021,6 +1019,11 @@ static int gru_stack_fwd_granule_impl(int nchains, int nlayers, const float* con
     const int nb = ((gw & 1) && ngroups * (H / 16) * ((B + 15) / 16) > device_cus() * 7 / 8) ? 2 : 1;
     granule_poll_delays(false, a, nb);
     dim3 grid(H / 16, (B + 16 * nb - 1) / (16 * nb), ngroups);
+    if ((int)(grid.x * grid.y * grid.z) > granule_capacity(false, H, bf16, nb)) {
+        set_error("gru_stack_fwd_granule: %u blocks cannot be co-resident on this device (capacity %d): use pbsed_gru_stack_fwd",
+                  grid.x * grid.y * grid.z, granule_capacity(false, H, bf16, nb));
+        return PBSED_E_UNSUPPORTED;
+    }
     if (granule_ring_xcd(false)) granule_xcd_grid(a, H, &grid, nb);
     unsigned* gran_gi = granules + (size_t)nchains * nlayers * T * Bp * H;
     hipStream_t s = (hipStream_t)stream;
@@ -1083,6 +1086,11 @@ static int gru_stack_bwd_granule_impl(int nchains, int nlayers, const float* con
     const int ngroups = nchains * (2 * nlayers - 1);
     granule_poll_delays(true, a);
     dim3 grid(H / 16, (B + 15) / 16, ngroups);
+    if ((int)(grid.x * grid.y * grid.z) > granule_capacity(true, H, bf16, 1)) {
+        set_error("gru_stack_bwd_granule: %u blocks cannot be co-resident on this device (capacity %d): use pbsed_gru_stack_bwd",
+                  grid.x * grid.y * grid.z, granule_capacity(true, H, bf16, 1));
+        return PBSED_E_UNSUPPORTED;
+    }
     if (granule_ring_xcd(true)) granule_xcd_grid(a, H, &grid);
     unsigned* gran_dy = granules + (size_t)nchains * nlayers * T * Bp * H;
     hipStream_t s = (hipStream_t)stream;
@@ -1116,7 +1124,94 @@ static int gru_stack_bwd_granule_impl(int nchains, int nlayers, const float* con
     return check_launch("gru_stack_bwd_granule");
 }
 
+// Co-residency is a precondition of the persistent scans (every block polls words other blocks publish): how many blocks of
+// the kernel a scan of this shape would launch fit on the CURRENT device at once, by the occupancy API (registers, LDS and
+// waves of that very instantiation) times the CU count, with the scans' own rule of one block per CU on top - the API may
+// report one block per CU more than the hardware admits (MI355X_MICROARCH.md, residency), and a second block on a CU would
+// share its memory queue with the first.  0 = the kernel cannot be resident at all.  Cached per (instantiation, device).
+template <class Kern>
+static int resident_blocks(Kern kern, int threads, size_t lds, int (&cache)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int& c = cache[dev & 63];
+    if (c == 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, lds) != hipSuccess) occ = 0;
+        c = occ >= 1 ? device_cus() : -1;
+    }
+    return c > 0 ? c : 0;
+}
+
+static int granule_capacity(bool bwd, int H, int bf16, int nb) {
+    static const int gw = [] { const char* e = getenv("PBSED_GRU_GW"); return e ? atoi(e) : 3; }();
+    static const int x3 = [] { const char* e = getenv("PBSED_GRU_X3"); return e ? atoi(e) : 3; }();
+#define CAP_FWD(KB_, NW_)                                                                                                          \
+    do {                                                                                                                           \
+        static int c0[64], c1[64], c2[64], c3[64];                                                                                 \
+        const size_t lds = (size_t)2 * NW_ * nb * 3 * 64 * 4 * sizeof(float);                                                      \
+        if (!(gw & 1)) return resident_blocks(gru_granule_fwd_kernel<KB_, NW_>, NW_ * 64, 0, c0);                                  \
+        if (nb == 2) {                                                                                                             \
+            if (bf16 && KB_ < 4) return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 1, 2>, (NW_ + 4) * 64, lds, c1);       \
+            if ((x3 & 1) && KB_ < 4) return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 3, 2>, (NW_ + 4) * 64, lds, c2);   \
+            return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 0, 2>, (NW_ + 4) * 64, lds, c3);                            \
+        }                                                                                                                          \
+        if (bf16) return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 1, 1>, (NW_ + 4) * 64, lds, c1);                      \
+        if (x3 & 1) return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 3, 1>, (NW_ + 4) * 64, lds, c2);                    \
+        return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 0, 1>, (NW_ + 4) * 64, lds, c3);                                \
+    } while (0)
+#define CAP_BWD(KB_, NW_)                                                                                                          \
+    do {                                                                                                                           \
+        static int c0[64], c1[64], c2[64], c3[64];                                                                                 \
+        if (!(gw & 2)) return resident_blocks(gru_granule_bwd_kernel<KB_, NW_>, NW_ * 64, 0, c0);                                  \
+        if (bf16 && KB_ < 4) return resident_blocks(gru_granule_bwd_gw_kernel<KB_, NW_, 1>, (NW_ + 4) * 64, 0, c1);                \
+        if ((x3 & 2) && KB_ < 4) return resident_blocks(gru_granule_bwd_gw_kernel<KB_, NW_, 3>, (NW_ + 4) * 64, 0, c2);            \
+        return resident_blocks(gru_granule_bwd_gw_kernel<KB_, NW_, 0>, (NW_ + 4) * 64, 0, c3);                                     \
+    } while (0)
+    if (!bwd) {
+        switch (H) {
+            case 64: CAP_FWD(1, 4);
+            case 128: CAP_FWD(1, 8);
+            case 256: CAP_FWD(2, 8);
+            default: CAP_FWD(4, 8);
+        }
+    }
+    switch (H) {
+        case 64: CAP_BWD(1, 4);
+        case 128: CAP_BWD(1, 8);
+        case 256: CAP_BWD(2, 8);
+        default: CAP_BWD(4, 8);
+    }
+#undef CAP_FWD
+#undef CAP_BWD
+}
+
 extern "C" {
+
+// Blocks of the persistent scan kernel of this shape that can be co-resident on the current device (see granule_capacity):
+// a caller runs pbsed_gru_stack_*_granule only for scans of at most this many blocks - nchains * (2 nlayers - 1) * (H / 16) *
+// ceil(B / (16 * tiles_per_block)) - and the launch-per-step pbsed_gru_stack_fwd / _bwd otherwise; the granule entry points
+// check the same bound and return PBSED_E_UNSUPPORTED instead of launching a scan that could never finish.
+int pbsed_gru_get_poll_delays(int kind, int* out4 /*host*/) {
+    if (kind < 0 || kind > 2 || !out4) { set_error("gru_get_poll_delays: kind 0..2"); return PBSED_E_ARG; }
+    const int* t = granule_delay_table(kind);
+    for (int i = 0; i < 4; ++i) out4[i] = t[i];
+    return PBSED_OK;
+}
+
+int pbsed_gru_set_poll_delays(int kind, int fwd, int fwd_gate, int bwd, int bwd_gate) {
+    if (kind < 0 || kind > 2 || fwd < 0 || fwd_gate < 0 || bwd < 0 || bwd_gate < 0 || fwd > 4096 || bwd > 4096) {
+        set_error("gru_set_poll_delays: kind 0..2, delays 0..4096 units of 64 clocks");
+        return PBSED_E_ARG;
+    }
+    int* t = granule_delay_table(kind);
+    t[0] = fwd; t[1] = fwd_gate; t[2] = bwd; t[3] = bwd_gate;
+    return PBSED_OK;
+}
+
+int pbsed_gru_granule_capacity(int H, int bwd, int bf16, int tiles_per_block) {
+    if (H != 64 && H != 128 && H != 256 && H != 512) return 0;
+    return granule_capacity(bwd != 0, H, bf16, tiles_per_block == 2 ? 2 : 1);
+}
 
 int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
                                 const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,

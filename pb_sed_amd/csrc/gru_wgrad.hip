@@ -317,21 +317,8 @@ __global__ void gru_wgrad_slot_reduce_kernel(GruWgradArgs a, int n) {
 
 using namespace pbsed;
 
-// device scratch of the slot mode, grown on demand, one per device ordinal (one stream per device at a time, as for the
-// convolution weight gradients' slots)
-static float* gru_wgrad_scratch(size_t floats) {
-    static float* buf[64] = {nullptr};
-    static size_t cap[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    dev &= 63;
-    if (cap[dev] < floats) {
-        if (buf[dev]) { (void)hipDeviceSynchronize(); (void)hipFree(buf[dev]); buf[dev] = nullptr; cap[dev] = 0; }
-        if (hipMalloc(&buf[dev], floats * sizeof(float)) != hipSuccess) return nullptr;
-        cap[dev] = floats;
-    }
-    return buf[dev];
-}
+// device scratch of the slot mode: the caller's registered buffer for (device, stream) or the library's per-device one (api.hip)
+static float* gru_wgrad_scratch(size_t floats, hipStream_t s) { return scratch_for(s, floats); }
 
 struct GwExt {                 // 1-D convolution layers: prologue of X and the strides of dw
     const float* scale; const float* shift; const float* rowmask;
@@ -363,12 +350,7 @@ static int gru_wgrad_launch(int n, const float* const* dg, const float* const* x
     a.rowmask = ext ? ext->rowmask : nullptr; a.relu = ext ? ext->relu : 0;
     if (ext && !operands) { set_error("gru_wgrad: the convolution form needs the bf16-MFMA kernel"); return PBSED_E_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = device_cus();
     if (operands) {
         if ((size_t)a.TB * (G > kmax ? G : kmax) * 4 >= (1ull << 31)) { set_error("gru_wgrad: an operand of %d x %d floats exceeds the 2 GiB the loaders address", a.TB, G > kmax ? G : kmax); return PBSED_E_ARG; }
         int ny = 0;
@@ -394,7 +376,7 @@ static int gru_wgrad_launch(int n, const float* const* dg, const float* const* x
         if (a.nsplit > slot_min && slot_min > 0) {
             a.slot_kmax = kmax;
             const size_t need = (size_t)n * a.nsplit * G * kmax;
-            if (need * sizeof(float) <= (1ull << 30)) a.slots = gru_wgrad_scratch(need);
+            if (need * sizeof(float) <= (1ull << 30)) a.slots = gru_wgrad_scratch(need, s);
         }
         const size_t lds = (size_t)operands * GB_KG * (GB_BM + GB_BN) * sizeof(u32x4_t);
 #define GW_GO(NS_, EXT_)                                                                          \

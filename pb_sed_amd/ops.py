@@ -299,10 +299,27 @@ def conv_bwd_data(g, pc, wd, x_shape, unpool_idx=None, seq_len=None, bn=None, re
     return dz, stats
 
 
+_SCRATCH = {}           # (device index, stream handle) -> the partial-sum scratch this side owns and registered with the library
+
+
+def ensure_scratch(device):
+    """The weight-gradient kernels put their partial-sum slots into a buffer of the CALLER per (device, stream)
+    (include/pbsed.h: pbsed_set_scratch); registered on first use, kept alive here."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream())
+    if key not in _SCRATCH:
+        with torch.cuda.device(key[0]):
+            buf = torch.empty(_lib.lib().pbsed_scratch_bytes(), dtype=torch.uint8, device=f'cuda:{key[0]}')
+            call('pbsed_set_scratch', ptr(buf), buf.numel(), key[1])
+        _SCRATCH[key] = buf
+    return _SCRATCH[key]
+
+
 def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, seq_len=None,
                     unpool_idx=None, precision='f32'):
     """dw (+=), db (+=): gradients of the conv parameters (buffers must be pre-zeroed/accumulating).  ``precision``
     'bf16': bf16-MFMA operands, fp32 accumulation (layers with >= 32 input and output channels)."""
+    ensure_scratch(x.device)
     b, cin, f, t = _dims4(x)
     if precision == 'bf16' and cin >= 32 and pc.cout >= 32:
         call('pbsed_conv_bwd_weight_bf16', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(g),
@@ -559,6 +576,7 @@ def tm_conv_bwd_data(g, tc, rowmask=None, bn=None, precision='f32'):
 
 def tm_conv_bwd_weight(x, g, tc, dw, db, st_in=None, rowmask=None, precision='f32'):
     """dw [Cout,Cin,KW] (+=), db [Cout] (+=) of layer ``tc`` from its raw input x [T,B,Cin] and g [T,B,N4]."""
+    ensure_scratch(x.device)
     t, b, k = x.shape
     if tc.n4 == tc.cout:
         dwp, dbp = dw, db
@@ -704,20 +722,88 @@ class ScanWatch:
 scan_watch = ScanWatch()
 
 
-def _granule_scan(nch, nlayers, b, h, t, device=None, fwd=False):
-    """Persistent granule-exchange scans need every workgroup co-resident (one per CU): a ring per (chain, layer)
-    plus a projection group per layer boundary, each H/16 x ceil(B/16) blocks, on at most 7/8 of the device's CUs
-    (256 on an MI355X in SPX mode; a partitioned device falls back to the launch-per-step scans).  The forward scan
-    switches to two batch tiles per block (H/16 x ceil(B/32)) when one tile per block does not fit (the library applies the
-    same rule)."""
-    blocks = nch * (2 * nlayers - 1) * ((b + 15) // 16) * (h // 16)
+def _dev_index(dev):
+    dev = dev.index if isinstance(dev, torch.device) else dev
+    return torch.cuda.current_device() if dev is None else dev
+
+
+_POLL_TUNED = {}        # (device, kind, slot, shape) -> chosen delay: every scan shape is measured once per process and device
+
+
+def _tune_poll_delay(dev, kind, slot, shape, launch):
+    """In-place measurement of a persistent scan's first-poll delay (slot 0: forward, 2: BPTT; units of 64 clocks) on THIS
+    device, with THIS shape and these operands: the built-in defaults were measured on one box in one DVFS state, the forward
+    optimum is sharp (one unit early costs 30 %) and moves with clocks and with what shares the device.  At the first scan
+    of a shape (T >= 64: short scans are not worth it) the scan is run a few times per candidate around the default - it is
+    idempotent: outputs are rewritten, the workspace parity flips per launch - the fastest candidate is installed with
+    pbsed_gru_set_poll_delays, and ties go to the LATER delay (the safe side of the cliff).  PBSED_GRU_AUTOTUNE=0 keeps the
+    defaults / PBSED_GRU_POLL_DELAYS.  One host sync per shape, never again."""
+    key = (_dev_index(dev), kind, slot, shape)
+    if key in _POLL_TUNED or shape[4] < 64 or os.environ.get('PBSED_GRU_AUTOTUNE', '1') == '0' or os.environ.get('PBSED_GRU_POLL_DELAYS'):
+        return
+    cur = (C.c_int * 4)()
+    with torch.cuda.device(key[0]):
+        call('pbsed_gru_get_poll_delays', kind, cur)
+        base = list(cur)
+        cands = sorted({max(base[slot] + d, 0) for d in ((-3, -2, -1, 0, 1, 2, 3, 5) if slot == 0 else (-8, -4, -2, 0, 2, 4, 8))})
+        timing_was = _lib.timing
+        _lib.timing = None                          # the bench's event brackets must not see the tuning runs
+        try:
+            best = None
+            for d in cands:
+                trial = list(base)
+                trial[slot] = d
+                call('pbsed_gru_set_poll_delays', kind, *trial)
+                launch(tag='tune')
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    launch(tag='tune')
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1) / 3
+                if best is None or ms < best[0] * .995:           # a later delay wins ties within 0.5 %
+                    best = (ms, d)
+                elif ms <= best[0] * 1.005:
+                    best = (min(ms, best[0]), d)
+            base[slot] = best[1]
+            call('pbsed_gru_set_poll_delays', kind, *base)
+        finally:
+            _lib.timing = timing_was
+    check_gru_sync()
+    _POLL_TUNED[key] = best[1]
+
+
+def _granule_capacity(dev, h, bwd, bf16, tiles):
+    """Blocks of the persistent scan kernel of this shape that can be co-resident on ``dev`` (pbsed_gru_granule_capacity: the
+    occupancy API of that very kernel instantiation x CUs, one block per CU at most)."""
+    key = (dev, h, bwd, bf16, tiles)
+    if key not in _CU_COUNT:
+        with torch.cuda.device(dev):
+            _CU_COUNT[key] = int(_lib.lib().pbsed_gru_granule_capacity(h, int(bwd), int(bf16), tiles))
+    return _CU_COUNT[key]
+
+
+def _granule_scan(nch, nlayers, b, h, t, device=None, fwd=False, precision='f32'):
+    """Persistent granule-exchange scans need every workgroup co-resident: a ring per (chain, layer) plus a projection
+    group per layer boundary, each H/16 x ceil(B/16) blocks, on at most 7/8 of what the library reports as resident capacity
+    for that kernel on this device (one block per CU where the kernel fits at all: 256 on an MI355X in SPX mode; a
+    partitioned device or a kernel that does not fit falls back to the launch-per-step scans instead of raising).  The
+    forward scan switches to two batch tiles per block (H/16 x ceil(B/32)) when one tile per block does not fit (the library
+    applies the same rule).  The forward decision also covers the BPTT scan that will read its saved factors."""
+    if h not in (64, 128, 256, 512) or os.environ.get('PBSED_GRU_PERSIST', '2') != '2':
+        return False
     dev = torch.cuda.current_device() if device is None else device
-    if dev not in _CU_COUNT:
-        _CU_COUNT[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
-    if fwd and blocks > _CU_COUNT[dev] * 7 // 8 and int(os.environ.get('PBSED_GRU_GW', '3')) & 1:
+    dev = dev.index if isinstance(dev, torch.device) else dev
+    if dev is None:
+        dev = torch.cuda.current_device()
+    bf16 = precision == 'bf16'
+    blocks = nch * (2 * nlayers - 1) * ((b + 15) // 16) * (h // 16)
+    cap = min(_granule_capacity(dev, h, False, bf16, 1), _granule_capacity(dev, h, True, bf16, 1))
+    if fwd and blocks > cap * 7 // 8 and int(os.environ.get('PBSED_GRU_GW', '3')) & 1:
         blocks = nch * (2 * nlayers - 1) * ((b + 31) // 32) * (h // 16)
-    return (os.environ.get('PBSED_GRU_PERSIST', '2') == '2' and blocks <= _CU_COUNT[dev] * 7 // 8
-            and nch * nlayers * t * ((b + 15) // 16 * 16) * h * 4 < 2 ** 32)
+        cap = _granule_capacity(dev, h, False, bf16, 2)
+    return blocks <= cap * 7 // 8 and nch * nlayers * t * ((b + 15) // 16 * 16) * h * 4 < 2 ** 32
 
 
 def _per_chain(nch, nlayers, b, h, t, dev, fwd=False):
@@ -756,15 +842,21 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
         if gw is None:
             gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (nlayers + 3 * (nlayers - 1)), dtype=torch.int32, device=dev), 0]
         ws = _gru_err_flag(dev)
+
+        def launch(tag=f'{nch}x{nlayers} B{b} H{h} T{t}'):
+            call('pbsed_gru_stack_fwd_granule_bf16' if precision == 'bf16' else 'pbsed_gru_stack_fwd_granule', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih),
+                 _lib.ptr_array(b_ih), _lib.ptr_array(w_hh), _lib.ptr_array(b_hh), _lib.ptr_array(hs),
+                 _lib.ptr_array(sv) if save else None, _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]),
+                 gw[1] + 1, ptr(ws), stream(), tag=tag,
+                 flops=2. * nch * (2 * nlayers - 1) * t * b * 3 * h * h)        # recurrent + layer-boundary projection products
+            gw[1] += 1                               # parity flips per launched call: the previous call's words never match
+
+        two_tiles = nch * (2 * nlayers - 1) * ((b + 15) // 16) * (h // 16) > _granule_capacity(_dev_index(dev), h, False, precision == 'bf16', 1) * 7 // 8
+        _tune_poll_delay(dev, 2 if two_tiles else 1 if nlayers == 1 else 0, 0, (nch, nlayers, b, h, t, precision), launch)
         watch_end = scan_watch.bracket(('fwd', nch, nlayers, b, h, t)) if scan_watch is not None else None
-        call('pbsed_gru_stack_fwd_granule_bf16' if precision == 'bf16' else 'pbsed_gru_stack_fwd_granule', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih),
-             _lib.ptr_array(b_ih), _lib.ptr_array(w_hh), _lib.ptr_array(b_hh), _lib.ptr_array(hs),
-             _lib.ptr_array(sv) if save else None, _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]),
-             gw[1] + 1, ptr(ws), stream(), tag=f'{nch}x{nlayers} B{b} H{h} T{t}',
-             flops=2. * nch * (2 * nlayers - 1) * t * b * 3 * h * h)        # recurrent + layer-boundary projection products
+        launch()
         if watch_end is not None:
             watch_end.record()
-        gw[1] += 1                                   # parity flips per launched call: the previous call's words never match
         return hs, sv
     call('pbsed_gru_stack_fwd', nch, nlayers, _lib.ptr_array(gi0), _lib.ptr_array(w_ih), _lib.ptr_array(b_ih),
          _lib.ptr_array(w_hh), _lib.ptr_array(b_hh), _lib.ptr_array(hs), _lib.ptr_array(sv) if save else None,
@@ -794,14 +886,19 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
         if gw is None:
             gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (2 * nlayers - 1), dtype=torch.int32, device=dev), 0]
         ws = _gru_err_flag(dev)
+
+        def launch(tag=f'{nch}x{nlayers} B{b} H{h} T{t}'):
+            call('pbsed_gru_stack_bwd_granule_bf16' if precision == 'bf16' else 'pbsed_gru_stack_bwd_granule', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t),
+                 _lib.ptr_array(hs), _lib.ptr_array(save), _lib.ptr_array(dy_top), _lib.ptr_array(dgi), _lib.ptr_array(dgh),
+                 _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]), gw[1] + 1, ptr(ws), stream(),
+                 tag=tag, flops=2. * nch * (2 * nlayers - 1) * t * b * 3 * h * h)
+            gw[1] += 1
+
+        _tune_poll_delay(dev, 1 if nlayers == 1 else 0, 2, (nch, nlayers, b, h, t, precision), launch)
         watch_end = scan_watch.bracket(('bwd', nch, nlayers, b, h, t)) if scan_watch is not None else None
-        call('pbsed_gru_stack_bwd_granule_bf16' if precision == 'bf16' else 'pbsed_gru_stack_bwd_granule', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t),
-             _lib.ptr_array(hs), _lib.ptr_array(save), _lib.ptr_array(dy_top), _lib.ptr_array(dgi), _lib.ptr_array(dgh),
-             _lib.int_array(reverse), ptr(seq_len), b, h, t, ptr(gw[0]), gw[1] + 1, ptr(ws), stream(),
-             tag=f'{nch}x{nlayers} B{b} H{h} T{t}', flops=2. * nch * (2 * nlayers - 1) * t * b * 3 * h * h)
+        launch()
         if watch_end is not None:
             watch_end.record()
-        gw[1] += 1
         return dgi, dgh
     dhz = [torch.empty((t, b, h), device=dev, dtype=torch.float32) for _ in range(n)]
     call('pbsed_gru_stack_bwd', nch, nlayers, _lib.ptr_array(w_hh_t), _lib.ptr_array(w_ih_up_t), _lib.ptr_array(hs),
@@ -814,6 +911,7 @@ def gru_wgrad(dg, x, shift, dw, db, precision='f32'):
     """dw[i] += dg[i]^T x[i] (time shift shift[i] on x), db[i] += column sums of dg[i]; all time-major [T,B,*]; the x[i] may
     differ in width (all weight gradients of a GRU backward pass go in one launch, at most 16 per launch).
     'f32': fp32-class products (exact bf16x3 operand splits on the bf16 MFMA); 'bf16': plain bf16 operands."""
+    ensure_scratch(dg[0].device)
     t, b, g = dg[0].shape
     ks = [v.shape[2] for v in x]
     assert all(d.shape == (t, b, g) and d.is_contiguous() for d in dg) and all(v.shape[:2] == (t, b) and v.is_contiguous() for v in x)

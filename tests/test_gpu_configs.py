@@ -763,3 +763,57 @@ def test_reference_doctest_configurations(kind):
     # the waveform contract needs the experiments' STFT geometry and says so
     with pytest.raises(NotImplementedError, match='1024'):
         model({'audio_data': torch.randn(4, 4800, device=DEV), 'seq_len': seq})
+
+
+def test_f4_audioset_527_class_heads_vs_oracle():
+    """The AudioSet configuration of the reference's training script (pb_sed/experiments/weak_label_crnn/training.py:113-150:
+    num_events = 527, strong_fwd_bwd_loss_weight = 0, gradient clipping 0.1): head convolutions with Cout = 527 (padded to
+    the kernels' tiles), 527 rows per clip through the squash and loss launches (weak loss only, no boundary targets), the
+    gradient-norm clip actually clipping - one train step of a small net against the oracle, then Adam with the clip."""
+    from oracle import frontend as ofe, models as om
+    from pb_sed_amd import ops
+    from pb_sed_amd.models import weak_label
+    from tests.test_gpu_model import TINY
+    torch.manual_seed(0)
+    k = 527
+    kw = dict(num_events=k, hidden_size=64, num_layers=2, net=TINY, strong_fwd_bwd_loss_weight=0.)
+    ref = om.FBCRNN.build(**kw)
+    _randomise(ref, 9)
+    model = weak_label.CRNN.build(**kw)
+    _copy_weights(model, ref)
+    model.to(DEV).train()
+    ref.train()
+    ref64 = copy.deepcopy(ref).double().train()
+    wav, seq, _, _, t = synth_batch(4, 16000 * 2, 10, seed=17)
+    g = torch.Generator().manual_seed(3)
+    weak = (torch.rand(4, k, generator=g) < .02).float()
+    weak[:, 5] = 1
+    inp_ref = {'stft': ofe.stft(wav), 'seq_len': seq.tolist(), 'weak_targets': weak}
+    out_ref = ref(dict(inp_ref))
+    rev_ref = ref.review(inp_ref, out_ref)
+    rev_ref['loss'].backward()
+    in64 = {'stft': ofe.stft(wav).double(), 'seq_len': seq.tolist(), 'weak_targets': weak.double()}
+    ref64.review(in64, ref64(dict(in64)))['loss'].backward()
+    inp = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV)}
+    out, rev, grads = _train_step(model, inp)
+    assert out[0].shape == (4, k, t) and out[1].shape == (4, k, t)
+    assert (out[0].cpu() - out_ref[0]).abs().max() < 1e-4 and (out[1].cpu() - out_ref[1]).abs().max() < 1e-4
+    assert rev['loss'].item() == pytest.approx(rev_ref['loss'].item(), rel=1e-4)
+    bad = _grad_table(grads, ref64, ref, {n: 0. for n in grads}, tol=5e-3)
+    assert not bad, '\n'.join(bad)
+    # clip_grad_norm_(0.1) + Adam(lr 1e-4) as in the AudioSet branch: the clip coefficient is < 1 here and must be applied
+    fp, fg = model.flat_parameters()
+    before = fp.clone()
+    m, v = torch.zeros_like(fp), torch.zeros_like(fp)
+    ss = torch.zeros((), dtype=torch.float64, device=fp.device)
+    norm = torch.zeros((), device=fp.device)
+    ops.grad_sumsq(fg, ss)
+    ops.adam_step(fp, fg, m, v, lr=1e-4, step=1, sumsq=ss, max_norm=.1, norm_out=norm)
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-4)
+    total = torch.nn.utils.clip_grad_norm_(ref.parameters(), .1)
+    assert total.item() > .1 and norm.item() == pytest.approx(total.item(), rel=1e-3)
+    opt.step()
+    upd_ref = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+    upd = dict(zip([n for n, _ in model.named_parameters()], [p.detach().cpu() for _, p in model.named_parameters()]))
+    got = torch.cat([upd[n].reshape(-1) for n, _ in ref.named_parameters()])
+    assert (got - upd_ref).abs().max().item() < 2e-6 and (fp - before).abs().max().item() > 0

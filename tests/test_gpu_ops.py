@@ -753,3 +753,34 @@ def test_gru_scans_with_bf16_operands_stay_close_to_the_fp32_scans(b, h, t, nl):
         for a, r in zip(out['bf16'][k], out['f32'][k]):
             assert ((a - r).norm() / r.norm().clamp_min(1e-6)).item() < 5e-2
     assert (out['bf16'][0][0] - out['f32'][0][0]).abs().max().item() > 0      # it is the other kernel
+
+
+def test_weight_gradients_on_two_streams_with_caller_owned_scratch():
+    """include/pbsed.h: the only memory the library would own is the partial-sum scratch of the weight-gradient kernels;
+    with pbsed_set_scratch it is the caller's per (device, stream), and two streams of one device run the slotted weight
+    gradient of the same layer concurrently with independent results (ops.ensure_scratch registers one buffer per stream)."""
+    from pb_sed_amd import ops
+    torch.manual_seed(5)
+    b, cin, cout, f, t = 4, 16, 16, 32, 500                         # few channels: the slotted (scratch) reduction
+    xs = [torch.randn(b, cin, f, t, device=DEV) for _ in range(2)]
+    gs = [torch.randn(b, cout, f, t, device=DEV) for _ in range(2)]
+    w = torch.randn(cout, cin, 3, 3, device=DEV) * .1
+    pc = ops.PackedConv(w)
+    ref = []
+    for x, g in zip(xs, gs):
+        dw, db = torch.zeros_like(w), torch.zeros(cout, device=DEV)
+        ops.conv_bwd_weight(x, g, pc, dw, db, relu=False)
+        ref.append((dw.clone(), db.clone()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    out = [(torch.zeros_like(w), torch.zeros(cout, device=DEV)) for _ in range(2)]
+    for rep in range(8):                                            # interleaved enqueues on both streams
+        for k, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                out[k][0].zero_(), out[k][1].zero_()
+                ops.conv_bwd_weight(xs[k], gs[k], pc, out[k][0], out[k][1], relu=False)
+    torch.cuda.synchronize()
+    assert len({key for key in ops._SCRATCH if key[1] in [st.cuda_stream for st in streams]}) == 2
+    for k in range(2):
+        close(out[k][0], ref[k][0], atol=2e-3, rtol=1e-4, name=f'dw stream {k}')
+        close(out[k][1], ref[k][1], atol=2e-3, rtol=1e-4, name=f'db stream {k}')
