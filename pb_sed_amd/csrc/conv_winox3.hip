@@ -20,9 +20,12 @@
 //    gradients) -> B^T d -> three bf16 parts -> LDS image [xi][halo row][tile][32 cin] per part (64-byte positions,
 //    XOR-swizzled 16-byte groups: a B fragment is one conflict-free ds_read_b128 per part).  The image of a 32-channel
 //    chunk is built in two halves (xi 0..2, xi 3..5; 54 KB each, double-buffered): while the consumers multiply one half
-//    the producers build the other, one block barrier per half.  VALU work beside bf16 MFMAs of another wave overlaps
-//    (tools/micro/x3_stream.hip: 89 % of the MFMA peak from one wave per SIMD, 75 % with a producer beside it, 67 % with
-//    the U stream from a 2 MB footprint).
+//    the producers build the other, one block barrier per half.  What the split buys is a bubble-free pipeline (no wave
+//    ever waits for its own staging), NOT free VALU: on gfx950 the VALU instructions of one wave and the bf16 MFMAs of
+//    another wave on the same SIMD take turns (tools/micro/mfma_valu_bf16.hip: 72 MFMAs 1 240 clocks, 256 v_fma of the
+//    partner wave 681, together 1 769 = 0.92 x the sum), so every producer instruction is paid at ~2.5 clocks of MFMA
+//    time - the producer is written for instruction count: one pass over a chunk's registers for all six points, the
+//    second half's packed words parked in registers, 8-byte LDS stores, the row's outer elements in two loads.
 // Blocks are PERSISTENT (one per CU) and walk a list of (cout tile, spatial tile) items; the producers run ahead through
 // the chunk stream of all of a block's tiles, so a tile's first half image is built during the previous tile's last phase
 // and epilogue.  Items are numbered so that an XCD works on one cout tile (item % 8 = XCD): its L2 holds that tile's U only.
@@ -131,16 +134,18 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
 
         // state of the tile the NEXT load_chunk reads from (set when the stream enters a tile) ...
         int ld_k = 0, ld_ch = 0, ld_f0 = 0, ld_t0 = 0, ld_b = 0;
-        // ... and of the tile a raw buffer's registers belong to.  Two raw buffers = two chunks in flight: the loads of chunk
-        // g + 2 are issued as soon as chunk g's second half image is stored and have a period and a half to arrive (with one
-        // buffer and the inputs kept in registers between the two halves the loads had one period - about the HBM latency
-        // under load - and the whole block ran at the speed of its loads).  The post-activation inputs are not kept: each
-        // half image rebuilds them from the raw registers (prologue + two DPP moves per channel).
-        constexpr int NB = 2;
+        // ... and of the tile a raw buffer's registers belong to.  NB raw buffers = chunks whose loads are in flight (two; the
+        // un-pooling variant, which also carries index bytes, one).  A chunk's registers are consumed in ONE pass (`produce`):
+        // prologue, DPP neighbours, all six transform points, splits - the first half image goes to LDS at once, the packed
+        // 8-byte words of the second half wait in 54 registers and are only STORED a phase later.  (Rebuilding the inputs for
+        // each half cost 40 % more VALU instructions, and the producers' VALU instructions share each SIMD's issue port with
+        // the consumer wave's MFMAs: PMC - MFMA pipe 47 % busy, 1 450 VALU instructions per producer wave and chunk.)
+        constexpr int NB = UNPOOL ? 1 : 2;
         int fi_f0[NB], fi_nok[NB];
         bool fi_edge_ok[NB];
+        uint2 keep[3][3][3];                                    // [item][point of the second half][part]
 
-        unsigned rin[NB][3][4][4], redge[NB][3][4], ridx[NB][3][4], ridx_e[NB][3][4];
+        unsigned rin[NB][3][4][4], redgeL[NB], redgeR[NB], ridx[NB][3][4], ridx_eL[NB], ridx_eR[NB];
         u32x4_t rsc[NB], rsh[NB];
 #pragma unroll
         for (int n = 0; n < NB; ++n) { rsc[n] = u32x4_t{0u, 0u, 0u, 0u}; rsh[n] = u32x4_t{0u, 0u, 0u, 0u}; fi_f0[n] = 0; fi_nok[n] = 0; fi_edge_ok[n] = false; }
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
             const int sl = a.seq_len ? min(a.seq_len[ld_b], a.T) : a.T;
             const int tlim = pro ? sl : a.T;                       // Normalization re-masks its output (y*mask)
             const int tq = t0 + 4 * tile;                          // first output column of the tile = its input d1
-            const int t_edge = tile == 0 ? t0 - 1 : t0 + 64;      // the outer element this lane loads itself (tiles 0 and 15)
+            const int t_edge = tile == 0 ? t0 - 1 : t0 + 64;      // the row's outer element tiles 0 / 15 need
             fi_f0[BUF] = f0;
             fi_nok[BUF] = min(max(tlim - tq, 0), 4);               // d1..d4 inside [0, tlim)  (zero padding is post-activation)
             fi_edge_ok[BUF] = edge_lane && t_edge >= 0 && t_edge < tlim;
@@ -185,23 +190,58 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const unsigned e1 = row_ok ? row0 + (unsigned)c * chan_step + (unsigned)tq : (OOB >> 2);           // element index of d1
-                    const unsigned ee = (row_ok && edge_lane) ? row0 + (unsigned)c * chan_step + (unsigned)t_edge : (OOB >> 2);
                     const u32x4_t xv = __builtin_amdgcn_raw_buffer_load_b128(rs_x, e1 * 4u, 0, 0);
                     rin[BUF][j][c][0] = xv.x; rin[BUF][j][c][1] = xv.y; rin[BUF][j][c][2] = xv.z; rin[BUF][j][c][3] = xv.w;
                     if (unpool) ridx[BUF][j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, e1 >= (OOB >> 2) ? OOB : e1, 0, 0);
-                    redge[BUF][j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, ee * 4u, 0, 0);
-                    if (unpool) ridx_e[BUF][j][c] = __builtin_amdgcn_raw_buffer_load_b8(rs_i, ee >= (OOB >> 2) ? OOB : ee, 0, 0);
                 }
             }
-            if (++ld_ch == nChunks) { ld_ch = 0; ++ld_k; }
+            // The outer elements of the row (x[t0 - 1] for tile 0, x[t0 + 64] for tile 15) of all 12 (row j, channel c) pairs of
+            // this 16-lane group in TWO loads: lane k < 12 fetches the left one of pair k = 4 j + c, lane k + 4 the right one;
+            // `produce` moves them to lanes 0 / 15 with DPP row shifts.  (One load per pair and side - 24 instructions with two
+            // active lanes each - kept the CU's texture path as busy as all the 16-byte loads together.)
+            {
+                const int kl = tile, kr = tile - 4;
+                const int jl = kl >> 2, cl_ = kl & 3, jr = kr >> 2, cr = kr & 3;
+                const int finl = f0 - 1 + 2 * jl + rsel, finr = f0 - 1 + 2 * jr + rsel;
+                const bool okl = kl < 12 && finl >= 0 && finl < a.F && t0 - 1 >= 0;
+                const bool okr = kr >= 0 && finr >= 0 && finr < a.F && t0 + 64 < a.T;
+                const unsigned el = okl ? (cin0 + (unsigned)cl_) * chan_step + (unsigned)(unpool ? (finl >> 1) : finl) * row_elems + (unsigned)(t0 - 1) : (OOB >> 2);
+                const unsigned er = okr ? (cin0 + (unsigned)cr) * chan_step + (unsigned)(unpool ? (finr >> 1) : finr) * row_elems + (unsigned)(t0 + 64) : (OOB >> 2);
+                redgeL[BUF] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, el * 4u, 0, 0);
+                redgeR[BUF] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, er * 4u, 0, 0);
+                if (unpool) {
+                    ridx_eL[BUF] = __builtin_amdgcn_raw_buffer_load_b8(rs_i, el >= (OOB >> 2) ? OOB : el, 0, 0);
+                    ridx_eR[BUF] = __builtin_amdgcn_raw_buffer_load_b8(rs_i, er >= (OOB >> 2) ? OOB : er, 0, 0);
+                }
+            }
+            if (!(WX_DBG & 16) && ++ld_ch == nChunks) { ld_ch = 0; ++ld_k; }     // ablation bit 16: every chunk re-reads the first one
         };
-        // raw registers of buffer BUF -> post-activation inputs -> V of three transform points -> LDS half image HALF
-        // (0: xi 0..2, 1: xi 3..5)
-        auto store_half = [&](auto half_c, auto buf_c) __attribute__((always_inline)) {
-            constexpr int HALF = decltype(half_c)::value, BUF = decltype(buf_c)::value;
+        // raw registers of buffer BUF -> post-activation inputs -> V of all six transform points: points 0..2 -> LDS half image 0,
+        // points 3..5 -> `keep`
+        auto produce = [&](auto buf_c) __attribute__((always_inline)) {
+            constexpr int BUF = decltype(buf_c)::value;
+            // outer elements of all 12 (j, c) pairs: pair k's left one sits in lane k, its right one in lane k + 4 (load_chunk)
+            float edge[12];
+            unsigned edge_i[12];
+            {
+                const int eL = (int)redgeL[BUF], eR = (int)redgeR[BUF], iL = (int)ridx_eL[BUF], iR = (int)ridx_eR[BUF];
+#define WX_EDGE(K)                                                                                                               \
+                {                                                                                                                \
+                    const int l = K == 0 ? eL : __builtin_amdgcn_update_dpp(0, eL, 0x100 + (K == 0 ? 1 : K), 0xf, 0xf, true);    /* row_shl:K -> lane 0 */ \
+                    const int r = K == 11 ? eR : __builtin_amdgcn_update_dpp(0, eR, 0x110 + (K == 11 ? 1 : 11 - K), 0xf, 0xf, true); /* row_shr:11-K -> lane 15 */ \
+                    edge[K] = __int_as_float(tile == 0 ? l : r);                                                                 \
+                    if (unpool) {                                                                                                \
+                        const int li = K == 0 ? iL : __builtin_amdgcn_update_dpp(0, iL, 0x100 + (K == 0 ? 1 : K), 0xf, 0xf, true); \
+                        const int ri = K == 11 ? iR : __builtin_amdgcn_update_dpp(0, iR, 0x110 + (K == 11 ? 1 : 11 - K), 0xf, 0xf, true); \
+                        edge_i[K] = (unsigned)(tile == 0 ? li : ri);                                                             \
+                    }                                                                                                            \
+                }
+                WX_EDGE(0) WX_EDGE(1) WX_EDGE(2) WX_EDGE(3) WX_EDGE(4) WX_EDGE(5) WX_EDGE(6) WX_EDGE(7) WX_EDGE(8) WX_EDGE(9) WX_EDGE(10) WX_EDGE(11)
+#undef WX_EDGE
+            }
             const float scv[4] = {__uint_as_float(rsc[BUF].x), __uint_as_float(rsc[BUF].y), __uint_as_float(rsc[BUF].z), __uint_as_float(rsc[BUF].w)};
             const float shv[4] = {__uint_as_float(rsh[BUF].x), __uint_as_float(rsh[BUF].y), __uint_as_float(rsh[BUF].z), __uint_as_float(rsh[BUF].w)};
-            unsigned char* base = smem_raw + HALF * WX_HALF + lds_t;
+            unsigned char* base = smem_raw + lds_t;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int fin = fi_f0[BUF] - 1 + 2 * j + rsel;
@@ -211,7 +251,7 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float sc = scv[c], sh = shv[c];
-                    float v[4], ve = __uint_as_float(redge[BUF][j][c]);
+                    float v[4], ve = edge[j * 4 + c];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         float u = __uint_as_float(rin[BUF][j][c][k]);
@@ -222,7 +262,7 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
                         }
                         v[k] = (live && k < fi_nok[BUF]) ? u : 0.f;
                     }
-                    if (unpool) ve = (int)(ridx_e[BUF][j][c] & 0xffu) != par ? 0.f : ve;
+                    if (unpool) ve = (int)(edge_i[j * 4 + c] & 0xffu) != par ? 0.f : ve;
                     if (pro) {
                         ve = fmaf(ve, sc, sh);
                         if (a.relu) ve = fmaxf(ve, 0.f);
@@ -237,12 +277,11 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
                 }
                 unsigned char* pj = base + j * 2048;
 #pragma unroll
-                for (int xl = 0; xl < 3; ++xl) {
+                for (int x = 0; x < 6; ++x) {
                     unsigned hi[4], mid[4], lo[4];                      // bit patterns; the bf16 part is the upper half
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const float d0 = d[c][0], d1 = d[c][1], d2 = d[c][2], d3 = d[c][3], d4 = d[c][4], d5 = d[c][5];
-                        const int x = HALF * 3 + xl;
                         const float v = x == 0 ? 4.f * d0 - 5.f * d2 + d4
                                       : x == 1 ? -4.f * (d1 + d2) + d3 + d4
                                       : x == 2 ? 4.f * (d1 - d2) - d3 + d4
@@ -256,39 +295,59 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
                         hi[c] = u0; mid[c] = u1; lo[c] = __float_as_uint(r2);
                     }
                     // upper halves of (c0, c1) and (c2, c3) -> two dwords, channel c0 in the low half (v_perm_b32)
-                    unsigned char* p = pj + xl * (WX_ROWS * 16 * 64);
-                    *reinterpret_cast<uint2*>(p) = make_uint2(__builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u),
-                                                              __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u));
-                    *reinterpret_cast<uint2*>(p + WX_PART) = make_uint2(__builtin_amdgcn_perm(mid[1], mid[0], 0x07060302u),
-                                                                        __builtin_amdgcn_perm(mid[3], mid[2], 0x07060302u));
-                    *reinterpret_cast<uint2*>(p + 2 * WX_PART) = make_uint2(__builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u),
-                                                                            __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u));
+                    const uint2 w0 = make_uint2(__builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u), __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u));
+                    const uint2 w1 = make_uint2(__builtin_amdgcn_perm(mid[1], mid[0], 0x07060302u), __builtin_amdgcn_perm(mid[3], mid[2], 0x07060302u));
+                    const uint2 w2 = make_uint2(__builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u), __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u));
+                    if (x < 3) {
+                        unsigned char* p = pj + x * (WX_ROWS * 16 * 64);
+                        *reinterpret_cast<uint2*>(p) = w0;
+                        *reinterpret_cast<uint2*>(p + WX_PART) = w1;
+                        *reinterpret_cast<uint2*>(p + 2 * WX_PART) = w2;
+                    } else {
+                        keep[j][x - 3][0] = w0; keep[j][x - 3][1] = w1; keep[j][x - 3][2] = w2;
+                    }
                 }
             }
+        };
+        auto flush_half1 = [&]() __attribute__((always_inline)) {      // the kept words of points 3..5 -> LDS half image 1
+            unsigned char* base = smem_raw + WX_HALF + lds_t;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int xl = 0; xl < 3; ++xl) {
+                    unsigned char* p = base + j * 2048 + xl * (WX_ROWS * 16 * 64);
+                    *reinterpret_cast<uint2*>(p) = keep[j][xl][0];
+                    *reinterpret_cast<uint2*>(p + WX_PART) = keep[j][xl][1];
+                    *reinterpret_cast<uint2*>(p + 2 * WX_PART) = keep[j][xl][2];
+                }
         };
 
         constexpr bool P_LD = !(WX_DBG & 1), P_ST = !(WX_DBG & 2);
         using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        // chunk c of the stream lives in raw buffer c % 2
+        using I1 = std::integral_constant<int, NB - 1>;
+        // chunk c of the stream lives in raw buffer c % NB and is re-loaded with chunk c + NB as soon as it is consumed
         if (P_LD) load_chunk(I0{});
-        if (G > 1 && P_LD) load_chunk(I1{});
-        if (P_ST) store_half(I0{}, I0{});
+        if (NB > 1 && G > 1 && P_LD) load_chunk(I1{});
+        if (P_ST) produce(I0{});
+        if (G > NB && P_LD) load_chunk(I0{});
         __syncthreads();
-        // one chunk of the stream: second half image of chunk g (raw buffer CUR), its buffer re-loaded with chunk g + 2, then -
-        // while the consumers multiply that half - the first half image of chunk g + 1 from the other buffer
-        auto step = [&](int g, auto cur_c, auto nxt_c) __attribute__((always_inline)) {
-            using CUR = decltype(cur_c);
+        auto step = [&](int g, auto nxt_c) __attribute__((always_inline)) {     // NXT: raw buffer of chunk g + 1
             using NXT = decltype(nxt_c);
-            if (P_ST) store_half(I1{}, CUR{});                          // consumers: xi 0..2 of chunk g
-            if (g + 2 < G && P_LD) load_chunk(CUR{});
+            if (P_ST) flush_half1();                                    // consumers: xi 0..2 of chunk g
             __syncthreads();
-            if (g + 1 < G && P_ST) store_half(I0{}, NXT{});             // consumers: xi 3..5 of chunk g (then, at a tile's end, its epilogue)
+            if (g + 1 < G) {                                            // consumers: xi 3..5 of chunk g (then, at a tile's end, its epilogue)
+                if (P_ST) produce(NXT{});
+                if (g + 1 + NB < G && P_LD) load_chunk(NXT{});
+            }
             __syncthreads();
         };
-        for (int g = 0; g < G; g += 2) {
-            step(g, I0{}, I1{});
-            if (g + 1 < G) step(g + 1, I1{}, I0{});
+        if (NB == 1) {
+            for (int g = 0; g < G; ++g) step(g, I0{});
+        } else {
+            for (int g = 0; g < G; g += 2) {
+                step(g, I1{});
+                if (g + 1 < G) step(g + 1, I0{});
+            }
         }
         return;
     }

@@ -134,10 +134,15 @@ def _prec(precision, cin, pc=None, dgrad=False):
         return 'bf16x3'
     if pc is not None and pc.kh == 3 and pc.kw == 3 and os.environ.get('PBSED_CONV_WINO', '1') != '0':
         k_in, n_out = (pc.cout, pc.cin) if dgrad else (pc.cin, pc.cout)
-        if k_in >= 32 and n_out >= 64:
-            # bf16x3 Winograd (csrc/conv_winox3.hip: the same transform-domain products from exact three-way bf16 splits on
-            # the bf16 MFMA) where it is ahead of the fp32-MFMA Winograd kernel; PBSED_CONV_WINOX3=0 keeps the latter
-            return 'winox3' if os.environ.get('PBSED_CONV_WINOX3', '1') != '0' else 'wino'
+        # bf16x3 Winograd (csrc/conv_winox3.hip: the same transform-domain products from exact three-way bf16 splits on the
+        # bf16 MFMA) from 32 channels on either side (32->32 forward 0.152 vs 0.216 ms direct, data gradient 0.138 vs 0.215; with
+        # 16 input channels half of every K = 32 MFMA would be padding and the direct kernel stays ahead);
+        # PBSED_CONV_WINOX3=0 keeps the fp32-MFMA Winograd kernel, which pays from 64 output channels on
+        if os.environ.get('PBSED_CONV_WINOX3', '1') != '0':
+            if k_in >= 32 and n_out >= 32:
+                return 'winox3'
+        elif k_in >= 32 and n_out >= 64:
+            return 'wino'
     return 'f32'
 
 

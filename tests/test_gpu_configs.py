@@ -801,17 +801,18 @@ def test_f4_audioset_527_class_heads_vs_oracle():
     assert rev['loss'].item() == pytest.approx(rev_ref['loss'].item(), rel=1e-4)
     bad = _grad_table(grads, ref64, ref, {n: 0. for n in grads}, tol=5e-3)
     assert not bad, '\n'.join(bad)
-    # clip_grad_norm_(0.1) + Adam(lr 1e-4) as in the AudioSet branch: the clip coefficient is < 1 here and must be applied
+    # clip_grad_norm_ + Adam(lr 1e-4) as in the AudioSet branch (threshold 0.1 there; 0.05 here so that this small net's
+    # gradient norm of ~0.086 is above it): the clip coefficient is < 1 and must be applied
     fp, fg = model.flat_parameters()
     before = fp.clone()
     m, v = torch.zeros_like(fp), torch.zeros_like(fp)
     ss = torch.zeros((), dtype=torch.float64, device=fp.device)
     norm = torch.zeros((), device=fp.device)
     ops.grad_sumsq(fg, ss)
-    ops.adam_step(fp, fg, m, v, lr=1e-4, step=1, sumsq=ss, max_norm=.1, norm_out=norm)
+    ops.adam_step(fp, fg, m, v, lr=1e-4, step=1, sumsq=ss, max_norm=.05, norm_out=norm)
     opt = torch.optim.Adam(ref.parameters(), lr=1e-4)
-    total = torch.nn.utils.clip_grad_norm_(ref.parameters(), .1)
-    assert total.item() > .1 and norm.item() == pytest.approx(total.item(), rel=1e-3)
+    total = torch.nn.utils.clip_grad_norm_(ref.parameters(), .05)
+    assert total.item() > .05 and norm.item() == pytest.approx(total.item(), rel=1e-3)
     opt.step()
     upd_ref = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
     upd = dict(zip([n for n, _ in model.named_parameters()], [p.detach().cpu() for _, p in model.named_parameters()]))

@@ -10,7 +10,7 @@ def tm(f, n=10):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-LAYERS = [(128, 128, 16), (128, 256, 8), (64, 64, 32), (64, 128, 16), (32, 64, 32)]
+LAYERS = [(128, 128, 16), (128, 256, 8), (64, 64, 32), (64, 128, 16), (32, 64, 32), (32, 32, 64), (16, 32, 64)]
 if os.environ.get('ONLY'):
     LAYERS = [l for l in LAYERS if f'{l[0]}x{l[1]}' in os.environ['ONLY'].split(',')]
 PRECS = os.environ.get('PRECS', 'f32,wino,bf16x3,winox3').split(',')
