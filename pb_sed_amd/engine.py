@@ -120,7 +120,7 @@ def _count(seq_host, t, rows):
     return float(np.minimum(np.asarray(seq_host), t).sum() * rows)
 
 
-def _prec(precision, cin, pc=None, dgrad=False):
+def _prec(precision, cin, pc=None, dgrad=False, unpool=False):
     """Operand format / algorithm of one conv launch.  bf16 modes need >= 32 input channels (below that the conv
     is HBM-bound and the fp32 kernel is as fast).  In fp32 mode the MFMA-bound 3x3 layers run the Winograd-F(4,3)
     kernels (csrc/conv_wino.hip: same arithmetic type and results, half the multiplications): contraction over
@@ -139,7 +139,9 @@ def _prec(precision, cin, pc=None, dgrad=False):
         # 16 input channels half of every K = 32 MFMA would be padding and the direct kernel stays ahead);
         # PBSED_CONV_WINOX3=0 keeps the fp32-MFMA Winograd kernel, which pays from 64 output channels on
         if os.environ.get('PBSED_CONV_WINOX3', '1') != '0':
-            if k_in >= 32 and n_out >= 32:
+            # (the data gradient through a pool into 32 channels stays direct: its un-pooling producer carries index bytes and
+            # one chunk in flight, 0.254 vs 0.231 ms at 32->32)
+            if k_in >= 32 and (n_out >= 64 or (n_out >= 32 and not (dgrad and unpool))):
                 return 'winox3'
         elif k_in >= 32 and n_out >= 64:
             return 'wino'
@@ -381,7 +383,7 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
             if on_layer_done is not None:
                 on_layer_done(0)
             return None
-        pr = _prec('f32' if pr in ('wino', 'winox3') else pr, pc.cin, pc, dgrad=True)
+        pr = _prec('f32' if pr in ('wino', 'winox3') else pr, pc.cin, pc, dgrad=True, unpool=idx is not None)
         wd = pc.dgrad(pr)
         if st_in is not None:
             dz, stats = ops.conv_bwd_data(g, pc, wd, x.shape, idx, seq_dev,

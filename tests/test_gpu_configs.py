@@ -66,16 +66,17 @@ def _train_step(model, inp):
 
 def _rounding_sensitivity(model, inp, grads):
     """How far rounding-level input changes move each gradient tensor of the HIP path itself: the step is repeated with
-    the waveform scaled by 1 +- 2^-21, 1 +- 2^-20 and 1 +- 3 * 2^-22 (the exact gradient moves by ~1e-6 relative) and the largest
+    the waveform scaled by 1 +- k 2^-22, k = 1..8 (the exact gradient moves by ~1e-6 relative) and the largest
     per-tensor max-abs difference relative to the tensor's max is returned.  At this size that is NOT ~1e-6: a conv layer
     has 8..130 M pre-activations, a rounding-level change puts a few of them on the other side of their ReLU (or flips a
     pool argmax), each flip switches one position's contribution on or off and moves the layer's gradient by
     ~sqrt(flips / positions).  No fp32 implementation can be pinned below this floor, the CPU oracle included."""
     state = {n: b.detach().clone() for n, b in model.named_buffers()}
     noise = {n: 0. for n in grads}
-    # six rounding-level scalings (three left the maximum to chance: a tensor dominated by one flip was measured at
-    # 2.7e-3 in one run and 1.1e-2 in the next with an UNCHANGED 1.1e-2 error against float64)
-    for f in (1 + 2. ** -21, 1 - 2. ** -21, 1 + 2. ** -20, 1 - 2. ** -20, 1 + 3 * 2. ** -22, 1 - 3 * 2. ** -22):
+    # sixteen rounding-level scalings 1 +- k 2^-22, k = 1..8 (a probe costs one train step on the GPU, the oracle is what takes
+    # time): with three of them the maximum was left to chance - a tensor dominated by ONE discrete flip was measured at 2.7e-3
+    # in one run and 1.1e-2 in the next, with an unchanged 1.1e-2 error against float64 in both
+    for f in [1 + s_ * k * 2. ** -22 for k in range(1, 9) for s_ in (1, -1)]:
         model.load_state_dict(state, strict=False)
         _, _, g = _train_step(model, dict(inp, audio_data=inp['audio_data'] * f))
         for n in g:

@@ -70,7 +70,7 @@ with open(os.path.join(out, f'{tag}_pmc_hbm_traffic.csv'), 'w') as fh:
 print('wrote', f'profiles/{tag}_pmc_hbm_traffic.csv')
 
 # SQ / TCC counter passes (collected WITH the persistent GRU scans on): per kernel template, averages per dispatch
-for name, fname in (('prof_sq', 'pmc_sq'), ('prof_tcc', 'pmc_tcc')):
+for name, fname in (('prof_sq', 'pmc_sq'), ('prof_tcc', 'pmc_tcc'), ('prof_mfma', 'pmc_mfma')):
     files = glob.glob(os.path.join(go, name, '*', '*_counter_collection.csv'))
     if not files:
         continue
@@ -84,7 +84,8 @@ for name, fname in (('prof_sq', 'pmc_sq'), ('prof_tcc', 'pmc_tcc')):
     counters = sorted({c for v in agg.values() for c in v if c != 'dur_us'})
     with open(os.path.join(out, f'{tag}_{fname}.csv'), 'w') as fh:
         w = csv.writer(fh)
-        extra = (['wait_any_frac', 'wait_inst_frac', 'active_frac'] if fname == 'pmc_sq' else ['l2_hit_rate'])
+        extra = (['wait_any_frac', 'wait_inst_frac', 'active_frac'] if fname == 'pmc_sq' else ['l2_hit_rate'] if fname == 'pmc_tcc'
+                 else ['mfma_pipe_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)', 'bf16_tflops_at_kernel_clock_equiv'])
         w.writerow(['kernel', 'grid_threads', 'wg', 'dispatches', 'avg_us(pmc run)'] + counters + extra)
         for (k, g, wg), v in sorted(agg.items(), key=lambda kv: -sum(kv[1]['dur_us'])):
             n = len(v[counters[0]])
@@ -95,11 +96,16 @@ for name, fname in (('prof_sq', 'pmc_sq'), ('prof_tcc', 'pmc_tcc')):
                 wc = max(avg.get('SQ_WAVE_CYCLES', 0.), 1.)
                 ex = [round(avg.get('SQ_WAIT_ANY', 0.) / wc, 3), round(avg.get('SQ_WAIT_INST_ANY', 0.) / wc, 3),
                       round(avg.get('SQ_ACTIVE_INST_ANY', 0.) / wc, 3)]
-            else:
+            elif fname == 'pmc_tcc':
                 ex = [round(avg.get('TCC_HIT_sum', 0.) / max(avg.get('TCC_HIT_sum', 0.) + avg.get('TCC_MISS_sum', 0.), 1.), 3)]
+            else:
+                clk = max(avg.get('GRBM_GUI_ACTIVE', 0.) / 8., 1.)                 # the kernel's duration in shader clocks
+                dur = sum(v['dur_us']) / len(v['dur_us'])
+                ex = [round(avg.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.) / (1024. * clk), 3),
+                      round(avg.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0.) * 512 / (dur * 1e-6) / 1e12, 1)]
             w.writerow([k, g, wg, n, round(sum(v['dur_us']) / len(v['dur_us']), 1)] + [round(avg[c], 1) for c in counters] + ex)
     print('wrote', f'profiles/{tag}_{fname}.csv')
-for cfg in ('c3', 'c5'):
+for cfg in ('c3', 'c5', 'deep'):
     stc = glob.glob(os.path.join(go, f'prof_stats_{cfg}', '*', '*_kernel_stats.csv'))
     if stc:
         shutil.copy(stc[0], os.path.join(out, f'{tag}_{cfg}_kernel_stats.csv'))
@@ -112,6 +118,10 @@ for cfg in ('c3', 'c5'):
 # `roofline.traffic`); keyed by bench.py's "<entry point> <layer tag>", matched to (kernel template, 3-D grid).
 import json
 ROOFLINE_ROWS = {
+    'pbsed_conv_bwd_weight 128->128 k3x3 B32 F16 T500 x3pc': ('conv_wgrad_pc_kernel<2, 2>', None),
+    'pbsed_conv_bwd_weight 128->256 k3x3 B32 F8 T500 x3pc': ('conv_wgrad_pc_kernel<2, 2>', None),
+    'pbsed_conv_bwd_data_winox3 128->128 k3x3 B32 F16 T500 winox3': ('conv_winox3_kernel<false, true, true>', None),
+    'pbsed_conv_fwd_winox3 128->128 k3x3 B32 F16 T500 winox3': ('conv_winox3_kernel<true, false, false>', None),
     'pbsed_conv_bwd_weight 128->128 k3x3 B32 F16 T500 wino': ('conv_wgrad_wino_kernel', None),
     'pbsed_conv_bwd_data_wino 128->128 k3x3 B32 F16 T500 wino': ('conv_wino_kernel<false, true>', None),
     'pbsed_conv_fwd_wino 128->128 k3x3 B32 F16 T500 wino': ('conv_wino_kernel<true, false>', None),
