@@ -207,7 +207,7 @@ def _bicrnn_inputs(wav, seq, weak, strong, device=None, dtype=torch.float32):
 def test_c3_bicrnn_shallow_b8(precision):
     """BASELINE configs[2] network at its real width (B = 8 so that the CPU oracle finishes in seconds).  fp32: the
     fp32 bars (logits 1e-4, scores 2.5e-5, loss 2e-5, per-tensor gradients 2e-3 where fp32 allows it, see _grad_table).  bf16 (the config's dtype: bf16 MFMA
-    operands, fp32 accumulation / BN / GRU state): logits 0.3, scores 6e-2, loss 2 %, gradients 0.3 in the L2 sense
+    operands, fp32 accumulation / BN / GRU state): logits 0.3, scores 6e-2, loss 0.2 %, gradients 0.3 in the L2 sense
     over all parameters - bf16 has 8 mantissa bits and the net is 16 layers deep."""
     ref, model = _bicrnn_pair()
     model.conv_precision = precision
@@ -246,7 +246,9 @@ def test_c3_bicrnn_shallow_b8(precision):
         bad = _grad_table(grads, ref64, ref, _rounding_sensitivity(model, inp, grads))
         assert not bad, '\n'.join(bad)
     else:
-        assert e_logit < .3 and e_score < 6e-2 and e_loss < 2e-2 and e_g < .3
+        # measured (profiles/parity_r03.json): logits 0.197, scores 4.3e-2, loss 4.7e-4, gradients 0.234 - the gates are within
+        # 1.3 - 1.5x of the measured logits / scores / gradients and 4x of the loss
+        assert e_logit < .3 and e_score < 6e-2 and e_loss < 2e-3 and e_g < .3
         assert all(torch.isfinite(g_).all() for g_ in grads.values())
 
 
@@ -814,8 +816,14 @@ def test_f4_audioset_527_class_heads_vs_oracle():
     opt = torch.optim.Adam(ref.parameters(), lr=1e-4)
     total = torch.nn.utils.clip_grad_norm_(ref.parameters(), .05)
     assert total.item() > .05 and norm.item() == pytest.approx(total.item(), rel=1e-3)
+    g_ref = torch.cat([p.grad.detach().reshape(-1) for p in ref.parameters()])          # clipped gradients
     opt.step()
     upd_ref = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
     upd = dict(zip([n for n, _ in model.named_parameters()], [p.detach().cpu() for _, p in model.named_parameters()]))
     got = torch.cat([upd[n].reshape(-1) for n, _ in ref.named_parameters()])
-    assert (got - upd_ref).abs().max().item() < 2e-6 and (fp - before).abs().max().item() > 0
+    # the first Adam step moves a parameter by lr * g / (|g| + eps): where |g| is far above eps = 1e-8 both sides agree to
+    # rounding, where it is not (gradients that are zero up to noise) the step is anywhere within +- lr
+    big = g_ref.abs() > 1e-5
+    assert big.float().mean().item() > .5
+    assert (got - upd_ref)[big].abs().max().item() < 2e-6 and (got - upd_ref).abs().max().item() <= 2.01e-4
+    assert (fp - before).abs().max().item() > 0
