@@ -151,7 +151,8 @@ typedef struct {
     int Cout, Cin, KH, KW, InP, OutP;
     int mode;               /* 0 / 1: direct forward / data-gradient layout, 2 / 3: Winograd forward / data-gradient,
                              * 4 / 5: bf16 (nsplit 1) forward / data-gradient layout of pbsed_pack_conv_weights_bf16 (dst: uint16),
-                             * 6 / 7: its three-part (nsplit 3) form, 8 / 9: pbsed_pack_conv_weights_winox3 forward / data gradient */
+                             * 6 / 7: its three-part (nsplit 3) form, 8 / 9: pbsed_pack_conv_weights_winox3 forward / data gradient,
+                             * 10 / 11: pbsed_pack_conv1d_weights_x3 forward / data gradient (KH = 1) */
     int pad_;
 } pbsed_pack_desc;
 int pbsed_pack_conv_weights_batched(const pbsed_pack_desc* descs /*device*/, int n, void* stream);
@@ -181,6 +182,20 @@ int pbsed_conv_bwd_data_winox3(const float* g, const unsigned short* ud_packed_x
                                const int* seq_len, float* dz, const float* bx, const float* bmean, const float* binvstd,
                                const float* bscale, const float* bshift, int relu, double* stats, int B, int Cin,
                                int Cout, int F, int T, void* stream);
+/* Conv1d (kernel size 1 or 3, zero padding) forward / data gradient on [B, C, T] tensors with exact three-way bf16 operand
+ * splits on the bf16 MFMA, producer / consumer form (csrc/conv1d_pc.hip; fp32-class results).  Replaces the CNN1d layers and
+ * per-frame output nets of pb_sed/models/weak_label/crnn.py:93-101 and pb_sed/models/strong_label/crnn.py:88-104 in the
+ * fp32 path: same prologue (BN-apply + ReLU + mask), bias, masked batch statistics [PBSED_STAT_SLOTS][Cout][2] and
+ * BN-ReLU-backward epilogue as pbsed_conv_fwd / pbsed_conv_bwd_data with F = 1, KH = 1.  u_packed_x3: uint16
+ * [in_padded/32][KW][out_padded/16][3 parts][64 lanes][8] from pbsed_pack_conv1d_weights_x3 (pbsed_pack_desc modes 10 / 11). */
+void pbsed_conv1d_pack_dims_x3(int Cin, int Cout, int dgrad, int* in_padded /*host*/, int* out_padded /*host*/);
+int pbsed_pack_conv1d_weights_x3(const float* w, unsigned short* u_packed_x3, int Cout, int Cin, int KW, int dgrad, void* stream);
+int pbsed_conv1d_fwd_x3(const float* x, const unsigned short* u_packed_x3, const float* bias, const float* scale,
+                        const float* shift, int relu, const int* seq_len, float* y, double* stats, int B, int Cin, int Cout,
+                        int T, int KW, void* stream);
+int pbsed_conv1d_bwd_data_x3(const float* g, const unsigned short* ud_packed_x3, const int* seq_len, float* dz, const float* bx,
+                             const float* bmean, const float* binvstd, const float* bscale, const float* bshift, int relu,
+                             double* stats, int B, int Cin, int Cout, int T, int KW, void* stream);
 void pbsed_conv_pack_dims_bf16(int Cin, int Cout, int dgrad, int* in_padded /*host*/, int* out_padded /*host*/);
 int pbsed_pack_conv_weights_bf16(const float* w, unsigned short* w_packed_bf16, int Cout, int Cin, int KH, int KW,
                                  int dgrad, int nsplit, void* stream);

@@ -1244,6 +1244,334 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
     }
 }
 
+// ============================================================================================
+// Conv1d (F = 1 rows; kernel sizes 1 and 3) weight gradient of the fp32 path, PRODUCER / CONSUMER form of the bf16x3 kernel:
+// conv_wgrad_pc_kernel without the column walk - a step is a (clip, 32-t range) unit, every operand element is staged once
+// per step (the 3-tap kernel stages x[t0 - 8 .. t0 + 40) and builds the kw = 0 / 2 operands by shifting the centre one in
+// registers, boundary elements from the side array, as there).  What makes these layers different is the ratio of staged
+// elements to products: without kernel rows sharing an x row a step has 1 / 3 of the MFMAs per staged element, so the blocks
+// are as large as the accumulators allow: consumer wave = 64 cout x 32 cin x 3 taps (k = 3; block 128 x 64) or
+// 64 cout x 64 cin (k = 1; block 128 x 128).  The producers' VALU instructions and the consumers' MFMAs share the SIMDs' issue
+// cycles (conv_winox3.hip), which is what bounds this kernel.
+// ============================================================================================
+template <int KW>
+struct Wgrad1dPcCfg {
+    static constexpr int FT = 1, TT = 32, KK = KW, NT = 512;
+    static constexpr int MTL = 4, NTL = KW == 3 ? 2 : 4;                 // 16-row tiles per consumer wave: cout, cin
+    static constexpr int COUT_T = 2 * MTL * 16, CIN_T = 2 * NTL * 16;    // 2 x 2 consumer waves
+    static constexpr int XQ = KW == 3 ? 12 : 8;                          // 4-element quads staged per x row
+    static constexpr int XCH = KW == 3 ? 112 : 64;                       // bytes per x row (k = 3: 48 t + 16, 16 bytes mod 128)
+    static constexpr int DY_PART = COUT_T * 64, X_PART = CIN_T * XCH;
+    static constexpr int XB_CH = 20, XB_PART = KW == 3 ? CIN_T * XB_CH : 0;
+    static constexpr int DY_STAGE = 3 * DY_PART, X_STAGE = 3 * (X_PART + XB_PART);
+    static constexpr int X_BASE = 2 * DY_STAGE;
+    static constexpr int LDS_MAIN = X_BASE + 2 * X_STAGE;
+    static constexpr int DY_ITEMS = COUT_T * 8, X_ITEMS = CIN_T * XQ;
+    static constexpr int DY_PER_T = DY_ITEMS / 256, X_PER_T = X_ITEMS / 256;
+    static constexpr int OUT_ROW = CIN_T * KK + 1, OUT_ROWS = 64;
+    static constexpr int LDS_FLOATS = cmax((LDS_MAIN + 3) / 4, OUT_ROWS * OUT_ROW);
+    static_assert(DY_ITEMS % 256 == 0 && X_ITEMS % 256 == 0, "whole items per producer thread");
+};
+
+template <int KW>
+__global__ __launch_bounds__(512) void conv1d_wgrad_pc_kernel(ConvWgradArgs a) {
+    using C = Wgrad1dPcCfg<KW>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    const int lq = lane >> 4, lr = lane & 15;
+    const int cin0 = blockIdx.y * C::CIN_T, cout0 = blockIdx.z * C::COUT_T;
+    const int nTt = (a.T + C::TT - 1) / C::TT;
+    const int nUnits = a.B * nTt;                                        // steps = (clip, 32-t range) units
+    const bool pro = a.scale != nullptr;
+    const int wmi = wave >> 1, wni = wave & 1;                           // consumer wave -> (64-cout group, cin group)
+    const bool do_bias = (a.db != nullptr) && (blockIdx.y == 0) && wni == 0;
+    int nSteps = 0;
+    if ((int)blockIdx.x < nUnits) nSteps = (nUnits - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+
+    f32x4 acc[C::MTL][C::NTL][KW], accb[C::MTL];
+#pragma unroll
+    for (int m = 0; m < C::MTL; ++m) {
+        accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < C::NTL; ++n)
+#pragma unroll
+            for (int k = 0; k < KW; ++k) acc[m][n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    if (!consumer && nSteps > 0) {
+        // ================================================================ PRODUCER
+        const int pt = tid - 256;
+        constexpr unsigned OOB = 0x20000000u;            // element offset beyond every clip (x 4 = 2^31 bytes)
+        const unsigned gclip = (unsigned)(a.Cout * a.T), xclip = (unsigned)(a.Cin * a.T);
+        const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.scale), 0, pro ? (unsigned)a.Cin * 4u : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.shift), 0, pro ? (unsigned)a.Cin * 4u : 0u, 0x00020000);
+        // per-thread item constants: dY item = (cout row, quad of 8), x item = (cin row, quad of XQ)
+        int y_q[C::DY_PER_T], y_valid[C::DY_PER_T];
+        unsigned y_lds[C::DY_PER_T], y_base[C::DY_PER_T];
+#pragma unroll
+        for (int i = 0; i < C::DY_PER_T; ++i) {
+            const int it = pt + i * 256, cl = it >> 3;
+            y_q[i] = it & 7;
+            const int row = cl & 15;
+            y_lds[i] = (unsigned)(cl * 64 + ((((y_q[i] >> 1) ^ ((-(row >> 2)) & 3)) & 3) * 16) + (y_q[i] & 1) * 8);
+            y_valid[i] = cout0 + cl < a.Cout;
+            y_base[i] = (unsigned)((cout0 + cl) * a.T + 4 * y_q[i]);
+        }
+        constexpr int XOFF = KW == 3 ? 8 : 0;               // the x window starts XOFF elements before the step's range
+        int x_q[C::X_PER_T], x_valid[C::X_PER_T];
+        unsigned x_lds[C::X_PER_T], x_bnd[C::X_PER_T];
+        int x_base[C::X_PER_T];
+        float x_sc[C::X_PER_T], x_sh[C::X_PER_T];
+#pragma unroll
+        for (int i = 0; i < C::X_PER_T; ++i) {
+            const int it = pt + i * 256, cl = it / C::XQ;
+            x_q[i] = it % C::XQ;
+            if (KW == 3) {
+                x_lds[i] = (unsigned)(cl * C::XCH + x_q[i] * 8);
+            } else {
+                const int row = cl & 15;
+                x_lds[i] = (unsigned)(cl * 64 + ((((x_q[i] >> 1) ^ ((-(row >> 2)) & 3)) & 3) * 16) + (x_q[i] & 1) * 8);
+            }
+            x_bnd[i] = (unsigned)(cl * C::XB_CH);
+            x_valid[i] = cin0 + cl < a.Cin;
+            x_base[i] = (cin0 + cl) * a.T + 4 * x_q[i] - XOFF;
+            const bool ok = x_valid[i] && pro;
+            x_sc[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_sc, ok ? (unsigned)(cin0 + cl) * 4u : 0x80000000u, 0, 0));
+            x_sh[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_sh, ok ? (unsigned)(cin0 + cl) * 4u : 0x80000000u, 0, 0));
+            if (!pro) x_sc[i] = 1.f;
+        }
+        const float relu_floor = (pro && a.relu) ? 0.f : -__builtin_inff();
+        constexpr int NB = 2;                              // raw register sets = steps whose loads are in flight
+        u32x4_t ry[NB][C::DY_PER_T], rx[NB][C::X_PER_T];
+        int ry_n[NB][C::DY_PER_T], rx_lo[NB][C::X_PER_T], rx_hi[NB][C::X_PER_T];
+        const bool vec = (a.T & 3) == 0;                   // rows 16-byte aligned: one load per quad
+
+        auto locate = [&](int S, int& b, int& t0) __attribute__((always_inline)) {
+            const int u = (int)blockIdx.x + S * (int)gridDim.x;
+            b = u / nTt; t0 = (u % nTt) * C::TT;
+        };
+        auto load_quad = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned e, int lo, int hi) __attribute__((always_inline)) -> u32x4_t {
+            // elements lo <= k < hi of the quad at element offset e are inside the row (branch-free selects)
+            if (vec) {
+                const unsigned ok = (unsigned)-(int)(hi > lo);
+                return __builtin_amdgcn_raw_buffer_load_b128(rs, ((e * 4u) & ok) | ((OOB * 4u) & ~ok), 0, 0);
+            }
+            unsigned w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned ok = (unsigned)-(int)(k >= lo && k < hi);
+                w[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (((e + (unsigned)k) * 4u) & ok) | ((OOB * 4u) & ~ok), 0, 0);
+            }
+            return u32x4_t{w[0], w[1], w[2], w[3]};
+        };
+        auto load_step = [&](int S, auto buf_c) __attribute__((always_inline)) {
+            constexpr int BUF = decltype(buf_c)::value;
+            int b, t0;
+            locate(S, b, t0);
+            const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
+            const int tlim = pro ? sl : a.T;
+            const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a.g) + (size_t)b * gclip, 0, gclip * 4u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a.x) + (size_t)b * xclip, 0, xclip * 4u, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < C::DY_PER_T; ++i) {
+                const int tq = t0 + 4 * y_q[i];
+                const int hi = y_valid[i] ? min(max(a.T - tq, 0), 4) : 0;
+                ry[BUF][i] = load_quad(rs_g, y_base[i] + (unsigned)t0, 0, hi);
+                ry_n[BUF][i] = hi;
+            }
+#pragma unroll
+            for (int i = 0; i < C::X_PER_T; ++i) {
+                const int tq = t0 - XOFF + 4 * x_q[i];
+                const int lo = x_valid[i] ? min(max(-tq, 0), 4) : 4;          // elements before the row's start
+                const int hi_row = x_valid[i] ? min(max(a.T - tq, 0), 4) : 0;
+                rx[BUF][i] = load_quad(rs_x, (unsigned)(x_base[i] + t0), vec ? 0 : lo, vec ? (tq >= 0 ? hi_row : 0) : hi_row);
+                rx_lo[BUF][i] = lo;
+                rx_hi[BUF][i] = x_valid[i] ? min(max(tlim - tq, 0), 4) : 0;   // zero padding is post-activation
+            }
+        };
+        auto put = [&](unsigned char* p, int part_bytes, const float (&v)[4]) __attribute__((always_inline)) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            split3_pair(v[0], v[1], h0, m0, l0);
+            split3_pair(v[2], v[3], h1, m1, l1);
+            *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(p + part_bytes) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(p + 2 * part_bytes) = make_uint2(l0, l1);
+        };
+        auto store_step = [&](int stage, auto buf_c) __attribute__((always_inline)) {
+            constexpr int BUF = decltype(buf_c)::value;
+            unsigned char* dy_s = lds + stage * C::DY_STAGE;
+            unsigned char* x_s = lds + C::X_BASE + stage * C::X_STAGE;
+#pragma unroll
+            for (int i = 0; i < C::DY_PER_T; ++i) {
+                const u32x4_t r = ry[BUF][i];
+                float v[4] = {__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = e < ry_n[BUF][i] ? v[e] : 0.f;
+                put(dy_s + y_lds[i], C::DY_PART, v);
+            }
+#pragma unroll
+            for (int i = 0; i < C::X_PER_T; ++i) {
+                const u32x4_t r = rx[BUF][i];
+                float v[4] = {__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = fmaxf(fmaf(v[e], x_sc[i], x_sh[i]), relu_floor);
+                    v[e] = (e >= rx_lo[BUF][i] && e < rx_hi[BUF][i]) ? u : 0.f;
+                }
+                put(x_s + x_lds[i], C::X_PART, v);
+                if (KW == 3) {
+                    // boundary words: quad 1 + 2 j ends with x[8 j - 1] (low half of word j), quad 4 + 2 j starts with x[8 j + 8]
+                    // (high half of word j); relative to the row image the centre starts at element 8
+                    const int q = x_q[i];
+                    const bool lo_w = (q & 1) && q <= 7, hi_w = !(q & 1) && q >= 4 && q <= 10;
+                    if (lo_w || hi_w) {
+                        const float bv = lo_w ? v[3] : v[0];
+                        const int j = lo_w ? (q - 1) >> 1 : (q - 4) >> 1;
+                        const unsigned u0 = __float_as_uint(bv);
+                        const float r1 = bv - __uint_as_float(u0 & 0xffff0000u);
+                        const unsigned u1 = __float_as_uint(r1);
+                        const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+                        unsigned char* pb = x_s + 3 * C::X_PART + x_bnd[i] + j * 4 + (hi_w ? 2 : 0);
+                        *reinterpret_cast<unsigned short*>(pb) = (unsigned short)(u0 >> 16);
+                        *reinterpret_cast<unsigned short*>(pb + C::XB_PART) = (unsigned short)(u1 >> 16);
+                        *reinterpret_cast<unsigned short*>(pb + 2 * C::XB_PART) = (unsigned short)(__float_as_uint(r2) >> 16);
+                    }
+                }
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        // step S lives in raw set S % 2 and LDS stage S % 2; its loads are issued two steps ahead
+        load_step(0, I0{});
+        if (nSteps > 1) load_step(1, I1{});
+        store_step(0, I0{});
+        if (nSteps > 2) load_step(2, I0{});
+        __syncthreads();
+        auto stage_step = [&](int S, auto nxt_c) __attribute__((always_inline)) {     // consumers: step S; stage step S + 1
+            using NXT = decltype(nxt_c);
+            if (S + 1 < nSteps) {
+                store_step((S + 1) & 1, NXT{});
+                if (S + 3 < nSteps) load_step(S + 3, NXT{});
+            }
+            __syncthreads();
+        };
+        for (int S = 0; S < nSteps; S += 2) {
+            stage_step(S, I1{});
+            if (S + 1 < nSteps) stage_step(S + 1, I0{});
+        }
+    } else if (nSteps > 0) {
+        // ================================================================ CONSUMER
+        const u32x4_t ones = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+        const unsigned a_lane = (unsigned)(lr * 64 + (((lq ^ ((-(lr >> 2)) & 3)) & 3) * 16));     // dY fragment: row lr, t group lq
+        const unsigned b_lane = KW == 3 ? (unsigned)(lr * C::XCH + 16 + lq * 16) : a_lane;          // x fragment: cin lr, t = 8 lq .. + 7
+        const unsigned bnd_lane = (unsigned)(lr * C::XB_CH + lq * 4);                              // its boundary word
+        __syncthreads();                                                 // the prologue's images are in place
+        for (int S = 0; S < nSteps; ++S) {
+            const unsigned char* dy_s = lds + (S & 1) * C::DY_STAGE;
+            const unsigned char* x_s = lds + C::X_BASE + (S & 1) * C::X_STAGE;
+            u32x4_t af[C::MTL][3];
+#pragma unroll
+            for (int m = 0; m < C::MTL; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[m][p] = *reinterpret_cast<const u32x4_t*>(dy_s + p * C::DY_PART + ((wmi * C::MTL + m) * 16) * 64 + a_lane);
+#pragma unroll
+            for (int n = 0; n < C::NTL; ++n) {
+                u32x4_t c[3], left[3], right[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    c[p] = *reinterpret_cast<const u32x4_t*>(x_s + p * C::X_PART + ((wni * C::NTL + n) * 16) * C::XCH + b_lane);
+                    if (KW == 3) {
+                        // {x[t - 1] (low half), x[t + 8] (high half)} of this lane's 8-element group
+                        const unsigned w = *reinterpret_cast<const unsigned*>(x_s + 3 * C::X_PART + p * C::XB_PART +
+                                                                                 ((wni * C::NTL + n) * 16) * C::XB_CH + bnd_lane);
+                        const unsigned s1 = __builtin_amdgcn_alignbit(c[p].y, c[p].x, 16), s2 = __builtin_amdgcn_alignbit(c[p].z, c[p].y, 16),
+                                       s3 = __builtin_amdgcn_alignbit(c[p].w, c[p].z, 16);
+                        left[p] = u32x4_t{__builtin_amdgcn_perm(c[p].x, w, 0x05040100u), s1, s2, s3};     // x[t-1 .. t+6]
+                        right[p] = u32x4_t{s1, s2, s3, __builtin_amdgcn_perm(w, c[p].w, 0x07060302u)};    // x[t+1 .. t+8]
+                    }
+                }
+                // six part products of the (m, kw) accumulators round-robin, smallest first
+#pragma unroll
+                for (int pp = 0; pp < 6; ++pp) {
+                    const int pa = pp == 0 ? 2 : pp == 1 ? 0 : pp == 2 ? 1 : pp == 3 ? 1 : 0;     // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+                    const int pb = pp == 0 ? 0 : pp == 1 ? 2 : pp == 2 ? 1 : pp == 3 ? 0 : pp == 4 ? 1 : 0;
+#pragma unroll
+                    for (int m = 0; m < C::MTL; ++m) {
+                        if (KW == 3) {
+                            acc[m][n][0] = wg_mfma(af[m][pa], left[pb], acc[m][n][0]);
+                            acc[m][n][1] = wg_mfma(af[m][pa], c[pb], acc[m][n][1]);
+                            acc[m][n][2] = wg_mfma(af[m][pa], right[pb], acc[m][n][2]);
+                        } else {
+                            acc[m][n][0] = wg_mfma(af[m][pa], c[pb], acc[m][n][0]);
+                        }
+                    }
+                }
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int m = 0; m < C::MTL; ++m)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) accb[m] = wg_mfma(af[m][2 - p], ones, accb[m]);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- reduce: transpose the block's partial dW through LDS, then row-contiguous atomics (as conv_wgrad_pc_kernel)
+    __syncthreads();
+    float* out_s = smem;                             // [OUT_ROWS][OUT_ROW]
+    const int ncol = min(C::CIN_T, a.Cin - cin0) * KW;
+    const int slot = a.nslots > 1 ? (int)(blockIdx.x % a.nslots) : 0;
+    float* dwp = a.dw + (size_t)slot * a.slot_w;
+#pragma unroll 1
+    for (int part = 0; part < C::COUT_T / C::OUT_ROWS; ++part) {
+        if (part > 0) __syncthreads();
+        if (consumer && wmi == part) {               // a consumer wave's 64 cout rows = one part
+#pragma unroll
+            for (int m = 0; m < C::MTL; ++m)
+#pragma unroll
+                for (int n = 0; n < C::NTL; ++n)
+#pragma unroll
+                    for (int kk = 0; kk < KW; ++kk)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            out_s[(m * 16 + lq * 4 + r) * C::OUT_ROW + ((wni * C::NTL + n) * 16 + lr) * KW + kk] = acc[m][n][kk][r];
+        }
+        __syncthreads();
+        if (nSteps > 0) {
+            for (int row = wave; row < C::OUT_ROWS; row += 8) {
+                const int cout = cout0 + part * C::OUT_ROWS + row;
+                if (cout >= a.Cout) break;
+                float* dst = dwp + ((size_t)cout * a.Cin + cin0) * KW;
+                for (int col = lane; col < ncol; col += 64) atomicAdd(dst + col, out_s[row * C::OUT_ROW + col]);
+            }
+        }
+    }
+    if (consumer && do_bias && lr == 0 && nSteps > 0) {
+#pragma unroll
+        for (int m = 0; m < C::MTL; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cout = cout0 + (wmi * C::MTL + m) * 16 + lq * 4 + r;
+                if (cout < a.Cout) atomicAdd(&a.db[(size_t)slot * a.slot_b + cout], accb[m][r]);
+            }
+    }
+}
+
+static bool pc1d_force() {                 // PBSED_WGRAD_PC=2: the producer / consumer Conv1d kernel for every eligible shape (tests)
+    static const bool f = getenv("PBSED_WGRAD_PC") && atoi(getenv("PBSED_WGRAD_PC")) == 2;
+    return f;
+}
+
 int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     if (a.unpool_idx && (a.F % 2)) { set_error("conv_wgrad: unpool needs even F"); return PBSED_E_ARG; }
     // the loaders address one clip with 32-bit element offsets (buffer loads; 2^29 elements marks "out of range")
@@ -1254,6 +1582,14 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     // Conv1d layers of the fp32 path (F = 1 rows): the same kernel with exact three-way operand splits - fp32-class gradients
     // (256->256 k = 3: 100 us on the fp32-MFMA kernel); very wide inputs stay on the fp32 kernel's 128-wide cin tiles
     static const bool x3_1d = getenv("PBSED_CONV1D_X3") ? atoi(getenv("PBSED_CONV1D_X3")) != 0 : true;
+    // ... in producer / consumer form from 64 channels on either side (PBSED_WGRAD_PC=0: the kernels below).  Measured at B = 32,
+    // T = 500: 256->256 k = 3 87 -> 67 us, 2048->256 k = 1 245 -> 166 us; a 256->256 k = 1 gradient is four 128 x 128 output tiles
+    // with eight steps per block of a 64-way split - its fill and reduction outweigh the steps (41 -> 49 us), it stays below
+    static const bool pc1d = getenv("PBSED_WGRAD_PC") ? atoi(getenv("PBSED_WGRAD_PC")) != 0 : true;
+    if (!a.bf16 && x3_1d && pc1d && KH == 1 && a.F == 1 && !a.unpool_idx && a.Cin >= 64 && a.Cout >= 64) {
+        if (KW == 3) return launch_wgrad_cfg<Wgrad1dPcCfg<3>>(conv1d_wgrad_pc_kernel<3>, a, s);
+        if (KW == 1 && (a.Cin >= 512 || pc1d_force())) return launch_wgrad_cfg<Wgrad1dPcCfg<1>>(conv1d_wgrad_pc_kernel<1>, a, s);
+    }
     if (!a.bf16 && x3_1d && KH == 1 && a.F == 1 && !a.unpool_idx && a.Cin >= 32 && a.Cout >= 32 && a.Cin < 1024) {
         if (KW == 3) return launch_wgrad_cfg<WgradB16Cfg<1, 3, 2, 3>>(conv_wgrad_bf16_kernel<1, 3, 2, 3>, a, s);
         if (KW == 1) return launch_wgrad_cfg<WgradB16Cfg<1, 1, 2, 3>>(conv_wgrad_bf16_kernel<1, 1, 2, 3>, a, s);

@@ -115,11 +115,16 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
         // come from the neighbouring lanes by DPP after the prologue; only the row's first / last tile loads its outer
         // element itself.  Four channels per item make every LDS store an 8-byte one (4 cin x bf16 of one transform point and
         // part): 27 stores per thread and half image instead of 108 two-byte ones.
-        // A thread's 3 items: cin group q >> 1 (channels 4 (q >> 1) .. + 3), rows 2 j + (q & 1), q = producer wave * 4 + lane / 16.
+        // A thread's 3 items: cin group lane / 16 + 4 (producer wave & 1) (4 channels), rows 2 j + (producer wave >> 1).
         // The producers run through the chunk stream of ALL tiles of the block: the first half image of the next tile is
         // built while the consumers are still in the last phase / the epilogue of the current one.
         const int pw = wave - 4, tile = lr;
-        const int q = pw * 4 + lq, cgp = q >> 1, rsel = q & 1;
+        // (lanes 0..31 of a wave = the two 4-channel halves of ONE 16-byte k-group: their 8-byte stores cover all 64 banks)
+#if WX_DBG & 32                                                      // ablation: the mapping whose stores are two-way bank conflicts
+        const int cgp = (pw * 4 + lq) >> 1, rsel = (pw * 4 + lq) & 1;
+#else
+        const int cgp = lq | ((pw & 1) << 2), rsel = pw >> 1;
+#endif
         constexpr unsigned OOB = 0x80000000u;
         const unsigned clip_elems = (unsigned)(a.Cin * Fsrc * a.T);
         const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(

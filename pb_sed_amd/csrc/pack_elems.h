@@ -63,4 +63,32 @@ __device__ __forceinline__ unsigned short pack_winox3_elem(const float* __restri
     return (unsigned short)(__float_as_uint(r2) >> 16);
 }
 
+// Conv1d bf16x3 layout (csrc/conv1d_pc.hip): halfwords [InP/32][kw][OutP/16][part 3][lane 64][8]: the 16 bytes a lane holds of an MFMA A fragment (row = cout tile * 16 +
+// (lane & 15), k = chunk * 32 + (lane >> 4) * 8 + j) contiguous, one 1 KB piece per (chunk, tap, cout tile, part); split by
+// truncation (hi + mid + lo == w exactly).  dgrad: in / out channels swapped, taps flipped.
+__device__ __forceinline__ unsigned short pack_c1x3_elem(const float* __restrict__ w, size_t i, int Cout, int Cin, int KW, int InP,
+                                                         int OutP, int dgrad) {
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    size_t r = i >> 9;
+    const int part = (int)(r % 3); r /= 3;
+    const int MT = OutP / 16;
+    const int mt = (int)(r % MT); r /= MT;
+    const int kw = (int)(r % KW);
+    const int c = (int)(r / KW);
+    const int o = mt * 16 + (lane & 15), ii = c * 32 + (lane >> 4) * 8 + j;
+    float u = 0.f;
+    if (!dgrad) {
+        if (o < Cout && ii < Cin) u = w[((size_t)o * Cin + ii) * KW + kw];
+    } else if (o < Cin && ii < Cout) {
+        u = w[((size_t)ii * Cin + o) * KW + (KW - 1 - kw)];
+    }
+    const unsigned b0 = __float_as_uint(u);
+    if (part == 0) return (unsigned short)(b0 >> 16);
+    const float r1 = u - __uint_as_float(b0 & 0xffff0000u);
+    const unsigned b1 = __float_as_uint(r1);
+    if (part == 1) return (unsigned short)(b1 >> 16);
+    const float r2 = r1 - __uint_as_float(b1 & 0xffff0000u);
+    return (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
 }  // namespace pbsed

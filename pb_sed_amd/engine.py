@@ -131,6 +131,11 @@ def _prec(precision, cin, pc=None, dgrad=False, unpool=False):
     # csrc/conv_bf16.hip NS = 3) is ahead of the fp32-MFMA kernel there (256->256 k = 3: 66 -> 44 us, k = 1: 31 -> 25 us)
     if pc is not None and pc.weight.dim() == 3 and pc.cin >= 32 and pc.cout >= 32 \
             and os.environ.get('PBSED_CONV1D_X3', '1') != '0':
+        # ... and from 96 output channels of the launch on (blocks of 128) the producer / consumer kernel of csrc/conv1d_pc.hip
+        # (weights streamed from L2 in fragment order, four producer waves staging x): PBSED_CONV1D_PC=0 keeps the pipelined one
+        n_out = pc.cin if dgrad else pc.cout
+        if n_out >= 96 and pc.kw in (1, 3) and os.environ.get('PBSED_CONV1D_PC', '1') != '0':
+            return 'c1x3'
         return 'bf16x3'
     if pc is not None and pc.kh == 3 and pc.kw == 3 and os.environ.get('PBSED_CONV_WINO', '1') != '0':
         k_in, n_out = (pc.cout, pc.cin) if dgrad else (pc.cin, pc.cout)
@@ -383,7 +388,7 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
             if on_layer_done is not None:
                 on_layer_done(0)
             return None
-        pr = _prec('f32' if pr in ('wino', 'winox3') else pr, pc.cin, pc, dgrad=True, unpool=idx is not None)
+        pr = _prec('f32' if pr in ('wino', 'winox3', 'c1x3') else pr, pc.cin, pc, dgrad=True, unpool=idx is not None)
         wd = pc.dgrad(pr)
         if st_in is not None:
             dz, stats = ops.conv_bwd_data(g, pc, wd, x.shape, idx, seq_dev,

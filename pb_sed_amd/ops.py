@@ -191,7 +191,32 @@ class PackedConv:
         _register_pack(self.owner, self.weight, up, (self.cout, self.cin, 3, 3, inp.value, outp.value), 8 + dgrad, ck)
         return up
 
+    def _pack_c1x3(self, dgrad):
+        """Fragment-ordered three-part Conv1d weights of csrc/conv1d_pc.hip (uint16)."""
+        assert self.kh == 1 and self.kw in (1, 3)
+        key = (self.owner._version, PACK_EPOCH[0], self.owner.data_ptr())
+        cache = getattr(self.owner, '_pbsed_pack', None)
+        if cache is None or cache.get('key') != key:
+            cache = {'key': key}
+            try:
+                self.owner._pbsed_pack = cache
+            except AttributeError:
+                pass
+        ck = ('c1x3', dgrad)
+        if ck in cache:
+            return cache[ck]
+        inp, outp = C.c_int(), C.c_int()
+        _lib.lib().pbsed_conv1d_pack_dims_x3(self.cin, self.cout, dgrad, C.byref(inp), C.byref(outp))
+        up = torch.empty(self.kw * inp.value * outp.value * 3, device=self.weight.device, dtype=torch.int16)
+        w = self.weight.detach().contiguous()
+        call('pbsed_pack_conv1d_weights_x3', ptr(w), ptr(up), self.cout, self.cin, self.kw, dgrad, stream())
+        cache[ck] = up
+        _register_pack(self.owner, self.weight, up, (self.cout, self.cin, 1, self.kw, inp.value, outp.value), 10 + dgrad, ck)
+        return up
+
     def fwd(self, precision='f32'):
+        if precision == 'c1x3':
+            return self._pack_c1x3(0)
         if precision == 'winox3':
             return self._pack_winox3(0)
         if precision == 'wino':
@@ -199,6 +224,8 @@ class PackedConv:
         return self._pack(0) if precision == 'f32' else self._pack_bf16(0, NSPLIT[precision])
 
     def dgrad(self, precision='f32'):
+        if precision == 'c1x3':
+            return self._pack_c1x3(1)
         if precision == 'winox3':
             return self._pack_winox3(1)
         if precision == 'wino':
@@ -247,6 +274,12 @@ def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=No
     assert residual is None or precision == 'f32', 'a residual add needs the fp32 direct kernel'
     if precision == 'winox3' and t % 4:               # the bf16x3 kernel needs 16-byte aligned rows: same result from the fp32 form
         precision, wp = 'wino', pc.fwd('wino')
+    if precision == 'c1x3':
+        assert f == 1 and pc.kh == 1 and not pool, 'the producer / consumer Conv1d kernel takes [B, C, T] tensors'
+        call('pbsed_conv1d_fwd_x3', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(y),
+             ptr(stats), b, cin, pc.cout, t, pc.kw, stream(), tag=_conv_tag(b, cin, pc, f, t) + ' c1x3',
+             flops=_conv_flops(b, cin, pc, f, t))
+        return y, idx, stats
     if precision in ('wino', 'winox3'):
         call('pbsed_conv_fwd_' + precision, ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
              ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, int(pool), stream(),
@@ -282,6 +315,12 @@ def conv_bwd_data(g, pc, wd, x_shape, unpool_idx=None, seq_len=None, bn=None, re
         stats = _zero_stats(cin, g.device)
     if precision == 'winox3' and t % 4:
         precision, wd = 'wino', pc.dgrad('wino')
+    if precision == 'c1x3':
+        assert f == 1 and pc.kh == 1 and unpool_idx is None
+        call('pbsed_conv1d_bwd_data_x3', ptr(g), ptr(wd), ptr(seq_len), ptr(dz), ptr(bx), ptr(bmean), ptr(binv), ptr(bsc),
+             ptr(bsh), int(relu), ptr(stats), b, cin, pc.cout, t, pc.kw, stream(),
+             tag=_conv_tag(b, cin, pc, f, t) + ' c1x3', flops=_conv_flops(b, cin, pc, f, t))
+        return dz, stats
     if precision in ('wino', 'winox3'):
         call('pbsed_conv_bwd_data_' + precision, ptr(g), ptr(wd), ptr(unpool_idx), ptr(seq_len), ptr(dz), ptr(bx),
              ptr(bmean), ptr(binv), ptr(bsc), ptr(bsh), int(relu), ptr(stats), b, cin, pc.cout, f, t, stream(),

@@ -92,6 +92,12 @@ CONV_CASES = [
     dict(cin=40, cout=10, f=1, t=77, k=(1, 1), pool=False, pro=True),
     dict(cin=48, cout=96, f=1, t=100, k=(1, 3), pool=False, pro=True),
     dict(cin=266, cout=768, f=1, t=45, k=(1, 1), pool=False, pro=False),
+    # Conv1d weight gradients of the producer / consumer bf16x3 kernel (>= 64 channels either side): 3 taps with rows off the
+    # 16-byte alignment, the CNN1d shape, channel counts off the 128 / 64 tiles
+    dict(cin=96, cout=160, f=1, t=203, k=(1, 3), pool=False, pro=True),
+    dict(cin=256, cout=256, f=1, t=500, k=(1, 3), pool=False, pro=True),
+    dict(cin=200, cout=72, f=1, t=64, k=(1, 3), pool=False, pro=False),
+    dict(cin=520, cout=136, f=1, t=130, k=(1, 1), pool=False, pro=True),      # k = 1: wide inputs only (>= 512 channels)
 ]
 
 
@@ -573,6 +579,57 @@ def test_conv_winograd_vs_torch(case, prec):
     if not pro:
         g, _ = ops.conv_bwd_data(dx(gy), pc, pc.dgrad(prec), xd.shape, idx, None, precision=prec)
         close(g, xr.grad, atol=2e-4, rtol=1e-3, name='conv_dgrad wino')
+
+
+C1X3_CASES = [
+    # cin, cout, kw, T, B, prologue
+    (256, 256, 3, 500, 3, True),          # the CNN1d shape: 4 time tiles per clip, the last one partial
+    (2048, 256, 1, 130, 2, True),         # 64 chunks of one tap
+    (96, 128, 3, 77, 5, False),           # odd T, one partial tile
+    (40, 100, 1, 129, 9, True),           # channel counts off the 32 / 128 tiles, 9 clips > 8 XCD slots
+    (64, 384, 3, 256, 2, True),           # three cout tiles, exact time tiles
+    (32, 96, 3, 1, 2, False),             # a single frame
+]
+
+
+@pytest.mark.parametrize('cin,cout,kw,t,b,pro', C1X3_CASES)
+def test_conv1d_producer_consumer_x3_vs_torch(cin, cout, kw, t, b, pro):
+    """csrc/conv1d_pc.hip (precision 'c1x3'): forward with prologue, bias and masked statistics, plain data gradient, and the
+    data gradient with the fused BN-ReLU-mask backward epilogue against the direct fp32 kernel."""
+    from pb_sed_amd import ops
+    torch.manual_seed(5)
+    x = torch.randn(b, cin, 1, t, dtype=torch.float64)
+    w = torch.randn(cout, cin, 1, kw, dtype=torch.float64) / np.sqrt(cin * kw)
+    bias = torch.randn(cout, dtype=torch.float64)
+    seq = np.array([max(t - 7 * i, 1) for i in range(b)])
+    scale = (torch.rand(cin, dtype=torch.float64) + .5) if pro else None
+    shift = torch.randn(cin, dtype=torch.float64) * .3 if pro else None
+    xr = x.clone().requires_grad_()
+    y_ref = _conv_ref(xr, w, bias, scale, shift, seq, (1, kw), False)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    dx = lambda a: None if a is None else a.float().to(DEV).contiguous()
+    seq_dev = torch.as_tensor(seq, dtype=torch.int32).to(DEV)
+    pc = ops.PackedConv(dx(w[:, :, 0]))
+    xd = dx(x[:, :, 0])
+    y, _, stats = ops.conv_fwd(xd, pc, pc.fwd('c1x3'), bias=dx(bias), scale=dx(scale), shift=dx(shift), relu=True,
+                               seq_len=seq_dev, want_stats=True, precision='c1x3')
+    close(y, y_ref[:, :, 0], atol=1e-4, rtol=1e-4, name='conv1d fwd c1x3')
+    m = (torch.arange(t)[None] < torch.as_tensor(seq)[:, None]).to(torch.float64)[:, None]
+    ym = y_ref[:, :, 0].detach() * m
+    close(stats.sum(0), torch.stack([ym.sum((0, 2)), (ym * ym).sum((0, 2))], 1), atol=2e-3, rtol=1e-4, name='conv1d statistics c1x3')
+    if not pro:
+        g, _ = ops.conv_bwd_data(dx(gy[:, :, 0]), pc, pc.dgrad('c1x3'), xd.shape, None, None, precision='c1x3')
+        close(g, xr.grad[:, :, 0], atol=1e-4, rtol=1e-4, name='conv1d dgrad c1x3')
+    # fused BN-ReLU-mask backward epilogue: same dz and (sum dz, sum dz * xhat) as the direct kernel
+    mean, invstd = torch.randn(cin, device=DEV) * .1, torch.rand(cin, device=DEV) + .5
+    gamma, beta = torch.rand(cin, device=DEV) + .5, torch.randn(cin, device=DEV) * .3
+    bsc, bsh = gamma * invstd, beta - mean * gamma * invstd
+    gd = dx(gy[:, :, 0])
+    dz_r, st_r = ops.conv_bwd_data(gd, pc, pc.dgrad('f32'), xd.shape, None, seq_dev, bn=(xd, mean, invstd, bsc, bsh), precision='f32')
+    dz, st = ops.conv_bwd_data(gd, pc, pc.dgrad('c1x3'), xd.shape, None, seq_dev, bn=(xd, mean, invstd, bsc, bsh), precision='c1x3')
+    close(dz, dz_r, atol=2e-5, rtol=1e-4, name='conv1d dz c1x3 vs direct')
+    close(st.sum(0), st_r.sum(0), atol=2e-3, rtol=1e-4, name='conv1d bn-backward sums c1x3 vs direct')
 
 
 @pytest.mark.parametrize('cin,cout,f,t,pool', [(64, 64, 8, 150, True), (32, 96, 6, 65, False), (128, 64, 4, 500, True)])

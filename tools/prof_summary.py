@@ -11,12 +11,20 @@ tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, out = os.path.join(root, 'gpurun_out'), os.path.join(root, 'profiles')
 os.makedirs(out, exist_ok=True)
-st = glob.glob(os.path.join(go, 'prof_stats', '*', '*_kernel_stats.csv'))
+
+
+def newest(pattern):
+    """gpurun merges every call's outputs into the same gpurun_out/ directories: only the latest file of a pass counts."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
+st = newest(os.path.join(go, 'prof_stats', '*', '*_kernel_stats.csv'))
 if st:
     shutil.copy(st[0], os.path.join(out, f'{tag}_kernel_stats.csv'))
     print('wrote', f'profiles/{tag}_kernel_stats.csv')
 # per (kernel, grid) durations from the kernel trace: one template instance serves several layers, the grid tells them apart
-tr = glob.glob(os.path.join(go, 'prof_stats', '*', '*_kernel_trace.csv'))
+tr = newest(os.path.join(go, 'prof_stats', '*', '*_kernel_trace.csv'))
 if tr:
     per = defaultdict(list)
     for r in csv.DictReader(open(tr[0])):
@@ -45,7 +53,7 @@ if tr:
     per_step = {k: len(v) // max(n_steps, 1) for k, v in seq3d.items()}
 rows = defaultdict(lambda: defaultdict(list))
 for name, ctr in (('prof_fetch', 'FETCH_SIZE'), ('prof_write', 'WRITE_SIZE')):
-    for f in glob.glob(os.path.join(go, name, '*', '*_counter_collection.csv')):
+    for f in newest(os.path.join(go, name, '*', '*_counter_collection.csv')):
         seen = defaultdict(int)
         for r in sorted(csv.DictReader(open(f)), key=lambda r: int(r['Dispatch_Id'])):
             if r['Counter_Name'] == ctr:
@@ -71,7 +79,7 @@ print('wrote', f'profiles/{tag}_pmc_hbm_traffic.csv')
 
 # SQ / TCC counter passes (collected WITH the persistent GRU scans on): per kernel template, averages per dispatch
 for name, fname in (('prof_sq', 'pmc_sq'), ('prof_tcc', 'pmc_tcc'), ('prof_mfma', 'pmc_mfma')):
-    files = glob.glob(os.path.join(go, name, '*', '*_counter_collection.csv'))
+    files = newest(os.path.join(go, name, '*', '*_counter_collection.csv'))
     if not files:
         continue
     agg = defaultdict(lambda: defaultdict(list))
@@ -106,7 +114,7 @@ for name, fname in (('prof_sq', 'pmc_sq'), ('prof_tcc', 'pmc_tcc'), ('prof_mfma'
             w.writerow([k, g, wg, n, round(sum(v['dur_us']) / len(v['dur_us']), 1)] + [round(avg[c], 1) for c in counters] + ex)
     print('wrote', f'profiles/{tag}_{fname}.csv')
 for cfg in ('c3', 'c5', 'deep'):
-    stc = glob.glob(os.path.join(go, f'prof_stats_{cfg}', '*', '*_kernel_stats.csv'))
+    stc = newest(os.path.join(go, f'prof_stats_{cfg}', '*', '*_kernel_stats.csv'))
     if stc:
         shutil.copy(stc[0], os.path.join(out, f'{tag}_{cfg}_kernel_stats.csv'))
         print('wrote', f'profiles/{tag}_{cfg}_kernel_stats.csv')
