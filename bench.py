@@ -341,6 +341,7 @@ def _timed_steps(trainer, batches, steps, world, device):
     for i in range(steps):
         review = trainer.step(batches[i % 2])
         enq += trainer.last_enqueue_s
+    trainer.finish()                      # the scan error words of the last step (Trainer looks at step n's when step n + 1 returns)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -152,7 +152,8 @@ typedef struct {
     int mode;               /* 0 / 1: direct forward / data-gradient layout, 2 / 3: Winograd forward / data-gradient,
                              * 4 / 5: bf16 (nsplit 1) forward / data-gradient layout of pbsed_pack_conv_weights_bf16 (dst: uint16),
                              * 6 / 7: its three-part (nsplit 3) form, 8 / 9: pbsed_pack_conv_weights_winox3 forward / data gradient,
-                             * 10 / 11: pbsed_pack_conv1d_weights_x3 forward / data gradient (KH = 1) */
+                             * 10 / 11: pbsed_pack_conv1d_weights_x3 forward / data gradient (KH = 1),
+                             * 12: dst [Cin][Cout] = src^T of a [Cout][Cin] fp32 matrix (the W^T operands of pbsed_gru_stack_bwd*) */
     int pad_;
 } pbsed_pack_desc;
 int pbsed_pack_conv_weights_batched(const pbsed_pack_desc* descs /*device*/, int n, void* stream);

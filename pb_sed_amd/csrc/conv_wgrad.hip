@@ -303,6 +303,9 @@ static float* wgrad_slot_scratch(hipStream_t s) { return scratch_for(s, (size_t)
 // Shared launcher: K-split so that the grid is (close to) an integer number of full residency rounds (blocks per CU
 // from the occupancy query, n_cu * occ resident slots, one or two rounds depending on how much K there is), slotted
 // accumulation for small gradients.  C supplies TT, FT, CIN_T, COUT_T, KK, NT, LDS_FLOATS.
+template <class C, class = void> struct wgrad_columns : std::false_type {};
+template <class C> struct wgrad_columns<C, std::enable_if_t<C::COLUMNS>> : std::true_type {};
+
 template <class C, class Kern>
 static int launch_wgrad_cfg(Kern kern, const ConvWgradArgs& a_in, hipStream_t s) {
     ConvWgradArgs a = a_in;
@@ -334,7 +337,7 @@ static int launch_wgrad_cfg(Kern kern, const ConvWgradArgs& a_in, hipStream_t s)
     const int cap = (slot_ok ? slot_cap : 1024) / (gy * gz);                              // atomics-per-address cap
     if (split > cap) split = cap > 0 ? cap : 1;
     if (split > nChunks) split = nChunks;
-    if constexpr (C::FT == 1 && C::TT == 32 && C::NT == 512) {        // column-walking kernels split over (clip, column) units
+    if constexpr (wgrad_columns<C>::value) {                          // column-walking kernels split over (clip, column) units
         if (split > a.B * nTt) split = a.B * nTt;
     }
     dim3 grid(split, gy, gz);
@@ -908,25 +911,37 @@ __global__ __launch_bounds__(MH * 128) void conv_wgrad_bf16_kernel(ConvWgradArgs
 #ifndef WGPC_DBG
 #define WGPC_DBG 0          // ablation switches of tools/kernel_ablation.sh (never set in the product build)
 #endif
-template <int WM, int WN>
+// Consumer waves: WM x WN wave tiles of (MTL x 16 cout) x (NTL x 16 cin), times KS waves that SPLIT THE STEP'S TIME RANGE (wave
+// ks contracts over t = 32 ks .. + 31 of a 32 KS wide step; the partial sums meet in the final LDS reduction): the layers with
+// 16 / 32 channels have one or two MFMA tiles per side, and four waves only find work along t.  WM * WN * KS = 4.
+template <int WM, int WN, int KS = 1, int MTL = 2, int NTL = 2>
 struct WgradPcCfg {
-    static constexpr int FT = 1, TT = 32, KK = 9, NT = 512;
-    static constexpr int COUT_T = WM * 32, CIN_T = WN * 32;
-    static constexpr int XCH = 112;                                      // bytes: channel stride of an x row slot (48 t + 16)
-    static constexpr int DY_PART = COUT_T * 64, X_PART = CIN_T * XCH;   // bytes per operand part
-    static constexpr int XB_CH = 20, XB_PART = CIN_T * XB_CH;            // boundary words: per channel 4 dwords {x[8j - 1], x[8j + 8]} (+ 1 pad:
+    static_assert(WM * WN * KS == 4, "four consumer waves");
+    static constexpr bool COLUMNS = true;                                // launch_wgrad_cfg: the split is over (clip, column) units
+    static constexpr int FT = 1, TT = 32 * KS, KK = 9, NT = 512, NJ = TT / 8;
+    static constexpr int COUT_T = WM * MTL * 16, CIN_T = WN * NTL * 16;
+    // bytes: channel stride of an x row slot (TT + 16 t, then padded to an odd multiple of 16 bytes: the 16 rows of a fragment
+    // read cover all banks)
+    static constexpr int XCH = ((TT + 16) * 2 / 16) % 2 ? (TT + 16) * 2 : (TT + 16) * 2 + 16;
+    static constexpr int DY_PART = KS * COUT_T * 64, X_PART = CIN_T * XCH;   // bytes per operand part; dY: [ks][cout][32 t]
+    static constexpr int XB_CH = (NJ + 1) * 4, XB_PART = CIN_T * XB_CH;  // boundary words: per channel NJ dwords {x[8j - 1], x[8j + 8]} (+ 1 pad:
     static constexpr int DY_STAGE = 3 * DY_PART, X_SLOT = 3 * (X_PART + XB_PART);   // odd dword stride = conflict-free 4-byte reads)
     static constexpr int X_BASE = 2 * DY_STAGE;                         // LDS: dY stage 0, dY stage 1, x slots 0..3, zero slot
     static constexpr int LDS_MAIN = X_BASE + 5 * X_SLOT;
-    static constexpr int DY_ITEMS = COUT_T * 8, X_ITEMS = CIN_T * 12;    // 4-element quads per step
+    static constexpr int XQ = (TT + 16) / 4;                             // 4-element quads per x row
+    static constexpr int DY_ITEMS = COUT_T * TT / 4, X_ITEMS = CIN_T * XQ;
     static constexpr int DY_PER_T = (DY_ITEMS + 255) / 256, X_PER_T = (X_ITEMS + 255) / 256;
-    static constexpr int OUT_ROW = CIN_T * KK + 1, OUT_ROWS = 64;
+    // steps whose global loads are in flight: the steps of the few-channel configurations are short (a few hundred clocks), two
+    // of them do not cover the memory latency
+    static constexpr int NB = (KS > 1) ? 4 : 2;
+    static constexpr int OUT_ROW = CIN_T * KK + 1, OUT_ROWS = COUT_T < 64 ? COUT_T : 64;
     static constexpr int LDS_FLOATS = cmax((LDS_MAIN + 3) / 4, OUT_ROWS * OUT_ROW);
+    static_assert(XB_CH / 4 % 2 == 1 && (XCH / 16) % 2 == 1, "odd strides");
 };
 
-template <int WM, int WN>
+template <int WM, int WN, int KS = 1, int MTL = 2, int NTL = 2>
 __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
-    using C = WgradPcCfg<WM, WN>;
+    using C = WgradPcCfg<WM, WN, KS, MTL, NTL>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
 
@@ -936,23 +951,24 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
     const int lq = lane >> 4, lr = lane & 15;
     const int cin0 = blockIdx.y * C::CIN_T, cout0 = blockIdx.z * C::COUT_T;
     const int nTt = (a.T + C::TT - 1) / C::TT;
-    const int nCols = a.B * nTt;                                         // columns = (clip, 32-t range); the launcher's chunks = columns x rows
+    const int nCols = a.B * nTt;                                         // columns = (clip, TT-wide t range); the launcher's chunks = columns x rows
     const bool pro = a.scale != nullptr;
     const bool unpool = a.unpool_idx != nullptr;
     const int Fg = unpool ? a.F / 2 : a.F;
-    const int wmi = wave / WN, wni = wave % WN;                          // consumer wave -> (32-cout group, 32-cin group)
+    // consumer wave -> (cout group, cin group, 32-t slice of the step)
+    const int wks = wave % KS, wni = (wave / KS) % WN, wmi = wave / (KS * WN);
     const bool do_bias = (a.db != nullptr) && (blockIdx.y == 0) && wni == 0;
     // columns of this block: blockIdx.x, + gridDim.x, ..; its steps run through them row by row
     int nColMine = 0;
     if ((int)blockIdx.x < nCols) nColMine = (nCols - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
     const int nSteps = nColMine * a.F;
 
-    f32x4 acc[2][2][9], accb[2];
+    f32x4 acc[MTL][NTL][9], accb[MTL];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MTL; ++m) {
         accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NTL; ++n)
 #pragma unroll
             for (int k = 0; k < 9; ++k) acc[m][n][k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -970,15 +986,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
         const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.shift), 0, pro ? (unsigned)a.Cin * 4u : 0u, 0x00020000);
         // per-thread item constants (computed once: the step loop only adds a uniform offset and selects, no divisions and no
-        // divergent branches): dY item i = (cout row, quad of 8), x item i = (cin, quad of 12)
+        // divergent branches): dY item i = (cout row, quad of TT / 4), x item i = (cin, quad of XQ)
         int y_q[C::DY_PER_T], y_valid[C::DY_PER_T];
         unsigned y_lds[C::DY_PER_T], y_base[C::DY_PER_T];
 #pragma unroll
         for (int i = 0; i < C::DY_PER_T; ++i) {
-            const int it = pt + i * 256, cl = it >> 3;
-            y_q[i] = it & 7;
-            const int row = cl & 15;
-            y_lds[i] = (unsigned)(cl * 64 + ((((y_q[i] >> 1) ^ ((-(row >> 2)) & 3)) & 3) * 16) + (y_q[i] & 1) * 8);
+            const int it = pt + i * 256, cl = it / (C::TT / 4);
+            y_q[i] = it % (C::TT / 4);
+            const int row = cl & 15, q8 = y_q[i] & 7, ks = y_q[i] >> 3;          // 32-t slice ks, quad q8 of its 8
+            y_lds[i] = (unsigned)((ks * C::COUT_T + cl) * 64 + ((((q8 >> 1) ^ ((-(row >> 2)) & 3)) & 3) * 16) + (q8 & 1) * 8);
             y_valid[i] = (it < C::DY_ITEMS) & (cout0 + cl < a.Cout);
             y_base[i] = (unsigned)((cout0 + cl) * Fg * a.T + 4 * y_q[i]);
         }
@@ -988,8 +1004,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
         float x_sc[C::X_PER_T], x_sh[C::X_PER_T];
 #pragma unroll
         for (int i = 0; i < C::X_PER_T; ++i) {
-            const int it = pt + i * 256, cl = it / 12;
-            x_q[i] = it % 12;
+            const int it = pt + i * 256, cl = it / C::XQ;
+            x_q[i] = it % C::XQ;
             x_lds[i] = (unsigned)(cl * C::XCH + x_q[i] * 8);
             x_bnd[i] = (unsigned)(cl * C::XB_CH);
             x_item[i] = it < C::X_ITEMS;
@@ -999,7 +1015,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
             x_sc[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_sc, ok ? (unsigned)(cin0 + cl) * 4u : 0x80000000u, 0, 0));
             x_sh[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_sh, ok ? (unsigned)(cin0 + cl) * 4u : 0x80000000u, 0, 0));
         }
-        constexpr int NB = 2;                              // raw register sets = steps whose loads are in flight
+        constexpr int NB = C::NB;                          // raw register sets = steps whose loads are in flight
         u32x4_t ry[NB][C::DY_PER_T], rx[NB][C::X_PER_T];
         unsigned ryi[NB][C::DY_PER_T];
         int ry_n[NB][C::DY_PER_T], rx_n[NB][C::X_PER_T], r_par[NB];
@@ -1096,7 +1112,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
                     // boundary words: quad 1 + 2 j ends with x[8 j - 1] (low half of word j), quad 4 + 2 j starts with x[8 j + 8]
                     // (high half of word j); relative to the row image the centre starts at element 8
                     const int q = x_q[i];
-                    const bool lo_w = (q & 1) && q <= 7, hi_w = !(q & 1) && q >= 4 && q <= 10;
+                    const bool lo_w = (q & 1) && q <= 2 * C::NJ - 1, hi_w = !(q & 1) && q >= 4 && q <= 2 * C::NJ + 2;
                     if (lo_w || hi_w) {
                         const float bv = lo_w ? v[3] : v[0];
                         const int j = lo_w ? (q - 1) >> 1 : (q - 4) >> 1;
@@ -1114,37 +1130,55 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2 % NB>;
+        using I3 = std::integral_constant<int, 3 % NB>;
         constexpr bool P_LD = !(WGPC_DBG & 1), P_ST = !(WGPC_DBG & 2);
-        // prologue: x rows 0 and 1, dY of step 0 staged; the loads of {dY 1, x row 2} in flight
+        // Raw set k % NB holds the pair {dY of step k, x row k + 1}.  Prologue: x rows 0 and 1 and dY of step 0 staged, the pairs
+        // of steps 1 .. NB in flight.
         if (P_LD) { load_dy(0, I0{}); load_x(0, I0{}); }
         if (nSteps > 1 && P_LD) load_x(1, I1{});
         if (P_ST) { store_dy(0, I0{}); store_x(0, I0{}); }
         if (nSteps > 1 && P_ST) store_x(1, I1{});
-        if (nSteps > 1 && P_LD) load_dy(1, I1{});
-        if (nSteps > 2 && P_LD) load_x(2, I1{});
-        if (nSteps > 2 && P_LD) load_dy(2, I0{});
-        if (nSteps > 3 && P_LD) load_x(3, I0{});
+        auto load_pair = [&](int k, auto buf_c) __attribute__((always_inline)) {
+            if (k < nSteps && P_LD) load_dy(k, buf_c);
+            if (k + 1 < nSteps && P_LD) load_x(k + 1, buf_c);
+        };
+        load_pair(1, I1{});
+        if (NB == 2) {
+            load_pair(2, I0{});
+        } else {
+            load_pair(2, I2{}); load_pair(3, I3{}); load_pair(4, I0{});
+        }
         __syncthreads();
-        // during step S (consumers: dY stage S % 2, x rows S - 1, S, S + 1): stage dY of step S + 1 and x row S + 2 from raw set
-        // (S + 1) % 2, then re-load that set with {dY of step S + 3, x row S + 4}
+        // during step S (consumers: dY stage S % 2, x rows S - 1, S, S + 1): stage the pair of step S + 1 (dY of step S + 1, x row
+        // S + 2), then re-load its raw set with the pair of step S + 1 + NB
         auto stage_step = [&](int S, auto buf_c) __attribute__((always_inline)) {
             using BUF = decltype(buf_c);
             if (S + 1 < nSteps && P_ST) store_dy((S + 1) & 1, BUF{});
             if (S + 2 < nSteps && P_ST) store_x((S + 2) & 3, BUF{});
-            if (S + 3 < nSteps && P_LD) load_dy(S + 3, BUF{});
-            if (S + 4 < nSteps && P_LD) load_x(S + 4, BUF{});
+            load_pair(S + 1 + NB, BUF{});
             __syncthreads();
         };
-        for (int S = 0; S < nSteps; S += 2) {
-            stage_step(S, I1{});
-            if (S + 1 < nSteps) stage_step(S + 1, I0{});
+        if (NB == 2) {
+            for (int S = 0; S < nSteps; S += 2) {
+                stage_step(S, I1{});
+                if (S + 1 < nSteps) stage_step(S + 1, I0{});
+            }
+        } else {
+            for (int S = 0; S < nSteps; S += 4) {
+                stage_step(S, I1{});
+                if (S + 1 < nSteps) stage_step(S + 1, I2{});
+                if (S + 2 < nSteps) stage_step(S + 2, I3{});
+                if (S + 3 < nSteps) stage_step(S + 3, I0{});
+            }
         }
     } else if (nSteps > 0) {
         // ================================================================ CONSUMER
         const u32x4_t ones = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-        const unsigned a_lane = (unsigned)(lr * 64 + (((lq ^ ((-(lr >> 2)) & 3)) & 3) * 16));     // dY fragment: row lr, t group lq
-        const unsigned b_lane = (unsigned)(lr * C::XCH + 16 + lq * 16);                            // x fragment: cin lr, t = 8 lq .. + 7 of the centre
-        const unsigned bnd_lane = (unsigned)(lr * C::XB_CH + lq * 4);                              // its boundary word
+        // dY fragment: slice wks, row lr, t group lq;  x fragment: cin lr, t = 32 wks + 8 lq .. + 7 of the centre;  its boundary word
+        const unsigned a_lane = (unsigned)(wks * C::COUT_T * 64 + lr * 64 + (((lq ^ ((-(lr >> 2)) & 3)) & 3) * 16));
+        const unsigned b_lane = (unsigned)(lr * C::XCH + 16 + (wks * 4 + lq) * 16);
+        const unsigned bnd_lane = (unsigned)(lr * C::XB_CH + (wks * 4 + lq) * 4);
         auto step = [&](int S) __attribute__((always_inline)) {
             const int f = S % a.F;
             const unsigned char* dy_s = lds + (S & 1) * C::DY_STAGE;
@@ -1153,47 +1187,57 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
             xoff[0] = (unsigned)(C::X_BASE + (f > 0 ? ((S - 1) & 3) : 4) * C::X_SLOT);
             xoff[1] = (unsigned)(C::X_BASE + (S & 3) * C::X_SLOT);
             xoff[2] = (unsigned)(C::X_BASE + (f + 1 < a.F ? ((S + 1) & 3) : 4) * C::X_SLOT);
-            u32x4_t af[2][3];
+            u32x4_t af[MTL][3];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MTL; ++m)
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
-                    af[m][p] = *reinterpret_cast<const u32x4_t*>(dy_s + p * C::DY_PART + ((wmi * 2 + m) * 16) * 64 + a_lane);
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
+                    af[m][p] = *reinterpret_cast<const u32x4_t*>(dy_s + p * C::DY_PART + ((wmi * MTL + m) * 16) * 64 + a_lane);
+            // x fragments of the (kernel row, cin tile) pairs one pair ahead: the reads of pair j + 1 are in flight during the shift
+            // arithmetic and the MFMAs of pair j (the scheduler alone sinks every read to its use)
+            u32x4_t craw[2][3];
+            unsigned wraw[2][3];
+            auto read_x = [&](int j, u32x4_t (&cr)[3], unsigned (&wr)[3]) __attribute__((always_inline)) {
+                const int kh = j / NTL, n = j % NTL;
                 const unsigned char* x_s = lds + xoff[kh];
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    u32x4_t c[3], left[3], right[3];
+                for (int p = 0; p < 3; ++p) {
+                    cr[p] = *reinterpret_cast<const u32x4_t*>(x_s + p * C::X_PART + ((wni * NTL + n) * 16) * C::XCH + b_lane);
+                    // {x[t - 1] (low half), x[t + 8] (high half)} of this lane's 8-element group
+                    wr[p] = *reinterpret_cast<const unsigned*>(x_s + 3 * C::X_PART + p * C::XB_PART + ((wni * NTL + n) * 16) * C::XB_CH + bnd_lane);
+                }
+            };
+            read_x(0, craw[0], wraw[0]);
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        const unsigned char* row = x_s + p * C::X_PART + ((wni * 2 + n) * 16) * C::XCH + b_lane;
-                        c[p] = *reinterpret_cast<const u32x4_t*>(row);
-                        // {x[t - 1] (low half), x[t + 8] (high half)} of this lane's 8-element group
-                        const unsigned w = *reinterpret_cast<const unsigned*>(x_s + 3 * C::X_PART + p * C::XB_PART +
-                                                                                 ((wni * 2 + n) * 16) * C::XB_CH + bnd_lane);
-                        const unsigned s1 = __builtin_amdgcn_alignbit(c[p].y, c[p].x, 16), s2 = __builtin_amdgcn_alignbit(c[p].z, c[p].y, 16),
-                                       s3 = __builtin_amdgcn_alignbit(c[p].w, c[p].z, 16);
-                        left[p] = u32x4_t{__builtin_amdgcn_perm(c[p].x, w, 0x05040100u), s1, s2, s3};     // x[t-1 .. t+6]
-                        right[p] = u32x4_t{s1, s2, s3, __builtin_amdgcn_perm(w, c[p].w, 0x07060302u)};    // x[t+1 .. t+8]
-                    }
-                    // six part products of the six (m, kw) accumulators round-robin, smallest first
+            for (int j = 0; j < 3 * NTL; ++j) {
+                const int kh = j / NTL, n = j % NTL, cur = j & 1;
+                if (j + 1 < 3 * NTL) read_x(j + 1, craw[cur ^ 1], wraw[cur ^ 1]);
+                u32x4_t c[3], left[3], right[3];
 #pragma unroll
-                    for (int pp = 0; pp < 6; ++pp) {
-                        const int pa = pp == 0 ? 2 : pp == 1 ? 0 : pp == 2 ? 1 : pp == 3 ? 1 : 0;     // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
-                        const int pb = pp == 0 ? 0 : pp == 1 ? 2 : pp == 2 ? 1 : pp == 3 ? 0 : pp == 4 ? 1 : 0;
+                for (int p = 0; p < 3; ++p) {
+                    c[p] = craw[cur][p];
+                    const unsigned w = wraw[cur][p];
+                    const unsigned s1 = __builtin_amdgcn_alignbit(c[p].y, c[p].x, 16), s2 = __builtin_amdgcn_alignbit(c[p].z, c[p].y, 16),
+                                   s3 = __builtin_amdgcn_alignbit(c[p].w, c[p].z, 16);
+                    left[p] = u32x4_t{__builtin_amdgcn_perm(c[p].x, w, 0x05040100u), s1, s2, s3};     // x[t-1 .. t+6]
+                    right[p] = u32x4_t{s1, s2, s3, __builtin_amdgcn_perm(w, c[p].w, 0x07060302u)};    // x[t+1 .. t+8]
+                }
+                // six part products of the (m, kw) accumulators round-robin, smallest first
 #pragma unroll
-                        for (int m = 0; m < 2; ++m) {
-                            acc[m][n][kh * 3 + 0] = wg_mfma(af[m][pa], left[pb], acc[m][n][kh * 3 + 0]);
-                            acc[m][n][kh * 3 + 1] = wg_mfma(af[m][pa], c[pb], acc[m][n][kh * 3 + 1]);
-                            acc[m][n][kh * 3 + 2] = wg_mfma(af[m][pa], right[pb], acc[m][n][kh * 3 + 2]);
-                        }
+                for (int pp = 0; pp < 6; ++pp) {
+                    const int pa = pp == 0 ? 2 : pp == 1 ? 0 : pp == 2 ? 1 : pp == 3 ? 1 : 0;     // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+                    const int pb = pp == 0 ? 0 : pp == 1 ? 2 : pp == 2 ? 1 : pp == 3 ? 0 : pp == 4 ? 1 : 0;
+#pragma unroll
+                    for (int m = 0; m < MTL; ++m) {
+                        acc[m][n][kh * 3 + 0] = wg_mfma(af[m][pa], left[pb], acc[m][n][kh * 3 + 0]);
+                        acc[m][n][kh * 3 + 1] = wg_mfma(af[m][pa], c[pb], acc[m][n][kh * 3 + 1]);
+                        acc[m][n][kh * 3 + 2] = wg_mfma(af[m][pa], right[pb], acc[m][n][kh * 3 + 2]);
                     }
                 }
             }
             if (do_bias) {
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < MTL; ++m)
 #pragma unroll
                     for (int p = 0; p < 3; ++p) accb[m] = wg_mfma(af[m][2 - p], ones, accb[m]);
             }
@@ -1205,25 +1249,32 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
         }
     }
 
-    // ---- reduce: transpose the block's partial dW through LDS, then row-contiguous atomics (as conv_wgrad_bf16_kernel)
+    // ---- reduce: transpose the block's partial dW through LDS (the KS time slices add up there, one after the other), then
+    // row-contiguous atomics (as conv_wgrad_bf16_kernel)
     __syncthreads();
     float* out_s = smem;                             // [OUT_ROWS][OUT_ROW]
     const int ncol = min(C::CIN_T, a.Cin - cin0) * 9;
     const int slot = a.nslots > 1 ? (int)(blockIdx.x % a.nslots) : 0;
     float* dwp = a.dw + (size_t)slot * a.slot_w;
+    constexpr int WROWS = MTL * 16;                  // cout rows of a consumer wave
 #pragma unroll 1
     for (int part = 0; part < (C::COUT_T + C::OUT_ROWS - 1) / C::OUT_ROWS; ++part) {
-        if (part > 0) __syncthreads();
-        if (consumer && (wmi * 32) / C::OUT_ROWS == part) {
+#pragma unroll 1
+        for (int ks = 0; ks < KS; ++ks) {
+            if (part > 0 || ks > 0) __syncthreads();
+            if (consumer && wks == ks && (wmi * WROWS) / C::OUT_ROWS == part) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < MTL; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                    for (int n = 0; n < NTL; ++n)
 #pragma unroll
-                    for (int kk = 0; kk < 9; ++kk)
+                        for (int kk = 0; kk < 9; ++kk)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            out_s[((wmi * 32) % C::OUT_ROWS + m * 16 + lq * 4 + r) * C::OUT_ROW + ((wni * 2 + n) * 16 + lr) * 9 + kk] = acc[m][n][kk][r];
+                            for (int r = 0; r < 4; ++r) {
+                                float* o = &out_s[((wmi * WROWS) % C::OUT_ROWS + m * 16 + lq * 4 + r) * C::OUT_ROW + ((wni * NTL + n) * 16 + lr) * 9 + kk];
+                                *o = ks == 0 ? acc[m][n][kk][r] : *o + acc[m][n][kk][r];
+                            }
+            }
         }
         __syncthreads();
         for (int row = wave; row < C::OUT_ROWS; row += 8) {
@@ -1235,10 +1286,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
     }
     if (consumer && do_bias && lr == 0) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MTL; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int cout = cout0 + (wmi * 2 + m) * 16 + lq * 4 + r;
+                const int cout = cout0 + (wmi * MTL + m) * 16 + lq * 4 + r;
                 if (cout < a.Cout) atomicAdd(&a.db[(size_t)slot * a.slot_b + cout], accb[m][r]);
             }
     }
@@ -1256,6 +1307,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
 // ============================================================================================
 template <int KW>
 struct Wgrad1dPcCfg {
+    static constexpr bool COLUMNS = true;
     static constexpr int FT = 1, TT = 32, KK = KW, NT = 512;
     static constexpr int MTL = 4, NTL = KW == 3 ? 2 : 4;                 // 16-row tiles per consumer wave: cout, cin
     static constexpr int COUT_T = 2 * MTL * 16, CIN_T = 2 * NTL * 16;    // 2 x 2 consumer waves
@@ -1483,16 +1535,29 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_pc_kernel(ConvWgradArgs a) {
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
                     af[m][p] = *reinterpret_cast<const u32x4_t*>(dy_s + p * C::DY_PART + ((wmi * C::MTL + m) * 16) * 64 + a_lane);
+            // x fragments one cin tile ahead of the MFMAs that use them
+            u32x4_t craw[2][3];
+            unsigned wraw[2][3];
+            auto read_x = [&](int n, u32x4_t (&cr)[3], unsigned (&wr)[3]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    cr[p] = *reinterpret_cast<const u32x4_t*>(x_s + p * C::X_PART + ((wni * C::NTL + n) * 16) * C::XCH + b_lane);
+                    // {x[t - 1] (low half), x[t + 8] (high half)} of this lane's 8-element group
+                    if (KW == 3)
+                        wr[p] = *reinterpret_cast<const unsigned*>(x_s + 3 * C::X_PART + p * C::XB_PART + ((wni * C::NTL + n) * 16) * C::XB_CH + bnd_lane);
+                }
+            };
+            read_x(0, craw[0], wraw[0]);
 #pragma unroll
             for (int n = 0; n < C::NTL; ++n) {
+                const int cur = n & 1;
+                if (n + 1 < C::NTL) read_x(n + 1, craw[cur ^ 1], wraw[cur ^ 1]);
                 u32x4_t c[3], left[3], right[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    c[p] = *reinterpret_cast<const u32x4_t*>(x_s + p * C::X_PART + ((wni * C::NTL + n) * 16) * C::XCH + b_lane);
+                    c[p] = craw[cur][p];
                     if (KW == 3) {
-                        // {x[t - 1] (low half), x[t + 8] (high half)} of this lane's 8-element group
-                        const unsigned w = *reinterpret_cast<const unsigned*>(x_s + 3 * C::X_PART + p * C::XB_PART +
-                                                                                 ((wni * C::NTL + n) * 16) * C::XB_CH + bnd_lane);
+                        const unsigned w = wraw[cur][p];
                         const unsigned s1 = __builtin_amdgcn_alignbit(c[p].y, c[p].x, 16), s2 = __builtin_amdgcn_alignbit(c[p].z, c[p].y, 16),
                                        s3 = __builtin_amdgcn_alignbit(c[p].w, c[p].z, 16);
                         left[p] = u32x4_t{__builtin_amdgcn_perm(c[p].x, w, 0x05040100u), s1, s2, s3};     // x[t-1 .. t+6]
@@ -1605,6 +1670,21 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     static const bool pc_on = getenv("PBSED_WGRAD_PC") ? atoi(getenv("PBSED_WGRAD_PC")) != 0 : true;
     if (!a.bf16 && KH == 3 && KW == 3 && (a.T & 3) == 0) {
         if (pc_on && x3_2d == 0 && a.Cin >= 64 && a.Cout >= 64) return launch_wgrad_cfg<WgradPcCfg<2, 2>>(conv_wgrad_pc_kernel<2, 2>, a, s);
+        // the 32->32 layer: the same kernel with its consumer waves slicing the step's time range (KS = 2: 64 t per step, wave =
+        // 32 cout x 16 cin x one 32-t slice) - one block covers all of cout x cin: 0.278 -> 0.190 ms against the fp32-MFMA kernel.
+        // Measured and NOT taken (PBSED_WGRAD_PC_SMALL=2 runs them): 16->16 (KS = 4) 0.197 -> 0.316 ms, 16->32 0.169 -> 0.200,
+        // 32->64 0.148 (fp32 Winograd) -> 0.173 - with one or two MFMA tiles per wave and step (18 .. 36 MFMAs per kernel row)
+        // nothing covers the LDS round trip and the shift arithmetic of the next fragment, and 16->16 has 128 columns for 256 CUs
+        static const int pc_small = getenv("PBSED_WGRAD_PC_SMALL") ? atoi(getenv("PBSED_WGRAD_PC_SMALL")) : 1;
+        if (pc_on && pc_small && x3_2d == 0 && a.Cin >= 16 && a.Cout >= 16) {
+            if (a.Cin == 32 && a.Cout == 32) return launch_wgrad_cfg<WgradPcCfg<1, 2, 2, 2, 1>>(conv_wgrad_pc_kernel<1, 2, 2, 2, 1>, a, s);
+            if (pc_small >= 2) {
+                if (a.Cin <= 16 && a.Cout <= 16) return launch_wgrad_cfg<WgradPcCfg<1, 1, 4, 1, 1>>(conv_wgrad_pc_kernel<1, 1, 4, 1, 1>, a, s);
+                if (a.Cin <= 16 && a.Cout <= 32) return launch_wgrad_cfg<WgradPcCfg<1, 1, 4, 2, 1>>(conv_wgrad_pc_kernel<1, 1, 4, 2, 1>, a, s);
+                if (a.Cin <= 32 && a.Cout <= 32) return launch_wgrad_cfg<WgradPcCfg<1, 2, 2, 2, 1>>(conv_wgrad_pc_kernel<1, 2, 2, 2, 1>, a, s);
+                if (a.Cin <= 32) return launch_wgrad_cfg<WgradPcCfg<2, 1, 2, 2, 2>>(conv_wgrad_pc_kernel<2, 1, 2, 2, 2>, a, s);      // 64-cout blocks
+            }
+        }
         if (x3_2d >= 4 && a.Cin >= 32 && a.Cout >= 32) {
             if ((a.Cout <= 64 || x3_2d == 5) && a.Cin >= 64) return launch_wgrad_cfg<WgradPcCfg<2, 2>>(conv_wgrad_pc_kernel<2, 2>, a, s);
             return launch_wgrad_cfg<WgradPcCfg<4, 1>>(conv_wgrad_pc_kernel<4, 1>, a, s);

@@ -27,7 +27,8 @@ struct PackDesc {
     int mode;      // 0/1: direct forward / data-gradient layout, 2/3: Winograd forward / data-gradient layout,
                    // 4/5: bf16 [tap][OutP][InP] forward / data-gradient layout (dst holds uint16), 6/7: its three-part form,
                    // 8/9: bf16x3 Winograd fragment layout forward / data gradient (csrc/conv_winox3.hip),
-                   // 10/11: bf16x3 Conv1d fragment layout forward / data gradient (csrc/conv1d_pc.hip)
+                   // 10/11: bf16x3 Conv1d fragment layout forward / data gradient (csrc/conv1d_pc.hip),
+                   // 12: dst [Cin][Cout] = src^T (fp32; KH, KW, InP, OutP unused)
     int pad_;
 };
 
@@ -40,6 +41,14 @@ __device__ __forceinline__ unsigned short f2bf_rne(float x) {
 __global__ void pack_batched_kernel(const PackDesc* __restrict__ descs) {
     const PackDesc d = descs[blockIdx.y];
     const int KK = d.KH * d.KW;
+    if (d.mode >= 12) {                                  // plain transpose of a [Cout][Cin] matrix (the GRU scans' W^T operands)
+        const size_t total = (size_t)d.Cout * d.Cin;
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const size_t c = i / d.Cout, r = i % d.Cout;     // dst [Cin][Cout]
+            d.dst[i] = d.src[r * d.Cin + c];
+        }
+        return;
+    }
     if (d.mode >= 10) {                                  // csrc/conv1d_pc.hip: fragment-ordered three-part Conv1d weights (KH = 1)
         const size_t total = (size_t)d.KW * d.InP * d.OutP * 3;
         unsigned short* dst = reinterpret_cast<unsigned short*>(d.dst);

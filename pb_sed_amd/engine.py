@@ -486,8 +486,8 @@ def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
         d = stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True, want_tbc=True)
         dy_top.append(d if isinstance(c[0][0], str) else ops.bct_to_tbc(d))      # time-major heads hand back [T,B,H]
     idx = [(ch, l) for ch in chains for l in range(nl)]
-    w_hh_t = [ops.transpose2d(ch.p('weight_hh', l).detach()) for ch, l in idx]
-    w_ih_up_t = [ops.transpose2d(ch.p('weight_ih', l + 1).detach()) if l + 1 < nl else None for ch, l in idx]
+    w_hh_t = [ops.transposed(ch.p('weight_hh', l)) for ch, l in idx]
+    w_ih_up_t = [ops.transposed(ch.p('weight_ih', l + 1)) if l + 1 < nl else None for ch, l in idx]
     dgi, dgh = ops.gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, [ch.reverse for ch in chains], seq_dev, nl,
                                  precision='bf16' if precision == 'bf16' else 'f32')
     dh = None
@@ -508,7 +508,7 @@ def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
                 dh = dx if dh is None else dh.add_(dx)
     if pcs0[0] is None:
         # data gradient of the first layers' input projections, all chains in one time-major product: dh = sum_c dgi_c W_ih,c
-        w_t = [ops.transpose2d(ch.p('weight_ih', 0).detach()) for ch in chains]
+        w_t = [ops.transposed(ch.p('weight_ih', 0)) for ch in chains]
         dh = ops.tbc_to_bct(ops.tm_gemm([dgi[ci * nl] for ci in range(len(chains))], w_t, None, _gemm_prec(precision, w_t[0].shape[1]), role='bwd'))
     if jobs[0]:
         ops.gru_wgrad(*jobs, precision='bf16' if precision == 'bf16' else 'f32')
@@ -609,7 +609,7 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     padded = []                                  # (gradient of a zero-padded W_ih, the parameter's gradient)
     for l in reversed(range(num_layers)):
         src, pcs, hs, save = layer_ctx[l]
-        w_hh_t = [ops.transpose2d(ch.p('weight_hh', l).detach()) for ch in chains]
+        w_hh_t = [ops.transposed(ch.p('weight_hh', l)) for ch in chains]
         if _scan_as_stack(wrappers):
             dgi, dgh = ops.gru_stack_bwd(w_hh_t, [None] * len(chains), hs, save, dy, [ch.reverse for ch in chains],
                                          seq_dev, 1, precision='bf16' if precision == 'bf16' else 'f32')
@@ -645,7 +645,7 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
         for wi in range(len(wrappers)):
             mine = of_w[wi]
             if pcs[mine[0]] is None:
-                w_t = [ops.transpose2d(chains[i].p('weight_ih', l).detach()) for i in mine]       # [In, 3H]
+                w_t = [ops.transposed(chains[i].p('weight_ih', l)) for i in mine]       # [In, 3H]
                 k_in = src[wi][0].shape[2] if len(src[wi]) == 1 else w_t[0].shape[0]
                 if k_in != w_t[0].shape[0]:               # zero-padded input channels: zero rows
                     w_t = [torch.cat([w, w.new_zeros((k_in - w.shape[0], w.shape[1]))]) for w in w_t]

@@ -513,6 +513,27 @@ def tbc_to_bct(x, shift=0):
     return y
 
 
+def transposed(param):
+    """W^T of a 2-D parameter, cached ON the parameter per version and refreshed with the packed conv weights in the one
+    launch after every optimiser step (refresh_packs, mode 12) instead of one transpose launch per matrix and step."""
+    key = (param._version, PACK_EPOCH[0], param.data_ptr())
+    cache = getattr(param, '_pbsed_pack', None)
+    if cache is None or cache.get('key') != key:
+        cache = {'key': key}
+        try:
+            param._pbsed_pack = cache
+        except AttributeError:
+            pass
+    if 'T' in cache:
+        return cache['T']
+    w = param.detach()
+    y = transpose2d(w)
+    cache['T'] = y
+    r, c = w.shape
+    _register_pack(param, w, y, (r, c, 1, 1, c, r), 12, 'T')
+    return y
+
+
 def transpose2d(x):
     r, c = x.shape
     y = torch.empty((c, r), device=x.device, dtype=torch.float32)

@@ -173,7 +173,7 @@ def load_init_checkpoint(model, state_dict):
     return sorted(picked)
 
 class Trainer:
-    def __init__(self, model, lr=5e-4, gradient_clipping=1e10, betas=(.9, .999), eps=1e-8, allreduce=None):
+    def __init__(self, model, lr=5e-4, gradient_clipping=1e10, betas=(.9, .999), eps=1e-8, allreduce=None, flag_check_lag=1):
         """``allreduce``: 'torch' (torch.distributed all_reduce on the initialised process group: "nccl" = RCCL on
         ROCm; default) or 'library' (the C-ABI's own RCCL communicator, LibraryGradSync); env PBSED_ALLREDUCE."""
         self.model = model
@@ -191,7 +191,16 @@ class Trainer:
         self.allreduce = allreduce
         model._grad_hook = self._on_grads_ready
         self._defer = 'defer_summary' in inspect.signature(model.review).parameters
-        self._flags_host = torch.zeros(ops.GRU_FLAG_WORDS, dtype=torch.int32).pin_memory() if self.flat_param.is_cuda else None
+        # Error words of the persistent scans.  The device side is immediate: a step whose scan timed out skips its own Adam
+        # update (adam_step's skip_flags).  The HOST looks at step n's words when step n + flag_check_lag returns (default 1; the
+        # words are sticky, so nothing is lost): waiting for them inside step n means waiting for the END of step n's device
+        # work before the first launch of step n + 1 can be enqueued - the device then idles at every step boundary for as long
+        # as the host needs to get going again (0.3 .. 0.5 ms of a 10.8 ms step; 1.4 ms on a box with a slow host).  finish()
+        # looks at what is still pending; flag_check_lag=0 restores the check inside the step.
+        self.flag_check_lag = flag_check_lag
+        self._flags_hosts = [torch.zeros(ops.GRU_FLAG_WORDS, dtype=torch.int32).pin_memory() for _ in range(2)] \
+            if self.flat_param.is_cuda else None
+        self._pending_checks = []
         self.last_enqueue_s = 0.            # host time of the last step up to (not including) the wait for its summary
         self.measure_sync, self.sync_events = False, None   # bench.py: event pairs around the wait for the collectives
 
@@ -284,19 +293,30 @@ class Trainer:
         ops.invalidate_packed()          # parameters changed in place behind torch's version counters
         ops.refresh_packs()              # ... and every packed copy is rebuilt in one launch
         review['scalars']['grad_norm'] = self.grad_norm
-        checked = None
         if flags is not None and flags[1]:
-            self._flags_host.copy_(flags[0], non_blocking=True)       # rides along with the summary copy
+            host_words = self._flags_hosts[self.iteration & 1]
+            host_words.copy_(flags[0], non_blocking=True)
             checked = torch.cuda.Event()
             checked.record()
             flags[1] = 0
+            self._pending_checks.append((checked, host_words))
         if ops.scan_watch is not None:
             ops.scan_watch.check()               # completed event pairs only: a scan slowed down by CU contention warns
         self.last_enqueue_s = time.perf_counter() - t_start
         finalize = review.pop('_finalize', None)
         if finalize is not None:
             finalize()                               # host-side summary: waits for a copy issued after the forward pass
-        if checked is not None:
-            checked.synchronize()
-            ops.gru_flags_raise(self._flags_host.numpy())   # once per step, before the caller can use the results
+        self._check_flags(self.flag_check_lag)
         return review
+
+    def _check_flags(self, keep):
+        """Wait for and look at the scan error words of all but the last ``keep`` steps."""
+        while len(self._pending_checks) > keep:
+            checked, host_words = self._pending_checks.pop(0)
+            checked.synchronize()
+            ops.gru_flags_raise(host_words.numpy())
+
+    def finish(self):
+        """Look at the scan error words of the steps whose check is still pending (flag_check_lag > 0): call it before the
+        results of the last steps are used - at the end of an epoch, before a checkpoint or a validation pass."""
+        self._check_flags(0)

@@ -548,6 +548,39 @@ def test_bf16_weight_copies_follow_the_optimiser():
         assert torch.equal(fresh, e.dst), (e.dims, e.mode)
 
 
+def test_trainer_reports_a_timed_out_scan_one_step_late_and_never_updates_from_it():
+    """A raised scan error word: the step's own Adam update is skipped on the device at once; the host looks at step n's
+    words when step n + 1 returns (flag_check_lag = 1: it never waits for the end of a step before enqueuing the next one),
+    or in finish()."""
+    from pb_sed_amd import ops
+    from pb_sed_amd.models import strong_label
+    from pb_sed_amd.trainer import Trainer
+    torch.manual_seed(0)
+    net = dict(out_channels_2d=[16, 32], pool_sizes_2d=[1, (2, 1)], kernel_size_2d=3, out_channels_1d=[64], kernel_size_1d=[3])
+    model = strong_label.CRNN.build(num_events=10, hidden_size=64, num_layers=1, net=net, tag_conditioning=False).to(DEV)
+    wav, seq, weak, strong, t = synth_batch(4, 16000, 10, seed=3)
+    batch = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV), 'strong_targets': strong.to(DEV)}
+    for lag in (1, 0):
+        trainer = Trainer(model, lr=1e-2, flag_check_lag=lag)
+        trainer.step(batch)
+        trainer.finish()
+        before = trainer.flat_param.clone()
+        flags = ops.gru_flags(trainer.flat_param.device)
+        flags[0][ops.GRU_FLAG_WORDS - 1] = 1                 # as a scan's bounded spin would leave it
+        if lag == 0:
+            with pytest.raises(RuntimeError, match='timed out'):
+                trainer.step(batch)
+        else:
+            trainer.step(batch)                              # returns: the words of this step are looked at a step later ...
+            with pytest.raises(RuntimeError, match='timed out'):
+                trainer.finish()                             # ... or here
+        assert torch.equal(trainer.flat_param, before)       # the flagged step did not touch the parameters
+        assert not flags[0].any()                            # gru_flags_raise cleared the words
+        trainer.step(batch)
+        trainer.finish()
+        assert not torch.equal(trainer.flat_param, before)
+
+
 def test_time_major_1d_stack_matches_the_default_path(monkeypatch):
     """PBSED_TM_STACK=1 runs the CNN1d layers and the GRU output nets on the scans' time-major layout (pbsed_tm_conv_*):
     same scores, loss and gradients as the default kernels on the CNN layout (FBCRNN and tag-conditioned BiCRNN, ragged

@@ -98,6 +98,13 @@ CONV_CASES = [
     dict(cin=256, cout=256, f=1, t=500, k=(1, 3), pool=False, pro=True),
     dict(cin=200, cout=72, f=1, t=64, k=(1, 3), pool=False, pro=False),
     dict(cin=520, cout=136, f=1, t=130, k=(1, 1), pool=False, pro=True),      # k = 1: wide inputs only (>= 512 channels)
+    # 3x3 weight gradients of the 16- / 32-channel layers on the producer / consumer bf16x3 kernel with time-sliced consumer
+    # waves (rows 16-byte aligned: T % 4 == 0), partial time tiles, channel counts off the tiles
+    dict(cin=16, cout=16, f=8, t=152, k=(3, 3), pool=True, pro=True),
+    dict(cin=16, cout=32, f=6, t=260, k=(3, 3), pool=False, pro=True),
+    dict(cin=32, cout=32, f=8, t=132, k=(3, 3), pool=True, pro=True),
+    dict(cin=24, cout=40, f=5, t=100, k=(3, 3), pool=False, pro=False),
+    dict(cin=32, cout=128, f=4, t=64, k=(3, 3), pool=True, pro=True),
 ]
 
 
@@ -156,6 +163,21 @@ def test_conv_fwd_bwd_vs_torch(case):
     if not pro:
         g, _ = ops.conv_bwd_data(dx(gy), pc, pc.dgrad(), xd.shape, idx, None)
         close(g, xr.grad, atol=2e-4, rtol=1e-3, name='conv_dgrad')
+
+
+def test_conv_kernels_behind_experiment_switches():
+    """The weight-gradient kernels that are compiled in but not the default for their shapes (time-sliced producer / consumer
+    blocks for 16 / 32 channels: PBSED_WGRAD_PC_SMALL=2; the producer / consumer Conv1d k = 1 gradient below 512 inputs:
+    PBSED_WGRAD_PC=2) against the same torch references: the switches are read once per process, so the cases run in a child."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get('PBSED_TEST_CHILD'):
+        pytest.skip('already the child')
+    env = dict(os.environ, PBSED_WGRAD_PC_SMALL='2', PBSED_WGRAD_PC='2', PBSED_TEST_CHILD='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu', '-k', 'test_conv_fwd_bwd_vs_torch',
+                        '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
 def test_conv_bn_relu_backward_chain_vs_autograd():

@@ -148,3 +148,10 @@ for tagname, (kern, grid) in ROOFLINE_ROWS.items():
 if traffic:
     json.dump(traffic, open(os.path.join(out, 'roofline_traffic.json'), 'w'), indent=1)
     print('wrote profiles/roofline_traffic.json', list(traffic))
+
+# per-kernel counter sets of tools/prof_kernel.sh (FETCH / WRITE / TCC / SQ / MFMA passes of ONE kernel's own bench command)
+for pk, name in (('pk_wx', 'winox3'), ('pk_wgpc', 'wgrad_pc'), ('pk_c1', 'conv1d_pc')):
+    f = os.path.join(go, pk, 'summary.json')
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(out, f'{tag}_pmc_{name}.json'))
+        print('wrote', f'profiles/{tag}_pmc_{name}.json')
