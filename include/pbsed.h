@@ -320,37 +320,10 @@ int pbsed_gru_wgrad_multi(int n, const float* const* dg, const float* const* x, 
 int pbsed_tm_gemm(int n_src, const float* const* x, const float* const* w, const int* k /*host*/, const float* bias,
                   float* y, int R, int N, int bf16, void* stream);
 
-/* 1-D convolution layers (CNN1d stack, GRU output nets: pb_sed/experiments/weak_label_crnn/training.py:232-260) on the
- * scans' time-major layout [T, B, C] (rows r = t*B + b): a layer of kernel size n_taps (1 or 3, 'same' zero padding) is a
- * product with n_taps row-shifted sources, y[t] = bias + sum_tap w[tap] @ pro(x)[t + tap - n_taps/2], where
- * pro(x) = rowmask * relu?(x * scale + shift) is the fused batch-norm + ReLU + sequence-mask prologue of the CNN-layout
- * kernels (scale NULL: none).  w: host array of n_taps device matrices [N, K] (tap matrices of the Conv1d weight);
- * rowmask [T*B] = 1 / 0 from pbsed_tm_rowmask (NULL: no masking); stats: NULL or [PBSED_STAT_SLOTS][N][2] zeroed doubles
- * that receive the masked sums of y (batch statistics of the next layer's norm).  Same operand formats as pbsed_tm_gemm. */
-int pbsed_tm_conv_fwd(const float* x, int n_taps, const float* const* w /*host*/, const float* bias, const float* scale,
-                      const float* shift, int relu, const float* rowmask, float* y, double* stats, int T, int B, int K, int N,
-                      int bf16, void* stream);
-/* data gradient: g [T, B, N_out] -> dz [T, B, K_in]; wt: n_taps device matrices [K_in, N_out] (transposed taps).  bx != NULL:
- * backward through the layer's prologue (mask, ReLU, BN-apply of the raw input bx [T, B, K_in]) with the sums
- * (sum dz, sum dz * xhat) in stats - finish with pbsed_bn_bwd_tm. */
-int pbsed_tm_conv_bwd_data(const float* g, int n_taps, const float* const* wt /*host*/, const float* rowmask, float* dz,
-                           const float* bx, const float* bscale, const float* bshift, const float* bmean,
-                           const float* binvstd, int brelu, double* stats, int T, int B, int N_out, int K_in, int bf16,
-                           void* stream);
-/* weight / bias gradient: dw [N_out][K_in][n_taps] (the Conv1d weight layout) += sum_r g[r] (x) pro(x)[r + (tap - n_taps/2) B],
- * db [N_out] (or NULL) += column sums of g. */
-int pbsed_tm_conv_bwd_weight(const float* x, const float* g, int n_taps, const float* scale, const float* shift, int relu,
-                             const float* rowmask, float* dw, float* db, int T, int B, int K_in, int N_out, int bf16,
-                             void* stream);
-/* BN backward on [R, C] in place (pbsed_bn_bwd for the time-major layout); scratch: 2*C floats. */
-int pbsed_bn_bwd_tm(float* dz, const float* x, const double* sums, double count, const float* mean, const float* invstd,
-                    const float* scale, float* dgamma, float* dbeta, const float* rowmask, float* scratch, int R, int C,
-                    void* stream);
 /* masked per-channel sums (sum x, sum x^2 over frames < seq_len) of a network input x [B, C, S, T] into stats
  * [PBSED_STAT_SLOTS][C][2] (zeroed doubles): batch statistics of a FIRST layer that has its own pre-activation norm
  * (padertorch CNN input_layer=False; every other norm gets its statistics from the producing convolution's epilogue). */
 int pbsed_channel_stats(const float* x, const int* seq_len, double* stats, int B, int C, int S, int T, void* stream);
-int pbsed_tm_rowmask(const int* seq_len, float* mask, int T, int B, void* stream);
 /* A norm + ReLU that CLOSES a stack (padertorch pre-activation CNN1d / CNN2d with a final norm + activation behind the last
  * conv; SURVEY.md A.4 variant (iii) of pb_sed/experiments/weak_label_crnn/training.py:218-242): y = mask * relu(x * scale[c] +
  * shift[c]) on [B, C, S, T]; backward writes dz = dy * mask * relu'(z) and the (sum dz, sum dz * xhat) partial sums

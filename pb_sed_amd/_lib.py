@@ -66,11 +66,6 @@ SIGNATURES = {
     'pbsed_tbc_to_bct': [_v, _v, I, I, I, I, _v],
     'pbsed_transpose2d': [_v, _v, I, I, _v],
     'pbsed_gru_wgrad': [I, _pp, _pp, _i, _pp, _pp, I, I, I, I, _v],
-    'pbsed_tm_conv_fwd': [_v, I, _pp, _v, _v, _v, I, _v, _v, _v, I, I, I, I, I, _v],
-    'pbsed_tm_conv_bwd_data': [_v, I, _pp, _v, _v, _v, _v, _v, _v, _v, I, _v, I, I, I, I, I, _v],
-    'pbsed_tm_conv_bwd_weight': [_v, _v, I, _v, _v, I, _v, _v, _v, I, I, I, I, I, _v],
-    'pbsed_bn_bwd_tm': [_v, _v, _v, F64, _v, _v, _v, _v, _v, _v, _v, I, I, _v],
-    'pbsed_tm_rowmask': [_v, _v, I, I, _v],
     'pbsed_bn_relu_fwd': [_v, _v, _v, _v, _v, I, I, I, I, I, _v],
     'pbsed_bn_relu_bwd': [_v, _v, _v, _v, _v, _v, _v, _v, _v, I, I, I, I, I, _v],
     'pbsed_channel_stats': [_v, _v, _v, I, I, I, I, _v],

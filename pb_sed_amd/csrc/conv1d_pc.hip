@@ -267,6 +267,43 @@ __global__ __launch_bounds__(512) void conv1d_pc_kernel(ConvFwdArgs a, int nCt, 
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.bias), 0, a.bias ? (unsigned)a.Cout * 4u : 0u, 0x00020000);
 
+    // BN-backward epilogue of the data gradient: the layer's raw input of the wave's 32 x 128 tile (lane = 4 consecutive t, half a
+    // wave per row, 16 rows pairs) and the per-channel constants are requested at the START of a tile's last chunk, a chunk
+    // step ahead of the epilogue that uses them - the epilogue no longer begins with a round trip to HBM
+    const bool bnb = DGRAD && a.bx != nullptr;
+    u32x4_t xq[DGRAD ? 16 : 1];
+    float p_sc = 0.f, p_sh = 0.f, p_mu = 0.f, p_is = 0.f;
+    auto request_bx = [&]() __attribute__((always_inline)) {
+        constexpr unsigned OOB_C = 0x80000000u;
+        const int t0 = (sp % nTt) * C1_TT, b = sp / nTt, cout0 = ct * C1_CT;
+        const unsigned oclip = (unsigned)(a.Cout * a.T);
+        const __amdgpu_buffer_rsrc_t rs_bx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.bx) + (size_t)b * oclip, 0, oclip * 4u, 0x00020000);
+        const int half = lane >> 5, tq = t0 + 4 * (lane & 31);
+        const bool vec = (a.T & 3) == 0;
+        const int n_T = min(max(a.T - tq, 0), 4);
+        const int c = cout0 + wave * 32 + (lane & 31);
+        p_sc = p_sh = p_mu = p_is = 0.f;
+        if (c < a.Cout) { p_sc = a.bscale[c]; p_sh = a.bshift[c]; p_mu = a.bmean[c]; p_is = a.binvstd[c]; }
+#pragma unroll
+        for (int i = 0; i < (DGRAD ? 16 : 1); ++i) {
+            const int cout = cout0 + wave * 32 + 2 * i + half;
+            const unsigned e = (unsigned)(cout * a.T + tq);
+            if (vec) {
+                const unsigned ok = (unsigned)-(int)(cout < a.Cout && n_T > 0);
+                xq[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_bx, ((e * 4u) & ok) | (OOB_C & ~ok), 0, 0);
+            } else {
+                unsigned w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned ok = (unsigned)-(int)(cout < a.Cout && k < n_T);
+                    w[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_bx, (((e + (unsigned)k) * 4u) & ok) | (OOB_C & ~ok), 0, 0);
+                }
+                xq[i] = u32x4_t{w[0], w[1], w[2], w[3]};
+            }
+        }
+    };
+
     auto epilogue = [&]() __attribute__((always_inline)) {
         // Accumulator layout: t = t0 + 16 n + lr, cout = cout0 + 32 wave + 16 m + 4 lq + r - a store instruction would cover four
         // 64-byte row pieces.  The wave's 32 x 128 tile goes through its own LDS region instead and leaves as whole 512-byte rows
@@ -277,9 +314,6 @@ __global__ __launch_bounds__(512) void conv1d_pc_kernel(ConvFwdArgs a, int nCt, 
         const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
         const unsigned oclip = (unsigned)(a.Cout * a.T);
         const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)b * oclip, 0, oclip * 4u, 0x00020000);
-        const bool bnb = DGRAD && a.bx != nullptr;
-        const __amdgpu_buffer_rsrc_t rs_bx = __builtin_amdgcn_make_buffer_rsrc(
-            bnb ? const_cast<float*>(a.bx) + (size_t)b * oclip : nullptr, 0, bnb ? oclip * 4u : 0u, 0x00020000);
         const int slot = (int)(sp & (PBSED_STAT_SLOTS - 1));
         float* tr = reinterpret_cast<float*>(smem_raw + C1_LDS) + wave * (32 * C1_TRS);
         if (!DGRAD && a.stats) {
@@ -317,30 +351,7 @@ __global__ __launch_bounds__(512) void conv1d_pc_kernel(ConvFwdArgs a, int nCt, 
         const int half = lane >> 5, tq = t0 + 4 * (lane & 31);            // row parity of the lane, its first t
         const bool vec = (a.T & 3) == 0;                                  // rows 16-byte aligned
         const int n_T = min(max(a.T - tq, 0), 4), n_sl = min(max(sl - tq, 0), 4);
-        // BN-backward constants of the wave's channels: lane k < 32 fetches channel k's, rows pick them up with v_readlane
-        float p_sc = 0.f, p_sh = 0.f, p_mu = 0.f, p_is = 0.f;
-        u32x4_t xq[16];
-        if (bnb) {
-            const int c = cout0 + wave * 32 + (lane & 31);
-            if (c < a.Cout) { p_sc = a.bscale[c]; p_sh = a.bshift[c]; p_mu = a.bmean[c]; p_is = a.binvstd[c]; }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int cout = cout0 + wave * 32 + 2 * i + half;
-                const unsigned e = (unsigned)(cout * a.T + tq);
-                if (vec) {
-                    const unsigned ok = (unsigned)-(int)(cout < a.Cout && n_T > 0);
-                    xq[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_bx, ((e * 4u) & ok) | (OOB_C & ~ok), 0, 0);
-                } else {
-                    unsigned w[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const unsigned ok = (unsigned)-(int)(cout < a.Cout && k < n_T);
-                        w[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_bx, (((e + (unsigned)k) * 4u) & ok) | (OOB_C & ~ok), 0, 0);
-                    }
-                    xq[i] = u32x4_t{w[0], w[1], w[2], w[3]};
-                }
-            }
-        }
+        // (BN-backward constants: lane k < 32 holds channel k's, rows pick them up with v_readlane; xq: request_bx)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = 2 * i + half, cout = cout0 + wave * 32 + row;
@@ -405,6 +416,7 @@ __global__ __launch_bounds__(512) void conv1d_pc_kernel(ConvFwdArgs a, int nCt, 
                         rs_b, (unsigned)(ct * C1_CT + wave * 32 + m * 16 + lq * 4 + r) * 4u, 0, 0));      // beyond Cout / no bias: 0
             }
         }
+        if (DGRAD && bnb && ch == nChunks - 1) request_bx();
         u32x4_t Bf[2][2][3];                                          // [buffer][n of the pair][part]
         auto read_B = [&](int kw, int np, u32x4_t (&dst)[2][3]) __attribute__((always_inline)) {
 #pragma unroll

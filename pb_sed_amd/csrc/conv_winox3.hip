@@ -62,7 +62,10 @@ __global__ void winox3_pack_kernel(const float* __restrict__ w, unsigned short* 
         up[i] = pack_winox3_elem(w, i, Cout, Cin, InP, OutP, dgrad);
 }
 
-template <bool POOL, bool DGRAD, bool UNPOOL>
+// CT: cout per block.  64: consumer wave w owns cout tile w (16 cout) and all 4 rows.  32 (launches that produce <= 32
+// channels - with 64-cout blocks two of the four consumer waves would multiply zero padding): wave w owns cout tile w & 1 and
+// the row pair w >> 1, i.e. 16 cout x 2 rows x 16 tiles x 6 points (48 accumulator registers) and 4 of the 6 halo rows.
+template <bool POOL, bool DGRAD, bool UNPOOL, int CT = WX_CT>
 __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt, int nSp, int xcd_map, int nWork) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
@@ -374,33 +377,37 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
             for (int p = 0; p < 3; ++p)
                 A[slot][kh][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u, soff + kh * step_bytes + p * 1024u, 0);
     };
+    constexpr bool H32 = CT == 32;
+    constexpr int NF = H32 ? 2 : WX_FT;                              // output rows of a consumer wave
+    const int cw = H32 ? (wave & 1) : wave;                          // its 16-cout tile inside the block
+    const int f_lo = H32 ? (wave >> 1) * 2 : 0;                      // its first output row
     int ct, sp;
     item(0, ct, sp);
-    unsigned u_base = (unsigned)(ct * (WX_CT / 16) + wave) * 3072u;  // point 0 of chunk 0, this wave's cout tile
+    unsigned u_base = (unsigned)(ct * (CT / 16) + cw) * 3072u;       // point 0 of chunk 0, this wave's cout tile
     static_assert(WX_RING == 2, "the ring holds the current point and the next one");
     load_A(0, u_base);
 
-    f32x4 acc[6][4];
+    f32x4 acc[6][NF];
     __syncthreads();                                                 // half 0 of the first chunk is staged
     for (int k = 0; k < nT; ++k) {
         const int t0 = (sp % nTt) * WX_TT;
         const int f0 = ((sp / nTt) % nFt) * WX_FT;
         const int b = sp / (nTt * nFt);
-        const int cout0 = ct * WX_CT;
+        const int cout0 = ct * CT;
         const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
         int ct_n = ct, sp_n = sp;
         const bool more = k + 1 < nT && item(k + 1, ct_n, sp_n);
-        const unsigned u_base_n = more ? (unsigned)(ct_n * (WX_CT / 16) + wave) * 3072u : 0xC0000000u;   // past the end: reads 0
+        const unsigned u_base_n = more ? (unsigned)(ct_n * (CT / 16) + cw) * 3072u : 0xC0000000u;       // past the end: reads 0
 #pragma unroll
         for (int x = 0; x < 6; ++x)
 #pragma unroll
-            for (int fl = 0; fl < 4; ++fl) acc[x][fl] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int fl = 0; fl < NF; ++fl) acc[x][fl] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int ch = 0; ch < nChunks; ++ch) {
             const unsigned soff_u = u_base + (unsigned)ch * 6u * point_bytes;
             const unsigned soff_next = ch + 1 < nChunks ? soff_u + 6u * point_bytes : u_base_n;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                const unsigned char* vb = smem_raw + half * WX_HALF + v_lane;
+                const unsigned char* vb = smem_raw + half * WX_HALF + v_lane + f_lo * 1024;     // the wave's first halo row
                 u32x4_t Bf[2][3];                                        // V fragments of two halo rows: the next row's reads are
                 auto read_B = [&](int xl, int h, u32x4_t (&dst)[3]) __attribute__((always_inline)) {   // in flight during a row's MFMAs
 #pragma unroll
@@ -415,9 +422,9 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
                     if (!(WX_DBG & 4)) load_A((x + 1) % WX_RING, x + 1 < 6 ? soff_u + (unsigned)(x + 1) * point_bytes : soff_next);
                     if (WX_DBG & 8) continue;
 #pragma unroll
-                    for (int h = 0; h < WX_ROWS; ++h) {
-                        const int cur = (xl * WX_ROWS + h) & 1;
-                        if (h + 1 < WX_ROWS) read_B(xl, h + 1, Bf[cur ^ 1]);
+                    for (int h = 0; h < NF + 2; ++h) {                     // halo rows f_lo + h of the wave's NF output rows
+                        const int cur = (xl * (NF + 2) + h) & 1;
+                        if (h + 1 < NF + 2) read_B(xl, h + 1, Bf[cur ^ 1]);
                         else if (xl + 1 < 3) read_B(xl + 1, 0, Bf[cur ^ 1]);
                         // six part products, smallest first, round-robin over the (row, kh) sets of this halo row
 #pragma unroll
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
 #pragma unroll
                             for (int kh = 0; kh < 3; ++kh) {
                                 const int fl = h - kh;
-                                if (fl >= 0 && fl < WX_FT) acc[x][fl] = mfma_b16(A[x % WX_RING][kh][pa], Bf[cur][pb], acc[x][fl]);
+                                if (fl >= 0 && fl < NF) acc[x][fl] = mfma_b16(A[x % WX_RING][kh][pa], Bf[cur][pb], acc[x][fl]);
                             }
                         }
                     }
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
         constexpr int NFO = POOL ? 1 : 2;                             // output rows per row pair
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int cout = cout0 + wave * 16 + lq * 4 + r;
+            const int cout = cout0 + cw * 16 + lq * 4 + r;
             const bool cv = cout < a.Cout;
             const float bias = (a.bias && cv) ? a.bias[cout] : 0.f;
             const unsigned coff = cv ? (unsigned)(cout * Fo * a.T) * 4u : OOB_C;
@@ -466,7 +473,8 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
             if (bnb && cv) { bsc = a.bscale[cout]; bsh = a.bshift[cout]; bmu = a.bmean[cout]; bis = a.binvstd[cout]; }
             float c1 = 0.f, c2 = 0.f;                                   // per-channel statistics over the block's rows
 #pragma unroll
-            for (int rp = 0; rp < 2; ++rp) {                            // row pairs (0,1), (2,3): one pool window each
+            for (int rpl = 0; rpl < NF / 2; ++rpl) {                    // the wave's row pairs ((0,1), (2,3)): one pool window each
+                const int rp = rpl + f_lo / 2;
                 unsigned roff[NFO];
                 bool orow_ok[NFO];
                 int fo_of[NFO];
@@ -485,7 +493,7 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
                 float y[2][4];
 #pragma unroll
                 for (int fl = 0; fl < 2; ++fl) {
-                    const int f = rp * 2 + fl;
+                    const int f = rpl * 2 + fl;
                     const float m0 = acc[0][f][r], m1 = acc[1][f][r], m2 = acc[2][f][r], m3 = acc[3][f][r], m4 = acc[4][f][r],
                                 m5 = acc[5][f][r];
                     const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
     }
 }
 
-template <bool POOL, bool DGRAD, bool UNPOOL>
+template <bool POOL, bool DGRAD, bool UNPOOL, int CT = WX_CT>
 static int launch_winox3(const ConvFwdArgs& a, hipStream_t s) {
     using C = WxCfg<POOL>;
     // the loaders address one clip with 32-bit byte offsets (buffer loads; 2^31 marks "out of range")
@@ -572,7 +580,7 @@ static int launch_winox3(const ConvFwdArgs& a, hipStream_t s) {
     }
     if ((size_t)18 * a.CinP * a.CoutP * 6 >= (1ull << 31)) { set_error("conv_winox3: packed weights exceed 2 GiB"); return PBSED_E_ARG; }
     const int nTt = (a.T + WX_TT - 1) / WX_TT, nFt = (a.F + WX_FT - 1) / WX_FT;
-    const int nSp = nTt * nFt * a.B, nCt = a.CoutP / WX_CT;
+    const int nSp = nTt * nFt * a.B, nCt = (a.Cout + CT - 1) / CT;          // CT = 32: the padding tiles of CoutP are never visited
     static const int map_env = getenv("PBSED_WX_MAP") ? atoi(getenv("PBSED_WX_MAP")) : 3;
     int xcd_map = map_env, nWork;
     if (xcd_map == 1 && !(nCt <= 8 && 8 % nCt == 0)) xcd_map = 0;
@@ -586,7 +594,7 @@ static int launch_winox3(const ConvFwdArgs& a, hipStream_t s) {
     int blocks = device_cus() / 8 * 8;
     if (blocks < 8) blocks = 8;
     if (blocks > nWork) blocks = (nWork + 7) / 8 * 8;
-    auto kern = conv_winox3_kernel<POOL, DGRAD, UNPOOL>;
+    auto kern = conv_winox3_kernel<POOL, DGRAD, UNPOOL, CT>;
     PBSED_DYN_LDS_ONCE(kern, C::LDS_BYTES);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), C::LDS_BYTES, s, a, nCt, nSp, xcd_map, nWork);
     return check_launch("conv_winox3");
@@ -595,6 +603,11 @@ static int launch_winox3(const ConvFwdArgs& a, hipStream_t s) {
 }  // namespace pbsed
 
 using namespace pbsed;
+
+static bool wx_ct32() {                    // PBSED_WX_CT32=0: 64-cout blocks for every launch (two idle consumer waves at <= 32 channels)
+    static const bool on = getenv("PBSED_WX_CT32") ? atoi(getenv("PBSED_WX_CT32")) != 0 : true;
+    return on;
+}
 
 extern "C" {
 
@@ -623,6 +636,8 @@ int pbsed_conv_fwd_winox3(const float* x, const unsigned short* u_packed, const 
     a.y = y; a.pool_idx = pool_idx; a.stats = stats; a.stats_cf = stats_per_cf; a.relu = relu;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.F = F; a.T = T;
     pbsed_conv_pack_dims_winox3(Cin, Cout, 0, &a.CinP, &a.CoutP);
+    if (Cout <= 32 && wx_ct32())
+        return pool ? launch_winox3<true, false, false, 32>(a, (hipStream_t)stream) : launch_winox3<false, false, false, 32>(a, (hipStream_t)stream);
     return pool ? launch_winox3<true, false, false>(a, (hipStream_t)stream) : launch_winox3<false, false, false>(a, (hipStream_t)stream);
 }
 
@@ -637,6 +652,8 @@ int pbsed_conv_bwd_data_winox3(const float* g, const unsigned short* ud_packed, 
     a.relu = relu; a.stats = bx ? stats : nullptr;
     a.B = B; a.Cin = Cout; a.Cout = Cin; a.F = F; a.T = T;      // roles swapped
     pbsed_conv_pack_dims_winox3(Cin, Cout, 1, &a.CinP, &a.CoutP);
+    if (Cin <= 32 && wx_ct32())                                  // the launch produces the layer's Cin channels
+        return unpool_idx ? launch_winox3<false, true, true, 32>(a, (hipStream_t)stream) : launch_winox3<false, true, false, 32>(a, (hipStream_t)stream);
     return unpool_idx ? launch_winox3<false, true, true>(a, (hipStream_t)stream) : launch_winox3<false, true, false>(a, (hipStream_t)stream);
 }
 

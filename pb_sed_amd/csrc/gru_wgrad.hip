@@ -31,14 +31,6 @@ struct GruWgradArgs {
     // bf16-MFMA kernel: GEMMs of different K share a launch; blockIdx.y enumerates the (GEMM, column tile) pairs
     int Ks[GW_MAX];
     unsigned char y_gemm[4 * GW_MAX], y_tile[4 * GW_MAX];
-    // weight gradients of 1-D convolution layers on the time-major layout (pbsed_tm_conv_bwd_weight): prologue of X
-    // (v = rowmask * relu?(x * scale + shift), per input channel) and the element strides of dw (a tap of a [Cout][Cin][KW]
-    // weight is not contiguous)
-    const float* scale[GW_MAX];
-    const float* shift[GW_MAX];
-    const float* rowmask;     // [TB] or null
-    int relu;
-    int ldg[GW_MAX], ldk[GW_MAX];
     // many-way splits of small gradients: every (GEMM, split) writes its partial tile to its own slot [G][K_max] with plain
     // stores and gru_wgrad_slot_reduce_kernel adds the slots up - instead of nsplit atomics per gradient element
     float* slots;
@@ -155,8 +147,7 @@ __global__ __launch_bounds__(BN * 2) void gru_wgrad_kernel(GruWgradArgs a) {
 // (= columns c with the same c % 4, stride 4); the output indices follow the same bijection.
 constexpr int GB_BM = 128, GB_BN = 256, GB_KC = 32, GB_KG = GB_KC / 8;
 
-// EXT: the convolution form (prologue of X, sequence mask) - compiled out of the GRU launches.
-template <int NS, bool EXT>
+template <int NS>
 __global__ __launch_bounds__(512) void gru_wgrad_b16_kernel(GruWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4_t smem_b16[];
     u32x4_t* As = smem_b16;                              // [NS][KG][BM] 16-byte rows (8 bf16 along the contraction index)
@@ -188,23 +179,16 @@ __global__ __launch_bounds__(512) void gru_wgrad_b16_kernel(GruWgradArgs a) {
     // two stages of operand rows are in flight in registers (rv0 / rv1): a stage's loads are issued two iterations before
     // they are converted, so a CU keeps ~100 KB of requests outstanding - the launch is bound by the fetch of its operands
     u32x4_t rv0[8], rv1[8];
-    unsigned rm0 = 0u, rm1 = 0u;                         // X rows: bit rr = row rr of the stage is inside the tensor and the sequence
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool masked = EXT && is_b && a.scale[gemm] != nullptr;      // without a prologue the rows are taken as they are
-    auto fetch = [&](u32x4_t (&rv)[8], unsigned& rmk, int r0) __attribute__((always_inline)) {
-        rmk = 0u;
+    auto fetch = [&](u32x4_t (&rv)[8], int r0) __attribute__((always_inline)) {
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             const int r = r0 + kg * 8 + rr, rs = r + shift_u;
             const bool ok = col_ok && r < r_end && rs >= 0 && rs < a.TB;
             rv[rr] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? (unsigned)(((size_t)rs * ld + col) * 4) : OOB, 0, 0);
-            if (masked && ok && (!a.rowmask || a.rowmask[rs] != 0.f)) rmk |= 1u << rr;
         }
     };
-    const bool pro = EXT && is_b && a.scale[gemm] != nullptr;
-    float4 psc = make_float4(0.f, 0.f, 0.f, 0.f), psh = psc;
-    if (pro && col_ok) { psc = *reinterpret_cast<const float4*>(a.scale[gemm] + col); psh = *reinterpret_cast<const float4*>(a.shift[gemm] + col); }
-    auto stage = [&](const u32x4_t (&rv)[8], unsigned rmk) __attribute__((always_inline)) {
+    auto stage = [&](const u32x4_t (&rv)[8]) __attribute__((always_inline)) {
         if (!(is_a || is_b)) return;
         u32x4_t* dst = (is_a ? As : Bs) + (size_t)kg * (4 * wq) + jq;
         const int part_stride = GB_KG * 4 * wq;
@@ -213,16 +197,6 @@ __global__ __launch_bounds__(512) void gru_wgrad_b16_kernel(GruWgradArgs a) {
             float v[8];
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) v[rr] = __uint_as_float(i == 0 ? rv[rr].x : i == 1 ? rv[rr].y : i == 2 ? rv[rr].z : rv[rr].w);
-            if (EXT && pro) {
-                const float sc = i == 0 ? psc.x : i == 1 ? psc.y : i == 2 ? psc.z : psc.w;
-                const float sh = i == 0 ? psh.x : i == 1 ? psh.y : i == 2 ? psh.z : psh.w;
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    float t = fmaf(v[rr], sc, sh);
-                    if (a.relu) t = fmaxf(t, 0.f);
-                    v[rr] = ((rmk >> rr) & 1u) ? t : 0.f;          // masked / outside rows are zero after the activation
-                }
-            }
             if (is_a) bsum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
             if constexpr (NS == 3) {
                 const Bf3 p = split3x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
@@ -260,19 +234,19 @@ __global__ __launch_bounds__(512) void gru_wgrad_b16_kernel(GruWgradArgs a) {
         }
     };
 
-    fetch(rv0, rm0, r_begin);
-    fetch(rv1, rm1, r_begin + GB_KC);                    // rows past r_end read as zeros
+    fetch(rv0, r_begin);
+    fetch(rv1, r_begin + GB_KC);                         // rows past r_end read as zeros
     for (int r0 = r_begin; r0 < r_end; r0 += 2 * GB_KC) {
         __syncthreads();                                 // the previous stage's fragments have been read
-        stage(rv0, rm0);
+        stage(rv0);
         __syncthreads();
-        fetch(rv0, rm0, r0 + 2 * GB_KC);
+        fetch(rv0, r0 + 2 * GB_KC);
         compute();
         if (r0 + GB_KC >= r_end) break;
         __syncthreads();
-        stage(rv1, rm1);
+        stage(rv1);
         __syncthreads();
-        fetch(rv1, rm1, r0 + 3 * GB_KC);
+        fetch(rv1, r0 + 3 * GB_KC);
         compute();
     }
 
@@ -290,7 +264,7 @@ __global__ __launch_bounds__(512) void gru_wgrad_b16_kernel(GruWgradArgs a) {
                 const int g = m0 + 4 * (pa % (GB_BM / 4)) + pa / (GB_BM / 4);
                 if (g < a.G && k < K) {
                     if (slot) slot[(size_t)g * a.slot_kmax + k] = acc[mi][ni][r];
-                    else unsafeAtomicAdd(dw + (size_t)g * a.ldg[gemm] + (size_t)k * a.ldk[gemm], acc[mi][ni][r]);
+                    else unsafeAtomicAdd(dw + (size_t)g * K + k, acc[mi][ni][r]);
                 }
             }
         }
@@ -309,7 +283,7 @@ __global__ void gru_wgrad_slot_reduce_kernel(GruWgradArgs a, int n) {
         const float* p = a.slots + (size_t)gemm * a.nsplit * a.G * a.slot_kmax + (size_t)g * a.slot_kmax + k;
         float v = 0.f;
         for (int sp = 0; sp < a.nsplit; ++sp) v += p[(size_t)sp * a.G * a.slot_kmax];
-        a.dw[gemm][(size_t)g * a.ldg[gemm] + (size_t)k * a.ldk[gemm]] += v;
+        a.dw[gemm][(size_t)g * a.Ks[gemm] + k] += v;
     }
 }
 
@@ -320,14 +294,8 @@ using namespace pbsed;
 // device scratch of the slot mode: the caller's registered buffer for (device, stream) or the library's per-device one (api.hip)
 static float* gru_wgrad_scratch(size_t floats, hipStream_t s) { return scratch_for(s, floats); }
 
-struct GwExt {                 // 1-D convolution layers: prologue of X and the strides of dw
-    const float* scale; const float* shift; const float* rowmask;
-    int relu, ldg, ldk;
-};
-
 static int gru_wgrad_launch(int n, const float* const* dg, const float* const* x, const int* shift, float* const* dw,
-                            float* const* db, int T, int B, int G, const int* Ks, int operands, void* stream,
-                            const GwExt* ext = nullptr) {
+                            float* const* db, int T, int B, int G, const int* Ks, int operands, void* stream) {
     if (n < 1 || n > GW_MAX || T < 1 || B < 1 || G < 4 || (G & 3)) {
         set_error("gru_wgrad: need 1 <= n <= %d, G a multiple of 4 (n=%d G=%d)", GW_MAX, n, G);
         return PBSED_E_ARG;
@@ -341,14 +309,10 @@ static int gru_wgrad_launch(int n, const float* const* dg, const float* const* x
         a.dg[i] = dg[i]; a.x[i] = x[i]; a.dw[i] = dw[i]; a.db[i] = db ? db[i] : nullptr;
         a.shift_rows[i] = shift[i] * B;
         a.Ks[i] = Ks[i];
-        a.ldg[i] = ext ? ext->ldg : Ks[i]; a.ldk[i] = ext ? ext->ldk : 1;
-        a.scale[i] = ext ? ext->scale : nullptr; a.shift[i] = ext ? ext->shift : nullptr;
         kmax = Ks[i] > kmax ? Ks[i] : kmax;
     }
     const int K = Ks[0];
     a.TB = T * B; a.G = G; a.K = K;
-    a.rowmask = ext ? ext->rowmask : nullptr; a.relu = ext ? ext->relu : 0;
-    if (ext && !operands) { set_error("gru_wgrad: the convolution form needs the bf16-MFMA kernel"); return PBSED_E_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     const int n_cu = device_cus();
     if (operands) {
@@ -379,14 +343,13 @@ static int gru_wgrad_launch(int n, const float* const* dg, const float* const* x
             if (need * sizeof(float) <= (1ull << 30)) a.slots = gru_wgrad_scratch(need, s);
         }
         const size_t lds = (size_t)operands * GB_KG * (GB_BM + GB_BN) * sizeof(u32x4_t);
-#define GW_GO(NS_, EXT_)                                                                          \
-    do {                                                                                          \
-        PBSED_DYN_LDS_ONCE((gru_wgrad_b16_kernel<NS_, EXT_>), lds);                               \
-        hipLaunchKernelGGL((gru_wgrad_b16_kernel<NS_, EXT_>), grid, dim3(512), lds, s, a);        \
-    } while (0)
-        if (operands == 3) { if (ext) GW_GO(3, true); else GW_GO(3, false); }
-        else { if (ext) GW_GO(1, true); else GW_GO(1, false); }
-#undef GW_GO
+        if (operands == 3) {
+            PBSED_DYN_LDS_ONCE(gru_wgrad_b16_kernel<3>, lds);
+            hipLaunchKernelGGL(gru_wgrad_b16_kernel<3>, grid, dim3(512), lds, s, a);
+        } else {
+            PBSED_DYN_LDS_ONCE(gru_wgrad_b16_kernel<1>, lds);
+            hipLaunchKernelGGL(gru_wgrad_b16_kernel<1>, grid, dim3(512), lds, s, a);
+        }
         if (a.slots) {
             const size_t per = (size_t)G * kmax;
             hipLaunchKernelGGL(gru_wgrad_slot_reduce_kernel, dim3((unsigned)((per + 255) / 256 < 1024 ? (per + 255) / 256 : 1024), n),
@@ -437,22 +400,4 @@ extern "C" int pbsed_gru_wgrad_multi(int n, const float* const* dg, const float*
                                      float* const* db, int T, int B, int G, const int* K, int bf16, void* stream) {
     if (!K) { set_error("gru_wgrad_multi: K is null"); return PBSED_E_ARG; }
     return gru_wgrad_launch(n, dg, x, shift, dw, db, T, B, G, K, bf16 ? 1 : x3_default(), stream);
-}
-
-// Weight / bias gradient of a 1-D convolution layer on the time-major layout:
-//   dw[n][k][tap] += sum_r g[r][n] * pro(x)[r + (tap - n_taps/2) B][k],   db[n] += sum_r g[r][n]
-// x [T, B, K_in] raw layer input with its prologue (scale / shift [K_in] or NULL, ReLU, rowmask [T*B] or NULL),
-// g [T, B, N_out], dw [N_out][K_in][n_taps] (the reference's Conv1d weight layout), db [N_out] or NULL.
-extern "C" int pbsed_tm_conv_bwd_weight(const float* x, const float* g, int n_taps, const float* scale, const float* shift,
-                                        int relu, const float* rowmask, float* dw, float* db, int T, int B, int K_in, int N_out,
-                                        int bf16, void* stream) {
-    if (n_taps < 1 || n_taps > 4 || !(n_taps & 1)) { set_error("tm_conv_bwd_weight: %d taps", n_taps); return PBSED_E_ARG; }
-    const float* dgs[4]; const float* xs[4]; float* dws[4]; float* dbs[4];
-    int shifts[4], ks[4];
-    for (int i = 0; i < n_taps; ++i) {
-        dgs[i] = g; xs[i] = x; dws[i] = dw + i; dbs[i] = i == 0 ? db : nullptr;
-        shifts[i] = i - n_taps / 2; ks[i] = K_in;
-    }
-    const GwExt ext{scale, shift, rowmask, relu, K_in * n_taps, n_taps};
-    return gru_wgrad_launch(n_taps, dgs, xs, shifts, dws, dbs, T, B, N_out, ks, bf16 ? 1 : 3, stream, &ext);
 }

@@ -231,49 +231,6 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(float* __restrict__ d
     }
 }
 
-// BN backward on the time-major layout [R = T*B][C] (the 1-D stack around the scans, csrc/tm_gemm.hip): the slot sums of
-// (sum dz, sum dz * xhat) become per-channel means (+ dgamma / dbeta), then dz is rewritten in place.
-__global__ void bn_bwd_tm_finalize_kernel(const double* __restrict__ sums, double count, float* __restrict__ a12, float* dgamma,
-                                          float* dbeta, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < PBSED_STAT_SLOTS; ++k) {
-        s1 += sums[((size_t)k * C + c) * 2];
-        s2 += sums[((size_t)k * C + c) * 2 + 1];
-    }
-    a12[2 * c] = (float)(s1 / count);
-    a12[2 * c + 1] = (float)(s2 / count);
-    if (dbeta) dbeta[c] += (float)s1;
-    if (dgamma) dgamma[c] += (float)s2;
-}
-
-__global__ __launch_bounds__(256) void bn_bwd_tm_apply_kernel(float* __restrict__ dz, const float* __restrict__ x,
-                                                              const float* __restrict__ a12, const float* __restrict__ mean,
-                                                              const float* __restrict__ invstd, const float* __restrict__ scale,
-                                                              const float* __restrict__ rowmask, size_t R, int C) {
-    const int Cq = C / 4;
-    const size_t total = R * Cq;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t r = i / Cq;
-        const int c = (int)(i % Cq) * 4;
-        float4 d = reinterpret_cast<float4*>(dz)[i];
-        if (rowmask && rowmask[r] == 0.f) {
-            d = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {
-            const float4 xv = reinterpret_cast<const float4*>(x)[i];
-            const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
-            const float4 sc = *reinterpret_cast<const float4*>(scale + c);
-            const float4 p0 = *reinterpret_cast<const float4*>(a12 + 2 * c), p1 = *reinterpret_cast<const float4*>(a12 + 2 * c + 4);
-            d.x = sc.x * (d.x - p0.x - (xv.x - mu.x) * is.x * p0.y);
-            d.y = sc.y * (d.y - p0.z - (xv.y - mu.y) * is.y * p0.w);
-            d.z = sc.z * (d.z - p1.x - (xv.z - mu.z) * is.z * p1.y);
-            d.w = sc.w * (d.w - p1.z - (xv.w - mu.w) * is.w * p1.w);
-        }
-        reinterpret_cast<float4*>(dz)[i] = d;
-    }
-}
-
 // Masked per-channel sums (sum x, sum x^2 over t < seq_len[b]) of a network INPUT [B, C, S, T] - the batch statistics of a
 // first layer that carries its own pre-activation norm (padertorch CNN with input_layer=False; SURVEY.md A.4 variant (i)).
 // Everywhere else the statistics come out of the producing convolution's epilogue.
@@ -343,12 +300,6 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* __restric
         const float v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
         atomicAdd(&stats[((size_t)(b & (PBSED_STAT_SLOTS - 1)) * C + c) * 2 + tid], (double)v);
     }
-}
-
-// rowmask[t * B + b] = t < seq_len[b] ? 1 : 0
-__global__ void tm_rowmask_kernel(const int* __restrict__ seq_len, float* __restrict__ mask, int T, int B) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < T * B) mask[i] = (i / B) < seq_len[i % B] ? 1.f : 0.f;
 }
 
 // ------------------------------------------------------------------------------------ FBCRNN loss
@@ -840,18 +791,6 @@ int pbsed_bn_bwd(float* dz, const float* x, const double* sums, double count, co
     return check_launch("bn_bwd");
 }
 
-int pbsed_bn_bwd_tm(float* dz, const float* x, const double* sums, double count, const float* mean, const float* invstd,
-                    const float* scale, float* dgamma, float* dbeta, const float* rowmask, float* scratch, int R, int C,
-                    void* stream) {
-    if (C < 4 || (C & 3) || !scratch) { set_error("bn_bwd_tm: C=%d must be a multiple of 4, scratch [2C] floats", C); return PBSED_E_ARG; }
-    hipLaunchKernelGGL(bn_bwd_tm_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, scratch,
-                       dgamma, dbeta, C);
-    const size_t total = (size_t)R * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_tm_apply_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, dz, x, scratch, mean,
-                       invstd, scale, rowmask, (size_t)R, C);
-    return check_launch("bn_bwd_tm");
-}
-
 int pbsed_channel_stats(const float* x, const int* seq_len, double* stats, int B, int C, int S, int T, void* stream) {
     if (B < 1 || B > 65535 || C < 1) { set_error("channel_stats: bad B=%d C=%d", B, C); return PBSED_E_ARG; }
     hipLaunchKernelGGL(channel_stats_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, seq_len, stats, C, S, T);
@@ -872,11 +811,6 @@ int pbsed_bn_relu_bwd(const float* dy, const float* x, const float* scale, const
     hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, dy, x, scale, shift, mean, invstd,
                        seq_len, dz, stats, C, S, T, relu);
     return check_launch("bn_relu_bwd");
-}
-
-int pbsed_tm_rowmask(const int* seq_len, float* mask, int T, int B, void* stream) {
-    hipLaunchKernelGGL(tm_rowmask_kernel, dim3((T * B + 255) / 256), dim3(256), 0, (hipStream_t)stream, seq_len, mask, T, B);
-    return check_launch("tm_rowmask");
 }
 
 int pbsed_fbcrnn_loss(const float* logit_fwd, const float* logit_bwd, const float* weak_targets,

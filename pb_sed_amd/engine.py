@@ -146,7 +146,7 @@ def _prec(precision, cin, pc=None, dgrad=False, unpool=False):
         if os.environ.get('PBSED_CONV_WINOX3', '1') != '0':
             # (the data gradient through a pool into 32 channels stays direct: its un-pooling producer carries index bytes and
             # one chunk in flight, 0.254 vs 0.231 ms at 32->32)
-            if k_in >= 32 and (n_out >= 64 or (n_out >= 32 and not (dgrad and unpool))):
+            if k_in >= 32 and (n_out >= 64 or (n_out >= 32 and (not (dgrad and unpool) or os.environ.get('PBSED_WX_UNPOOL32', '1') != '0'))):
                 return 'winox3'
         elif k_in >= 32 and n_out >= 64:
             return 'wino'
@@ -154,48 +154,22 @@ def _prec(precision, cin, pc=None, dgrad=False, unpool=False):
 
 
 class _StackCtx(list):
-    """ctx of stack_forward (one entry per layer) + the stack output in the scans' layout when the last layers ran time-major."""
-    tbc_out = None
+    """ctx of stack_forward (one entry per layer)."""
     final = None                # (raw output of the last conv, BN state, frozen) of a stack that closes with norm + ReLU
-
-
-def _tm_start(layers, precision):
-    """First layer of the trailing run of layers that the time-major kernels take (csrc/tm_gemm.hip: Conv1d of kernel size 1
-    or 3 without pooling or residual connections, input widths in whole float4s); len(layers) if there is none.
-    Opt-in (PBSED_TM_STACK=1): measured on the headline step the forward / data-gradient launches gain 10-20 % over the
-    kernels on the CNN layout, but the weight gradients of these small matrices (256 x 256 x 3 over 16 000 rows) need a
-    40-fold split of the reduction to fill the device and drown in its atomics (0.46 ms against 0.10) - DESIGN.md section 4."""
-    j = len(layers)
-    if os.environ.get('PBSED_TM_STACK', '0') != '1' or precision not in ('f32', 'bf16', 'bf16x3'):
-        return j
-    while j > 0:
-        L = layers[j - 1]
-        w = L.conv.conv.weight
-        if not (L.conv.ndim == 1 and w.shape[2] in (1, 3) and not L.conv.pool_f and not L.skips_in and w.shape[1] % 4 == 0):
-            break
-        j -= 1
-    return j
 
 
 def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32', x_tbc=None):
     """Run a conv stack.  Returns (y, ctx) - ctx is what stack_backward needs.  ``precision``: 'f32' |
     'bf16' | 'bf16x3' operand format of the forward / data-gradient MFMAs (weight gradients are always fp32).
-    The trailing 1-D layers run on the scans' time-major layout (``x_tbc``: the stack input already in that layout, for
-    stacks that are 1-D throughout); ``ctx.tbc_out`` is then the output [T,B,C] next to the returned [B,C,T]."""
+    ``x_tbc``: the stack input in the scans' time-major layout [T,B,C] instead of ``x`` (the output nets behind the GRUs)."""
     ctx = _StackCtx()
     st_in, st_frozen = None, False
-    j_tm = _tm_start(layers, precision)
-    if layers[-1].out_norm is not None:
-        j_tm = len(layers)                             # the closing norm + ReLU runs on the CNN layout
-    x_t = rowmask = None
-    if x is None and (j_tm > 0 or layers[0].in_norm is not None):       # only the time-major form of the input was handed over
+    if x is None:
         x = ops.tbc_to_bct(x_tbc)
     if layers[0].in_norm is not None:
         # a first layer with its own pre-activation norm (padertorch input_layer=False, SURVEY.md A.4 variant (i)): the batch
         # statistics of the stack input come from a reduction of their own, every other norm gets them from a conv epilogue
         n0 = layers[0].in_norm
-        if j_tm == 0:
-            raise NotImplementedError('a first layer with its own norm runs on the CNN layout (PBSED_TM_STACK=0)')
         st_frozen = bool(training and n0.freeze_stats)
         if training and not n0.freeze_stats:
             rows = x.shape[2] if x.dim() == 4 else 1
@@ -209,25 +183,6 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32', x_tbc
         # frozen statistics (cnn_2d.freeze(n, freeze_norm_stats=True), pb_sed/experiments/weak_label_crnn/training.py:343-350):
         # the layer normalises with its running statistics in training too and they are not updated
         batch_stats = training and next_norm is not None and not next_norm.freeze_stats
-        if j >= j_tm:
-            if x_t is None:                            # entering the time-major run
-                x_shape = None if x is None else tuple(x.shape)
-                x_t = x_tbc if (x_tbc is not None and j == 0) else ops.bct_to_tbc(x.flatten(1, 2) if x.dim() == 4 else x)
-                rowmask = ops.tm_rowmask(seq_dev, x_t.shape[0], x_t.shape[1])
-            tc = ops.TmConv(c.conv.weight, c.conv.bias)
-            assert tc.n4 == tc.cout or next_norm is None
-            gp = _gemm_prec(precision, tc.cin)
-            y_t, stats = ops.tm_conv_fwd(x_t, tc, st_in, rowmask, want_stats=batch_stats, precision=gp)
-            ctx.append(('tm', x_t, st_in, tc, gp, st_frozen, rowmask, x_shape if j == j_tm else None))
-            st_frozen = bool(training and next_norm is not None and next_norm.freeze_stats)
-            if next_norm is None:
-                st_in = None
-            elif batch_stats:
-                st_in = ops.bn_finalize(stats, _count(seq_host, x_t.shape[0], 1), next_norm)
-            else:
-                st_in = ops.bn_eval_params(next_norm)
-            x_t = y_t
-            continue
         per_cf = bool(batch_stats and c.ndim == 2 and nxt.conv.ndim == 1)
         if c.ndim == 1 and x.dim() == 4:
             x = x.flatten(1, 2)                       # 'b c f t -> b (c f) t' is a view in this layout
@@ -261,13 +216,6 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32', x_tbc
         # the stack's closing norm + ReLU (st_in / st_frozen are the last conv's "next norm" state): a launch of its own
         ctx.final = (x, st_in, st_frozen)
         x = ops.bn_relu_fwd(x, st_in, seq_dev)
-    if x_t is not None:                                # back to the CNN layout for the callers on it
-        cout = layers[-1].conv.conv.weight.shape[0]
-        x = ops.tbc_to_bct(x_t)
-        if x.shape[1] != cout:
-            x = x[:, :cout].contiguous()
-            x_t = None                                 # padded output channels: no [T,B,C] view of exactly C channels
-        ctx.tbc_out = x_t
     return x, ctx
 
 
@@ -303,69 +251,28 @@ def _skip_backward(ctx, src, skip_conv, sctx, g):
     return g
 
 
-def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_done=None, g_tbc=None, want_tbc=False):
+def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_done=None, g_tbc=None):
     """Backward of stack_forward; accumulates parameter grads, returns grad wrt the stack input.
-    ``on_layer_done(j)`` fires once every gradient owned by layers >= j is final.  ``g_tbc``: the output gradient already in
-    the time-major layout [T,B,C] (instead of ``g``); ``want_tbc``: return the input gradient in that layout when the first
-    layer ran time-major."""
+    ``on_layer_done(j)`` fires once every gradient owned by layers >= j is final.  ``g_tbc``: the output gradient in the
+    time-major layout [T,B,C] (instead of ``g``)."""
     def trainable(j):
         mods = [layers[j].conv.conv] + ([layers[j].in_norm] if layers[j].in_norm is not None else [])
         return any(p.requires_grad for m in mods for p in m.parameters())
 
     lowest = min((j for j in range(len(layers)) if trainable(j)), default=len(layers))
+    if g is None:
+        g = ops.tbc_to_bct(g_tbc)
     if ctx.final is not None:                    # backward through the closing ReLU + norm first
         x_raw, st_f, frozen_f = ctx.final
         norm_f = layers[-1].out_norm
-        if g is None:
-            g = ops.tbc_to_bct(g_tbc)
-            g_tbc = None
         dz, stats_f = ops.bn_relu_bwd(g, x_raw, st_f, seq_dev)
         rows = 1 if x_raw.dim() == 3 else x_raw.shape[2]
         count = float('inf') if frozen_f else _count(seq_host, x_raw.shape[-1], rows)
         g = ops.bn_backward(dz, x_raw, st_f, stats_f, count, _grad(norm_f.gamma), _grad(norm_f.beta), seq_dev)
     pending = {}                                 # source layer -> gradient arriving over residual connections
-    g_t = None                                   # the gradient while it travels through the time-major layers
     for j in reversed(range(len(layers))):
         L = layers[j]
         c = L.conv
-        if isinstance(ctx[j][0], str):               # a layer that ran time-major
-            _, x_t, st_in, tc, gp, frozen, rowmask, x_shape = ctx[j]
-            if g_t is None:                          # entering from the top
-                if g_tbc is not None and g_tbc.shape[2] == tc.n4:
-                    g_t = g_tbc
-                else:
-                    if g is None:
-                        g = ops.tbc_to_bct(g_tbc)
-                    if tc.n4 != tc.cout:
-                        g = torch.cat([g, g.new_zeros((g.shape[0], tc.n4 - tc.cout, g.shape[2]))], dim=1)
-                    g_t = ops.bct_to_tbc(g.contiguous())
-            if j < lowest and not need_input_grad:
-                if on_layer_done is not None:
-                    on_layer_done(0)
-                return None
-            dw, db = _grad(c.conv.weight), _grad(c.conv.bias)
-            if dw is not None:
-                ops.tm_conv_bwd_weight(x_t, g_t, tc, dw, db, st_in, rowmask, precision=gp)
-            if j == 0 and not need_input_grad:
-                if on_layer_done is not None:
-                    on_layer_done(0)
-                return None
-            if st_in is not None:
-                dz, stats = ops.tm_conv_bwd_data(g_t, tc, rowmask, bn=(x_t, st_in), precision=gp)
-                count = float('inf') if frozen else _count(seq_host, x_t.shape[0], 1)
-                norm = L.in_norm
-                g_t = ops.bn_backward_tm(dz, x_t, st_in, stats, count, _grad(norm.gamma), _grad(norm.beta), rowmask)
-            else:
-                g_t, _ = ops.tm_conv_bwd_data(g_t, tc, None, None, precision=gp)
-            if on_layer_done is not None:
-                on_layer_done(j)
-            if x_shape is not None or j == 0:        # leaving the time-major run
-                if j == 0 and want_tbc:
-                    return g_t
-                g = ops.tbc_to_bct(g_t)
-                if x_shape is not None:
-                    g = g.reshape(x_shape)
-            continue
         x, st_in, pc, idx, pr, frozen, skip_ctx = ctx[j]
         # g = dL/d(output of conv j) = dL/d(input of layer j+1): the residuals summed into it take the same gradient
         for src, skip_conv, sctx in skip_ctx:
@@ -483,8 +390,8 @@ def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     dy_top = []
     for wi, w in enumerate(wrappers):
         layers, c = head_ctx[wi]
-        d = stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True, want_tbc=True)
-        dy_top.append(d if isinstance(c[0][0], str) else ops.bct_to_tbc(d))      # time-major heads hand back [T,B,H]
+        d = stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True)
+        dy_top.append(ops.bct_to_tbc(d))
     idx = [(ch, l) for ch in chains for l in range(nl)]
     w_hh_t = [ops.transposed(ch.p('weight_hh', l)) for ch, l in idx]
     w_ih_up_t = [ops.transposed(ch.p('weight_ih', l + 1)) if l + 1 < nl else None for ch, l in idx]
@@ -598,12 +505,9 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     dy = [None] * len(chains)                    # per chain: grad wrt its top-layer output, time-major [T,B,H]
     for wi, w in enumerate(wrappers):
         layers, c = head_ctx[wi]
-        d_out = stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True, want_tbc=True)
+        d_out = stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True)       # [B, H*dirs, T]
         for k, i in enumerate(of_w[wi]):
-            if isinstance(c[0][0], str):             # time-major heads: [T, B, H*dirs]
-                dy[i] = d_out[:, :, k * hid:(k + 1) * hid].contiguous() if len(of_w[wi]) > 1 else d_out
-            else:                                    # [B, H*dirs, T]
-                dy[i] = ops.bct_to_tbc(d_out[:, k * hid:(k + 1) * hid].contiguous())
+            dy[i] = ops.bct_to_tbc(d_out[:, k * hid:(k + 1) * hid].contiguous())
     dh_in = None
     jobs = ([], [], [], [], [])                  # weight gradients of ALL layers: one launch after the last scan
     padded = []                                  # (gradient of a zero-padded W_ih, the parameter's gradient)

@@ -23,7 +23,7 @@ class _NetFunction(torch.autograd.Function):
             # there, so the first layer's projections run time-major like the others (the padded width is the engine's affair)
             b, _, t = h.shape
             k = tag.shape[1]
-            hc = cnn_ctx.tbc_out if cnn_ctx.tbc_out is not None else ops.bct_to_tbc(h)
+            hc = ops.bct_to_tbc(h)
             parts = [hc, tag.to(h.dtype).reshape(1, b, k).expand(t, b, k)]
             if (n_h + k) % 4:
                 parts.append(h.new_zeros((t, b, 4 - (n_h + k) % 4)))

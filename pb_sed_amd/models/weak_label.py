@@ -22,8 +22,7 @@ class _NetFunction(torch.autograd.Function):
         layers = engine.describe_stack([model.cnn.cnn_2d, model.cnn.cnn_1d])
         h, cnn_ctx = engine.stack_forward(layers, x, seq_dev, seq_host, training, model.conv_precision)
         wrappers = [model.rnn_fwd] + ([model.rnn_bwd] if model.rnn_bwd is not None else [])
-        logits, rnn_ctx = engine.rnn_forward(wrappers, h, seq_dev, seq_host, training, model.conv_precision,
-                                             h_tbc=cnn_ctx.tbc_out)
+        logits, rnn_ctx = engine.rnn_forward(wrappers, h, seq_dev, seq_host, training, model.conv_precision)
         if model.keep_logits:                       # pre-squash head outputs, for parity checks at the logit level
             model.last_logits = [l.detach().clone() for l in logits]
         ys = [ops.squash_fwd(l, model.minimum_score) for l in logits]

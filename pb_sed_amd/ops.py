@@ -557,112 +557,6 @@ def tm_gemm(xs, ws, bias=None, precision='f32', role='fwd'):
     return y
 
 
-# ------------------------------------------------------------------------------------- 1-D layers, time-major
-class TmConv:
-    """Tap matrices of a Conv1d weight [Cout, Cin, KW] for the time-major kernels: forward taps [N4, Cin] (Cout padded with zero
-    rows to a multiple of 4), data-gradient taps [Cin, N4]; cached on the parameter until it changes (version / PACK_EPOCH)."""
-
-    def __init__(self, weight, bias):
-        self.weight, self.bias = weight, bias
-        self.cout, self.cin, self.kw = weight.shape
-        self.n4 = (self.cout + 3) // 4 * 4
-
-    def _cache(self):
-        key = (self.weight._version, PACK_EPOCH[0], self.weight.data_ptr())
-        cache = getattr(self.weight, '_pbsed_tm', None)
-        if cache is None or cache.get('key') != key:
-            cache = {'key': key}
-            try:
-                self.weight._pbsed_tm = cache
-            except AttributeError:
-                pass
-        return cache
-
-    def fwd(self):
-        c = self._cache()
-        if 'fwd' not in c:
-            w = self.weight.detach()
-            if self.n4 != self.cout:
-                w = torch.cat([w, w.new_zeros((self.n4 - self.cout, self.cin, self.kw))])
-            c['fwd'] = [w.reshape(self.n4, self.cin)] if self.kw == 1 else list(w.permute(2, 0, 1).contiguous().unbind(0))
-            b = self.bias.detach()
-            c['bias'] = b if self.n4 == self.cout else torch.cat([b, b.new_zeros(self.n4 - self.cout)])
-        return c['fwd'], c['bias']
-
-    def bwd(self):
-        c = self._cache()
-        if 'bwd' not in c:
-            c['bwd'] = [transpose2d(w) for w in self.fwd()[0]]
-        return c['bwd']
-
-
-def tm_rowmask(seq_len, t, b):
-    """[T*B] floats: 1 where t < seq_len[b] (the sequence mask of the time-major kernels)."""
-    m = torch.empty((t * b,), device=seq_len.device, dtype=torch.float32)
-    call('pbsed_tm_rowmask', ptr(seq_len), ptr(m), t, b, stream())
-    return m
-
-
-def tm_conv_fwd(x, tc, st_in=None, rowmask=None, want_stats=False, precision='f32'):
-    """x [T,B,Cin] -> (y [T,B,N4], stats | None): Conv1d layer ``tc`` (TmConv) with the fused prologue of ``st_in`` (BNState)."""
-    t, b, k = x.shape
-    assert k == tc.cin and x.is_contiguous()
-    ws, bias = tc.fwd()
-    y = torch.empty((t, b, tc.n4), device=x.device, dtype=torch.float32)
-    stats = _zero_stats(tc.n4, x.device) if want_stats else None
-    call('pbsed_tm_conv_fwd', ptr(x), tc.kw, _lib.ptr_array(ws), ptr(bias), ptr(None if st_in is None else st_in.scale),
-         ptr(None if st_in is None else st_in.shift), 1, ptr(rowmask), ptr(y), ptr(stats), t, b, k, tc.n4,
-         int(precision == 'bf16'), stream(), tag=f'{k}->{tc.cout} k{tc.kw} R{t * b}' + (' bf16' if precision == 'bf16' else ''),
-         flops=2. * t * b * k * tc.cout * tc.kw)
-    return y, stats
-
-
-def tm_conv_bwd_data(g, tc, rowmask=None, bn=None, precision='f32'):
-    """g [T,B,N4] -> (dz [T,B,Cin], stats | None).  ``bn = (x, BNState)``: also back through the layer's prologue."""
-    t, b, n4 = g.shape
-    assert n4 == tc.n4 and g.is_contiguous()
-    dz = torch.empty((t, b, tc.cin), device=g.device, dtype=torch.float32)
-    stats = bx = st = None
-    if bn is not None:
-        bx, st = bn
-        stats = _zero_stats(tc.cin, g.device)
-    call('pbsed_tm_conv_bwd_data', ptr(g), tc.kw, _lib.ptr_array(tc.bwd()), ptr(rowmask), ptr(dz), ptr(bx),
-         ptr(None if st is None else st.scale), ptr(None if st is None else st.shift), ptr(None if st is None else st.mean),
-         ptr(None if st is None else st.invstd), 1, ptr(stats), t, b, n4, tc.cin, int(precision == 'bf16'), stream(),
-         tag=f'{tc.cin}->{tc.cout} k{tc.kw} R{t * b}' + (' bf16' if precision == 'bf16' else ''),
-         flops=2. * t * b * tc.cin * tc.cout * tc.kw)
-    return dz, stats
-
-
-def tm_conv_bwd_weight(x, g, tc, dw, db, st_in=None, rowmask=None, precision='f32'):
-    """dw [Cout,Cin,KW] (+=), db [Cout] (+=) of layer ``tc`` from its raw input x [T,B,Cin] and g [T,B,N4]."""
-    ensure_scratch(x.device)
-    t, b, k = x.shape
-    if tc.n4 == tc.cout:
-        dwp, dbp = dw, db
-    else:                                            # padded output channels: gradient of the padded weight, then its first rows
-        dwp = torch.zeros((tc.n4, tc.cin, tc.kw), device=x.device, dtype=torch.float32)
-        dbp = torch.zeros((tc.n4,), device=x.device, dtype=torch.float32) if db is not None else None
-    assert dwp.is_contiguous()
-    call('pbsed_tm_conv_bwd_weight', ptr(x), ptr(g), tc.kw, ptr(None if st_in is None else st_in.scale),
-         ptr(None if st_in is None else st_in.shift), 1, ptr(rowmask), ptr(dwp), ptr(dbp), t, b, k,
-         tc.n4, int(precision == 'bf16'), stream(), tag=f'{k}->{tc.cout} k{tc.kw} R{t * b}' + (' bf16' if precision == 'bf16' else ''),
-         flops=2. * t * b * k * tc.cout * tc.kw)
-    if dwp is not dw:
-        dw.add_(dwp[:tc.cout])
-        if db is not None:
-            db.add_(dbp[:tc.cout])
-
-
-def bn_backward_tm(dz, x, st, stats, count, dgamma, dbeta, rowmask):
-    """In place dz -> dx on [T,B,C]; accumulates dgamma / dbeta."""
-    t, b, c = x.shape
-    scratch = torch.empty((2 * c,), device=x.device, dtype=torch.float32)
-    call('pbsed_bn_bwd_tm', ptr(dz), ptr(x), ptr(stats), float(count), ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(dgamma),
-         ptr(dbeta), ptr(rowmask), ptr(scratch), t * b, c, stream())
-    return dz
-
-
 def gru_scan_fwd(gi, w_hh, b_hh, reverse, seq_len, save=True):
     """gi: list of [T,B,3H] per chain.  Returns (hs list [T,B,H], save list [T,B,4,H]|None)."""
     n = len(gi)

@@ -579,41 +579,3 @@ def test_trainer_reports_a_timed_out_scan_one_step_late_and_never_updates_from_i
         trainer.step(batch)
         trainer.finish()
         assert not torch.equal(trainer.flat_param, before)
-
-
-def test_time_major_1d_stack_matches_the_default_path(monkeypatch):
-    """PBSED_TM_STACK=1 runs the CNN1d layers and the GRU output nets on the scans' time-major layout (pbsed_tm_conv_*):
-    same scores, loss and gradients as the default kernels on the CNN layout (FBCRNN and tag-conditioned BiCRNN, ragged
-    lengths, training mode with batch statistics)."""
-    from pb_sed_amd.models import strong_label, weak_label
-    wav, seq, weak, strong, t = synth_batch(5, 24000, 10, seed=5)
-    tag = (weak > .99).float()
-    for kind in ('fb', 'bi'):
-        res = {}
-        for flag in ('0', '1'):
-            monkeypatch.setenv('PBSED_TM_STACK', flag)
-            torch.manual_seed(0)
-            if kind == 'fb':
-                model = weak_label.CRNN.build(num_events=10, hidden_size=64, net=TINY).to(DEV)
-                inp = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV),
-                       'boundary_targets': strong.to(DEV)}
-            else:
-                model = strong_label.CRNN.build(num_events=10, hidden_size=64, num_layers=2, net=TINY, tag_conditioning=True).to(DEV)
-                inp = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV),
-                       'strong_targets': strong.to(DEV), 'tag_condition': tag.to(DEV)}
-            model.train()
-            model.flat_parameters()[1].zero_()
-            out = model(dict(inp))
-            loss = model.review(inp, out)['loss']
-            loss.backward()
-            res[flag] = (out[0].detach().clone(), loss.item(),
-                         {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
-        y0, l0, g0 = res['0']
-        y1, l1, g1 = res['1']
-        assert (y0 - y1).abs().max().item() < 2e-5, kind
-        assert abs(l0 - l1) < 1e-5 * max(abs(l0), 1.), kind
-        assert g0.keys() == g1.keys()
-        floor = 1e-3 * max(v.norm().item() for v in g0.values())      # biases in front of a batch norm have a zero gradient: noise
-        for n in g0:
-            err = (g0[n] - g1[n]).norm().item() / max(g0[n].norm().item(), floor)
-            assert err < 2e-3, (kind, n, err)

@@ -733,74 +733,6 @@ def test_bicrnn_review_buffers_vs_reference_golden(golden, name):
     assert 'macro_fscore_strong' in summary['scalars'] and summary['scalars']['num_examples_strong'] == len(g[f'{name}/y_strong'])
 
 
-@pytest.mark.parametrize('precision', ['f32', 'bf16'])
-@pytest.mark.parametrize('cin,cout,kw,t,b,pro', [(64, 32, 3, 37, 5, True), (256, 256, 1, 130, 7, True), (32, 10, 1, 50, 4, True),
-                                                  (48, 64, 3, 33, 3, False), (256, 256, 3, 500, 32, True)])
-def test_tm_conv_layer_vs_torch(cin, cout, kw, t, b, pro, precision):
-    """Conv1d layer on the time-major layout (pbsed_tm_conv_fwd / _bwd_data / _bwd_weight + pbsed_bn_bwd_tm) against fp64
-    torch on the CNN layout: fused BN + ReLU + sequence-mask prologue, masked output statistics, the data gradient pushed
-    back through the prologue with its BN-backward sums, weight / bias gradients (output channels padded to 4)."""
-    from pb_sed_amd import ops
-    torch.manual_seed(3)
-    seq = np.sort(np.random.RandomState(1).randint(t // 2, t + 1, b))[::-1].copy()
-    seq[0] = t
-    x = torch.randn(b, cin, t, dtype=torch.float64)
-    w = torch.randn(cout, cin, kw, dtype=torch.float64) * (cin * kw) ** -.5
-    bias = torch.randn(cout, dtype=torch.float64)
-    gamma, beta = torch.rand(cin, dtype=torch.float64) + .5, torch.randn(cin, dtype=torch.float64) * .3
-    mask = (torch.arange(t)[None, None] < torch.as_tensor(seq)[:, None, None]).double()
-    n = float(seq.sum())
-    xr = x.clone().requires_grad_(True)
-    wr, br = w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
-    gr, ber = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
-    if pro:
-        mean = (xr * mask).sum((0, 2)) / n
-        var = (((xr - mean[None, :, None]) ** 2) * mask).sum((0, 2)) / n
-        invstd = (var + 1e-3) ** -.5
-        xin = torch.relu((xr - mean[None, :, None]) * (invstd * gr)[None, :, None] + ber[None, :, None]) * mask
-    else:
-        xin = xr
-    y = torch.nn.functional.conv1d(xin, wr, br, padding=kw // 2)
-    g = torch.randn(b, cout, t, dtype=torch.float64) * mask
-    (y * g).sum().backward()
-    ym = y.detach() * mask
-    ref_stats = torch.stack([ym.sum((0, 2)), (ym * ym).sum((0, 2))], 1)
-
-    dev = lambda v: v.detach().float().to(DEV).contiguous()
-    tbc = lambda v: dev(v).permute(2, 0, 1).contiguous()
-    seq_dev = torch.as_tensor(seq, dtype=torch.int32).to(DEV)
-    rowmask = ops.tm_rowmask(seq_dev, t, b)
-    assert torch.equal(rowmask.reshape(t, b).cpu(), mask[:, 0].T.float())
-    wp, bp = torch.nn.Parameter(dev(w)), torch.nn.Parameter(dev(bias))
-    tc = ops.TmConv(wp, bp)
-    st = None
-    if pro:
-        st = ops.BNState(cin, DEV)
-        st.mean.copy_(dev(mean)), st.invstd.copy_(dev(invstd))
-        st.scale.copy_(dev(invstd * gamma)), st.shift.copy_(dev(beta - mean * invstd * gamma))
-    x_t = tbc(x)
-    yk, stats = ops.tm_conv_fwd(x_t, tc, st, rowmask, want_stats=True, precision=precision)
-    lo = precision == 'bf16'
-    tol = 3e-2 if lo else 2e-5
-    close(yk[:, :, :cout].permute(1, 2, 0), y.detach().float(), atol=tol, rtol=tol, name='tm conv y')
-    if tc.n4 != cout:
-        assert yk[:, :, cout:].abs().max().item() == 0
-    close(stats.sum(0)[:cout].float(), ref_stats.float(), atol=(2e-1 if lo else 1e-3) * n ** .5, rtol=1e-2 if lo else 1e-4, name='tm conv stats')
-    g_t = torch.zeros(t, b, tc.n4, device=DEV)
-    g_t[:, :, :cout] = tbc(g)
-    dz, bstats = ops.tm_conv_bwd_data(g_t, tc, rowmask, bn=(x_t, st) if pro else None, precision=precision)
-    dgamma, dbeta = torch.zeros(cin, device=DEV), torch.zeros(cin, device=DEV)
-    if pro:
-        dz = ops.bn_backward_tm(dz, x_t, st, bstats, n, dgamma, dbeta, rowmask)
-        close(dgamma, gr.grad.float(), atol=(3e-1 if lo else 2e-3), rtol=tol, name='tm dgamma')
-        close(dbeta, ber.grad.float(), atol=(3e-1 if lo else 2e-3), rtol=tol, name='tm dbeta')
-    close(dz.permute(1, 2, 0), xr.grad.float(), atol=(5e-2 if lo else 5e-5), rtol=tol, name='tm conv dx')
-    dw, db = torch.zeros(cout, cin, kw, device=DEV), torch.zeros(cout, device=DEV)
-    ops.tm_conv_bwd_weight(x_t, g_t, tc, dw, db, st, rowmask, precision=precision)
-    close(dw, wr.grad.float(), atol=(3e-2 if lo else 3e-5) * n ** .5, rtol=tol, name='tm conv dw')
-    close(db, br.grad.float(), atol=1e-4 * n ** .5, rtol=1e-4, name='tm conv db')
-
-
 @pytest.mark.parametrize('b,h,t,nl', [(7, 128, 130, 2), (32, 256, 500, 1), (40, 64, 33, 2)])
 def test_gru_scans_with_bf16_operands_stay_close_to_the_fp32_scans(b, h, t, nl):
     """pbsed_gru_stack_{fwd,bwd}_granule_bf16 (plain bf16 operands of the recurrent / projection products, the bf16 training
