@@ -654,7 +654,8 @@ def test_conv1d_producer_consumer_x3_vs_torch(cin, cout, kw, t, b, pro):
     close(st.sum(0), st_r.sum(0), atol=2e-3, rtol=1e-4, name='conv1d bn-backward sums c1x3 vs direct')
 
 
-@pytest.mark.parametrize('cin,cout,f,t,pool', [(64, 64, 8, 150, True), (32, 96, 6, 65, False), (128, 64, 4, 500, True)])
+@pytest.mark.parametrize('cin,cout,f,t,pool', [(64, 64, 8, 150, True), (32, 96, 6, 65, False), (128, 64, 4, 500, True),
+                                              (32, 48, 6, 64, True), (32, 32, 8, 132, False)])      # <= 32 channels produced: 32-cout blocks
 def test_conv_winograd_dgrad_bn_epilogue_matches_direct(cin, cout, f, t, pool):
     """Data gradient with the fused BN-ReLU-mask backward epilogue (and un-pooling): Winograd vs direct kernel on
     the same inputs - dz, and the (sum dz, sum dz*xhat) statistics BN backward needs."""
