@@ -43,9 +43,9 @@ constexpr int C1_LDS_ALL = C1_LDS + 4 * 32 * C1_TRS * 4;  // accumulator-layout 
 
 __global__ void c1x3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ up, int Cout, int Cin, int KW, int InP,
                                  int OutP, int dgrad) {
-    const size_t total = (size_t)KW * InP * OutP * 3;
+    const size_t total = (size_t)KW * InP * OutP;               // weights; three halfwords each
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-        up[i] = pack_c1x3_elem(w, i, Cout, Cin, KW, InP, OutP, dgrad);
+        pack_c1x3_value(w, up, i, Cout, Cin, KW, InP, OutP, dgrad);
 }
 
 template <int KW, bool DGRAD>
@@ -510,7 +510,7 @@ int pbsed_pack_conv1d_weights_x3(const float* w, unsigned short* up, int Cout, i
     if (KW != 1 && KW != 3) { set_error("pack_conv1d_weights_x3: kernel size %d (1 or 3)", KW); return PBSED_E_UNSUPPORTED; }
     int InP, OutP;
     pbsed_conv1d_pack_dims_x3(Cin, Cout, dgrad, &InP, &OutP);
-    const size_t total = (size_t)KW * InP * OutP * 3;
+    const size_t total = (size_t)KW * InP * OutP;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(c1x3_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, up, Cout, Cin, KW, InP, OutP, dgrad);
     return check_launch("pack_conv1d_weights_x3");

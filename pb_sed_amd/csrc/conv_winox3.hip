@@ -57,9 +57,9 @@ struct WxCfg {
 
 __global__ void winox3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ up, int Cout, int Cin, int InP,
                                    int OutP, int dgrad) {
-    const size_t total = (size_t)18 * InP * OutP * 3;
+    const size_t total = (size_t)18 * InP * OutP;               // weights; three halfwords each
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-        up[i] = pack_winox3_elem(w, i, Cout, Cin, InP, OutP, dgrad);
+        pack_winox3_value(w, up, i, Cout, Cin, InP, OutP, dgrad);
 }
 
 // CT: cout per block.  64: consumer wave w owns cout tile w (16 cout) and all 4 rows.  32 (launches that produce <= 32
@@ -621,7 +621,7 @@ void pbsed_conv_pack_dims_winox3(int Cin, int Cout, int dgrad, int* InP, int* Ou
 int pbsed_pack_conv_weights_winox3(const float* w, unsigned short* up, int Cout, int Cin, int dgrad, void* stream) {
     int InP, OutP;
     pbsed_conv_pack_dims_winox3(Cin, Cout, dgrad, &InP, &OutP);
-    const size_t total = (size_t)18 * InP * OutP * 3;
+    const size_t total = (size_t)18 * InP * OutP;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(winox3_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, up, Cout, Cin, InP, OutP, dgrad);
     return check_launch("pack_conv_weights_winox3");

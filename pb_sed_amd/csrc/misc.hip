@@ -50,17 +50,17 @@ __global__ void pack_batched_kernel(const PackDesc* __restrict__ descs) {
         return;
     }
     if (d.mode >= 10) {                                  // csrc/conv1d_pc.hip: fragment-ordered three-part Conv1d weights (KH = 1)
-        const size_t total = (size_t)d.KW * d.InP * d.OutP * 3;
+        const size_t total = (size_t)d.KW * d.InP * d.OutP;           // weights: a thread forms one and writes its three parts
         unsigned short* dst = reinterpret_cast<unsigned short*>(d.dst);
         for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-            dst[i] = pack_c1x3_elem(d.src, i, d.Cout, d.Cin, d.KW, d.InP, d.OutP, d.mode & 1);
+            pack_c1x3_value(d.src, dst, i, d.Cout, d.Cin, d.KW, d.InP, d.OutP, d.mode & 1);
         return;
     }
     if (d.mode >= 8) {                                   // csrc/conv_winox3.hip: fragment-ordered three-part Winograd weights
-        const size_t total = (size_t)18 * d.InP * d.OutP * 3;
+        const size_t total = (size_t)18 * d.InP * d.OutP;
         unsigned short* dst = reinterpret_cast<unsigned short*>(d.dst);
         for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-            dst[i] = pack_winox3_elem(d.src, i, d.Cout, d.Cin, d.InP, d.OutP, d.mode & 1);
+            pack_winox3_value(d.src, dst, i, d.Cout, d.Cin, d.InP, d.OutP, d.mode & 1);
         return;
     }
     if (d.mode >= 4) {                                   // csrc/conv_bf16.hip layout: [tap][OutP][InP], input channels innermost

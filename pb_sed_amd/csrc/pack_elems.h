@@ -38,15 +38,27 @@ __device__ __forceinline__ float pack_wino_elem(const float* __restrict__ w, siz
     }
 }
 
+// Exact three-way bf16 split by truncation (hi + mid + lo == u); returns the parts as halfwords.
+__device__ __forceinline__ void split3_halfs(float u, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    const unsigned b0 = __float_as_uint(u);
+    hi = (unsigned short)(b0 >> 16);
+    const float r1 = u - __uint_as_float(b0 & 0xffff0000u);
+    const unsigned b1 = __float_as_uint(r1);
+    mid = (unsigned short)(b1 >> 16);
+    const float r2 = r1 - __uint_as_float(b1 & 0xffff0000u);
+    lo = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
 // bf16x3 Winograd layout (csrc/conv_winox3.hip): halfwords [InP/32][xi 6][kh 3][OutP/16][part 3][lane 64][8] - the 16 bytes
 // a lane holds of an MFMA A fragment (row = cout tile * 16 + (lane & 15), k = chunk * 32 + (lane >> 4) * 8 + j) contiguous,
 // one 1 KB piece per (point, kernel row, cout tile, part).  U is formed in fp32 exactly as pack_wino_elem does and split by
-// truncation into three bf16 parts (hi + mid + lo == U exactly).
-__device__ __forceinline__ unsigned short pack_winox3_elem(const float* __restrict__ w, size_t i, int Cout, int Cin, int InP,
-                                                           int OutP, int dgrad) {
-    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-    size_t r = i >> 9;
-    const int part = (int)(r % 3); r /= 3;
+// truncation into three bf16 parts (hi + mid + lo == U exactly).  One call = one weight: v = index over
+// [InP/32][xi][kh][OutP/16][lane][8]; writes its three parts (1 KB apart).
+__device__ __forceinline__ void pack_winox3_value(const float* __restrict__ w, unsigned short* __restrict__ up, size_t v, int Cout, int Cin,
+                                                  int InP, int OutP, int dgrad) {
+    const int j = (int)(v & 7), lane = (int)((v >> 3) & 63);
+    size_t r = v >> 9;
+    const size_t piece = r;                       // (chunk, xi, kh, cout tile): three 1 KB parts each
     const int MT = OutP / 16;
     const int mt = (int)(r % MT); r /= MT;
     const int kh = (int)(r % 3); r /= 3;
@@ -54,23 +66,20 @@ __device__ __forceinline__ unsigned short pack_winox3_elem(const float* __restri
     const int c = (int)(r / 6);
     const int o = mt * 16 + (lane & 15), ii = c * 32 + (lane >> 4) * 8 + j;
     const float u = pack_wino_elem(w, ((size_t)(kh * 6 + xi) * InP + ii) * OutP + o, Cout, Cin, InP, OutP, dgrad);
-    const unsigned b0 = __float_as_uint(u);
-    if (part == 0) return (unsigned short)(b0 >> 16);
-    const float r1 = u - __uint_as_float(b0 & 0xffff0000u);
-    const unsigned b1 = __float_as_uint(r1);
-    if (part == 1) return (unsigned short)(b1 >> 16);
-    const float r2 = r1 - __uint_as_float(b1 & 0xffff0000u);
-    return (unsigned short)(__float_as_uint(r2) >> 16);
+    unsigned short h, m, l;
+    split3_halfs(u, h, m, l);
+    unsigned short* dst = up + piece * 1536 + (size_t)lane * 8 + j;
+    dst[0] = h; dst[512] = m; dst[1024] = l;
 }
 
-// Conv1d bf16x3 layout (csrc/conv1d_pc.hip): halfwords [InP/32][kw][OutP/16][part 3][lane 64][8]: the 16 bytes a lane holds of an MFMA A fragment (row = cout tile * 16 +
-// (lane & 15), k = chunk * 32 + (lane >> 4) * 8 + j) contiguous, one 1 KB piece per (chunk, tap, cout tile, part); split by
-// truncation (hi + mid + lo == w exactly).  dgrad: in / out channels swapped, taps flipped.
-__device__ __forceinline__ unsigned short pack_c1x3_elem(const float* __restrict__ w, size_t i, int Cout, int Cin, int KW, int InP,
-                                                         int OutP, int dgrad) {
-    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-    size_t r = i >> 9;
-    const int part = (int)(r % 3); r /= 3;
+// Conv1d bf16x3 layout (csrc/conv1d_pc.hip): halfwords [InP/32][kw][OutP/16][part 3][lane 64][8], same fragment order; split by
+// truncation (hi + mid + lo == w exactly).  dgrad: in / out channels swapped, taps flipped.  v = index over
+// [InP/32][kw][OutP/16][lane][8].
+__device__ __forceinline__ void pack_c1x3_value(const float* __restrict__ w, unsigned short* __restrict__ up, size_t v, int Cout, int Cin,
+                                                int KW, int InP, int OutP, int dgrad) {
+    const int j = (int)(v & 7), lane = (int)((v >> 3) & 63);
+    size_t r = v >> 9;
+    const size_t piece = r;
     const int MT = OutP / 16;
     const int mt = (int)(r % MT); r /= MT;
     const int kw = (int)(r % KW);
@@ -82,13 +91,10 @@ __device__ __forceinline__ unsigned short pack_c1x3_elem(const float* __restrict
     } else if (o < Cin && ii < Cout) {
         u = w[((size_t)ii * Cin + o) * KW + (KW - 1 - kw)];
     }
-    const unsigned b0 = __float_as_uint(u);
-    if (part == 0) return (unsigned short)(b0 >> 16);
-    const float r1 = u - __uint_as_float(b0 & 0xffff0000u);
-    const unsigned b1 = __float_as_uint(r1);
-    if (part == 1) return (unsigned short)(b1 >> 16);
-    const float r2 = r1 - __uint_as_float(b1 & 0xffff0000u);
-    return (unsigned short)(__float_as_uint(r2) >> 16);
+    unsigned short h, m, l;
+    split3_halfs(u, h, m, l);
+    unsigned short* dst = up + piece * 1536 + (size_t)lane * 8 + j;
+    dst[0] = h; dst[512] = m; dst[1024] = l;
 }
 
 }  // namespace pbsed

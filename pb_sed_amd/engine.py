@@ -141,11 +141,12 @@ def _prec(precision, cin, pc=None, dgrad=False, unpool=False):
         k_in, n_out = (pc.cout, pc.cin) if dgrad else (pc.cin, pc.cout)
         # bf16x3 Winograd (csrc/conv_winox3.hip: the same transform-domain products from exact three-way bf16 splits on the
         # bf16 MFMA) from 32 channels on either side (32->32 forward 0.152 vs 0.216 ms direct, data gradient 0.138 vs 0.215; with
-        # 16 input channels half of every K = 32 MFMA would be padding and the direct kernel stays ahead);
+        # 16 input channels half of every K = 32 MFMA would be padding and the producers stage 32 channels per chunk whatever
+        # the layer has - measured: 16->32 forward 0.144 vs 0.116 ms direct, data gradient 0.164 vs 0.130, 16->16 twice as slow);
         # PBSED_CONV_WINOX3=0 keeps the fp32-MFMA Winograd kernel, which pays from 64 output channels on
         if os.environ.get('PBSED_CONV_WINOX3', '1') != '0':
-            # (the data gradient through a pool into 32 channels stays direct: its un-pooling producer carries index bytes and
-            # one chunk in flight, 0.254 vs 0.231 ms at 32->32)
+            # (with 32-cout blocks the data gradient through a pool into 32 channels is ahead too: 0.193 vs 0.232 ms direct at
+            # 32->32; with 64-cout blocks it was not, 0.254 - PBSED_WX_UNPOOL32=0 sends it back to the direct kernel)
             if k_in >= 32 and (n_out >= 64 or (n_out >= 32 and (not (dgrad and unpool) or os.environ.get('PBSED_WX_UNPOOL32', '1') != '0'))):
                 return 'winox3'
         elif k_in >= 32 and n_out >= 64:
