@@ -920,23 +920,23 @@ struct WgradPcCfg {
     static constexpr bool COLUMNS = true;                                // launch_wgrad_cfg: the split is over (clip, column) units
     static constexpr int FT = 1, TT = 32 * KS, KK = 9, NT = 512, NJ = TT / 8;
     static constexpr int COUT_T = WM * MTL * 16, CIN_T = WN * NTL * 16;
-    // bytes: channel stride of an x row slot (TT + 16 t, then padded to an odd multiple of 16 bytes: the 16 rows of a fragment
-    // read cover all banks)
-    static constexpr int XCH = ((TT + 16) * 2 / 16) % 2 ? (TT + 16) * 2 : (TT + 16) * 2 + 16;
+    // bytes: channel stride of an x row slot (TT t, then padded to an odd multiple of 16 bytes: the 16 rows of a fragment read
+    // cover all banks)
+    static constexpr int XCH = (TT * 2 / 16) % 2 ? TT * 2 : TT * 2 + 16;
     static constexpr int DY_PART = KS * COUT_T * 64, X_PART = CIN_T * XCH;   // bytes per operand part; dY: [ks][cout][32 t]
-    static constexpr int XB_CH = (NJ + 1) * 4, XB_PART = CIN_T * XB_CH;  // boundary words: per channel NJ dwords {x[8j - 1], x[8j + 8]} (+ 1 pad:
-    static constexpr int DY_STAGE = 3 * DY_PART, X_SLOT = 3 * (X_PART + XB_PART);   // odd dword stride = conflict-free 4-byte reads)
+    static constexpr int YB_CH = (NJ + 1) * 4, YB_PART = COUT_T * YB_CH; // boundary words: per cout row NJ dwords {dY[8j - 1], dY[8j + 8]} (+ 1 pad:
+    static constexpr int DY_STAGE = 3 * (DY_PART + YB_PART), X_SLOT = 3 * X_PART;   // odd dword stride = conflict-free 4-byte reads)
     static constexpr int X_BASE = 2 * DY_STAGE;                         // LDS: dY stage 0, dY stage 1, x slots 0..3, zero slot
     static constexpr int LDS_MAIN = X_BASE + 5 * X_SLOT;
-    static constexpr int XQ = (TT + 16) / 4;                             // 4-element quads per x row
-    static constexpr int DY_ITEMS = COUT_T * TT / 4, X_ITEMS = CIN_T * XQ;
+    static constexpr int XQ = TT / 4, YQ = TT / 4 + 2;                   // 4-element quads per x row / per dY row (one more on either side)
+    static constexpr int DY_ITEMS = COUT_T * YQ, X_ITEMS = CIN_T * XQ;
     static constexpr int DY_PER_T = (DY_ITEMS + 255) / 256, X_PER_T = (X_ITEMS + 255) / 256;
     // steps whose global loads are in flight: the steps of the few-channel configurations are short (a few hundred clocks), two
     // of them do not cover the memory latency
     static constexpr int NB = (KS > 1) ? 4 : 2;
     static constexpr int OUT_ROW = CIN_T * KK + 1, OUT_ROWS = COUT_T < 64 ? COUT_T : 64;
     static constexpr int LDS_FLOATS = cmax((LDS_MAIN + 3) / 4, OUT_ROWS * OUT_ROW);
-    static_assert(XB_CH / 4 % 2 == 1 && (XCH / 16) % 2 == 1, "odd strides");
+    static_assert(YB_CH / 4 % 2 == 1 && (XCH / 16) % 2 == 1, "odd strides");
 };
 
 template <int WM, int WN, int KS = 1, int MTL = 2, int NTL = 2>
@@ -986,20 +986,25 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
         const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.shift), 0, pro ? (unsigned)a.Cin * 4u : 0u, 0x00020000);
         // per-thread item constants (computed once: the step loop only adds a uniform offset and selects, no divisions and no
-        // divergent branches): dY item i = (cout row, quad of TT / 4), x item i = (cin, quad of XQ)
-        int y_q[C::DY_PER_T], y_valid[C::DY_PER_T];
-        unsigned y_lds[C::DY_PER_T], y_base[C::DY_PER_T];
+        // divergent branches): dY item i = (cout row, quad -1 .. TT / 4 of the step's range: the outer two only feed the
+        // boundary words), x item i = (cin, quad of XQ)
+        int y_q[C::DY_PER_T], y_valid[C::DY_PER_T], y_item[C::DY_PER_T];
+        unsigned y_lds[C::DY_PER_T], y_bnd[C::DY_PER_T];
+        int y_base[C::DY_PER_T];
 #pragma unroll
         for (int i = 0; i < C::DY_PER_T; ++i) {
-            const int it = pt + i * 256, cl = it / (C::TT / 4);
-            y_q[i] = it % (C::TT / 4);
-            const int row = cl & 15, q8 = y_q[i] & 7, ks = y_q[i] >> 3;          // 32-t slice ks, quad q8 of its 8
+            const int it = pt + i * 256, cl = it / C::YQ;
+            y_q[i] = it % C::YQ - 1;
+            const int qq = y_q[i] & (C::TT / 4 - 1);                             // (the outer quads have no place in the tile)
+            const int row = cl & 15, q8 = qq & 7, ks = qq >> 3;                  // 32-t slice ks, quad q8 of its 8
             y_lds[i] = (unsigned)((ks * C::COUT_T + cl) * 64 + ((((q8 >> 1) ^ ((-(row >> 2)) & 3)) & 3) * 16) + (q8 & 1) * 8);
-            y_valid[i] = (it < C::DY_ITEMS) & (cout0 + cl < a.Cout);
-            y_base[i] = (unsigned)((cout0 + cl) * Fg * a.T + 4 * y_q[i]);
+            y_bnd[i] = (unsigned)(cl * C::YB_CH);
+            y_item[i] = it < C::DY_ITEMS;
+            y_valid[i] = y_item[i] & (cout0 + cl < a.Cout);
+            y_base[i] = (cout0 + cl) * Fg * a.T + 4 * y_q[i];
         }
         int x_q[C::X_PER_T], x_valid[C::X_PER_T], x_item[C::X_PER_T];
-        unsigned x_lds[C::X_PER_T], x_bnd[C::X_PER_T];
+        unsigned x_lds[C::X_PER_T];
         int x_base[C::X_PER_T];
         float x_sc[C::X_PER_T], x_sh[C::X_PER_T];
 #pragma unroll
@@ -1007,10 +1012,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
             const int it = pt + i * 256, cl = it / C::XQ;
             x_q[i] = it % C::XQ;
             x_lds[i] = (unsigned)(cl * C::XCH + x_q[i] * 8);
-            x_bnd[i] = (unsigned)(cl * C::XB_CH);
             x_item[i] = it < C::X_ITEMS;
             x_valid[i] = x_item[i] & (cin0 + cl < a.Cin);
-            x_base[i] = (cin0 + cl) * a.F * a.T + 4 * x_q[i] - 8;
+            x_base[i] = (cin0 + cl) * a.F * a.T + 4 * x_q[i];
             const bool ok = x_valid[i] && pro;
             x_sc[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_sc, ok ? (unsigned)(cin0 + cl) * 4u : 0x80000000u, 0, 0));
             x_sh[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_sh, ok ? (unsigned)(cin0 + cl) * 4u : 0x80000000u, 0, 0));
@@ -1041,8 +1045,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
             for (int i = 0; i < C::DY_PER_T; ++i) {
                 const int tq = t0 + 4 * y_q[i];
                 // branch-free selects (as ?: the compiler forks into two load sites that must wait for each other)
-                const unsigned ok = (unsigned)-(y_valid[i] & (tq < a.T));
-                const unsigned off = ((y_base[i] + y_row) & ok) | (OOB & ~ok);
+                const unsigned ok = (unsigned)-(y_valid[i] & (tq >= 0) & (tq < a.T));
+                const unsigned off = ((unsigned)(y_base[i] + (int)y_row) & ok) | (OOB & ~ok);
                 ry[BUF][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, off * 4u, 0, 0);
                 if (unpool) ryi[BUF][i] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, off, 0, 0);
                 ry_n[BUF][i] = (int)((unsigned)min(a.T - tq, 4) & ok);
@@ -1059,8 +1063,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
             const int x_row = f * a.T + t0;
 #pragma unroll
             for (int i = 0; i < C::X_PER_T; ++i) {
-                const int tq = t0 - 8 + 4 * x_q[i];
-                const unsigned ok = (unsigned)-(x_valid[i] & (tq >= 0) & (tq < a.T));
+                const int tq = t0 + 4 * x_q[i];
+                const unsigned ok = (unsigned)-(x_valid[i] & (tq < a.T));
                 const unsigned off = ((unsigned)(x_base[i] + x_row) & ok) | (OOB & ~ok);
                 rx[BUF][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off * 4u, 0, 0);
                 rx_n[BUF][i] = (int)((unsigned)min(max(tlim - tq, 0), 4) & ok);
@@ -1079,7 +1083,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
             unsigned char* dy_s = lds + stage * C::DY_STAGE;
 #pragma unroll
             for (int i = 0; i < C::DY_PER_T; ++i) {
-                if (C::DY_ITEMS % 256 == 0 || pt + i * 256 < C::DY_ITEMS) {
+                if (y_item[i]) {
                     const u32x4_t r = ry[BUF][i];
                     float v[4] = {__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
 #pragma unroll
@@ -1088,7 +1092,23 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
                         if (unpool) keep = keep && (int)((ryi[BUF][i] >> (8 * e)) & 0xffu) == r_par[BUF];
                         v[e] = keep ? v[e] : 0.f;
                     }
-                    put(dy_s + y_lds[i], C::DY_PART, v);
+                    const int q = y_q[i];
+                    if (q >= 0 && q < C::TT / 4) put(dy_s + y_lds[i], C::DY_PART, v);
+                    // boundary words of the row's 8-element groups: quad 2 j - 1 ends with dY[8 j - 1] (low half of word j), quad
+                    // 2 j + 2 starts with dY[8 j + 8] (high half of word j)
+                    const bool lo_w = (q & 1) && q <= 2 * C::NJ - 3, hi_w = !(q & 1) && q >= 2;
+                    if (lo_w || hi_w) {
+                        const float bv = lo_w ? v[3] : v[0];
+                        const int j = lo_w ? (q + 1) >> 1 : (q - 2) >> 1;
+                        const unsigned u0 = __float_as_uint(bv);
+                        const float r1 = bv - __uint_as_float(u0 & 0xffff0000u);
+                        const unsigned u1 = __float_as_uint(r1);
+                        const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+                        unsigned char* pb = dy_s + 3 * C::DY_PART + y_bnd[i] + j * 4 + (hi_w ? 2 : 0);
+                        *reinterpret_cast<unsigned short*>(pb) = (unsigned short)(u0 >> 16);
+                        *reinterpret_cast<unsigned short*>(pb + C::YB_PART) = (unsigned short)(u1 >> 16);
+                        *reinterpret_cast<unsigned short*>(pb + 2 * C::YB_PART) = (unsigned short)(__float_as_uint(r2) >> 16);
+                    }
                 }
             }
         };
@@ -1109,22 +1129,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
                         v[e] = e < rx_n[BUF][i] ? v[e] : 0.f;            // zero padding is post-activation
                     }
                     put(x_s + x_lds[i], C::X_PART, v);
-                    // boundary words: quad 1 + 2 j ends with x[8 j - 1] (low half of word j), quad 4 + 2 j starts with x[8 j + 8]
-                    // (high half of word j); relative to the row image the centre starts at element 8
-                    const int q = x_q[i];
-                    const bool lo_w = (q & 1) && q <= 2 * C::NJ - 1, hi_w = !(q & 1) && q >= 4 && q <= 2 * C::NJ + 2;
-                    if (lo_w || hi_w) {
-                        const float bv = lo_w ? v[3] : v[0];
-                        const int j = lo_w ? (q - 1) >> 1 : (q - 4) >> 1;
-                        const unsigned u0 = __float_as_uint(bv);
-                        const float r1 = bv - __uint_as_float(u0 & 0xffff0000u);
-                        const unsigned u1 = __float_as_uint(r1);
-                        const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
-                        unsigned char* pb = x_s + 3 * C::X_PART + x_bnd[i] + j * 4 + (hi_w ? 2 : 0);
-                        *reinterpret_cast<unsigned short*>(pb) = (unsigned short)(u0 >> 16);
-                        *reinterpret_cast<unsigned short*>(pb + C::XB_PART) = (unsigned short)(u1 >> 16);
-                        *reinterpret_cast<unsigned short*>(pb + 2 * C::XB_PART) = (unsigned short)(__float_as_uint(r2) >> 16);
-                    }
                 }
             }
         };
@@ -1175,10 +1179,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
     } else if (nSteps > 0) {
         // ================================================================ CONSUMER
         const u32x4_t ones = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-        // dY fragment: slice wks, row lr, t group lq;  x fragment: cin lr, t = 32 wks + 8 lq .. + 7 of the centre;  its boundary word
+        // dY fragment: slice wks, row lr, t group lq, and its boundary word;  x fragment: cin lr, t = 32 wks + 8 lq .. + 7
         const unsigned a_lane = (unsigned)(wks * C::COUT_T * 64 + lr * 64 + (((lq ^ ((-(lr >> 2)) & 3)) & 3) * 16));
-        const unsigned b_lane = (unsigned)(lr * C::XCH + 16 + (wks * 4 + lq) * 16);
-        const unsigned bnd_lane = (unsigned)(lr * C::XB_CH + (wks * 4 + lq) * 4);
+        const unsigned bnd_lane = (unsigned)(lr * C::YB_CH + (wks * 4 + lq) * 4);
+        const unsigned b_lane = (unsigned)(lr * C::XCH + (wks * 4 + lq) * 16);
         auto step = [&](int S) __attribute__((always_inline)) {
             const int f = S % a.F;
             const unsigned char* dy_s = lds + (S & 1) * C::DY_STAGE;
@@ -1187,41 +1191,39 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
             xoff[0] = (unsigned)(C::X_BASE + (f > 0 ? ((S - 1) & 3) : 4) * C::X_SLOT);
             xoff[1] = (unsigned)(C::X_BASE + (S & 3) * C::X_SLOT);
             xoff[2] = (unsigned)(C::X_BASE + (f + 1 < a.F ? ((S + 1) & 3) : 4) * C::X_SLOT);
-            u32x4_t af[MTL][3];
+            // dW[kw] = sum_t dY[t] x[t + kw - 1] = sum_u dY[u - kw + 1] x[u]: the kw = 0 / 2 taps take the dY operand shifted by one
+            // element (built ONCE per step in registers from the centre fragment and its boundary word, shared by the three kernel
+            // rows and the cin tiles) against the SAME x fragment - the x fragments need no arithmetic at all.  (Shifting x, as
+            // the first form of this kernel did, costs the shifts per (kernel row, cin tile): 220 VALU instructions per 222 MFMAs.)
+            u32x4_t af[MTL][3], aL[MTL][3], aR[MTL][3];             // dY[t], dY[t - 1] (tap kw = 2), dY[t + 1] (tap kw = 0)
 #pragma unroll
             for (int m = 0; m < MTL; ++m)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    af[m][p] = *reinterpret_cast<const u32x4_t*>(dy_s + p * C::DY_PART + ((wmi * MTL + m) * 16) * 64 + a_lane);
-            // x fragments of the (kernel row, cin tile) pairs one pair ahead: the reads of pair j + 1 are in flight during the shift
-            // arithmetic and the MFMAs of pair j (the scheduler alone sinks every read to its use)
-            u32x4_t craw[2][3];
-            unsigned wraw[2][3];
-            auto read_x = [&](int j, u32x4_t (&cr)[3], unsigned (&wr)[3]) __attribute__((always_inline)) {
+                for (int p = 0; p < 3; ++p) {
+                    const u32x4_t c = *reinterpret_cast<const u32x4_t*>(dy_s + p * C::DY_PART + ((wmi * MTL + m) * 16) * 64 + a_lane);
+                    // {dY[t - 1] (low half), dY[t + 8] (high half)} of this lane's 8-element group
+                    const unsigned w = *reinterpret_cast<const unsigned*>(dy_s + 3 * C::DY_PART + p * C::YB_PART +
+                                                                             ((wmi * MTL + m) * 16) * C::YB_CH + bnd_lane);
+                    const unsigned s1 = __builtin_amdgcn_alignbit(c.y, c.x, 16), s2 = __builtin_amdgcn_alignbit(c.z, c.y, 16),
+                                   s3 = __builtin_amdgcn_alignbit(c.w, c.z, 16);
+                    af[m][p] = c;
+                    aL[m][p] = u32x4_t{__builtin_amdgcn_perm(c.x, w, 0x05040100u), s1, s2, s3};     // dY[t-1 .. t+6]
+                    aR[m][p] = u32x4_t{s1, s2, s3, __builtin_amdgcn_perm(w, c.w, 0x07060302u)};    // dY[t+1 .. t+8]
+                }
+            // x fragments of the (kernel row, cin tile) pairs one pair ahead of the MFMAs that use them
+            u32x4_t cx[2][3];
+            auto read_x = [&](int j, u32x4_t (&cr)[3]) __attribute__((always_inline)) {
                 const int kh = j / NTL, n = j % NTL;
                 const unsigned char* x_s = lds + xoff[kh];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < 3; ++p)
                     cr[p] = *reinterpret_cast<const u32x4_t*>(x_s + p * C::X_PART + ((wni * NTL + n) * 16) * C::XCH + b_lane);
-                    // {x[t - 1] (low half), x[t + 8] (high half)} of this lane's 8-element group
-                    wr[p] = *reinterpret_cast<const unsigned*>(x_s + 3 * C::X_PART + p * C::XB_PART + ((wni * NTL + n) * 16) * C::XB_CH + bnd_lane);
-                }
             };
-            read_x(0, craw[0], wraw[0]);
+            read_x(0, cx[0]);
 #pragma unroll
             for (int j = 0; j < 3 * NTL; ++j) {
                 const int kh = j / NTL, n = j % NTL, cur = j & 1;
-                if (j + 1 < 3 * NTL) read_x(j + 1, craw[cur ^ 1], wraw[cur ^ 1]);
-                u32x4_t c[3], left[3], right[3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    c[p] = craw[cur][p];
-                    const unsigned w = wraw[cur][p];
-                    const unsigned s1 = __builtin_amdgcn_alignbit(c[p].y, c[p].x, 16), s2 = __builtin_amdgcn_alignbit(c[p].z, c[p].y, 16),
-                                   s3 = __builtin_amdgcn_alignbit(c[p].w, c[p].z, 16);
-                    left[p] = u32x4_t{__builtin_amdgcn_perm(c[p].x, w, 0x05040100u), s1, s2, s3};     // x[t-1 .. t+6]
-                    right[p] = u32x4_t{s1, s2, s3, __builtin_amdgcn_perm(w, c[p].w, 0x07060302u)};    // x[t+1 .. t+8]
-                }
+                if (j + 1 < 3 * NTL) read_x(j + 1, cx[cur ^ 1]);
                 // six part products of the (m, kw) accumulators round-robin, smallest first
 #pragma unroll
                 for (int pp = 0; pp < 6; ++pp) {
@@ -1229,9 +1231,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
                     const int pb = pp == 0 ? 0 : pp == 1 ? 2 : pp == 2 ? 1 : pp == 3 ? 0 : pp == 4 ? 1 : 0;
 #pragma unroll
                     for (int m = 0; m < MTL; ++m) {
-                        acc[m][n][kh * 3 + 0] = wg_mfma(af[m][pa], left[pb], acc[m][n][kh * 3 + 0]);
-                        acc[m][n][kh * 3 + 1] = wg_mfma(af[m][pa], c[pb], acc[m][n][kh * 3 + 1]);
-                        acc[m][n][kh * 3 + 2] = wg_mfma(af[m][pa], right[pb], acc[m][n][kh * 3 + 2]);
+                        acc[m][n][kh * 3 + 0] = wg_mfma(aR[m][pa], cx[cur][pb], acc[m][n][kh * 3 + 0]);
+                        acc[m][n][kh * 3 + 1] = wg_mfma(af[m][pa], cx[cur][pb], acc[m][n][kh * 3 + 1]);
+                        acc[m][n][kh * 3 + 2] = wg_mfma(aL[m][pa], cx[cur][pb], acc[m][n][kh * 3 + 2]);
                     }
                 }
             }
