@@ -900,11 +900,14 @@ __global__ __launch_bounds__(MH * 128) void conv_wgrad_bf16_kernel(ConvWgradArgs
 // each whatever they hit (an ablation that re-reads one cached chunk is no faster), which is what bounded the
 // chunk-at-a-time form of this kernel.
 // Operand images are t-innermost as in the bf16 kernel: dY rows are 64 bytes with XOR-swizzled 16-byte groups, x rows
-// [cin][48 t] with a 112-byte channel stride (16 bytes mod 128), so every fragment is one conflict-free ds_read_b128 per
-// part; the kw = 0 / 2 operands are the centre operand shifted by one element in registers - the two elements a shift pulls
-// in from outside the lane's 8 (x[8j - 1], x[8j + 8]) sit packed in one dword of a small side array with an odd dword
-// stride per channel (read straight from the row image they are 8-way bank conflicts: every channel row starts on the
-// same 4 banks).
+// [cin][32 t] with an 80-byte channel stride (an odd multiple of 16 bytes), so every fragment is one conflict-free
+// ds_read_b128 per part.  The kw = 0 / 2 taps use the dY operand shifted by one element against the SAME x fragment
+// (dW[kw] = sum_t dY[t] x[t + kw - 1] = sum_u dY[u - kw + 1] x[u]): the shifted forms are built once per step in registers and
+// serve all three kernel rows and cin tiles; the two elements a shift pulls in from outside the lane's 8 (dY[8j - 1],
+// dY[8j + 8]) sit packed in one dword of a small side array with an odd dword stride per row (read straight from the row
+// image they are 8-way bank conflicts: every row starts on the same 4 banks), the row's outer elements come with two extra
+// quads per dY row.  (The first form shifted x instead - per kernel row and cin tile: 220 VALU instructions per 222 MFMAs in
+// the consumer, and VALU instructions are paid in MFMA time.)
 // Why not the Winograd form here: its operands are 6/4 as large per part and are read once per transform point and kernel
 // row - at bf16x3 rates that kernel is bound by LDS bytes, this one by the MFMA pipe.
 // ============================================================================================
