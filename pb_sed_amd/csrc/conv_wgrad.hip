@@ -1021,7 +1021,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
             const bool ok = x_valid[i] && pro;
             x_sc[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_sc, ok ? (unsigned)(cin0 + cl) * 4u : 0x80000000u, 0, 0));
             x_sh[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_sh, ok ? (unsigned)(cin0 + cl) * 4u : 0x80000000u, 0, 0));
+            if (!pro) x_sc[i] = 1.f;
         }
+        const float relu_floor = (pro && a.relu) ? 0.f : -__builtin_inff();
         constexpr int NB = C::NB;                          // raw register sets = steps whose loads are in flight
         u32x4_t ry[NB][C::DY_PER_T], rx[NB][C::X_PER_T];
         unsigned ryi[NB][C::DY_PER_T];
@@ -1125,11 +1127,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
                     float v[4] = {__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (pro) {
-                            v[e] = fmaf(v[e], x_sc[i], x_sh[i]);
-                            if (a.relu) v[e] = fmaxf(v[e], 0.f);
-                        }
-                        v[e] = e < rx_n[BUF][i] ? v[e] : 0.f;            // zero padding is post-activation
+                        const float u = fmaxf(fmaf(v[e], x_sc[i], x_sh[i]), relu_floor);      // no prologue: x * 1 + 0, floor -inf
+                        v[e] = e < rx_n[BUF][i] ? u : 0.f;               // zero padding is post-activation
                     }
                     put(x_s + x_lds[i], C::X_PART, v);
                 }

@@ -47,7 +47,10 @@ constexpr int WX_V_BYTES = 2 * WX_HALF;
 #ifndef WX_DBG
 #define WX_DBG 0            // ablation switches of tools/kernel_ablation.sh (never set in the product build)
 #endif
-constexpr int WX_RING = 2;                              // U register ring in transform points (3 kh x 3 parts x 16 B per lane each)
+#ifndef WX_RING_N
+#define WX_RING_N 2
+#endif
+constexpr int WX_RING = WX_RING_N;                      // U register ring in transform points (3 kh x 3 parts x 16 B per lane each)
 
 template <bool POOL>
 struct WxCfg {
@@ -384,8 +387,9 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
     int ct, sp;
     item(0, ct, sp);
     unsigned u_base = (unsigned)(ct * (CT / 16) + cw) * 3072u;       // point 0 of chunk 0, this wave's cout tile
-    static_assert(WX_RING == 2, "the ring holds the current point and the next one");
+    static_assert(WX_RING == 2 || WX_RING == 3, "the ring holds the current point and the next one (two)");
     load_A(0, u_base);
+    if (WX_RING == 3) load_A(1, u_base + point_bytes);
 
     f32x4 acc[6][NF];
     __syncthreads();                                                 // half 0 of the first chunk is staged
@@ -419,7 +423,10 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
                 for (int xl = 0; xl < 3; ++xl) {
                     const int x = half * 3 + xl;
                     // U of the next point into the slot the previous point left
-                    if (!(WX_DBG & 4)) load_A((x + 1) % WX_RING, x + 1 < 6 ? soff_u + (unsigned)(x + 1) * point_bytes : soff_next);
+                    constexpr int AHEAD = WX_RING - 1;                  // points between a load and its use
+                    if (!(WX_DBG & 4))
+                        load_A((x + AHEAD) % WX_RING, x + AHEAD < 6 ? soff_u + (unsigned)(x + AHEAD) * point_bytes
+                                                                    : soff_next + (unsigned)(x + AHEAD - 6) * point_bytes);
                     if (WX_DBG & 8) continue;
 #pragma unroll
                     for (int h = 0; h < NF + 2; ++h) {                     // halo rows f_lo + h of the wave's NF output rows
