@@ -138,6 +138,7 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
         const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.shift), 0, pro ? (unsigned)a.Cin * 4u : 0u, 0x00020000);
         const bool edge_lane = tile == 0 || tile == 15;
+        const float relu_floor = (pro && a.relu) ? 0.f : -__builtin_inff();
         const unsigned row_elems = (unsigned)a.T;
         const unsigned chan_step = (unsigned)(Fsrc * a.T);
         // LDS byte offset of this thread's 8-byte slot in a (point, row) plane: tile position, swizzled k-group, half
@@ -183,8 +184,8 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
             const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
                 unpool ? const_cast<uint8_t*>(a.unpool_idx) + (size_t)ld_b * clip_elems : nullptr, 0, unpool ? clip_elems : 0u, 0x00020000);
             const unsigned cin0 = (unsigned)(ld_ch * WX_CK + 4 * cgp);
-            if (pro) {                                             // four consecutive channels: one 16-byte load each (Cin % 4 == 0 is not
-                rsc[BUF].x = __builtin_amdgcn_raw_buffer_load_b32(rs_sc, cin0 * 4u, 0, 0);          // required: element loads, range-checked)
+            {                                                      // four consecutive channels (Cin % 4 == 0 is not required: element
+                rsc[BUF].x = __builtin_amdgcn_raw_buffer_load_b32(rs_sc, cin0 * 4u, 0, 0);          // loads, range-checked; no prologue: empty)
                 rsc[BUF].y = __builtin_amdgcn_raw_buffer_load_b32(rs_sc, cin0 * 4u + 4u, 0, 0);
                 rsc[BUF].z = __builtin_amdgcn_raw_buffer_load_b32(rs_sc, cin0 * 4u + 8u, 0, 0);
                 rsc[BUF].w = __builtin_amdgcn_raw_buffer_load_b32(rs_sc, cin0 * 4u + 12u, 0, 0);
@@ -250,7 +251,10 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
                 WX_EDGE(0) WX_EDGE(1) WX_EDGE(2) WX_EDGE(3) WX_EDGE(4) WX_EDGE(5) WX_EDGE(6) WX_EDGE(7) WX_EDGE(8) WX_EDGE(9) WX_EDGE(10) WX_EDGE(11)
 #undef WX_EDGE
             }
-            const float scv[4] = {__uint_as_float(rsc[BUF].x), __uint_as_float(rsc[BUF].y), __uint_as_float(rsc[BUF].z), __uint_as_float(rsc[BUF].w)};
+            // prologue without selects: x * 1 + 0 when there is none (the empty scale / shift resources read 0), ReLU as a max with
+            // 0 or -inf
+            const float scv[4] = {pro ? __uint_as_float(rsc[BUF].x) : 1.f, pro ? __uint_as_float(rsc[BUF].y) : 1.f,
+                                  pro ? __uint_as_float(rsc[BUF].z) : 1.f, pro ? __uint_as_float(rsc[BUF].w) : 1.f};
             const float shv[4] = {__uint_as_float(rsh[BUF].x), __uint_as_float(rsh[BUF].y), __uint_as_float(rsh[BUF].z), __uint_as_float(rsh[BUF].w)};
             unsigned char* base = smem_raw + lds_t;
 #pragma unroll
@@ -267,17 +271,11 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
                     for (int k = 0; k < 4; ++k) {
                         float u = __uint_as_float(rin[BUF][j][c][k]);
                         if (unpool) u = (int)((ridx[BUF][j][c] >> (8 * k)) & 0xffu) != par ? 0.f : u;
-                        if (pro) {
-                            u = fmaf(u, sc, sh);
-                            if (a.relu) u = fmaxf(u, 0.f);
-                        }
+                        u = fmaxf(fmaf(u, sc, sh), relu_floor);
                         v[k] = (live && k < fi_nok[BUF]) ? u : 0.f;
                     }
                     if (unpool) ve = (int)(edge_i[j * 4 + c] & 0xffu) != par ? 0.f : ve;
-                    if (pro) {
-                        ve = fmaf(ve, sc, sh);
-                        if (a.relu) ve = fmaxf(ve, 0.f);
-                    }
+                    ve = fmaxf(fmaf(ve, sc, sh), relu_floor);
                     ve = (live && fi_edge_ok[BUF]) ? ve : 0.f;
                     // d0 = the left neighbour's last input, d5 = the right neighbour's first one
                     const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[3]), 0x111, 0xf, 0xf, true));    // row_shr:1
@@ -392,7 +390,17 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
     if (WX_RING == 3) load_A(1, u_base + point_bytes);
 
     f32x4 acc[6][NF];
+#if WX_DBG & 128
+    // profiling build: shader-clock time of consumer wave 0 of block 0 in (a) the MFMA phases, (b) the block barriers, (c) the
+    // epilogues; written over the first floats of y at the end (thousands of clocks)
+    unsigned long long pt_mfma = 0, pt_bar = 0, pt_epi = 0, pt_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long pt_begin = pt_t;
+#define WX_TICK(acc_) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - pt_t; pt_t = now_; }
+#else
+#define WX_TICK(acc_)
+#endif
     __syncthreads();                                                 // half 0 of the first chunk is staged
+    WX_TICK(pt_bar)
     for (int k = 0; k < nT; ++k) {
         const int t0 = (sp % nTt) * WX_TT;
         const int f0 = ((sp / nTt) % nFt) * WX_FT;
@@ -446,7 +454,9 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
                         }
                     }
                 }
+                WX_TICK(pt_mfma)
                 __syncthreads();
+                WX_TICK(pt_bar)
             }
         }
 
@@ -573,7 +583,14 @@ __global__ __launch_bounds__(512) void conv_winox3_kernel(ConvFwdArgs a, int nCt
         }
         (void)FO_T;
         ct = ct_n; sp = sp_n; u_base = u_base_n;
+        WX_TICK(pt_epi)
     }
+#if WX_DBG & 128
+    if (blockIdx.x == 0 && tid == 0) {
+        a.y[0] = (float)(pt_mfma >> 10); a.y[1] = (float)(pt_bar >> 10); a.y[2] = (float)(pt_epi >> 10);
+        a.y[3] = (float)((__builtin_amdgcn_s_memtime() - pt_begin) >> 10); a.y[4] = (float)nT; a.y[5] = (float)nChunks;
+    }
+#endif
 }
 
 template <bool POOL, bool DGRAD, bool UNPOOL, int CT = WX_CT>
