@@ -972,9 +972,11 @@ static void granule_poll_delays(bool bwd, GruStackArgs& a, int nb = 1) {
 }
 
 // Ring-per-XCD placement (granule_role) per scan direction: bit 0 = forward, bit 1 = BPTT.  Measured on MI355X with the
-// paced 4-byte polls: forward 1.35 ms with / 1.48 ms without, BPTT 1.66 / 1.64 ms.
+// paced 4-byte polls: forward 1.35 ms with / 1.48 ms without, BPTT 1.66 / 1.64 ms (round 2: forward only).  Round 3, with the
+// tile-major exchange, the bf16x3 products and the delays tuned in place: BPTT 1.335 ms spread over all XCDs, 1.285 ms with
+// one ring per XCD (three same-box pairs) - both directions by default.
 static bool granule_ring_xcd(bool bwd) {
-    static const int v = [] { const char* e = getenv("PBSED_GRU_RING_XCD"); return e ? atoi(e) : 1; }();
+    static const int v = [] { const char* e = getenv("PBSED_GRU_RING_XCD"); return e ? atoi(e) : 3; }();
     return (v >> (bwd ? 1 : 0)) & 1;
 }
 
