@@ -40,13 +40,14 @@ XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7
 FWD_GFLOP = {'c2': 11.82, 'c3': 12.34}
 # what 'dtype' means in detail (the value itself stays the plain type name)
 ARITHMETIC_NOTE = {
-    'f32': 'fp32 storage, accumulation, state and results throughout.  3x3 conv layers: fp32 MFMA (Winograd F(4,3) along t where '
-           'MFMA-bound).  GRU scans, GRU weight gradients, the projections around the scans and the Conv1d layers form their '
-           'products on the bf16 MFMA from EXACT three-way bf16 splits of both fp32 operands (x = hi + mid + lo, 8 + 8 + 8 '
-           'significant bits; the six part products above 2^-24 accumulated in fp32): fp32-class results - rms error vs fp64 '
-           '5.0e-7 against 5.9e-7 of the fp32-MFMA kernel on the same layer - held to the same 1e-4 logit / gradient parity '
-           'tests; PBSED_GRU_X3=0 PBSED_GRU_WGRAD_X3=0 PBSED_CONV1D_X3=0 select the fp32-MFMA forms of the scans, GRU weight '
-           'gradients and Conv1d layers',
+    'f32': 'fp32 storage, accumulation, state and results throughout.  Every product with >= 32 channels on either side - the '
+           '3x3 conv layers (Winograd F(4,3) along t) and their weight gradients, the Conv1d layers, GRU scans, GRU weight '
+           'gradients, the projections around the scans - is formed on the bf16 MFMA from EXACT three-way bf16 splits of both '
+           'fp32 operands (x = hi + mid + lo by truncation, 8 + 8 + 8 significant bits; the six part products above 2^-24 '
+           'accumulated in fp32): fp32-class results - rms error vs an fp64 convolution 9.4e-7 (Winograd bf16x3) / 5.0e-7 (direct '
+           'bf16x3) against 1.1e-6 / 5.9e-7 of the fp32-MFMA kernels on the same layers - held to the same 1e-4 logit / gradient '
+           'parity tests.  The 1- and 16-channel layers run on the fp32 MFMA.  PBSED_CONV_WINOX3=0 PBSED_WGRAD_PC=0 '
+           'PBSED_CONV1D_X3=0 PBSED_GRU_X3=0 PBSED_GRU_WGRAD_X3=0 select the fp32-MFMA forms',
     'bf16': 'bf16 MFMA operands (rounded to nearest even while staged) in every conv / projection / scan / weight-gradient '
             'product with >= 32 channels; fp32 accumulation, BN, GRU state, losses, master weights and optimiser',
     'bf16x3': 'every conv product from exact three-way bf16 operand splits on the bf16 MFMA (fp32-class); the rest as f32',
