@@ -35,7 +35,9 @@ const char* pbsed_last_error(void);
 int pbsed_version(void);
 /* Caller-owned scratch for (current device, stream): pbsed_conv_bwd_weight* and pbsed_gru_wgrad* take their partial-sum slots
  * from it instead of the library's per-device buffer (several streams of one device may then run them concurrently).
- * scratch = NULL removes the registration; pbsed_scratch_bytes() covers every launch of the reference networks. */
+ * scratch = NULL removes the registration; pbsed_scratch_bytes() covers every launch of the reference networks.  The
+ * library fills the first 2 MB of a registered buffer with zeros once and KEEPS them zero between its launches (the slotted
+ * convolution gradients add into them, their reduction pass clears them again): hands off while it is registered. */
 size_t pbsed_scratch_bytes(void);
 int pbsed_set_scratch(void* scratch /*device*/, size_t bytes, void* stream);
 

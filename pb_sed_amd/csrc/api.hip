@@ -48,6 +48,7 @@ struct ScratchSlot {
     float* ptr;
     size_t floats;
     bool owned;            // library-owned fallback (per device, stream = any)
+    size_t clean;          // floats at the front that are known to be zero (scratch_zeroed_front)
 };
 constexpr int kScratchSlots = 64;
 ScratchSlot g_scratch[kScratchSlots] = {};
@@ -71,10 +72,10 @@ float* scratch_for(hipStream_t stream, size_t floats) {
         if (e.owned) own = &e;
     }
     if (!out) {
-        if (!own && g_scratch_n < kScratchSlots) { own = &g_scratch[g_scratch_n++]; *own = ScratchSlot{dev, nullptr, nullptr, 0, true}; }
+        if (!own && g_scratch_n < kScratchSlots) { own = &g_scratch[g_scratch_n++]; *own = ScratchSlot{dev, nullptr, nullptr, 0, true, 0}; }
         if (own) {
             if (own->floats < floats) {
-                if (own->ptr) { (void)hipDeviceSynchronize(); (void)hipFree(own->ptr); own->ptr = nullptr; own->floats = 0; }
+                if (own->ptr) { (void)hipDeviceSynchronize(); (void)hipFree(own->ptr); own->ptr = nullptr; own->floats = 0; own->clean = 0; }
                 if (hipMalloc(&own->ptr, floats * sizeof(float)) == hipSuccess) own->floats = floats;
             }
             out = own->floats >= floats ? own->ptr : nullptr;
@@ -82,6 +83,25 @@ float* scratch_for(hipStream_t stream, size_t floats) {
     }
     pthread_mutex_unlock(&g_scratch_mu);
     return out;
+}
+
+// The first `front` floats of that scratch, ZERO on return and kept zero by their users (the slotted weight-gradient launches add
+// into them and wgrad_slot_reduce_kernel writes zeros back behind its reads): filled once per registration / allocation, in
+// stream order, instead of once per launch.  Everything behind `front` is free-for-all (scratch_for(..) + front).
+float* scratch_zeroed_front(hipStream_t stream, size_t front, size_t total) {
+    float* base = scratch_for(stream, total);
+    if (!base) return nullptr;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool fill = false;
+    pthread_mutex_lock(&g_scratch_mu);
+    for (int i = 0; i < g_scratch_n; ++i) {
+        ScratchSlot& e = g_scratch[i];
+        if (e.dev == dev && e.ptr == base && e.clean < front) { e.clean = front; fill = true; }
+    }
+    pthread_mutex_unlock(&g_scratch_mu);
+    if (fill && hipMemsetAsync(base, 0, front * sizeof(float), stream) != hipSuccess) return nullptr;
+    return base;
 }
 
 }  // namespace pbsed
@@ -109,7 +129,7 @@ int pbsed_set_scratch(void* scratch, size_t bytes, void* stream) {
         if (g_scratch_n < kScratchSlots) hit = g_scratch_n++;
         else { set_error("pbsed_set_scratch: registration table full (%d)", kScratchSlots); rc = PBSED_E_ARG; }
     }
-    if (hit >= 0) g_scratch[hit] = ScratchSlot{dev, (hipStream_t)stream, scratch ? (float*)scratch : nullptr, scratch ? bytes / sizeof(float) : 0, false};
+    if (hit >= 0) g_scratch[hit] = ScratchSlot{dev, (hipStream_t)stream, scratch ? (float*)scratch : nullptr, scratch ? bytes / sizeof(float) : 0, false, 0};
     pthread_mutex_unlock(&g_scratch_mu);
     return rc;
 }

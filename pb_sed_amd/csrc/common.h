@@ -116,6 +116,8 @@ void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 int device_cus();                                             // CUs of the CURRENT device (cached per device ordinal)
 float* scratch_for(hipStream_t stream, size_t floats);        // partial-sum scratch of (current device, stream); api.hip
+float* scratch_zeroed_front(hipStream_t stream, size_t front, size_t total);     // ... whose first `front` floats are zero and stay so
+constexpr size_t PBSED_SCRATCH_FRONT = (size_t)32 * (16384 + 64);               // the slotted conv weight gradients' part of it
 
 // runtime calls in front of a launch (attributes, memsets): report a failure like a failed launch
 #define PBSED_HIP_TRY(expr, what)                                               \

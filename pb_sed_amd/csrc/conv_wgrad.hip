@@ -288,17 +288,22 @@ void conv_wgrad_kernel(ConvWgradArgs a) {
 // lines; their blocks add into WGRAD_SLOTS partial copies instead, summed into the gradient by this kernel.
 constexpr int WGRAD_SLOTS = 32, WGRAD_SLOT_MAX = 16384 + 64;      // floats per slot (weights + bias)
 
-__global__ void wgrad_slot_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+// ... and leaves the slots zero behind it: they are filled once per scratch registration, not once per launch
+__global__ void wgrad_slot_reduce_kernel(float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
                                          int nw, int nb, int stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nw + nb) return;
     float v = 0.f;
 #pragma unroll 8
-    for (int sl = 0; sl < WGRAD_SLOTS; ++sl) v += part[(size_t)sl * stride + i];
+    for (int sl = 0; sl < WGRAD_SLOTS; ++sl) {
+        v += part[(size_t)sl * stride + i];
+        part[(size_t)sl * stride + i] = 0.f;
+    }
     if (i < nw) dw[i] += v; else if (db) db[i - nw] += v;
 }
 
-static float* wgrad_slot_scratch(hipStream_t s) { return scratch_for(s, (size_t)WGRAD_SLOTS * WGRAD_SLOT_MAX); }
+static_assert(PBSED_SCRATCH_FRONT == (size_t)WGRAD_SLOTS * WGRAD_SLOT_MAX, "common.h");
+static float* wgrad_slot_scratch(hipStream_t s) { return scratch_zeroed_front(s, PBSED_SCRATCH_FRONT, PBSED_SCRATCH_FRONT); }
 
 // Shared launcher: K-split so that the grid is (close to) an integer number of full residency rounds (blocks per CU
 // from the occupancy query, n_cu * occ resident slots, one or two rounds depending on how much K there is), slotted
@@ -344,7 +349,6 @@ static int launch_wgrad_cfg(Kern kern, const ConvWgradArgs& a_in, hipStream_t s)
     float* scratch = (slot_ok && split >= 4 * WGRAD_SLOTS) ? wgrad_slot_scratch(s) : nullptr;
     if (scratch) {
         const int stride = (nw + nb + 63) / 64 * 64;
-        PBSED_HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(float) * WGRAD_SLOTS * stride, s), "hipMemsetAsync");
         a.dw = scratch; a.db = a_in.db ? scratch + nw : nullptr;
         a.nslots = WGRAD_SLOTS; a.slot_w = stride; a.slot_b = stride;
         hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, s, a);

@@ -292,7 +292,11 @@ __global__ void gru_wgrad_slot_reduce_kernel(GruWgradArgs a, int n) {
 using namespace pbsed;
 
 // device scratch of the slot mode: the caller's registered buffer for (device, stream) or the library's per-device one (api.hip)
-static float* gru_wgrad_scratch(size_t floats, hipStream_t s) { return scratch_for(s, floats); }
+// (behind the front part that the slotted conv weight gradients keep zero)
+static float* gru_wgrad_scratch(size_t floats, hipStream_t s) {
+    float* base = scratch_for(s, PBSED_SCRATCH_FRONT + floats);
+    return base ? base + PBSED_SCRATCH_FRONT : nullptr;
+}
 
 static int gru_wgrad_launch(int n, const float* const* dg, const float* const* x, const int* shift, float* const* dw,
                             float* const* db, int T, int B, int G, const int* Ks, int operands, void* stream) {
