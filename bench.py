@@ -94,6 +94,25 @@ def pmc_traffic(kernel_tag):
     return (None, None) if row is None else (row['hbm_bytes_per_launch'], row['source'])
 
 
+def _pmc_mfma_busy(kernel_prefixes):
+    """MFMA-pipe busy share of kernels of the headline step from the committed counter pass (profiles/r03_pmc_mfma.csv:
+    SQ_VALU_MFMA_BUSY_CYCLES per SIMD over the kernel's clocks, tools/run_profiles.sh step 5); {} if the file is not there."""
+    import csv
+    path = os.path.join(ROOT, 'profiles', 'r03_pmc_mfma.csv')
+    out = {}
+    try:
+        for r in csv.DictReader(open(path)):
+            for pre in kernel_prefixes:
+                if pre in r['kernel']:
+                    key = [c for c in r if c.startswith('mfma_pipe_busy_frac')][0]
+                    out[pre] = float(r[key])
+    except (OSError, ValueError, IndexError, KeyError):
+        return {}
+    if out:
+        out['source'] = 'profiles/r03_pmc_mfma.csv (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ..., own pass)'
+    return out
+
+
 def host_cpu():
     model = 'unknown'
     try:
@@ -297,6 +316,9 @@ def roofline_objects(agg, by_family, steps, batch, precision, gru_shape, kind):
                           'executed / frac_executed: what the MFMA pipe actually ran (bf16x3 scans: 6 bf16 products each, over the bf16 peak)',
                      peak=PEAK_TFLOPS['f32'], peak_executed=PEAK_TFLOPS['bf16'], unit='TFLOP/s',
                      shape=dict(chains=nch, layers=nl, T=t, B=b, H=h))
+            pmc = _pmc_mfma_busy(('gru_granule_fwd', 'gru_granule_bwd'))
+            if pmc:
+                g['mfma_pipe_busy_pmc'] = pmc
             out['roofline_gru'] = g
     fe = [v for k, v in agg.items() if k[0] in ('pbsed_logmel_fwd', 'pbsed_logmel_from_stft')]
     if fe:
