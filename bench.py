@@ -679,8 +679,9 @@ def main():
             print(f'[bench] RCCL spans {world} ranks: {rendezvous}', file=sys.stderr, flush=True)
     full = args.config == 'c2' and not args.headline_only and args.conv_precision is None and args.batch == 32
     out = run_config(args, args.config, world, rank, device, sustained_steps=args.sustained_steps if full else 0)
-    if full:
+    if full and world == 1:
         # the driver runs the default command only: carry the sustained figure and the other BASELINE configs on the same line
+        # (N = 1 only: the scaling runs at N > 1 time the headline config and its sustained figure, nothing a rank could trip over)
         others = {}
         for kind in ('c3', 'c5', 'deep'):
             sub = argparse.Namespace(**vars(args))
