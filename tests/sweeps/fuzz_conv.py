@@ -57,6 +57,8 @@ for case in range(n_cases):
     seq = np.sort(rng.integers(max(t // 3, 1), t + 1, b))[::-1].copy(); seq[0] = t
     scale = (torch.rand(cin, dtype=torch.float64) + .5) if pro else None
     shift = torch.randn(cin, dtype=torch.float64) * .3 if pro else None
+    if os.environ.get('FUZZ_ONLY') and case != int(os.environ['FUZZ_ONLY']):      # same random stream, one case evaluated
+        continue
     xr = x.clone().requires_grad_()
     y_ref = ref_layer(xr, w, bias, scale, shift, seq, k, pool)
     gy = torch.randn_like(y_ref)
@@ -75,14 +77,36 @@ for case in range(n_cases):
         e['stats'] = err(stats.sum(0)[:, 0], (y_ref.detach() * m).sum((0, 2, 3)))
         dw = torch.zeros_like(pc.weight); db = torch.zeros(cout, device=DEV)
         ops.conv_bwd_weight(xd, gyd, pc, dw, db, scale=dx(scale), shift=dx(shift), relu=True, seq_len=seq_dev, unpool_idx=idx)
-        e['wgrad'] = err(dw, w.grad); e['bgrad'] = err(db, bias.grad)
+        w_grad, x_grad = w.grad, xr.grad
+        if pool:
+            # a pool window whose two rows agree to fp32 rounding may pick the other row here than the float64 reference does
+            # (found by this sweep: 40->96 F22 T500, one such window moved the weight gradient by 4e-3): the gradients are then
+            # compared for the argmax THIS run took - the reference is re-differentiated through the kernel's own pool indices
+            a = xr.detach().clone().requires_grad_()
+            w2 = w.detach().clone().requires_grad_()
+            pre = ref_layer(a, w2, bias.detach(), scale, shift, seq, k, False)
+            sel = idx.cpu().long()                                                    # 0 / 1: row of the window
+            ref_sel = (pre[:, :, 1::2] > pre[:, :, 0::2]).long()
+            n_flip = int((sel != ref_sel).sum())
+            if n_flip:
+                e['pool_argmax_flips'] = float(n_flip)
+                if os.environ.get('FUZZ_DEBUG'):
+                    gap = (pre[:, :, 1::2] - pre[:, :, 0::2]).abs()[sel != ref_sel]
+                    where = (sel != ref_sel).nonzero()
+                    print('   flipped windows: |row1 - row0| max', gap.max().item(), 'median', gap.median().item(),
+                          ' t range', where[:, 3].min().item(), where[:, 3].max().item(), ' seq', seq.tolist(),
+                          ' clips', sorted(set(where[:, 0].tolist())))
+                picked = torch.where(sel.bool(), pre[:, :, 1::2], pre[:, :, 0::2])
+                picked.backward(gy)
+                w_grad, x_grad = w2.grad, a.grad
+        e['wgrad'] = err(dw, w_grad); e['bgrad'] = err(db, bias.grad)
         if not pro:
             dz, _ = ops.conv_bwd_data(gyd, pc, pc.dgrad(prec), xd.shape, idx, None, precision=prec)
-            e['dgrad'] = err(dz.reshape(x.shape), xr.grad)
+            e['dgrad'] = err(dz.reshape(x.shape), x_grad)
         torch.cuda.synchronize()
     except Exception as ex:                      # an argument error is a finding too
         print(tag, 'EXCEPTION', type(ex).__name__, str(ex)[:120]); continue
-    bad = {k_: v for k_, v in e.items() if v > (1e-3 if prec == 'bf16x3' else 2e-4)}
+    bad = {k_: v for k_, v in e.items() if k_ != 'pool_argmax_flips' and v > (1e-3 if prec == 'bf16x3' else 2e-4)}
     n_bad = globals().get('n_bad', 0) + bool(bad)
     for k_, v in e.items(): worst[k_] = max(worst.get(k_, 0.), v)
     print(tag, {k_: f'{v:.1e}' for k_, v in e.items()}, 'BAD' if bad else '')
