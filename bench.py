@@ -316,7 +316,7 @@ def roofline_objects(agg, by_family, steps, batch, precision, gru_shape, kind):
                           'executed / frac_executed: what the MFMA pipe actually ran (bf16x3 scans: 6 bf16 products each, over the bf16 peak)',
                      peak=PEAK_TFLOPS['f32'], peak_executed=PEAK_TFLOPS['bf16'], unit='TFLOP/s',
                      shape=dict(chains=nch, layers=nl, T=t, B=b, H=h))
-            pmc = _pmc_mfma_busy(('gru_granule_fwd', 'gru_granule_bwd'))
+            pmc = _pmc_mfma_busy(('gru_granule_fwd', 'gru_granule_bwd')) if kind == 'c2' else {}     # the counter pass ran the headline config
             if pmc:
                 g['mfma_pipe_busy_pmc'] = pmc
             out['roofline_gru'] = g
