@@ -7,16 +7,19 @@
 // pb_sed/data_preparation/transform.py:53) + NormalizedLogMelExtractor call
 // pb_sed/models/weak_label/crnn.py:86-90 (config pb_sed/experiments/weak_label_crnn/training.py:190-217).
 //
-// HBM-bound by design: algorithmic traffic = 4 B/sample in + 4 B/(mel bin, frame) out
-// (896 000 B per 10 s clip).  Block = 4 waves x FR frames; each wave runs whole 512-point complex
-// FFTs (3 radix-8 Stockham passes, one butterfly per lane) in its private LDS ping-pong buffers.
+// Algorithmic traffic = 4 B/sample in + 4 B/(mel bin, frame) out (896 000 B per 10 s clip); the kernel itself is bound
+// by the VALU work of the FFTs (~550 wave instructions per frame) and the mel stage, not by HBM.  Block = 4 waves x FR
+// frames; each wave runs whole 512-point complex FFTs (3 radix-8 Stockham passes, one butterfly per lane) in private LDS.
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.h"
 #include "fft512.h"
 
 namespace pbsed {
 
 constexpr int LM_SHIFT = 320, LM_WIN = 960, LM_FR = 16, LM_NMEL_MAX = 128;
-constexpr int LM_MW_MAX = 1152;      // packed non-zero filter weights staged in LDS (128 HTK-mel filters over 513 bins: ~1030); sized so that two blocks share a CU (79.3 KB each)
+constexpr int LM_MW_MAX = 1152;      // packed non-zero filter weights staged in LDS (128 HTK-mel filters over 513 bins: ~1030); two blocks share a CU (74.5 KB each)
 
 struct LogmelArgs {
     const float* wav;        // [B][N]
@@ -91,115 +94,274 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---- the fused front-end kernel.  Block = 16 frames of one clip, 4 waves; a wave transforms its 4 frames (two at a time),
+// then the block runs the mel stage over all 16.  Built around few LDS instructions per frame (the round-2 form - samples,
+// window and twiddles in LDS, ping-pong buffers, a gather loop per mel filter - was LDS-instruction-bound at ~250 wave-level
+// ds_* per frame: 63 us for 32 clips; this one 40 us, 47 with the statistics atomics):
+//  * samples straight from the clip through a raw buffer (out-of-range = 0 without a branch), the next pair of frames
+//    requested during the current pair's passes;
+//  * window, the pass twiddles and the rFFT twiddles of a lane's eight bins live in registers for all frames of the block;
+//  * pass 1 reads the samples and multiplies by the window on the fly (no packed copy), the three radix-8 passes share ONE
+//    buffer per wave, in place (a wave's LDS instructions execute in order: every lane has its eight inputs before the
+//    first output is written), at index i + (i >> 3) - the 8-consecutive / stride-64 / stride-8 access patterns of the three
+//    passes are then free of bank conflicts;
+//  * pass 3 leaves Z[lane + 64 r] in registers; the mirror bins Z[512 - k] of the real-FFT unpacking come through
+//    ds_bpermute from lane 64 - lane (register 7 - r), nothing is written back;
+//  * the mel filterbank is a banded GEMM on the fp32 MFMA over the block's 16 frames: A = filter weights [16 filters x 4 bins]
+//    (looked up in the packed sparse table, or the warped triangle computed on the fly), B = power rows [4 bins x 16 frames];
+//    a group of 16 filters only walks its own band of bins (~150 MFMAs per block for 128 HTK-mel filters instead of a
+//    variable-length gather loop whose longest lane does ~40 taps per frame).  The waves take groups (w, 7 - w) - narrow and
+//    wide bands paired.
+#ifndef LM_DBG
+#define LM_DBG 0             // ablation switches of tools/kernel_ablation.sh (never set in the product build): 1 no FFT frames, 2 no mel, 4 no sample staging
+#endif
+constexpr int LM_PS = 516;           // power-row stride in floats (4 mod 64 banks: the 16 frames x 4 bins of a B fragment hit 64 banks)
+constexpr int LM_FB = 576;           // cpx per wave FFT buffer: 512 + 512 / 8 padding
+
+__device__ __forceinline__ int fft_phys(int i) { return i + (i >> 3); }
+
 __global__ __launch_bounds__(256) void logmel_kernel(LogmelArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NS_SAMP = (LM_FR - 1) * LM_SHIFT + LM_WIN;      // 5760
-    float* samp = smem;                                           // [5760]
-    float* win = samp + NS_SAMP;                                  // [960]
-    cpx* tw = reinterpret_cast<cpx*>(win + LM_WIN);               // [1024]
-    cpx* bufs = tw + 1024;                                        // [4 waves][2][512]
-    float* tile = reinterpret_cast<float*>(bufs + 4 * 2 * 512);   // [F][LM_FR+1]
-    float* mw = tile + a.F * (LM_FR + 1);                         // packed filter weights (static filterbank)
+    cpx* bufs = reinterpret_cast<cpx*>(smem);                     // [4 waves][2][LM_FB]
+    float* P = reinterpret_cast<float*>(bufs + 8 * LM_FB);        // [LM_FR][LM_PS] power rows
+    float* mw = P + LM_FR * LM_PS;                                // packed filter weights (static filterbank)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
     const int nTt = (a.T + LM_FR - 1) / LM_FR;
-    const int b = blockIdx.x / nTt, t0 = (blockIdx.x % nTt) * LM_FR;
-    const long s0 = (long)t0 * LM_SHIFT - a.pad_front;
-    const float* wav = a.wav + (size_t)b * a.N;
+    // neighbouring 16-frame tiles of a clip write the two halves of the same 128-byte output lines: workgroups go to the XCDs
+    // round-robin, so the linear id is re-read as (xcd, slot) and every XCD gets a contiguous range of tiles
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+    const int b = bid / nTt, t0 = (bid % nTt) * LM_FR;
     const int* fpos = a.frame_pos ? a.frame_pos + (size_t)b * a.T : nullptr;
-    if (!fpos) {
-        for (int i = tid; i < NS_SAMP; i += 256) {
-            const long n = s0 + i;
-            samp[i] = (n >= 0 && n < a.N) ? wav[n] : 0.f;
+    // the clip as a raw buffer: samples before its start / past its end read as 0 without a branch (byte offsets wrap to
+    // values above the clip's size; the launcher keeps clips below 2^29 samples)
+    const __amdgpu_buffer_rsrc_t clip = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wav + (size_t)b * a.N), 0, (unsigned)a.N * 4u, 0x00020000);
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    // samples 2 n, 2 n + 1 (n = lane + 64 r) of the frame starting at sample s; a regular grid starts frames at even samples,
+    // so a pair never straddles the clip's start and one 8-byte load per pair is in range or not per dword
+    auto load_frame = [&](int fl, u32x2_t (&raw)[8]) __attribute__((always_inline)) {
+        const int t = t0 + fl;
+        if (t >= a.T || (LM_DBG & 4)) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) raw[r] = u32x2_t{0u, 0u};
+            return;
+        }
+        const int s = fpos ? fpos[t] : t * LM_SHIFT - a.pad_front;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int n = lane + 64 * r;
+            if (2 * n >= LM_WIN) { raw[r] = u32x2_t{0u, 0u}; continue; }
+            const int i0 = s + 2 * n;
+            const unsigned off = (unsigned)i0 * 4u;
+            if (fpos || (a.pad_front & 1)) {
+                // arbitrary starts: a pair may straddle the clip's start (i0 = -1); two loads whose offsets do not differ by a
+                // constant 4 (the compiler would fuse them into one 8-byte load whose second half wraps past 2^32 = out of range)
+                const unsigned off1 = i0 + 1 >= 0 ? (unsigned)(i0 + 1) * 4u : 0x80000000u;
+                raw[r] = u32x2_t{__builtin_amdgcn_raw_buffer_load_b32(clip, i0 >= 0 ? off : 0x80000000u, 0, 0),
+                                 __builtin_amdgcn_raw_buffer_load_b32(clip, off1, 0, 0)};
+            } else {
+                raw[r] = __builtin_amdgcn_raw_buffer_load_b64(clip, off, 0, 0);
+            }
+        }
+    };
+    u32x2_t raw0[8], raw1[8];
+    load_frame(wave * (LM_FR / 4), raw0);                         // the first two frames' samples are on their way during the set-up
+    load_frame(wave * (LM_FR / 4) + 1, raw1);
+
+    const float* pts = a.mel_pts ? a.mel_pts + (size_t)b * (a.F + 2) : nullptr;
+    const int n_mw = pts ? 0 : a.mel_off[a.F - 1] + a.mel_len[a.F - 1];
+    for (int i = tid; i < n_mw; i += 256) mw[i] = a.mel_w[i];
+
+    // per-lane constants: window pairs of the samples 2 n, 2 n + 1, twiddles of pass 2 (k = lane & 7), pass 3 (k = lane) and of
+    // the real-FFT unpacking of the bins lane + 64 r
+    const float2* twid = reinterpret_cast<const float2*>(a.twiddle);
+    float2 win2[8];
+    cpx tw2[7], tw3[7], twp[8];
+    const int k2 = lane & 7;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int n = lane + 64 * r;
+        win2[r] = (2 * n < LM_WIN) ? *reinterpret_cast<const float2*>(a.window + 2 * n) : make_float2(0.f, 0.f);
+        const float2 w = twid[lane + 64 * r];
+        twp[r] = cpx{w.x, w.y};
+        if (r > 0) {
+            const float2 u = twid[(r * k2 * 16) & 1023], v = twid[(r * lane * 2) & 1023];
+            tw2[r - 1] = cpx{u.x, u.y};
+            tw3[r - 1] = cpx{v.x, v.y};
         }
     }
-    const int n_mw = a.mel_pts ? 0 : a.mel_off[a.F - 1] + a.mel_len[a.F - 1];
-    for (int i = tid; i < n_mw; i += 256) mw[i] = a.mel_w[i];
-    for (int i = tid; i < LM_WIN; i += 256) win[i] = a.window[i];
-    for (int i = tid; i < 1024; i += 256) {
-        const float2 w = reinterpret_cast<const float2*>(a.twiddle)[i];
-        tw[i] = cpx{w.x, w.y};
+
+    // the mel stage's descriptors: this lane's A row (filter 16 g + lr) and the constants of its four output rows
+    // (filters 16 g + 4 lq + i); requested here, used after the FFTs
+    struct MelDesc { int st, en, off; float lo, hi, il, ih, wsum, mean[4], is[4]; };
+    auto load_desc = [&](int g) __attribute__((always_inline)) -> MelDesc {
+        MelDesc d;
+        const int m = 16 * g + lr;
+        d.st = 1 << 30; d.en = 0; d.off = 0; d.lo = d.hi = d.il = d.ih = 0.f; d.wsum = 1.f;
+        if (m < a.F) {
+            if (pts) {
+                d.lo = pts[m]; d.hi = pts[m + 2];
+                const float cc = pts[m + 1];
+                d.il = 1.f / (cc - d.lo); d.ih = 1.f / (d.hi - cc);
+                d.st = max((int)ceilf(d.lo), 0); d.en = min((int)floorf(d.hi), 512) + 1;
+                d.wsum = 0.f;
+                for (int k = d.st; k < d.en; ++k) d.wsum += fmaxf(fminf(((float)k - d.lo) * d.il, (d.hi - (float)k) * d.ih), 0.f);
+            } else {
+                d.st = a.mel_start[m]; d.en = d.st + a.mel_len[m]; d.off = a.mel_off[m] - d.st;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mo = min(16 * g + 4 * lq + i, a.F - 1);
+            d.mean[i] = a.mean[mo]; d.is[i] = a.inv_std[mo];
+        }
+        return d;
+    };
+    const int nG = (a.F + 15) / 16;
+    // groups of a wave: (w, 7 - w) of every eight - narrow and wide bands paired
+    auto group_of = [&](int gi) { return 8 * (gi >> 1) + ((gi & 1) ? 7 - wave : wave); };
+    MelDesc d0 = load_desc(min(group_of(0), nG - 1)), d1 = load_desc(min(group_of(1), nG - 1));
+
+    // two frames at a time per wave (two independent chains of LDS round trips), each in its own buffer; a frame past the
+    // clip's last one transforms zeros (its power row must be finite for the MFMAs)
+    cpx* buf0 = bufs + (2 * wave) * LM_FB;
+    cpx* buf1 = buf0 + LM_FB;
+    const int j0 = (lane - k2) * 8 + k2;
+    const int mirror = (64 - lane) & 63;
+    auto power_row = [&](const cpx (&v)[8], float* Prow) __attribute__((always_inline)) {
+        // |X[k]|^2 of the 1024-point real FFT, k = lane + 64 r: needs Z[(512 - k) & 511] = register 7 - r of lane 64 - lane
+        // (lane 0: its own register 8 - r)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            cpx zr = cpx{__shfl(v[7 - r].x, mirror), __shfl(v[7 - r].y, mirror)};
+            if (lane == 0) zr = v[(8 - r) & 7];
+            const cpx zk = v[r];
+            const cpx e = cpx{.5f * (zk.x + zr.x), .5f * (zk.y - zr.y)};
+            const cpx d = cpx{zk.x - zr.x, zk.y + zr.y};
+            const cpx o = cpx{.5f * d.y, -.5f * d.x};
+            const cpx xk = cadd(e, cmul(twp[r], o));
+            Prow[lane + 64 * r] = xk.x * xk.x + xk.y * xk.y;
+        }
+        if (lane == 0) { const float n = v[0].x - v[0].y; Prow[512] = n * n; }
+        else if (lane < 4) Prow[512 + lane] = 0.f;
+    };
+#pragma unroll
+    for (int fp = 0; fp < LM_FR / 8; ++fp) {
+        const int fl = wave * (LM_FR / 4) + 2 * fp;
+        cpx v[8], u[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            v[r] = cpx{__uint_as_float(raw0[r].x) * win2[r].x, __uint_as_float(raw0[r].y) * win2[r].y};
+            u[r] = cpx{__uint_as_float(raw1[r].x) * win2[r].x, __uint_as_float(raw1[r].y) * win2[r].y};
+        }
+        if (fp + 1 < LM_FR / 8) { load_frame(fl + 2, raw0); load_frame(fl + 3, raw1); }     // the next pair's samples during this pair's passes
+        if (LM_DBG & 1) continue;
+        // pass 1 (no twiddles): butterfly `lane` of stride 64 -> outputs 8 lane .. 8 lane + 7
+        dft8(v); dft8(u);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { buf0[fft_phys(8 * lane + r)] = v[r]; buf1[fft_phys(8 * lane + r)] = u[r]; }
+        wave_lds_sync();
+        // pass 2
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { v[r] = buf0[fft_phys(lane + 64 * r)]; u[r] = buf1[fft_phys(lane + 64 * r)]; }
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { v[r] = cmul(v[r], tw2[r - 1]); u[r] = cmul(u[r], tw2[r - 1]); }
+        dft8(v); dft8(u);
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { buf0[fft_phys(j0 + 8 * r)] = v[r]; buf1[fft_phys(j0 + 8 * r)] = u[r]; }
+        wave_lds_sync();
+        // pass 3: Z[lane + 64 r] stays in registers
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { v[r] = buf0[fft_phys(lane + 64 * r)]; u[r] = buf1[fft_phys(lane + 64 * r)]; }
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { v[r] = cmul(v[r], tw3[r - 1]); u[r] = cmul(u[r], tw3[r - 1]); }
+        dft8(v); dft8(u);
+        wave_lds_sync();                                           // the next pair's pass 1 rewrites the buffers
+        power_row(v, P + fl * LM_PS);
+        power_row(u, P + (fl + 1) * LM_PS);
     }
+    if (LM_DBG & 1)
+        for (int k = tid; k < LM_FR * LM_PS; k += 256) P[k] = 0.f;
     __syncthreads();
 
-    cpx* A = bufs + wave * 1024;
-    cpx* Bf = A + 512;
+    // ---- mel as a banded GEMM: out[m][frame] = sum_k W[m][k] P[frame][k]
     const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
-    // per-lane filter descriptors (filters m = lane, lane + 64, ...) stay in registers for all frames of the block
-    constexpr int MPL = LM_NMEL_MAX * 4 / 64;
-    int f_st[MPL], f_ln[MPL], f_off[MPL];
-    float f_mean[MPL], f_is[MPL], f_lo[MPL], f_c[MPL], f_hi[MPL];
-    const float* pts = a.mel_pts ? a.mel_pts + (size_t)b * (a.F + 2) : nullptr;
+    double* stat = a.stats ? a.stats + (size_t)(bid % PBSED_STAT_SLOTS) * a.F * 2 : nullptr;
+    const float* prow = P + lr * LM_PS;
+    const int t = t0 + lr;
+    const bool tv = t < a.T;
+    for (int gi = 0; !(LM_DBG & 2); ++gi) {
+        const int g = group_of(gi);
+        if (8 * (gi >> 1) >= nG) break;
+        if (g >= nG) continue;
+        const MelDesc d = gi == 0 ? d0 : gi == 1 ? d1 : load_desc(g);
+        int kb = d.st, ke = d.en;
 #pragma unroll
-    for (int i = 0; i < MPL; ++i) {
-        const int m = lane + 64 * i;
-        if (m < a.F) {
-            f_mean[i] = a.mean[m]; f_is[i] = a.inv_std[m];
-            if (pts) { f_lo[i] = pts[m]; f_c[i] = pts[m + 1]; f_hi[i] = pts[m + 2]; }
-            else { f_st[i] = a.mel_start[m]; f_ln[i] = a.mel_len[m]; f_off[i] = a.mel_off[m]; }
-        }
-    }
-    for (int fi = 0; fi < LM_FR / 4; ++fi) {
-        const int fl = wave * (LM_FR / 4) + fi;
-        const int t = t0 + fl;
-        const float* x = samp + fl * LM_SHIFT;
-        // pack windowed real frame (zero padded 960 -> 1024) as 512 complex
-        if (fpos) {
-            // warped framing: the windows of neighbouring frames start at arbitrary samples, so each wave reads its frame
-            // straight from the clip (L2-resident: every sample is touched by ~3 frames)
-            const long s = t < a.T ? (long)fpos[t] : (long)a.N;
+        for (int o = 1; o < 16; o <<= 1) { kb = min(kb, __shfl_xor(kb, o)); ke = max(ke, __shfl_xor(ke, o)); }
+        kb &= ~3;
+        // four k-steps per trip: the weights and power values of a trip are requested together, two accumulators alternate
+        // (a dependent fp32 MFMA chain issues every ~40 clocks)
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        // kb / ke are the same in every lane (all four 16-lane rows reduce the same filters): scalar loop bounds.  The weight
+        // look-up is straight-line (an index select, one LDS read, a value select): no branch around the read, or every
+        // read would be waited for on its own
+        const int kbu = __builtin_amdgcn_readfirstlane(kb), keu = (LM_DBG & 16) ? kbu : __builtin_amdgcn_readfirstlane(ke);
+        auto fetch = [&](int k0, float (&w)[4], float (&pv)[4], auto warped_c) __attribute__((always_inline)) {
+            constexpr bool WARPED = decltype(warped_c)::value;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int n = lane + r * 64;
-                cpx v = cpx{0.f, 0.f};
-                if (2 * n < LM_WIN) {
-                    const long i0 = s + 2 * n, i1 = i0 + 1;
-                    v = cpx{(i0 >= 0 && i0 < a.N ? wav[i0] : 0.f) * win[2 * n], (i1 >= 0 && i1 < a.N ? wav[i1] : 0.f) * win[2 * n + 1]};
-                }
-                A[n] = v;
+            for (int q = 0; q < 4; ++q) {
+                const int k = min(k0 + 4 * q + lq, LM_PS - 1);      // steps past the band: weight 0 x a finite value
+                const bool in = (k >= d.st) & (k < d.en) & (k0 + 4 * q < keu);
+                float wv;
+                if constexpr (WARPED) wv = fmaxf(fminf(((float)k - d.lo) * d.il, (d.hi - (float)k) * d.ih), 0.f);
+                else wv = mw[in ? d.off + k : 0];
+                w[q] = in ? wv : 0.f;
+                pv[q] = prow[k];
             }
-        } else {
+        };
+        auto band = [&](auto warped_c) __attribute__((always_inline)) {
+            float w[4], pv[4];
+            fetch(kbu, w, pv, warped_c);
+            for (int k0 = kbu; k0 < keu; k0 += 16) {
+                float wn[4], pn[4];
+                fetch(k0 + 16, wn, pn, warped_c);                  // the next trip's operands during this trip's MFMAs
+                acc = mfma16(w[0], pv[0], acc);
+                acc2 = mfma16(w[1], pv[1], acc2);
+                acc = mfma16(w[2], pv[2], acc);
+                acc2 = mfma16(w[3], pv[3], acc2);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int n = lane + r * 64;
-                cpx v = cpx{0.f, 0.f};
-                if (2 * n < LM_WIN) v = cpx{x[2 * n] * win[2 * n], x[2 * n + 1] * win[2 * n + 1]};
-                A[n] = v;
+                for (int q = 0; q < 4; ++q) { w[q] = wn[q]; pv[q] = pn[q]; }
             }
-        }
-        wave_lds_sync();
-        fft512_pass<1>(A, Bf, tw, lane);
-        wave_lds_sync();
-        fft512_pass<8>(Bf, A, tw, lane);
-        wave_lds_sync();
-        fft512_pass<64>(A, Bf, tw, lane);
-        wave_lds_sync();
-        float* P = reinterpret_cast<float*>(A);                 // [513] power spectrum
-        for (int k = lane; k <= 512; k += 64) P[k] = rfft1024_power(Bf, tw, k);
-        wave_lds_sync();
+        };
+        if (pts) band(std::true_type{}); else band(std::false_type{});
+        acc += acc2;
+        // D[row 4 lq + i = filter][col lr = frame]
 #pragma unroll
-        for (int i = 0; i < MPL; ++i) {
-            const int m = lane + 64 * i;
-            if (m >= a.F) break;
-            float s = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int mo = 16 * g + 4 * lq + i;
+            float s = acc[i];
             if (pts) {
-                s = mel_triangle(P, 513, f_lo[i], f_c[i], f_hi[i]);
-            } else {
-                const float* p = P + f_st[i];
-                const float* w = mw + f_off[i];
-                for (int j = 0; j < f_ln[i]; ++j) s = fmaf(p[j], w[j], s);
+                const float ws = __shfl(d.wsum, 4 * lq + i);
+                s = ws > 0.f ? s / ws : 0.f;
             }
-            float v = (logf(s + a.eps) - f_mean[i]) * f_is[i];
-            v = fminf(fmaxf(v, -a.clampv), a.clampv);
-            tile[m * (LM_FR + 1) + fl] = (t < sl) ? v : 0.f;
+            float val = 0.f;
+            if (mo < a.F) {
+                val = (logf(s + a.eps) - d.mean[i]) * d.is[i];
+                val = fminf(fmaxf(val, -a.clampv), a.clampv);
+                val = (tv && t < sl) ? val : 0.f;
+                if (tv && !(LM_DBG & 8)) a.out[((size_t)b * a.F + mo) * a.T + t] = val;
+            }
+            if (stat) {
+                const float sum = wave_sum16(val), sq = wave_sum16(val * val);
+                if (lr == 0 && mo < a.F) {
+                    atomicAdd(stat + 2 * mo, (double)sum);
+                    atomicAdd(stat + 2 * mo + 1, (double)sq);
+                }
+            }
         }
-        wave_lds_sync();
-    }
-    __syncthreads();
-    if (a.stats) logmel_tile_stats(tile, a.stats, a.F, tid);
-    for (int i = tid; i < a.F * LM_FR; i += 256) {
-        const int m = i / LM_FR, fl = i % LM_FR;
-        if (t0 + fl < a.T) a.out[((size_t)b * a.F + m) * a.T + t0 + fl] = tile[m * (LM_FR + 1) + fl];
     }
 }
 
@@ -354,8 +516,8 @@ static int logmel_launch(const float* wav, int B, int n_samples, int T, const in
     LogmelArgs a{wav, window, twiddle, mel_start, mel_len, mel_off, mel_w, mean, inv_std, seq_len_frames,
                  out, stats, B, n_samples, T, F, eps, clampv, mel_pts, pad_front, frame_pos};
     const int nTt = (T + LM_FR - 1) / LM_FR;
-    const size_t lds = ((LM_FR - 1) * LM_SHIFT + LM_WIN + LM_WIN) * sizeof(float) + 1024 * sizeof(cpx) +
-                       4 * 2 * 512 * sizeof(cpx) + (size_t)F * (LM_FR + 1) * sizeof(float) + LM_MW_MAX * sizeof(float);
+    if (n_samples >= (1 << 29)) { set_error("logmel: clips of %d samples (the loader addresses 2^29)", n_samples); return PBSED_E_UNSUPPORTED; }
+    const size_t lds = (LM_FR * LM_PS + LM_MW_MAX) * sizeof(float) + 8 * LM_FB * sizeof(cpx);
     PBSED_DYN_LDS_ONCE(logmel_kernel, lds);
     hipLaunchKernelGGL(logmel_kernel, dim3(B * nTt), dim3(256), lds, (hipStream_t)stream, a);
     return check_launch("logmel_fwd");
