@@ -1,6 +1,5 @@
-// 512-point complex Stockham FFT (3 radix-8 passes), one butterfly per lane of a 64-wide wave,
-// plus the real-FFT-1024 unpacking.  Plain C++ so the same code is unit-tested on the host
-// (tests/test_fft_host.py compiles it with g++) and used by logmel.hip on the device.
+// Complex helpers and the radix-8 butterfly of the 512-point Stockham FFT in logmel.hip (3 radix-8 passes, one butterfly
+// per lane of a 64-wide wave; the passes and the real-FFT-1024 unpacking live next to their LDS indexing in logmel.hip).
 #pragma once
 #ifdef __HIPCC__
 #define PBSED_HD __host__ __device__ __forceinline__
@@ -30,34 +29,6 @@ PBSED_HD void dft8(cpx* v) {
     b3 = cpx{(b3.y - b3.x) * h, (-b3.x - b3.y) * h};    // * (-1-i)/sqrt2
     dft4(a0, a1, a2, a3, v[0], v[2], v[4], v[6]);
     dft4(b0, b1, b2, b3, v[1], v[3], v[5], v[7]);
-}
-
-// One radix-8 Stockham pass for butterfly j in [0,64).  tw: exp(-2 pi i q / 1024), q in [0,1024).
-template <int NS>
-PBSED_HD void fft512_pass(const cpx* in, cpx* out, const cpx* tw, int j) {
-    cpx v[8];
-    const int k = j & (NS - 1);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = in[j + r * 64];
-    if (NS > 1) {
-#pragma unroll
-        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw[(r * k * (128 / NS)) & 1023]);
-    }
-    dft8(v);
-    const int j0 = (j - k) * 8 + k;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) out[j0 + r * NS] = v[r];
-}
-
-// Z = FFT512(x_even + i x_odd)  ->  |X[k]|^2 of the 1024-point real FFT, k in [0, 512].
-PBSED_HD float rfft1024_power(const cpx* z, const cpx* tw, int k) {
-    const cpx zk = z[k & 511], zr = z[(512 - k) & 511];
-    const cpx e = cpx{.5f * (zk.x + zr.x), .5f * (zk.y - zr.y)};
-    const cpx d = cpx{zk.x - zr.x, zk.y + zr.y};            // zk - conj(zr)
-    const cpx o = cpx{.5f * d.y, -.5f * d.x};               // d / (2i)
-    cpx w = (k == 512) ? cpx{-1.f, 0.f} : tw[k];
-    const cpx x = cadd(e, cmul(w, o));
-    return x.x * x.x + x.y * x.y;
 }
 
 }  // namespace pbsed
