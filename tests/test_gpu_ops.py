@@ -42,6 +42,33 @@ def test_logmel_vs_oracle(n, b):
     close(out, ref, atol=2e-4, name='logmel')
 
 
+@pytest.mark.parametrize('n_filters', [40, 64, 200])
+def test_logmel_other_filter_counts_and_statistics_vs_oracle(n_filters):
+    """Filter counts that are no multiple of the mel stage's 16-filter groups / leave waves without a group / need more than
+    one group pair per wave, and the per-mel sums the same launch accumulates (masked sum and sum of squares of what it wrote)."""
+    from oracle import frontend as fe
+    from pb_sed_amd import ops
+    from pb_sed_amd.modules import get_fbanks, num_frames
+    g = torch.Generator().manual_seed(99)
+    b, n = 3, 40000
+    wav = torch.randn(b, n, generator=g)
+    wav = wav / wav.abs().max(-1, keepdim=True)[0]
+    t = num_frames(n)
+    seq = np.array([t, t - 5, t // 3])
+    ext = fe.LogMelExtractor(number_of_filters=n_filters).eval()
+    ext.mean.copy_(torch.linspace(-8, -4, n_filters))
+    ext.inv_std.copy_(torch.linspace(.3, .6, n_filters))
+    ref, _ = ext(fe.stft(wav), seq_len=seq)
+    tables = ops.LogMelTables(get_fbanks(16000, 1024, n_filters), DEV)
+    stats = torch.zeros(32 * n_filters * 2, dtype=torch.float64, device=DEV)
+    out = ops.logmel_fwd(wav.to(DEV), tables, ext.mean.to(DEV), ext.inv_std.to(DEV), t,
+                         torch.as_tensor(seq, dtype=torch.int32).to(DEV), stats=stats)
+    close(out, ref, atol=2e-4, name=f'logmel {n_filters} filters')
+    sums = stats.view(32, n_filters, 2).sum(0).cpu()
+    o = out.double().cpu()[:, 0]
+    assert torch.allclose(sums[:, 0], o.sum((0, 2)), rtol=1e-6, atol=1e-3) and torch.allclose(sums[:, 1], (o * o).sum((0, 2)), rtol=1e-6, atol=1e-3)
+
+
 def test_logmel_time_warped_frames_vs_oracle():
     """pbsed_logmel_fwd_frames: the front-end at explicit frame positions (time-warped STFT, data.TimeWarp).  The regular
     grid reproduces pbsed_logmel_fwd bit for bit; warped positions (incl. windows hanging over both clip ends) match the
