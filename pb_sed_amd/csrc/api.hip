@@ -115,7 +115,7 @@ const char* pbsed_last_error(void) { return g_err; }
 // Caller-owned scratch for (current device, `stream`): the weight-gradient kernels (conv and GRU) put their partial-sum
 // slots there instead of into the library's per-device buffer, so several streams of one device can run them concurrently.
 // scratch = NULL removes the registration.  pbsed_scratch_bytes() is large enough for every launch of the reference nets.
-size_t pbsed_scratch_bytes(void) { return (size_t)64 << 20; }
+size_t pbsed_scratch_bytes(void) { return (size_t)160 << 20; }
 
 int pbsed_set_scratch(void* scratch, size_t bytes, void* stream) {
     int dev = 0;

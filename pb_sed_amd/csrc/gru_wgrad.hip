@@ -520,13 +520,23 @@ static int gru_wgrad_launch(int n, const float* const* dg, const float* const* x
                 if (ny >= 4 * GW_MAX) { set_error("gru_wgrad: more than %d column tiles in one launch", 4 * GW_MAX); return PBSED_E_ARG; }
                 a.y_gemm[ny] = (unsigned char)i; a.y_tile[ny] = (unsigned char)j; ++ny;
             }
-        // one block per CU (8 waves with 64 accumulator registers each): split the (t, b) reduction to one residency round
+        // one block per CU: split the (t, b) reduction to one residency round
         dim3 grid((G + GB_BM - 1) / GB_BM, ny, 1);
         const int tiles = grid.x * ny;
         int nsplit = n_cu / tiles;
         const int max_split = (a.TB + 4 * GB_KC - 1) / (4 * GB_KC);
-        if (nsplit > max_split) nsplit = max_split;
         if (nsplit < 1) nsplit = 1;
+        // one round that leaves more than 15 % of the CUs without a block (2 x 512-wide stacks: 192 tiles on 256 CUs): a few
+        // rounds of shorter blocks instead - the split count with the least rounds x rows
+        if (tiles * nsplit * 100 < n_cu * 85) {
+            int best = nsplit;
+            for (int ns = nsplit + 1; ns <= 8 && ns <= max_split; ++ns) {
+                const int r_ns = (tiles * ns + n_cu - 1) / n_cu, r_b = (tiles * best + n_cu - 1) / n_cu;
+                if (r_ns * best < r_b * ns) best = ns;
+            }
+            nsplit = best;
+        }
+        if (nsplit > max_split) nsplit = max_split;
         a.rows_per_split = ((a.TB + nsplit - 1) / nsplit + GB_KC - 1) / GB_KC * GB_KC;
         a.nsplit = (a.TB + a.rows_per_split - 1) / a.rows_per_split;
         grid.z = a.nsplit;

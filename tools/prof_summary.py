@@ -150,7 +150,7 @@ if traffic:
     print('wrote profiles/roofline_traffic.json', list(traffic))
 
 # per-kernel counter sets of tools/prof_kernel.sh (FETCH / WRITE / TCC / SQ / MFMA passes of ONE kernel's own bench command)
-for pk, name in (('pk_wx', 'winox3'), ('pk_wgpc', 'wgrad_pc'), ('pk_c1', 'conv1d_pc')):
+for pk, name in (('pk_wx', 'winox3'), ('pk_wgpc', 'wgrad_pc'), ('pk_c1', 'conv1d_pc'), ('pk_gw', 'gru_wgrad_pc'), ('pk_lm', 'logmel')):
     f = os.path.join(go, pk, 'summary.json')
     if os.path.exists(f):
         shutil.copy(f, os.path.join(out, f'{tag}_pmc_{name}.json'))
