@@ -49,41 +49,6 @@ __device__ __forceinline__ double wave_sum64d(double v) {
     return v;
 }
 
-// ---- loads the compiler's wait-count insertion does not see.  hipcc tracks every load it issues and places s_waitcnt vmcnt(N)
-// itself; where control-flow paths with different numbers of outstanding loads meet (loop headers of software-pipelined
-// loops) it assumes the FEWEST and so waits for loads issued one iteration ago, i.e. the prefetch distance collapses to one
-// step.  A producer wave that keeps NB register sets in flight issues its loads through these (inline asm, in program order,
-// invisible to that analysis) and waits with vm_wait<N>() = "at most N loads outstanding" right before it reads a set;
-// vm_pin() ties the set's registers to the wait so no use can be scheduled above it.  Rules: every register set is waited for
-// before its registers die (vm_wait<0>() after the loop), and the wave issues no compiler-visible load inside the pipelined
-// region that it would need earlier than these (the compiler's own waits can only be stricter, never too weak).
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ i32x4_t raw_rsrc(const void* base, unsigned bytes) {
-    const unsigned long long p = (unsigned long long)base;
-    return i32x4_t{(int)(unsigned)p, (int)(unsigned)((p >> 32) & 0xffffu), (int)bytes, 0x00020000};
-}
-__device__ __forceinline__ u32x4_t ld128_untracked(i32x4_t rsrc, unsigned voff) {
-    u32x4_t r;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rsrc) : "memory");
-    return r;
-}
-__device__ __forceinline__ u32x2_t ld64_untracked(i32x4_t rsrc, unsigned voff) {
-    u32x2_t r;
-    asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rsrc) : "memory");
-    return r;
-}
-__device__ __forceinline__ unsigned ld32_untracked(i32x4_t rsrc, unsigned voff) {
-    unsigned r;
-    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rsrc) : "memory");
-    return r;
-}
-template <int N>
-__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-template <class T>
-__device__ __forceinline__ void vm_pin(T& r) { asm volatile("" : "+v"(r)); }
-
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 // bf16x3 operands (GRU scans, GRU weight gradients).  An fp32 value splits EXACTLY into three bf16 parts

@@ -331,6 +331,7 @@ __global__ __launch_bounds__(512) void gru_wgrad_pc_kernel(GruWgradArgs a) {
         const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dg[gemm]), 0, (unsigned)((size_t)a.TB * a.G * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x[gemm]), 0, (unsigned)((size_t)a.TB * K * 4), 0x00020000);
         u32x4_t rb[2][8];
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
         u32x2_t ra[2][8];
         // byte offsets stay below 2^31 (checked by the launcher); rows outside the split / the sequence read as zeros through
         // an out-of-range offset picked with masks (no branch per load).  The scheduling barriers keep every step's loads and
