@@ -969,6 +969,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
     int nColMine = 0;
     if ((int)blockIdx.x < nCols) nColMine = (nCols - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
     const int nSteps = nColMine * a.F;
+    constexpr int NBU = WgradPcCfg<WM, WN, KS, MTL, NTL>::NB;
+    const int nStepsR = (nSteps + NBU - 1) / NBU * NBU;                  // the producers' loop body covers NB steps without conditions
 
     f32x4 acc[MTL][NTL][9], accb[MTL];
 #pragma unroll
@@ -1044,6 +1046,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
             constexpr int BUF = decltype(buf_c)::value;
             int b, f, t0;
             locate(S, b, f, t0);
+            const int live = S < nSteps;                   // steps past the block's last one: every offset out of range, zeros staged
             const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(a.g) + (size_t)b * gclip, 0, gclip * 4u, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
@@ -1054,7 +1057,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
             for (int i = 0; i < C::DY_PER_T; ++i) {
                 const int tq = t0 + 4 * y_q[i];
                 // branch-free selects (as ?: the compiler forks into two load sites that must wait for each other)
-                const unsigned ok = (unsigned)-(y_valid[i] & (tq >= 0) & (tq < a.T));
+                const unsigned ok = (unsigned)-(y_valid[i] & (tq >= 0) & (tq < a.T) & live);
                 const unsigned off = ((unsigned)(y_base[i] + (int)y_row) & ok) | (OOB & ~ok);
                 ry[BUF][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, off * 4u, 0, 0);
                 if (unpool) ryi[BUF][i] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, off, 0, 0);
@@ -1065,6 +1068,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
             constexpr int BUF = decltype(buf_c)::value;
             int b, f, t0;
             locate(S, b, f, t0);
+            const int live = S < nSteps;
+            b = min(b, a.B - 1);
             const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
             const int tlim = pro ? sl : a.T;
             const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
@@ -1073,7 +1078,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
 #pragma unroll
             for (int i = 0; i < C::X_PER_T; ++i) {
                 const int tq = t0 + 4 * x_q[i];
-                const unsigned ok = (unsigned)-(x_valid[i] & (tq < a.T));
+                const unsigned ok = (unsigned)-(x_valid[i] & (tq < a.T) & live);
                 const unsigned off = ((unsigned)(x_base[i] + x_row) & ok) | (OOB & ~ok);
                 rx[BUF][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off * 4u, 0, 0);
                 rx_n[BUF][i] = (int)((unsigned)min(max(tlim - tq, 0), 4) & ok);
@@ -1145,13 +1150,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
         constexpr bool P_LD = !(WGPC_DBG & 1), P_ST = !(WGPC_DBG & 2);
         // Raw set k % NB holds the pair {dY of step k, x row k + 1}.  Prologue: x rows 0 and 1 and dY of step 0 staged, the pairs
         // of steps 1 .. NB in flight.
-        if (P_LD) { load_dy(0, I0{}); load_x(0, I0{}); }
-        if (nSteps > 1 && P_LD) load_x(1, I1{});
-        if (P_ST) { store_dy(0, I0{}); store_x(0, I0{}); }
-        if (nSteps > 1 && P_ST) store_x(1, I1{});
+        // No conditions between here and the end of the loop (loads of steps past the last one are masked out of range and
+        // stage zeros into images nobody reads): where paths with different numbers of outstanding loads meet, the compiler's
+        // wait counts assume the fewest and a step's loads are waited for right after they were requested - the prefetch
+        // distance collapses to one step.  The scheduling barriers keep the load / convert groups in program order, so the queue
+        // of outstanding loads looks the same on every path into the loop.
+        if (P_LD) { load_dy(0, I0{}); load_x(0, I0{}); load_x(1, I1{}); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (P_ST) { store_dy(0, I0{}); store_x(0, I0{}); store_x(1, I1{}); }
+        __builtin_amdgcn_sched_barrier(0);
         auto load_pair = [&](int k, auto buf_c) __attribute__((always_inline)) {
-            if (k < nSteps && P_LD) load_dy(k, buf_c);
-            if (k + 1 < nSteps && P_LD) load_x(k + 1, buf_c);
+            if (P_LD) { load_dy(k, buf_c); load_x(k + 1, buf_c); }
+            __builtin_amdgcn_sched_barrier(0);
         };
         load_pair(1, I1{});
         if (NB == 2) {
@@ -1164,22 +1174,22 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
         // S + 2), then re-load its raw set with the pair of step S + 1 + NB
         auto stage_step = [&](int S, auto buf_c) __attribute__((always_inline)) {
             using BUF = decltype(buf_c);
-            if (S + 1 < nSteps && P_ST) store_dy((S + 1) & 1, BUF{});
-            if (S + 2 < nSteps && P_ST) store_x((S + 2) & 3, BUF{});
+            if (P_ST) { store_dy((S + 1) & 1, BUF{}); store_x((S + 2) & 3, BUF{}); }
+            __builtin_amdgcn_sched_barrier(0);
             load_pair(S + 1 + NB, BUF{});
             __syncthreads();
         };
         if (NB == 2) {
-            for (int S = 0; S < nSteps; S += 2) {
+            for (int S = 0; S < nStepsR; S += 2) {
                 stage_step(S, I1{});
-                if (S + 1 < nSteps) stage_step(S + 1, I0{});
+                stage_step(S + 1, I0{});
             }
         } else {
-            for (int S = 0; S < nSteps; S += 4) {
+            for (int S = 0; S < nStepsR; S += 4) {
                 stage_step(S, I1{});
-                if (S + 1 < nSteps) stage_step(S + 1, I2{});
-                if (S + 2 < nSteps) stage_step(S + 2, I3{});
-                if (S + 3 < nSteps) stage_step(S + 3, I0{});
+                stage_step(S + 1, I2{});
+                stage_step(S + 2, I3{});
+                stage_step(S + 3, I0{});
             }
         }
     } else if (nSteps > 0) {
@@ -1251,8 +1261,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
             }
         };
         __syncthreads();                                                 // the prologue's images are in place
-        for (int S = 0; S < nSteps; ++S) {
-            if (!(WGPC_DBG & 8)) step(S);
+        for (int S = 0; S < nStepsR; ++S) {
+            if (!(WGPC_DBG & 8) && S < nSteps) step(S);
             __syncthreads();
         }
     }
