@@ -44,7 +44,8 @@ int pbsed_set_scratch(void* scratch /*device*/, size_t bytes, void* stream);
 /* ---- fused front-end.  Replaces the CPU STFT (pb_sed/data_preparation/provider.py:315-323, called at
  * pb_sed/data_preparation/transform.py:53) + NormalizedLogMelExtractor (pb_sed/models/weak_label/crnn.py:86-90).
  * wav [B, n_samples] -> out [B, 1, F, T];  window[960], twiddle[1024][2], sparse mel filters
- * (mel_start/mel_len/mel_off [F], mel_w flat with mel_w_count <= 1152 entries), mean/inv_std [F]; seq_len_frames [B] or NULL. */
+ * (mel_start/mel_len/mel_off [F], mel_w flat with mel_w_count <= 1152 entries), mean/inv_std [F]; seq_len_frames [B] or NULL.
+ * F <= 512, n_samples < 2^29 (the kernel addresses a clip with 32-bit byte offsets); PBSED_E_UNSUPPORTED beyond. */
 int pbsed_logmel_fwd(const float* wav, int B, int n_samples, int T, const int* seq_len_frames,
                      const float* window, const float* twiddle, const int* mel_start, const int* mel_len,
                      const int* mel_off, const float* mel_w, int mel_w_count, int F, const float* mean, const float* inv_std,
