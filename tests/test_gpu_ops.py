@@ -207,6 +207,21 @@ def test_conv_kernels_behind_experiment_switches():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+@pytest.mark.parametrize('switches', [{'PBSED_GRU_WGRAD_PC': '0', 'PBSED_GRU_WGRAD_SLOT_MIN': '8'}, {'PBSED_GRU_WGRAD_PC': '2'}])
+def test_gru_wgrad_kernels_behind_switches(switches):
+    """The GRU weight-gradient forms that are compiled in but not the default: the non-specialised kernel with float atomics
+    below 9 splits (round 2's form), and the producer / consumer kernel without the per-XCD placement of a row-tile group."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get('PBSED_TEST_CHILD'):
+        pytest.skip('already the child')
+    env = dict(os.environ, PBSED_TEST_CHILD='1', **switches)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu', '-k', 'test_gru_wgrad_vs_torch',
+                        '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
 def test_conv_bn_relu_backward_chain_vs_autograd():
     """conv_i output -> Normalization(train) -> ReLU -> conv_{i+1}: statistics epilogue, bn_finalize,
     fused dgrad epilogue and bn_bwd_apply against autograd through the oracle layers."""
