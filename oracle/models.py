@@ -29,8 +29,10 @@ def squash(y, minimum_score=1e-5):
 
 def fbcrnn_loss(y_fwd, y_bwd, seq_len, weak_targets, boundary_targets=None, *,
                 strong_fwd_bwd_loss_weight=1., slat=False, label_smoothing=0.,
-                class_weights=None):
-    """weak_label/crnn.py:107-153 + :180-206.  Returns (loss, weak_mask, boundary_mask)."""
+                class_weights=None, imposed_sel=None):
+    """weak_label/crnn.py:107-153 + :180-206.  Returns (loss, weak_mask, boundary_mask).
+    ``imposed_sel`` (tests only, see oracle/nn.py::_ConvLayer.imposed): bool [B,K,T], True where max(y_fwd, y_bwd) is to
+    take y_fwd - the selector of another implementation's run instead of this one's."""
     w_mask = (weak_targets < .01) | (weak_targets > .99)
     w = weak_targets * w_mask
     wt = torch.clip(w, label_smoothing, 1 - label_smoothing) if label_smoothing > 0 else w
@@ -38,7 +40,8 @@ def fbcrnn_loss(y_fwd, y_bwd, seq_len, weak_targets, boundary_targets=None, *,
         y_last = TakeLast(axis=2)(y_fwd, seq_len)
         loss = bce(y_last, wt)[..., None].expand(y_fwd.shape)
     else:
-        loss = bce(torch.maximum(y_fwd, y_bwd), wt[..., None].expand(y_fwd.shape))
+        y_max = torch.maximum(y_fwd, y_bwd) if imposed_sel is None else torch.where(imposed_sel, y_fwd, y_bwd)
+        loss = bce(y_max, wt[..., None].expand(y_fwd.shape))
     loss = loss * w_mask[..., None]
     b_mask = None
     if strong_fwd_bwd_loss_weight > 0.:
@@ -161,7 +164,8 @@ class FBCRNN(nn.Module):
         loss, w_mask, b_mask = fbcrnn_loss(
             y_fwd, y_bwd, seq_len, targets[0], targets[1] if len(targets) > 1 else None,
             strong_fwd_bwd_loss_weight=self.strong_fwd_bwd_loss_weight, slat=self.slat,
-            label_smoothing=self.label_smoothing, class_weights=self.class_weights)
+            label_smoothing=self.label_smoothing, class_weights=self.class_weights,
+            imposed_sel=getattr(self, 'imposed_sel', None))
         labeled = (w_mask.numpy() == 1).all(-1)
         y_weak = TakeLast(axis=2)(y_fwd, seq_len)
         if y_bwd is not None:

@@ -144,17 +144,48 @@ class _ConvLayer(nn.Module):
         nn.init.zeros_(self.conv.bias)
         self.norm = Normalization(cin if pre else cout, eps=eps) if (pre or post) else None
 
+    # Discrete decisions of a forward pass (tests only).  ``record = True`` keeps the layer's ReLU mask / (2,1)-pool row
+    # selector of the last forward in ``recorded``; ``imposed = {'relu': bool mask, 'pool': 0/1 selector}`` REPLACES the
+    # layer's own decisions by given ones: relu(v) -> v * mask, max-pool -> the selected row.  With the decisions of another
+    # implementation's run imposed, a float64 pass differentiates the same piecewise-smooth branch of the network that run
+    # took, so its gradient can be compared at rounding level (a pre-activation within rounding of zero or a pool-window tie
+    # otherwise switches a whole position's contribution on or off, see tests/test_gpu_configs.py::_impose_decisions).
+    record = False
+    imposed = None
+
+    def _relu(self, v):
+        imp = None if self.imposed is None else self.imposed.get('relu')
+        if imp is not None:
+            return v * imp.reshape(v.shape).to(v.dtype)
+        if self.record:
+            self.recorded = dict(getattr(self, 'recorded', None) or {}, relu=(v > 0).detach())
+        return F.relu(v)
+
+    def _pool(self, y):
+        imp = None if self.imposed is None else self.imposed.get('pool')
+        if imp is None and not self.record:
+            return F.max_pool2d(y, self.pool) if self.ndim == 2 else F.max_pool1d(y, self.pool)
+        assert self.ndim == 2 and tuple(self.pool) == (2, 1), 'decisions are recorded / imposed for (2,1) pools'
+        fo = y.shape[2] // 2
+        lo, hi = y[:, :, 0:2 * fo:2], y[:, :, 1:2 * fo:2]
+        if imp is None:
+            sel = (hi > lo).detach()                      # ties: the first row, as max_pool2d
+            self.recorded = dict(getattr(self, 'recorded', None) or {}, pool=sel)
+        else:
+            sel = imp.reshape(lo.shape).bool()
+        return torch.where(sel, hi, lo)
+
     def forward(self, x, seq_len=None):
         if self.pre:
-            x = F.relu(self.norm(x, seq_len))
+            x = self._relu(self.norm(x, seq_len))
         p = self.k - 1
         lo, hi = p // 2, int(math.ceil(p / 2))
         x = F.pad(x, (lo, hi, lo, hi) if self.ndim == 2 else (lo, hi))
         y = self.conv(x)
         if self.post:
-            y = F.relu(self.norm(y, seq_len))
+            y = self._relu(self.norm(y, seq_len))
         if self.pool != 1:
-            y = F.max_pool2d(y, self.pool) if self.ndim == 2 else F.max_pool1d(y, self.pool)
+            y = self._pool(y)
         return y
 
 
@@ -198,6 +229,23 @@ class _CNN(nn.Module):
                 nn.init.zeros_(conv.bias)
                 self.skip_convs[f'{src}_{dst}'] = conv
 
+    def _skip_pool(self, r, pool, key):
+        """Max-pool on a skip path; decisions recorded / imposed per (src, dst, crossed layer) like _ConvLayer's."""
+        imp = (getattr(self, 'imposed_skip_pool', None) or {}).get(key)
+        if imp is None and not getattr(self, 'record', False):
+            return F.max_pool2d(r, pool) if self.ndim == 2 else F.max_pool1d(r, pool)
+        assert self.ndim == 2 and tuple(pool) == (2, 1)
+        fo = r.shape[2] // 2
+        lo, hi = r[:, :, 0:2 * fo:2], r[:, :, 1:2 * fo:2]
+        if imp is None:
+            sel = (hi > lo).detach()
+            if not hasattr(self, 'recorded_skip_pool'):
+                self.recorded_skip_pool = {}
+            self.recorded_skip_pool[key] = sel
+        else:
+            sel = imp.reshape(lo.shape).bool()
+        return torch.where(sel, hi, lo)
+
     def forward(self, x, seq_len=None):
         inputs = []
         for j, conv in enumerate(self.convs):
@@ -206,7 +254,7 @@ class _CNN(nn.Module):
                     r = inputs[src]
                     for k in range(src, dst):
                         if self.convs[k].pool != 1:
-                            r = F.max_pool2d(r, self.convs[k].pool) if self.ndim == 2 else F.max_pool1d(r, self.convs[k].pool)
+                            r = self._skip_pool(r, self.convs[k].pool, (src, dst, k))
                     key = f'{src}_{dst}'
                     if key in self.skip_convs:
                         r = self.skip_convs[key](r)
@@ -214,7 +262,14 @@ class _CNN(nn.Module):
             inputs.append(x)
             x = conv(x, seq_len)
         if self.out_norm is not None:
-            x = F.relu(self.out_norm(x, seq_len))
+            v = self.out_norm(x, seq_len)
+            imp = getattr(self, 'imposed_out_relu', None)
+            if imp is not None:                           # see _ConvLayer.imposed
+                x = v * imp.reshape(v.shape).to(v.dtype)
+            else:
+                if getattr(self, 'record', False):
+                    self.recorded_out_relu = (v > 0).detach()
+                x = F.relu(v)
         return x, seq_len
 
     def freeze(self, num_layers=None, freeze_norm_stats=True):

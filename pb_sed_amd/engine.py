@@ -116,6 +116,15 @@ def describe_stack(cnns):
     return layers
 
 
+# Verification tap: when a list is assigned, every conv layer of stack_forward appends what decided its ReLU and its
+# (2,1) pool - (layer's conv module, norm module whose ReLU feeds it | None, raw layer input, BN scale, BN shift, pool
+# argmax bytes | None) - and every skip-path pool ('skip', source conv, destination conv, crossed conv, argmax bytes).  The
+# kernels decide a ReLU as fmaf(x, scale, shift) > 0 everywhere (forward prologues, data- and weight-gradient kernels), so
+# the sign of the exact x * scale + shift reproduces it.  tests/hip_decisions.py turns the entries into the masks the float64
+# oracle is run with (oracle/decisions.py).
+DECISION_TAP = None
+
+
 def _count(seq_host, t, rows):
     return float(np.minimum(np.asarray(seq_host), t).sum() * rows)
 
@@ -204,6 +213,9 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32', x_tbc
             relu=True, seq_len=seq_dev, pool=c.pool_f, want_stats=batch_stats, stats_per_cf=per_cf, precision=pr,
             residual=res)
         ctx.append((x, st_in, pc, idx, pr, st_frozen, skip_ctx))
+        if DECISION_TAP is not None:
+            DECISION_TAP.append(('layer', c, L.in_norm if st_in is not None else None, x,
+                                 None if st_in is None else st_in.scale, None if st_in is None else st_in.shift, idx))
         st_frozen = bool(training and next_norm is not None and next_norm.freeze_stats)
         if next_norm is None:
             st_in = None
@@ -216,6 +228,8 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32', x_tbc
     if layers[-1].out_norm is not None:
         # the stack's closing norm + ReLU (st_in / st_frozen are the last conv's "next norm" state): a launch of its own
         ctx.final = (x, st_in, st_frozen)
+        if DECISION_TAP is not None:
+            DECISION_TAP.append(('final', layers[-1].out_norm, x, st_in.scale, st_in.shift))
         x = ops.bn_relu_fwd(x, st_in, seq_dev)
     return x, ctx
 
@@ -228,6 +242,8 @@ def _skip_forward(layers, ctx, src, dst, skip_conv):
         if layers[k].conv.pool_f:
             r, pidx = ops.pool21_fwd(r)
             pools.append(pidx)
+            if DECISION_TAP is not None:
+                DECISION_TAP.append(('skip', layers[src].conv, layers[dst].conv, layers[k].conv, pidx))
     pcs = None
     r_in = r
     if skip_conv is not None:

@@ -681,33 +681,61 @@ def _dev_index(dev):
     return torch.cuda.current_device() if dev is None else dev
 
 
-_POLL_TUNED = {}        # (device, kind, slot, shape) -> chosen delay: every scan shape is measured once per process and device
+_POLL_TUNED = {}        # (device, kind, slot, shape) -> chosen delay: a scan shape is measured once per process and device
+_POLL_DEFAULT = {}      # (device, kind) -> the library's built-in delays [fwd, fwd_gate, bwd, bwd_gate], read before any change
+_POLL_INSTALLED = {}    # (device, kind) -> the delays the library holds right now
+POLL_TUNE_MAX_SHAPES = 8        # shapes measured per (device, kind, slot); further shapes take the built-in delay
 
 
-def _tune_poll_delay(dev, kind, slot, shape, launch):
+def _install_poll_delay(dev_i, kind, slot, delay):
+    """The library keeps ONE delay set per (device, kind); a tuned value belongs to ONE shape.  So the value of the shape
+    that is about to be launched is installed in front of every launch (a dictionary look-up; a C-ABI call only when the
+    value differs from what the library holds) - a validation pass at another T or B neither inherits the training
+    shape's delay nor leaves its own behind.  ``delay`` None = the built-in default."""
+    key = (dev_i, kind)
+    if key not in _POLL_DEFAULT:
+        cur = (C.c_int * 4)()
+        call('pbsed_gru_get_poll_delays', kind, cur)
+        _POLL_DEFAULT[key] = list(cur)
+        _POLL_INSTALLED[key] = list(cur)
+    want = _POLL_DEFAULT[key][slot] if delay is None else delay
+    have = _POLL_INSTALLED[key]
+    if have[slot] != want:
+        have[slot] = want
+        call('pbsed_gru_set_poll_delays', kind, *have)
+
+
+def _tune_poll_delay(dev, kind, slot, shape, launch, allow_tune=True):
     """In-place measurement of a persistent scan's first-poll delay (slot 0: forward, 2: BPTT; units of 64 clocks) on THIS
     device, with THIS shape and these operands: the built-in defaults were measured on one box in one DVFS state, the forward
     optimum is sharp (one unit early costs 30 %) and moves with clocks and with what shares the device.  At the first scan
     of a shape (T >= 64: short scans are not worth it) the scan is run a few times per candidate around the default - it is
-    idempotent: outputs are rewritten, the workspace parity flips per launch - the fastest candidate is installed with
-    pbsed_gru_set_poll_delays, and ties go to the LATER delay (the safe side of the cliff).  PBSED_GRU_AUTOTUNE=0 keeps the
-    defaults / PBSED_GRU_POLL_DELAYS.  One host sync per shape, never again."""
-    key = (_dev_index(dev), kind, slot, shape)
-    if key in _POLL_TUNED or shape[4] < 64 or os.environ.get('PBSED_GRU_AUTOTUNE', '1') == '0' or os.environ.get('PBSED_GRU_POLL_DELAYS'):
-        return
-    cur = (C.c_int * 4)()
-    with torch.cuda.device(key[0]):
-        call('pbsed_gru_get_poll_delays', kind, cur)
-        base = list(cur)
-        cands = sorted({max(base[slot] + d, 0) for d in ((-3, -2, -1, 0, 1, 2, 3, 5) if slot == 0 else (-8, -4, -2, 0, 2, 4, 8))})
+    idempotent: outputs are rewritten, the workspace parity flips per launch - and ties go to the LATER delay (the safe side
+    of the cliff).  The result is remembered PER SHAPE and installed in front of every launch of that shape
+    (_install_poll_delay).  At most POLL_TUNE_MAX_SHAPES shapes per (device, kind, slot) are measured (inference over
+    variable-length batches would otherwise pay ~30 extra scans and a host sync per distinct length; ``allow_tune=False``
+    skips the measurement for a call); everything else runs the built-in delay.  PBSED_GRU_AUTOTUNE=0 keeps the defaults /
+    PBSED_GRU_POLL_DELAYS.  One host sync per measured shape, never again."""
+    dev_i = _dev_index(dev)
+    key = (dev_i, kind, slot, shape)
+    with torch.cuda.device(dev_i):
+        if key in _POLL_TUNED:
+            _install_poll_delay(dev_i, kind, slot, _POLL_TUNED[key])
+            return
+        n_tuned = sum(1 for k in _POLL_TUNED if k[:3] == key[:3])
+        if shape[4] < 64 or not allow_tune or n_tuned >= POLL_TUNE_MAX_SHAPES or os.environ.get('PBSED_GRU_AUTOTUNE', '1') == '0' \
+                or os.environ.get('PBSED_GRU_POLL_DELAYS'):
+            _install_poll_delay(dev_i, kind, slot, None)
+            return
+        _install_poll_delay(dev_i, kind, slot, None)
+        base = _POLL_DEFAULT[(dev_i, kind)][slot]
+        cands = sorted({max(base + d, 0) for d in ((-3, -2, -1, 0, 1, 2, 3, 5) if slot == 0 else (-8, -4, -2, 0, 2, 4, 8))})
         timing_was = _lib.timing
         _lib.timing = None                          # the bench's event brackets must not see the tuning runs
         try:
             best = None
             for d in cands:
-                trial = list(base)
-                trial[slot] = d
-                call('pbsed_gru_set_poll_delays', kind, *trial)
+                _install_poll_delay(dev_i, kind, slot, d)
                 launch(tag='tune')
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -720,8 +748,7 @@ def _tune_poll_delay(dev, kind, slot, shape, launch):
                     best = (ms, d)
                 elif ms <= best[0] * 1.005:
                     best = (min(ms, best[0]), d)
-            base[slot] = best[1]
-            call('pbsed_gru_set_poll_delays', kind, *base)
+            _install_poll_delay(dev_i, kind, slot, best[1])
         finally:
             _lib.timing = timing_was
     check_gru_sync()

@@ -203,6 +203,19 @@ class Trainer:
         self._pending_checks = []
         self.last_enqueue_s = 0.            # host time of the last step up to (not including) the wait for its summary
         self.measure_sync, self.sync_events = False, None   # bench.py: event pairs around the wait for the collectives
+        self.snapshot_statistics()
+
+    def snapshot_statistics(self):
+        """Record the cumulative statistics (modules with a ``num_tracked_values`` counter) as the state all replicas share
+        - the baseline of the first sync_buffers() merge.  Called by __init__; call it again after loading a checkpoint."""
+        buffers = dict(self.model.named_buffers())
+        self._synced_stats, self._synced_verified = {}, set()
+        for name in buffers:
+            if name.endswith('num_tracked_values'):
+                prefix = name[:-len('num_tracked_values')]
+                stats = [buffers[prefix + k] for k in ('running_mean', 'running_power') if prefix + k in buffers]
+                self._synced_stats[prefix] = (buffers[name].detach().double().reshape(-1)[:1].clone(),
+                                              [s_.detach().double().clone() for s_ in stats])
 
     def _on_grads_ready(self, name):
         if name in self.bucket_names:
@@ -214,13 +227,15 @@ class Trainer:
         ranks; CUMULATIVE statistics (a module with a ``num_tracked_values`` counter: the feature extractor) are merged
         with their counts as weights - every rank contributes what it tracked SINCE the last merge (count delta and the
         matching sum deltas), so the call is idempotent: calling it twice in a row, or before every checkpoint, neither
-        inflates the counter nor re-weights old data.  The replicas are assumed identical before the first call (they are
-        built / loaded identically) unless their counters say otherwise (then each rank's whole history is its delta).
+        inflates the counter nor re-weights old data.  The baseline of the first merge is the state snapshot_statistics()
+        recorded when the Trainer was built (call it again after loading a checkpoint into every replica); it is used only
+        if all ranks hold the same snapshot, otherwise each rank's whole history is its delta.
         ``'rank0'`` broadcasts rank 0's buffers.  No-op without a process group."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         world = dist.get_world_size()
         synced = self.__dict__.setdefault('_synced_stats', {})
+        verified = self.__dict__.setdefault('_synced_verified', set())
         buffers = dict(self.model.named_buffers())
         counted = {n[:-len('num_tracked_values')] for n in buffers if n.endswith('num_tracked_values')}
         with torch.no_grad():
@@ -241,15 +256,21 @@ class Trainer:
                 if mode != 'rank0':
                     n = cnt.double().reshape(-1)[:1]
                     base = synced.get(prefix)
-                    if base is None:
-                        # never merged: equal counters = identical replicas (baseline = that common state, nothing new);
-                        # different counters = independent histories (baseline empty)
-                        lo, hi = n.clone(), n.clone()
+                    if prefix not in verified:
+                        # First merge of this module.  The baseline is the state the replicas SHARE: the snapshot taken when
+                        # the Trainer was built (replicas are built / loaded identically; snapshot_statistics()), or, without
+                        # one, the current state.  Whether it really is shared is checked on the values themselves (MIN / MAX
+                        # all-reduce of counter and statistics), never inferred from the counters alone: ranks that start at
+                        # 0 and train on equally long clips reach EQUAL counters with DIFFERENT statistics.  Not shared ->
+                        # independent histories, every rank's whole history is its delta (baseline empty).
+                        cand = base if base is not None else (n.clone(), [s_.double().clone() for s_ in stats])
+                        vec = torch.cat([cand[0].reshape(-1)] + [c.reshape(-1) for c in cand[1]])
+                        lo, hi = vec.clone(), vec.clone()
                         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
                         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-                        same = bool(lo.item() == hi.item())
-                        base = (n.clone() if same else torch.zeros_like(n),
-                                [s.double().clone() if same else torch.zeros_like(s, dtype=torch.float64) for s in stats])
+                        same = bool(torch.equal(lo, hi))
+                        base = cand if same else (torch.zeros_like(n), [torch.zeros_like(s_, dtype=torch.float64) for s_ in stats])
+                        verified.add(prefix)
                     base_n, base_stats = base
                     delta_n = n - base_n
                     sums = [s.double() * n - bs * base_n for s, bs in zip(stats, base_stats)]

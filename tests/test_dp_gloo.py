@@ -108,6 +108,62 @@ def _buffer_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _equal_count_worker(rank, world, port, out_dir):
+    """Two replicas start from the same (snapshotted) state, track the SAME number of frames with DIFFERENT statistics
+    (equal-length clips, equal per-rank batches - the normal data-parallel case) and merge for the first time."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pb_sed_amd.modules import NormalizedLogMelExtractor
+    from pb_sed_amd.trainer import Trainer
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.feature_extractor = NormalizedLogMelExtractor(number_of_filters=8)
+    ok = True
+    for start, with_snapshot in ((0., True), (50., True), (0., False)):
+        m = M()
+        fe = m.feature_extractor
+        with torch.no_grad():
+            fe.running_mean.fill_(2.), fe.running_power.fill_(7.), fe.num_tracked_values.fill_(start)
+        t = Trainer.__new__(Trainer)
+        t.model = m
+        if with_snapshot:
+            t.snapshot_statistics()
+        with torch.no_grad():                         # 100 more frames per rank: mean rank + 1, power 10 * (rank + 1)
+            fe.running_mean.copy_((fe.running_mean * start + (rank + 1.) * 100.) / (start + 100.))
+            fe.running_power.copy_((fe.running_power * start + 10. * (rank + 1.) * 100.) / (start + 100.))
+            fe.num_tracked_values.fill_(start + 100.)
+        t.sync_buffers()
+        if with_snapshot:
+            tot = start + 200.
+            want_mean, want_pow = (2. * start + 300.) / tot, (7. * start + 3000.) / tot
+        else:
+            # no snapshot and the current states differ: independent histories, both counted in full
+            tot = 2 * (start + 100.)
+            want_mean, want_pow = 1.5, 15.
+        ok = ok and fe.num_tracked_values.item() == tot
+        ok = ok and torch.allclose(fe.running_mean, torch.full((8,), want_mean), atol=1e-6)
+        ok = ok and torch.allclose(fe.running_power, torch.full((8,), want_pow), atol=1e-5)
+        got = [fe.running_mean.clone(), fe.running_power.clone()]
+        gathered = [torch.zeros(16) for _ in range(world)]
+        dist.all_gather(gathered, torch.cat(got))
+        ok = ok and all(torch.equal(g_, gathered[0]) for g_ in gathered)        # the replicas AGREE afterwards
+        t.sync_buffers()                              # ... and stay put
+        ok = ok and fe.num_tracked_values.item() == tot and torch.allclose(fe.running_mean, got[0], atol=1e-7)
+    with open(os.path.join(out_dir, f'eq{rank}'), 'w') as f:
+        f.write(str(bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_sync_buffers_equal_counters_different_statistics_world2(tmp_path):
+    """equal ``num_tracked_values`` on the first merge is not proof of identical replicas."""
+    mp.spawn(_equal_count_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f'eq{r}').read() == 'True'
+
+
 def test_sync_buffers_world2(tmp_path):
     """Per-replica running statistics are averaged (tracked-value counters summed) before a checkpoint."""
     mp.spawn(_buffer_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)

@@ -105,3 +105,112 @@ def test_load_init_checkpoint_surgery():
     broken = {k: v for k, v in ckpt.items() if k != 'cnn.cnn_1d.convs.2.conv.weight'}
     with pytest.raises(KeyError):
         load_init_checkpoint(dst, broken)
+
+
+def _decision_net():
+    net = dict(out_channels_2d=[8, 8, 16, 16], pool_sizes_2d=[1, (2, 1), 1, (2, 1)], kernel_size_2d=3,
+               out_channels_1d=[32, 32], kernel_size_1d=[1, 3], residual_connections_2d=[None, 3, None, None],
+               final_norm_1d=True)
+    torch.manual_seed(5)
+    m = om.FBCRNN.build(num_events=6, number_of_filters=32, stft_size=512, hidden_size=16, num_layers=2, net=net)
+    g = torch.Generator().manual_seed(0)
+    b, t = 6, 40
+    inp = {'stft': torch.randn(b, 1, t, 257, 2, generator=g), 'seq_len': [40, 40, 37, 30, 22, 9],
+           'weak_targets': (torch.rand(b, 6, generator=g) < .4).float(),
+           'boundary_targets': (torch.rand(b, 6, t, generator=g) < .3).float()}
+    return m.train(), inp
+
+
+def _step(m, inp):
+    m.zero_grad()
+    out = m(dict(inp))
+    loss = m.review(inp, out)['loss']
+    loss.backward()
+    return out, loss.item(), {n: p.grad.clone() for n, p in m.named_parameters()}
+
+
+def test_imposed_decisions_reproduce_the_recorded_run_and_remove_branch_noise():
+    """oracle/decisions.py: (1) a run with its OWN recorded decisions imposed is the same run (loss and every gradient
+    agree to rounding) - the imposed forms of ReLU / (2,1) pool / skip pool / closing norm / max(y_fwd, y_bwd) are the
+    functions they replace; (2) the float64 oracle with the FLOAT32 run's decisions imposed agrees with the float32 gradients
+    at rounding level on every tensor, and at least as well as the free float64 run does."""
+    import copy
+    from oracle import decisions as od
+    m32, inp = _decision_net()
+    m64 = copy.deepcopy(m32).double()
+    inp64 = {k: (v.double() if torch.is_tensor(v) else v) for k, v in inp.items()}
+    od.record(m64)
+    out64, loss64, g64 = _step(m64, inp64)
+    dec64 = od.collect(m64, out64)
+    kinds = {k for d in dec64.values() if isinstance(d, dict) for k in d}
+    assert kinds == {'relu', 'pool', 'out_relu', 'skip_pool'} and 'max_sel' in dec64
+    od.record(m64, False)
+    n = od.impose(m64, dec64)
+    assert n == sum(len(d) if isinstance(d, dict) else 1 for d in dec64.values())
+    _, loss64i, g64i = _step(m64, inp64)
+    assert loss64i == pytest.approx(loss64, rel=1e-12)
+    for k in g64:
+        assert (g64i[k] - g64[k]).abs().max() <= 1e-10 * g64[k].abs().max() + 1e-13, k   # (biases in front of a norm: 0 + noise)
+    # float32 run's decisions on the float64 model
+    od.record(m32)
+    out32, loss32, g32 = _step(m32, inp)
+    dec32 = od.collect(m32, out32)
+    od.impose(m64, dec32)
+    _, _, g64_32 = _step(m64, inp64)
+    worst_free = worst_imposed = 0.
+    for k in g32:
+        scale = g64_32[k].abs().max().item()
+        if scale < 1e-12:
+            continue
+        worst_imposed = max(worst_imposed, (g32[k].double() - g64_32[k]).abs().max().item() / scale)
+        worst_free = max(worst_free, (g32[k].double() - g64[k]).abs().max().item() / scale)
+    assert worst_imposed < 2e-4, worst_imposed
+    assert worst_imposed <= worst_free * 1.5 + 1e-6
+    od.impose(m64, None)
+    _, loss_again, _ = _step(m64, inp64)
+    assert loss_again == pytest.approx(loss64, rel=1e-12)
+
+
+def test_bf16_emulating_oracle_is_the_oracle_up_to_the_operand_rounding(monkeypatch):
+    """oracle/bf16emu.py: with the rounding function replaced by the identity the restatement (explicit GRU scans with
+    packed-sequence masks, reversed chains, the conv / projection autograd Functions with their hand-written backward
+    products) IS the oracle - loss and every gradient to float64 rounding, for the FBCRNN (forward + reversed two-layer GRUs)
+    and the tag-conditioned BiCRNN (bidirectional GRU); with the rounding on, results move by bf16-operand amounts."""
+    import copy
+    from oracle import bf16emu
+    net = dict(out_channels_2d=[8, 32, 32], pool_sizes_2d=[1, (2, 1), 1], kernel_size_2d=3,
+               out_channels_1d=[32, 32], kernel_size_1d=[1, 3])
+    g = torch.Generator().manual_seed(0)
+    b, t = 4, 24
+    seq = [24, 24, 17, 9]
+    stft = torch.randn(b, 1, t, 257, 2, generator=g, dtype=torch.float64)
+    weak = (torch.rand(b, 6, generator=g) < .4).double()
+    strong = (torch.rand(b, 6, t, generator=g) < .3).double()
+    cases = []
+    torch.manual_seed(7)
+    cases.append((om.FBCRNN.build(num_events=6, number_of_filters=32, stft_size=512, hidden_size=16, num_layers=2, net=net),
+                  {'stft': stft, 'seq_len': seq, 'weak_targets': weak, 'boundary_targets': strong}))
+    cases.append((om.BiCRNN.build(num_events=6, number_of_filters=32, stft_size=512, hidden_size=16, num_layers=2, net=net,
+                                  tag_conditioning=True),
+                  {'stft': stft, 'seq_len': seq, 'weak_targets': weak, 'strong_targets': strong * weak[..., None],
+                   'tag_condition': weak.clone()}))
+    for m, inp in cases:
+        m = m.double().train()
+        _, loss, grads = _step(m, inp)
+        emu = copy.deepcopy(m)
+        assert bf16emu.enable(emu) >= 8
+        with monkeypatch.context() as mp:
+            mp.setattr(bf16emu, 'rbf', lambda x: x)
+            _, loss_id, grads_id = _step(emu, inp)
+        assert loss_id == pytest.approx(loss, rel=1e-12)
+        for k in grads:
+            assert (grads_id[k] - grads[k]).abs().max() <= 1e-9 * grads[k].abs().max() + 1e-13, k
+        _, loss_bf, grads_bf = _step(emu, inp)
+        assert 1e-6 < abs(loss_bf - loss) / abs(loss) < 5e-2
+        gv = torch.cat([v.reshape(-1) for v in grads.values()])
+        gb = torch.cat([grads_bf[k].reshape(-1) for k in grads])
+        rel = ((gb - gv).norm() / gv.norm()).item()
+        assert 1e-4 < rel < .2, rel
+        bf16emu.enable(emu, False)
+        _, loss_off, _ = _step(emu, inp)
+        assert loss_off == pytest.approx(loss, rel=1e-12)
