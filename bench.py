@@ -505,7 +505,7 @@ def bench_train(args, kind, world, rank, device, sustained_steps=0):
     if world > 1:
         s_bytes = 4 * n_params
         out['allreduce'] = {
-            'bytes_per_step': s_bytes, 'buckets': trainer.bucket_names,
+            'implementation': trainer.allreduce, 'bytes_per_step': s_bytes, 'buckets': trainer.bucket_names,
             'exposed_ms_per_step': None if exposed_ms is None else round(exposed_ms, 4),
             'bus_bytes_per_step': round(s_bytes * 2 * (world - 1) / world),
             'busbw_GBs_if_fully_exposed': None if not exposed_ms else round(s_bytes * 2 * (world - 1) / world / (exposed_ms * 1e-3) / 1e9, 1),

@@ -260,6 +260,12 @@ int pbsed_gru_granule_capacity(int H, int bwd, int bf16, int tiles_per_block);
  * does at the first scan of every shape) instead of relying on the built-in defaults. */
 int pbsed_gru_get_poll_delays(int kind, int* out4 /*host*/);
 int pbsed_gru_set_poll_delays(int kind, int fwd, int fwd_gate, int bwd, int bwd_gate);
+/* Diagnostics of the persistent scans: the scans launched after this call write shader-clock stamps of workgroup `block`
+ * (1-D index of the launch), scan steps 200..231, to buf[32][16] (device, 4 KB) - slots 0..4: first contraction wave at the top
+ * of the step / first poll issued / poll satisfied / partial sums written / past the barrier; 5: poll attempts that missed;
+ * 8..12: first gate wave at the top / past the barrier / partial sums reduced / state published / outputs stored.
+ * buf = NULL switches it off (the default).  tools/gru_scan_prof.py prints the timeline the rooflines of DESIGN.md quote. */
+int pbsed_gru_set_prof(unsigned long long* buf, int block);
 /* Persistent forward scan (one launch for the whole scan; needs nchains*(2*nlayers-1)*(H/16)*ceil(B/16) <= #CUs
  * co-resident workgroups) exchanging h_t (and the projected inputs of layers > 0) between workgroups as 4-byte words
  * = the fp32 value with its mantissa LSB replaced by the call's parity bit (the exchanged quantity is defined as the

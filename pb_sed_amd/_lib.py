@@ -93,6 +93,7 @@ SIGNATURES = {
     'pbsed_gru_granule_capacity': [I, I, I, I],
     'pbsed_gru_get_poll_delays': [I, _v],
     'pbsed_gru_set_poll_delays': [I, I, I, I, I],
+    'pbsed_gru_set_prof': [_v, I],
     'pbsed_set_scratch': [_v, SZ, _v],
     'pbsed_scratch_bytes': [],
     'pbsed_memset_async': [_v, I, SZ, _v],

@@ -42,7 +42,27 @@ struct GruStackArgs {
     int B, T, nchains, nlayers, launch;
     int poll_delay, poll_delay_gate;   // granule kernels: first-poll delays (PollPacer) of the non-gate / gate waves
     int ring_xcd, nby;    // granule kernels: ring_xcd = H/16 > 0 selects the 1-D XCD-aware role mapping (granule_role)
+    int fast_gates;       // granule forward scan: gate activations from v_exp_f32 / v_rcp_f32 (gate_sigmoid / gate_tanh)
+    unsigned long long* prof;   // diagnostics (pbsed_gru_set_prof): shader-clock stamps of block `prof_block`, steps 200..231
+    int prof_block;
 };
+
+// Gate activations of the persistent forward scan.  The libm forms (expf, a full-precision division, tanhf with its
+// small-argument branch) are ~110 VALU instructions per gate thread ON the step's critical path (reduction -> gates ->
+// publish); the hardware forms are 12: sigmoid(x) = rcp(1 + exp2(-x log2 e)), tanh(x) = 1 - 2 rcp(1 + exp2(2 x log2 e))
+// (v_exp_f32 / v_rcp_f32: 1 ulp each; exp2 overflowing to +inf gives rcp(inf) = 0, the right limit on both sides).
+// Absolute error <= 2e-7 per activation, the same class as the tagged LSB of the exchanged state.
+__device__ __forceinline__ float gate_sigmoid(float x, bool fast) {
+    if (fast) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+    return 1.f / (1.f + expf(-x));
+}
+__device__ __forceinline__ float gate_tanh(float x, bool fast) {
+    if (fast) return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+    return tanhf(x);
+}
+
+// shader-clock stamp of one lane (diagnostics only; s_memtime waits for the wave's outstanding LDS / scalar loads)
+__device__ __forceinline__ void prof_stamp(unsigned long long* p) { *p = __builtin_readcyclecounter(); }
 
 // acc[g] += W[g*H + j0 + lr][k..] * v[b0 + lr][k..] over this wave's quarter of K = KB*64.
 template <int KB, int NG>
@@ -294,7 +314,7 @@ struct PollPacer {
 
 // One wave polls the words of its K range [k0, k0 + 16*NL) for 16 batch rows with 16-byte write-through-visible
 // (sc1) buffer loads: lane (lq, lr) reads, per load n, the four words k0 + n*16 + lq*4 + {0..3} of row lr.  The exchange
-// arrays are TILE-MAJOR - [T][batch tile][H/16 producers][16 rows][16 units] - so one load instruction covers exactly the
+// arrays are TILE-MAJOR - [T][batch tile][H/16 producers][4 unit groups][16 rows][4 units] - so one load instruction covers exactly the
 // contiguous 1 KB tile one producer block published (8 whole 128-byte lines instead of 16 half lines of a row-major
 // [T][B][H] array) and a producer's 256 publishing threads write one contiguous 1 KB; nothing is fetched twice.  All loads of a step are issued
 // before any tag is looked at (one fabric round trip per step); out[n] = the four (tag-cleared) values.
@@ -404,14 +424,15 @@ __device__ __forceinline__ void wait_own_granules(unsigned (&q)[NQ], const gu32*
 // NB: 16-row batch tiles per block (1, or 2 for more than 32 clips: the rings of 64 clips then need 192 instead of 384
 // co-resident blocks and stay one launch; a block's two tiles share the W fragments, their polls are issued together).
 template <int NL, int NB>
-__device__ __forceinline__ void poll_tiles(float4 (&out)[NB][NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned tile_stride,
+__device__ __forceinline__ int poll_tiles(float4 (&out)[NB][NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned tile_stride,
                                            unsigned parity, const bool (&valid)[NB], unsigned* err_flag) {
     u32x4_t q[NB][NL];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int n = 0; n < NL; ++n) q[nb][n] = u32x4_t{0u, 0u, 0u, 0u};
-    for (int spin = 0;; ++spin) {
+    int spin = 0;
+    for (;; ++spin) {
         unsigned all1 = 1u, any1 = 0u;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -443,6 +464,7 @@ __device__ __forceinline__ void poll_tiles(float4 (&out)[NB][NL], __amdgpu_buffe
         for (int n = 0; n < NL; ++n)
             out[nb][n] = make_float4(__uint_as_float(q[nb][n].x & ~1u), __uint_as_float(q[nb][n].y & ~1u),
                                      __uint_as_float(q[nb][n].z & ~1u), __uint_as_float(q[nb][n].w & ~1u));
+    return spin;
 }
 
 template <int KB, int NW, bool GW, int XS = 0, int NB = 1>
@@ -467,7 +489,12 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
     // ring: h_t, tile-major; this block's first tile of step t starts at g_own + t * Bp * H, the next one H * 16 words on
     gu32* g_own = (gu32*)gran_h_ + (size_t)(chain * a.nlayers + layer) * per_cl + ((size_t)role.by * NB * (H / 16) + role.bx) * 256;
     gu32* g_gi = (gu32*)gran_gi_ + (size_t)(chain * (a.nlayers - 1) + (layer > 0 ? layer - 1 : 0)) * per_cl_b * 3;  // [T][B][3][H]
-    const int u = tid & 15, bb = tid >> 4, j = j0 + u;
+    // gate thread -> (unit, batch row): thread tid owns the accumulator element (lane tid >> 2, register tid & 3) of the MFMA D
+    // layout, i.e. the partial sums it adds are the consecutive floats red[..][tid] (conflict-free LDS reads; the row-major
+    // mapping read them at a 256-byte stride: 4-way bank conflicts, 1 000 of a step's 6 100 clocks), and a producer's 1 KB
+    // exchange tile is [unit / 4][batch row][unit % 4] = that same order: thread tid publishes word tid, a consumer lane
+    // (lq, lr) reads the 16 bytes at word lq * 64 + lr * 4 = byte lane * 16 (one contiguous 1 KB per load instruction)
+    const int u = ((tid >> 6) & 3) * 4 + (tid & 3), bb = (tid >> 2) & 15, j = j0 + u;
     int b[NB], sl[NB];
     bool bv[NB], rowv[NB];
 #pragma unroll
@@ -506,7 +533,7 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
     }
     // a projection reads h_t of the layer below, a ring its own h_{t-1}
     const unsigned cl_src = chain * a.nlayers + (is_proj ? layer - 1 : layer);
-    const unsigned voff0 = (unsigned)(((size_t)cl_src * per_cl + (size_t)role.by * NB * 16 * H + (k0 / 16) * 256 + lr * 16 + lq * 4) * 4);
+    const unsigned voff0 = (unsigned)(((size_t)cl_src * per_cl + (size_t)role.by * NB * 16 * H + (k0 / 16) * 256 + lq * 64 + lr * 4) * 4);
     const unsigned step_t = (unsigned)(Bp * H * 4);           // bytes per time step of one (chain, layer)
     constexpr unsigned tile_bytes = 16u * H * 4u;            // one batch tile of one step
     float h_reg[NB];
@@ -529,12 +556,20 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
         }
     };
     load_gi(0);
+    const bool fast = a.fast_gates != 0;
+    // diagnostics: lane 0 of the first contraction wave (slots 0..5) and of the first gate wave (slots 8..12) of one block
+    const bool prof_blk = a.prof != nullptr && (int)blockIdx.x == a.prof_block;
+    const bool prof_c = prof_blk && tid == GWV * 64, prof_g = prof_blk && tid == 0;
 
     for (int step = 0; step < a.T; ++step) {
         const int t = rev ? a.T - 1 - step : step;
         const int tp = rev ? t + 1 : t - 1;
         const bool has_prev = step > 0;
         const int par = step & 1;                     // `red` is double-buffered: one barrier per step
+        const bool prof_now = prof_blk && step >= 200 && step < 232;
+        unsigned long long* pslot = a.prof + (prof_now ? (step - 200) * 16 : 0);
+        if (prof_now && prof_c) prof_stamp(pslot + 0);
+        if (prof_now && prof_g) prof_stamp(pslot + 8);
         float gi_r[NB], gi_z[NB], gi_n[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) { gi_r[nb] = gn_r[nb]; gi_z[nb] = gn_z[nb]; gi_n[nb] = gn_n[nb]; }
@@ -549,7 +584,9 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
         const bool contract = (is_proj || has_prev) && is_mfma;
         if (contract) {
             pacer.wait();
-            poll_tiles<NL, NB>(x, rsrc, voff0 + (unsigned)(is_proj ? t : tp) * step_t, tile_bytes, parity, rowv, err_flag);
+            if (prof_now && prof_c) prof_stamp(pslot + 1);
+            const int spins = poll_tiles<NL, NB>(x, rsrc, voff0 + (unsigned)(is_proj ? t : tp) * step_t, tile_bytes, parity, rowv, err_flag);
+            if (prof_now && prof_c) { prof_stamp(pslot + 2); pslot[5] = (unsigned long long)spins; }
         }
         // requests issued behind the poll (loads return in order, anything older would hold the poll back):
         // next step's input projection (first layer) / this step's projected input granules (other rings)
@@ -597,13 +634,20 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
                     red[par][wave][nb][2][lane][r] = acc[nb][2][r];
                 }
         }
+        if (prof_now && prof_c) prof_stamp(pslot + 3);
         __syncthreads();
-        if (s_err) return;                            // some hand-off timed out
+        if (prof_now && prof_c) prof_stamp(pslot + 4);
+        if (prof_now && prof_g) prof_stamp(pslot + 9);
+        // some hand-off timed out: every wave leaves - but the look at the flag is a dependent LDS round trip, and the gate
+        // threads are on the step's critical path here (barrier -> reduction -> gates -> publish): they read it with the
+        // partial sums and act on it after the publish (what they publish in a failed call is discarded with the call)
+        const int err_seen = s_err;
+        if (tid >= 256 && err_seen) return;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             if (!bv[nb]) continue;
             const size_t tb = (size_t)t * B + b[nb];
-            const int src = (u >> 2) * 16 + bb, reg = u & 3;
+            const int src = (tid >> 2) & 63, reg = tid & 3;
             float s[3] = {bs_r, bs_z, bs_n};
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
@@ -622,13 +666,15 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
                     gi_n[nb] = __uint_as_float(qg[nb][2] & ~1u);
                 }
                 const float ghn = s[2];
-                const float r = 1.f / (1.f + expf(-(gi_r[nb] + s[0])));
-                const float z = 1.f / (1.f + expf(-(gi_z[nb] + s[1])));
-                const float n = tanhf(gi_n[nb] + r * ghn);
+                if (prof_now && prof_g && nb == 0) prof_stamp(pslot + 10);
+                const float r = gate_sigmoid(gi_r[nb] + s[0], fast);
+                const float z = gate_sigmoid(gi_z[nb] + s[1], fast);
+                const float n = gate_tanh(gi_n[nb] + r * ghn, fast);
                 const float hp = h_reg[nb];
                 const float h = tag_clear((t < sl[nb]) ? (1.f - z) * n + z * hp : 0.f);    // the state IS the truncated value
                 h_reg[nb] = h;
-                publish(g_own + (size_t)t * Bp * H + (size_t)nb * (H / 16) * 256 + bb * 16 + u, h, parity);
+                publish(g_own + (size_t)t * Bp * H + (size_t)nb * (H / 16) * 256 + (tid & 255), h, parity);
+                if (prof_now && prof_g && nb == 0) prof_stamp(pslot + 11);
                 L.hs[tb * H + j] = h;
                 if (L.save) {
                     // what BPTT multiplies dh_t with: d(r,z,n pre-activations)/dh, d(gh_n)/dh and z (granule save format)
@@ -639,6 +685,8 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
                 }
             }
         }
+        if (prof_now && prof_g) prof_stamp(pslot + 12);
+        if (err_seen) return;
     }
 }
 
@@ -686,7 +734,7 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
     const unsigned parity = epoch & 1u;
     gu32* g_own = (gu32*)gran_dh_ + (size_t)(chain * a.nlayers + layer) * per_cl + ((size_t)role.by * (H / 16) + role.bx) * 256;
     gu32* g_dy = (gu32*)gran_dy_ + (size_t)(chain * (a.nlayers - 1) + (layer < top ? layer : 0)) * per_cl_b;
-    const int u = tid & 15, bb = tid >> 4, b = b0 + bb, j = j0 + u;
+    const int u = ((tid >> 6) & 3) * 4 + (tid & 3), bb = (tid >> 2) & 15, b = b0 + bb, j = j0 + u;     // see gru_granule_fwd_body
     const bool bv = tid < 256 && b < B;
     const bool rowv = (b0 + lr) < B;
     const int sl = bv ? a.seq_len[b] : 0;
@@ -715,7 +763,7 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         }
     }
     const unsigned cl_src = chain * a.nlayers + (is_proj ? layer + 1 : layer);
-    const unsigned voff0 = (unsigned)(((size_t)cl_src * per_cl + (size_t)role.by * 16 * H + (k0 / 16) * 256 + lr * 16 + lq * 4) * 4);
+    const unsigned voff0 = (unsigned)(((size_t)cl_src * per_cl + (size_t)role.by * 16 * H + (k0 / 16) * 256 + lq * 64 + lr * 4) * 4);
     const unsigned step_t = (unsigned)(Bp * H * 4);
     float dhz_prev = 0.f;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -757,6 +805,8 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
     };
     load_operands(0);
     load_own(0);
+    const bool prof_blk = a.prof != nullptr && (int)blockIdx.x == a.prof_block;        // see gru_granule_fwd_body
+    const bool prof_c = prof_blk && tid == GWV * 64, prof_g = prof_blk && tid == 0;
 
     for (int bstep = 0; bstep < a.T; ++bstep) {
         const int s = a.T - 1 - bstep;
@@ -765,6 +815,10 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         const bool has_next = bstep > 0;
         const size_t tb = (size_t)t * B + b;
         const int par = bstep & 1;
+        const bool prof_now = prof_blk && bstep >= 200 && bstep < 232;
+        unsigned long long* pslot = a.prof + (prof_now ? (bstep - 200) * 16 : 0);
+        if (prof_now && prof_c) prof_stamp(pslot + 0);
+        if (prof_now && prof_g) prof_stamp(pslot + 8);
         if (tid == 0 && (bstep & 31) == 31 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
         f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         c_r = x_r; c_z = x_z; c_n = x_n; c_nr = x_nr; z = x_zz; dyv = x_dy;
@@ -772,7 +826,9 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         const bool contract = (is_proj || has_next) && is_mfma;
         if (contract) {
             pacer.wait();
-            poll_batch<NL>(dh4, rsrc, voff0 + (unsigned)(is_proj ? t : tn) * step_t, parity, rowv, err_flag);
+            if (prof_now && prof_c) prof_stamp(pslot + 1);
+            const int spins = poll_batch<NL>(dh4, rsrc, voff0 + (unsigned)(is_proj ? t : tn) * step_t, parity, rowv, err_flag);
+            if (prof_now && prof_c) { prof_stamp(pslot + 2); pslot[5] = (unsigned long long)spins; }
         }
         unsigned qd[1] = {0};                         // behind the poll: loads return in order
         if (!is_proj && layer < top && bv)
@@ -815,13 +871,18 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
 #pragma unroll
             for (int q = 0; q < 4; ++q) red[par][wave][lane][q] = acc[0][q] + acc[1][q] + acc[2][q];
         }
+        if (prof_now && prof_c) prof_stamp(pslot + 3);
         __syncthreads();
-        if (s_err) return;
+        if (prof_now && prof_c) prof_stamp(pslot + 4);
+        if (prof_now && prof_g) prof_stamp(pslot + 9);
+        const int err_seen = s_err;                    // acted on behind the publish (see gru_granule_fwd_body)
+        if (tid >= 256 && err_seen) return;
         if (bv) {
-            const int src = (u >> 2) * 16 + bb, reg = u & 3;
+            const int src = (tid >> 2) & 63, reg = tid & 3;
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) sum += red[par][w][src][reg];
+            if (prof_now && prof_g) prof_stamp(pslot + 10);
             if (is_proj) {
                 publish(g_dy + tb * H + j, tag_clear(sum), parity);
             } else {
@@ -836,13 +897,16 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
                     dhzv = dh * z;
                 }
                 dhz_prev = dhzv;
-                publish(g_own + (size_t)t * Bp * H + bb * 16 + u, dh, parity);
+                publish(g_own + (size_t)t * Bp * H + (tid & 255), dh, parity);
+                if (prof_now && prof_g) prof_stamp(pslot + 11);
                 float* dgi = L.dgi + tb * G;
                 float* dgh = L.dgh + tb * G;
                 dgi[j] = dr; dgi[H + j] = dz; dgi[2 * H + j] = dn;
                 dgh[j] = dr; dgh[H + j] = dz; dgh[2 * H + j] = dnr;
             }
         }
+        if (prof_now && prof_g) prof_stamp(pslot + 12);
+        if (err_seen) return;
     }
 }
 
@@ -956,6 +1020,16 @@ static int* granule_delay_table(int kind) {
 
 static int granule_capacity(bool bwd, int H, int bf16, int nb);       // co-resident blocks of the scan kernel (below)
 
+// diagnostics (pbsed_gru_set_prof) and the gate-activation form of the forward scan (PBSED_GRU_FAST_GATES, default on)
+static unsigned long long* g_prof_buf = nullptr;
+static int g_prof_block = 0;
+static void granule_common(GruStackArgs& a) {
+    static const int fast = [] { const char* e = getenv("PBSED_GRU_FAST_GATES"); return e ? atoi(e) : 1; }();
+    a.fast_gates = fast;
+    a.prof = g_prof_buf;
+    a.prof_block = g_prof_block;
+}
+
 static void granule_poll_delays(bool bwd, GruStackArgs& a, int nb = 1) {
     // measured with the tile-major exchange arrays and bf16x3 products (tools/sweep_poll_delays.sh, B = 32, H = 256, T = 500).
     // Two-layer stacks (FBCRNN): forward 21 1.28 ms, 23 0.99, 24 0.94, 25 0.97, 26 1.04, 27 1.10; BPTT 14 1.37, 16 1.35,
@@ -1020,6 +1094,7 @@ static int gru_stack_fwd_granule_impl(int nchains, int nlayers, const float* con
     // every block has to be co-resident (one per CU, 7/8 of the device at most): past that, two batch tiles per block
     const int nb = ((gw & 1) && ngroups * (H / 16) * ((B + 15) / 16) > device_cus() * 7 / 8) ? 2 : 1;
     granule_poll_delays(false, a, nb);
+    granule_common(a);
     dim3 grid(H / 16, (B + 16 * nb - 1) / (16 * nb), ngroups);
     if ((int)(grid.x * grid.y * grid.z) > granule_capacity(false, H, bf16, nb)) {
         set_error("gru_stack_fwd_granule: %u blocks cannot be co-resident on this device (capacity %d): use pbsed_gru_stack_fwd",
@@ -1087,6 +1162,7 @@ static int gru_stack_bwd_granule_impl(int nchains, int nlayers, const float* con
     a.seq_len = seq_len; a.B = B; a.T = T; a.nchains = nchains; a.nlayers = nlayers;
     const int ngroups = nchains * (2 * nlayers - 1);
     granule_poll_delays(true, a);
+    granule_common(a);
     dim3 grid(H / 16, (B + 15) / 16, ngroups);
     if ((int)(grid.x * grid.y * grid.z) > granule_capacity(true, H, bf16, 1)) {
         set_error("gru_stack_bwd_granule: %u blocks cannot be co-resident on this device (capacity %d): use pbsed_gru_stack_bwd",
@@ -1193,6 +1269,17 @@ extern "C" {
 // a caller runs pbsed_gru_stack_*_granule only for scans of at most this many blocks - nchains * (2 nlayers - 1) * (H / 16) *
 // ceil(B / (16 * tiles_per_block)) - and the launch-per-step pbsed_gru_stack_fwd / _bwd otherwise; the granule entry points
 // check the same bound and return PBSED_E_UNSUPPORTED instead of launching a scan that could never finish.
+// Diagnostics: the persistent scans launched after this call write shader-clock stamps of block `block` (1-D block index of
+// the XCD-aware grid), scan steps 200..231, to buf[32][16] (device, 4 KB): slots 0..4 = first contraction wave at step top /
+// first poll issued / poll satisfied / partial sums written / past the barrier, 5 = poll attempts that missed, 8..12 = first
+// gate wave at step top / past the barrier / partial sums reduced / state published / outputs stored.  buf = NULL switches
+// it off.  tools/gru_scan_prof.py prints the timeline.
+int pbsed_gru_set_prof(unsigned long long* buf, int block) {
+    g_prof_buf = buf;
+    g_prof_block = block;
+    return PBSED_OK;
+}
+
 int pbsed_gru_get_poll_delays(int kind, int* out4 /*host*/) {
     if (kind < 0 || kind > 2 || !out4) { set_error("gru_get_poll_delays: kind 0..2"); return PBSED_E_ARG; }
     const int* t = granule_delay_table(kind);

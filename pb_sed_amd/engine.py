@@ -117,8 +117,11 @@ def describe_stack(cnns):
 
 
 # Verification tap: when a list is assigned, every conv layer of stack_forward appends what decided its ReLU and its
-# (2,1) pool - (layer's conv module, norm module whose ReLU feeds it | None, raw layer input, BN scale, BN shift, pool
-# argmax bytes | None) - and every skip-path pool ('skip', source conv, destination conv, crossed conv, argmax bytes).  The
+# (2,1) pool - ('layer', the layer's conv module, norm module whose ReLU feeds it | None, raw layer input, BN scale, BN shift,
+# pool argmax bytes | None, BN state, operand format of the launch) - every skip-path pool ('skip', source conv, destination
+# conv, crossed conv, argmax bytes), a stack's raw output ('out', last conv, y), and stack_backward the gradient arriving at
+# every conv's output ('grad', conv, g) and leaving the stack ('grad_in', first conv, g): what a layer-by-layer check of the
+# launches needs (tests/test_gpu_configs.py::test_c3_bf16_launches_in_situ).  The
 # kernels decide a ReLU as fmaf(x, scale, shift) > 0 everywhere (forward prologues, data- and weight-gradient kernels), so
 # the sign of the exact x * scale + shift reproduces it.  tests/hip_decisions.py turns the entries into the masks the float64
 # oracle is run with (oracle/decisions.py).
@@ -215,7 +218,7 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32', x_tbc
         ctx.append((x, st_in, pc, idx, pr, st_frozen, skip_ctx))
         if DECISION_TAP is not None:
             DECISION_TAP.append(('layer', c, L.in_norm if st_in is not None else None, x,
-                                 None if st_in is None else st_in.scale, None if st_in is None else st_in.shift, idx))
+                                 None if st_in is None else st_in.scale, None if st_in is None else st_in.shift, idx, st_in, pr))
         st_frozen = bool(training and next_norm is not None and next_norm.freeze_stats)
         if next_norm is None:
             st_in = None
@@ -225,6 +228,8 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32', x_tbc
         else:
             st_in = ops.bn_eval_params(next_norm)
         x = y
+    if DECISION_TAP is not None:
+        DECISION_TAP.append(('out', layers[-1].conv, x))          # raw output of the stack's last conv
     if layers[-1].out_norm is not None:
         # the stack's closing norm + ReLU (st_in / st_frozen are the last conv's "next norm" state): a launch of its own
         ctx.final = (x, st_in, st_frozen)
@@ -300,6 +305,8 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
                 on_layer_done(0)
             return None
         g = g.contiguous()
+        if DECISION_TAP is not None:
+            DECISION_TAP.append(('grad', c, g))                   # gradient wrt this conv's (pooled) output
         dw, db = _grad(c.conv.weight), _grad(c.conv.bias)
         if dw is not None:
             ops.conv_bwd_weight(x, g, pc, dw, db,
@@ -328,6 +335,8 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
             g = ops.add_inplace(g, pending.pop(j))
         if on_layer_done is not None:
             on_layer_done(j)        # layer j's in_norm belongs to it or to j-1's tail: both done now
+    if DECISION_TAP is not None:
+        DECISION_TAP.append(('grad_in', layers[0].conv, g))      # gradient wrt the stack input
     return g
 
 

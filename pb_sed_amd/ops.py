@@ -729,7 +729,7 @@ def _tune_poll_delay(dev, kind, slot, shape, launch, allow_tune=True):
             return
         _install_poll_delay(dev_i, kind, slot, None)
         base = _POLL_DEFAULT[(dev_i, kind)][slot]
-        cands = sorted({max(base + d, 0) for d in ((-3, -2, -1, 0, 1, 2, 3, 5) if slot == 0 else (-8, -4, -2, 0, 2, 4, 8))})
+        cands = sorted({max(base + d, 0) for d in ((-10, -8, -6, -5, -4, -3, -2, -1, 0, 1, 2, 3, 5) if slot == 0 else (-12, -8, -4, -2, 0, 2, 4, 8))})
         timing_was = _lib.timing
         _lib.timing = None                          # the bench's event brackets must not see the tuning runs
         try:

@@ -51,58 +51,107 @@ class GradSync:
         return 1.0 / self.world
 
 
+class _LibraryComm:
+    """The C-ABI communicator behind LibraryGradSync (include/pbsed.h: pbsed_comm_* / pbsed_allreduce_*)."""
+
+    def __init__(self, device):
+        from . import _lib
+        self._lib, self.device, self.handle = _lib, device, None
+
+    def id_bytes(self):
+        return self._lib.lib().pbsed_comm_id_bytes()
+
+    def unique_id(self):
+        import ctypes as C
+        buf = C.create_string_buffer(self.id_bytes())
+        self._lib.call('pbsed_comm_unique_id', buf)
+        return bytes(buf.raw)
+
+    def create(self, unique_id, rank, world):
+        import ctypes as C
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            self._lib.call('pbsed_comm_create', C.c_char_p(unique_id), rank, world, C.byref(handle))
+        self.handle = handle
+
+    def begin(self, data_ptr, count):
+        self._lib.call('pbsed_allreduce_begin', self.handle, data_ptr, count, self._lib.stream())
+
+    def finish(self):
+        self._lib.call('pbsed_allreduce_finish', self.handle, self._lib.stream())
+
+    def destroy(self):
+        if self.handle is not None:
+            self._lib.call('pbsed_comm_destroy', self.handle)
+            self.handle = None
+
+
 class LibraryGradSync:
     """Same interface as GradSync, but the collective is the library's own (``pbsed_allreduce_begin`` /
     ``pbsed_allreduce_finish`` in include/pbsed.h: RCCL on a library-owned stream, event-fenced against the compute
     stream, no torch.distributed call on the data path).  The RCCL unique id is made on rank 0 and handed to the other
-    ranks through whatever process group / store is initialised (a 128-byte control message, once)."""
+    ranks through whatever process group / store is initialised (a 128-byte control message, once).
+    ``comm``: the communicator object (default: the C-ABI's; tests/test_dp_gloo.py passes a recording stand-in to
+    check the bucket / ordering logic of this class without a GPU)."""
 
-    def __init__(self, flat_grad, buckets, rank=None, world=None, unique_id=None):
-        import ctypes as C
-        from . import _lib
+    def __init__(self, flat_grad, buckets, rank=None, world=None, unique_id=None, comm=None):
         self.flat_grad, self.buckets = flat_grad, list(buckets)
         if world is None:
             world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
             rank = dist.get_rank() if world > 1 else 0
         self.world, self.rank = world, rank
-        lib = _lib.lib()
-        n = lib.pbsed_comm_id_bytes()
+        self._comm = _LibraryComm(flat_grad.device) if comm is None else comm
         if unique_id is None:
-            buf = C.create_string_buffer(n)
-            if rank == 0:
-                _lib.call('pbsed_comm_unique_id', buf)
-            box = [bytes(buf.raw)]
+            box = [self._comm.unique_id() if rank == 0 else None]
             if world > 1:
                 dist.broadcast_object_list(box, src=0)
             unique_id = box[0]
-        assert len(unique_id) == n
-        handle = C.c_void_p()
-        with torch.cuda.device(flat_grad.device):
-            _lib.call('pbsed_comm_create', C.c_char_p(unique_id), rank, world, C.byref(handle))
-        self._comm, self._done = handle, set()
+        assert len(unique_id) == self._comm.id_bytes()
+        self._comm.create(unique_id, rank, world)
+        self._done = set()
 
     def bucket_ready(self, i):
-        from . import _lib
         if i in self._done:
             return
         self._done.add(i)
         a, b = self.buckets[i]
         if b > a and self.world > 1:
-            _lib.call('pbsed_allreduce_begin', self._comm, self.flat_grad.data_ptr() + 4 * a, b - a, _lib.stream())
+            self._comm.begin(self.flat_grad.data_ptr() + 4 * a, b - a)
 
     def finish(self):
-        from . import _lib
         for i in range(len(self.buckets)):
             self.bucket_ready(i)
-        _lib.call('pbsed_allreduce_finish', self._comm, _lib.stream())
+        self._comm.finish()
         self._done = set()
         return 1.0 / self.world
 
     def close(self):
-        from . import _lib
         if self._comm is not None:
-            _lib.call('pbsed_comm_destroy', self._comm)
+            self._comm.destroy()
             self._comm = None
+
+
+def make_grad_sync(flat_grad, buckets, allreduce=None):
+    """The gradient exchange of a Trainer.  ``allreduce``: 'library' | 'torch' | None (env PBSED_ALLREDUCE, else the
+    default).  Default: with a process group of more than one rank and the gradients on a GPU, the C-ABI's own
+    communicator (LibraryGradSync - the path include/pbsed.h describes: RCCL on a library-owned stream, event fences, no
+    torch call on the data path); 'torch' (torch.distributed.all_reduce on the initialised group, backend "nccl" = RCCL)
+    otherwise - a single process, CPU tensors (gloo tests), or when the library's communicator cannot be created (a warning
+    says so; every rank takes the same branch because ncclCommInitRank fails or succeeds collectively)."""
+    import os
+    import warnings
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    choice = allreduce or os.environ.get('PBSED_ALLREDUCE') or ('library' if multi and flat_grad.is_cuda else 'torch')
+    if choice == 'library':
+        try:
+            return LibraryGradSync(flat_grad, buckets), 'library'
+        except (RuntimeError, OSError) as ex:
+            if allreduce == 'library' or not multi:
+                raise
+            warnings.warn(f'library communicator unavailable ({ex}); falling back to torch.distributed.all_reduce')
+            ok = torch.ones((), device=flat_grad.device)
+            dist.all_reduce(ok)                          # keep the ranks in step before the first bucket
+    return GradSync(flat_grad, buckets), 'torch'
 
 
 def shard_batch(batch, rank, world):
@@ -174,8 +223,9 @@ def load_init_checkpoint(model, state_dict):
 
 class Trainer:
     def __init__(self, model, lr=5e-4, gradient_clipping=1e10, betas=(.9, .999), eps=1e-8, allreduce=None, flag_check_lag=1):
-        """``allreduce``: 'torch' (torch.distributed all_reduce on the initialised process group: "nccl" = RCCL on
-        ROCm; default) or 'library' (the C-ABI's own RCCL communicator, LibraryGradSync); env PBSED_ALLREDUCE."""
+        """``allreduce``: 'library' (the C-ABI's own RCCL communicator, LibraryGradSync: the default with more than one
+        rank on GPUs) or 'torch' (torch.distributed all_reduce on the initialised process group: "nccl" = RCCL on ROCm;
+        the default otherwise and the fallback); env PBSED_ALLREDUCE.  See make_grad_sync."""
         self.model = model
         self.lr, self.clip, self.betas, self.eps = lr, gradient_clipping, betas, eps
         self.flat_param, self.flat_grad = model.flat_parameters()
@@ -185,10 +235,7 @@ class Trainer:
         self.grad_norm = torch.zeros((), dtype=torch.float32, device=self.flat_param.device)
         self.iteration = 0
         self.bucket_names, buckets = param_buckets(model)
-        import os
-        allreduce = allreduce or os.environ.get('PBSED_ALLREDUCE', 'torch')
-        self.sync = (LibraryGradSync if allreduce == 'library' else GradSync)(self.flat_grad, buckets)
-        self.allreduce = allreduce
+        self.sync, self.allreduce = make_grad_sync(self.flat_grad, buckets, allreduce)
         model._grad_hook = self._on_grads_ready
         self._defer = 'defer_summary' in inspect.signature(model.review).parameters
         # Error words of the persistent scans.  The device side is immediate: a step whose scan timed out skips its own Adam

@@ -27,7 +27,7 @@ class _Tap:
 
     def append(self, e):
         if e[0] == 'layer':
-            _, conv, norm, x, scale, shift, idx = e
+            _, conv, norm, x, scale, shift, idx = e[:7]
             if norm is not None:
                 owner = self.names[norm].rsplit('.', 1)[0]            # 'cnn.cnn_2d.convs.3.norm' -> the layer applying norm + ReLU
                 self.dec.setdefault(owner, {})['relu'] = self._mask(x, scale, shift)
@@ -43,7 +43,7 @@ class _Tap:
             stack, i_src = self.names[src].rsplit('.convs.', 1)
             key = (int(i_src), int(self.names[dst].rsplit('.convs.', 1)[1]), int(self.names[crossed].rsplit('.convs.', 1)[1]))
             self.dec.setdefault(stack, {}).setdefault('skip_pool', {})[key] = pidx.bool()
-        else:
+        elif e[0] not in ('out', 'grad', 'grad_in'):
             raise ValueError(e[0])
 
     def decisions(self, outputs=None):

@@ -171,6 +171,92 @@ def test_sync_buffers_world2(tmp_path):
         assert open(tmp_path / f'buf{r}').read() == 'True'
 
 
+class _RecordingComm:
+    """Stand-in for the C-ABI communicator (pb_sed_amd.trainer._LibraryComm): records the calls LibraryGradSync makes and
+    performs the sum with gloo so that the result can be checked too."""
+
+    def __init__(self, flat):
+        self.flat, self.calls, self.pending = flat, [], []
+
+    def id_bytes(self):
+        return 128
+
+    def unique_id(self):
+        self.calls.append(('unique_id',))
+        return bytes(range(128))
+
+    def create(self, unique_id, rank, world):
+        self.calls.append(('create', unique_id, rank, world))
+
+    def begin(self, data_ptr, count):
+        off = (data_ptr - self.flat.data_ptr()) // 4
+        self.calls.append(('begin', off, count))
+        self.pending.append(dist.all_reduce(self.flat[off:off + count], async_op=True) if dist.is_initialized() else None)
+
+    def finish(self):
+        self.calls.append(('finish',))
+        for w in self.pending:
+            if w is not None:
+                w.wait()
+        self.pending = []
+
+    def destroy(self):
+        self.calls.append(('destroy',))
+
+
+def _library_sync_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pb_sed_amd.trainer import LibraryGradSync
+    n = 1000
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    comm = _RecordingComm(g)
+    sync = LibraryGradSync(g, [(600, 1000), (250, 600), (0, 250), (250, 250)], comm=comm)
+    ok = sync.world == world and sync.rank == rank
+    # the unique id is made on rank 0 only and reaches every rank unchanged
+    ok = ok and (('unique_id',) in comm.calls) == (rank == 0)
+    ok = ok and comm.calls[-1] == ('create', bytes(range(128)), rank, world)
+    comm.calls.clear()
+    sync.bucket_ready(0)                 # backward-completion order, announced from inside backward
+    sync.bucket_ready(1)
+    sync.bucket_ready(1)                 # idempotent
+    scale = sync.finish()                # announces what is left (bucket 2; bucket 3 is empty: no collective), then ONE finish
+    ok = ok and comm.calls == [('begin', 600, 400), ('begin', 250, 350), ('begin', 0, 250), ('finish',)]
+    ok = ok and scale == 1.0 / world and torch.equal(g, torch.arange(n, dtype=torch.float32) * 3)
+    comm.calls.clear()
+    g.copy_(torch.ones(n) * (rank + 1))
+    sync.finish()                        # re-armed: the next step issues all three again
+    ok = ok and comm.calls == [('begin', 600, 400), ('begin', 250, 350), ('begin', 0, 250), ('finish',)]
+    ok = ok and torch.equal(g, torch.full((n,), 3.))
+    sync.close()
+    ok = ok and comm.calls[-1] == ('destroy',)
+    with open(os.path.join(out_dir, f'lib{rank}'), 'w') as f:
+        f.write(str(bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_library_gradsync_bucket_logic_with_a_stand_in_communicator_world2(tmp_path):
+    """the bucket / ordering logic of LibraryGradSync (the default exchange with > 1 rank on GPUs) on
+    the CPU - communicator creation (unique id from rank 0), begin calls in announcement order with the right slices of
+    the flat buffer, empty buckets skipped, one finish per step, re-arming."""
+    mp.spawn(_library_sync_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f'lib{r}').read() == 'True'
+
+
+def test_make_grad_sync_defaults():
+    """One process / CPU tensors -> torch.distributed path; the library path is the default only with > 1 rank on GPUs."""
+    from pb_sed_amd.trainer import GradSync, LibraryGradSync, make_grad_sync
+    g = torch.ones(10)
+    sync, name = make_grad_sync(g, [(0, 10)])
+    assert isinstance(sync, GradSync) and name == 'torch'
+    comm = _RecordingComm(g)
+    one = LibraryGradSync(g, [(0, 10)], rank=0, world=1, comm=comm)
+    one.bucket_ready(0)
+    assert one.finish() == 1.0 and ('begin', 0, 10) not in comm.calls and comm.calls[-1] == ('finish',)     # world 1: no collective
+
+
 def test_gradsync_single_process_is_noop():
     from pb_sed_amd.trainer import GradSync
     g = torch.ones(10)

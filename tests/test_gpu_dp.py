@@ -67,7 +67,8 @@ def _worker(rank, world, port, out_dir, frozen):
     torch.cuda.set_device(0)
     from pb_sed_amd.trainer import Trainer, shard_batch
     model = _model(frozen)
-    trainer = Trainer(model, lr=1e-3, gradient_clipping=5.)
+    # gloo + two ranks on ONE device: RCCL (the default exchange with > 1 rank on GPUs) refuses two ranks per device
+    trainer = Trainer(model, lr=1e-3, gradient_clipping=5., allreduce='torch')
     mine = shard_batch(_to(_batch(16), 'cuda:0'), rank, world)
     rows = []
     for step in range(3):
@@ -122,8 +123,8 @@ def test_library_allreduce_world1_and_trainer_sync():
     # world 1 skips the collective in bucket_ready; drive the entry points directly: a 1-rank sum is the identity, and
     # it must be ordered AFTER the producer stream's pending work and BEFORE the consumer's next kernel
     x.mul_(3)
-    _lib.call('pbsed_allreduce_begin', sync._comm, x.data_ptr(), x.numel(), _lib.stream())
-    _lib.call('pbsed_allreduce_finish', sync._comm, _lib.stream())
+    _lib.call('pbsed_allreduce_begin', sync._comm.handle, x.data_ptr(), x.numel(), _lib.stream())
+    _lib.call('pbsed_allreduce_finish', sync._comm.handle, _lib.stream())
     x.add_(1)
     torch.cuda.synchronize()
     assert torch.equal(x, want)

@@ -41,6 +41,51 @@ __global__ void pingpong(unsigned* buf, int partner_a, int partner_b, int iters,
     else out[2] = fails;
 }
 
+// Fresh address per iteration (the scans' situation: every exchanged word has its own location, written once per call): the
+// FIRST look at a location may be a plain load - the CU's L1 cannot hold a stale copy of a line it never read, and inside an
+// XCD the L2 is the coherence point - with sc1 loads only for the retries.  WAIT = clocks the consumer sleeps before the first
+// look (0 = immediately: the first plain look usually comes too early and leaves the stale line in L1, every retry is sc1).
+template <int ST, int FIRST, int WAIT>
+__global__ void pingpong_fresh(unsigned* buf, int partner_a, int partner_b, int iters, unsigned* out) {
+    const int me = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    if (me != partner_a && me != partner_b) return;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(buf, 0, 1u << 26, 0x00020000);
+    const bool is_a = me == partner_a;
+    unsigned fails = 0, first_ok = 0;
+    long long t0 = wall_clock64();
+    for (int i = 1; i <= iters; ++i) {
+        const unsigned mine = (unsigned)i * 512u + (is_a ? 0u : 256u), theirs = (unsigned)i * 512u + (is_a ? 256u : 0u);
+        if (is_a) __builtin_amdgcn_raw_buffer_store_b32((unsigned)i, rs, mine, 0, ST);
+        for (int w = 0; w < WAIT; w += 64) __builtin_amdgcn_s_sleep(1);
+        int spin = 0;
+        for (;; ++spin) {
+            asm volatile("" ::: "memory");
+            const unsigned v = spin == 0 ? __builtin_amdgcn_raw_buffer_load_b32(rs, theirs, 0, FIRST)
+                                         : __builtin_amdgcn_raw_buffer_load_b32(rs, theirs, 0, 16);
+            if (v == (unsigned)i) { first_ok += spin == 0; break; }
+            if (spin > 2000000) { ++fails; break; }
+        }
+        if (fails) break;
+        if (!is_a) __builtin_amdgcn_raw_buffer_store_b32((unsigned)i, rs, mine, 0, ST);
+    }
+    long long t1 = wall_clock64();
+    if (is_a) { out[0] = (unsigned)(t1 - t0); out[1] = fails; out[3] = first_ok; }
+    else { out[2] = fails; out[4] = first_ok; }
+}
+
+template <int ST, int FIRST, int WAIT>
+void run_fresh(const char* name, unsigned* big, unsigned* out, int a, int b) {
+    const int iters = 20000;
+    hipMemset(big, 0, 1u << 26); hipMemset(out, 0, 256);
+    hipLaunchKernelGGL((pingpong_fresh<ST, FIRST, WAIT>), dim3(16), dim3(64), 0, 0, big, a, b, iters, out);
+    hipDeviceSynchronize();
+    unsigned h[32]; hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+    int rate = 0; hipDeviceGetAttribute(&rate, hipDeviceAttributeWallClockRate, 0);
+    printf("fresh address, %-34s wait %4d blocks %2d<->%2d: %s  %.0f ns per round trip, first look ok %u / %u of %d\n", name, WAIT, a, b,
+           (h[1] || h[2]) ? "NOT VISIBLE" : "ok", h[0] * 1e6 / rate / iters, h[3], h[4], iters);
+}
+
 template <int ST, int LD>
 void run(const char* name, unsigned* buf, unsigned* out, int a, int b) {
     const int iters = 20000;
@@ -76,6 +121,24 @@ int main() {
         run<0, 103>("store plain, inv sc1 + plain load", buf, out, a, b);
         run<16, 103>("store sc1, inv sc1 + plain load", buf, out, a, b);
         run<16, 104>("store sc1, inv sc0sc1 + plain load", buf, out, a, b);
+    }
+    unsigned* big; hipMalloc(&big, 1u << 26);
+    for (int pass = 0; pass < 2; ++pass) {
+        const int a = 0, b = pass == 0 ? 8 : 1;
+        run_fresh<16, 16, 0>("store sc1, looks sc1", big, out, a, b);
+        run_fresh<16, 0, 0>("store sc1, first look plain", big, out, a, b);
+        run_fresh<16, 0, 512>("store sc1, first look plain", big, out, a, b);
+        run_fresh<16, 0, 768>("store sc1, first look plain", big, out, a, b);
+        run_fresh<16, 0, 1024>("store sc1, first look plain", big, out, a, b);
+        run_fresh<16, 0, 1536>("store sc1, first look plain", big, out, a, b);
+        run_fresh<16, 16, 768>("store sc1, looks sc1", big, out, a, b);
+        run_fresh<16, 16, 1024>("store sc1, looks sc1", big, out, a, b);
+        run_fresh<16, 16, 1536>("store sc1, looks sc1", big, out, a, b);
+        run_fresh<0, 0, 512>("store plain, first look plain", big, out, a, b);
+        run_fresh<0, 0, 768>("store plain, first look plain", big, out, a, b);
+        run_fresh<0, 0, 1024>("store plain, first look plain", big, out, a, b);
+        run_fresh<1, 0, 768>("store sc0, first look plain", big, out, a, b);
+        run_fresh<16, 1, 768>("store sc1, first look sc0", big, out, a, b);
     }
     return 0;
 }
