@@ -42,6 +42,7 @@ struct GruStackArgs {
     int B, T, nchains, nlayers, launch;
     int poll_delay, poll_delay_gate;   // granule kernels: first-poll delays (PollPacer) of the non-gate / gate waves
     int ring_xcd, nby;    // granule kernels: ring_xcd = H/16 > 0 selects the 1-D XCD-aware role mapping (granule_role)
+    unsigned* gran_loc;   // granule scans: the rings' XCD-local copy of the exchanged states (see poll_batch); null = off
     int fast_gates;       // granule forward scan: gate activations from v_exp_f32 / v_rcp_f32 (gate_sigmoid / gate_tanh)
     unsigned long long* prof;   // diagnostics (pbsed_gru_set_prof): shader-clock stamps of block `prof_block`, steps 200..231
     int prof_block;
@@ -318,18 +319,36 @@ struct PollPacer {
 // contiguous 1 KB tile one producer block published (8 whole 128-byte lines instead of 16 half lines of a row-major
 // [T][B][H] array) and a producer's 256 publishing threads write one contiguous 1 KB; nothing is fetched twice.  All loads of a step are issued
 // before any tag is looked at (one fabric round trip per step); out[n] = the four (tag-cleared) values.
+// XCD-local exchange of a ring.  A ring's 16 workgroups sit on ONE XCD (granule_role) and share its L2.  tools/micro/
+// l2_pingpong.hip on fresh addresses: a write-through (sc1) store takes 1 000 .. 1 500 clocks to become visible - to an sc1
+// load and to a plain load alike - and the scans' sc1 polls return after ~2 000 clocks under the scan's own traffic (shader-clock
+// profile, tools/gru_scan_prof.py: published -> satisfied = 2 750 of a forward step's 5 500 clocks); a PLAIN store is in the
+// XCD's L2 within ~500 clocks and a plain load of a line the CU never read comes from that L2.  So every state word is
+// published twice: a plain store into the ring's local copy `gran_loc` (same tile order) and the write-through store into
+// the main array.  A ring's FIRST look at a step's words is a plain load from the local copy - every word has its own
+// location, written once per call, and the CU looks at it for the first time (its L1 cannot hold a stale copy of a line it
+// never read; L1s are invalidated at kernel boundaries) - and whatever it returns is validated by the parity tags like any
+// other look: stale, half-written or (ring not on one XCD after all) never-arriving data fails the test, and the retries are
+// sc1 loads from the main array, which is also what the projection blocks on the other XCDs read.  Correctness therefore does
+// not depend on where the blocks run; the placement only decides which path is taken.
 template <int NL, int STEP = 1024>
-__device__ __forceinline__ int poll_batch(float4 (&out)[NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned parity,
-                                          bool valid, unsigned* err_flag) {
+__device__ __forceinline__ int poll_batch(float4 (&out)[NL], __amdgpu_buffer_rsrc_t rsrc, __amdgpu_buffer_rsrc_t rsrc_loc, unsigned voff,
+                                          unsigned parity, bool valid, unsigned* err_flag, bool first_plain) {
     u32x4_t q[NL];
 #pragma unroll
     for (int n = 0; n < NL; ++n) q[n] = u32x4_t{0u, 0u, 0u, 0u};
     int spin = 0;
     for (;; ++spin) {
         bool ok = true;
+        asm volatile("" ::: "memory");                  // the load builtins are not volatile: every attempt loads again
         if (valid) {
+            if (spin == 0 && first_plain) {
 #pragma unroll
-            for (int n = 0; n < NL; ++n) q[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + n * STEP, 0, /*aux = sc1*/ 16);
+                for (int n = 0; n < NL; ++n) q[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_loc, voff + n * STEP, 0, 0);
+            } else {
+#pragma unroll
+                for (int n = 0; n < NL; ++n) q[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + n * STEP, 0, /*aux = sc1*/ 16);
+            }
             unsigned all1 = 1u, any1 = 0u;
 #pragma unroll
             for (int n = 0; n < NL; ++n) {
@@ -424,8 +443,8 @@ __device__ __forceinline__ void wait_own_granules(unsigned (&q)[NQ], const gu32*
 // NB: 16-row batch tiles per block (1, or 2 for more than 32 clips: the rings of 64 clips then need 192 instead of 384
 // co-resident blocks and stay one launch; a block's two tiles share the W fragments, their polls are issued together).
 template <int NL, int NB>
-__device__ __forceinline__ int poll_tiles(float4 (&out)[NB][NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned tile_stride,
-                                           unsigned parity, const bool (&valid)[NB], unsigned* err_flag) {
+__device__ __forceinline__ int poll_tiles(float4 (&out)[NB][NL], __amdgpu_buffer_rsrc_t rsrc, __amdgpu_buffer_rsrc_t rsrc_loc, unsigned voff,
+                                           unsigned tile_stride, unsigned parity, const bool (&valid)[NB], unsigned* err_flag, bool first_plain) {
     u32x4_t q[NB][NL];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -434,12 +453,19 @@ __device__ __forceinline__ int poll_tiles(float4 (&out)[NB][NL], __amdgpu_buffer
     int spin = 0;
     for (;; ++spin) {
         unsigned all1 = 1u, any1 = 0u;
+        asm volatile("" ::: "memory");                  // see poll_batch
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
             if (valid[nb]) {
+                if (spin == 0 && first_plain) {                   // see poll_batch
 #pragma unroll
-                for (int n = 0; n < NL; ++n)
-                    q[nb][n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + nb * tile_stride + n * 1024, 0, /*aux = sc1*/ 16);
+                    for (int n = 0; n < NL; ++n)
+                        q[nb][n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_loc, voff + nb * tile_stride + n * 1024, 0, 0);
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NL; ++n)
+                        q[nb][n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + nb * tile_stride + n * 1024, 0, /*aux = sc1*/ 16);
+                }
             }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -488,6 +514,10 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
     const unsigned parity = epoch & 1u;
     // ring: h_t, tile-major; this block's first tile of step t starts at g_own + t * Bp * H, the next one H * 16 words on
     gu32* g_own = (gu32*)gran_h_ + (size_t)(chain * a.nlayers + layer) * per_cl + ((size_t)role.by * NB * (H / 16) + role.bx) * 256;
+    // the rings' XCD-local copy (poll_batch): same offsets in a second array
+    const __amdgpu_buffer_rsrc_t rsrc_loc =
+        __builtin_amdgcn_make_buffer_rsrc(a.gran_loc ? a.gran_loc : gran_h_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 4), 0x00020000);
+    gu32* g_loc = a.gran_loc ? (gu32*)a.gran_loc + (g_own - (gu32*)gran_h_) : nullptr;
     gu32* g_gi = (gu32*)gran_gi_ + (size_t)(chain * (a.nlayers - 1) + (layer > 0 ? layer - 1 : 0)) * per_cl_b * 3;  // [T][B][3][H]
     // gate thread -> (unit, batch row): thread tid owns the accumulator element (lane tid >> 2, register tid & 3) of the MFMA D
     // layout, i.e. the partial sums it adds are the consecutive floats red[..][tid] (conflict-free LDS reads; the row-major
@@ -557,6 +587,7 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
     };
     load_gi(0);
     const bool fast = a.fast_gates != 0;
+    const bool first_plain = a.gran_loc != nullptr && !is_proj;
     // diagnostics: lane 0 of the first contraction wave (slots 0..5) and of the first gate wave (slots 8..12) of one block
     const bool prof_blk = a.prof != nullptr && (int)blockIdx.x == a.prof_block;
     const bool prof_c = prof_blk && tid == GWV * 64, prof_g = prof_blk && tid == 0;
@@ -585,7 +616,7 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
         if (contract) {
             pacer.wait();
             if (prof_now && prof_c) prof_stamp(pslot + 1);
-            const int spins = poll_tiles<NL, NB>(x, rsrc, voff0 + (unsigned)(is_proj ? t : tp) * step_t, tile_bytes, parity, rowv, err_flag);
+            const int spins = poll_tiles<NL, NB>(x, rsrc, rsrc_loc, voff0 + (unsigned)(is_proj ? t : tp) * step_t, tile_bytes, parity, rowv, err_flag, first_plain);
             if (prof_now && prof_c) { prof_stamp(pslot + 2); pslot[5] = (unsigned long long)spins; }
         }
         // requests issued behind the poll (loads return in order, anything older would hold the poll back):
@@ -673,7 +704,9 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
                 const float hp = h_reg[nb];
                 const float h = tag_clear((t < sl[nb]) ? (1.f - z) * n + z * hp : 0.f);    // the state IS the truncated value
                 h_reg[nb] = h;
-                publish(g_own + (size_t)t * Bp * H + (size_t)nb * (H / 16) * 256 + (tid & 255), h, parity);
+                const size_t own_off = (size_t)t * Bp * H + (size_t)nb * (H / 16) * 256 + (tid & 255);
+                if (g_loc) __hip_atomic_store(g_loc + own_off, __float_as_uint(h) | parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                publish(g_own + own_off, h, parity);
                 if (prof_now && prof_g && nb == 0) prof_stamp(pslot + 11);
                 L.hs[tb * H + j] = h;
                 if (L.save) {
@@ -733,6 +766,9 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         __builtin_amdgcn_make_buffer_rsrc(gran_dh_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 4), 0x00020000);
     const unsigned parity = epoch & 1u;
     gu32* g_own = (gu32*)gran_dh_ + (size_t)(chain * a.nlayers + layer) * per_cl + ((size_t)role.by * (H / 16) + role.bx) * 256;
+    const __amdgpu_buffer_rsrc_t rsrc_loc =                    // the rings' XCD-local copy (poll_batch)
+        __builtin_amdgcn_make_buffer_rsrc(a.gran_loc ? a.gran_loc : gran_dh_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 4), 0x00020000);
+    gu32* g_loc = a.gran_loc ? (gu32*)a.gran_loc + (g_own - (gu32*)gran_dh_) : nullptr;
     gu32* g_dy = (gu32*)gran_dy_ + (size_t)(chain * (a.nlayers - 1) + (layer < top ? layer : 0)) * per_cl_b;
     const int u = ((tid >> 6) & 3) * 4 + (tid & 3), bb = (tid >> 2) & 15, b = b0 + bb, j = j0 + u;     // see gru_granule_fwd_body
     const bool bv = tid < 256 && b < B;
@@ -806,6 +842,7 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
     load_operands(0);
     load_own(0);
     const bool prof_blk = a.prof != nullptr && (int)blockIdx.x == a.prof_block;        // see gru_granule_fwd_body
+    const bool first_plain = a.gran_loc != nullptr && !is_proj;
     const bool prof_c = prof_blk && tid == GWV * 64, prof_g = prof_blk && tid == 0;
 
     for (int bstep = 0; bstep < a.T; ++bstep) {
@@ -827,7 +864,7 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         if (contract) {
             pacer.wait();
             if (prof_now && prof_c) prof_stamp(pslot + 1);
-            const int spins = poll_batch<NL>(dh4, rsrc, voff0 + (unsigned)(is_proj ? t : tn) * step_t, parity, rowv, err_flag);
+            const int spins = poll_batch<NL>(dh4, rsrc, rsrc_loc, voff0 + (unsigned)(is_proj ? t : tn) * step_t, parity, rowv, err_flag, first_plain);
             if (prof_now && prof_c) { prof_stamp(pslot + 2); pslot[5] = (unsigned long long)spins; }
         }
         unsigned qd[1] = {0};                         // behind the poll: loads return in order
@@ -897,7 +934,9 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
                     dhzv = dh * z;
                 }
                 dhz_prev = dhzv;
-                publish(g_own + (size_t)t * Bp * H + (tid & 255), dh, parity);
+                const size_t own_off = (size_t)t * Bp * H + (tid & 255);
+                if (g_loc) __hip_atomic_store(g_loc + own_off, __float_as_uint(dh) | parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                publish(g_own + own_off, dh, parity);
                 if (prof_now && prof_g) prof_stamp(pslot + 11);
                 float* dgi = L.dgi + tb * G;
                 float* dgh = L.dgh + tb * G;
@@ -1023,9 +1062,12 @@ static int granule_capacity(bool bwd, int H, int bf16, int nb);       // co-resi
 // diagnostics (pbsed_gru_set_prof) and the gate-activation form of the forward scan (PBSED_GRU_FAST_GATES, default on)
 static unsigned long long* g_prof_buf = nullptr;
 static int g_prof_block = 0;
-static void granule_common(GruStackArgs& a) {
+static void granule_common(GruStackArgs& a, unsigned* loc) {
     static const int fast = [] { const char* e = getenv("PBSED_GRU_FAST_GATES"); return e ? atoi(e) : 1; }();
     a.fast_gates = fast;
+    // PBSED_GRU_LOCAL=0: the rings poll the write-through array only (the form of rounds 1 - 3)
+    static const int local = [] { const char* e = getenv("PBSED_GRU_LOCAL"); return e ? atoi(e) : 1; }();
+    a.gran_loc = local ? loc : nullptr;
     a.prof = g_prof_buf;
     a.prof_block = g_prof_block;
 }
@@ -1055,7 +1097,8 @@ static bool granule_ring_xcd(bool bwd) {
 }
 
 // Granule-exchange persistent forward scan (see gru_granule_fwd_kernel).  granules: device uint32 workspace of
-// nchains*T*Bp*H*(nlayers + 3*(nlayers-1)) words, Bp = B rounded up to 16 (h_t of every layer, then the projected inputs of layers > 0) that
+// nchains*T*Bp*H*(2*nlayers + 3*(nlayers-1)) words, Bp = B rounded up to 16 (h_t of every layer, the projected inputs of layers > 0,
+// then the rings' XCD-local copy of h_t) that
 // must be ZERO before its first use; `epoch` must be odd on the first use of a workspace and change parity with
 // every call that uses it (the words of the previous call then never match); same T, B, H for the life of a
 // workspace.  err_flag: device uint32 (0 on entry; non-zero after a hand-off timed out: re-zero the workspace).
@@ -1094,7 +1137,7 @@ static int gru_stack_fwd_granule_impl(int nchains, int nlayers, const float* con
     // every block has to be co-resident (one per CU, 7/8 of the device at most): past that, two batch tiles per block
     const int nb = ((gw & 1) && ngroups * (H / 16) * ((B + 15) / 16) > device_cus() * 7 / 8) ? 2 : 1;
     granule_poll_delays(false, a, nb);
-    granule_common(a);
+    granule_common(a, granules + (size_t)nchains * T * Bp * H * (nlayers + 3 * (nlayers - 1)));
     dim3 grid(H / 16, (B + 16 * nb - 1) / (16 * nb), ngroups);
     if ((int)(grid.x * grid.y * grid.z) > granule_capacity(false, H, bf16, nb)) {
         set_error("gru_stack_fwd_granule: %u blocks cannot be co-resident on this device (capacity %d): use pbsed_gru_stack_fwd",
@@ -1102,6 +1145,7 @@ static int gru_stack_fwd_granule_impl(int nchains, int nlayers, const float* con
         return PBSED_E_UNSUPPORTED;
     }
     if (granule_ring_xcd(false)) granule_xcd_grid(a, H, &grid, nb);
+    if (!a.ring_xcd) a.gran_loc = nullptr;                // rings spread over the XCDs: the local copy would never be seen in time
     unsigned* gran_gi = granules + (size_t)nchains * nlayers * T * Bp * H;
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_GW(KB_, NW_, X3_, NB_)                                                                                  \
@@ -1136,8 +1180,9 @@ static int gru_stack_fwd_granule_impl(int nchains, int nlayers, const float* con
 }
 
 
-// Granule-exchange persistent BPTT.  granules: device uint32 workspace of nchains*T*Bp*H*(2*nlayers-1) words (Bp as above)
-// (dh_t of every layer, then dy_t of the layers below the top), zero before first use, epoch parity as above.
+// Granule-exchange persistent BPTT.  granules: device uint32 workspace of nchains*T*Bp*H*(3*nlayers-1) words (Bp as above)
+// (dh_t of every layer, dy_t of the layers below the top, then the rings' XCD-local copy of dh_t), zero before first use,
+// epoch parity as above.
 static int gru_stack_bwd_granule_impl(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
                                       const float* const* hs, const float* const* save, const float* const* dy_top,
                                       float* const* dgi, float* const* dgh, const int* reverse, const int* seq_len, int B, int H,
@@ -1162,7 +1207,7 @@ static int gru_stack_bwd_granule_impl(int nchains, int nlayers, const float* con
     a.seq_len = seq_len; a.B = B; a.T = T; a.nchains = nchains; a.nlayers = nlayers;
     const int ngroups = nchains * (2 * nlayers - 1);
     granule_poll_delays(true, a);
-    granule_common(a);
+    granule_common(a, granules + (size_t)nchains * T * Bp * H * (2 * nlayers - 1));
     dim3 grid(H / 16, (B + 15) / 16, ngroups);
     if ((int)(grid.x * grid.y * grid.z) > granule_capacity(true, H, bf16, 1)) {
         set_error("gru_stack_bwd_granule: %u blocks cannot be co-resident on this device (capacity %d): use pbsed_gru_stack_bwd",
@@ -1170,6 +1215,7 @@ static int gru_stack_bwd_granule_impl(int nchains, int nlayers, const float* con
         return PBSED_E_UNSUPPORTED;
     }
     if (granule_ring_xcd(true)) granule_xcd_grid(a, H, &grid);
+    if (!a.ring_xcd) a.gran_loc = nullptr;
     unsigned* gran_dy = granules + (size_t)nchains * nlayers * T * Bp * H;
     hipStream_t s = (hipStream_t)stream;
     // PBSED_GRU_GW: bit 0 forward / bit 1 BPTT scan with dedicated gate waves (default both; 1.35 -> 1.21 ms and

@@ -729,12 +729,10 @@ def _tune_poll_delay(dev, kind, slot, shape, launch, allow_tune=True):
             return
         _install_poll_delay(dev_i, kind, slot, None)
         base = _POLL_DEFAULT[(dev_i, kind)][slot]
-        cands = sorted({max(base + d, 0) for d in ((-10, -8, -6, -5, -4, -3, -2, -1, 0, 1, 2, 3, 5) if slot == 0 else (-12, -8, -4, -2, 0, 2, 4, 8))})
         timing_was = _lib.timing
         _lib.timing = None                          # the bench's event brackets must not see the tuning runs
         try:
-            best = None
-            for d in cands:
+            def measure(d):
                 _install_poll_delay(dev_i, kind, slot, d)
                 launch(tag='tune')
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -743,11 +741,20 @@ def _tune_poll_delay(dev, kind, slot, shape, launch, allow_tune=True):
                     launch(tag='tune')
                 e1.record()
                 e1.synchronize()
-                ms = e0.elapsed_time(e1) / 3
-                if best is None or ms < best[0] * .995:           # a later delay wins ties within 0.5 %
-                    best = (ms, d)
-                elif ms <= best[0] * 1.005:
-                    best = (min(ms, best[0]), d)
+                return e0.elapsed_time(e1) / 3
+
+            def pick(cands, best):
+                for d in cands:
+                    ms = measure(d)
+                    if best is None or ms < best[0] * .995:           # a later delay wins ties within 0.5 %
+                        best = (ms, d)
+                    elif ms <= best[0] * 1.005 and d > best[1]:
+                        best = (min(ms, best[0]), d)
+                return best
+            # coarse pass over everything between "no wait" and a little past the built-in value (the XCD-local exchange moved
+            # the optimum far below the write-through protocol's 20 .. 25 units), then single units around the best
+            best = pick(range(0, base + 7, 3), None)
+            best = pick([d for d in range(max(best[1] - 2, 0), best[1] + 3) if d != best[1]], best)
             _install_poll_delay(dev_i, kind, slot, best[1])
         finally:
             _lib.timing = timing_was
@@ -821,7 +828,7 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
         key = (str(dev), n, t, b, h)
         gw = _GRANULE_WS.get(key)
         if gw is None:
-            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (nlayers + 3 * (nlayers - 1)), dtype=torch.int32, device=dev), 0]
+            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (2 * nlayers + 3 * (nlayers - 1)), dtype=torch.int32, device=dev), 0]
         ws = _gru_err_flag(dev)
 
         def launch(tag=f'{nch}x{nlayers} B{b} H{h} T{t}'):
@@ -865,7 +872,7 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
         key = (str(dev), 'bwd', n, t, b, h)
         gw = _GRANULE_WS.get(key)
         if gw is None:
-            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (2 * nlayers - 1), dtype=torch.int32, device=dev), 0]
+            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (3 * nlayers - 1), dtype=torch.int32, device=dev), 0]
         ws = _gru_err_flag(dev)
 
         def launch(tag=f'{nch}x{nlayers} B{b} H{h} T{t}'):

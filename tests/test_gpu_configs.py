@@ -1026,9 +1026,12 @@ def test_c3_conv_launches_in_situ(precision):
                 dw = torch.nn.grad.conv1d_weight(ap, w.shape, gr)
                 dz = torch.nn.grad.conv1d_input(ap.shape, wr, gr)[:, :, lo:ap.shape[2] - hi]
             assert err(f'{lname} dW', grads[lname + '.conv.weight'], dw) < 1e-4, (lname, worst)
-            db = gr.sum([0] + list(range(2, gr.dim())))
-            if db.abs().max() > 1e-6 * gr.abs().sum() / gr.shape[1]:     # (a bias in front of a norm: zero + noise)
-                assert err(f'{lname} db', grads[lname + '.conv.bias'], db) < 1e-4, (lname, worst)
+            # bias gradient: in front of a norm it is a sum that cancels to (almost) nothing - measured against the sum of the
+            # magnitudes it is made of (fp32 accumulation of ~1e5 terms), not against its own size
+            red_g = [0] + list(range(2, gr.dim()))
+            e_db = (grads[lname + '.conv.bias'].cpu().double() - gr.sum(red_g)).abs().max().item() / gr.abs().sum(red_g).max().item()
+            worst[f'{lname} db (/ sum |dY|)'] = e_db
+            assert e_db < 1e-5, (lname, e_db)
             prev = layers[j - 1][1] if j > 0 else None
             dx_hip = g_out.get(prev) if prev is not None else g_in.get(conv_l)
             if st is None:

@@ -135,16 +135,42 @@ CONV_CASES = [
 ]
 
 
-def _conv_ref(x, w, bias, scale, shift, seq, k, pool):
-    """CPU reference of one layer: [BN-apply -> ReLU -> mask] -> pad -> conv -> pool."""
+def _rbf(v):
+    """Round to the nearest bf16 (ties to even) as the kernels do to an fp32 operand; float64 out."""
+    return v.float().to(torch.bfloat16).double()
+
+
+class _RoundedConv(torch.autograd.Function):
+    """The bf16 mode of one conv launch restated (oracle/bf16emu.py::_ConvBf16 for a test-local reference): forward from
+    rounded operands, each backward product from ITS rounded operands."""
+
+    @staticmethod
+    def forward(ctx, a, w, bias):
+        ar, wr = _rbf(a), _rbf(w)
+        ctx.save_for_backward(ar, wr)
+        return F.conv2d(ar, wr, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        ar, wr = ctx.saved_tensors
+        gr = _rbf(gy)
+        return torch.nn.grad.conv2d_input(ar.shape, wr, gr), torch.nn.grad.conv2d_weight(ar, wr.shape, gr), gr.sum((0, 2, 3))
+
+
+def _conv_ref(x, w, bias, scale, shift, seq, k, pool, rounded=False):
+    """CPU reference of one layer: [BN-apply -> ReLU -> mask] -> pad -> conv -> pool.  ``rounded``: the bf16 mode - operands
+    of every product rounded to bf16 where the kernels round them (the activation is formed in fp32 first, as fmaf does)."""
     a = x
     if scale is not None:
-        a = F.relu(x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+        a = x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        if rounded:
+            a = a + (a.detach().float().double() - a.detach())          # the value the kernel holds before it rounds to bf16
+        a = F.relu(a)
         m = (torch.arange(x.shape[-1])[None] < torch.as_tensor(seq)[:, None]).to(x.dtype)
         a = a * m[:, None, None, :]
     ph, pw = k[0] - 1, k[1] - 1
     a = F.pad(a, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
-    y = F.conv2d(a, w, bias)
+    y = _RoundedConv.apply(a, w, bias) if rounded else F.conv2d(a, w, bias)
     if pool:
         y, idx = F.max_pool2d(y, (2, 1), return_indices=True)
     return y
@@ -486,6 +512,18 @@ def test_conv_bf16_mfma_vs_torch(case, precision):
     if not pro and not pool:
         g, _ = ops.conv_bwd_data(dx(gy), pc, pc.dgrad(precision), xd.shape, None, None, precision=precision)
         close(g, xr.grad, name=f'conv_dgrad {precision}', **tol)
+    if precision == 'bf16':
+        # THE bf16 gate: against the same layer from operands rounded to bf16 where the kernel rounds them - what is left is
+        # fp32 accumulation order (the comparison above only bounds the inherent effect of the rounding, 4e-2)
+        x32 = x.float().double()                      # the kernel's inputs are these fp32 values
+        xq = x32.clone().requires_grad_()
+        w32 = w.float().double()
+        y_q = _conv_ref(xq, w32, bias.float().double(), None if scale is None else scale.float().double(),
+                        None if shift is None else shift.float().double(), seq, k, pool, rounded=True)
+        close(y, y_q, name='conv_fwd bf16 vs rounded operands', atol=2e-5, rtol=2e-5)
+        if not pro and not pool:
+            y_q.backward(gy.float().double())
+            close(g, xq.grad, name='conv_dgrad bf16 vs rounded operands', atol=2e-5, rtol=2e-5)
 
 
 WGRAD_BF16_CASES = [
@@ -545,6 +583,15 @@ def test_conv_wgrad_bf16_vs_torch(case):
     l2 = ((out['bf16'][0].cpu().double() - w.grad).norm() / w.grad.norm()).item()
     assert l2 < 6e-3, l2
     close(out['bf16'][1], bias.grad, atol=.25, rtol=2e-2, name='conv_bgrad bf16')      # sums of bf16-rounded dY
+    # THE bf16 gate: rounded-operand restatement (R(dY) x R(relu(fma(x)) mask), bias gradient = sum R(dY))
+    x32, wq = x.float().double(), w.detach().float().double().requires_grad_()
+    bq = bias.detach().float().double().requires_grad_()
+    yq = _conv_ref(x32, wq, bq, None if scale is None else scale.float().double(), None if shift is None else shift.float().double(),
+                   seq, k, False, rounded=True)
+    yq.backward(g_full.float().double())
+    errq = (out['bf16'][0].cpu().double() - wq.grad).abs().max().item() / wq.grad.abs().max().item()
+    assert errq < 5e-5, errq
+    close(out['bf16'][1], bq.grad, atol=2e-4, rtol=2e-5, name='conv_bgrad bf16 vs rounded operands')
 
 
 @pytest.mark.parametrize('precision', ['f32', 'bf16'])
@@ -574,6 +621,9 @@ def test_gru_wgrad_vs_torch(t, b, g, k, precision):
             xs[:-1] = x[i][1:]
         ref = dw0[i].double() + torch.einsum('tbg,tbk->gk', dg[i].double(), xs)
         close(dw[i], ref.float(), atol=tol * (t * b) ** .5, rtol=1e-5, name=f'gru_wgrad dW shift {sh}')
+        if precision == 'bf16':                        # THE bf16 gate: both operands rounded to bf16, fp32 accumulation
+            refq = dw0[i].double() + torch.einsum('tbg,tbk->gk', _rbf(dg[i]), _rbf(xs))
+            close(dw[i], refq.float(), atol=2e-5 * (t * b) ** .5, rtol=1e-5, name=f'gru_wgrad dW shift {sh} vs rounded operands')
         if db[i] is not None:
             close(db[i], (db0[i].double() + dg[i].double().sum((0, 1))).float(), atol=2e-5 * (t * b) ** .5, rtol=1e-5,
                   name=f'gru_wgrad db shift {sh}')
@@ -594,6 +644,9 @@ def test_tm_gemm_vs_torch(t, b, n, ks, precision):
     out = ops.tm_gemm([x.to(DEV) for x in xs], [w.to(DEV) for w in ws], bias.to(DEV), precision=precision)
     scale = sum(ks) ** .5 * .2
     close(out, ref.float(), atol=(3e-6 if precision == 'f32' else 4e-2) * scale, rtol=1e-5, name=f'tm_gemm {precision}')
+    if precision == 'bf16':                            # THE bf16 gate: rounded operands, fp32 accumulation
+        refq = bias.double() + sum(_rbf(x) @ _rbf(w).T for x, w in zip(xs, ws))
+        close(out, refq.float(), atol=3e-6 * scale, rtol=1e-5, name='tm_gemm bf16 vs rounded operands')
     out0 = ops.tm_gemm([xs[0].to(DEV)], [ws[0].to(DEV)], None, precision=precision)
     close(out0, (xs[0].double() @ ws[0].double().T).float(), atol=(3e-6 if precision == 'f32' else 4e-2) * ks[0] ** .5 * .2, rtol=1e-5,
           name='tm_gemm without bias')
@@ -807,6 +860,36 @@ def test_gru_scans_with_bf16_operands_stay_close_to_the_fp32_scans(b, h, t, nl):
         for a, r in zip(out['bf16'][k], out['f32'][k]):
             assert ((a - r).norm() / r.norm().clamp_min(1e-6)).item() < 5e-2
     assert (out['bf16'][0][0] - out['f32'][0][0]).abs().max().item() > 0      # it is the other kernel
+    # THE bf16 gate: the bf16-operand oracle scan (oracle/bf16emu.py: bf16(h_{t-1}) bf16(W_hh)^T in the recurrence, the layer
+    # boundary projection and every BPTT product from ITS rounded operands) in float64 on the same inputs.  A rounding of h
+    # that falls the other way (fp32 vs float64 pre-rounding values) perturbs later steps - the recurrence is contractive, so
+    # the states agree to ~1e-4 where the fp32 scans are 3e-2 away.
+    if t <= 130:
+        from oracle import bf16emu
+        seq_c = seq.cpu().numpy()
+        for c in range(nch):
+            rev = bool(c)
+            x_in = gi0[c].cpu().double().transpose(0, 1)          # [B,T,3H] = W_ih x + b_ih of layer 0
+            m = (torch.arange(t)[None] < torch.as_tensor(seq_c)[:, None]).double()
+            from oracle.nn import reverse_sequence
+            leaves, y = [], None
+            gi = (reverse_sequence(x_in, seq_c) if rev else x_in).clone().requires_grad_()
+            leaves.append(gi)
+            cur = gi
+            for l in range(nl):
+                i = c * nl + l
+                if l:
+                    cur = bf16emu._LinearBf16.apply(y, w_ih[i].cpu().double()) + b_ih[i].cpu().double()
+                y = bf16emu._scan(cur, w_hh[i].cpu().double(), b_hh[i].cpu().double(), m)
+            y_out = reverse_sequence(y, seq_c) if rev else y
+            got = out['bf16'][0][c * nl + nl - 1].cpu().double().transpose(0, 1)
+            e = (got - y_out.detach()).abs().max().item()
+            assert e < 1e-3, (c, e)
+            (y_out * dy[c].cpu().double().transpose(0, 1)).sum().backward()
+            dgi_ref = reverse_sequence(gi.grad, seq_c) if rev else gi.grad          # gradient wrt layer 0's projected input
+            dgi_hip = out['bf16'][1][c * nl].cpu().double().transpose(0, 1)
+            eg = ((dgi_hip - dgi_ref).norm() / dgi_ref.norm()).item()
+            assert eg < 5e-3, (c, eg)
 
 
 def test_weight_gradients_on_two_streams_with_caller_owned_scratch():

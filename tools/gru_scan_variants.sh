@@ -3,7 +3,7 @@
 # Usage (GPU box): tools/gru_scan_variants.sh [shape] > gpurun_out/gru_variants.txt
 shape=${1:-c2}
 cd "$(dirname "$0")/.."
-run() { echo "=== $*"; env "$@" python tools/gru_scan_prof.py --shape $shape $EXTRA 2>&1 | grep -v Warning; }
-run PBSED_GRU_FAST_GATES=0
-run PBSED_GRU_FAST_GATES=1
-EXTRA=--no-prof run PBSED_GRU_FAST_GATES=1 PBSED_GRU_AUTOTUNE=0
+run() { echo "=== $*"; env "$@" python tools/gru_scan_prof.py --shape $shape $EXTRA 2>&1 | grep -v "Warning\|amdgpu.ids"; }
+run PBSED_GRU_LOCAL=0
+run PBSED_GRU_LOCAL=1
+EXTRA=--no-prof run PBSED_GRU_LOCAL=1 PBSED_GRU_FAST_GATES=0
