@@ -43,6 +43,7 @@ struct GruStackArgs {
     int poll_delay, poll_delay_gate;   // granule kernels: first-poll delays (PollPacer) of the non-gate / gate waves
     int ring_xcd, nby;    // granule kernels: ring_xcd = H/16 > 0 selects the 1-D XCD-aware role mapping (granule_role)
     unsigned* gran_loc;   // granule scans: the rings' XCD-local copy of the exchanged states (see poll_batch); null = off
+    int dbg;              // diagnostics (PBSED_GRU_DBG): bit 0 = the scans skip their output stores (timing experiments only)
     int fast_gates;       // granule forward scan: gate activations from v_exp_f32 / v_rcp_f32 (gate_sigmoid / gate_tanh)
     unsigned long long* prof;   // diagnostics (pbsed_gru_set_prof): shader-clock stamps of block `prof_block`, steps 200..231
     int prof_block;
@@ -284,6 +285,10 @@ static void launch_stack(bool bwd, GruStackArgs& a, dim3 grid, hipStream_t s) {
 
 typedef unsigned int __attribute__((address_space(1))) gu32;
 
+// Partial sums of one (wave, gate) in LDS: the accumulator fragment (64 lanes x 4 registers) with its four lane groups 80 floats
+// apart instead of 64 (see gru_granule_fwd_body): writer lane (lq, lr) -> lq * 80 + lr * 4, gate thread (bb, u) -> its element.
+constexpr int RED_ROW = 4 * 80;
+
 // ============================================================================================
 // Persistent scans ("granules"): the exchanged values ARE the flags.  Every h value is published as one 4-byte word
 // - the fp32 value with its mantissa LSB replaced by the call's parity bit - with a single write-through (sc1) store
@@ -315,7 +320,7 @@ struct PollPacer {
 
 // One wave polls the words of its K range [k0, k0 + 16*NL) for 16 batch rows with 16-byte write-through-visible
 // (sc1) buffer loads: lane (lq, lr) reads, per load n, the four words k0 + n*16 + lq*4 + {0..3} of row lr.  The exchange
-// arrays are TILE-MAJOR - [T][batch tile][H/16 producers][4 unit groups][16 rows][4 units] - so one load instruction covers exactly the
+// arrays are TILE-MAJOR - [T][batch tile][H/16 producers][16 rows][16 units] - so one load instruction covers exactly the
 // contiguous 1 KB tile one producer block published (8 whole 128-byte lines instead of 16 half lines of a row-major
 // [T][B][H] array) and a producer's 256 publishing threads write one contiguous 1 KB; nothing is fetched twice.  All loads of a step are issued
 // before any tag is looked at (one fabric round trip per step); out[n] = the four (tag-cleared) values.
@@ -495,7 +500,7 @@ __device__ __forceinline__ int poll_tiles(float4 (&out)[NB][NL], __amdgpu_buffer
 
 template <int KB, int NW, bool GW, int XS = 0, int NB = 1>
 __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsigned* gran_h_, unsigned* gran_gi_, unsigned epoch,
-                                                     unsigned* err_flag, float (&red)[2][NW][NB][3][64][4], int& s_err) {
+                                                     unsigned* err_flag, float (&red)[2][NW][NB][3][RED_ROW], int& s_err) {
     constexpr int H = KB * NW * 16, NL = KB;           // NL: 16-byte loads per lane (16 k each) of this wave's H/NW range
     constexpr int GWV = GW ? 4 : 0;
     const GranuleRole role = granule_role(a);
@@ -519,12 +524,13 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
         __builtin_amdgcn_make_buffer_rsrc(a.gran_loc ? a.gran_loc : gran_h_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 4), 0x00020000);
     gu32* g_loc = a.gran_loc ? (gu32*)a.gran_loc + (g_own - (gu32*)gran_h_) : nullptr;
     gu32* g_gi = (gu32*)gran_gi_ + (size_t)(chain * (a.nlayers - 1) + (layer > 0 ? layer - 1 : 0)) * per_cl_b * 3;  // [T][B][3][H]
-    // gate thread -> (unit, batch row): thread tid owns the accumulator element (lane tid >> 2, register tid & 3) of the MFMA D
-    // layout, i.e. the partial sums it adds are the consecutive floats red[..][tid] (conflict-free LDS reads; the row-major
-    // mapping read them at a 256-byte stride: 4-way bank conflicts, 1 000 of a step's 6 100 clocks), and a producer's 1 KB
-    // exchange tile is [unit / 4][batch row][unit % 4] = that same order: thread tid publishes word tid, a consumer lane
-    // (lq, lr) reads the 16 bytes at word lq * 64 + lr * 4 = byte lane * 16 (one contiguous 1 KB per load instruction)
-    const int u = ((tid >> 6) & 3) * 4 + (tid & 3), bb = (tid >> 2) & 15, j = j0 + u;
+    // gate thread -> (batch row, unit) row-major: a wave's global stores / loads are whole 64-byte row segments and a producer's
+    // 1 KB exchange tile is [16 rows][16 units].  The partial sums a gate thread adds sit in the MFMA D layout (lane (u >> 2) *
+    // 16 + bb, register u & 3): with the accumulators stored lane after lane those reads hit 16 banks four times each (1 000 of a
+    // step's 6 100 clocks in the shader-clock profile), so the four lane groups of a fragment are 80 floats apart (RED_POS):
+    // bank = (u >> 2) * 16 + (bb & 3) * 4 + (u & 3), all 64 different.
+    const int u = tid & 15, bb = (tid >> 4) & 15, j = j0 + u;
+    const int red_w = lq * 80 + lr * 4, red_r = (u >> 2) * 80 + bb * 4 + (u & 3);
     int b[NB], sl[NB];
     bool bv[NB], rowv[NB];
 #pragma unroll
@@ -563,7 +569,7 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
     }
     // a projection reads h_t of the layer below, a ring its own h_{t-1}
     const unsigned cl_src = chain * a.nlayers + (is_proj ? layer - 1 : layer);
-    const unsigned voff0 = (unsigned)(((size_t)cl_src * per_cl + (size_t)role.by * NB * 16 * H + (k0 / 16) * 256 + lq * 64 + lr * 4) * 4);
+    const unsigned voff0 = (unsigned)(((size_t)cl_src * per_cl + (size_t)role.by * NB * 16 * H + (k0 / 16) * 256 + lr * 16 + lq * 4) * 4);
     const unsigned step_t = (unsigned)(Bp * H * 4);           // bytes per time step of one (chain, layer)
     constexpr unsigned tile_bytes = 16u * H * 4u;            // one batch tile of one step
     float h_reg[NB];
@@ -660,9 +666,9 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    red[par][wave][nb][0][lane][r] = acc[nb][0][r];
-                    red[par][wave][nb][1][lane][r] = acc[nb][1][r];
-                    red[par][wave][nb][2][lane][r] = acc[nb][2][r];
+                    red[par][wave][nb][0][red_w + r] = acc[nb][0][r];
+                    red[par][wave][nb][1][red_w + r] = acc[nb][1][r];
+                    red[par][wave][nb][2][red_w + r] = acc[nb][2][r];
                 }
         }
         if (prof_now && prof_c) prof_stamp(pslot + 3);
@@ -678,13 +684,12 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
         for (int nb = 0; nb < NB; ++nb) {
             if (!bv[nb]) continue;
             const size_t tb = (size_t)t * B + b[nb];
-            const int src = (tid >> 2) & 63, reg = tid & 3;
             float s[3] = {bs_r, bs_z, bs_n};
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                s[0] += red[par][w][nb][0][src][reg];
-                s[1] += red[par][w][nb][1][src][reg];
-                s[2] += red[par][w][nb][2][src][reg];
+                s[0] += red[par][w][nb][0][red_r];
+                s[1] += red[par][w][nb][1][red_r];
+                s[2] += red[par][w][nb][2][red_r];
             }
             if (is_proj) {
                 gu32* dst = g_gi + tb * 3 * H + j;
@@ -708,6 +713,7 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
                 if (g_loc) __hip_atomic_store(g_loc + own_off, __float_as_uint(h) | parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 publish(g_own + own_off, h, parity);
                 if (prof_now && prof_g && nb == 0) prof_stamp(pslot + 11);
+                if (a.dbg & 1) continue;
                 L.hs[tb * H + j] = h;
                 if (L.save) {
                     // what BPTT multiplies dh_t with: d(r,z,n pre-activations)/dh, d(gh_n)/dh and z (granule save format)
@@ -727,7 +733,7 @@ template <int KB, int NW>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gru_granule_fwd_kernel(GruStackArgs a, unsigned* gran_h_,
                                                                  unsigned* gran_gi_, unsigned epoch,
                                                                  unsigned* err_flag) {
-    __shared__ float red[2][NW][1][3][64][4];
+    __shared__ float red[2][NW][1][3][RED_ROW];
     __shared__ int s_err;
     gru_granule_fwd_body<KB, NW, false>(a, gran_h_, gran_gi_, epoch, err_flag, red, s_err);
 }
@@ -735,9 +741,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 template <int KB, int NW, int XS, int NB>
 __global__ __launch_bounds__((NW + 4) * 64) void gru_granule_fwd_gw_kernel(GruStackArgs a, unsigned* gran_h_, unsigned* gran_gi_,
                                                                          unsigned epoch, unsigned* err_flag) {
-    extern __shared__ __attribute__((aligned(16))) float red_dyn[];          // [2][NW][NB][3][64][4]: over 64 KB for NB = 2
+    extern __shared__ __attribute__((aligned(16))) float red_dyn[];          // [2][NW][NB][3][RED_ROW]: over 64 KB for NB = 2
     __shared__ int s_err;
-    auto& red = *reinterpret_cast<float (*)[2][NW][NB][3][64][4]>(red_dyn);
+    auto& red = *reinterpret_cast<float (*)[2][NW][NB][3][RED_ROW]>(red_dyn);
     gru_granule_fwd_body<KB, NW, true, XS, NB>(a, gran_h_, gran_gi_, epoch, err_flag, red, s_err);
 }
 
@@ -747,7 +753,7 @@ __global__ __launch_bounds__((NW + 4) * 64) void gru_granule_fwd_gw_kernel(GruSt
 // below (granules [T][B][H] as well); dh*z of a thread's own unit stays in a register.  Scan order = top layer first.
 template <int KB, int NW, bool GW, int XS = 0>
 __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsigned* gran_dh_, unsigned* gran_dy_, unsigned epoch,
-                                                     unsigned* err_flag, float (&red)[2][NW][64][4], int& s_err) {
+                                                     unsigned* err_flag, float (&red)[2][NW][RED_ROW], int& s_err) {
     constexpr int H = KB * NW * 16, G = 3 * H, NL = KB;     // NL: 16-byte loads per lane (16 units each)
     constexpr int GWV = GW ? 4 : 0;                         // dedicated gate waves in front (see gru_granule_fwd_body)
     const GranuleRole role = granule_role(a);
@@ -770,7 +776,8 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         __builtin_amdgcn_make_buffer_rsrc(a.gran_loc ? a.gran_loc : gran_dh_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 4), 0x00020000);
     gu32* g_loc = a.gran_loc ? (gu32*)a.gran_loc + (g_own - (gu32*)gran_dh_) : nullptr;
     gu32* g_dy = (gu32*)gran_dy_ + (size_t)(chain * (a.nlayers - 1) + (layer < top ? layer : 0)) * per_cl_b;
-    const int u = ((tid >> 6) & 3) * 4 + (tid & 3), bb = (tid >> 2) & 15, b = b0 + bb, j = j0 + u;     // see gru_granule_fwd_body
+    const int u = tid & 15, bb = (tid >> 4) & 15, b = b0 + bb, j = j0 + u;     // see gru_granule_fwd_body
+    const int red_w = lq * 80 + lr * 4, red_r = (u >> 2) * 80 + bb * 4 + (u & 3);
     const bool bv = tid < 256 && b < B;
     const bool rowv = (b0 + lr) < B;
     const int sl = bv ? a.seq_len[b] : 0;
@@ -799,7 +806,7 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         }
     }
     const unsigned cl_src = chain * a.nlayers + (is_proj ? layer + 1 : layer);
-    const unsigned voff0 = (unsigned)(((size_t)cl_src * per_cl + (size_t)role.by * 16 * H + (k0 / 16) * 256 + lq * 64 + lr * 4) * 4);
+    const unsigned voff0 = (unsigned)(((size_t)cl_src * per_cl + (size_t)role.by * 16 * H + (k0 / 16) * 256 + lr * 16 + lq * 4) * 4);
     const unsigned step_t = (unsigned)(Bp * H * 4);
     float dhz_prev = 0.f;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -906,7 +913,7 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         if (bstep + 1 < a.T) load_operands(bstep + 1);
         if (is_mfma) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) red[par][wave][lane][q] = acc[0][q] + acc[1][q] + acc[2][q];
+            for (int q = 0; q < 4; ++q) red[par][wave][red_w + q] = acc[0][q] + acc[1][q] + acc[2][q];
         }
         if (prof_now && prof_c) prof_stamp(pslot + 3);
         __syncthreads();
@@ -915,10 +922,9 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         const int err_seen = s_err;                    // acted on behind the publish (see gru_granule_fwd_body)
         if (tid >= 256 && err_seen) return;
         if (bv) {
-            const int src = (tid >> 2) & 63, reg = tid & 3;
             float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) sum += red[par][w][src][reg];
+            for (int w = 0; w < NW; ++w) sum += red[par][w][red_r];
             if (prof_now && prof_g) prof_stamp(pslot + 10);
             if (is_proj) {
                 publish(g_dy + tb * H + j, tag_clear(sum), parity);
@@ -938,6 +944,7 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
                 if (g_loc) __hip_atomic_store(g_loc + own_off, __float_as_uint(dh) | parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 publish(g_own + own_off, dh, parity);
                 if (prof_now && prof_g) prof_stamp(pslot + 11);
+                if (a.dbg & 1) continue;
                 float* dgi = L.dgi + tb * G;
                 float* dgh = L.dgh + tb * G;
                 dgi[j] = dr; dgi[H + j] = dz; dgi[2 * H + j] = dn;
@@ -953,7 +960,7 @@ template <int KB, int NW>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gru_granule_bwd_kernel(GruStackArgs a, unsigned* gran_dh_,
                                                                  unsigned* gran_dy_, unsigned epoch,
                                                                  unsigned* err_flag) {
-    __shared__ float red[2][NW][64][4];
+    __shared__ float red[2][NW][RED_ROW];
     __shared__ int s_err;
     gru_granule_bwd_body<KB, NW, false>(a, gran_dh_, gran_dy_, epoch, err_flag, red, s_err);
 }
@@ -961,7 +968,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 template <int KB, int NW, int XS>
 __global__ __launch_bounds__((NW + 4) * 64) void gru_granule_bwd_gw_kernel(GruStackArgs a, unsigned* gran_dh_, unsigned* gran_dy_,
                                                                          unsigned epoch, unsigned* err_flag) {
-    __shared__ float red[2][NW][64][4];
+    __shared__ float red[2][NW][RED_ROW];
     __shared__ int s_err;
     gru_granule_bwd_body<KB, NW, true, XS>(a, gran_dh_, gran_dy_, epoch, err_flag, red, s_err);
 }
@@ -1058,6 +1065,11 @@ static int* granule_delay_table(int kind) {
 }
 
 static int granule_capacity(bool bwd, int H, int bf16, int nb);       // co-resident blocks of the scan kernel (below)
+// bf16 / bf16x3 operands for H = 512 too (KB = 4: the W fragments take 72 registers as three-way splits): bit 0 forward, bit 1 BPTT
+static int granule_x3_h512() {
+    static const int v = [] { const char* e = getenv("PBSED_GRU_X3_H512"); return e ? atoi(e) : 0; }();
+    return v;
+}
 
 // diagnostics (pbsed_gru_set_prof) and the gate-activation form of the forward scan (PBSED_GRU_FAST_GATES, default on)
 static unsigned long long* g_prof_buf = nullptr;
@@ -1065,6 +1077,8 @@ static int g_prof_block = 0;
 static void granule_common(GruStackArgs& a, unsigned* loc) {
     static const int fast = [] { const char* e = getenv("PBSED_GRU_FAST_GATES"); return e ? atoi(e) : 1; }();
     a.fast_gates = fast;
+    static const int dbg = [] { const char* e = getenv("PBSED_GRU_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
     // PBSED_GRU_LOCAL=0: the rings poll the write-through array only (the form of rounds 1 - 3)
     static const int local = [] { const char* e = getenv("PBSED_GRU_LOCAL"); return e ? atoi(e) : 1; }();
     a.gran_loc = local ? loc : nullptr;
@@ -1151,15 +1165,15 @@ static int gru_stack_fwd_granule_impl(int nchains, int nlayers, const float* con
 #define LAUNCH_GW(KB_, NW_, X3_, NB_)                                                                                  \
     do {                                                                                                             \
         auto kern = gru_granule_fwd_gw_kernel<KB_, NW_, X3_, NB_>;                                                   \
-        const size_t lds = (size_t)2 * NW_ * NB_ * 3 * 64 * 4 * sizeof(float);                                       \
+        const size_t lds = (size_t)2 * NW_ * NB_ * 3 * RED_ROW * sizeof(float);                                       \
         PBSED_DYN_LDS_ONCE(kern, lds);                                                                               \
         hipLaunchKernelGGL(kern, grid, dim3((NW_ + 4) * 64), lds, s, a, granules, gran_gi, epoch, err_flag);         \
     } while (0)
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
     do {                                                                                                             \
         if ((gw & 1) && nb == 2) {                                                                                   \
-            if (bf16 && KB_ < 4) LAUNCH_GW(KB_, NW_, 1, 2);                                                          \
-            else if ((x3 & 1) && KB_ < 4) LAUNCH_GW(KB_, NW_, 3, 2);                                                 \
+            if (bf16 && (KB_ < 4 || (granule_x3_h512() & 1))) LAUNCH_GW(KB_, NW_, 1, 2);                                                          \
+            else if ((x3 & 1) && (KB_ < 4 || (granule_x3_h512() & 1))) LAUNCH_GW(KB_, NW_, 3, 2);                                                 \
             else LAUNCH_GW(KB_, NW_, 0, 2);                                                                          \
         } else if (gw & 1) {                                                                                         \
             if (bf16) LAUNCH_GW(KB_, NW_, 1, 1); else if (x3 & 1) LAUNCH_GW(KB_, NW_, 3, 1); else LAUNCH_GW(KB_, NW_, 0, 1);  \
@@ -1224,10 +1238,10 @@ static int gru_stack_bwd_granule_impl(int nchains, int nlayers, const float* con
     static const int x3 = [] { const char* e = getenv("PBSED_GRU_X3"); return e ? atoi(e) : 3; }();     // bit 1 = BPTT scan
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
     do {                                                                                                             \
-        if ((gw & 2) && bf16 && KB_ < 4) {                                                                           \
+        if ((gw & 2) && bf16 && (KB_ < 4 || (granule_x3_h512() & 2))) {                                                                           \
             hipLaunchKernelGGL((gru_granule_bwd_gw_kernel<KB_, NW_, 1>), grid, dim3((NW_ + 4) * 64), 0, s, a,         \
                                granules, gran_dy, epoch, err_flag);                                                  \
-        } else if ((gw & 2) && (x3 & 2) && KB_ < 4) {                                                                \
+        } else if ((gw & 2) && (x3 & 2) && (KB_ < 4 || (granule_x3_h512() & 2))) {                                                                \
             hipLaunchKernelGGL((gru_granule_bwd_gw_kernel<KB_, NW_, 3>), grid, dim3((NW_ + 4) * 64), 0, s, a,         \
                                granules, gran_dy, epoch, err_flag);                                                  \
         } else if (gw & 2) {                                                                                         \
@@ -1272,11 +1286,11 @@ static int granule_capacity(bool bwd, int H, int bf16, int nb) {
 #define CAP_FWD(KB_, NW_)                                                                                                          \
     do {                                                                                                                           \
         static int c0[64], c1[64], c2[64], c3[64];                                                                                 \
-        const size_t lds = (size_t)2 * NW_ * nb * 3 * 64 * 4 * sizeof(float);                                                      \
+        const size_t lds = (size_t)2 * NW_ * nb * 3 * RED_ROW * sizeof(float);                                                      \
         if (!(gw & 1)) return resident_blocks(gru_granule_fwd_kernel<KB_, NW_>, NW_ * 64, 0, c0);                                  \
         if (nb == 2) {                                                                                                             \
-            if (bf16 && KB_ < 4) return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 1, 2>, (NW_ + 4) * 64, lds, c1);       \
-            if ((x3 & 1) && KB_ < 4) return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 3, 2>, (NW_ + 4) * 64, lds, c2);   \
+            if (bf16 && (KB_ < 4 || (granule_x3_h512() & 1))) return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 1, 2>, (NW_ + 4) * 64, lds, c1);       \
+            if ((x3 & 1) && (KB_ < 4 || (granule_x3_h512() & 1))) return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 3, 2>, (NW_ + 4) * 64, lds, c2);   \
             return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 0, 2>, (NW_ + 4) * 64, lds, c3);                            \
         }                                                                                                                          \
         if (bf16) return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 1, 1>, (NW_ + 4) * 64, lds, c1);                      \
@@ -1287,8 +1301,8 @@ static int granule_capacity(bool bwd, int H, int bf16, int nb) {
     do {                                                                                                                           \
         static int c0[64], c1[64], c2[64], c3[64];                                                                                 \
         if (!(gw & 2)) return resident_blocks(gru_granule_bwd_kernel<KB_, NW_>, NW_ * 64, 0, c0);                                  \
-        if (bf16 && KB_ < 4) return resident_blocks(gru_granule_bwd_gw_kernel<KB_, NW_, 1>, (NW_ + 4) * 64, 0, c1);                \
-        if ((x3 & 2) && KB_ < 4) return resident_blocks(gru_granule_bwd_gw_kernel<KB_, NW_, 3>, (NW_ + 4) * 64, 0, c2);            \
+        if (bf16 && (KB_ < 4 || (granule_x3_h512() & 2))) return resident_blocks(gru_granule_bwd_gw_kernel<KB_, NW_, 1>, (NW_ + 4) * 64, 0, c1);                \
+        if ((x3 & 2) && (KB_ < 4 || (granule_x3_h512() & 2))) return resident_blocks(gru_granule_bwd_gw_kernel<KB_, NW_, 3>, (NW_ + 4) * 64, 0, c2);            \
         return resident_blocks(gru_granule_bwd_gw_kernel<KB_, NW_, 0>, (NW_ + 4) * 64, 0, c3);                                     \
     } while (0)
     if (!bwd) {

@@ -6,4 +6,7 @@ cd "$(dirname "$0")/.."
 run() { echo "=== $*"; env "$@" python tools/gru_scan_prof.py --shape $shape $EXTRA 2>&1 | grep -v "Warning\|amdgpu.ids"; }
 run PBSED_GRU_LOCAL=0
 run PBSED_GRU_LOCAL=1
-EXTRA=--no-prof run PBSED_GRU_LOCAL=1 PBSED_GRU_FAST_GATES=0
+run PBSED_GRU_LOCAL=0 PBSED_GRU_DBG=1
+run PBSED_GRU_LOCAL=1 PBSED_GRU_DBG=1
+EXTRA=--no-prof run PBSED_GRU_LOCAL=0
+EXTRA=--no-prof run PBSED_GRU_LOCAL=1
