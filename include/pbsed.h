@@ -269,8 +269,7 @@ int pbsed_gru_set_prof(unsigned long long* buf, int block);
 /* Persistent forward scan (one launch for the whole scan; needs nchains*(2*nlayers-1)*(H/16)*ceil(B/16) <= #CUs
  * co-resident workgroups) exchanging h_t (and the projected inputs of layers > 0) between workgroups as 4-byte words
  * = the fp32 value with its mantissa LSB replaced by the call's parity bit (the exchanged quantity is defined as the
- * truncated value).  granules: device uint32 workspace of nchains*T*Bp*H*(2*nlayers + 3*(nlayers-1)) words (the last nchains*nlayers*T*Bp*H: the
- * rings' XCD-local copy of the states, plain stores / plain first looks inside an XCD; Bp = B rounded up to 16:
+ * truncated value).  granules: device uint32 workspace of nchains*T*Bp*H*(nlayers + 3*(nlayers-1)) words (Bp = B rounded up to 16:
  * the exchanged states are stored as [T][batch tile][H/16][16 rows][16 units] tiles), ZERO before
  * its first use; epoch: odd on the first use of a workspace, parity flipped on every further call with it.
  * err_flag: device uint32, non-zero afterwards if a hand-off timed out (re-zero the workspace then).
@@ -285,8 +284,7 @@ int pbsed_gru_stack_bwd(int nchains, int nlayers, const float* const* w_hh_t, co
                         float* const* dgi, float* const* dgh, float* const* dhz, const int* reverse /*host*/,
                         const int* seq_len, int B, int H, int T, void* stream);
 /* Persistent BPTT exchanging dh_t / dy_t the same way (gate gradients are rebuilt by the consumer from the factors
- * the granule forward scan saved).  granules: device uint32 workspace of nchains*T*Bp*H*(3*nlayers-1) words
- * (dh_t, dy_t, the rings' XCD-local copy of dh_t). */
+ * the granule forward scan saved).  granules: device uint32 workspace of nchains*T*Bp*H*(2*nlayers-1) words. */
 int pbsed_gru_stack_bwd_granule(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
                                 const float* const* hs, const float* const* save, const float* const* dy_top,
                                 float* const* dgi, float* const* dgh, const int* reverse /*host*/, const int* seq_len,

@@ -13,7 +13,8 @@ forward: each rounds its own operands, which is what the kernels do and what thi
 
 * convolutions with >= 32 input channels (pb_sed_amd/engine.py::_prec; the 11- / 16-channel layers stay fp32):
   y = conv(bf16(relu(norm(x)) * mask), bf16(w)) + b;   dx = conv^T(bf16(dy), bf16(w));
-  dw = corr(bf16(dy), bf16(relu(norm(x)) * mask));   db = sum bf16(dy)   (the kernels' ones-vector MFMA)
+  dw = corr(bf16(dy), bf16(relu(norm(x)) * mask));   db = sum bf16(dy)   (the kernels' ones-vector MFMA; both from the
+  unrounded operands when the layer has fewer than 32 OUTPUT channels: the heads' class layers keep the fp32 kernels)
 * time-major projections of the GRUs (W_ih x + b_ih, all layers / directions): y = bf16(x) bf16(W)^T + b,
   dx = bf16(dy) bf16(W), dW = bf16(dy)^T bf16(x), db = sum dy
 * the recurrence: gh_t = bf16(h_{t-1}) bf16(W_hh)^T + b_hh;   BPTT: dh_{t-1} += bf16(d gh_t) bf16(W_hh)
@@ -44,22 +45,26 @@ class _ConvBf16(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         xr, wr = rbf(x), rbf(w)
-        ctx.save_for_backward(xr, wr)
+        # the weight gradient takes bf16 operands from 32 OUTPUT channels on as well (csrc/conv_wgrad.hip::conv_wgrad_launch:
+        # narrower layers - the 10-class output layers of the heads - keep the fp32 weight-gradient kernels)
+        ctx.wgrad_rounded = w.shape[0] >= MIN_CIN
+        ctx.save_for_backward(xr, wr, xr if ctx.wgrad_rounded else x)
         ctx.has_bias = b is not None
         conv = F.conv2d if w.dim() == 4 else F.conv1d
         return conv(xr, wr, b)
 
     @staticmethod
     def backward(ctx, dy):
-        xr, wr = ctx.saved_tensors
+        xr, wr, xw = ctx.saved_tensors
         dyr = rbf(dy)
+        dyw = dyr if ctx.wgrad_rounded else dy
         if wr.dim() == 4:
             dx = torch.nn.grad.conv2d_input(xr.shape, wr, dyr)
-            dw = torch.nn.grad.conv2d_weight(xr, wr.shape, dyr)
+            dw = torch.nn.grad.conv2d_weight(xw, wr.shape, dyw)
         else:
             dx = torch.nn.grad.conv1d_input(xr.shape, wr, dyr)
-            dw = torch.nn.grad.conv1d_weight(xr, wr.shape, dyr)
-        db = dyr.sum([0] + list(range(2, dyr.dim()))) if ctx.has_bias else None
+            dw = torch.nn.grad.conv1d_weight(xw, wr.shape, dyw)
+        db = dyw.sum([0] + list(range(2, dyw.dim()))) if ctx.has_bias else None
         return dx, dw, db
 
 

@@ -60,128 +60,6 @@ struct ConvBCfg {
     static_assert(TT16 % WN == 0 && (IN_HALFS % 8) == 0 && (W_HALFS % 8) == 0, "tile granularity");
 };
 
-template <int FT, int TT, int KH, int KW, int NSPLIT, bool POOL, bool DGRAD>
-__global__ __launch_bounds__(256) void conv_bf16_kernel(ConvFwdArgs a, const unsigned short* __restrict__ wpb) {
-    using C = ConvBCfg<FT, TT, KH, KW, NSPLIT, POOL>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned short* in_s = reinterpret_cast<unsigned short*>(smem_raw);            // [NSPLIT][ROWS][ROW][CKP]
-    unsigned short* w_s = in_s + C::IN_HALFS;                                       // [NSPLIT][KW][64][CKP]
-    float* st_s = reinterpret_cast<float*>(w_s + C::W_HALFS);                       // [64][FO_T][2]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / C::WN, wn = wave % C::WN;
-    const int lq = lane >> 4, lr = lane & 15;
-    const int nTt = (a.T + TT - 1) / TT, nFt = (a.F + FT - 1) / FT;
-    int bx = blockIdx.x;
-    const int t0 = (bx % nTt) * TT; bx /= nTt;
-    const int f0 = (bx % nFt) * FT;
-    const int b = bx / nFt;
-    const int cout0 = blockIdx.y * CB_COUT_T;
-    const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
-    const bool pro = a.scale != nullptr;
-    constexpr int PADH = (KH - 1) / 2, PADW = (KW - 1) / 2;
-    const bool unpool = DGRAD && a.unpool_idx != nullptr;
-    const int Fsrc = unpool ? a.F / 2 : a.F;
-    const int tlim = pro ? sl : a.T;
-
-    f32x4 acc[C::MTW][C::NTW];
-#pragma unroll
-    for (int m = 0; m < C::MTW; ++m)
-#pragma unroll
-        for (int n = 0; n < C::NTW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int c0 = 0; c0 < a.CinP; c0 += CB_CK) {
-        __syncthreads();                       // all MFMA reads of the previous chunk are done
-        // ---- stage the input halo tile for 32 channels: item = (octet, row, position), position fastest
-#pragma unroll
-        for (int i = 0; i < C::IN_PER_T; ++i) {
-            const int item = tid + i * 256;
-            if (item < C::IN_ITEMS) {
-                const int p = item % C::ROW, r = (item / C::ROW) % C::ROWS, oc = item / (C::ROW * C::ROWS);
-                const int f = f0 - PADH + r, t = t0 - C::HALO + p;
-                const bool pos_ok = f >= 0 && f < a.F && t >= 0 && t < tlim;
-                us8 o[NSPLIT];
-#pragma unroll
-                for (int s = 0; s < NSPLIT; ++s) o[s] = us8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (pos_ok) {
-                    const size_t off = ((size_t)(unpool ? (f >> 1) : f)) * a.T + t;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int cin = c0 + oc * 8 + e;
-                        float v = 0.f;
-                        if (cin < a.Cin) {
-                            const size_t o1 = (size_t)(b * a.Cin + cin) * Fsrc * a.T + off;
-                            v = a.x[o1];
-                            if (unpool) v = (a.unpool_idx[o1] == (uint8_t)(f & 1)) ? v : 0.f;
-                            if (pro) {
-                                v = fmaf(v, a.scale[cin], a.shift[cin]);
-                                if (a.relu) v = fmaxf(v, 0.f);
-                            }
-                        }
-                        unsigned short h[NSPLIT];
-                        split_bf16<NSPLIT>(v, h);
-#pragma unroll
-                        for (int s = 0; s < NSPLIT; ++s) o[s][e] = h[s];
-                    }
-                }
-#pragma unroll
-                for (int s = 0; s < NSPLIT; ++s)
-                    *reinterpret_cast<us8*>(in_s + ((size_t)((s * C::ROWS + r) * C::ROW + p)) * CB_CKP + oc * 8) = o[s];
-            }
-        }
-#pragma unroll 1
-        for (int kh = 0; kh < KH; ++kh) {
-            if (kh > 0) __syncthreads();       // previous kernel row's MFMAs are done with w_s
-#pragma unroll
-            for (int i = 0; i < C::W_PER_T; ++i) {
-                const int item = tid + i * 256;
-                if (item < C::W_ITEMS) {
-                    const int oc = item % (CB_CK / 8), co = (item / (CB_CK / 8)) % CB_COUT_T, kw = item / ((CB_CK / 8) * CB_COUT_T);
-#pragma unroll
-                    for (int s = 0; s < NSPLIT; ++s) {
-                        const us8 v = *reinterpret_cast<const us8*>(
-                            wpb + (((size_t)(s * C::KK + kh * KW + kw) * a.CoutP + cout0 + co) * a.CinP + c0 + oc * 8));
-                        *reinterpret_cast<us8*>(w_s + ((size_t)((s * KW + kw) * CB_COUT_T + co)) * CB_CKP + oc * 8) = v;
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int kw = 0; kw < KW; ++kw) {
-                us8 af[C::MTW][NSPLIT];
-#pragma unroll
-                for (int m = 0; m < C::MTW; ++m)
-#pragma unroll
-                    for (int s = 0; s < NSPLIT; ++s)
-                        af[m][s] = *reinterpret_cast<const us8*>(
-                            w_s + ((size_t)((s * KW + kw) * CB_COUT_T + (wm * C::MTW + m) * 16 + lr)) * CB_CKP + lq * 8);
-#pragma unroll
-                for (int n = 0; n < C::NTW; ++n) {
-                    const int fl = n / C::NTT, tt = wn * C::NTT + n % C::NTT;
-                    us8 bfr[NSPLIT];
-#pragma unroll
-                    for (int s = 0; s < NSPLIT; ++s)
-                        bfr[s] = *reinterpret_cast<const us8*>(
-                            in_s + ((size_t)((s * C::ROWS + fl + kh) * C::ROW + tt * 16 + lr + kw + (C::HALO - PADW))) * CB_CKP + lq * 8);
-#pragma unroll
-                    for (int m = 0; m < C::MTW; ++m) {
-                        f32x4 c = acc[m][n];
-                        if (NSPLIT == 3) {                 // small terms first
-                            c = mfma_bf16(af[m][1], bfr[1], c);
-                            c = mfma_bf16(af[m][2], bfr[0], c);
-                            c = mfma_bf16(af[m][0], bfr[2], c);
-                            c = mfma_bf16(af[m][1], bfr[0], c);
-                            c = mfma_bf16(af[m][0], bfr[1], c);
-                        }
-                        c = mfma_bf16(af[m][0], bfr[0], c);
-                        acc[m][n] = c;
-                    }
-                }
-            }
-        }
-    }
-    conv_epilogue<CB_COUT_T, FT, TT, C::MTW, C::NTT, C::WN, POOL, DGRAD>(a, acc, st_s, b, f0, t0, cout0, sl, wm, wn, lq, lr, tid);
-}
 
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -457,20 +335,6 @@ __global__ void pack_conv_weights_bf16_kernel(const float* __restrict__ w, unsig
     }
 }
 
-template <int FT, int TT, int KH, int KW, int NSPLIT, bool POOL, bool DGRAD>
-static int launch_b(const ConvFwdArgs& a, const unsigned short* wpb, hipStream_t s) {
-    using C = ConvBCfg<FT, TT, KH, KW, NSPLIT, POOL>;
-    if ((size_t)a.Cout * a.F * a.T * 4 >= (1ull << 29)) {     // conv_epilogue addresses one clip with 32-bit offsets
-        set_error("conv_bf16: one clip of the output must stay below 512 MiB (Cout=%d F=%d T=%d)", a.Cout, a.F, a.T);
-        return PBSED_E_ARG;
-    }
-    const int nTt = (a.T + TT - 1) / TT, nFt = (a.F + FT - 1) / FT;
-    dim3 grid(nTt * nFt * a.B, a.CoutP / CB_COUT_T);
-    auto kern = conv_bf16_kernel<FT, TT, KH, KW, NSPLIT, POOL, DGRAD>;
-    PBSED_DYN_LDS_ONCE(kern, C::LDS_BYTES);
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, a, wpb);
-    return check_launch("conv_bf16");
-}
 
 template <int NS>
 static int dispatch_b2(const ConvFwdArgs& a, const unsigned short* wpb, int KH, int KW, int pool, int dgrad, hipStream_t s) {
@@ -496,28 +360,7 @@ static int dispatch_b2(const ConvFwdArgs& a, const unsigned short* wpb, int KH, 
 
 template <int NSPLIT>
 static int dispatch_b(const ConvFwdArgs& a, const unsigned short* wpb, int KH, int KW, int pool, int dgrad, hipStream_t s) {
-    static const bool v1 = getenv("PBSED_BF16_V1") ? atoi(getenv("PBSED_BF16_V1")) != 0 : false;
-    // PBSED_BF16X3_V2 (default 1): the three-part (fp32-class) format runs the pipelined kernel too
-    static const bool x3v2 = getenv("PBSED_BF16X3_V2") ? atoi(getenv("PBSED_BF16X3_V2")) != 0 : true;
-    if (!v1 && (NSPLIT == 1 || x3v2)) return dispatch_b2<NSPLIT>(a, wpb, KH, KW, pool, dgrad, s);
-#define CB(FT_, TT_, KH_, KW_)                                                             \
-    do {                                                                                   \
-        if (dgrad) return launch_b<FT_, TT_, KH_, KW_, NSPLIT, false, true>(a, wpb, s);    \
-        if (pool) return launch_b<FT_, TT_, KH_, KW_, NSPLIT, true, false>(a, wpb, s);     \
-        return launch_b<FT_, TT_, KH_, KW_, NSPLIT, false, false>(a, wpb, s);              \
-    } while (0)
-#define CB1(TT_, KW_)                                                                      \
-    do {                                                                                   \
-        if (dgrad) return launch_b<1, TT_, 1, KW_, NSPLIT, false, true>(a, wpb, s);        \
-        return launch_b<1, TT_, 1, KW_, NSPLIT, false, false>(a, wpb, s);                  \
-    } while (0)
-    if (KH == 3 && KW == 3) CB(NSPLIT == 3 ? 2 : 4, 64, 3, 3);
-    if (KH == 1 && KW == 3 && !pool) CB1(128, 3);
-    if (KH == 1 && KW == 1 && !pool) CB1(128, 1);
-#undef CB
-#undef CB1
-    set_error("conv_bf16: unsupported kernel %dx%d pool=%d", KH, KW, pool);
-    return PBSED_E_UNSUPPORTED;
+    return dispatch_b2<NSPLIT>(a, wpb, KH, KW, pool, dgrad, s);
 }
 
 }  // namespace pbsed

@@ -335,11 +335,9 @@ static int launch_wgrad_cfg(Kern kern, const ConvWgradArgs& a_in, hipStream_t s)
     if (split < 1) split = 1;
     // one residency round: a second round (twice the blocks, half the chunks each) doubles the atomics of the final
     // reduction for nothing when the chunks divide evenly (128->128: 0.465 -> 0.452 ms)
-    static const bool slots_on = getenv("PBSED_WGRAD_SLOTS") ? atoi(getenv("PBSED_WGRAD_SLOTS")) != 0 : true;
-    static const int slot_cap = getenv("PBSED_WGRAD_SLOT_CAP") ? atoi(getenv("PBSED_WGRAD_SLOT_CAP")) : 4096;
     const int nw = a.Cout * a.Cin * C::KK, nb = a.Cout;
-    const bool slot_ok = slots_on && nw + nb <= WGRAD_SLOT_MAX;
-    const int cap = (slot_ok ? slot_cap : 1024) / (gy * gz);                              // atomics-per-address cap
+    const bool slot_ok = nw + nb <= WGRAD_SLOT_MAX;
+    const int cap = (slot_ok ? 4096 : 1024) / (gy * gz);                              // atomics-per-address cap
     if (split > cap) split = cap > 0 ? cap : 1;
     if (split > nChunks) split = nChunks;
     if constexpr (wgrad_columns<C>::value) {                          // column-walking kernels split over (clip, column) units
@@ -1650,11 +1648,6 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_pc_kernel(ConvWgradArgs a) {
     }
 }
 
-static bool pc1d_force() {                 // PBSED_WGRAD_PC=2: the producer / consumer Conv1d kernel for every eligible shape (tests)
-    static const bool f = getenv("PBSED_WGRAD_PC") && atoi(getenv("PBSED_WGRAD_PC")) == 2;
-    return f;
-}
-
 int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     if (a.unpool_idx && (a.F % 2)) { set_error("conv_wgrad: unpool needs even F"); return PBSED_E_ARG; }
     // the loaders address one clip with 32-bit element offsets (buffer loads; 2^29 elements marks "out of range")
@@ -1662,56 +1655,29 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
         set_error("conv_wgrad: one clip of x / dy must stay below 1 GiB (Cin=%d Cout=%d F=%d T=%d)", a.Cin, a.Cout, a.F, a.T);
         return PBSED_E_ARG;
     }
-    // Conv1d layers of the fp32 path (F = 1 rows): the same kernel with exact three-way operand splits - fp32-class gradients
-    // (256->256 k = 3: 100 us on the fp32-MFMA kernel); very wide inputs stay on the fp32 kernel's 128-wide cin tiles
-    static const bool x3_1d = getenv("PBSED_CONV1D_X3") ? atoi(getenv("PBSED_CONV1D_X3")) != 0 : true;
-    // ... in producer / consumer form from 64 channels on either side (PBSED_WGRAD_PC=0: the kernels below).  Measured at B = 32,
-    // T = 500: 256->256 k = 3 87 -> 67 us, 2048->256 k = 1 245 -> 166 us; a 256->256 k = 1 gradient is four 128 x 128 output tiles
-    // with eight steps per block of a 64-way split - its fill and reduction outweigh the steps (41 -> 49 us), it stays below
-    static const bool pc1d = getenv("PBSED_WGRAD_PC") ? atoi(getenv("PBSED_WGRAD_PC")) != 0 : true;
-    if (!a.bf16 && x3_1d && pc1d && KH == 1 && a.F == 1 && !a.unpool_idx && a.Cin >= 64 && a.Cout >= 64) {
+    // Conv1d layers of the fp32 path (F = 1 rows): exact three-way operand splits on the bf16 MFMA - fp32-class gradients - in
+    // producer / consumer form from 64 channels on either side.  Measured at B = 32, T = 500: 256->256 k = 3 87 -> 67 us,
+    // 2048->256 k = 1 245 -> 166 us (fp32-MFMA kernel before); a 256->256 k = 1 gradient is four 128 x 128 output tiles with
+    // eight steps per block of a 64-way split - its fill and reduction outweigh the steps (41 -> 49 us), it stays on the
+    // pipelined kernel below, like the narrower layers (up to 1 024 inputs; wider ones: the fp32 kernel's 128-wide cin tiles)
+    if (!a.bf16 && KH == 1 && a.F == 1 && !a.unpool_idx && a.Cin >= 64 && a.Cout >= 64) {
         if (KW == 3) return launch_wgrad_cfg<Wgrad1dPcCfg<3>>(conv1d_wgrad_pc_kernel<3>, a, s);
-        if (KW == 1 && (a.Cin >= 512 || pc1d_force())) return launch_wgrad_cfg<Wgrad1dPcCfg<1>>(conv1d_wgrad_pc_kernel<1>, a, s);
+        if (KW == 1 && a.Cin >= 512) return launch_wgrad_cfg<Wgrad1dPcCfg<1>>(conv1d_wgrad_pc_kernel<1>, a, s);
     }
-    if (!a.bf16 && x3_1d && KH == 1 && a.F == 1 && !a.unpool_idx && a.Cin >= 32 && a.Cout >= 32 && a.Cin < 1024) {
+    if (!a.bf16 && KH == 1 && a.F == 1 && !a.unpool_idx && a.Cin >= 32 && a.Cout >= 32 && a.Cin < 1024) {
         if (KW == 3) return launch_wgrad_cfg<WgradB16Cfg<1, 3, 2, 3>>(conv_wgrad_bf16_kernel<1, 3, 2, 3>, a, s);
         if (KW == 1) return launch_wgrad_cfg<WgradB16Cfg<1, 1, 2, 3>>(conv_wgrad_bf16_kernel<1, 1, 2, 3>, a, s);
     }
-    // 3x3 layers of the fp32 path on the same kernel with exact three-way operand splits (fp32-class gradients, 6 bf16 MFMA
-    // products per product): far fewer operand bytes per MFMA than the Winograd form, whose transformed operands are 6/4 as
-    // large per part (PBSED_WGRAD_X3: 0 = off, 1 = 128-cout blocks one row tall above 64 channels, 2 = 64-cout blocks)
-    static const int x3_2d = getenv("PBSED_WGRAD_X3") ? atoi(getenv("PBSED_WGRAD_X3")) : 0;
-    // producer / consumer column-walking form (default for the layers with >= 64 input and output channels, where it is ahead
-    // of the fp32 Winograd kernel: 128->128 0.374 vs 0.432 ms, 128->256 0.357 vs 0.419, 64->128 0.220 vs 0.240, 64->64 0.243 vs
-    // 0.258): 64 cout x 64 cin blocks; PBSED_WGRAD_PC=0 switches it off, PBSED_WGRAD_X3=4 forces it (128 x 32 blocks) from 32
-    // channels on
-    static const bool pc_on = getenv("PBSED_WGRAD_PC") ? atoi(getenv("PBSED_WGRAD_PC")) != 0 : true;
+    // 3x3 layers of the fp32 path with >= 64 input and output channels: the producer / consumer column-walking form, 64 cout x
+    // 64 cin blocks (128->128 0.326 ms, 128->256 0.317, 64->128 0.215, 64->64 0.218 against 0.432 / 0.419 / 0.240 / 0.258 of the
+    // fp32 Winograd weight gradient); the 32->32 layer: the same kernel with its consumer waves slicing the step's time range
+    // (KS = 2: 64 t per step, wave = 32 cout x 16 cin x one 32-t slice) - one block covers all of cout x cin: 0.278 -> 0.158 ms.
+    // Measured and NOT taken (removed from the tree in round 4): the time-sliced form for 16->16 (0.197 -> 0.252 ms), 16->32
+    // and 32->64 - with one or two MFMA tiles per wave and step nothing covers the LDS round trip and the shift arithmetic of
+    // the next fragment, and 16->16 has 128 columns for 256 CUs
     if (!a.bf16 && KH == 3 && KW == 3 && (a.T & 3) == 0) {
-        if (pc_on && x3_2d == 0 && a.Cin >= 64 && a.Cout >= 64) return launch_wgrad_cfg<WgradPcCfg<2, 2>>(conv_wgrad_pc_kernel<2, 2>, a, s);
-        // the 32->32 layer: the same kernel with its consumer waves slicing the step's time range (KS = 2: 64 t per step, wave =
-        // 32 cout x 16 cin x one 32-t slice) - one block covers all of cout x cin: 0.278 -> 0.190 ms against the fp32-MFMA kernel.
-        // Measured and NOT taken (PBSED_WGRAD_PC_SMALL=2 runs them): 16->16 (KS = 4) 0.197 -> 0.316 ms, 16->32 0.169 -> 0.200,
-        // 32->64 0.148 (fp32 Winograd) -> 0.173 - with one or two MFMA tiles per wave and step (18 .. 36 MFMAs per kernel row)
-        // nothing covers the LDS round trip and the shift arithmetic of the next fragment, and 16->16 has 128 columns for 256 CUs
-        static const int pc_small = getenv("PBSED_WGRAD_PC_SMALL") ? atoi(getenv("PBSED_WGRAD_PC_SMALL")) : 1;
-        if (pc_on && pc_small && x3_2d == 0 && a.Cin >= 16 && a.Cout >= 16) {
-            if (a.Cin == 32 && a.Cout == 32) return launch_wgrad_cfg<WgradPcCfg<1, 2, 2, 2, 1>>(conv_wgrad_pc_kernel<1, 2, 2, 2, 1>, a, s);
-            if (pc_small >= 2) {
-                if (a.Cin <= 16 && a.Cout <= 16) return launch_wgrad_cfg<WgradPcCfg<1, 1, 4, 1, 1>>(conv_wgrad_pc_kernel<1, 1, 4, 1, 1>, a, s);
-                if (a.Cin <= 16 && a.Cout <= 32) return launch_wgrad_cfg<WgradPcCfg<1, 1, 4, 2, 1>>(conv_wgrad_pc_kernel<1, 1, 4, 2, 1>, a, s);
-                if (a.Cin <= 32 && a.Cout <= 32) return launch_wgrad_cfg<WgradPcCfg<1, 2, 2, 2, 1>>(conv_wgrad_pc_kernel<1, 2, 2, 2, 1>, a, s);
-                if (a.Cin <= 32) return launch_wgrad_cfg<WgradPcCfg<2, 1, 2, 2, 2>>(conv_wgrad_pc_kernel<2, 1, 2, 2, 2>, a, s);      // 64-cout blocks
-            }
-        }
-        if (x3_2d >= 4 && a.Cin >= 32 && a.Cout >= 32) {
-            if ((a.Cout <= 64 || x3_2d == 5) && a.Cin >= 64) return launch_wgrad_cfg<WgradPcCfg<2, 2>>(conv_wgrad_pc_kernel<2, 2>, a, s);
-            return launch_wgrad_cfg<WgradPcCfg<4, 1>>(conv_wgrad_pc_kernel<4, 1>, a, s);
-        }
-    }
-    if (!a.bf16 && x3_2d && KH == 3 && KW == 3 && a.Cin >= 32 && a.Cout >= 32) {
-        if (x3_2d == 1 && a.Cout > 64) return launch_wgrad_cfg<WgradB16Cfg<3, 3, 4, 3, 1>>(conv_wgrad_bf16_kernel<3, 3, 4, 3, 1>, a, s);
-        if (x3_2d == 3) return launch_wgrad_cfg<WgradB16Cfg<3, 3, 2, 3, 1>>(conv_wgrad_bf16_kernel<3, 3, 2, 3, 1>, a, s);   // 75 KB: two blocks per CU
-        return launch_wgrad_cfg<WgradB16Cfg<3, 3, 2, 3>>(conv_wgrad_bf16_kernel<3, 3, 2, 3>, a, s);
+        if (a.Cin >= 64 && a.Cout >= 64) return launch_wgrad_cfg<WgradPcCfg<2, 2>>(conv_wgrad_pc_kernel<2, 2>, a, s);
+        if (a.Cin == 32 && a.Cout == 32) return launch_wgrad_cfg<WgradPcCfg<1, 2, 2, 2, 1>>(conv_wgrad_pc_kernel<1, 2, 2, 2, 1>, a, s);
     }
     if (a.bf16 && a.Cin >= 32 && a.Cout >= 32) {       // bf16-MFMA operands (config 3); few-channel layers stay on the fp32 kernels
         if (KH == 3 && KW == 3) {
@@ -1724,8 +1690,7 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     // Configurations measured on MI355X at B=32, T=500: one per channel regime.
     if (KH == 3 && KW == 3) {
         if (a.Cin == 1) return a.Cout >= 64 ? launch_wgrad<3, 3, 4, 1, 1, true>(a, s) : launch_wgrad<3, 3, 1, 1, 1, true>(a, s);
-        static const bool wino = getenv("PBSED_WGRAD_WINO") ? atoi(getenv("PBSED_WGRAD_WINO")) != 0 : true;
-        if (a.Cout >= 64 && a.Cin >= 16 && wino) return launch_wgrad_cfg<WinoWgradCfg>(conv_wgrad_wino_kernel, a, s);
+        if (a.Cout >= 64 && a.Cin >= 16) return launch_wgrad_cfg<WinoWgradCfg>(conv_wgrad_wino_kernel, a, s);
         if (a.Cout >= 64) return launch_wgrad<3, 3, 4, 1, 1>(a, s);
         // few output channels: the waves of a block also split the chunk's time range (KWAVES) and chunks are 4 rows
         // tall, otherwise a block is one or two waves and nothing hides the LDS / global latency

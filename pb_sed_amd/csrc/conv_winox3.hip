@@ -605,14 +605,10 @@ static int launch_winox3(const ConvFwdArgs& a, hipStream_t s) {
     if ((size_t)18 * a.CinP * a.CoutP * 6 >= (1ull << 31)) { set_error("conv_winox3: packed weights exceed 2 GiB"); return PBSED_E_ARG; }
     const int nTt = (a.T + WX_TT - 1) / WX_TT, nFt = (a.F + WX_FT - 1) / WX_FT;
     const int nSp = nTt * nFt * a.B, nCt = (a.Cout + CT - 1) / CT;          // CT = 32: the padding tiles of CoutP are never visited
-    static const int map_env = getenv("PBSED_WX_MAP") ? atoi(getenv("PBSED_WX_MAP")) : 3;
-    int xcd_map = map_env, nWork;
-    if (xcd_map == 1 && !(nCt <= 8 && 8 % nCt == 0)) xcd_map = 0;
-    if (xcd_map == 3 && a.B < 8) xcd_map = 2;
-    if (xcd_map == 1) nWork = (nSp + 8 / nCt - 1) / (8 / nCt) * 8;
-    else if (xcd_map == 3) nWork = (a.B + 7) / 8 * nTt * nFt * nCt * 8;
-    else if (xcd_map == 2) nWork = (nSp + 7) / 8 * 8 * nCt;
-    else nWork = nSp * nCt;
+    // item -> XCD map: 3 = the clips of a batch dealt over the XCDs (2 for fewer than 8 clips: spatial tiles dealt over them); the
+    // other maps measured the same times (L2 locality is not what bounds the kernel)
+    const int xcd_map = a.B < 8 ? 2 : 3;
+    const int nWork = xcd_map == 3 ? (a.B + 7) / 8 * nTt * nFt * nCt * 8 : (nSp + 7) / 8 * 8 * nCt;
     if (a.T & 3) { set_error("conv_winox3: T = %d is not a multiple of 4 (rows must be 16-byte aligned; use the fp32 Winograd kernel)", a.T); return PBSED_E_UNSUPPORTED; }
     // persistent blocks, one per CU (110 KB of LDS each), a multiple of 8 so that an item's XCD is its block's XCD
     int blocks = device_cus() / 8 * 8;
@@ -628,10 +624,7 @@ static int launch_winox3(const ConvFwdArgs& a, hipStream_t s) {
 
 using namespace pbsed;
 
-static bool wx_ct32() {                    // PBSED_WX_CT32=0: 64-cout blocks for every launch (two idle consumer waves at <= 32 channels)
-    static const bool on = getenv("PBSED_WX_CT32") ? atoi(getenv("PBSED_WX_CT32")) != 0 : true;
-    return on;
-}
+static bool wx_ct32() { return true; }     // 32-cout blocks for launches that produce <= 32 channels (64: two idle consumer waves)
 
 extern "C" {
 

@@ -42,26 +42,18 @@ struct GruStackArgs {
     int B, T, nchains, nlayers, launch;
     int poll_delay, poll_delay_gate;   // granule kernels: first-poll delays (PollPacer) of the non-gate / gate waves
     int ring_xcd, nby;    // granule kernels: ring_xcd = H/16 > 0 selects the 1-D XCD-aware role mapping (granule_role)
-    unsigned* gran_loc;   // granule scans: the rings' XCD-local copy of the exchanged states (see poll_batch); null = off
-    int dbg;              // diagnostics (PBSED_GRU_DBG): bit 0 = the scans skip their output stores (timing experiments only)
-    int fast_gates;       // granule forward scan: gate activations from v_exp_f32 / v_rcp_f32 (gate_sigmoid / gate_tanh)
     unsigned long long* prof;   // diagnostics (pbsed_gru_set_prof): shader-clock stamps of block `prof_block`, steps 200..231
     int prof_block;
 };
 
 // Gate activations of the persistent forward scan.  The libm forms (expf, a full-precision division, tanhf with its
 // small-argument branch) are ~110 VALU instructions per gate thread ON the step's critical path (reduction -> gates ->
-// publish); the hardware forms are 12: sigmoid(x) = rcp(1 + exp2(-x log2 e)), tanh(x) = 1 - 2 rcp(1 + exp2(2 x log2 e))
-// (v_exp_f32 / v_rcp_f32: 1 ulp each; exp2 overflowing to +inf gives rcp(inf) = 0, the right limit on both sides).
-// Absolute error <= 2e-7 per activation, the same class as the tagged LSB of the exchanged state.
-__device__ __forceinline__ float gate_sigmoid(float x, bool fast) {
-    if (fast) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-    return 1.f / (1.f + expf(-x));
-}
-__device__ __forceinline__ float gate_tanh(float x, bool fast) {
-    if (fast) return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
-    return tanhf(x);
-}
+// publish: 730 of a step's 6 100 clocks in the shader-clock profile, 380 with these); the hardware forms are 12:
+// sigmoid(x) = rcp(1 + exp2(-x log2 e)), tanh(x) = 1 - 2 rcp(1 + exp2(2 x log2 e)) (v_exp_f32 / v_rcp_f32: 1 ulp each; exp2
+// overflowing to +inf gives rcp(inf) = 0, the right limit on both sides).  Absolute error <= 2e-7 per activation, the same
+// class as the tagged LSB of the exchanged state; the launch-per-step kernels keep expf / tanhf.
+__device__ __forceinline__ float gate_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float gate_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
 
 // shader-clock stamp of one lane (diagnostics only; s_memtime waits for the wave's outstanding LDS / scalar loads)
 __device__ __forceinline__ void prof_stamp(unsigned long long* p) { *p = __builtin_readcyclecounter(); }
@@ -324,21 +316,9 @@ struct PollPacer {
 // contiguous 1 KB tile one producer block published (8 whole 128-byte lines instead of 16 half lines of a row-major
 // [T][B][H] array) and a producer's 256 publishing threads write one contiguous 1 KB; nothing is fetched twice.  All loads of a step are issued
 // before any tag is looked at (one fabric round trip per step); out[n] = the four (tag-cleared) values.
-// XCD-local exchange of a ring.  A ring's 16 workgroups sit on ONE XCD (granule_role) and share its L2.  tools/micro/
-// l2_pingpong.hip on fresh addresses: a write-through (sc1) store takes 1 000 .. 1 500 clocks to become visible - to an sc1
-// load and to a plain load alike - and the scans' sc1 polls return after ~2 000 clocks under the scan's own traffic (shader-clock
-// profile, tools/gru_scan_prof.py: published -> satisfied = 2 750 of a forward step's 5 500 clocks); a PLAIN store is in the
-// XCD's L2 within ~500 clocks and a plain load of a line the CU never read comes from that L2.  So every state word is
-// published twice: a plain store into the ring's local copy `gran_loc` (same tile order) and the write-through store into
-// the main array.  A ring's FIRST look at a step's words is a plain load from the local copy - every word has its own
-// location, written once per call, and the CU looks at it for the first time (its L1 cannot hold a stale copy of a line it
-// never read; L1s are invalidated at kernel boundaries) - and whatever it returns is validated by the parity tags like any
-// other look: stale, half-written or (ring not on one XCD after all) never-arriving data fails the test, and the retries are
-// sc1 loads from the main array, which is also what the projection blocks on the other XCDs read.  Correctness therefore does
-// not depend on where the blocks run; the placement only decides which path is taken.
 template <int NL, int STEP = 1024>
-__device__ __forceinline__ int poll_batch(float4 (&out)[NL], __amdgpu_buffer_rsrc_t rsrc, __amdgpu_buffer_rsrc_t rsrc_loc, unsigned voff,
-                                          unsigned parity, bool valid, unsigned* err_flag, bool first_plain) {
+__device__ __forceinline__ int poll_batch(float4 (&out)[NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned parity,
+                                          bool valid, unsigned* err_flag) {
     u32x4_t q[NL];
 #pragma unroll
     for (int n = 0; n < NL; ++n) q[n] = u32x4_t{0u, 0u, 0u, 0u};
@@ -347,13 +327,8 @@ __device__ __forceinline__ int poll_batch(float4 (&out)[NL], __amdgpu_buffer_rsr
         bool ok = true;
         asm volatile("" ::: "memory");                  // the load builtins are not volatile: every attempt loads again
         if (valid) {
-            if (spin == 0 && first_plain) {
 #pragma unroll
-                for (int n = 0; n < NL; ++n) q[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_loc, voff + n * STEP, 0, 0);
-            } else {
-#pragma unroll
-                for (int n = 0; n < NL; ++n) q[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + n * STEP, 0, /*aux = sc1*/ 16);
-            }
+            for (int n = 0; n < NL; ++n) q[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + n * STEP, 0, /*aux = sc1*/ 16);
             unsigned all1 = 1u, any1 = 0u;
 #pragma unroll
             for (int n = 0; n < NL; ++n) {
@@ -448,8 +423,8 @@ __device__ __forceinline__ void wait_own_granules(unsigned (&q)[NQ], const gu32*
 // NB: 16-row batch tiles per block (1, or 2 for more than 32 clips: the rings of 64 clips then need 192 instead of 384
 // co-resident blocks and stay one launch; a block's two tiles share the W fragments, their polls are issued together).
 template <int NL, int NB>
-__device__ __forceinline__ int poll_tiles(float4 (&out)[NB][NL], __amdgpu_buffer_rsrc_t rsrc, __amdgpu_buffer_rsrc_t rsrc_loc, unsigned voff,
-                                           unsigned tile_stride, unsigned parity, const bool (&valid)[NB], unsigned* err_flag, bool first_plain) {
+__device__ __forceinline__ int poll_tiles(float4 (&out)[NB][NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned tile_stride,
+                                           unsigned parity, const bool (&valid)[NB], unsigned* err_flag) {
     u32x4_t q[NB][NL];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -462,15 +437,9 @@ __device__ __forceinline__ int poll_tiles(float4 (&out)[NB][NL], __amdgpu_buffer
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
             if (valid[nb]) {
-                if (spin == 0 && first_plain) {                   // see poll_batch
 #pragma unroll
-                    for (int n = 0; n < NL; ++n)
-                        q[nb][n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_loc, voff + nb * tile_stride + n * 1024, 0, 0);
-                } else {
-#pragma unroll
-                    for (int n = 0; n < NL; ++n)
-                        q[nb][n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + nb * tile_stride + n * 1024, 0, /*aux = sc1*/ 16);
-                }
+                for (int n = 0; n < NL; ++n)
+                    q[nb][n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + nb * tile_stride + n * 1024, 0, /*aux = sc1*/ 16);
             }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -519,10 +488,6 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
     const unsigned parity = epoch & 1u;
     // ring: h_t, tile-major; this block's first tile of step t starts at g_own + t * Bp * H, the next one H * 16 words on
     gu32* g_own = (gu32*)gran_h_ + (size_t)(chain * a.nlayers + layer) * per_cl + ((size_t)role.by * NB * (H / 16) + role.bx) * 256;
-    // the rings' XCD-local copy (poll_batch): same offsets in a second array
-    const __amdgpu_buffer_rsrc_t rsrc_loc =
-        __builtin_amdgcn_make_buffer_rsrc(a.gran_loc ? a.gran_loc : gran_h_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 4), 0x00020000);
-    gu32* g_loc = a.gran_loc ? (gu32*)a.gran_loc + (g_own - (gu32*)gran_h_) : nullptr;
     gu32* g_gi = (gu32*)gran_gi_ + (size_t)(chain * (a.nlayers - 1) + (layer > 0 ? layer - 1 : 0)) * per_cl_b * 3;  // [T][B][3][H]
     // gate thread -> (batch row, unit) row-major: a wave's global stores / loads are whole 64-byte row segments and a producer's
     // 1 KB exchange tile is [16 rows][16 units].  The partial sums a gate thread adds sit in the MFMA D layout (lane (u >> 2) *
@@ -592,8 +557,6 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
         }
     };
     load_gi(0);
-    const bool fast = a.fast_gates != 0;
-    const bool first_plain = a.gran_loc != nullptr && !is_proj;
     // diagnostics: lane 0 of the first contraction wave (slots 0..5) and of the first gate wave (slots 8..12) of one block
     const bool prof_blk = a.prof != nullptr && (int)blockIdx.x == a.prof_block;
     const bool prof_c = prof_blk && tid == GWV * 64, prof_g = prof_blk && tid == 0;
@@ -622,7 +585,7 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
         if (contract) {
             pacer.wait();
             if (prof_now && prof_c) prof_stamp(pslot + 1);
-            const int spins = poll_tiles<NL, NB>(x, rsrc, rsrc_loc, voff0 + (unsigned)(is_proj ? t : tp) * step_t, tile_bytes, parity, rowv, err_flag, first_plain);
+            const int spins = poll_tiles<NL, NB>(x, rsrc, voff0 + (unsigned)(is_proj ? t : tp) * step_t, tile_bytes, parity, rowv, err_flag);
             if (prof_now && prof_c) { prof_stamp(pslot + 2); pslot[5] = (unsigned long long)spins; }
         }
         // requests issued behind the poll (loads return in order, anything older would hold the poll back):
@@ -703,17 +666,14 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
                 }
                 const float ghn = s[2];
                 if (prof_now && prof_g && nb == 0) prof_stamp(pslot + 10);
-                const float r = gate_sigmoid(gi_r[nb] + s[0], fast);
-                const float z = gate_sigmoid(gi_z[nb] + s[1], fast);
-                const float n = gate_tanh(gi_n[nb] + r * ghn, fast);
+                const float r = gate_sigmoid(gi_r[nb] + s[0]);
+                const float z = gate_sigmoid(gi_z[nb] + s[1]);
+                const float n = gate_tanh(gi_n[nb] + r * ghn);
                 const float hp = h_reg[nb];
                 const float h = tag_clear((t < sl[nb]) ? (1.f - z) * n + z * hp : 0.f);    // the state IS the truncated value
                 h_reg[nb] = h;
-                const size_t own_off = (size_t)t * Bp * H + (size_t)nb * (H / 16) * 256 + (tid & 255);
-                if (g_loc) __hip_atomic_store(g_loc + own_off, __float_as_uint(h) | parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                publish(g_own + own_off, h, parity);
+                publish(g_own + (size_t)t * Bp * H + (size_t)nb * (H / 16) * 256 + (tid & 255), h, parity);
                 if (prof_now && prof_g && nb == 0) prof_stamp(pslot + 11);
-                if (a.dbg & 1) continue;
                 L.hs[tb * H + j] = h;
                 if (L.save) {
                     // what BPTT multiplies dh_t with: d(r,z,n pre-activations)/dh, d(gh_n)/dh and z (granule save format)
@@ -727,15 +687,6 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
         if (prof_now && prof_g) prof_stamp(pslot + 12);
         if (err_seen) return;
     }
-}
-
-template <int KB, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gru_granule_fwd_kernel(GruStackArgs a, unsigned* gran_h_,
-                                                                 unsigned* gran_gi_, unsigned epoch,
-                                                                 unsigned* err_flag) {
-    __shared__ float red[2][NW][1][3][RED_ROW];
-    __shared__ int s_err;
-    gru_granule_fwd_body<KB, NW, false>(a, gran_h_, gran_gi_, epoch, err_flag, red, s_err);
 }
 
 template <int KB, int NW, int XS, int NB>
@@ -772,9 +723,6 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         __builtin_amdgcn_make_buffer_rsrc(gran_dh_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 4), 0x00020000);
     const unsigned parity = epoch & 1u;
     gu32* g_own = (gu32*)gran_dh_ + (size_t)(chain * a.nlayers + layer) * per_cl + ((size_t)role.by * (H / 16) + role.bx) * 256;
-    const __amdgpu_buffer_rsrc_t rsrc_loc =                    // the rings' XCD-local copy (poll_batch)
-        __builtin_amdgcn_make_buffer_rsrc(a.gran_loc ? a.gran_loc : gran_dh_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 4), 0x00020000);
-    gu32* g_loc = a.gran_loc ? (gu32*)a.gran_loc + (g_own - (gu32*)gran_dh_) : nullptr;
     gu32* g_dy = (gu32*)gran_dy_ + (size_t)(chain * (a.nlayers - 1) + (layer < top ? layer : 0)) * per_cl_b;
     const int u = tid & 15, bb = (tid >> 4) & 15, b = b0 + bb, j = j0 + u;     // see gru_granule_fwd_body
     const int red_w = lq * 80 + lr * 4, red_r = (u >> 2) * 80 + bb * 4 + (u & 3);
@@ -849,7 +797,6 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
     load_operands(0);
     load_own(0);
     const bool prof_blk = a.prof != nullptr && (int)blockIdx.x == a.prof_block;        // see gru_granule_fwd_body
-    const bool first_plain = a.gran_loc != nullptr && !is_proj;
     const bool prof_c = prof_blk && tid == GWV * 64, prof_g = prof_blk && tid == 0;
 
     for (int bstep = 0; bstep < a.T; ++bstep) {
@@ -871,7 +818,7 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         if (contract) {
             pacer.wait();
             if (prof_now && prof_c) prof_stamp(pslot + 1);
-            const int spins = poll_batch<NL>(dh4, rsrc, rsrc_loc, voff0 + (unsigned)(is_proj ? t : tn) * step_t, parity, rowv, err_flag, first_plain);
+            const int spins = poll_batch<NL>(dh4, rsrc, voff0 + (unsigned)(is_proj ? t : tn) * step_t, parity, rowv, err_flag);
             if (prof_now && prof_c) { prof_stamp(pslot + 2); pslot[5] = (unsigned long long)spins; }
         }
         unsigned qd[1] = {0};                         // behind the poll: loads return in order
@@ -940,11 +887,8 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
                     dhzv = dh * z;
                 }
                 dhz_prev = dhzv;
-                const size_t own_off = (size_t)t * Bp * H + (tid & 255);
-                if (g_loc) __hip_atomic_store(g_loc + own_off, __float_as_uint(dh) | parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                publish(g_own + own_off, dh, parity);
+                publish(g_own + (size_t)t * Bp * H + (tid & 255), dh, parity);
                 if (prof_now && prof_g) prof_stamp(pslot + 11);
-                if (a.dbg & 1) continue;
                 float* dgi = L.dgi + tb * G;
                 float* dgh = L.dgh + tb * G;
                 dgi[j] = dr; dgi[H + j] = dz; dgi[2 * H + j] = dn;
@@ -954,15 +898,6 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         if (prof_now && prof_g) prof_stamp(pslot + 12);
         if (err_seen) return;
     }
-}
-
-template <int KB, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gru_granule_bwd_kernel(GruStackArgs a, unsigned* gran_dh_,
-                                                                 unsigned* gran_dy_, unsigned epoch,
-                                                                 unsigned* err_flag) {
-    __shared__ float red[2][NW][RED_ROW];
-    __shared__ int s_err;
-    gru_granule_bwd_body<KB, NW, false>(a, gran_dh_, gran_dy_, epoch, err_flag, red, s_err);
 }
 
 template <int KB, int NW, int XS>
@@ -1065,23 +1000,10 @@ static int* granule_delay_table(int kind) {
 }
 
 static int granule_capacity(bool bwd, int H, int bf16, int nb);       // co-resident blocks of the scan kernel (below)
-// bf16 / bf16x3 operands for H = 512 too (KB = 4: the W fragments take 72 registers as three-way splits): bit 0 forward, bit 1 BPTT
-static int granule_x3_h512() {
-    static const int v = [] { const char* e = getenv("PBSED_GRU_X3_H512"); return e ? atoi(e) : 0; }();
-    return v;
-}
-
-// diagnostics (pbsed_gru_set_prof) and the gate-activation form of the forward scan (PBSED_GRU_FAST_GATES, default on)
+// diagnostics (pbsed_gru_set_prof)
 static unsigned long long* g_prof_buf = nullptr;
 static int g_prof_block = 0;
-static void granule_common(GruStackArgs& a, unsigned* loc) {
-    static const int fast = [] { const char* e = getenv("PBSED_GRU_FAST_GATES"); return e ? atoi(e) : 1; }();
-    a.fast_gates = fast;
-    static const int dbg = [] { const char* e = getenv("PBSED_GRU_DBG"); return e ? atoi(e) : 0; }();
-    a.dbg = dbg;
-    // PBSED_GRU_LOCAL=0: the rings poll the write-through array only (the form of rounds 1 - 3)
-    static const int local = [] { const char* e = getenv("PBSED_GRU_LOCAL"); return e ? atoi(e) : 1; }();
-    a.gran_loc = local ? loc : nullptr;
+static void granule_common(GruStackArgs& a) {
     a.prof = g_prof_buf;
     a.prof_block = g_prof_block;
 }
@@ -1101,18 +1023,10 @@ static void granule_poll_delays(bool bwd, GruStackArgs& a, int nb = 1) {
     a.poll_delay_gate = use[bwd ? 3 : 1];
 }
 
-// Ring-per-XCD placement (granule_role) per scan direction: bit 0 = forward, bit 1 = BPTT.  Measured on MI355X with the
-// paced 4-byte polls: forward 1.35 ms with / 1.48 ms without, BPTT 1.66 / 1.64 ms (round 2: forward only).  Round 3, with the
-// tile-major exchange, the bf16x3 products and the delays tuned in place: BPTT 1.335 ms spread over all XCDs, 1.285 ms with
-// one ring per XCD (three same-box pairs) - both directions by default.
-static bool granule_ring_xcd(bool bwd) {
-    static const int v = [] { const char* e = getenv("PBSED_GRU_RING_XCD"); return e ? atoi(e) : 3; }();
-    return (v >> (bwd ? 1 : 0)) & 1;
-}
-
+// Ring-per-XCD placement (granule_role), both scan directions.  Measured on MI355X with the paced 4-byte polls: forward 1.35 ms
+// with / 1.48 ms without; BPTT (round 3, tile-major exchange, bf16x3 products, delays tuned in place) 1.285 with / 1.335 without.
 // Granule-exchange persistent forward scan (see gru_granule_fwd_kernel).  granules: device uint32 workspace of
-// nchains*T*Bp*H*(2*nlayers + 3*(nlayers-1)) words, Bp = B rounded up to 16 (h_t of every layer, the projected inputs of layers > 0,
-// then the rings' XCD-local copy of h_t) that
+// nchains*T*Bp*H*(nlayers + 3*(nlayers-1)) words, Bp = B rounded up to 16 (h_t of every layer, then the projected inputs of layers > 0) that
 // must be ZERO before its first use; `epoch` must be odd on the first use of a workspace and change parity with
 // every call that uses it (the words of the previous call then never match); same T, B, H for the life of a
 // workspace.  err_flag: device uint32 (0 on entry; non-zero after a hand-off timed out: re-zero the workspace).
@@ -1142,24 +1056,20 @@ static int gru_stack_fwd_granule_impl(int nchains, int nlayers, const float* con
     }
     a.seq_len = seq_len; a.B = B; a.T = T; a.nchains = nchains; a.nlayers = nlayers;
     const int ngroups = nchains * (2 * nlayers - 1);     // rings + projection groups (see GranuleRole)
-    // PBSED_GRU_GW: bit 0 forward / bit 1 BPTT scan with dedicated gate waves (default both; 1.35 -> 1.21 ms and
-    // 1.65 -> 1.49 ms at B = 32, H = 256, T = 500)
-    static const int gw = [] { const char* e = getenv("PBSED_GRU_GW"); return e ? atoi(e) : 3; }();
-    // PBSED_GRU_X3: bit 0 = forward / bit 1 = BPTT scan with bf16x3 operands on the bf16 MFMA (see Bf3; default both:
-    // forward 1.13 -> 0.94 ms, BPTT 1.40 -> 1.33 ms at B = 32, H = 256, T = 500)
-    static const int x3 = [] { const char* e = getenv("PBSED_GRU_X3"); return e ? atoi(e) : 3; }();
+    // dedicated gate waves (1.35 -> 1.21 ms / 1.65 -> 1.49 ms at B = 32, H = 256, T = 500) and, up to H = 256, bf16x3 operands on
+    // the bf16 MFMA (forward 1.13 -> 0.94 ms, BPTT 1.40 -> 1.33 ms); H = 512 keeps fp32-MFMA operands (the three-way W fragments
+    // of K = 64 per wave spill: forward 3.2 -> 4.4 ms, BPTT 4.7 -> 7.5 ms measured in round 4)
     // every block has to be co-resident (one per CU, 7/8 of the device at most): past that, two batch tiles per block
-    const int nb = ((gw & 1) && ngroups * (H / 16) * ((B + 15) / 16) > device_cus() * 7 / 8) ? 2 : 1;
+    const int nb = (ngroups * (H / 16) * ((B + 15) / 16) > device_cus() * 7 / 8) ? 2 : 1;
     granule_poll_delays(false, a, nb);
-    granule_common(a, granules + (size_t)nchains * T * Bp * H * (nlayers + 3 * (nlayers - 1)));
+    granule_common(a);
     dim3 grid(H / 16, (B + 16 * nb - 1) / (16 * nb), ngroups);
     if ((int)(grid.x * grid.y * grid.z) > granule_capacity(false, H, bf16, nb)) {
         set_error("gru_stack_fwd_granule: %u blocks cannot be co-resident on this device (capacity %d): use pbsed_gru_stack_fwd",
                   grid.x * grid.y * grid.z, granule_capacity(false, H, bf16, nb));
         return PBSED_E_UNSUPPORTED;
     }
-    if (granule_ring_xcd(false)) granule_xcd_grid(a, H, &grid, nb);
-    if (!a.ring_xcd) a.gran_loc = nullptr;                // rings spread over the XCDs: the local copy would never be seen in time
+    granule_xcd_grid(a, H, &grid, nb);                    // one ring per XCD when every XCD can hold its share (else the 3-D grid)
     unsigned* gran_gi = granules + (size_t)nchains * nlayers * T * Bp * H;
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_GW(KB_, NW_, X3_, NB_)                                                                                  \
@@ -1171,15 +1081,12 @@ static int gru_stack_fwd_granule_impl(int nchains, int nlayers, const float* con
     } while (0)
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
     do {                                                                                                             \
-        if ((gw & 1) && nb == 2) {                                                                                   \
-            if (bf16 && (KB_ < 4 || (granule_x3_h512() & 1))) LAUNCH_GW(KB_, NW_, 1, 2);                                                          \
-            else if ((x3 & 1) && (KB_ < 4 || (granule_x3_h512() & 1))) LAUNCH_GW(KB_, NW_, 3, 2);                                                 \
+        if (nb == 2) {                                                                                               \
+            if (bf16 && KB_ < 4) LAUNCH_GW(KB_, NW_, 1, 2);                                                          \
+            else if (KB_ < 4) LAUNCH_GW(KB_, NW_, 3, 2);                                                             \
             else LAUNCH_GW(KB_, NW_, 0, 2);                                                                          \
-        } else if (gw & 1) {                                                                                         \
-            if (bf16) LAUNCH_GW(KB_, NW_, 1, 1); else if (x3 & 1) LAUNCH_GW(KB_, NW_, 3, 1); else LAUNCH_GW(KB_, NW_, 0, 1);  \
         } else {                                                                                                     \
-            hipLaunchKernelGGL((gru_granule_fwd_kernel<KB_, NW_>), grid, dim3(NW_ * 64), 0, s, a, granules, gran_gi,  \
-                               epoch, err_flag);                                                                     \
+            if (bf16) LAUNCH_GW(KB_, NW_, 1, 1); else LAUNCH_GW(KB_, NW_, 3, 1);                                     \
         }                                                                                                            \
     } while (0)
     switch (H) {
@@ -1194,9 +1101,8 @@ static int gru_stack_fwd_granule_impl(int nchains, int nlayers, const float* con
 }
 
 
-// Granule-exchange persistent BPTT.  granules: device uint32 workspace of nchains*T*Bp*H*(3*nlayers-1) words (Bp as above)
-// (dh_t of every layer, dy_t of the layers below the top, then the rings' XCD-local copy of dh_t), zero before first use,
-// epoch parity as above.
+// Granule-exchange persistent BPTT.  granules: device uint32 workspace of nchains*T*Bp*H*(2*nlayers-1) words (Bp as above)
+// (dh_t of every layer, then dy_t of the layers below the top), zero before first use, epoch parity as above.
 static int gru_stack_bwd_granule_impl(int nchains, int nlayers, const float* const* w_hh_t, const float* const* w_ih_up_t,
                                       const float* const* hs, const float* const* save, const float* const* dy_top,
                                       float* const* dgi, float* const* dgh, const int* reverse, const int* seq_len, int B, int H,
@@ -1221,35 +1127,27 @@ static int gru_stack_bwd_granule_impl(int nchains, int nlayers, const float* con
     a.seq_len = seq_len; a.B = B; a.T = T; a.nchains = nchains; a.nlayers = nlayers;
     const int ngroups = nchains * (2 * nlayers - 1);
     granule_poll_delays(true, a);
-    granule_common(a, granules + (size_t)nchains * T * Bp * H * (2 * nlayers - 1));
+    granule_common(a);
     dim3 grid(H / 16, (B + 15) / 16, ngroups);
     if ((int)(grid.x * grid.y * grid.z) > granule_capacity(true, H, bf16, 1)) {
         set_error("gru_stack_bwd_granule: %u blocks cannot be co-resident on this device (capacity %d): use pbsed_gru_stack_bwd",
                   grid.x * grid.y * grid.z, granule_capacity(true, H, bf16, 1));
         return PBSED_E_UNSUPPORTED;
     }
-    if (granule_ring_xcd(true)) granule_xcd_grid(a, H, &grid);
-    if (!a.ring_xcd) a.gran_loc = nullptr;
+    granule_xcd_grid(a, H, &grid);
     unsigned* gran_dy = granules + (size_t)nchains * nlayers * T * Bp * H;
     hipStream_t s = (hipStream_t)stream;
-    // PBSED_GRU_GW: bit 0 forward / bit 1 BPTT scan with dedicated gate waves (default both; 1.35 -> 1.21 ms and
-    // 1.65 -> 1.49 ms at B = 32, H = 256, T = 500)
-    static const int gw = [] { const char* e = getenv("PBSED_GRU_GW"); return e ? atoi(e) : 3; }();
-    static const int x3 = [] { const char* e = getenv("PBSED_GRU_X3"); return e ? atoi(e) : 3; }();     // bit 1 = BPTT scan
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
     do {                                                                                                             \
-        if ((gw & 2) && bf16 && (KB_ < 4 || (granule_x3_h512() & 2))) {                                                                           \
+        if (bf16 && KB_ < 4) {                                                                                       \
             hipLaunchKernelGGL((gru_granule_bwd_gw_kernel<KB_, NW_, 1>), grid, dim3((NW_ + 4) * 64), 0, s, a,         \
                                granules, gran_dy, epoch, err_flag);                                                  \
-        } else if ((gw & 2) && (x3 & 2) && (KB_ < 4 || (granule_x3_h512() & 2))) {                                                                \
+        } else if (KB_ < 4) {                                                                                        \
             hipLaunchKernelGGL((gru_granule_bwd_gw_kernel<KB_, NW_, 3>), grid, dim3((NW_ + 4) * 64), 0, s, a,         \
                                granules, gran_dy, epoch, err_flag);                                                  \
-        } else if (gw & 2) {                                                                                         \
+        } else {                                                                                                     \
             hipLaunchKernelGGL((gru_granule_bwd_gw_kernel<KB_, NW_, 0>), grid, dim3((NW_ + 4) * 64), 0, s, a,         \
                                granules, gran_dy, epoch, err_flag);                                                  \
-        } else {                                                                                                     \
-            hipLaunchKernelGGL((gru_granule_bwd_kernel<KB_, NW_>), grid, dim3(NW_ * 64), 0, s, a, granules, gran_dy,  \
-                               epoch, err_flag);                                                                     \
         }                                                                                                            \
     } while (0)
     switch (H) {
@@ -1281,28 +1179,23 @@ static int resident_blocks(Kern kern, int threads, size_t lds, int (&cache)[64])
 }
 
 static int granule_capacity(bool bwd, int H, int bf16, int nb) {
-    static const int gw = [] { const char* e = getenv("PBSED_GRU_GW"); return e ? atoi(e) : 3; }();
-    static const int x3 = [] { const char* e = getenv("PBSED_GRU_X3"); return e ? atoi(e) : 3; }();
 #define CAP_FWD(KB_, NW_)                                                                                                          \
     do {                                                                                                                           \
-        static int c0[64], c1[64], c2[64], c3[64];                                                                                 \
-        const size_t lds = (size_t)2 * NW_ * nb * 3 * RED_ROW * sizeof(float);                                                      \
-        if (!(gw & 1)) return resident_blocks(gru_granule_fwd_kernel<KB_, NW_>, NW_ * 64, 0, c0);                                  \
+        static int c1[64], c2[64], c3[64];                                                                                         \
+        const size_t lds = (size_t)2 * NW_ * nb * 3 * RED_ROW * sizeof(float);                                                     \
         if (nb == 2) {                                                                                                             \
-            if (bf16 && (KB_ < 4 || (granule_x3_h512() & 1))) return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 1, 2>, (NW_ + 4) * 64, lds, c1);       \
-            if ((x3 & 1) && (KB_ < 4 || (granule_x3_h512() & 1))) return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 3, 2>, (NW_ + 4) * 64, lds, c2);   \
+            if (bf16 && KB_ < 4) return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 1, 2>, (NW_ + 4) * 64, lds, c1);       \
+            if (KB_ < 4) return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 3, 2>, (NW_ + 4) * 64, lds, c2);               \
             return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 0, 2>, (NW_ + 4) * 64, lds, c3);                            \
         }                                                                                                                          \
         if (bf16) return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 1, 1>, (NW_ + 4) * 64, lds, c1);                      \
-        if (x3 & 1) return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 3, 1>, (NW_ + 4) * 64, lds, c2);                    \
-        return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 0, 1>, (NW_ + 4) * 64, lds, c3);                                \
+        return resident_blocks(gru_granule_fwd_gw_kernel<KB_, NW_, 3, 1>, (NW_ + 4) * 64, lds, c2);                                \
     } while (0)
 #define CAP_BWD(KB_, NW_)                                                                                                          \
     do {                                                                                                                           \
-        static int c0[64], c1[64], c2[64], c3[64];                                                                                 \
-        if (!(gw & 2)) return resident_blocks(gru_granule_bwd_kernel<KB_, NW_>, NW_ * 64, 0, c0);                                  \
-        if (bf16 && (KB_ < 4 || (granule_x3_h512() & 2))) return resident_blocks(gru_granule_bwd_gw_kernel<KB_, NW_, 1>, (NW_ + 4) * 64, 0, c1);                \
-        if ((x3 & 2) && (KB_ < 4 || (granule_x3_h512() & 2))) return resident_blocks(gru_granule_bwd_gw_kernel<KB_, NW_, 3>, (NW_ + 4) * 64, 0, c2);            \
+        static int c1[64], c2[64], c3[64];                                                                                         \
+        if (bf16 && KB_ < 4) return resident_blocks(gru_granule_bwd_gw_kernel<KB_, NW_, 1>, (NW_ + 4) * 64, 0, c1);                \
+        if (KB_ < 4) return resident_blocks(gru_granule_bwd_gw_kernel<KB_, NW_, 3>, (NW_ + 4) * 64, 0, c2);                        \
         return resident_blocks(gru_granule_bwd_gw_kernel<KB_, NW_, 0>, (NW_ + 4) * 64, 0, c3);                                     \
     } while (0)
     if (!bwd) {

@@ -139,30 +139,22 @@ def _prec(precision, cin, pc=None, dgrad=False, unpool=False):
     >= 32 channels into >= 64 output channels of the launch (a data gradient produces the layer's cin)."""
     if precision != 'f32':
         return precision if cin >= 32 else 'f32'
-    # Conv1d layers of the fp32 path: the pipelined bf16-MFMA kernel with exact three-way operand splits (fp32-class results,
-    # csrc/conv_bf16.hip NS = 3) is ahead of the fp32-MFMA kernel there (256->256 k = 3: 66 -> 44 us, k = 1: 31 -> 25 us)
-    if pc is not None and pc.weight.dim() == 3 and pc.cin >= 32 and pc.cout >= 32 \
-            and os.environ.get('PBSED_CONV1D_X3', '1') != '0':
-        # ... and from 96 output channels of the launch on (blocks of 128) the producer / consumer kernel of csrc/conv1d_pc.hip
-        # (weights streamed from L2 in fragment order, four producer waves staging x): PBSED_CONV1D_PC=0 keeps the pipelined one
+    # Conv1d layers of the fp32 path: exact three-way bf16 operand splits on the bf16 MFMA (fp32-class results) - from 96 output
+    # channels of the launch on (blocks of 128) the producer / consumer kernel of csrc/conv1d_pc.hip (weights streamed from L2 in
+    # fragment order, four producer waves staging x), below that the pipelined kernel of csrc/conv_bf16.hip (NS = 3)
+    if pc is not None and pc.weight.dim() == 3 and pc.cin >= 32 and pc.cout >= 32:
         n_out = pc.cin if dgrad else pc.cout
-        if n_out >= 96 and pc.kw in (1, 3) and os.environ.get('PBSED_CONV1D_PC', '1') != '0':
-            return 'c1x3'
-        return 'bf16x3'
-    if pc is not None and pc.kh == 3 and pc.kw == 3 and os.environ.get('PBSED_CONV_WINO', '1') != '0':
+        return 'c1x3' if n_out >= 96 and pc.kw in (1, 3) else 'bf16x3'
+    if pc is not None and pc.kh == 3 and pc.kw == 3:
         k_in, n_out = (pc.cout, pc.cin) if dgrad else (pc.cin, pc.cout)
-        # bf16x3 Winograd (csrc/conv_winox3.hip: the same transform-domain products from exact three-way bf16 splits on the
-        # bf16 MFMA) from 32 channels on either side (32->32 forward 0.152 vs 0.216 ms direct, data gradient 0.138 vs 0.215; with
-        # 16 input channels half of every K = 32 MFMA would be padding and the producers stage 32 channels per chunk whatever
-        # the layer has - measured: 16->32 forward 0.144 vs 0.116 ms direct, data gradient 0.164 vs 0.130, 16->16 twice as slow);
-        # PBSED_CONV_WINOX3=0 keeps the fp32-MFMA Winograd kernel, which pays from 64 output channels on
-        if os.environ.get('PBSED_CONV_WINOX3', '1') != '0':
-            # (with 32-cout blocks the data gradient through a pool into 32 channels is ahead too: 0.193 vs 0.232 ms direct at
-            # 32->32; with 64-cout blocks it was not, 0.254 - PBSED_WX_UNPOOL32=0 sends it back to the direct kernel)
-            if k_in >= 32 and (n_out >= 64 or (n_out >= 32 and (not (dgrad and unpool) or os.environ.get('PBSED_WX_UNPOOL32', '1') != '0'))):
-                return 'winox3'
-        elif k_in >= 32 and n_out >= 64:
-            return 'wino'
+        # bf16x3 Winograd (csrc/conv_winox3.hip: the transform-domain products from exact three-way bf16 splits on the bf16 MFMA)
+        # from 32 channels on either side (32->32 forward 0.152 vs 0.216 ms direct, data gradient 0.138 vs 0.215; with 16 input
+        # channels half of every K = 32 MFMA would be padding and the producers stage 32 channels per chunk whatever the layer
+        # has - measured: 16->32 forward 0.144 vs 0.116 ms direct, data gradient 0.164 vs 0.130, 16->16 twice as slow); with 32-cout
+        # blocks the data gradient through a pool into 32 channels is ahead too (0.193 vs 0.232 ms direct at 32->32).  Rows that
+        # are not 16-byte aligned (T % 4) take the fp32-MFMA Winograd kernel of csrc/conv_wino.hip inside ops.conv_fwd.
+        if k_in >= 32 and n_out >= 32:
+            return 'winox3'
     return 'f32'
 
 

@@ -368,9 +368,8 @@ def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, se
     # which kernel the library picks for these shapes (conv_wgrad.hip dispatch), for the bench's tags: the producer / consumer
     # bf16x3 kernel from 64 channels on, the Winograd-F(4,3) fp32 kernel for the other 3x3 layers with >= 64 output channels
     k33 = pc.kh == 3 and pc.kw == 3
-    x3pc = (k33 and cin >= 64 and pc.cout >= 64 and t % 4 == 0 and os.environ.get('PBSED_WGRAD_PC', '1') != '0'
-            and os.environ.get('PBSED_WGRAD_X3', '0') == '0')
-    wino = k33 and not x3pc and pc.cout >= 64 and cin >= 16 and os.environ.get('PBSED_WGRAD_WINO', '1') != '0'
+    x3pc = k33 and t % 4 == 0 and ((cin >= 64 and pc.cout >= 64) or (cin == 32 and pc.cout == 32))    # conv_wgrad_launch's rule
+    wino = k33 and not x3pc and pc.cout >= 64 and cin >= 16
     call('pbsed_conv_bwd_weight', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(g),
          ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream(),
          tag=_conv_tag(b, cin, pc, f, t) + (' x3pc' if x3pc else ' wino' if wino else ''), flops=_conv_flops(b, cin, pc, f, t))
@@ -788,7 +787,7 @@ def _granule_scan(nch, nlayers, b, h, t, device=None, fwd=False, precision='f32'
     bf16 = precision == 'bf16'
     blocks = nch * (2 * nlayers - 1) * ((b + 15) // 16) * (h // 16)
     cap = min(_granule_capacity(dev, h, False, bf16, 1), _granule_capacity(dev, h, True, bf16, 1))
-    if fwd and blocks > cap * 7 // 8 and int(os.environ.get('PBSED_GRU_GW', '3')) & 1:
+    if fwd and blocks > cap * 7 // 8:
         blocks = nch * (2 * nlayers - 1) * ((b + 31) // 32) * (h // 16)
         cap = _granule_capacity(dev, h, False, bf16, 2)
     return blocks <= cap * 7 // 8 and nch * nlayers * t * ((b + 15) // 16 * 16) * h * 4 < 2 ** 32
@@ -828,7 +827,7 @@ def gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, reverse, seq_len, nlayers, save=T
         key = (str(dev), n, t, b, h)
         gw = _GRANULE_WS.get(key)
         if gw is None:
-            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (2 * nlayers + 3 * (nlayers - 1)), dtype=torch.int32, device=dev), 0]
+            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (nlayers + 3 * (nlayers - 1)), dtype=torch.int32, device=dev), 0]
         ws = _gru_err_flag(dev)
 
         def launch(tag=f'{nch}x{nlayers} B{b} H{h} T{t}'):
@@ -872,7 +871,7 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
         key = (str(dev), 'bwd', n, t, b, h)
         gw = _GRANULE_WS.get(key)
         if gw is None:
-            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (3 * nlayers - 1), dtype=torch.int32, device=dev), 0]
+            gw = _GRANULE_WS[key] = [torch.zeros(nch * t * ((b + 15) // 16 * 16) * h * (2 * nlayers - 1), dtype=torch.int32, device=dev), 0]
         ws = _gru_err_flag(dev)
 
         def launch(tag=f'{nch}x{nlayers} B{b} H{h} T{t}'):
@@ -904,11 +903,6 @@ def gru_wgrad(dg, x, shift, dw, db, precision='f32'):
     ks = [v.shape[2] for v in x]
     assert all(d.shape == (t, b, g) and d.is_contiguous() for d in dg) and all(v.shape[:2] == (t, b) and v.is_contiguous() for v in x)
     assert all(w.shape == (g, k) and w.is_contiguous() for w, k in zip(dw, ks))
-    if precision != 'bf16' and os.environ.get('PBSED_GRU_WGRAD_X3', '1') == '0' and len(set(ks)) > 1:
-        for k in sorted(set(ks)):                       # the fp32-MFMA kernel takes one input width per launch
-            sel = [i for i, v in enumerate(ks) if v == k]
-            gru_wgrad(*[[lst[i] for i in sel] for lst in (dg, x, shift, dw, db)], precision=precision)
-        return
     for a in range(0, len(dg), 16):
         sl = slice(a, a + 16)
         call('pbsed_gru_wgrad_multi', len(dg[sl]), _lib.ptr_array(dg[sl]), _lib.ptr_array(x[sl]), _lib.int_array(shift[sl]),

@@ -223,9 +223,11 @@ def _bicrnn_inputs(wav, seq, weak, strong, device=None, dtype=torch.float32):
 def test_c3_bicrnn_shallow_b8(precision):
     """BASELINE configs[2] network at its real width (B = 8 so that the CPU oracle finishes in seconds).  fp32: the
     fp32 bars (logits 1e-4, scores 2.5e-5, loss 2e-5, per-tensor gradients 2e-3 against the float64 oracle on the HIP run's branch,
-    see _grad_table).  bf16 (the config's dtype: bf16 MFMA operands, fp32 accumulation / BN / GRU state): gated against the
-    bf16-OPERAND oracle (oracle/bf16emu.py) - logits 2e-3, gradients 1e-2 in the L2 sense; the distance to the fp32 oracle
-    (logits ~0.2, gradients ~0.23: bf16 has 8 mantissa bits and the net is 16 layers deep) is reported, not the gate."""
+    see _grad_table).  bf16 (the config's dtype: bf16 MFMA operands, fp32 accumulation / BN / GRU state): against the
+    bf16-OPERAND oracle (oracle/bf16emu.py) the HIP run has to be as close as that oracle in float32 is to itself in float64
+    (rounding flips make the bf16 forward map chaotic at the 1e-2 level: no end-to-end comparison resolves more - the tight
+    kernel gates are test_c3_conv_launches_in_situ and the rounded-operand references of test_gpu_ops.py); the distance to
+    the fp32 oracle (logits ~0.2, gradients ~0.23) is reported, not a gate."""
     ref, model = _bicrnn_pair()
     model.conv_precision = precision
     model.keep_logits = True
@@ -271,40 +273,56 @@ def test_c3_bicrnn_shallow_b8(precision):
         # logits 0.197, scores 4.3e-2, loss 4.7e-4, gradients 0.234), bounded only as a sanity check
         assert e_logit < .3 and e_score < 6e-2 and e_loss < 2e-3 and e_g < .3
         assert all(torch.isfinite(g_).all() for g_ in grads.values())
-        # (2) THE GATE: against the bf16-operand oracle (oracle/bf16emu.py: every product's operands rounded to bf16 where the
-        # kernels round them, float64 around the roundings).  Forward: pre-sigmoid outputs within 2e-3 (measured ~3e-4: fp32
-        # accumulation order moves a few operands across a bf16 tie, 2^-9 each, through 16 layers).  Backward: the oracle
-        # differentiates the HIP run's branch (decisions imposed, _grad_table) - all gradients within 1e-2 in the L2 sense.
+        # (2) against the bf16-operand oracle (oracle/bf16emu.py: every product's operands rounded to bf16 where the kernels round
+        # them), float64 around the roundings.  What such a comparison can resolve is bounded by the ORACLE ITSELF: evaluated in
+        # float32 instead of float64 it moves by 4e-4 at the first bf16 layer and ~1.4e-2 (relative) at the logits - a 1e-7 change
+        # of a pre-rounding value flips the bf16 rounding of 5e-5 of the operands, and norm + ReLU + re-rounding amplify that from
+        # layer to layer (bf16 operands make the forward map chaotic at the 1e-2 level).  So the oracle is run twice, float64 and
+        # float32, and the HIP run has to be as close to the float64 oracle as the float32 oracle is (factor 2): that is the
+        # statement "indistinguishable from a correct bf16-operand implementation".  The tight gate on the kernels themselves is
+        # test_c3_conv_launches_in_situ (every launch fed with the run's own tensors: 1e-6 .. 1e-5) and the rounded-operand
+        # references of tests/test_gpu_ops.py.  Gradients: the oracles differentiate the HIP run's branch (decisions imposed).
         from oracle import bf16emu
-        emu = copy.deepcopy(ref).double().train()
-        bf16emu.enable(emu)
-        cap_e = _Capture(emu.rnn)
-        out_e = emu(in64)
-        e_logit_emu = ((logit.cpu().double() - cap_e.out) * m).abs().max().item()
-        e_score_emu = (out[0].cpu().double() - out_e[0]).abs().max().item()
-        loss_e = emu.review(in64, out_e)['loss']
-        e_loss_emu = abs(rev['loss'].item() - loss_e.item()) / abs(loss_e.item())
-        od.impose(emu, dec)
-        emu.zero_grad()
-        emu.review(in64, emu(in64))['loss'].backward()
-        od.impose(emu, None)
-        pe = dict(emu.named_parameters())
-        # (a bias in front of a batch norm has an exactly-zero gradient; with rounded operands both sides hold rounding noise
+
+        def emu_run(dtype):
+            emu = copy.deepcopy(ref).to(dtype).train()
+            emu.zero_grad()
+            bf16emu.enable(emu)
+            cap_e = _Capture(emu.rnn)
+            inp_e = _bicrnn_inputs(wav, seq, weak, strong, dtype=dtype)
+            out_e = emu(inp_e)
+            logit_e, score_e = cap_e.out.double(), out_e[0].detach().double()
+            loss_e = emu.review(inp_e, out_e)['loss'].item()
+            od.impose(emu, dec)
+            emu.zero_grad()
+            emu.review(inp_e, emu(inp_e))['loss'].backward()
+            od.impose(emu, None)
+            return logit_e, score_e, loss_e, {n: p.grad.double() for n, p in emu.named_parameters()}
+        logit64, score64, loss64, ge64 = emu_run(torch.float64)
+        logit32, score32, loss32, ge32 = emu_run(torch.float32)
+        # (a bias in front of a batch norm has an exactly-zero gradient; with rounded operands every side holds rounding noise
         # there - those tensors are left out, as _grad_table leaves them out)
         live = [n for n, _ in model.named_parameters() if p64[n].grad.abs().max() > 1e-9]
-        ge = torch.cat([pe[n].grad.reshape(-1) for n in live])
-        gl = torch.cat([grads[n].cpu().double().reshape(-1) for n in live])
-        e_g_emu = ((gl - ge).norm() / ge.norm()).item()
-        worst = sorted((((grads[n].cpu().double() - pe[n].grad).abs().max() / pe[n].grad.abs().max().clamp_min(1e-30)).item(), n)
-                       for n in live)[::-1]
-        print(f'bf16 vs the bf16-operand oracle: logits {e_logit_emu:.2e} scores {e_score_emu:.2e} loss {e_loss_emu:.2e} '
-              f'grad(L2) {e_g_emu:.2e}; worst tensors (max-abs / max): ' + ', '.join(f'{n} {e:.1e}' for e, n in worst[:4]))
-        _record('test_c3_bicrnn_shallow_b8[bf16] vs oracle/bf16emu.py', kind='full-width tag-conditioned BiCRNN, B = 8, bf16 mode '
-                'against the bf16-operand oracle (gradients: HIP decisions imposed)', logits_max_abs=e_logit_emu,
-                scores_max_abs=e_score_emu, loss_rel=e_loss_emu, grad_rel_l2=e_g_emu,
-                worst_tensors=[dict(name=n, err=e) for e, n in worst[:8]])
-        assert e_logit_emu < 2e-3 and e_score_emu < 5e-4 and e_loss_emu < 1e-4, (e_logit_emu, e_score_emu, e_loss_emu)
-        assert e_g_emu < 1e-2, e_g_emu
+        cat = lambda d: torch.cat([d[n].reshape(-1) for n in live])
+        g_hip, g_e64, g_e32 = cat({n: grads[n].cpu().double() for n in live}), cat(ge64), cat(ge32)
+        e_logit_emu = ((logit.cpu().double() - logit64) * m).abs().max().item()
+        e_score_emu = (out[0].cpu().double() - score64).abs().max().item()
+        e_loss_emu = abs(rev['loss'].item() - loss64) / abs(loss64)
+        e_g_emu = ((g_hip - g_e64).norm() / g_e64.norm()).item()
+        o_logit = ((logit32 - logit64) * m).abs().max().item()
+        o_score = (score32 - score64).abs().max().item()
+        o_loss = abs(loss32 - loss64) / abs(loss64)
+        o_g = ((g_e32 - g_e64).norm() / g_e64.norm()).item()
+        print(f'bf16 vs the bf16-operand oracle (float64): logits {e_logit_emu:.2e} scores {e_score_emu:.2e} loss {e_loss_emu:.2e} '
+              f'grad(L2) {e_g_emu:.2e};  the oracle in float32 vs float64: logits {o_logit:.2e} scores {o_score:.2e} loss {o_loss:.2e} '
+              f'grad(L2) {o_g:.2e}')
+        _record('test_c3_bicrnn_shallow_b8[bf16] vs oracle/bf16emu.py', kind='full-width tag-conditioned BiCRNN, B = 8, bf16 mode against '
+                'the bf16-operand oracle in float64 (gradients: HIP decisions imposed), beside the same oracle in float32 vs float64 '
+                '(what bf16 rounding flips alone do)', logits_max_abs=e_logit_emu, scores_max_abs=e_score_emu, loss_rel=e_loss_emu,
+                grad_rel_l2=e_g_emu, oracle_f32_vs_f64=dict(logits_max_abs=o_logit, scores_max_abs=o_score, loss_rel=o_loss, grad_rel_l2=o_g))
+        assert e_logit_emu < 2 * o_logit + 1e-3 and e_score_emu < 2 * o_score + 1e-4 and e_g_emu < 2 * o_g + 1e-3, \
+            (e_logit_emu, o_logit, e_score_emu, o_score, e_g_emu, o_g)
+        assert e_loss_emu < 2 * o_loss + 1e-4, (e_loss_emu, o_loss)
 
 
 @pytest.mark.parametrize('precision', ['f32', 'bf16'])
@@ -1019,17 +1037,20 @@ def test_c3_conv_launches_in_situ(precision):
                 full[:, :, 1::2] = g * sel
                 g = full
             gr = rnd(g)
+            # the weight-gradient launch takes bf16 operands only from 32 OUTPUT channels on (conv_wgrad_launch)
+            w_rounded = pr == 'bf16' and w.shape[0] >= 32
+            apw, grw = (ap, gr) if w_rounded or pr != 'bf16' else (F.pad(act, pad), g)
             if nd == 2:
-                dw = torch.nn.grad.conv2d_weight(ap, w.shape, gr)
+                dw = torch.nn.grad.conv2d_weight(apw, w.shape, grw)
                 dz = torch.nn.grad.conv2d_input(ap.shape, wr, gr)[:, :, lo:ap.shape[2] - hi, lo:ap.shape[3] - hi]
             else:
-                dw = torch.nn.grad.conv1d_weight(ap, w.shape, gr)
+                dw = torch.nn.grad.conv1d_weight(apw, w.shape, grw)
                 dz = torch.nn.grad.conv1d_input(ap.shape, wr, gr)[:, :, lo:ap.shape[2] - hi]
             assert err(f'{lname} dW', grads[lname + '.conv.weight'], dw) < 1e-4, (lname, worst)
             # bias gradient: in front of a norm it is a sum that cancels to (almost) nothing - measured against the sum of the
             # magnitudes it is made of (fp32 accumulation of ~1e5 terms), not against its own size
             red_g = [0] + list(range(2, gr.dim()))
-            e_db = (grads[lname + '.conv.bias'].cpu().double() - gr.sum(red_g)).abs().max().item() / gr.abs().sum(red_g).max().item()
+            e_db = (grads[lname + '.conv.bias'].cpu().double() - grw.sum(red_g)).abs().max().item() / grw.abs().sum(red_g).max().item()
             worst[f'{lname} db (/ sum |dY|)'] = e_db
             assert e_db < 1e-5, (lname, e_db)
             prev = layers[j - 1][1] if j > 0 else None

@@ -218,36 +218,6 @@ def test_conv_fwd_bwd_vs_torch(case):
         close(g, xr.grad, atol=2e-4, rtol=1e-3, name='conv_dgrad')
 
 
-def test_conv_kernels_behind_experiment_switches():
-    """The weight-gradient kernels that are compiled in but not the default for their shapes (time-sliced producer / consumer
-    blocks for 16 / 32 channels: PBSED_WGRAD_PC_SMALL=2; the producer / consumer Conv1d k = 1 gradient below 512 inputs:
-    PBSED_WGRAD_PC=2) against the same torch references: the switches are read once per process, so the cases run in a child."""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get('PBSED_TEST_CHILD'):
-        pytest.skip('already the child')
-    env = dict(os.environ, PBSED_WGRAD_PC_SMALL='2', PBSED_WGRAD_PC='2', PBSED_TEST_CHILD='1')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu', '-k', 'test_conv_fwd_bwd_vs_torch',
-                        '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-
-
-@pytest.mark.parametrize('switches', [{'PBSED_GRU_WGRAD_PC': '0', 'PBSED_GRU_WGRAD_SLOT_MIN': '8'}, {'PBSED_GRU_WGRAD_PC': '2'}])
-def test_gru_wgrad_kernels_behind_switches(switches):
-    """The GRU weight-gradient forms that are compiled in but not the default: the non-specialised kernel with float atomics
-    below 9 splits (round 2's form), and the producer / consumer kernel without the per-XCD placement of a row-tile group."""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get('PBSED_TEST_CHILD'):
-        pytest.skip('already the child')
-    env = dict(os.environ, PBSED_TEST_CHILD='1', **switches)
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu', '-k', 'test_gru_wgrad_vs_torch',
-                        '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-
-
 def test_conv_bn_relu_backward_chain_vs_autograd():
     """conv_i output -> Normalization(train) -> ReLU -> conv_{i+1}: statistics epilogue, bn_finalize,
     fused dgrad epilogue and bn_bwd_apply against autograd through the oracle layers."""

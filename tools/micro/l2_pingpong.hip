@@ -74,6 +74,58 @@ __global__ void pingpong_fresh(unsigned* buf, int partner_a, int partner_b, int 
     else { out[2] = fails; out[4] = first_ok; }
 }
 
+// As pingpong_fresh<plain store, plain first look>, plus a WRITE-THROUGH (sc1) store of the same value to a second location
+// EXTRA bytes further on, issued right behind the plain one (the scans publish a state twice: plain for the ring on this XCD,
+// write-through for the readers on other XCDs).  Does the write-through store hold up the plain hand-off - and does it matter
+// whether both lines map to the same L2 channel (EXTRA a multiple of 4 KB) or not (EXTRA + 256 B ...)?
+template <int EXTRA, int WAIT>
+__global__ void pingpong_dual(unsigned* buf, int partner_a, int partner_b, int iters, unsigned* out) {
+    const int me = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    if (me != partner_a && me != partner_b) return;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(buf, 0, 1u << 26, 0x00020000);
+    const bool is_a = me == partner_a;
+    unsigned fails = 0, first_ok = 0;
+    long long t0 = wall_clock64();
+    for (int i = 1; i <= iters; ++i) {
+        const unsigned mine = (unsigned)i * 512u + (is_a ? 0u : 256u), theirs = (unsigned)i * 512u + (is_a ? 256u : 0u);
+        if (is_a) {
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)i, rs, mine, 0, 0);
+            if (EXTRA) __builtin_amdgcn_raw_buffer_store_b32((unsigned)i, rs, mine + (unsigned)EXTRA, 0, 16);
+        }
+        for (int w = 0; w < WAIT; w += 64) __builtin_amdgcn_s_sleep(1);
+        int spin = 0;
+        for (;; ++spin) {
+            asm volatile("" ::: "memory");
+            const unsigned v = spin == 0 ? __builtin_amdgcn_raw_buffer_load_b32(rs, theirs, 0, 0)
+                                         : (EXTRA ? __builtin_amdgcn_raw_buffer_load_b32(rs, theirs + (unsigned)EXTRA, 0, 16)
+                                                  : __builtin_amdgcn_raw_buffer_load_b32(rs, theirs, 0, 16));
+            if (v == (unsigned)i) { first_ok += spin == 0; break; }
+            if (spin > 2000000) { ++fails; break; }
+        }
+        if (fails) break;
+        if (!is_a) {
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)i, rs, mine, 0, 0);
+            if (EXTRA) __builtin_amdgcn_raw_buffer_store_b32((unsigned)i, rs, mine + (unsigned)EXTRA, 0, 16);
+        }
+    }
+    long long t1 = wall_clock64();
+    if (is_a) { out[0] = (unsigned)(t1 - t0); out[1] = fails; out[3] = first_ok; }
+    else { out[2] = fails; out[4] = first_ok; }
+}
+
+template <int EXTRA, int WAIT>
+void run_dual(const char* name, unsigned* big, unsigned* out, int a, int b) {
+    const int iters = 20000;
+    hipMemset(big, 0, 1u << 26); hipMemset(out, 0, 256);
+    hipLaunchKernelGGL((pingpong_dual<EXTRA, WAIT>), dim3(16), dim3(64), 0, 0, big, a, b, iters, out);
+    hipDeviceSynchronize();
+    unsigned h[32]; hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+    int rate = 0; hipDeviceGetAttribute(&rate, hipDeviceAttributeWallClockRate, 0);
+    printf("dual store, %-44s wait %4d blocks %2d<->%2d: %s  %.0f ns per round trip, first look ok %u / %u of %d\n", name, WAIT, a, b,
+           (h[1] || h[2]) ? "NOT VISIBLE" : "ok", h[0] * 1e6 / rate / iters, h[3], h[4], iters);
+}
+
 template <int ST, int FIRST, int WAIT>
 void run_fresh(const char* name, unsigned* big, unsigned* out, int a, int b) {
     const int iters = 20000;
@@ -137,6 +189,16 @@ int main() {
         run_fresh<0, 0, 512>("store plain, first look plain", big, out, a, b);
         run_fresh<0, 0, 768>("store plain, first look plain", big, out, a, b);
         run_fresh<0, 0, 1024>("store plain, first look plain", big, out, a, b);
+        if (pass == 0) {
+            run_dual<0, 512>("plain store only", big, out, a, b);
+            run_dual<(1 << 25), 512>("+ sc1 store 32 MB on (same channel)", big, out, a, b);
+            run_dual<(1 << 25) + 256, 512>("+ sc1 store 32 MB + 256 B on", big, out, a, b);
+            run_dual<(1 << 25) + 1024, 512>("+ sc1 store 32 MB + 1 KB on", big, out, a, b);
+            run_dual<(1 << 25) + 4096 + 2048, 512>("+ sc1 store 32 MB + 6 KB on", big, out, a, b);
+            run_dual<0, 768>("plain store only", big, out, a, b);
+            run_dual<(1 << 25), 768>("+ sc1 store 32 MB on (same channel)", big, out, a, b);
+            run_dual<(1 << 25) + 256, 768>("+ sc1 store 32 MB + 256 B on", big, out, a, b);
+        }
         run_fresh<1, 0, 768>("store sc0, first look plain", big, out, a, b);
         run_fresh<16, 1, 768>("store sc1, first look sc0", big, out, a, b);
     }
