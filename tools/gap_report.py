@@ -40,7 +40,9 @@ ops.sort()
 marks = [i for i, o in enumerate(ops) if marker in o[3]]
 if len(marks) < 3:
     sys.exit(f'fewer than 3 launches of {marker} in the trace ({len(ops)} records)')
-a, b = marks[-2], marks[-1]
+# the step with the most device operations among the last marker-to-marker intervals (bench.py also launches the front-end on
+# its own at the end)
+a, b = max(zip(marks[-12:-1], marks[-11:]), key=lambda ab: ab[1] - ab[0])
 step = ops[a:b]
 t0, t1 = step[0][0], ops[b][0]
 busy_until, busy, gaps = t0, 0, defaultdict(lambda: [0, 0])
