@@ -186,6 +186,22 @@ int pbsed_conv_bwd_data_winox3(const float* g, const unsigned short* ud_packed_x
                                const int* seq_len, float* dz, const float* bx, const float* bmean, const float* binvstd,
                                const float* bscale, const float* bshift, int relu, double* stats, int B, int Cin,
                                int Cout, int F, int T, void* stream);
+/* The FEW-CHANNEL 3x3 layers of the fp32 path - contraction over <= 16 channels into <= 32: the 16->16 (+ pool) and 16->32
+ * Conv2d + Normalization + ReLU sites of pb_sed/experiments/weak_label_crnn/training.py:161-168, the tag-conditioned 11->16 first
+ * layer of pb_sed/models/strong_label/crnn.py:60-75 - on the bf16 MFMA with exact three-way bf16 operand splits
+ * (csrc/conv_s16.hip; fp32-class results; K = 32 of an MFMA = two taps x 16 channels).  Same contracts as pbsed_conv_fwd /
+ * pbsed_conv_bwd_data with KH = KW = 3.  wfrag: uint16 [5 tap pairs][3 parts][out_padded/16][64 lanes][8] from
+ * pbsed_pack_conv_weights_s16 (pbsed_pack_desc modes 14 / 15); forward: Cin <= 16, Cout <= 32; data gradient: Cout <= 16 (the
+ * contraction), Cin <= 32 (produced) - anything else returns PBSED_E_UNSUPPORTED. */
+void pbsed_conv_pack_dims_s16(int Cin, int Cout, int dgrad, int* in_padded /*host*/, int* out_padded /*host*/);
+int pbsed_pack_conv_weights_s16(const float* w, unsigned short* wfrag, int Cout, int Cin, int dgrad, void* stream);
+int pbsed_conv_fwd_s16(const float* x, const unsigned short* wfrag, const float* bias, const float* scale,
+                       const float* shift, int relu, const int* seq_len, float* y, unsigned char* pool_idx,
+                       double* stats, int stats_per_cf, int B, int Cin, int Cout, int F, int T, int pool, void* stream);
+int pbsed_conv_bwd_data_s16(const float* g, const unsigned short* wfrag_d, const unsigned char* unpool_idx,
+                            const int* seq_len, float* dz, const float* bx, const float* bmean, const float* binvstd,
+                            const float* bscale, const float* bshift, int relu, double* stats, int B, int Cin,
+                            int Cout, int F, int T, void* stream);
 /* Conv1d (kernel size 1 or 3, zero padding) forward / data gradient on [B, C, T] tensors with exact three-way bf16 operand
  * splits on the bf16 MFMA, producer / consumer form (csrc/conv1d_pc.hip; fp32-class results).  Replaces the CNN1d layers and
  * per-frame output nets of pb_sed/models/weak_label/crnn.py:93-101 and pb_sed/models/strong_label/crnn.py:88-104 in the

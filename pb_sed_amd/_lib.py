@@ -39,9 +39,13 @@ SIGNATURES = {
     'pbsed_conv_fwd_wino': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, _v],
     'pbsed_conv_bwd_data_wino': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, _v, I, I, I, I, I, _v],
     'pbsed_conv_pack_dims_winox3': [I, I, I, _i, _i],
+    'pbsed_conv_pack_dims_s16': [I, I, I, _i, _i],
     'pbsed_pack_conv_weights_winox3': [_v, _v, I, I, I, _v],
+    'pbsed_pack_conv_weights_s16': [_v, _v, I, I, I, _v],
     'pbsed_conv_fwd_winox3': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, _v],
+    'pbsed_conv_fwd_s16': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, _v],
     'pbsed_conv_bwd_data_winox3': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, _v, I, I, I, I, I, _v],
+    'pbsed_conv_bwd_data_s16': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, _v, I, I, I, I, I, _v],
     'pbsed_conv1d_pack_dims_x3': [I, I, I, _i, _i],
     'pbsed_pack_conv1d_weights_x3': [_v, _v, I, I, I, I, _v],
     'pbsed_conv1d_fwd_x3': [_v, _v, _v, _v, _v, I, _v, _v, _v, I, I, I, I, I, _v],
@@ -105,7 +109,7 @@ SIGNATURES = {
     'pbsed_allreduce_finish': [_v, _v],
 }
 _NON_STATUS = {'pbsed_gru_granule_capacity': C.c_int, 'pbsed_scratch_bytes': C.c_size_t, 'pbsed_last_error': C.c_char_p, 'pbsed_version': C.c_int, 'pbsed_comm_id_bytes': C.c_int, 'pbsed_conv_pack_dims': None,
-               'pbsed_conv_pack_dims_bf16': None, 'pbsed_conv_pack_dims_wino': None, 'pbsed_conv_pack_dims_winox3': None,
+               'pbsed_conv_pack_dims_bf16': None, 'pbsed_conv_pack_dims_wino': None, 'pbsed_conv_pack_dims_winox3': None, 'pbsed_conv_pack_dims_s16': None,
                'pbsed_conv1d_pack_dims_x3': None}
 
 _lib = None

@@ -28,7 +28,8 @@ struct PackDesc {
                    // 4/5: bf16 [tap][OutP][InP] forward / data-gradient layout (dst holds uint16), 6/7: its three-part form,
                    // 8/9: bf16x3 Winograd fragment layout forward / data gradient (csrc/conv_winox3.hip),
                    // 10/11: bf16x3 Conv1d fragment layout forward / data gradient (csrc/conv1d_pc.hip),
-                   // 12: dst [Cin][Cout] = src^T (fp32; KH, KW, InP, OutP unused)
+                   // 12: dst [Cin][Cout] = src^T (fp32; KH, KW, InP, OutP unused),
+                   // 14/15: bf16x3 few-channel 3x3 fragment layout forward / data gradient (csrc/conv_s16.hip)
     int pad_;
 };
 
@@ -41,6 +42,13 @@ __device__ __forceinline__ unsigned short f2bf_rne(float x) {
 __global__ void pack_batched_kernel(const PackDesc* __restrict__ descs) {
     const PackDesc d = descs[blockIdx.y];
     const int KK = d.KH * d.KW;
+    if (d.mode >= 14) {                                  // csrc/conv_s16.hip: fragment-ordered three-part few-channel 3x3 weights
+        const size_t total = (size_t)5 * (d.OutP / 16) * 512;
+        unsigned short* dst = reinterpret_cast<unsigned short*>(d.dst);
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+            pack_s16_value(d.src, dst, i, d.Cout, d.Cin, d.OutP, d.mode & 1);
+        return;
+    }
     if (d.mode >= 12) {                                  // plain transpose of a [Cout][Cin] matrix (the GRU scans' W^T operands)
         const size_t total = (size_t)d.Cout * d.Cin;
         for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {

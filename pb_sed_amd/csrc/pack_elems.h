@@ -97,4 +97,29 @@ __device__ __forceinline__ void pack_c1x3_value(const float* __restrict__ w, uns
     dst[0] = h; dst[512] = m; dst[1024] = l;
 }
 
+// Few-channel 3x3 bf16x3 layout (csrc/conv_s16.hip): halfwords [step 5][part 3][OutP/16][lane 64][8] - the A fragments of the five
+// tap-pair steps: row = cout tile * 16 + (lane & 15), k = (lane >> 4) * 8 + j = tap 2 s + (lane >> 5), channel ((lane >> 4) & 1) * 8
+// + j; the tenth tap and padded channels are zero; split by truncation (hi + mid + lo == w exactly).  dgrad: in / out channels
+// swapped, taps flipped.  v = index over [step][OutP/16][lane][8].
+__device__ __forceinline__ void pack_s16_value(const float* __restrict__ w, unsigned short* __restrict__ up, size_t v, int Cout, int Cin,
+                                               int OutP, int dgrad) {
+    const int j = (int)(v & 7), lane = (int)((v >> 3) & 63);
+    const size_t r = v >> 9;
+    const int MT = OutP / 16;
+    const int mt = (int)(r % MT), s = (int)(r / MT);
+    const int kq = lane >> 4, tap = 2 * s + (kq >> 1), ch = (kq & 1) * 8 + j, o = mt * 16 + (lane & 15);
+    float u = 0.f;
+    if (tap < 9) {
+        if (!dgrad) {
+            if (o < Cout && ch < Cin) u = w[((size_t)o * Cin + ch) * 9 + tap];
+        } else if (o < Cin && ch < Cout) {
+            u = w[((size_t)ch * Cin + o) * 9 + (8 - tap)];
+        }
+    }
+    unsigned short h, m, l;
+    split3_halfs(u, h, m, l);
+    unsigned short* dst = up + ((size_t)(s * 3) * MT + mt) * 512 + (size_t)lane * 8 + j;
+    dst[0] = h; dst[(size_t)MT * 512] = m; dst[(size_t)2 * MT * 512] = l;
+}
+
 }  // namespace pbsed

@@ -134,11 +134,11 @@ def _count(seq_host, t, rows):
 
 def _prec(precision, cin, pc=None, dgrad=False, unpool=False):
     """Operand format / algorithm of one conv launch.  bf16 modes need >= 32 input channels (below that the conv
-    is HBM-bound and the fp32 kernel is as fast).  In fp32 mode the MFMA-bound 3x3 layers run the Winograd-F(4,3)
+    is HBM-bound and keeps fp32-class arithmetic).  In fp32 mode the MFMA-bound 3x3 layers run the Winograd-F(4,3)
     kernels (csrc/conv_wino.hip: same arithmetic type and results, half the multiplications): contraction over
     >= 32 channels into >= 64 output channels of the launch (a data gradient produces the layer's cin)."""
-    if precision != 'f32':
-        return precision if cin >= 32 else 'f32'
+    if precision != 'f32' and cin >= 32:
+        return precision                 # (layers below 32 input channels run fp32-class in every mode: the rules below)
     # Conv1d layers of the fp32 path: exact three-way bf16 operand splits on the bf16 MFMA (fp32-class results) - from 96 output
     # channels of the launch on (blocks of 128) the producer / consumer kernel of csrc/conv1d_pc.hip (weights streamed from L2 in
     # fragment order, four producer waves staging x), below that the pipelined kernel of csrc/conv_bf16.hip (NS = 3)
@@ -155,6 +155,11 @@ def _prec(precision, cin, pc=None, dgrad=False, unpool=False):
         # are not 16-byte aligned (T % 4) take the fp32-MFMA Winograd kernel of csrc/conv_wino.hip inside ops.conv_fwd.
         if k_in >= 32 and n_out >= 32:
             return 'winox3'
+        # few-channel layers (contraction over <= 16 channels into <= 32: 16->16, 16->32 forward, the data gradients that
+        # contract 16 channels, the tag-conditioned 11->16 first layer): csrc/conv_s16.hip - two taps x 16 channels per K = 32
+        # MFMA, bf16x3 operands; the 1-channel first layer of the FBCRNN (9 products per output) stays on the direct kernel
+        if 2 <= k_in <= 16 and n_out <= 32:
+            return 's16x3'
     return 'f32'
 
 
@@ -311,7 +316,7 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
             if on_layer_done is not None:
                 on_layer_done(0)
             return None
-        pr = _prec('f32' if pr in ('wino', 'winox3', 'c1x3') else pr, pc.cin, pc, dgrad=True, unpool=idx is not None)
+        pr = _prec('f32' if pr in ('wino', 'winox3', 'c1x3', 's16x3') else pr, pc.cin, pc, dgrad=True, unpool=idx is not None)
         wd = pc.dgrad(pr)
         if st_in is not None:
             dz, stats = ops.conv_bwd_data(g, pc, wd, x.shape, idx, seq_dev,

@@ -214,7 +214,32 @@ class PackedConv:
         _register_pack(self.owner, self.weight, up, (self.cout, self.cin, 1, self.kw, inp.value, outp.value), 10 + dgrad, ck)
         return up
 
+    def _pack_s16(self, dgrad):
+        """Fragment-ordered three-part weights of the few-channel 3x3 kernels of csrc/conv_s16.hip (uint16)."""
+        assert self.kh == 3 and self.kw == 3
+        key = (self.owner._version, PACK_EPOCH[0], self.owner.data_ptr())
+        cache = getattr(self.owner, '_pbsed_pack', None)
+        if cache is None or cache.get('key') != key:
+            cache = {'key': key}
+            try:
+                self.owner._pbsed_pack = cache
+            except AttributeError:
+                pass
+        ck = ('s16x3', dgrad)
+        if ck in cache:
+            return cache[ck]
+        inp, outp = C.c_int(), C.c_int()
+        _lib.lib().pbsed_conv_pack_dims_s16(self.cin, self.cout, dgrad, C.byref(inp), C.byref(outp))
+        up = torch.empty(5 * 3 * (outp.value // 16) * 512, device=self.weight.device, dtype=torch.int16)
+        w = self.weight.detach().contiguous()
+        call('pbsed_pack_conv_weights_s16', ptr(w), ptr(up), self.cout, self.cin, dgrad, stream())
+        cache[ck] = up
+        _register_pack(self.owner, self.weight, up, (self.cout, self.cin, 3, 3, inp.value, outp.value), 14 + dgrad, ck)
+        return up
+
     def fwd(self, precision='f32'):
+        if precision == 's16x3':
+            return self._pack_s16(0)
         if precision == 'c1x3':
             return self._pack_c1x3(0)
         if precision == 'winox3':
@@ -224,6 +249,8 @@ class PackedConv:
         return self._pack(0) if precision == 'f32' else self._pack_bf16(0, NSPLIT[precision])
 
     def dgrad(self, precision='f32'):
+        if precision == 's16x3':
+            return self._pack_s16(1)
         if precision == 'c1x3':
             return self._pack_c1x3(1)
         if precision == 'winox3':
@@ -285,6 +312,11 @@ def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=No
              ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, int(pool), stream(),
              tag=_conv_tag(b, cin, pc, f, t) + ' ' + precision, flops=_conv_flops(b, cin, pc, f, t))
         return y, idx, stats
+    if precision == 's16x3':
+        call('pbsed_conv_fwd_s16', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
+             ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, int(pool), stream(),
+             tag=_conv_tag(b, cin, pc, f, t) + ' s16x3', flops=_conv_flops(b, cin, pc, f, t))
+        return y, idx, stats
     if precision != 'f32':
         call('pbsed_conv_fwd_bf16', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
              ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, pc.kh, pc.kw, int(pool),
@@ -325,6 +357,11 @@ def conv_bwd_data(g, pc, wd, x_shape, unpool_idx=None, seq_len=None, bn=None, re
         call('pbsed_conv_bwd_data_' + precision, ptr(g), ptr(wd), ptr(unpool_idx), ptr(seq_len), ptr(dz), ptr(bx),
              ptr(bmean), ptr(binv), ptr(bsc), ptr(bsh), int(relu), ptr(stats), b, cin, pc.cout, f, t, stream(),
              tag=_conv_tag(b, cin, pc, f, t) + ' ' + precision, flops=_conv_flops(b, cin, pc, f, t))
+        return dz, stats
+    if precision == 's16x3':
+        call('pbsed_conv_bwd_data_s16', ptr(g), ptr(wd), ptr(unpool_idx), ptr(seq_len), ptr(dz), ptr(bx),
+             ptr(bmean), ptr(binv), ptr(bsc), ptr(bsh), int(relu), ptr(stats), b, cin, pc.cout, f, t, stream(),
+             tag=_conv_tag(b, cin, pc, f, t) + ' s16x3', flops=_conv_flops(b, cin, pc, f, t))
         return dz, stats
     if precision != 'f32':
         call('pbsed_conv_bwd_data_bf16', ptr(g), ptr(wd), ptr(unpool_idx), ptr(seq_len), ptr(dz), ptr(bx),

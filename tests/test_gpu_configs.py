@@ -999,7 +999,7 @@ def test_c3_conv_launches_in_situ(precision):
         for j, (_, conv_l, norm, x, scale, shift, idx, st, pr) in enumerate(layers):
             lname = names[conv_l]
             if precision == 'bf16':
-                assert pr in ('bf16', 'f32') and (pr == 'bf16') == (conv_l.conv.in_channels >= 32), (lname, pr)
+                assert pr in ('bf16', 'f32', 's16x3') and (pr == 'bf16') == (conv_l.conv.in_channels >= 32), (lname, pr)
             rnd = _rbf if pr == 'bf16' else (lambda v: v.double())
             n_bf16 += pr == 'bf16'
             w, bias = conv_l.conv.weight.detach().cpu(), conv_l.conv.bias.detach().cpu()

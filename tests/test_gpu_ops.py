@@ -668,6 +668,68 @@ def test_conv_winograd_vs_torch(case, prec):
         close(g, xr.grad, atol=2e-4, rtol=1e-3, name='conv_dgrad wino')
 
 
+S16_CASES = [
+    # cin, cout, F, T, B, pool, prologue
+    (16, 16, 8, 133, 3, True, True),         # the 16->16 + pool layer; odd T, tiles with partial rows / columns
+    (16, 32, 6, 64, 2, False, True),         # 16->32: two cout tiles per block (2 x 2 waves), F not a multiple of 4
+    (11, 16, 4, 70, 3, False, False),        # the tag-conditioned first layer: 11 input channels, no prologue
+    (16, 16, 128, 500, 2, True, True),       # real layer size: many tiles per persistent block
+    (5, 7, 3, 1, 2, False, True),            # one frame, tiny channel counts, F = 3
+    (16, 24, 10, 200, 9, True, False),       # cout off the 16 / 32 tiles, 9 clips
+]
+
+
+@pytest.mark.parametrize('cin,cout,f,t,b,pool,pro', S16_CASES)
+def test_conv_few_channel_bf16x3_vs_torch(cin, cout, f, t, b, pool, pro):
+    """csrc/conv_s16.hip: 3x3 conv over <= 16 channels on the bf16 MFMA (two taps x 16 channels per K = 32 step, exact
+    three-way operand splits): forward (prologue, bias, pool + argmax, statistics) and data gradient (plain, through the pool
+    argmax, and with the BN-ReLU-backward epilogue) at the fp32 tolerances of the direct kernel, and against that kernel."""
+    from pb_sed_amd import ops
+    torch.manual_seed(1)
+    k = (3, 3)
+    x = torch.randn(b, cin, f, t, dtype=torch.float64)
+    w = (torch.randn(cout, cin, *k, dtype=torch.float64) / np.sqrt(cin * 9))
+    bias = torch.randn(cout, dtype=torch.float64)
+    seq = np.maximum(np.array([t] + [max(t - 7 * i, 1) for i in range(1, b)]), 1)
+    scale = (torch.rand(cin, dtype=torch.float64) + .5) if pro else None
+    shift = torch.randn(cin, dtype=torch.float64) * .3 if pro else None
+    xr = x.clone().requires_grad_()
+    y_ref = _conv_ref(xr, w, bias, scale, shift, seq, k, pool)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    dx = lambda a: None if a is None else a.float().to(DEV).contiguous()
+    seq_dev = torch.as_tensor(seq, dtype=torch.int32).to(DEV)
+    pc = ops.PackedConv(dx(w))
+    xd = dx(x)
+    y, idx, stats = ops.conv_fwd(xd, pc, pc.fwd('s16x3'), bias=dx(bias), scale=dx(scale), shift=dx(shift), relu=True,
+                                 seq_len=seq_dev, pool=pool, want_stats=True, precision='s16x3')
+    close(y, y_ref, name='conv_fwd s16x3')
+    m = (torch.arange(t)[None] < torch.as_tensor(seq)[:, None]).double()[:, None, None, :]
+    yd = y_ref.detach()
+    close(stats.sum(0)[:, 0], (yd * m).sum((0, 2, 3)), atol=1e-3, rtol=1e-4, name='stats_sum s16x3')
+    close(stats.sum(0)[:, 1], (yd * yd * m).sum((0, 2, 3)), atol=1e-3, rtol=1e-4, name='stats_sumsq s16x3')
+    yd_, idx_d, _ = ops.conv_fwd(xd, pc, pc.fwd(), bias=dx(bias), scale=dx(scale), shift=dx(shift), relu=True,
+                                 seq_len=seq_dev, pool=pool)
+    assert (y - yd_).abs().max().item() < 2e-5 * max(yd_.abs().max().item(), 1.)          # the direct fp32 kernel
+    if pool:
+        valid = (torch.arange(t, device=DEV)[None] < seq_dev[:, None])[:, None, None, :]
+        assert ((idx != idx_d) & valid).float().mean().item() < 2e-3      # near-ties of the pooled rows may resolve differently
+    # data gradient of a layer that CONTRACTS <= 16 channels: roles swapped (this layer's cout must be <= 16)
+    if cout <= 16:
+        if not pro:
+            g, _ = ops.conv_bwd_data(dx(gy), pc, pc.dgrad('s16x3'), xd.shape, idx, None, precision='s16x3')
+            close(g, xr.grad, atol=2e-4, rtol=1e-3, name='conv_dgrad s16x3')
+        else:
+            # BN-ReLU-backward epilogue: dz = conv^T(unpool(gy)) * relu' * mask and its (sum dz, sum dz xhat) statistics,
+            # against the direct kernel's epilogue on the same inputs
+            mean, invstd = dx(torch.randn(cin, dtype=torch.float64) * .1), dx(torch.rand(cin, dtype=torch.float64) + .5)
+            bn = (xd, mean, invstd, dx(scale), dx(shift))
+            g1, st1 = ops.conv_bwd_data(dx(gy), pc, pc.dgrad('s16x3'), xd.shape, idx, seq_dev, bn=bn, precision='s16x3')
+            g0, st0 = ops.conv_bwd_data(dx(gy), pc, pc.dgrad(), xd.shape, idx, seq_dev, bn=bn)
+            close(g1, g0.double().cpu(), atol=2e-4, rtol=1e-3, name='conv_dgrad + BN-ReLU backward s16x3')
+            close(st1.sum(0), st0.sum(0).double().cpu(), atol=2e-3, rtol=1e-3, name='BN backward sums s16x3')
+
+
 C1X3_CASES = [
     # cin, cout, kw, T, B, prologue
     (256, 256, 3, 500, 3, True),          # the CNN1d shape: 4 time tiles per clip, the last one partial
