@@ -12,13 +12,14 @@
 //   tap has zero weights).  30 bf16 MFMAs per 16 t x 16 cout instead of 36 fp32 MFMAs at a sixteenth of the rate.
 //
 // Block = 256 threads, PERSISTENT over (clip, 4-row, 64-t) tiles: the pre-split weights (fragment order, 15 - 30 KB) are
-// copied to LDS once per block; per tile every thread stages (4 channels, 1 position) items - dword loads, lanes along t,
+// copied to LDS once per block; per tile every thread stages (4 channels, 4 positions) items - aligned 16-byte loads, lanes along t,
 // prologue (BN-apply + ReLU + mask, or the un-pool of a pooled gradient), truncation split, one 8-byte LDS store per part into
 // the image [part][row 6][position 66][16 channels] (32-byte positions, the two 16-byte halves swapped on every second group
-// of 8 positions: fragment reads conflict-free) - and the NEXT tile's loads are issued before the MFMAs of the current one.
+// of 8 positions: fragment reads conflict-free) - and the loads of the tile after next are issued as soon as a tile is staged.
 // Accumulators sit in conv_fwd_kernel's layout, so conv_epilogue.h (bias, pool + argmax byte, masked statistics, the
 // BN-ReLU-backward form of the data gradient) is reused as it is.  53 - 68 KB of LDS: two to three blocks per CU.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "conv_epilogue.h"
@@ -30,7 +31,8 @@ namespace pbsed {
 constexpr int S16_FT = 4, S16_TT = 64, S16_ROWS = S16_FT + 2, S16_POSW = S16_TT + 2;
 constexpr int S16_STEPS = 5;                                  // tap pairs (0,1) (2,3) (4,5) (6,7) (8,-)
 constexpr int S16_PART = S16_ROWS * S16_POSW * 32;            // bytes of one part of the image
-constexpr int S16_ITEMS = S16_ROWS * 4 * S16_POSW;            // (row, channel group of 4, position)
+constexpr int S16_QUADS = S16_TT / 4 + 2;                     // aligned 4-t quads of a row: t0 - 4 .. t0 + TT + 3
+constexpr int S16_ITEMS = S16_ROWS * 4 * S16_QUADS;           // (row, channel group of 4, quad): 4 channels x 4 positions each
 constexpr int S16_PER_T = (S16_ITEMS + 255) / 256;
 
 __global__ void s16_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ up, int Cout, int Cin, int OutP, int dgrad) {
@@ -81,15 +83,15 @@ __global__ __launch_bounds__(256) void conv_s16_kernel(ConvFwdArgs a, int nTiles
             sc_s[tid] = v;
         }
     }
-    // staging items of this thread: q = tid + 256 i -> (row r, channel group g, position p); fixed over the tiles
-    int it_r[S16_PER_T], it_p[S16_PER_T], it_g[S16_PER_T];
-    unsigned it_lds[S16_PER_T];
+    // staging items of this thread: q = tid + 256 i -> (row r, channel group g, quad qd): 4 channels x the 4 positions
+    // t0 - 4 + 4 qd .. + 3 (16-byte loads; image position p = t - (t0 - 1), kept when 0 <= p < POSW); fixed over the tiles
+    int it_r[S16_PER_T], it_g[S16_PER_T], it_q[S16_PER_T];
 #pragma unroll
     for (int i = 0; i < S16_PER_T; ++i) {
         const int q = tid + i * 256;
-        const int rg = q / S16_POSW, p = q - rg * S16_POSW;
-        it_r[i] = rg >> 2; it_g[i] = rg & 3; it_p[i] = p;
-        it_lds[i] = (unsigned)((it_r[i] * S16_POSW + p) * 32 + ((((rg & 3) >> 1) ^ ((p >> 3) & 1)) * 16) + (rg & 1) * 8);
+        const int rg = q / S16_QUADS;
+        it_q[i] = q - rg * S16_QUADS;
+        it_r[i] = rg >> 2; it_g[i] = rg & 3;
     }
     // B fragment offsets of the five steps: tap = 2 s + (lq >> 1), channels (lq & 1) * 8 ..; A fragment offset of this wave
     unsigned b_off[S16_STEPS];
@@ -101,78 +103,94 @@ __global__ __launch_bounds__(256) void conv_s16_kernel(ConvFwdArgs a, int nTiles
     }
     const unsigned a_off = (unsigned)(wm * 1024 + lane * 16);
 
-    unsigned rin[S16_PER_T][4], ridx[S16_PER_T];
-    unsigned ok_next = 0, ok_cur = 0;                               // bit i: item i lies inside the plane (next / current tile)
-    int nb = 0, nf0 = 0, nt0 = 0;
+    // two raw register sets: the loads of tile k + 2 are issued as soon as tile k is staged, i.e. they are in flight during the
+    // MFMAs and the epilogue of tile k AND the whole of tile k + 1 (a tile is ~4 us per block, HBM latency under load 2 - 4 us;
+    // with one set - loads issued behind the staging of the same iteration - the blocks waited for memory half of the time)
+    // (32-cout blocks keep ONE set: with two they exceed 256 registers and fall to one block per CU - 96 -> 131 us at 16->32)
+    constexpr int NSETS = COUT_T == 16 ? 2 : 1;
+    u32x4_t rin[NSETS][S16_PER_T][4];
+    unsigned ridx[NSETS][S16_PER_T][4];
+    struct TileMeta { int b, f0, t0; unsigned ok; };
+    TileMeta meta[NSETS];
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
 
-    auto load_tile = [&](int tile) __attribute__((always_inline)) {
-        nt0 = (tile % nTt) * S16_TT;
+    auto load_tile = [&](auto set_c, int tile) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value;
+        TileMeta& m = meta[SET];
+        m.t0 = (tile % nTt) * S16_TT;
         const int r2 = tile / nTt;
-        nf0 = (r2 % nFt) * S16_FT;
-        nb = r2 / nFt;
+        m.f0 = (r2 % nFt) * S16_FT;
+        m.b = r2 / nFt;
         const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(a.x) + (size_t)nb * clip_elems, 0, clip_elems * 4u, 0x00020000);
+            const_cast<float*>(a.x) + (size_t)m.b * clip_elems, 0, clip_elems * 4u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
-            unpool ? const_cast<uint8_t*>(a.unpool_idx) + (size_t)nb * clip_elems : nullptr, 0, unpool ? clip_elems : 0u, 0x00020000);
-        ok_next = 0;
+            unpool ? const_cast<uint8_t*>(a.unpool_idx) + (size_t)m.b * clip_elems : nullptr, 0, unpool ? clip_elems : 0u, 0x00020000);
+        m.ok = 0;
 #pragma unroll
         for (int i = 0; i < S16_PER_T; ++i) {
-            const int f = nf0 - 1 + it_r[i], t = nt0 - 1 + it_p[i];
-            const bool ok = (tid + i * 256 < S16_ITEMS) && f >= 0 && f < a.F && t >= 0 && t < a.T;
-            ok_next |= (unsigned)ok << i;
+            const int f = m.f0 - 1 + it_r[i], tq = m.t0 - 4 + 4 * it_q[i];
+            const bool ok = (tid + i * 256 < S16_ITEMS) && f >= 0 && f < a.F && tq >= 0 && tq < a.T;
+            m.ok |= (unsigned)ok << i;
             const int c0 = it_g[i] * 4;
-            const unsigned e0 = (unsigned)((c0 * Fsrc + (unpool ? (f >> 1) : f)) * a.T + t);
-            unsigned idx = 0;
+            const unsigned e0 = (unsigned)((c0 * Fsrc + (unpool ? (f >> 1) : f)) * a.T + tq);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const bool okc = ok && c0 + c < a.Cin;
                 const unsigned off = okc ? (e0 * 4u + (unsigned)c * ch_step) : OOB;
-                rin[i][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0);
-                if (unpool) idx |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_i, okc ? (off >> 2) : OOB, 0, 0) << (8 * c);
+                rin[SET][i][c] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+                if (unpool) ridx[SET][i][c] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, okc ? (off >> 2) : OOB, 0, 0);
             }
-            ridx[i] = idx;
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile < nTiles) load_tile(tile);
-    for (; tile < nTiles; tile += gridDim.x) {
-        const int b = nb, f0 = nf0, t0 = nt0;
-        ok_cur = ok_next;
+    auto do_tile = [&](auto set_c, int tile) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value;
+        const int b = meta[SET].b, f0 = meta[SET].f0, t0 = meta[SET].t0;
+        const unsigned ok_cur = meta[SET].ok;
         const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
         const int tlim = pro ? sl : a.T;                             // Normalization re-masks its output (y * mask)
         __syncthreads();                                             // the previous tile's fragment reads (and st_s) are done
-        // ---- stage: prologue / un-pool, split, 8-byte stores
+        // ---- stage: prologue / un-pool, split, 8-byte stores (4 channels of one position per store and part)
 #pragma unroll
         for (int i = 0; i < S16_PER_T; ++i) {
             if (tid + i * 256 >= S16_ITEMS) continue;
-            const int t = t0 - 1 + it_p[i];
-            const bool live = ((ok_cur >> i) & 1u) && t < tlim;
+            const bool inside = (ok_cur >> i) & 1u;
             const int par = (f0 - 1 + it_r[i]) & 1;
             const float4 sc = *reinterpret_cast<const float4*>(sc_s + it_g[i] * 4);
             const float4 sh = *reinterpret_cast<const float4*>(sc_s + 16 + it_g[i] * 4);
             const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-            float v[4];
+            const unsigned xv[4][4] = {{rin[SET][i][0].x, rin[SET][i][0].y, rin[SET][i][0].z, rin[SET][i][0].w},
+                                       {rin[SET][i][1].x, rin[SET][i][1].y, rin[SET][i][1].z, rin[SET][i][1].w},
+                                       {rin[SET][i][2].x, rin[SET][i][2].y, rin[SET][i][2].z, rin[SET][i][2].w},
+                                       {rin[SET][i][3].x, rin[SET][i][3].y, rin[SET][i][3].z, rin[SET][i][3].w}};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float u = __uint_as_float(rin[i][c]);
-                if (unpool) u = (int)((ridx[i] >> (8 * c)) & 0xffu) == par ? u : 0.f;
-                if (pro) {
-                    u = fmaf(u, scv[c], shv[c]);
-                    if (a.relu) u = fmaxf(u, 0.f);
+            for (int e = 0; e < 4; ++e) {
+                const int p = 4 * it_q[i] - 3 + e;                   // image position of t0 - 4 + 4 qd + e
+                if (p < 0 || p >= S16_POSW) continue;
+                const bool live = inside && (t0 - 1 + p) < tlim;
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float u = __uint_as_float(xv[c][e]);
+                    if (unpool) u = (int)((ridx[SET][i][c] >> (8 * e)) & 0xffu) == par ? u : 0.f;
+                    if (pro) {
+                        u = fmaf(u, scv[c], shv[c]);
+                        if (a.relu) u = fmaxf(u, 0.f);
+                    }
+                    v[c] = live ? u : 0.f;                            // zero padding is post-activation
                 }
-                v[c] = live ? u : 0.f;                                // zero padding is post-activation
+                unsigned h0, m0, l0, h1, m1, l1;
+                split3_pair(v[0], v[1], h0, m0, l0);
+                split3_pair(v[2], v[3], h1, m1, l1);
+                unsigned char* dst = img + (unsigned)((it_r[i] * S16_POSW + p) * 32 + ((((it_g[i] >> 1) ^ (p >> 3)) & 1) * 16) + (it_g[i] & 1) * 8);
+                *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(dst + S16_PART) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2*>(dst + 2 * S16_PART) = make_uint2(l0, l1);
             }
-            unsigned h0, m0, l0, h1, m1, l1;
-            split3_pair(v[0], v[1], h0, m0, l0);
-            split3_pair(v[2], v[3], h1, m1, l1);
-            unsigned char* p = img + it_lds[i];
-            *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(p + S16_PART) = make_uint2(m0, m1);
-            *reinterpret_cast<uint2*>(p + 2 * S16_PART) = make_uint2(l0, l1);
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < nTiles) load_tile(tile + gridDim.x);   // in flight during the MFMAs and the epilogue
+        if (tile + NSETS * (int)gridDim.x < nTiles) load_tile(set_c, tile + NSETS * (int)gridDim.x);     // this set is free again
         // ---- MFMAs
         f32x4 acc[1][C::NTW];
 #pragma unroll
@@ -195,6 +213,18 @@ __global__ __launch_bounds__(256) void conv_s16_kernel(ConvFwdArgs a, int nTiles
             }
         }
         conv_epilogue<COUT_T, S16_FT, S16_TT, 1, C::NTT, C::WN, POOL, DGRAD>(a, acc, st_s, b, f0, t0, 0, sl, wm, wn, lq, lr, tid);
+    };
+
+    const int first = blockIdx.x, stride = gridDim.x;
+    if (first < nTiles) load_tile(I0{}, first);
+    if constexpr (NSETS == 2) {
+        if (first + stride < nTiles) load_tile(I1{}, first + stride);
+        for (int tile = first; tile < nTiles; tile += 2 * stride) {
+            do_tile(I0{}, tile);
+            if (tile + stride < nTiles) do_tile(I1{}, tile + stride);
+        }
+    } else {
+        for (int tile = first; tile < nTiles; tile += stride) do_tile(I0{}, tile);
     }
 }
 
@@ -205,6 +235,7 @@ static int launch_s16(const ConvFwdArgs& a, hipStream_t s) {
         set_error("conv_s16: one clip of the input / output must stay below 1 GiB / 512 MiB (Cin=%d Cout=%d F=%d T=%d)", a.Cin, a.Cout, a.F, a.T);
         return PBSED_E_ARG;
     }
+    if (a.T & 3) { set_error("conv_s16: T = %d is not a multiple of 4 (rows must be 16-byte aligned; use the direct kernel)", a.T); return PBSED_E_UNSUPPORTED; }
     const int nTt = (a.T + S16_TT - 1) / S16_TT, nFt = (a.F + S16_FT - 1) / S16_FT;
     const long long nTiles = (long long)nTt * nFt * a.B;
     if (nTiles >= (1ll << 30)) { set_error("conv_s16: too many tiles"); return PBSED_E_ARG; }

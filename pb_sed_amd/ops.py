@@ -301,6 +301,8 @@ def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=No
     assert residual is None or precision == 'f32', 'a residual add needs the fp32 direct kernel'
     if precision == 'winox3' and t % 4:               # the bf16x3 kernel needs 16-byte aligned rows: same result from the fp32 form
         precision, wp = 'wino', pc.fwd('wino')
+    if precision == 's16x3' and t % 4:                # likewise the few-channel kernel: the direct fp32 kernel takes any T
+        precision, wp = 'f32', pc.fwd()
     if precision == 'c1x3':
         assert f == 1 and pc.kh == 1 and not pool, 'the producer / consumer Conv1d kernel takes [B, C, T] tensors'
         call('pbsed_conv1d_fwd_x3', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(y),
@@ -347,6 +349,8 @@ def conv_bwd_data(g, pc, wd, x_shape, unpool_idx=None, seq_len=None, bn=None, re
         stats = _zero_stats(cin, g.device)
     if precision == 'winox3' and t % 4:
         precision, wd = 'wino', pc.dgrad('wino')
+    if precision == 's16x3' and t % 4:
+        precision, wd = 'f32', pc.dgrad()
     if precision == 'c1x3':
         assert f == 1 and pc.kh == 1 and unpool_idx is None
         call('pbsed_conv1d_bwd_data_x3', ptr(g), ptr(wd), ptr(seq_len), ptr(dz), ptr(bx), ptr(bmean), ptr(binv), ptr(bsc),
