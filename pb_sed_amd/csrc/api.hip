@@ -126,7 +126,10 @@ int pbsed_set_scratch(void* scratch, size_t bytes, void* stream) {
         if (!g_scratch[i].owned && g_scratch[i].dev == dev && g_scratch[i].stream == (hipStream_t)stream) hit = i;
     int rc = PBSED_OK;
     if (hit < 0 && scratch) {
-        if (g_scratch_n < kScratchSlots) hit = g_scratch_n++;
+        for (int i = 0; i < g_scratch_n && hit < 0; ++i)          // a withdrawn registration (scratch = NULL) frees its entry
+            if (!g_scratch[i].owned && g_scratch[i].ptr == nullptr) hit = i;
+        if (hit >= 0) {}
+        else if (g_scratch_n < kScratchSlots) hit = g_scratch_n++;
         else { set_error("pbsed_set_scratch: registration table full (%d)", kScratchSlots); rc = PBSED_E_ARG; }
     }
     if (hit >= 0) g_scratch[hit] = ScratchSlot{dev, (hipStream_t)stream, scratch ? (float*)scratch : nullptr, scratch ? bytes / sizeof(float) : 0, false, 0};

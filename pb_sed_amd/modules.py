@@ -208,6 +208,11 @@ class Normalization(nn.Module):
         no use for (momentum statistics).  Flatten the former, drop the latter (pb_sed/experiments/weak_label_crnn/
         inference.py:407-413 loads such checkpoints through ``from_storage_dir``)."""
         state_dict.pop(prefix + 'num_tracked_values', None)
+        # parameter names: this build follows SURVEY.md App. A (gamma / beta); padertorch is not vendored and its Normalization
+        # may store the affine pair as scale / shift - accept either spelling (parity unpinned: no real checkpoint to test with)
+        for theirs, ours in (('scale', 'gamma'), ('shift', 'beta')):
+            if prefix + theirs in state_dict and prefix + ours not in state_dict:
+                state_dict[prefix + ours] = state_dict.pop(prefix + theirs)
         for name in ('gamma', 'beta', 'running_mean', 'running_power'):
             v = state_dict.get(prefix + name)
             if v is not None and v.dim() != 1 and v.numel() == self.num_channels:

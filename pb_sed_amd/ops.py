@@ -382,17 +382,30 @@ def conv_bwd_data(g, pc, wd, x_shape, unpool_idx=None, seq_len=None, bn=None, re
 _SCRATCH = {}           # (device index, stream handle) -> the partial-sum scratch this side owns and registered with the library
 
 
+SCRATCH_MAX_STREAMS = 8      # registered (device, stream) scratch buffers kept alive per device (least recently used go first)
+
+
 def ensure_scratch(device):
     """The weight-gradient kernels put their partial-sum slots into a buffer of the CALLER per (device, stream)
-    (include/pbsed.h: pbsed_set_scratch); registered on first use, kept alive here."""
+    (include/pbsed.h: pbsed_set_scratch); registered on first use and kept alive here - at most SCRATCH_MAX_STREAMS per
+    device: a program that cycles through fresh streams would otherwise pin 160 MB per stream handle for ever and run into
+    the library's 64-entry registration table; the least recently used registration is withdrawn (pbsed_set_scratch(NULL))
+    and its buffer released.  The stream is the CURRENT stream of ``device``."""
     dev = torch.device(device)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream())
-    if key not in _SCRATCH:
-        with torch.cuda.device(key[0]):
-            buf = torch.empty(_lib.lib().pbsed_scratch_bytes(), dtype=torch.uint8, device=f'cuda:{key[0]}')
+    dev_i = dev.index if dev.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(dev_i):
+        key = (dev_i, stream())
+        buf = _SCRATCH.pop(key, None)
+        if buf is None:
+            mine = [k for k in _SCRATCH if k[0] == dev_i]
+            while len(mine) >= SCRATCH_MAX_STREAMS:
+                old = mine.pop(0)                        # dict order = least recently used first (entries are re-inserted on use)
+                call('pbsed_set_scratch', None, 0, old[1])
+                _SCRATCH.pop(old)
+            buf = torch.empty(_lib.lib().pbsed_scratch_bytes(), dtype=torch.uint8, device=f'cuda:{dev_i}')
             call('pbsed_set_scratch', ptr(buf), buf.numel(), key[1])
-        _SCRATCH[key] = buf
-    return _SCRATCH[key]
+        _SCRATCH[key] = buf                              # (re-)insert at the most-recently-used end
+    return buf
 
 
 def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, seq_len=None,

@@ -925,6 +925,29 @@ def test_gru_scans_with_bf16_operands_stay_close_to_the_fp32_scans(b, h, t, nl):
             assert eg < 5e-3, (c, eg)
 
 
+def test_scratch_registrations_are_bounded_over_many_streams():
+    """ops.ensure_scratch keeps at most SCRATCH_MAX_STREAMS caller-owned scratch buffers per device (least recently
+    used first out, registration withdrawn) - a program cycling through streams neither pins 160 MB per stream for ever nor
+    fills the library's registration table; weight gradients on every stream stay correct."""
+    from pb_sed_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(2, 64, 4, 32, device=DEV)
+    g = torch.randn(2, 64, 4, 32, device=DEV)
+    w = torch.randn(64, 64, 3, 3, device=DEV) * .05
+    pc = ops.PackedConv(w)
+    ref = torch.zeros_like(w)
+    ops.conv_bwd_weight(x, g, pc, ref, None, relu=False)
+    torch.cuda.synchronize()
+    for i in range(ops.SCRATCH_MAX_STREAMS + 70):            # more streams than the library's 64-entry table
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            dw = torch.zeros_like(w)
+            ops.conv_bwd_weight(x, g, pc, dw, None, relu=False)
+        st.synchronize()
+        assert (dw - ref).abs().max().item() <= 2e-4 * ref.abs().max().item(), i
+        assert sum(1 for k in ops._SCRATCH if k[0] == torch.cuda.current_device()) <= ops.SCRATCH_MAX_STREAMS
+
+
 def test_weight_gradients_on_two_streams_with_caller_owned_scratch():
     """include/pbsed.h: the only memory the library would own is the partial-sum scratch of the weight-gradient kernels;
     with pbsed_set_scratch it is the caller's per (device, stream), and two streams of one device run the slotted weight

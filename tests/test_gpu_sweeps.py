@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('tool,args', [('fuzz_conv.py', ['30', '11']), ('fuzz_gru.py', ['10', '12']),
+@pytest.mark.parametrize('tool,args', [('fuzz_conv.py', ['30', '11']), ('fuzz_gru.py', ['7', '12']),
                                        ('fuzz_postproc.py', ['24', '13']), ('fuzz_frontend.py', ['12', '14']),
                                        ('fuzz_model.py', ['10', '15']), ('fuzz_gru_wgrad.py', ['30', '16'])])
 def test_randomised_sweep(tool, args):

@@ -126,6 +126,32 @@ def test_from_storage_dir_round_trip(tmp_path):
     assert torch.allclose(fe.inv_std, 1 / torch.sqrt(fe.running_power - fe.running_mean ** 2 + 1e-5))
 
 
+def test_normalization_accepts_scale_shift_spelling_in_a_strict_load():
+    """a checkpoint whose Normalization stores the affine pair as scale / shift (broadcast-shaped, with a
+    num_tracked_values counter) loads STRICTLY - no missing or unexpected keys - into gamma / beta."""
+    from pb_sed_amd import modules
+    torch.manual_seed(0)
+    net = modules.CNN2d(1, [4, 6], 3, pool_size=1)
+    sd = {}
+    for k, v in net.state_dict().items():
+        if k.endswith('.norm.gamma'):
+            sd[k[:-5] + 'scale'] = torch.randn_like(v).reshape(1, -1, 1, 1)
+        elif k.endswith('.norm.beta'):
+            sd[k[:-4] + 'shift'] = torch.randn_like(v).reshape(1, -1, 1, 1)
+        else:
+            sd[k] = torch.randn_like(v).reshape((1, -1, 1, 1)) if '.norm.running' in k else torch.randn_like(v)
+    norms = [k for k in sd if k.endswith('.norm.scale')]
+    assert norms
+    for k in norms:
+        sd[k[:-5] + 'num_tracked_values'] = torch.zeros(1)
+    want = {k: v.clone() for k, v in sd.items()}
+    missing, unexpected = net.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    for k in norms:
+        assert torch.equal(dict(net.state_dict())[k[:-5] + 'gamma'], want[k].reshape(-1))
+        assert torch.equal(dict(net.state_dict())[k[:-5] + 'beta'], want[k[:-5] + 'shift'].reshape(-1))
+
+
 def test_unsupported_reference_options_fail_loudly():
     from pb_sed_amd import modules
     with pytest.raises(NotImplementedError, match='dropout'):

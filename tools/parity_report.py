@@ -1,7 +1,8 @@
 """Turn the JSON lines the GPU parity tests append to gpurun_out/parity.jsonl (tests/test_gpu_configs.py::_record: per-tensor
-gradient errors against the float64 oracle with the rounding sensitivity and the fp32 CPU oracle's own error beside them, the
-measured bf16 logit / score / loss / gradient errors) into ONE committed file, profiles/parity_rNN.json, so that the gates'
-escape hatches can be audited without a GPU:   python tools/parity_report.py gpurun_out/parity.jsonl profiles/parity_r03.json"""
+gradient errors against the float64 oracle on the HIP run's branch with the free float64 run's and the fp32 CPU oracle's
+distances beside them, the bf16 figures against the bf16-operand oracle, the teacher-forced per-launch errors) into ONE
+committed file, profiles/parity_rNN.json, so that the gates can be audited without a GPU:
+    python tools/parity_report.py gpurun_out/parity.jsonl profiles/parity_r04.json"""
 import json
 import sys
 
@@ -16,9 +17,15 @@ def main(src, dst):
     summary = {}
     for name, r in records.items():
         if 'tensors' in r:
+            w = r['worst'][0]
             summary[name] = (f"{r['within_tol_outright']} of {r['tensors']} tensors within {r['tol']:g} outright, {r['failed']} failed; "
-                             f"worst {r['worst'][0]['name']} {r['worst'][0]['err']:.2e} (rounding sensitivity "
-                             f"{r['worst'][0]['rounding_sensitivity']:.2e}, fp32 CPU oracle {r['worst'][0]['fp32_cpu_oracle_err']:.2e})")
+                             f"worst {w['name']} {w['err']:.2e} on the HIP run's branch (free float64 run "
+                             f"{w.get('err_vs_free_float64_run', float('nan')):.2e}, fp32 CPU oracle vs free float64 "
+                             f"{w.get('fp32_cpu_oracle_vs_free_float64', float('nan')):.2e}); "
+                             f"{r.get('positions_the_free_float64_run_decides_differently', '?')} positions decided differently")
+        elif 'quantities' in r:
+            summary[name] = (f"{r['quantities']} quantities ({r['launches_with_bf16_operands']} launches with bf16 operands) within "
+                             f"{r['tol']:g}; worst {r['worst'][0]['name']} {r['worst'][0]['err']:.2e}")
         else:
             summary[name] = ', '.join(f'{k} {v:.2e}' for k, v in r.items() if isinstance(v, float))
     json.dump({'summary': summary, 'records': records}, open(dst, 'w'), indent=1, sort_keys=True)
