@@ -925,6 +925,56 @@ def test_gru_scans_with_bf16_operands_stay_close_to_the_fp32_scans(b, h, t, nl):
             assert eg < 5e-3, (c, eg)
 
 
+def test_persistent_scan_protocol_under_skewed_timing():
+    """A timing stress of the scans' inter-workgroup protocol (the data is the flag: tagged words, polled): the same scans with
+    the first-poll delay forced to 0 (every first look comes too early: the retry path runs at every step), to the built-in value
+    and to 4x that (consumers late), and with a second stream keeping compute units busy beside them - every run has to produce
+    BIT-IDENTICAL states, BPTT gradients and no time-out flag.  (SURVEY.md section 5 lists race tooling as optional; this is the
+    check the hand-off protocol can be given without a sanitizer.)"""
+    import ctypes as C
+    from pb_sed_amd import _lib, ops
+    torch.manual_seed(3)
+    nch, nl, b, h, t = 2, 2, 32, 256, 160
+    seq = torch.as_tensor(np.sort(np.random.RandomState(4).randint(t // 2, t + 1, b))[::-1].copy(), dtype=torch.int32).to(DEV)
+    gi0 = [torch.randn(t, b, 3 * h, device=DEV) * .5 for _ in range(nch)]
+    mk = lambda *s_: torch.randn(*s_, device=DEV) * h ** -.5
+    idx = [(c, l) for c in range(nch) for l in range(nl)]
+    w_ih, b_ih = [mk(3 * h, h) if l else None for c, l in idx], [mk(3 * h) if l else None for c, l in idx]
+    w_hh, b_hh = [mk(3 * h, h) for _ in idx], [mk(3 * h) for _ in idx]
+    w_hh_t = [ops.transpose2d(w) for w in w_hh]
+    w_up = [ops.transpose2d(w_ih[c * nl + l + 1]) if l + 1 < nl else None for c, l in idx]
+    dy = [torch.randn(t, b, h, device=DEV) * (torch.arange(t, device=DEV)[:, None, None] < seq[None, :, None]) for _ in range(nch)]
+
+    def run():
+        hs, save = ops.gru_stack_fwd(gi0, w_ih, b_ih, w_hh, b_hh, [False, True], seq, nl, save=True)
+        dgi, dgh = ops.gru_stack_bwd(w_hh_t, w_up, hs, save, dy, [False, True], seq, nl)
+        ops.check_gru_sync()
+        return [v.clone() for v in hs + dgi + dgh]
+    base = run()                                        # (tunes the delays of this shape in place)
+    cur = (C.c_int * 4)()
+    _lib.call('pbsed_gru_get_poll_delays', 0, cur)
+    tuned = list(cur)
+    default = ops._POLL_DEFAULT[(torch.cuda.current_device(), 0)]
+    saved = dict(ops._POLL_TUNED)
+    try:
+        for fwd_d, bwd_d, busy in ((0, 0, False), (default[0], default[2], False), (4 * default[0], 4 * default[2], False), (tuned[0], tuned[2], True)):
+            for k in [k for k in ops._POLL_TUNED if k[3][:5] == (nch, nl, b, h, t)]:
+                ops._POLL_TUNED[k] = fwd_d if k[2] == 0 else bwd_d
+            side = torch.cuda.Stream()
+            if busy:                                    # something else holds compute units while the scans run
+                with torch.cuda.stream(side):
+                    junk = torch.randn(2048, 2048, device=DEV)
+                    for _ in range(20):
+                        junk = junk @ junk * 1e-3
+            got = run()
+            side.synchronize()
+            for i, (a, r) in enumerate(zip(got, base)):
+                assert torch.equal(a, r), f'delays ({fwd_d}, {bwd_d}) busy={busy}: tensor {i} differs'
+    finally:
+        ops._POLL_TUNED.clear()
+        ops._POLL_TUNED.update(saved)
+
+
 def test_scratch_registrations_are_bounded_over_many_streams():
     """ops.ensure_scratch keeps at most SCRATCH_MAX_STREAMS caller-owned scratch buffers per device (least recently
     used first out, registration withdrawn) - a program cycling through streams neither pins 160 MB per stream for ever nor
