@@ -144,7 +144,11 @@ def cpu_train_baseline(kind, batches=(32, 16), steps=3):
     res = {}
     for batch in batches:
         torch.manual_seed(0)
-        model = (om.FBCRNN.build() if kind == 'c2' else om.BiCRNN.build(tag_conditioning=True)).train()
+        if kind == 'deep':
+            from pb_sed_amd.modules import DEEP                  # the net_config dictionary only (no device code)
+            model = om.FBCRNN.build(num_events=10, hidden_size=512, net=DEEP).train()
+        else:
+            model = (om.FBCRNN.build() if kind == 'c2' else om.BiCRNN.build(tag_conditioning=True)).train()
         opt = torch.optim.Adam(model.parameters(), lr=5e-4)
         b = synth_batch(batch, 'cpu', kind=kind)
         times, stages = [], []
@@ -157,7 +161,7 @@ def cpu_train_baseline(kind, batches=(32, 16), steps=3):
             st['front_end_incl_stft'] = time.perf_counter() - t0
             opt.zero_grad()
             t1 = time.perf_counter()
-            if kind == 'c2':
+            if kind in ('c2', 'deep'):
                 h, seq_h = model.cnn(x, seq_x)
                 st['cnn_fwd'] = time.perf_counter() - t1
                 t1 = time.perf_counter()
@@ -193,7 +197,7 @@ def cpu_train_baseline(kind, batches=(32, 16), steps=3):
         res[batch] = {'clips_per_s': round(batch / dt, 3), 's_per_step': round(dt, 3), 'timed_steps': len(timed),
                       'stage_s': {k: round(v, 3) for k, v in med.items()}}
     main_b = batches[0]
-    what = 'FBCRNN' if kind == 'c2' else 'tag-conditioned BiCRNN'
+    what = {'c2': 'FBCRNN', 'deep': "FBCRNN net_config 'deep' width 2"}.get(kind, 'tag-conditioned BiCRNN')
     out = {'value': res[main_b]['clips_per_s'], 'unit': 'clips/s', 'cores': n, 'kind': 'port',
            'sample': f'oracle (stock-PyTorch CPU restatement, fp32) {what} train step incl. STFT, batch {main_b} x 10 s clips, '
                      f'1 warm-up + {res[main_b]["timed_steps"]} timed steps, median',
@@ -540,7 +544,7 @@ def bench_train(args, kind, world, rank, device, sustained_steps=0):
     if os.environ.get('PBSED_BENCH_TABLE'):
         print_table(agg, ev_steps)
     if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_train_baseline(kind, batches=(32, 16) if kind == 'c2' else (32,))
+        out['cpu_baseline'] = cpu_train_baseline(kind, batches={'c2': (32, 16), 'deep': (8,)}.get(kind, (32,)))
     return out
 
 

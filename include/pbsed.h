@@ -329,7 +329,7 @@ int pbsed_transpose2d(const float* src, float* dst, int R, int C, void* stream);
 int pbsed_gru_wgrad(int n, const float* const* dg, const float* const* x, const int* shift /*host*/,
                     float* const* dw, float* const* db, int T, int B, int G, int K, void* stream);
 /* The fp32 entry point computes the products with exact three-way bf16 operand splits on the bf16 MFMA (fp32-class
- * results; PBSED_GRU_WGRAD_X3=0 selects the fp32-MFMA kernel).  pbsed_gru_wgrad_multi: the same for GEMMs of different
+ * results).  pbsed_gru_wgrad_multi: the same for GEMMs of different
  * width in ONE launch (K: host array of n input widths; dw[i] is [G, K[i]]) - all weight gradients of a GRU backward pass
  * together; bf16 != 0: plain bf16 operands with fp32 accumulation, the bf16 training mode (BASELINE.json configs[2]). */
 int pbsed_gru_wgrad_multi(int n, const float* const* dg, const float* const* x, const int* shift /*host*/,

@@ -1033,7 +1033,7 @@ static void granule_poll_delays(bool bwd, GruStackArgs& a, int nb = 1) {
 }  // extern "C"
 
 // bf16: plain bf16 operands of the recurrent / projection products (fp32 state, accumulation and gate maths) - the scans of
-// the bf16 training mode (BASELINE.json configs[2]); else fp32-class products (bf16x3, or the fp32 MFMA with PBSED_GRU_X3=0).
+// the bf16 training mode (BASELINE.json configs[2]); else fp32-class products (bf16x3).
 static int gru_stack_fwd_granule_impl(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
                                       const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
                                       float* const* hs, float* const* save, const int* reverse, const int* seq_len, int B,

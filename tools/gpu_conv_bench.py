@@ -1,6 +1,6 @@
 """Micro-benchmark (GPU box): time conv fwd / dgrad / wgrad of every FBCRNN layer shape at batch 32.
 The library reads its switches from the environment once per process (README.md, "Environment switches"), so A/B
-runs are separate processes:   PBSED_WGRAD_WINO=0 python tools/gpu_conv_bench.py"""
+runs are separate processes (tools/kernel_ablation.sh builds variants of one kernel: PBSED_LIB=... python tools/gpu_conv_bench.py)"""
 import os
 import sys
 

@@ -1,4 +1,4 @@
-"""Time pbsed_gru_wgrad_multi on the shapes of the bench configs (run once per PBSED_GRU_WGRAD_PC value: the switch is read once).
+"""Time pbsed_gru_wgrad_multi on the shapes of the bench configs (historic: round 3 compared kernel forms through PBSED_GRU_WGRAD_PC; the switch is read once).
 c2: 8 x [768 x 256] over 16 000 rows (FBCRNN 2 x 2 stack), c3: 4 x [768 x 256] + ... per BiGRU layer, deep: 8 x [1536 x 512]."""
 import os
 import sys
@@ -38,7 +38,7 @@ def main():
             ms = e0.elapsed_time(e1) / n
             fl = 2. * t * b * g * sum(ks)
             print(f'{name} {precision}: {ms * 1e3:.1f} us  {fl / ms / 1e9:.0f} TFLOP/s fp32-equivalent'
-                  f'  (PBSED_GRU_WGRAD_PC={os.environ.get("PBSED_GRU_WGRAD_PC", "1")})', flush=True)
+                  '', flush=True)
 
 
 if __name__ == '__main__':

@@ -3,7 +3,7 @@
 # (macro bits: 1 no producer global loads, 2 no producer transform / LDS stores, 4 no streamed operand (winox3: U),
 # 8 no consumer LDS reads / MFMAs) into gpurun_out/abl/ and times them.  GPU box only:
 #   bash tools/kernel_ablation.sh conv_winox3 WX_DBG   'NOERR=1 PRECS=winox3 ONLY=128x128 python tools/wino_bench.py'
-#   bash tools/kernel_ablation.sh conv_wgrad  WGPC_DBG 'PBSED_WGRAD_X3=4 ONLY=128x128 python tools/gpu_conv_bench.py'
+#   bash tools/kernel_ablation.sh conv_wgrad  WGPC_DBG 'ONLY=128x128 python tools/gpu_conv_bench.py'
 set -e
 cd "$(dirname "$0")/.."
 src=$1; macro=$2; cmd=$3
