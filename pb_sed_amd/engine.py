@@ -30,7 +30,7 @@ def seq_to_device(seq_host, device):
     if t is None:
         if len(_SEQ_CACHE) > 4096:
             _SEQ_CACHE.clear()
-        t = torch.as_tensor(np.asarray(seq_host), dtype=torch.int32).to(device)
+        t = ops.host_to_device(np.asarray(seq_host), device, torch.int32)
         _SEQ_CACHE[key] = t
     return t
 

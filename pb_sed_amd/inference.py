@@ -3,10 +3,11 @@
 ``sound_event_detection`` / ``inference``) with the whole post-processing chain on the GPU.
 
 Per batch: every model's inference head runs on the device (HIP path), the scores stay there, and
-mean over models -> sequence mask -> median filter -> (boundaries filter) -> tag masking are HIP kernels
+mean over models -> sequence mask -> median filter -> (boundaries filter) are HIP kernels
 that are bit-exact with the reference's numpy/scipy host code (tests/test_gpu_postproc.py replays the
 reference's own golden vectors).  Only the final per-clip ``[(n,)T,K]`` arrays go to the host, keyed by
-``example_id`` like the reference's result dict.
+``example_id`` like the reference's result dict.  One batch is kept in flight: batch n + 1 is queued before the host
+waits for batch n's scores (pinned buffer + event), so the per-clip host work overlaps the next batch's kernels.
 
 Long clips: ``max_segment_length`` / ``segment_overlap`` / ``merge_score_segments`` / ``score_segment_overlap`` split
 every batch into overlapping windows and merge the per-segment scores as the reference does
@@ -41,12 +42,15 @@ def filtering(scores, filter_fn, filter_length):
     return filter_fn(scores, np.broadcast_to(filter_length, (n, k)))
 
 
-def postprocess_batch(model_scores, seq_len, example_ids, *, medfilt_length=1, stepfilt_length=None,
-                      apply_mask=False, masks=None, post_processing_fn=None):
-    """inference.py:142-184 for one batch.  model_scores: list (one per model) of device tensors
-    [B,(n,)K,T]; seq_len: host int array [B].  Returns {example_id: np.ndarray [(n,)T,K]}."""
+def postprocess_enqueue(model_scores, seq_len, example_ids, *, medfilt_length=1, stepfilt_length=None,
+                        apply_mask=False, masks=None, post_processing_fn=None):
+    """Device half of inference.py:142-184 for one batch: ensemble mean -> sequence mask -> median filter ->
+    (boundaries filter) as HIP kernels, then an asynchronous copy of the result into pinned host memory and an event
+    behind it.  Nothing here waits for the device: ``postprocess_finish`` does, so a caller can enqueue the next batch
+    first.  model_scores: list (one per model) of device tensors [B,(n,)K,T]; seq_len: host int array [B]."""
     dev = model_scores[0].device
-    seq_dev = torch.as_tensor(np.asarray(seq_len), dtype=torch.int32).to(dev)
+    seq_len = np.asarray(seq_len)
+    seq_dev = ops.host_to_device(seq_len, dev, torch.int32)
     s = ops.ensemble_mean_mask(model_scores, seq_dev)
     s = filtering(s, ops.medfilt, np.array(medfilt_length, dtype=int))
     if stepfilt_length is not None:
@@ -55,12 +59,24 @@ def postprocess_batch(model_scores, seq_len, example_ids, *, medfilt_length=1, s
             s = ops.boundariesfilt(s, sl_arr, want_f64=True)
         else:
             s = filtering(s, ops.boundariesfilt, sl_arr)
-    s = s.cpu().numpy()
+    slot = ops.pinned_buffer(s.shape, s.dtype, hold=True)
+    slot[0].copy_(s, non_blocking=True)
+    return {'slot': slot, 'done': ops.pinned_buffer_used(slot), 'seq_len': seq_len, 'example_ids': list(example_ids), 'apply_mask': apply_mask,
+            'masks': masks, 'post_processing_fn': post_processing_fn}
+
+
+def postprocess_finish(pending):
+    """Host half: wait for the batch's copy, cut the per-clip ``[(n,)T,K]`` arrays (own memory: the pinned buffer is
+    reused), apply the per-clip function and the tag masks.  Returns {example_id: np.ndarray}."""
+    pending['done'].synchronize()
+    s = np.array(pending['slot'][0].numpy())
+    pending['slot'][2] = False
+    post_processing_fn, masks = pending['post_processing_fn'], pending['masks']
     out = {}
-    for i, (aid, sl) in enumerate(zip(example_ids, seq_len)):
+    for i, (aid, sl) in enumerate(zip(pending['example_ids'], pending['seq_len'])):
         x = s[i, ..., :sl].swapaxes(-2, -1)
         out[aid] = x if post_processing_fn is None else post_processing_fn(x)
-    apply_mask = np.array(apply_mask, dtype=bool)
+    apply_mask = np.array(pending['apply_mask'], dtype=bool)
     if apply_mask.any():
         assert masks is not None
         if apply_mask.ndim == 2:
@@ -70,6 +86,11 @@ def postprocess_batch(model_scores, seq_len, example_ids, *, medfilt_length=1, s
             out[aid] = np.array(out[aid])
             out[aid] *= np.maximum(masks[aid], 1 - apply_mask)        # in place: stays float32
     return out
+
+
+def postprocess_batch(model_scores, seq_len, example_ids, **kw):
+    """inference.py:142-184 for one batch, both halves back to back.  Returns {example_id: np.ndarray [(n,)T,K]}."""
+    return postprocess_finish(postprocess_enqueue(model_scores, seq_len, example_ids, **kw))
 
 
 def create_score_dataframe(scores, timestamps, event_classes):
@@ -114,6 +135,44 @@ def inference(model, method, dataset, device, max_segment_length=None, segment_o
         m.to(device)
         m.eval()
     scores = {}
+
+    def enqueue(batch):
+        """Everything of one batch that runs on the device, queued without waiting for it."""
+        segments = [batch] if max_segment_length is None else segment_batch(batch, max_segment_length, segment_overlap)
+        queued = []
+        for segment in segments:
+            segment = models[0].example_to_device(segment, device)
+            per_model, seq_len = [], None
+            for m, kw in zip(models, kwargs):
+                y, sl = getattr(m, method)(segment, **kw)
+                per_model.append(_as_dev_scores(y, device))
+                if seq_len is None:
+                    seq_len = np.asarray(sl)
+                else:
+                    assert (np.asarray(sl) == seq_len).all(), (seq_len, sl)
+            seg_masks = masks
+            if masks is not None and len(segments) > 1:       # tags are keyed by clip, segments by clip + position
+                seg_masks = {a: masks[a.split('_!segment!_')[0]] for a in segment['example_id']}
+            queued.append(postprocess_enqueue(per_model, seq_len, segment['example_id'], medfilt_length=medfilt_length,
+                                              stepfilt_length=stepfilt_length, apply_mask=apply_mask, masks=seg_masks,
+                                              post_processing_fn=post_processing_fn))
+        return queued, segments[-1]['example_id'][0], ops.gru_flags_snapshot()
+
+    def finish(pending):
+        queued, last_id, flags = pending
+        cache = {}
+        for q in queued:
+            cache.update(postprocess_finish(q))
+        ops.gru_flags_check(flags)      # copied behind the batch's scores: a timed-out persistent scan raises here
+        if merge_score_segments and not is_last_segment(last_id):
+            raise RuntimeError('a batch ended before its last segment')
+        if merge_score_segments:
+            cache = merge_segments(cache, segment_overlap if score_segment_overlap is None else score_segment_overlap)
+        scores.update(cache)
+
+    # one batch in flight: batch n + 1 is queued on the device before the host waits for batch n, so the per-clip host work
+    # of a batch (and the copy behind it) overlaps the next batch's kernels
+    pending = None
     with torch.no_grad():
         for batch in dataset:
             batch = {k: v for k, v in batch.items() if k not in ('weak_targets', 'boundary_targets', 'strong_targets')}
@@ -122,30 +181,12 @@ def inference(model, method, dataset, device, max_segment_length=None, segment_o
                 batch = shard_batch(batch, rank, world_size)
                 if not len(batch['seq_len']):            # a ragged last batch with fewer clips than ranks: nothing for this rank
                     continue
-            segments = [batch] if max_segment_length is None else segment_batch(batch, max_segment_length, segment_overlap)
-            cache = {}
-            for segment in segments:
-                segment = models[0].example_to_device(segment, device)
-                per_model, seq_len = [], None
-                for m, kw in zip(models, kwargs):
-                    y, sl = getattr(m, method)(segment, **kw)
-                    per_model.append(_as_dev_scores(y, device))
-                    if seq_len is None:
-                        seq_len = np.asarray(sl)
-                    else:
-                        assert (np.asarray(sl) == seq_len).all(), (seq_len, sl)
-                seg_masks = masks
-                if masks is not None and len(segments) > 1:       # tags are keyed by clip, segments by clip + position
-                    seg_masks = {a: masks[a.split('_!segment!_')[0]] for a in segment['example_id']}
-                cache.update(postprocess_batch(per_model, seq_len, segment['example_id'], medfilt_length=medfilt_length,
-                                               stepfilt_length=stepfilt_length, apply_mask=apply_mask, masks=seg_masks,
-                                               post_processing_fn=post_processing_fn))
-            ops.check_gru_sync()        # the scores are on the host already: a timed-out persistent scan raises here
-            if merge_score_segments and not is_last_segment(segments[-1]['example_id'][0]):
-                raise RuntimeError('a batch ended before its last segment')
-            if merge_score_segments:
-                cache = merge_segments(cache, segment_overlap if score_segment_overlap is None else score_segment_overlap)
-            scores.update(cache)
+            queued = enqueue(batch)
+            if pending is not None:
+                finish(pending)
+            pending = queued
+        if pending is not None:
+            finish(pending)
     if timestamps is not None or event_classes is not None:
         assert timestamps is not None and event_classes is not None
         return scores_to_dataframes(scores, timestamps, event_classes)
@@ -205,7 +246,7 @@ def scores_to_event_list(scores, thresholds, event_classes, timestamps, device='
         t = scores[a].shape[0]
         dense[i, :, :t] = np.asarray(scores[a], dtype=np.float32).T
         lens[i] = t
-    ev, cnt = ops.event_frames(torch.from_numpy(dense).to(device), thr[None, :], lens[:, None])
+    ev, cnt = ops.event_frames(torch.from_numpy(dense).to(device), thr[None, :], lens[:, None])      # end of the job: may wait
     ev, cnt = ev.cpu().numpy().reshape(len(ids), k, -1, 2), cnt.cpu().numpy().reshape(len(ids), k)
     out = {}
     for i, a in enumerate(ids):

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from .. import ops
 from ..configurable import Configurable
 from ..engine import flatten_parameters, seq_to_device
 
@@ -53,10 +54,16 @@ class SoundEventModel(nn.Module, Configurable, abc.ABC):
     def example_to_device(self, example, device=None):
         """Move every tensor / float ndarray of the (nested) example to ``device``."""
         def mv(v):
-            if isinstance(v, torch.Tensor):
-                return v.to(device)
+            # a copy out of pageable host memory stalls the host until the stream has drained (ops.host_to_device): pinned
+            # tensors go asynchronously, small pageable ones through a pinned staging buffer, big pageable ones as they are
             if isinstance(v, np.ndarray) and v.dtype.kind == 'f':
-                return torch.from_numpy(np.ascontiguousarray(v)).to(device)
+                v = torch.from_numpy(np.ascontiguousarray(v))
+            if isinstance(v, torch.Tensor):
+                if v.is_cuda or torch.device(device).type != 'cuda':
+                    return v.to(device)
+                if v.is_pinned():
+                    return v.to(device, non_blocking=True)
+                return ops.host_to_device(v, device) if v.numel() * v.element_size() <= (1 << 20) else v.to(device)
             if isinstance(v, dict):
                 return {k: mv(x) for k, x in v.items()}
             return v
@@ -139,7 +146,8 @@ class SoundEventModel(nn.Module, Configurable, abc.ABC):
             n_frames = int(inputs.get('num_frames', 0)) or num_frames(audio.shape[1])
             frame_pos = inputs.get('frame_pos')                  # time-warped framing drawn by data.TimeWarp
             if frame_pos is not None:
-                frame_pos = torch.as_tensor(frame_pos, dtype=torch.int32).to(audio.device).contiguous()
+                frame_pos = (frame_pos.to(device=audio.device, dtype=torch.int32) if isinstance(frame_pos, torch.Tensor)
+                             and frame_pos.is_cuda else ops.host_to_device(frame_pos, audio.device, torch.int32)).contiguous()
             return engine.features_from_audio(fe, audio, seq_dev, n_frames, seq_host,
                                               pad_front=int(inputs.get('stft_pad_front', 320)), frame_pos=frame_pos)
         return engine.features_from_stft(fe, x_in, seq_host, seq_dev)

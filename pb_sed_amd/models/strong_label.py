@@ -185,5 +185,5 @@ class CRNN(SoundEventModel):
         y, seq_len_y, *_ = self.forward(inputs)
         t = y.shape[-1]
         m = (torch.arange(t, device=y.device)[None] <
-             torch.as_tensor(np.asarray(seq_len_y), device=y.device)[:, None])[:, None, :]
+             engine.seq_to_device(seq_len_y, y.device)[:, None])[:, None, :]
         return y * m, seq_len_y

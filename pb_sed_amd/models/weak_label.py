@@ -214,7 +214,7 @@ class CRNN(SoundEventModel):
     def tagging(self, inputs):
         y_fwd, y_bwd, seq_len_y, *_ = self.forward(inputs)
         seq_len = np.ones_like(seq_len_y)
-        idx = torch.as_tensor(np.asarray(seq_len_y) - 1, device=y_fwd.device, dtype=torch.long)
+        idx = engine.seq_to_device(seq_len_y, y_fwd.device).long() - 1
         last = y_fwd[torch.arange(y_fwd.shape[0], device=y_fwd.device), :, idx][..., None]
         if y_bwd is None:
             return last, seq_len
@@ -224,7 +224,7 @@ class CRNN(SoundEventModel):
         y_fwd, y_bwd, seq_len_y, *_ = self.forward(inputs)
         t = y_fwd.shape[-1]
         m = (torch.arange(t, device=y_fwd.device)[None] <
-             torch.as_tensor(np.asarray(seq_len_y), device=y_fwd.device)[:, None])[:, None, :]
+             engine.seq_to_device(seq_len_y, y_fwd.device)[:, None])[:, None, :]
         return torch.minimum(y_fwd * m, y_bwd * m), seq_len_y
 
     def sound_event_detection(self, inputs, window_length, window_shift=1):

@@ -127,6 +127,51 @@ def test_inference_driver_end_to_end_vs_oracle():
         np.testing.assert_allclose(sed[a], ref[a], atol=1e-4)
 
 
+def test_inference_driver_keeps_a_batch_in_flight_without_changing_results():
+    """inference() queues batch n + 1 before it waits for batch n (pinned buffer + event per batch, reused buffers).  Five
+    batches of different content and (for one) different shape through one call must give, bit for bit, what five
+    one-batch calls give; a generator works as dataset and is pulled one batch ahead at most."""
+    from oracle import models as om
+    from pb_sed_amd import inference as inf
+    from pb_sed_amd.models import strong_label
+    from tests.test_gpu_model import TINY, synth_batch
+    torch.manual_seed(5)
+    kw = dict(num_events=10, number_of_filters=128, hidden_size=64, num_layers=2, net=TINY)
+    models = []
+    for _ in range(2):
+        m = strong_label.CRNN.build(tag_conditioning=True, **kw)
+        m.load_state_dict(om.BiCRNN.build(tag_conditioning=True, **kw).state_dict())
+        models.append(m)
+    batches, masks = [], {}
+    for j in range(5):
+        n = 3 if j == 2 else 4
+        wav, seq, *_ = synth_batch(n, 16000, 10, ragged=True, seed=20 + j)
+        ids = [f'b{j}_{i}' for i in range(n)]
+        cond = (torch.rand(n, 10, generator=torch.Generator().manual_seed(j)) > .5).float()
+        masks.update({a: cond[i].numpy() for i, a in enumerate(ids)})
+        batches.append({'audio_data': wav, 'seq_len': seq.tolist(), 'example_id': ids, 'tag_condition': cond})
+    ml = np.array([[1, 3, 5, 7, 9, 1, 3, 5, 7, 9], [3] * 10])
+    kwargs = dict(medfilt_length=ml, apply_mask=True, masks=masks)
+    one_by_one = {}
+    for b in batches:
+        one_by_one.update(inf.sound_event_detection(models, [dict(b)], DEV, **kwargs))
+    pulled = []
+
+    def dataset():
+        for j, b in enumerate(batches):
+            pulled.append(j)
+            yield dict(b)
+    together = inf.sound_event_detection(models, dataset(), DEV, **kwargs)
+    assert pulled == list(range(5)) and sorted(together) == sorted(one_by_one)
+    for a in one_by_one:
+        assert together[a].shape == one_by_one[a].shape
+        assert np.array_equal(together[a], one_by_one[a]), a
+    from pb_sed_amd import ops
+    assert not any(slot[2] for pool in ops._PINNED.values() for slot in pool), 'a pinned buffer is still held'
+    big = {k: len(v) for k, v in ops._PINNED.items() if int(np.prod(k[0])) >= 1000}
+    assert big and max(big.values()) <= 3, big                    # score buffers: the pipeline depth, not one per batch
+
+
 def test_medfilt_long_filters_bit_exact(golden):
     """Median filters up to 301 frames on 500-frame rows (the reference's tuning range,
     pb_sed/experiments/strong_label_crnn/tuning.py:64) incl. rows with ties and zero runs: the bisection-select kernel
