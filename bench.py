@@ -263,7 +263,7 @@ def _executed(flops, tag):
 
 def _x3(name, tag):
     """launches whose products are formed from exact three-way bf16 splits on the bf16 MFMA (6 part products each)"""
-    return tag.endswith(('winox3', 'x3pc', 'bf16x3', 'c1x3')) or name in ('pbsed_gru_wgrad_multi', 'pbsed_tm_gemm')
+    return tag.endswith(('winox3', 'x3pc', 'bf16x3', 'c1x3', 's16x3')) or name in ('pbsed_gru_wgrad_multi', 'pbsed_tm_gemm')
 
 
 def roofline_objects(agg, by_family, steps, batch, precision, gru_shape, kind):

@@ -305,6 +305,8 @@ __global__ void wgrad_slot_reduce_kernel(float* __restrict__ part, float* __rest
 static_assert(PBSED_SCRATCH_FRONT == (size_t)WGRAD_SLOTS * WGRAD_SLOT_MAX, "common.h");
 static float* wgrad_slot_scratch(hipStream_t s) { return scratch_zeroed_front(s, PBSED_SCRATCH_FRONT, PBSED_SCRATCH_FRONT); }
 
+#include "conv_wgrad_s16.h"
+
 // Shared launcher: K-split so that the grid is (close to) an integer number of full residency rounds (blocks per CU
 // from the occupancy query, n_cu * occ resident slots, one or two rounds depending on how much K there is), slotted
 // accumulation for small gradients.  C supplies TT, FT, CIN_T, COUT_T, KK, NT, LDS_FLOATS.
@@ -1655,6 +1657,7 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
         set_error("conv_wgrad: one clip of x / dy must stay below 1 GiB (Cin=%d Cout=%d F=%d T=%d)", a.Cin, a.Cout, a.F, a.T);
         return PBSED_E_ARG;
     }
+    if (wgrad_s16_takes(a, KH, KW)) return launch_wgrad_s16(a, s);      // 16-channel inputs: register-resident column walk
     // Conv1d layers of the fp32 path (F = 1 rows): exact three-way operand splits on the bf16 MFMA - fp32-class gradients - in
     // producer / consumer form from 64 channels on either side.  Measured at B = 32, T = 500: 256->256 k = 3 87 -> 67 us,
     // 2048->256 k = 1 245 -> 166 us (fp32-MFMA kernel before); a 256->256 k = 1 gradient is four 128 x 128 output tiles with

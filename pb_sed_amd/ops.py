@@ -423,10 +423,11 @@ def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, se
     # bf16x3 kernel from 64 channels on, the Winograd-F(4,3) fp32 kernel for the other 3x3 layers with >= 64 output channels
     k33 = pc.kh == 3 and pc.kw == 3
     x3pc = k33 and t % 4 == 0 and ((cin >= 64 and pc.cout >= 64) or (cin == 32 and pc.cout == 32))    # conv_wgrad_launch's rule
+    s16 = k33 and t % 4 == 0 and cin == 16 and pc.cout in (16, 32)
     wino = k33 and not x3pc and pc.cout >= 64 and cin >= 16
     call('pbsed_conv_bwd_weight', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(g),
          ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream(),
-         tag=_conv_tag(b, cin, pc, f, t) + (' x3pc' if x3pc else ' wino' if wino else ''), flops=_conv_flops(b, cin, pc, f, t))
+         tag=_conv_tag(b, cin, pc, f, t) + (' x3pc' if x3pc else ' s16x3' if s16 else ' wino' if wino else ''), flops=_conv_flops(b, cin, pc, f, t))
 
 
 def pool21_fwd(x):

@@ -132,6 +132,12 @@ CONV_CASES = [
     dict(cin=32, cout=32, f=8, t=132, k=(3, 3), pool=True, pro=True),
     dict(cin=24, cout=40, f=5, t=100, k=(3, 3), pool=False, pro=False),
     dict(cin=32, cout=128, f=4, t=64, k=(3, 3), pool=True, pro=True),
+    # ... and of the register-resident column walk (conv_wgrad_s16.h): several 16-row segments per column with a short last
+    # one, 32-t chunks cut by T and by the clip lengths, no prologue
+    dict(cin=16, cout=16, f=36, t=100, k=(3, 3), pool=True, pro=True),
+    dict(cin=32, cout=32, f=22, t=72, k=(3, 3), pool=False, pro=True),
+    dict(cin=32, cout=16, f=17, t=36, k=(3, 3), pool=False, pro=False),
+    dict(cin=16, cout=32, f=48, t=64, k=(3, 3), pool=True, pro=False),
 ]
 
 
