@@ -19,7 +19,7 @@
 namespace pbsed {
 
 constexpr int GRU_MAX_LAYERS = 4;
-constexpr int GRU_MAX_CHAINS = 2;
+constexpr int GRU_MAX_CHAINS = 6;        // both directions of three networks in one launch (ensemble inference)
 
 struct GruStackLayer {
     const float* gi;      // layer 0: [T][B][3H] (W_ih x + b_ih precomputed);  else null
@@ -561,131 +561,127 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
     const bool prof_blk = a.prof != nullptr && (int)blockIdx.x == a.prof_block;
     const bool prof_c = prof_blk && tid == GWV * 64, prof_g = prof_blk && tid == 0;
 
+    // NB = 2: the block's two batch tiles run half a step apart - tile 1 is polled, contracted and gated while tile 0's new
+    // states travel to the ring's other blocks and back (the hand-off is ~0.8 us of a 1.8 us step) -
+    // one barrier per tile and step; both tiles in one phase (poll both, contract both, gate both) put the hand-off
+    // behind twice the work instead: 2.8 us per step at B = 64 against 1.8 us staggered.
     for (int step = 0; step < a.T; ++step) {
         const int t = rev ? a.T - 1 - step : step;
         const int tp = rev ? t + 1 : t - 1;
         const bool has_prev = step > 0;
-        const int par = step & 1;                     // `red` is double-buffered: one barrier per step
+        const int par = step & 1;                     // `red` is double-buffered per tile: one barrier per tile and step
         const bool prof_now = prof_blk && step >= 200 && step < 232;
         unsigned long long* pslot = a.prof + (prof_now ? (step - 200) * 16 : 0);
         if (prof_now && prof_c) prof_stamp(pslot + 0);
         if (prof_now && prof_g) prof_stamp(pslot + 8);
-        float gi_r[NB], gi_z[NB], gi_n[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) { gi_r[nb] = gn_r[nb]; gi_z[nb] = gn_z[nb]; gi_n[nb] = gn_n[nb]; }
         // another block's time-out is looked for every 32 steps only: the agent-scope load stalls its wave
         if (tid == 0 && (step & 31) == 31 && __hip_atomic_load((gu32*)err_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err = 1;
-        f32x4 acc[NB][3];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int g = 0; g < 3; ++g) acc[nb][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float4 x[NB][NL];
         const bool contract = (is_proj || has_prev) && is_mfma;
-        if (contract) {
-            pacer.wait();
-            if (prof_now && prof_c) prof_stamp(pslot + 1);
-            const int spins = poll_tiles<NL, NB>(x, rsrc, voff0 + (unsigned)(is_proj ? t : tp) * step_t, tile_bytes, parity, rowv, err_flag);
-            if (prof_now && prof_c) { prof_stamp(pslot + 2); pslot[5] = (unsigned long long)spins; }
-        }
-        // requests issued behind the poll (loads return in order, anything older would hold the poll back):
-        // next step's input projection (first layer) / this step's projected input granules (other rings)
-        unsigned qg[NB][3];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            qg[nb][0] = qg[nb][1] = qg[nb][2] = 0u;
+            const bool p0 = nb == 0;                  // the diagnostics follow the first tile
+            float gi_r = gn_r[nb], gi_z = gn_z[nb], gi_n = gn_n[nb];
+            f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            float4 x[1][NL];
+            if (contract) {
+                pacer.wait();
+                if (prof_now && prof_c && p0) prof_stamp(pslot + 1);
+                const bool v1[1] = {rowv[nb]};
+                const int spins = poll_tiles<NL, 1>(x, rsrc, voff0 + (unsigned)(is_proj ? t : tp) * step_t + nb * tile_bytes, tile_bytes,
+                                                    parity, v1, err_flag);
+                if (prof_now && prof_c && p0) { prof_stamp(pslot + 2); pslot[5] = (unsigned long long)spins; }
+            }
+            // requests issued behind the poll (loads return in order, anything older would hold the poll back):
+            // next step's input projection (first layer) / this step's projected input granules (other rings)
+            unsigned qg[3] = {0u, 0u, 0u};
             if (!is_proj && layer > 0 && bv[nb]) {
                 const gu32* gp = g_gi + ((size_t)t * B + b[nb]) * 3 * H + j;
 #pragma unroll
-                for (int g = 0; g < 3; ++g) qg[nb][g] = __hip_atomic_load(gp + (size_t)g * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int g = 0; g < 3; ++g) qg[g] = __hip_atomic_load(gp + (size_t)g * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-        }
-        if (step + 1 < a.T) load_gi(step + 1);
-        if (contract) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
+            if (step + 1 < a.T && layer == 0 && bv[nb]) {
+                const float* gi = L.gi + ((size_t)(rev ? a.T - 2 - step : step + 1) * B + b[nb]) * 3 * H;
+                gn_r[nb] = gi[j]; gn_z[nb] = gi[H + j]; gn_n[nb] = gi[2 * H + j];
+            }
+            if (contract) {
                 if constexpr (XS > 0) {
 #pragma unroll
                     for (int m = 0; m < NM; ++m) {
-                        const BfOp<XS> xs = make_op<XS>(x[nb][2 * m], 2 * m + 1 < NL ? x[nb][2 * m + 1] : make_float4(0.f, 0.f, 0.f, 0.f));
+                        const BfOp<XS> xs = make_op<XS>(x[0][2 * m], 2 * m + 1 < NL ? x[0][2 * m + 1] : make_float4(0.f, 0.f, 0.f, 0.f));
 #pragma unroll
-                        for (int g = 0; g < 3; ++g) acc[nb][g] = mfma_op<XS>(w3[m][g], xs, acc[nb][g]);
+                        for (int g = 0; g < 3; ++g) acc[g] = mfma_op<XS>(w3[m][g], xs, acc[g]);
                     }
                 } else {
 #pragma unroll
                     for (int n = 0; n < NL; ++n)
 #pragma unroll
                         for (int g = 0; g < 3; ++g) {
-                            acc[nb][g] = mfma16(wv[n][g].x, x[nb][n].x, acc[nb][g]);
-                            acc[nb][g] = mfma16(wv[n][g].y, x[nb][n].y, acc[nb][g]);
-                            acc[nb][g] = mfma16(wv[n][g].z, x[nb][n].z, acc[nb][g]);
-                            acc[nb][g] = mfma16(wv[n][g].w, x[nb][n].w, acc[nb][g]);
+                            acc[g] = mfma16(wv[n][g].x, x[0][n].x, acc[g]);
+                            acc[g] = mfma16(wv[n][g].y, x[0][n].y, acc[g]);
+                            acc[g] = mfma16(wv[n][g].z, x[0][n].z, acc[g]);
+                            acc[g] = mfma16(wv[n][g].w, x[0][n].w, acc[g]);
                         }
                 }
             }
-        }
-        if (is_mfma) {
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+            if (is_mfma) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    red[par][wave][nb][0][red_w + r] = acc[nb][0][r];
-                    red[par][wave][nb][1][red_w + r] = acc[nb][1][r];
-                    red[par][wave][nb][2][red_w + r] = acc[nb][2][r];
-                }
-        }
-        if (prof_now && prof_c) prof_stamp(pslot + 3);
-        __syncthreads();
-        if (prof_now && prof_c) prof_stamp(pslot + 4);
-        if (prof_now && prof_g) prof_stamp(pslot + 9);
-        // some hand-off timed out: every wave leaves - but the look at the flag is a dependent LDS round trip, and the gate
-        // threads are on the step's critical path here (barrier -> reduction -> gates -> publish): they read it with the
-        // partial sums and act on it after the publish (what they publish in a failed call is discarded with the call)
-        const int err_seen = s_err;
-        if (tid >= 256 && err_seen) return;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            if (!bv[nb]) continue;
-            const size_t tb = (size_t)t * B + b[nb];
-            float s[3] = {bs_r, bs_z, bs_n};
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                s[0] += red[par][w][nb][0][red_r];
-                s[1] += red[par][w][nb][1][red_r];
-                s[2] += red[par][w][nb][2][red_r];
-            }
-            if (is_proj) {
-                gu32* dst = g_gi + tb * 3 * H + j;
-#pragma unroll
-                for (int g = 0; g < 3; ++g) publish(dst + (size_t)g * H, tag_clear(s[g]), parity);
-            } else {
-                if (layer > 0) {
-                    wait_own_granules<3>(qg[nb], g_gi + tb * 3 * H + j, (size_t)H, parity, err_flag);
-                    gi_r[nb] = __uint_as_float(qg[nb][0] & ~1u); gi_z[nb] = __uint_as_float(qg[nb][1] & ~1u);
-                    gi_n[nb] = __uint_as_float(qg[nb][2] & ~1u);
-                }
-                const float ghn = s[2];
-                if (prof_now && prof_g && nb == 0) prof_stamp(pslot + 10);
-                const float r = gate_sigmoid(gi_r[nb] + s[0]);
-                const float z = gate_sigmoid(gi_z[nb] + s[1]);
-                const float n = gate_tanh(gi_n[nb] + r * ghn);
-                const float hp = h_reg[nb];
-                const float h = tag_clear((t < sl[nb]) ? (1.f - z) * n + z * hp : 0.f);    // the state IS the truncated value
-                h_reg[nb] = h;
-                publish(g_own + (size_t)t * Bp * H + (size_t)nb * (H / 16) * 256 + (tid & 255), h, parity);
-                if (prof_now && prof_g && nb == 0) prof_stamp(pslot + 11);
-                L.hs[tb * H + j] = h;
-                if (L.save) {
-                    // what BPTT multiplies dh_t with: d(r,z,n pre-activations)/dh, d(gh_n)/dh and z (granule save format)
-                    float* sv = L.save + tb * 5 * H + j;
-                    const float cn = (1.f - z) * (1.f - n * n);
-                    sv[0] = cn * ghn * r * (1.f - r); sv[H] = (hp - n) * z * (1.f - z); sv[2 * H] = cn;
-                    sv[3 * H] = cn * r; sv[4 * H] = z;
+                    red[par][wave][nb][0][red_w + r] = acc[0][r];
+                    red[par][wave][nb][1][red_w + r] = acc[1][r];
+                    red[par][wave][nb][2][red_w + r] = acc[2][r];
                 }
             }
+            if (prof_now && prof_c && p0) prof_stamp(pslot + 3);
+            __syncthreads();
+            if (prof_now && prof_c && p0) prof_stamp(pslot + 4);
+            if (prof_now && prof_g && p0) prof_stamp(pslot + 9);
+            // some hand-off timed out: every wave leaves - but the look at the flag is a dependent LDS round trip, and the gate
+            // threads are on the step's critical path here (barrier -> reduction -> gates -> publish): they read it with the
+            // partial sums and act on it after the publish (what they publish in a failed call is discarded with the call)
+            const int err_seen = s_err;
+            if (tid >= 256 && err_seen) return;
+            if (bv[nb]) {
+                const size_t tb = (size_t)t * B + b[nb];
+                float sm[3] = {bs_r, bs_z, bs_n};
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    sm[0] += red[par][w][nb][0][red_r];
+                    sm[1] += red[par][w][nb][1][red_r];
+                    sm[2] += red[par][w][nb][2][red_r];
+                }
+                if (is_proj) {
+                    gu32* dst = g_gi + tb * 3 * H + j;
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) publish(dst + (size_t)g * H, tag_clear(sm[g]), parity);
+                } else {
+                    if (layer > 0) {
+                        wait_own_granules<3>(qg, g_gi + tb * 3 * H + j, (size_t)H, parity, err_flag);
+                        gi_r = __uint_as_float(qg[0] & ~1u); gi_z = __uint_as_float(qg[1] & ~1u);
+                        gi_n = __uint_as_float(qg[2] & ~1u);
+                    }
+                    const float ghn = sm[2];
+                    if (prof_now && prof_g && p0) prof_stamp(pslot + 10);
+                    const float r = gate_sigmoid(gi_r + sm[0]);
+                    const float z = gate_sigmoid(gi_z + sm[1]);
+                    const float n = gate_tanh(gi_n + r * ghn);
+                    const float hp = h_reg[nb];
+                    const float h = tag_clear((t < sl[nb]) ? (1.f - z) * n + z * hp : 0.f);    // the state IS the truncated value
+                    h_reg[nb] = h;
+                    publish(g_own + (size_t)t * Bp * H + (size_t)nb * (H / 16) * 256 + (tid & 255), h, parity);
+                    if (prof_now && prof_g && p0) prof_stamp(pslot + 11);
+                    L.hs[tb * H + j] = h;
+                    if (L.save) {
+                        // what BPTT multiplies dh_t with: d(r,z,n pre-activations)/dh, d(gh_n)/dh and z (granule save format)
+                        float* sv = L.save + tb * 5 * H + j;
+                        const float cn = (1.f - z) * (1.f - n * n);
+                        sv[0] = cn * ghn * r * (1.f - r); sv[H] = (hp - n) * z * (1.f - z); sv[2 * H] = cn;
+                        sv[3 * H] = cn * r; sv[4 * H] = z;
+                    }
+                }
+            }
+            if (prof_now && prof_g && nb == NB - 1) prof_stamp(pslot + 12);
+            if (err_seen) return;
         }
-        if (prof_now && prof_g) prof_stamp(pslot + 12);
-        if (err_seen) return;
     }
 }
 

@@ -355,8 +355,10 @@ def _chains(wrappers):
     for wi, w in enumerate(wrappers):
         for d in range(2 if w.bidirectional else 1):
             chains.append(_Chain(w, wi, d))
-    if len(chains) > 2:
-        raise NotImplementedError('at most two concurrent GRU chains (FBCRNN fwd+bwd or one BiGRU)')
+    if len(chains) > 6:
+        raise NotImplementedError('at most six concurrent GRU chains (pbsed.h: both directions of three networks)')
+    if len(chains) > 2 and not _scan_as_stack(wrappers):
+        raise NotImplementedError('more than two concurrent GRU chains need the stack scans (hidden size 64 / 128 / 256 / 512)')
     return chains
 
 
@@ -457,7 +459,8 @@ def _scan_as_stack(wrappers):
 
 def rnn_forward(wrappers, h, seq_dev, seq_host, training, precision='f32', h_tbc=None):
     """wrappers: list of modules.GRU sharing the input h [B,C,T] (``h_tbc``: the same in the scans' layout [T,B,C], if the
-    caller has it).  Returns (logits per wrapper, ctx).
+    caller has it; a LIST of such tensors, one per wrapper and h = None: independent networks whose layers share the scan
+    launches - inference only, no ctx for a backward pass).  Returns (logits per wrapper, ctx).
 
     Layer-by-layer path (bidirectional GRUs): every layer's input projection is a time-major product (ops.tm_gemm) - of the
     transposed CNN output for the first layer, of the previous layer's scan outputs (one source per direction, nothing
@@ -474,7 +477,11 @@ def rnn_forward(wrappers, h, seq_dev, seq_host, training, precision='f32', h_tbc
     # float4s): the first layer's weights are padded with zero columns to match
     if h_tbc is None and h.shape[1] % 4 == 0:
         h_tbc = ops.bct_to_tbc(h)
-    src = [[h_tbc] if h_tbc is not None else None for _ in wrappers]      # per wrapper: time-major sources of the layer input
+    if isinstance(h_tbc, (list, tuple)):          # one input per wrapper: independent networks sharing the scan launches
+        assert len(h_tbc) == len(wrappers) and h is None
+        src = [[x] for x in h_tbc]
+    else:
+        src = [[h_tbc] if h_tbc is not None else None for _ in wrappers]      # per wrapper: time-major sources of the layer input
     layer_ctx, hs = [], None
     for l in range(num_layers):
         gi, pcs = [], []

@@ -24,6 +24,17 @@ def _as_dev_scores(y, device):
     return y.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+def _run_models(models, method, segment, kwargs):
+    """[(scores, seq_len)] of every model for one segment.  Networks of one class and shape that offer ``<method>_jointly``
+    (models/strong_label.py) run their recurrent scans in shared launches; anything else one model after the other, as
+    the reference does (inference.py:133-141)."""
+    cls = type(models[0])
+    joint = getattr(cls, method + '_jointly', None)
+    if joint is not None and not any(kwargs) and getattr(cls, 'can_run_jointly', lambda m: False)(models):
+        return joint(models, segment)
+    return [getattr(m, method)(segment, **kw) for m, kw in zip(models, kwargs)]
+
+
 def filtering(scores, filter_fn, filter_length):
     """Device twin of inference.py:225-263: 0-d, per-class (1-d) or per-variant (2-d -> [B,n,K,T]) lengths."""
     filter_length = np.asarray(filter_length)
@@ -143,8 +154,7 @@ def inference(model, method, dataset, device, max_segment_length=None, segment_o
         for segment in segments:
             segment = models[0].example_to_device(segment, device)
             per_model, seq_len = [], None
-            for m, kw in zip(models, kwargs):
-                y, sl = getattr(m, method)(segment, **kw)
+            for y, sl in _run_models(models, method, segment, kwargs):
                 per_model.append(_as_dev_scores(y, device))
                 if seq_len is None:
                     seq_len = np.asarray(sl)

@@ -8,27 +8,33 @@ from ..modules import CNN, GRU, SHALLOW, NormalizedLogMelExtractor, build_cnn, b
 from .base import SoundEventModel
 
 
+def _cnn_forward(model, x, tag, seq_host, seq_dev, training):
+    """Features -> CNN output, as the scans take it: (h [B,C,T] or None, h_tbc [T,B,C+K(+pad)] or None, layers, ctx, C)."""
+    if tag is not None and model.cnn.conditional_dims:
+        b, _, f, t = x.shape
+        x = torch.cat([x, tag.reshape(b, -1, 1, 1).to(x.dtype).expand(b, tag.shape[1], f, t)], dim=1).contiguous()
+    layers = engine.describe_stack([model.cnn.cnn_2d, model.cnn.cnn_1d])
+    h, cnn_ctx = engine.stack_forward(layers, x, seq_dev, seq_host, training, model.conv_precision)
+    n_h = h.shape[1]
+    h_tbc = None
+    if tag is not None:
+        # the GRU input in the scans' layout [T, B, C + K (+ zero channels up to whole float4s)]: the tags are appended
+        # there, so the first layer's projections run time-major like the others (the padded width is the engine's affair)
+        b, _, t = h.shape
+        k = tag.shape[1]
+        hc = ops.bct_to_tbc(h)
+        parts = [hc, tag.to(h.dtype).reshape(1, b, k).expand(t, b, k)]
+        if (n_h + k) % 4:
+            parts.append(h.new_zeros((t, b, 4 - (n_h + k) % 4)))
+        h_tbc = torch.cat(parts, dim=2)
+        h = None
+    return h, h_tbc, layers, cnn_ctx, n_h
+
+
 class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, tag, seq_host, seq_dev, training, *params):
-        if tag is not None and model.cnn.conditional_dims:
-            b, _, f, t = x.shape
-            x = torch.cat([x, tag.reshape(b, -1, 1, 1).to(x.dtype).expand(b, tag.shape[1], f, t)], dim=1).contiguous()
-        layers = engine.describe_stack([model.cnn.cnn_2d, model.cnn.cnn_1d])
-        h, cnn_ctx = engine.stack_forward(layers, x, seq_dev, seq_host, training, model.conv_precision)
-        n_h = h.shape[1]
-        h_tbc = None
-        if tag is not None:
-            # the GRU input in the scans' layout [T, B, C + K (+ zero channels up to whole float4s)]: the tags are appended
-            # there, so the first layer's projections run time-major like the others (the padded width is the engine's affair)
-            b, _, t = h.shape
-            k = tag.shape[1]
-            hc = ops.bct_to_tbc(h)
-            parts = [hc, tag.to(h.dtype).reshape(1, b, k).expand(t, b, k)]
-            if (n_h + k) % 4:
-                parts.append(h.new_zeros((t, b, 4 - (n_h + k) % 4)))
-            h_tbc = torch.cat(parts, dim=2)
-            h = None
+        h, h_tbc, layers, cnn_ctx, n_h = _cnn_forward(model, x, tag, seq_host, seq_dev, training)
         logits, rnn_ctx = engine.rnn_forward([model.rnn], h, seq_dev, seq_host, training, model.conv_precision, h_tbc=h_tbc)
         if model.keep_logits:
             model.last_logits = [logits[0].detach().clone()]
@@ -123,6 +129,58 @@ class CRNN(SoundEventModel):
         training = self.training and torch.is_grad_enabled()
         y = _NetFunction.apply(self, x, tag, seq_host, seq_dev, training, *self._net_params)
         return y, seq_host, x, seq_host, targets
+
+    MAX_JOINT = 3           # networks per joint scan launch (two directions each: pbsed.h's limit of six chains)
+
+    @classmethod
+    def can_run_jointly(cls, models):
+        """Inference of several networks of one shape on one batch can share its recurrent scans (``forward_jointly``)."""
+        m0 = models[0]
+        return len(models) > 1 and all(
+            type(m) is cls and not m.training and m.conv_precision == m0.conv_precision
+            and m.tag_conditioning == m0.tag_conditioning and m.rnn.hidden_size == m0.rnn.hidden_size
+            and m.rnn.hidden_size in (64, 128, 256, 512)
+            and m.rnn.num_layers == m0.rnn.num_layers and m.rnn.bidirectional == m0.rnn.bidirectional
+            and m.rnn.rnn.input_size == m0.rnn.rnn.input_size for m in models)
+
+    @classmethod
+    def forward_jointly(cls, models, inputs):
+        """Scores [B,K,T] of every network for one batch (no gradients): each network's own features and CNN, then ONE
+        persistent scan launch per GRU layer for up to MAX_JOINT networks - the scans are latency-bound chains of T
+        dependent steps that leave most of the device idle, and an ensemble's networks are independent
+        (reference pb_sed/models/base/inference.py:133-141 runs them one after the other).  Same arithmetic per network as
+        ``forward``: the joint launch only adds chains to the scan's grid."""
+        assert cls.can_run_jointly(models)
+        m0 = models[0]
+        key = m0.input_key(inputs)
+        x_in = inputs[key]
+        seq_host, seq_dev = m0._seq(inputs, x_in.device)
+        tag = inputs['tag_condition'].to(torch.float32) if m0.tag_conditioning else None
+        ys = []
+        with torch.no_grad():
+            for g0 in range(0, len(models), cls.MAX_JOINT):
+                group = models[g0:g0 + cls.MAX_JOINT]
+                hs, h_tbcs = [], []
+                for m in group:
+                    engine.flatten_parameters(m)
+                    x = m.features(inputs, x_in, seq_host, seq_dev)
+                    h, h_tbc, *_ = _cnn_forward(m, x, tag, seq_host, seq_dev, False)
+                    if h_tbc is None:
+                        h_tbc = ops.bct_to_tbc(h)
+                    h_tbcs.append(h_tbc)
+                logits, _ = engine.rnn_forward([m.rnn for m in group], None, seq_dev, seq_host, False, m0.conv_precision,
+                                               h_tbc=h_tbcs)
+                ys += [ops.squash_fwd(lg, 0.) for lg in logits]
+        return ys, seq_host
+
+    @classmethod
+    def sound_event_detection_jointly(cls, models, inputs):
+        ys, seq_len_y = cls.forward_jointly(models, inputs)
+        t = ys[0].shape[-1]
+        m = (torch.arange(t, device=ys[0].device)[None] < engine.seq_to_device(seq_len_y, ys[0].device)[:, None])[:, None, :]
+        return [(y * m, seq_len_y) for y in ys]
+
+    boundaries_detection_jointly = sound_event_detection_jointly
 
     def modify_summary(self, summary):
         """Called by the trainer before dumping a summary (reference models/strong_label/crnn.py modify_summary): metrics

@@ -172,6 +172,47 @@ def test_inference_driver_keeps_a_batch_in_flight_without_changing_results():
     assert big and max(big.values()) <= 3, big                    # score buffers: the pipeline depth, not one per batch
 
 
+@pytest.mark.parametrize('hidden,batch', [(64, 5), (256, 40)])
+def test_detectors_sharing_scan_launches_give_the_scores_of_separate_runs(hidden, batch):
+    """strong_label.CRNN.sound_event_detection_jointly: the ensemble's networks run their GRU layers in shared persistent-scan
+    launches (up to three networks = six chains per launch; four networks here = a group of three and a single one; the
+    larger case switches the launch to two batch tiles per block).  Per network the arithmetic is that of its own run: the
+    scores must be identical, and inference() must take that path."""
+    from oracle import models as om
+    from pb_sed_amd import inference as inf
+    from pb_sed_amd.models import strong_label
+    from tests.test_gpu_model import TINY, synth_batch
+    torch.manual_seed(11)
+    kw = dict(num_events=10, number_of_filters=128, hidden_size=hidden, num_layers=2, net=TINY)
+    models = []
+    for _ in range(4):
+        m = strong_label.CRNN.build(tag_conditioning=True, **kw)
+        m.load_state_dict(om.BiCRNN.build(tag_conditioning=True, **kw).state_dict())
+        models.append(m.to(DEV).eval())
+    wav, seq, *_ = synth_batch(batch, 16000, 10, ragged=True, seed=3)
+    cond = (torch.rand(batch, 10, generator=torch.Generator().manual_seed(1)) > .5).float()
+    example = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'example_id': [f'e{i}' for i in range(batch)],
+               'tag_condition': cond.to(DEV)}
+    assert strong_label.CRNN.can_run_jointly(models)
+    with torch.no_grad():
+        separate = [m.sound_event_detection(dict(example)) for m in models]
+    joint = strong_label.CRNN.sound_event_detection_jointly(models, dict(example))
+    assert len(joint) == 4
+    for (ys, ls), (yj, lj) in zip(separate, joint):
+        assert (np.asarray(ls) == np.asarray(lj)).all()
+        assert torch.equal(ys, yj), (ys - yj).abs().max().item()
+    calls = []
+    orig = strong_label.CRNN.sound_event_detection_jointly.__func__
+    try:
+        strong_label.CRNN.sound_event_detection_jointly = classmethod(lambda cls, ms, seg: (calls.append(len(ms)), orig(cls, ms, seg))[1])
+        out = inf.sound_event_detection(models, [dict(example)], DEV)
+    finally:
+        strong_label.CRNN.sound_event_detection_jointly = classmethod(orig)
+    assert calls == [4] and len(out) == batch
+    models[1].train()                                   # a network in training mode (batch statistics): one model after the other
+    assert not strong_label.CRNN.can_run_jointly(models)
+
+
 def test_medfilt_long_filters_bit_exact(golden):
     """Median filters up to 301 frames on 500-frame rows (the reference's tuning range,
     pb_sed/experiments/strong_label_crnn/tuning.py:64) incl. rows with ties and zero runs: the bisection-select kernel
