@@ -202,6 +202,7 @@ def cpu_train_baseline(kind, batches=(32, 16), steps=3):
            'sample': f'oracle (stock-PyTorch CPU restatement, fp32) {what} train step incl. STFT, batch {main_b} x 10 s clips, '
                      f'1 warm-up + {res[main_b]["timed_steps"]} timed steps, median',
            'cpu_model': model_name, 'host_logical_cpus': n_logical, 'affinity_cpus': aff, 'threads_used': n,
+           'threads_note': 'intra-op threads capped at min(affinity, 32): the oracle step is many small GRU / conv ops whose CPU time stops falling (and then rises) beyond ~32 threads on this class of host; cores = threads used, not the host total',
            f'batch{main_b}': res[main_b]}
     for bb in batches[1:]:
         out[f'batch{bb}'] = res[bb]

@@ -257,7 +257,9 @@ int pbsed_gru_scan_bwd(int nchains, const float* const* w_hh_t, const float* con
                        void* stream);
 /* Multi-layer UNIDIRECTIONAL stacks (FBCRNN: forward + time-reversed 2-layer GRUs) as a layer wavefront of
  * T + nlayers - 1 per-step launches (the fallback of the persistent *_granule scans below; `save` rows [4][H]).
- * Pointer tables are host arrays indexed [chain*nlayers + layer]. */
+ * Pointer tables are host arrays indexed [chain*nlayers + layer].  1 <= nchains <= 6 (the chains are independent: both
+ * directions of up to three networks that share B, H, T and seq_len - ensemble inference runs its detectors' layers as one
+ * launch), 1 <= nlayers <= 4; the same limits hold for the *_granule entry points. */
 int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
                         const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
                         float* const* hs, float* const* save, const int* reverse /*host*/, const int* seq_len,
@@ -289,7 +291,9 @@ int pbsed_gru_set_prof(unsigned long long* buf, int block);
  * the exchanged states are stored as [T][batch tile][H/16][16 rows][16 units] tiles), ZERO before
  * its first use; epoch: odd on the first use of a workspace, parity flipped on every further call with it.
  * err_flag: device uint32, non-zero afterwards if a hand-off timed out (re-zero the workspace then).
- * `save` rows are [5][H] (factors of dh_t, see gru_stack.hip). */
+ * `save` rows are [5][H] (factors of dh_t, see gru_stack.hip).  When the one-tile-per-block grid exceeds 7/8 of the capacity
+ * the forward scan gives every block two batch tiles, run half a step apart (one tile's states travel while the other is
+ * computed). */
 int pbsed_gru_stack_fwd_granule(int nchains, int nlayers, const float* const* gi0, const float* const* w_ih,
                                 const float* const* b_ih, const float* const* w_hh, const float* const* b_hh,
                                 float* const* hs, float* const* save, const int* reverse /*host*/, const int* seq_len,
