@@ -223,6 +223,13 @@ int pbsed_conv_fwd_bf16(const float* x, const unsigned short* w_packed_bf16, con
                         const float* shift, int relu, const int* seq_len, float* y, unsigned char* pool_idx,
                         double* stats, int stats_per_cf, int B, int Cin, int Cout, int F, int T, int KH, int KW, int pool,
                         int nsplit, void* stream);
+/* pbsed_conv_fwd_bf16 whose (biased, pooled) output gets `residual` [B, Cout, Fo, T] added before the store and the
+ * statistics (see pbsed_conv_fwd_res): the 1x1 conv2d layers of net_config 'deep'
+ * (pb_sed/experiments/weak_label_crnn/training.py:170-183) with fp32-class bf16x3 operands (nsplit = 3). */
+int pbsed_conv_fwd_bf16_res(const float* x, const unsigned short* w_packed_bf16, const float* bias, const float* scale,
+                            const float* shift, int relu, const int* seq_len, float* y, unsigned char* pool_idx,
+                            double* stats, int stats_per_cf, int B, int Cin, int Cout, int F, int T, int KH, int KW, int pool,
+                            int nsplit, const float* residual, void* stream);
 int pbsed_conv_bwd_data_bf16(const float* g, const unsigned short* wd_packed_bf16, const unsigned char* unpool_idx,
                              const int* seq_len, float* dz, const float* bx, const float* bmean, const float* binvstd,
                              const float* bscale, const float* bshift, int relu, double* stats, int B, int Cin, int Cout,

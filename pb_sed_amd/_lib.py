@@ -53,6 +53,7 @@ SIGNATURES = {
     'pbsed_conv_pack_dims_bf16': [I, I, I, _i, _i],
     'pbsed_pack_conv_weights_bf16': [_v, _v, I, I, I, I, I, I, _v],
     'pbsed_conv_fwd_bf16': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, I, I, I, _v],
+    'pbsed_conv_fwd_bf16_res': [_v, _v, _v, _v, _v, I, _v, _v, _v, _v, I, I, I, I, I, I, I, I, I, I, _v, _v],
     'pbsed_conv_bwd_data_bf16': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, _v, I, I, I, I, I, I, I, I, _v],
     'pbsed_conv_bwd_weight': [_v, _v, _v, I, _v, _v, _v, _v, _v, I, I, I, I, I, I, I, _v],
     'pbsed_conv_bwd_weight_bf16': [_v, _v, _v, I, _v, _v, _v, _v, _v, I, I, I, I, I, I, I, _v],

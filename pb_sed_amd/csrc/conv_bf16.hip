@@ -352,6 +352,7 @@ static int dispatch_b2(const ConvFwdArgs& a, const unsigned short* wpb, int KH, 
     if (KH == 3 && KW == 3) CB2(4, 64, 3, 3);
     if (KH == 1 && KW == 3 && !pool) CB21(128, 3);
     if (KH == 1 && KW == 1 && !pool) CB21(128, 1);
+    if (KH == 1 && KW == 1 && pool && !dgrad) return launch_b2<NS, 2, 64, 1, 1, true, false>(a, wpb, s);      // 1x1 conv2d under a (2,1) pool
 #undef CB2
 #undef CB21
     set_error("conv_bf16: unsupported kernel %dx%d pool=%d", KH, KW, pool);
@@ -406,6 +407,24 @@ int pbsed_conv_fwd_bf16(const float* x, const unsigned short* wpb, const float* 
     if (nsplit == 1) return dispatch_b<1>(a, wpb, KH, KW, pool, 0, (hipStream_t)stream);
     if (nsplit == 3) return dispatch_b<3>(a, wpb, KH, KW, pool, 0, (hipStream_t)stream);
     set_error("conv_fwd_bf16: nsplit must be 1 or 3");
+    return PBSED_E_ARG;
+}
+
+// pbsed_conv_fwd_bf16 + a residual connection ending at this layer (added to the biased, pooled output before the store and
+// the statistics, as in pbsed_conv_fwd_res): the 1x1 conv2d layers of the 'deep' configuration.
+int pbsed_conv_fwd_bf16_res(const float* x, const unsigned short* wpb, const float* bias, const float* scale,
+                            const float* shift, int relu, const int* seq_len, float* y, unsigned char* pool_idx,
+                            double* stats, int stats_per_cf, int B, int Cin, int Cout, int F, int T, int KH, int KW, int pool,
+                            int nsplit, const float* residual, void* stream) {
+    ConvFwdArgs a{};
+    a.x = x; a.bias = bias; a.scale = scale; a.shift = shift; a.seq_len = seq_len;
+    a.y = y; a.pool_idx = pool_idx; a.stats = stats; a.stats_cf = stats_per_cf; a.relu = relu; a.res = residual;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.F = F; a.T = T;
+    pbsed_conv_pack_dims_bf16(Cin, Cout, 0, &a.CinP, &a.CoutP);
+    if (pool && (F % 2)) { set_error("conv_fwd_bf16_res: pool needs even F"); return PBSED_E_ARG; }
+    if (nsplit == 1) return dispatch_b<1>(a, wpb, KH, KW, pool, 0, (hipStream_t)stream);
+    if (nsplit == 3) return dispatch_b<3>(a, wpb, KH, KW, pool, 0, (hipStream_t)stream);
+    set_error("conv_fwd_bf16_res: nsplit must be 1 or 3");
     return PBSED_E_ARG;
 }
 

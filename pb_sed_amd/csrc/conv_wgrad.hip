@@ -1667,6 +1667,9 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
         if (KW == 3) return launch_wgrad_cfg<Wgrad1dPcCfg<3>>(conv1d_wgrad_pc_kernel<3>, a, s);
         if (KW == 1 && a.Cin >= 512) return launch_wgrad_cfg<Wgrad1dPcCfg<1>>(conv1d_wgrad_pc_kernel<1>, a, s);
     }
+    // 1x1 conv2d layers (F > 1: net_config 'deep'), also under a pool: the same kernel walks (clip, row, 128-t) chunks
+    if (!a.bf16 && KH == 1 && KW == 1 && a.F > 1 && a.Cin >= 32 && a.Cout >= 32 && a.Cin < 1024)
+        return launch_wgrad_cfg<WgradB16Cfg<1, 1, 2, 3>>(conv_wgrad_bf16_kernel<1, 1, 2, 3>, a, s);
     if (!a.bf16 && KH == 1 && a.F == 1 && !a.unpool_idx && a.Cin >= 32 && a.Cout >= 32 && a.Cin < 1024) {
         if (KW == 3) return launch_wgrad_cfg<WgradB16Cfg<1, 3, 2, 3>>(conv_wgrad_bf16_kernel<1, 3, 2, 3>, a, s);
         if (KW == 1) return launch_wgrad_cfg<WgradB16Cfg<1, 1, 2, 3>>(conv_wgrad_bf16_kernel<1, 1, 2, 3>, a, s);

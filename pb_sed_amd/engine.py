@@ -160,6 +160,13 @@ def _prec(precision, cin, pc=None, dgrad=False, unpool=False):
         # MFMA, bf16x3 operands; the 1-channel first layer of the FBCRNN (9 products per output) stays on the direct kernel
         if 2 <= k_in <= 16 and n_out <= 32:
             return 's16x3'
+    if pc is not None and pc.weight.dim() == 4 and pc.kh == 1 and pc.kw == 1:
+        # 1x1 conv2d layers (every second layer of net_config 'deep'): the pipelined bf16-MFMA kernel with exact three-way
+        # splits (csrc/conv_bf16.hip, NS = 3: one row per tile, two under a (2,1) pool; residual sums in its epilogue) from 32
+        # channels on either side instead of the fp32-MFMA direct kernel
+        k_in, n_out = (pc.cout, pc.cin) if dgrad else (pc.cin, pc.cout)
+        if k_in >= 32 and n_out >= 32:
+            return 'bf16x3'
     return 'f32'
 
 
@@ -205,8 +212,8 @@ def stack_forward(layers, x, seq_dev, seq_host, training, precision='f32', x_tbc
             r, sctx = _skip_forward(layers, ctx, src, j + 1, skip_conv)
             res = r if res is None else ops.add_inplace(res, r)
             skip_ctx.append((src, skip_conv, sctx))
-        if res is not None:
-            pr = 'f32'                       # the residual add lives in the fp32 direct kernels' epilogue
+        if res is not None and pr != 'bf16x3':
+            pr = 'f32'                       # the residual add lives in the epilogue of the direct fp32 / bf16-MFMA kernels
         y, idx, stats = ops.conv_fwd(
             x, pc, pc.fwd(pr), bias=c.conv.bias.detach(),
             scale=None if st_in is None else st_in.scale, shift=None if st_in is None else st_in.shift,

@@ -298,7 +298,7 @@ def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=No
     stats = None
     if want_stats:
         stats = _zero_stats(pc.cout * fo if stats_per_cf else pc.cout, x.device)
-    assert residual is None or precision == 'f32', 'a residual add needs the fp32 direct kernel'
+    assert residual is None or precision in ('f32', 'bf16x3', 'bf16'), 'a residual add needs the direct fp32 or bf16-MFMA kernel'
     if precision == 'winox3' and t % 4:               # the bf16x3 kernel needs 16-byte aligned rows: same result from the fp32 form
         precision, wp = 'wino', pc.fwd('wino')
     if precision == 's16x3' and t % 4:                # likewise the few-channel kernel: the direct fp32 kernel takes any T
@@ -320,6 +320,13 @@ def conv_fwd(x, pc, wp, bias=None, scale=None, shift=None, relu=True, seq_len=No
              tag=_conv_tag(b, cin, pc, f, t) + ' s16x3', flops=_conv_flops(b, cin, pc, f, t))
         return y, idx, stats
     if precision != 'f32':
+        if residual is not None:
+            assert residual.shape == y.shape and residual.is_contiguous(), (residual.shape, y.shape)
+            call('pbsed_conv_fwd_bf16_res', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
+                 ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, pc.kh, pc.kw, int(pool),
+                 NSPLIT[precision], ptr(residual), stream(), tag=_conv_tag(b, cin, pc, f, t) + ' +res ' + precision,
+                 flops=_conv_flops(b, cin, pc, f, t))
+            return y, idx, stats
         call('pbsed_conv_fwd_bf16', ptr(x), ptr(wp), ptr(bias), ptr(scale), ptr(shift), int(relu), ptr(seq_len),
              ptr(y), ptr(idx), ptr(stats), int(stats_per_cf), b, cin, pc.cout, f, t, pc.kh, pc.kw, int(pool),
              NSPLIT[precision], stream(), tag=_conv_tag(b, cin, pc, f, t) + ' ' + precision,
@@ -425,9 +432,10 @@ def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, se
     x3pc = k33 and t % 4 == 0 and ((cin >= 64 and pc.cout >= 64) or (cin == 32 and pc.cout == 32))    # conv_wgrad_launch's rule
     s16 = k33 and t % 4 == 0 and cin == 16 and pc.cout in (16, 32)
     wino = k33 and not x3pc and pc.cout >= 64 and cin >= 16
+    b16x3 = pc.kh == 1 and pc.kw == 1 and f > 1 and 32 <= cin < 1024 and pc.cout >= 32            # 1x1 conv2d: conv_wgrad_bf16_kernel<1,1,2,3>
     call('pbsed_conv_bwd_weight', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(g),
          ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream(),
-         tag=_conv_tag(b, cin, pc, f, t) + (' x3pc' if x3pc else ' s16x3' if s16 else ' wino' if wino else ''), flops=_conv_flops(b, cin, pc, f, t))
+         tag=_conv_tag(b, cin, pc, f, t) + (' x3pc' if x3pc else ' s16x3' if s16 else ' wino' if wino else ' bf16x3' if b16x3 else ''), flops=_conv_flops(b, cin, pc, f, t))
 
 
 def pool21_fwd(x):

@@ -138,6 +138,11 @@ CONV_CASES = [
     dict(cin=32, cout=32, f=22, t=72, k=(3, 3), pool=False, pro=True),
     dict(cin=32, cout=16, f=17, t=36, k=(3, 3), pool=False, pro=False),
     dict(cin=16, cout=32, f=48, t=64, k=(3, 3), pool=True, pro=False),
+    # 1x1 conv2d layers (every second layer of net_config 'deep'; forward / data gradient in the bf16 tests below, the
+    # weight gradient here): one row per tile, two under a (2,1) pool
+    dict(cin=64, cout=96, f=6, t=72, k=(1, 1), pool=True, pro=True),
+    dict(cin=40, cout=48, f=5, t=100, k=(1, 1), pool=False, pro=True),
+    dict(cin=32, cout=64, f=4, t=50, k=(1, 1), pool=False, pro=False),
 ]
 
 
@@ -459,6 +464,7 @@ BF16_CASES = [c for c in CONV_CASES if c['cin'] >= 20] + [
 ]
 
 
+
 @pytest.mark.parametrize('precision', ['bf16', 'bf16x3'])
 @pytest.mark.parametrize('case', BF16_CASES, ids=lambda c: f"{c['cin']}x{c['cout']}k{c['k'][0]}{c['k'][1]}p{int(c['pool'])}{'pro' if c['pro'] else ''}")
 def test_conv_bf16_mfma_vs_torch(case, precision):
@@ -488,6 +494,14 @@ def test_conv_bf16_mfma_vs_torch(case, precision):
     if not pro and not pool:
         g, _ = ops.conv_bwd_data(dx(gy), pc, pc.dgrad(precision), xd.shape, None, None, precision=precision)
         close(g, xr.grad, name=f'conv_dgrad {precision}', **tol)
+    if k == (1, 1) and f > 1:
+        # a residual connection ending at the layer (net_config 'deep'): added to the biased, pooled output in the epilogue
+        res = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+        y2, idx2, _ = ops.conv_fwd(xd, pc, pc.fwd(precision), bias=dx(bias), scale=dx(scale), shift=dx(shift), relu=True,
+                                   seq_len=seq_dev, pool=pool, want_stats=True, precision=precision, residual=res)
+        for i, n in enumerate(seq):
+            close(y2[i, ..., :n], (y + res)[i, ..., :n], name=f'conv_fwd {precision} + residual', atol=1e-6, rtol=1e-6)
+        assert idx is None or torch.equal(idx, idx2)
     if precision == 'bf16':
         # THE bf16 gate: against the same layer from operands rounded to bf16 where the kernel rounds them - what is left is
         # fp32 accumulation order (the comparison above only bounds the inherent effect of the rounding, 4e-2)
