@@ -343,7 +343,8 @@ static int launch_wgrad_cfg(Kern kern, const ConvWgradArgs& a_in, hipStream_t s)
     if (split > cap) split = cap > 0 ? cap : 1;
     if (split > nChunks) split = nChunks;
     if constexpr (wgrad_columns<C>::value) {                          // column-walking kernels split over (clip, column) units
-        if (split > a.B * nTt) split = a.B * nTt;
+        const int units = a.B * nTt * (C::KK <= 3 ? a.F : 1);       // the Conv1d form takes (clip, row, column) units, the 3x3 form walks the rows
+        if (split > units) split = units;
     }
     dim3 grid(split, gy, gz);
     float* scratch = (slot_ok && split >= 4 * WGRAD_SLOTS) ? wgrad_slot_scratch(s) : nullptr;
@@ -1355,7 +1356,7 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_pc_kernel(ConvWgradArgs a) {
     const int lq = lane >> 4, lr = lane & 15;
     const int cin0 = blockIdx.y * C::CIN_T, cout0 = blockIdx.z * C::COUT_T;
     const int nTt = (a.T + C::TT - 1) / C::TT;
-    const int nUnits = a.B * nTt;                                        // steps = (clip, 32-t range) units
+    const int nUnits = a.B * a.F * nTt;                                  // steps = (clip, row, 32-t range) units (rows: 1x1 conv2d layers)
     const bool pro = a.scale != nullptr;
     const int wmi = wave >> 1, wni = wave & 1;                           // consumer wave -> (64-cout group, cin group)
     const bool do_bias = (a.db != nullptr) && (blockIdx.y == 0) && wni == 0;
@@ -1376,7 +1377,8 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_pc_kernel(ConvWgradArgs a) {
         // ================================================================ PRODUCER
         const int pt = tid - 256;
         constexpr unsigned OOB = 0x20000000u;            // element offset beyond every clip (x 4 = 2^31 bytes)
-        const unsigned gclip = (unsigned)(a.Cout * a.T), xclip = (unsigned)(a.Cin * a.T);
+        const int plane = a.F * a.T;                       // elements per channel of a clip
+        const unsigned gclip = (unsigned)(a.Cout * plane), xclip = (unsigned)(a.Cin * plane);
         const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.scale), 0, pro ? (unsigned)a.Cin * 4u : 0u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc(
@@ -1391,7 +1393,7 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_pc_kernel(ConvWgradArgs a) {
             const int row = cl & 15;
             y_lds[i] = (unsigned)(cl * 64 + ((((y_q[i] >> 1) ^ ((-(row >> 2)) & 3)) & 3) * 16) + (y_q[i] & 1) * 8);
             y_valid[i] = cout0 + cl < a.Cout;
-            y_base[i] = (unsigned)((cout0 + cl) * a.T + 4 * y_q[i]);
+            y_base[i] = (unsigned)((cout0 + cl) * plane + 4 * y_q[i]);
         }
         constexpr int XOFF = KW == 3 ? 8 : 0;               // the x window starts XOFF elements before the step's range
         int x_q[C::X_PER_T], x_valid[C::X_PER_T];
@@ -1410,7 +1412,7 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_pc_kernel(ConvWgradArgs a) {
             }
             x_bnd[i] = (unsigned)(cl * C::XB_CH);
             x_valid[i] = cin0 + cl < a.Cin;
-            x_base[i] = (cin0 + cl) * a.T + 4 * x_q[i] - XOFF;
+            x_base[i] = (cin0 + cl) * plane + 4 * x_q[i] - XOFF;
             const bool ok = x_valid[i] && pro;
             x_sc[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_sc, ok ? (unsigned)(cin0 + cl) * 4u : 0x80000000u, 0, 0));
             x_sh[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_sh, ok ? (unsigned)(cin0 + cl) * 4u : 0x80000000u, 0, 0));
@@ -1422,9 +1424,11 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_pc_kernel(ConvWgradArgs a) {
         int ry_n[NB][C::DY_PER_T], rx_lo[NB][C::X_PER_T], rx_hi[NB][C::X_PER_T];
         const bool vec = (a.T & 3) == 0;                   // rows 16-byte aligned: one load per quad
 
-        auto locate = [&](int S, int& b, int& t0) __attribute__((always_inline)) {
+        auto locate = [&](int S, int& b, int& t0, int& row0) __attribute__((always_inline)) {
             const int u = (int)blockIdx.x + S * (int)gridDim.x;
-            b = u / nTt; t0 = (u % nTt) * C::TT;
+            const int bf = u / nTt;
+            t0 = (u % nTt) * C::TT;
+            b = bf / a.F; row0 = (bf % a.F) * a.T;
         };
         auto load_quad = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned e, int lo, int hi) __attribute__((always_inline)) -> u32x4_t {
             // elements lo <= k < hi of the quad at element offset e are inside the row (branch-free selects)
@@ -1442,8 +1446,8 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_pc_kernel(ConvWgradArgs a) {
         };
         auto load_step = [&](int S, auto buf_c) __attribute__((always_inline)) {
             constexpr int BUF = decltype(buf_c)::value;
-            int b, t0;
-            locate(S, b, t0);
+            int b, t0, row0;
+            locate(S, b, t0, row0);
             const int sl = a.seq_len ? min(a.seq_len[b], a.T) : a.T;
             const int tlim = pro ? sl : a.T;
             const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
@@ -1454,7 +1458,7 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_pc_kernel(ConvWgradArgs a) {
             for (int i = 0; i < C::DY_PER_T; ++i) {
                 const int tq = t0 + 4 * y_q[i];
                 const int hi = y_valid[i] ? min(max(a.T - tq, 0), 4) : 0;
-                ry[BUF][i] = load_quad(rs_g, y_base[i] + (unsigned)t0, 0, hi);
+                ry[BUF][i] = load_quad(rs_g, y_base[i] + (unsigned)(row0 + t0), 0, hi);
                 ry_n[BUF][i] = hi;
             }
 #pragma unroll
@@ -1462,7 +1466,7 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_pc_kernel(ConvWgradArgs a) {
                 const int tq = t0 - XOFF + 4 * x_q[i];
                 const int lo = x_valid[i] ? min(max(-tq, 0), 4) : 4;          // elements before the row's start
                 const int hi_row = x_valid[i] ? min(max(a.T - tq, 0), 4) : 0;
-                rx[BUF][i] = load_quad(rs_x, (unsigned)(x_base[i] + t0), vec ? 0 : lo, vec ? (tq >= 0 ? hi_row : 0) : hi_row);
+                rx[BUF][i] = load_quad(rs_x, (unsigned)(x_base[i] + row0 + t0), vec ? 0 : lo, vec ? (tq >= 0 ? hi_row : 0) : hi_row);
                 rx_lo[BUF][i] = lo;
                 rx_hi[BUF][i] = x_valid[i] ? min(max(tlim - tq, 0), 4) : 0;   // zero padding is post-activation
             }
@@ -1667,7 +1671,11 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
         if (KW == 3) return launch_wgrad_cfg<Wgrad1dPcCfg<3>>(conv1d_wgrad_pc_kernel<3>, a, s);
         if (KW == 1 && a.Cin >= 512) return launch_wgrad_cfg<Wgrad1dPcCfg<1>>(conv1d_wgrad_pc_kernel<1>, a, s);
     }
-    // 1x1 conv2d layers (F > 1: net_config 'deep'), also under a pool: the same kernel walks (clip, row, 128-t) chunks
+    // 1x1 conv2d layers (F > 1: net_config 'deep'): from 64 channels on and without a pool the producer / consumer kernel of
+    // the Conv1d layers over (clip, row, 32-t) units (256->256 at F = 16: 0.61 -> see DESIGN.md); the others - also under a
+    // pool - the pipelined bf16x3 kernel, which walks (clip, row, 128-t) chunks
+    if (!a.bf16 && KH == 1 && KW == 1 && a.F > 1 && !a.unpool_idx && a.Cin >= 64 && a.Cout >= 64 && (a.T & 3) == 0)
+        return launch_wgrad_cfg<Wgrad1dPcCfg<1>>(conv1d_wgrad_pc_kernel<1>, a, s);
     if (!a.bf16 && KH == 1 && KW == 1 && a.F > 1 && a.Cin >= 32 && a.Cout >= 32 && a.Cin < 1024)
         return launch_wgrad_cfg<WgradB16Cfg<1, 1, 2, 3>>(conv_wgrad_bf16_kernel<1, 1, 2, 3>, a, s);
     if (!a.bf16 && KH == 1 && a.F == 1 && !a.unpool_idx && a.Cin >= 32 && a.Cout >= 32 && a.Cin < 1024) {

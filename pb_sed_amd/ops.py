@@ -432,10 +432,12 @@ def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, se
     x3pc = k33 and t % 4 == 0 and ((cin >= 64 and pc.cout >= 64) or (cin == 32 and pc.cout == 32))    # conv_wgrad_launch's rule
     s16 = k33 and t % 4 == 0 and cin == 16 and pc.cout in (16, 32)
     wino = k33 and not x3pc and pc.cout >= 64 and cin >= 16
-    b16x3 = pc.kh == 1 and pc.kw == 1 and f > 1 and 32 <= cin < 1024 and pc.cout >= 32            # 1x1 conv2d: conv_wgrad_bf16_kernel<1,1,2,3>
+    k11 = pc.kh == 1 and pc.kw == 1 and f > 1                     # 1x1 conv2d: conv1d_wgrad_pc_kernel<1> over rows / conv_wgrad_bf16_kernel<1,1,2,3>
+    c1pc = k11 and unpool_idx is None and cin >= 64 and pc.cout >= 64 and t % 4 == 0
+    b16x3 = k11 and not c1pc and 32 <= cin < 1024 and pc.cout >= 32
     call('pbsed_conv_bwd_weight', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(g),
          ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream(),
-         tag=_conv_tag(b, cin, pc, f, t) + (' x3pc' if x3pc else ' s16x3' if s16 else ' wino' if wino else ' bf16x3' if b16x3 else ''), flops=_conv_flops(b, cin, pc, f, t))
+         tag=_conv_tag(b, cin, pc, f, t) + (' x3pc' if x3pc else ' s16x3' if s16 else ' wino' if wino else ' c1x3' if c1pc else ' bf16x3' if b16x3 else ''), flops=_conv_flops(b, cin, pc, f, t))
 
 
 def pool21_fwd(x):
