@@ -1671,10 +1671,11 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
         if (KW == 3) return launch_wgrad_cfg<Wgrad1dPcCfg<3>>(conv1d_wgrad_pc_kernel<3>, a, s);
         if (KW == 1 && a.Cin >= 512) return launch_wgrad_cfg<Wgrad1dPcCfg<1>>(conv1d_wgrad_pc_kernel<1>, a, s);
     }
-    // 1x1 conv2d layers (F > 1: net_config 'deep'): from 64 channels on and without a pool the producer / consumer kernel of
-    // the Conv1d layers over (clip, row, 32-t) units (256->256 at F = 16: 0.61 -> see DESIGN.md); the others - also under a
-    // pool - the pipelined bf16x3 kernel, which walks (clip, row, 128-t) chunks
-    if (!a.bf16 && KH == 1 && KW == 1 && a.F > 1 && !a.unpool_idx && a.Cin >= 64 && a.Cout >= 64 && (a.T & 3) == 0)
+    // 1x1 conv2d layers (F > 1: net_config 'deep'): from 128 channels on (whole 128 x 128 blocks) and without a pool the
+    // producer / consumer kernel of the Conv1d layers over (clip, row, 32-t) units (256->256 at F = 16: 0.65 -> 0.36 ms,
+    // 512->512 at F = 8: 1.13 -> 0.67; 64->64 at F = 64 with three quarters of the block idle: 0.15 -> 0.33, not taken); the
+    // others - also under a pool - the pipelined bf16x3 kernel, which walks (clip, row, 128-t) chunks
+    if (!a.bf16 && KH == 1 && KW == 1 && a.F > 1 && !a.unpool_idx && a.Cin >= 128 && a.Cout >= 128 && (a.T & 3) == 0)
         return launch_wgrad_cfg<Wgrad1dPcCfg<1>>(conv1d_wgrad_pc_kernel<1>, a, s);
     if (!a.bf16 && KH == 1 && KW == 1 && a.F > 1 && a.Cin >= 32 && a.Cout >= 32 && a.Cin < 1024)
         return launch_wgrad_cfg<WgradB16Cfg<1, 1, 2, 3>>(conv_wgrad_bf16_kernel<1, 1, 2, 3>, a, s);

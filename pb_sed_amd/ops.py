@@ -433,7 +433,7 @@ def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, se
     s16 = k33 and t % 4 == 0 and cin == 16 and pc.cout in (16, 32)
     wino = k33 and not x3pc and pc.cout >= 64 and cin >= 16
     k11 = pc.kh == 1 and pc.kw == 1 and f > 1                     # 1x1 conv2d: conv1d_wgrad_pc_kernel<1> over rows / conv_wgrad_bf16_kernel<1,1,2,3>
-    c1pc = k11 and unpool_idx is None and cin >= 64 and pc.cout >= 64 and t % 4 == 0
+    c1pc = k11 and unpool_idx is None and cin >= 128 and pc.cout >= 128 and t % 4 == 0
     b16x3 = k11 and not c1pc and 32 <= cin < 1024 and pc.cout >= 32
     call('pbsed_conv_bwd_weight', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(g),
          ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream(),

@@ -143,8 +143,8 @@ CONV_CASES = [
     dict(cin=64, cout=96, f=6, t=72, k=(1, 1), pool=True, pro=True),
     dict(cin=40, cout=48, f=5, t=100, k=(1, 1), pool=False, pro=True),
     dict(cin=32, cout=64, f=4, t=50, k=(1, 1), pool=False, pro=False),
-    dict(cin=72, cout=136, f=5, t=100, k=(1, 1), pool=False, pro=True),     # weight gradient: the Conv1d producer / consumer kernel over rows
-    dict(cin=64, cout=64, f=3, t=36, k=(1, 1), pool=False, pro=False),
+    dict(cin=136, cout=200, f=5, t=100, k=(1, 1), pool=False, pro=True),     # weight gradient: the Conv1d producer / consumer kernel over rows
+    dict(cin=128, cout=128, f=3, t=36, k=(1, 1), pool=False, pro=False),
 ]
 
 
