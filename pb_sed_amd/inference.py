@@ -24,6 +24,32 @@ def _as_dev_scores(y, device):
     return y.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+_COPY_STREAMS = {}      # device -> side stream of the host -> device hand-over
+
+
+def _to_device_ahead(model, segment, device):
+    """``model.example_to_device`` for a batch whose tensors lie in PINNED host memory: the copies go out on a side stream, so
+    the hand-over of batch n + 1 (queued while batch n still computes - inference() keeps one batch in flight) runs beside
+    batch n's kernels instead of in front of batch n + 1's; the compute stream waits for the copy's event.  Anything else
+    (device-resident or pageable inputs) takes the plain path."""
+    dev = torch.device(device)
+    if dev.type != 'cuda' or not any(isinstance(v, torch.Tensor) and not v.is_cuda and v.is_pinned() for v in segment.values()):
+        return model.example_to_device(segment, device)
+    side = _COPY_STREAMS.get(str(dev))
+    if side is None:
+        side = _COPY_STREAMS[str(dev)] = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    with torch.cuda.stream(side):
+        out = model.example_to_device(segment, device)
+        ready = torch.cuda.Event()
+        ready.record(side)
+    main.wait_event(ready)
+    for v in out.values():
+        if isinstance(v, torch.Tensor) and v.is_cuda:
+            v.record_stream(main)            # allocated under the side stream, consumed on the compute stream
+    return out
+
+
 def _run_models(models, method, segment, kwargs):
     """[(scores, seq_len)] of every model for one segment.  Networks of one class and shape that offer ``<method>_jointly``
     (models/strong_label.py) run their recurrent scans in shared launches; anything else one model after the other, as
@@ -152,7 +178,7 @@ def inference(model, method, dataset, device, max_segment_length=None, segment_o
         segments = [batch] if max_segment_length is None else segment_batch(batch, max_segment_length, segment_overlap)
         queued = []
         for segment in segments:
-            segment = models[0].example_to_device(segment, device)
+            segment = _to_device_ahead(models[0], segment, device)
             per_model, seq_len = [], None
             for y, sl in _run_models(models, method, segment, kwargs):
                 per_model.append(_as_dev_scores(y, device))

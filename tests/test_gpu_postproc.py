@@ -162,6 +162,11 @@ def test_inference_driver_keeps_a_batch_in_flight_without_changing_results():
             pulled.append(j)
             yield dict(b)
     together = inf.sound_event_detection(models, dataset(), DEV, **kwargs)
+    # the same batches handed over from pinned host memory: the copies run on a side stream, one batch ahead
+    pinned = [dict(b, audio_data=b['audio_data'].pin_memory(), tag_condition=b['tag_condition'].pin_memory()) for b in batches]
+    from_host = inf.sound_event_detection(models, pinned, DEV, **kwargs)
+    for a in one_by_one:
+        assert np.array_equal(from_host[a], one_by_one[a]), a
     assert pulled == list(range(5)) and sorted(together) == sorted(one_by_one)
     for a in one_by_one:
         assert together[a].shape == one_by_one[a].shape
