@@ -317,3 +317,47 @@ def collate(batch, pad_keys=('audio_data', 'stft', 'boundary_targets', 'strong_t
             padded.append(torch.nn.functional.pad(v, pad))
         out[k] = torch.stack(padded)
     return out
+
+
+class DevicePrefetcher:
+    """Iterate over host batches (dicts of tensors / arrays / lists; tensors in PINNED memory for the copies to be
+    asynchronous) with the host -> device hand-over of batch n + 1 in flight on a side stream while the caller trains on
+    batch n: a 10 s x 32-clip batch is 21 MB = 0.45 ms of PCIe time, 5 % of a train step if it runs in front of the step on
+    the compute stream (`h2d`).  The compute stream waits for a batch's copy event when the batch is
+    handed out.  On a CPU device the batches pass through unchanged.
+
+        for batch in DevicePrefetcher(loader, 'cuda:0'):
+            trainer.step(batch)
+    """
+
+    def __init__(self, iterable, device):
+        self.iterable, self.device = iterable, torch.device(device)
+        self._side = None
+
+    def _stage(self, batch):
+        if batch is None:
+            return None
+        if self.device.type != 'cuda':
+            return batch, None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._side):
+            out = {k: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) and not v.is_cuda else v)
+                   for k, v in batch.items()}
+            ready = torch.cuda.Event()
+            ready.record(self._side)
+        return out, ready
+
+    def __iter__(self):
+        it = iter(self.iterable)
+        staged = self._stage(next(it, None))
+        while staged is not None:
+            batch, ready = staged
+            if ready is not None:
+                main = torch.cuda.current_stream(self.device)
+                main.wait_event(ready)
+                for v in batch.values():
+                    if isinstance(v, torch.Tensor) and v.is_cuda:
+                        v.record_stream(main)        # allocated under the side stream, consumed on the compute stream
+            staged = self._stage(next(it, None))     # batch n + 1 starts travelling before the caller works on batch n
+            yield batch

@@ -579,3 +579,34 @@ def test_trainer_reports_a_timed_out_scan_one_step_late_and_never_updates_from_i
         trainer.step(batch)
         trainer.finish()
         assert not torch.equal(trainer.flat_param, before)
+
+
+def test_device_prefetcher_hands_over_identical_batches_one_ahead():
+    """data.DevicePrefetcher: pinned host batches arrive on the device unchanged, in order, with the copy of batch n + 1 issued
+    (side stream) before batch n is handed out; a model step on a prefetched batch gives the loss of the resident batch."""
+    from pb_sed_amd.data import DevicePrefetcher
+    from pb_sed_amd.models import weak_label
+    torch.manual_seed(2)
+    host = []
+    for i in range(4):
+        wav, seq, weak, bnd = synth_batch(3, 16000, 10, ragged=True, seed=40 + i)[:4]
+        host.append({'audio_data': wav.pin_memory(), 'seq_len': seq.tolist(), 'weak_targets': weak.pin_memory(),
+                     'boundary_targets': bnd.pin_memory()})
+    pulled = []
+
+    def loader():
+        for i, b in enumerate(host):
+            pulled.append(i)
+            yield b
+    model = weak_label.CRNN.build(num_events=10, number_of_filters=128, hidden_size=64, num_layers=2, net=TINY).to(DEV).eval()
+    n = 0
+    for i, b in enumerate(DevicePrefetcher(loader(), DEV)):
+        assert len(pulled) == min(i + 2, 4)                     # one batch ahead
+        assert b['audio_data'].is_cuda and torch.equal(b['audio_data'].cpu(), host[i]['audio_data'])
+        assert torch.equal(b['weak_targets'].cpu(), host[i]['weak_targets']) and b['seq_len'] == host[i]['seq_len']
+        with torch.no_grad():
+            ya = model.tagging(dict(b))[0]
+            yb = model.tagging({k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in host[i].items()})[0]
+        assert torch.equal(ya, yb)
+        n += 1
+    assert n == 4

@@ -351,3 +351,22 @@ def test_collate_pads_along_time():
     assert out['example_id'] == ['a', 'b'] and out['seq_len'] == [7, 5]
     assert out['audio_data'].shape == (2, 1, 50) and out['audio_data'][1, 0, 40:].abs().sum() == 0
     assert out['stft'].shape == (2, 1, 7, 3, 2) and out['stft'][1, 0, 5:].abs().sum() == 0 and out['stft'][1, 0, :5].min() == 1
+
+
+def test_device_prefetcher_passes_batches_through_in_order():
+    """data.DevicePrefetcher on a CPU device: same batches, same order, one batch pulled ahead at most (the GPU path - side
+    stream, events - is exercised by tests/test_gpu_model.py)."""
+    from pb_sed_amd.data import DevicePrefetcher
+    pulled = []
+
+    def loader():
+        for i in range(4):
+            pulled.append(i)
+            yield {'audio_data': torch.full((2, 8), float(i)), 'seq_len': [3, 2], 'example_id': [f'a{i}', f'b{i}']}
+    seen = []
+    for batch in DevicePrefetcher(loader(), 'cpu'):
+        seen.append(int(batch['audio_data'][0, 0]))
+        assert len(pulled) <= len(seen) + 1
+        assert batch['seq_len'] == [3, 2]
+    assert seen == [0, 1, 2, 3] and pulled == [0, 1, 2, 3]
+    assert list(DevicePrefetcher([], 'cpu')) == []
