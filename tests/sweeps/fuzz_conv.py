@@ -35,7 +35,7 @@ def err(a, b):
 worst = {}
 for case in range(n_cases):
     k = [(3, 3), (3, 3), (1, 1), (1, 3)][rng.integers(4)]
-    two_d = k == (3, 3)
+    two_d = k == (3, 3) or (k == (1, 1) and rng.random() < .4)       # 1x1 conv2d layers (net_config 'deep'): rows, pools
     cin = int(rng.choice([1, 3, 8, 11, 16, 24, 32, 40, 64, 96, 128, 200]))
     cout = int(rng.choice([5, 10, 16, 24, 32, 48, 64, 96, 128, 160, 256]))
     f = int(rng.choice([2, 4, 6, 8, 10, 16, 22])) if two_d else 1
@@ -43,10 +43,10 @@ for case in range(n_cases):
     pool = bool(two_d and f % 2 == 0 and rng.random() < .5)
     pro = bool(cin > 1 and rng.random() < .7)
     b = int(rng.integers(1, 4))
-    prec = 'wino' if (two_d and cin >= 16 and rng.random() < .6) else 'f32'
+    prec = 'wino' if (k == (3, 3) and cin >= 16 and rng.random() < .6) else 'f32'
     if cin >= 16 and rng.random() < .2:
         prec = 'bf16x3'                            # 3-way bf16 split: fp32-class accuracy through the bf16 MFMA kernels
-    if two_d and cin >= 16 and rng.random() < .4:
+    if k == (3, 3) and cin >= 16 and rng.random() < .4:
         prec = 'winox3'                            # round 3: producer / consumer bf16x3 Winograd (64- and 32-cout blocks; T % 4 != 0
     if not two_d and rng.random() < .5:            # falls back to the fp32 Winograd kernel), producer / consumer Conv1d
         prec = 'c1x3'
