@@ -14,8 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                        ('fuzz_postproc.py', ['24', '13']), ('fuzz_frontend.py', ['12', '14']),
                                        ('fuzz_model.py', ['10', '15']), ('fuzz_gru_wgrad.py', ['30', '16'])])
 def test_randomised_sweep(tool, args):
+    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '32'))      # the float64 references: see conftest.py
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'sweeps', tool), *args], capture_output=True, text=True,
-                         timeout=600, cwd=ROOT)
+                         timeout=600, cwd=ROOT, env=env)
     text = out.stdout + out.stderr
     assert out.returncode == 0, text[-2000:]
     flagged = [line for line in text.splitlines() if ' BAD' in line or 'EXCEPTION' in line or 'FAILED' in line]
