@@ -10,9 +10,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('tool,args', [('fuzz_conv.py', ['30', '11']), ('fuzz_gru.py', ['7', '12']),
-                                       ('fuzz_postproc.py', ['24', '13']), ('fuzz_frontend.py', ['12', '14']),
-                                       ('fuzz_model.py', ['10', '15']), ('fuzz_gru_wgrad.py', ['30', '16'])])
+@pytest.mark.parametrize('tool,args', [('fuzz_conv.py', ['100', '11']), ('fuzz_gru.py', ['16', '12']),
+                                       ('fuzz_postproc.py', ['48', '13']), ('fuzz_frontend.py', ['24', '14']),
+                                       ('fuzz_model.py', ['20', '15']), ('fuzz_gru_wgrad.py', ['60', '16'])])
 def test_randomised_sweep(tool, args):
     env = dict(os.environ, OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '32'))      # the float64 references: see conftest.py
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'sweeps', tool), *args], capture_output=True, text=True,
