@@ -146,6 +146,16 @@ def _grad_table(grads, ref64, ref32, dec, rerun64, tol=2e-4, tag=None, seq_len=N
 
 # ------------------------------------------------------------------------------------------------ C2
 def test_c2_fbcrnn_shallow_b8_logits_loss_grads():
+    _c2_parity(REAL_B)
+
+
+def test_c2_fbcrnn_shallow_b32_logits_loss_grads():
+    """The same comparison at the batch the benchmark is quoted on (BASELINE.json configs[1]: 32 clips): three oracle passes on
+    the CPU, two of them in float64 - the longest test of the suite."""
+    _c2_parity(32)
+
+
+def _c2_parity(batch):
     from oracle import frontend as ofe, models as om
     from pb_sed_amd.models import weak_label
     torch.manual_seed(0)
@@ -156,7 +166,7 @@ def test_c2_fbcrnn_shallow_b8_logits_loss_grads():
     model.to(DEV).train()
     model.keep_logits = True
     ref64 = copy.deepcopy(ref).double().train()
-    wav, seq, weak, bnd, t = _sorted_batch(REAL_B, 160000, seed=21)      # (three oracle passes on the CPU: fp32, float64 free / imposed)
+    wav, seq, weak, bnd, t = _sorted_batch(batch, 160000, seed=21)      # (three oracle passes on the CPU: fp32, float64 free / imposed)
     assert t == 500
     cap_f, cap_b = _Capture(ref.rnn_fwd), _Capture(ref.rnn_bwd)
     ref.train()
