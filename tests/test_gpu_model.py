@@ -290,22 +290,24 @@ def test_bicrnn_bf16_train_step():
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
 
 
-def test_trainer_three_steps_follow_the_oracle():
+@pytest.mark.parametrize('size', ['small', 'config2'])
+def test_trainer_three_steps_follow_the_oracle(size):
     """pb_sed_amd.trainer.Trainer (flat buffers, fused clip + Adam, one batched weight re-pack per step, deferred
     host summary) for three optimisation steps vs the oracle driven by clip_grad_norm_ + torch.optim.Adam: loss
-    trajectory, gradient norm and the parameters after the last step."""
+    trajectory, gradient norm and the parameters after the last step.  'config2': the 'shallow' FBCRNN of BASELINE.json
+    configs[1] at its real width on 10 s clips (8 of them)."""
     from oracle import frontend as ofe, models as om
     from pb_sed_amd.models import weak_label
     from pb_sed_amd.trainer import Trainer
     torch.manual_seed(1)
     wide = dict(out_channels_2d=[16, 32, 64], pool_sizes_2d=[1, (2, 1), (2, 1)], kernel_size_2d=3,
                 out_channels_1d=[64, 64], kernel_size_1d=[3, 1])          # 32->64 3x3: Winograd kernels in the loop
-    kw = dict(num_events=10, number_of_filters=128, hidden_size=64, num_layers=2, net=wide)
+    kw = dict(num_events=10, number_of_filters=128, hidden_size=64, num_layers=2, net=wide) if size == 'small' else dict(num_events=10)
     ref = om.FBCRNN.build(**kw)
     model = weak_label.CRNN.build(**kw)
     _copy_weights(model, ref)
     model.to(DEV)
-    wav, seq, weak, bnd, t = synth_batch(6, 16000 * 2, 10)
+    wav, seq, weak, bnd, t = synth_batch(6, 16000 * 2, 10) if size == 'small' else synth_batch(8, 160000, 10, seed=5)
     inputs_ref = {'stft': ofe.stft(wav), 'seq_len': seq.tolist(), 'weak_targets': weak, 'boundary_targets': bnd}
     inputs = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV),
               'boundary_targets': bnd.to(DEV)}
@@ -313,6 +315,19 @@ def test_trainer_three_steps_follow_the_oracle():
     opt = torch.optim.Adam(ref.parameters(), lr=lr)
     trainer = Trainer(model, lr=lr, gradient_clipping=clip)
     ref.train()
+
+    def parameters_agree(after_steps, frac_bar, mean_bar):
+        refp = dict(ref.named_parameters())
+        for name, p in model.named_parameters():
+            # Adam steps of size <= lr each: a wrong / stale weight copy anywhere shows up as O(lr) differences
+            if refp[name].grad.abs().max().item() < 1e-6:
+                continue          # a bias in front of a batch norm: exactly-zero gradient, Adam random-walks on rounding noise
+            # Adam's first steps move every element by ~lr * sign(g): elements whose gradient is at rounding-noise level may
+            # walk differently, anything systematic (a stale weight copy, a wrong moment) moves whole tensors by O(lr)
+            diff = (p.detach().cpu() - refp[name].detach()).abs()
+            assert (diff > 0.5 * lr).float().mean().item() < frac_bar and diff.mean().item() < mean_bar * lr, \
+                f'{name}: parameters differ (mean {diff.mean():.2e}, max {diff.max():.2e}) after {after_steps} step(s) of lr {lr}'
+
     for step in range(3):
         opt.zero_grad()
         rev_ref = ref.review(inputs_ref, ref(inputs_ref))
@@ -320,19 +335,22 @@ def test_trainer_three_steps_follow_the_oracle():
         norm_ref = torch.nn.utils.clip_grad_norm_(ref.parameters(), clip)
         opt.step()
         rev = trainer.step(inputs)
-        assert rev['loss'].item() == pytest.approx(rev_ref['loss'].item(), rel=2e-4), f'loss at step {step}'
-        assert rev['scalars']['grad_norm'].item() == pytest.approx(norm_ref.item(), rel=5e-3), f'grad norm at step {step}'
+        # The sign-like first Adam steps amplify rounding-level differences: at the real width (3.9 M parameters, 10 s clips)
+        # 0.8 % of a tensor's elements step the other way after one update, 6 % differ by half a step after two, 12 % after
+        # three (tools/micro/traj_debug.py) and the losses drift apart at 1e-4 .. 1e-3 - the same happens between two float32
+        # CPU runs with different summation orders.  What is exact is step 0; after that the small net stays tight and the
+        # real one is held to bounds that a stale weight copy or a wrong moment (O(lr) on whole tensors) would break.
+        tight = size == 'small' or step == 0
+        assert rev['loss'].item() == pytest.approx(rev_ref['loss'].item(), rel=2e-4 if tight else 1e-2), f'loss at step {step}'
+        assert rev['scalars']['grad_norm'].item() == pytest.approx(norm_ref.item(), rel=5e-3 if tight else 6e-2), f'grad norm at step {step}'
         assert rev['scalars']['weak_label_rate'] == pytest.approx(float(rev_ref['scalars']['weak_label_rate']), abs=1e-6)
-    refp = dict(ref.named_parameters())
-    for name, p in model.named_parameters():
-        # three Adam steps of size <= lr each: a wrong / stale weight copy anywhere shows up as O(lr) differences
-        if refp[name].grad.abs().max().item() < 1e-6:
-            continue          # a bias in front of a batch norm: exactly-zero gradient, Adam random-walks on rounding noise
-        # Adam's first steps move every element by ~lr * sign(g): elements whose gradient is at rounding-noise level may
-        # walk differently, anything systematic (a stale weight copy, a wrong moment) moves whole tensors by O(lr)
-        diff = (p.detach().cpu() - refp[name].detach()).abs()
-        assert (diff > 0.5 * lr).float().mean().item() < 0.01 and diff.mean().item() < 0.05 * lr, \
-            f'{name}: parameters differ (mean {diff.mean():.2e}, max {diff.max():.2e}) after 3 steps of lr {lr}'
+        if step == 0 and size != 'small':
+            torch.cuda.synchronize()
+            parameters_agree(1, 0.02, 0.04)
+    if size == 'small':
+        parameters_agree(3, 0.01, 0.05)
+    else:
+        parameters_agree(3, 0.6, 0.8)        # (see above: 12 - 30 % of a small tensor's elements are half a step apart by now)
 
 
 def test_fbcrnn_full_size_properties():
