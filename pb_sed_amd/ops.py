@@ -435,6 +435,9 @@ def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, se
     k11 = pc.kh == 1 and pc.kw == 1 and f > 1                     # 1x1 conv2d: conv1d_wgrad_pc_kernel<1> over rows / conv_wgrad_bf16_kernel<1,1,2,3>
     c1pc = k11 and unpool_idx is None and cin >= 128 and pc.cout >= 128 and t % 4 == 0
     b16x3 = k11 and not c1pc and 32 <= cin < 1024 and pc.cout >= 32
+    if f == 1 and pc.kh == 1 and unpool_idx is None:              # Conv1d layers: conv1d_wgrad_pc_kernel / conv_wgrad_bf16_kernel<1,KW,2,3>
+        c1pc = cin >= 64 and pc.cout >= 64 and (pc.kw == 3 or (pc.kw == 1 and cin >= 512))
+        b16x3 = not c1pc and pc.kw in (1, 3) and 32 <= cin < 1024 and pc.cout >= 32
     call('pbsed_conv_bwd_weight', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(g),
          ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream(),
          tag=_conv_tag(b, cin, pc, f, t) + (' x3pc' if x3pc else ' s16x3' if s16 else ' wino' if wino else ' c1x3' if c1pc else ' bf16x3' if b16x3 else ''), flops=_conv_flops(b, cin, pc, f, t))
