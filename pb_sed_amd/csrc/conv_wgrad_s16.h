@@ -1,5 +1,6 @@
-// 3x3 weight gradient of the few-channel layers (16 or 32 input channels, 16 or 32 output channels: layers 2 - 4 of the
-// 'shallow' net, the 32-channel groups of 'deep') with fp32-class operands on the bf16 MFMA; included by conv_wgrad.hip.
+// 3x3 weight gradient of the few-channel layers (16 input channels, 16 or 32 output channels: layers 2 and 3 of the 'shallow'
+// net; the kernel itself takes 16-channel tiles of any multiple, the dispatch at the end of this file says which shapes win)
+// with fp32-class operands on the bf16 MFMA; included by conv_wgrad.hip.
 //
 //     dW[co][ci][kf][kt] = sum_{b,f,t} dY[b,co,f,t] * a[b,ci,f+kf-1,t+kt-1]          (a = prologue(x), dY un-pooled)
 //
