@@ -34,7 +34,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_s16_kernel(ConvWgradArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci = blockIdx.y * 16 + lr, cout0 = blockIdx.z * 16 * MT;
     const bool pro = a.scale != nullptr;
-    const float sc = pro ? a.scale[ci] : 1.f, sh = pro ? a.shift[ci] : 0.f;
+    const bool ci_ok = ci < a.Cin;                        // fewer than 16 input channels (the tag-conditioned 11 -> 16 layer): the
+                                                          // missing lanes read zeros and their columns are not written
+    const float sc = !ci_ok ? 0.f : pro ? a.scale[ci] : 1.f, sh = (pro && ci_ok) ? a.shift[ci] : 0.f;
     const float floor_v = (pro && a.relu) ? 0.f : -__builtin_inff();
     const bool do_bias = a.db != nullptr && blockIdx.y == 0;
     const int Fg = UNPOOL ? a.F / 2 : a.F;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_s16_kernel(ConvWgradArgs a)
         RawX rx[3];
         RawG rg[3];
         auto load_x = [&](int f, RawX& o) __attribute__((always_inline)) {
-            const unsigned off = (f >= 0 && f < a.F) ? xo + (unsigned)(f * a.T) : OOB;
+            const unsigned off = (f >= 0 && f < a.F && ci_ok) ? xo + (unsigned)(f * a.T) : OOB;
             o.q0 = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off * 4u, 0, 0);
             o.q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off * 4u + 16u, 0, 0);
             o.l = __builtin_amdgcn_raw_buffer_load_b32(rs_x, off * 4u - 4u, 0, 0);
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_s16_kernel(ConvWgradArgs a)
     float* dwp = a.dw + (size_t)slot * a.slot_w;
     for (int i = tid; i < 16 * MT * OUT_ROW; i += 256) {
         const int co = cout0 + i / OUT_ROW, col = i % OUT_ROW;
-        atomicAdd(dwp + ((size_t)co * a.Cin + blockIdx.y * 16) * 9 + col, smem[i]);
+        if ((int)blockIdx.y * 16 + col / 9 < a.Cin) atomicAdd(dwp + ((size_t)co * a.Cin + blockIdx.y * 16) * 9 + col, smem[i]);
     }
     if (do_bias) {
         // a lane's partial bias sum covers its channel's eight t of every row: the four k groups of a wave, then the waves
@@ -214,7 +216,7 @@ static int launch_wgrad_s16_t(const ConvWgradArgs& a_in, hipStream_t s) {
     ConvWgradArgs a = a_in;
     auto kern = conv_wgrad_s16_kernel<MT, UNPOOL>;
     const int nUnits = a.B * ((a.T + 31) / 32) * ((a.F + WgradS16::FS - 1) / WgradS16::FS);
-    const int gy = a.Cin / 16, gz = a.Cout / (16 * MT);
+    const int gy = (a.Cin + 15) / 16, gz = a.Cout / (16 * MT);
     // two blocks per CU over all (input tile, output tile) pairs; a multiple of 8 columns keeps the pairs of one unit range on
     // one XCD (block id = x + gx * (y + gy * z), XCD = id % 8): they read the same rows, from one L2
     int gx = (2 * device_cus()) / (gy * gz) / 8 * 8;
@@ -235,12 +237,13 @@ static int launch_wgrad_s16_t(const ConvWgradArgs& a_in, hipStream_t s) {
     return check_launch("conv_wgrad_s16");
 }
 
-// 3x3, fp32 path, 16 input channels, 16 or 32 output channels, T % 4 == 0 (16-byte loads).  Measured at B = 32, T = 500
+// 3x3, fp32 path, 2 .. 16 input channels (11: the tag-conditioned first layer of the BiCRNN), 16 or 32 output channels, T % 4 == 0
+// (16-byte loads).  Measured at B = 32, T = 500
 // (tools/gpu_conv_bench.py): 16->16 F = 128 under a pool 187 -> 116 us, 16->32 F = 64 162 -> 118 us; 32->32 F = 64 (four tile
 // pairs) 185 us against 153 us of conv_wgrad_pc_kernel, which keeps it.  A row is ~260 VALU instructions (splits 110, un-pool
 // 30, prologue 20, addresses) and 54 MFMAs, and the two do not overlap on a SIMD: ~1 900 clocks per row and wave.
 static bool wgrad_s16_takes(const ConvWgradArgs& a, int KH, int KW) {
-    return !a.bf16 && KH == 3 && KW == 3 && a.Cin == 16 && (a.Cout == 16 || a.Cout == 32) && (a.T & 3) == 0;
+    return !a.bf16 && KH == 3 && KW == 3 && a.Cin >= 2 && a.Cin <= 16 && (a.Cout == 16 || a.Cout == 32) && (a.T & 3) == 0;
 }
 
 // one (16 cout, 16 cin) tile pair per wave: two output tiles per wave need 256 registers with one row in flight, and the

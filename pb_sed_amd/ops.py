@@ -430,7 +430,7 @@ def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, se
     # bf16x3 kernel from 64 channels on, the Winograd-F(4,3) fp32 kernel for the other 3x3 layers with >= 64 output channels
     k33 = pc.kh == 3 and pc.kw == 3
     x3pc = k33 and t % 4 == 0 and ((cin >= 64 and pc.cout >= 64) or (cin == 32 and pc.cout == 32))    # conv_wgrad_launch's rule
-    s16 = k33 and t % 4 == 0 and cin == 16 and pc.cout in (16, 32)
+    s16 = k33 and t % 4 == 0 and 2 <= cin <= 16 and pc.cout in (16, 32)
     wino = k33 and not x3pc and pc.cout >= 64 and cin >= 16
     k11 = pc.kh == 1 and pc.kw == 1 and f > 1                     # 1x1 conv2d: conv1d_wgrad_pc_kernel<1> over rows / conv_wgrad_bf16_kernel<1,1,2,3>
     c1pc = k11 and unpool_idx is None and cin >= 128 and pc.cout >= 128 and t % 4 == 0

@@ -138,6 +138,8 @@ CONV_CASES = [
     dict(cin=32, cout=32, f=22, t=72, k=(3, 3), pool=False, pro=True),
     dict(cin=32, cout=16, f=17, t=36, k=(3, 3), pool=False, pro=False),
     dict(cin=16, cout=32, f=48, t=64, k=(3, 3), pool=True, pro=False),
+    dict(cin=11, cout=16, f=20, t=64, k=(3, 3), pool=True, pro=True),       # fewer than 16 input channels: idle lanes, unwritten columns
+    dict(cin=5, cout=32, f=6, t=36, k=(3, 3), pool=False, pro=True),
     # 1x1 conv2d layers (every second layer of net_config 'deep'; forward / data gradient in the bf16 tests below, the
     # weight gradient here): one row per tile, two under a (2,1) pool
     dict(cin=64, cout=96, f=6, t=72, k=(1, 1), pool=True, pro=True),
