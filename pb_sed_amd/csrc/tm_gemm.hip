@@ -16,6 +16,9 @@
 
 namespace pbsed {
 
+#ifndef TG_DBG
+#define TG_DBG 0            // ablation switches of tools/kernel_ablation.sh (never set in the product build): 1 W not staged, 2 X not staged, 8 no MFMAs
+#endif
 constexpr int TG_MAX = 4;                 // (X, W) pairs per launch
 constexpr int TG_BR = 128, TG_BN = 128, TG_KC = 32, TG_KP = 40;
 
@@ -91,8 +94,8 @@ __global__ __launch_bounds__(256, 2) void tm_gemm_kernel(TmGemmArgs a) {
         __syncthreads();                                           // the previous stage's fragments have been read
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            put(xs, it_row + 64 * i, rx[i]);
-            put(ws, it_row + 64 * i, rw[i]);
+            if (!(TG_DBG & 2)) put(xs, it_row + 64 * i, rx[i]);
+            if (!(TG_DBG & 1)) put(ws, it_row + 64 * i, rw[i]);
         }
         __syncthreads();
         more = advance();
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(256, 2) void tm_gemm_kernel(TmGemmArgs a) {
                 bf[p] = *reinterpret_cast<const u32x4_t*>(xs + (size_t)(p * TG_BR + wr * 64 + rt * 16 + lr) * TG_KP + lq * 8);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
+                if (TG_DBG & 8) continue;
                 if constexpr (NS == 3) acc[nt][rt] = mfma_x3(Bf3{af[nt][0], af[nt][1], af[nt][2]}, Bf3{bf[0], bf[1], bf[2]}, acc[nt][rt]);
                 else acc[nt][rt] = mfma_b16(af[nt][0], bf[0], acc[nt][rt]);
             }
