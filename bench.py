@@ -141,7 +141,7 @@ def cpu_train_baseline(kind, batches=(32, 16), steps=3):
     from oracle import frontend as ofe, models as om
     n = _cpu_threads()
     model_name, n_logical, aff = host_cpu()
-    res = {}
+    res, scan = {}, None
     for batch in batches:
         torch.manual_seed(0)
         if kind == 'deep':
@@ -151,9 +151,9 @@ def cpu_train_baseline(kind, batches=(32, 16), steps=3):
             model = (om.FBCRNN.build() if kind == 'c2' else om.BiCRNN.build(tag_conditioning=True)).train()
         opt = torch.optim.Adam(model.parameters(), lr=5e-4)
         b = synth_batch(batch, 'cpu', kind=kind)
-        times, stages = [], []
-        for i in range(steps + 1):
-            st = {}
+
+        def step_once(st):
+            st = {} if st is None else st
             t0 = time.perf_counter()
             stft = ofe.stft(b['audio_data'])
             seq = np.array(b['seq_len'])
@@ -186,26 +186,47 @@ def cpu_train_baseline(kind, batches=(32, 16), steps=3):
             torch.nn.utils.clip_grad_norm_(model.parameters(), 1e10)
             opt.step()
             st['clip_adam'] = time.perf_counter() - t1
-            times.append(time.perf_counter() - t0)
+            return time.perf_counter() - t0
+
+        times, stages = [], []
+        for i in range(steps + 1):
+            st = {}
+            times.append(step_once(st))
             stages.append(st)
             print(f'[bench] cpu_baseline {kind} batch {batch} step {i}: {times[-1]:.2f} s on {n} threads', file=sys.stderr, flush=True)
             if sum(times) > 60.:                     # bounded sample: stop early on a slow host
                 break
+        if kind == 'c2' and batch == batches[0] and aff >= 64 and sum(times) < 60.:
+            # SURVEY.md 8(d) says "all host cores": one step each at 64 / 128 intra-op threads shows why the baseline stops at 32
+            scan = {}
+            for nt in (64, 128):
+                if nt > aff:
+                    break
+                torch.set_num_threads(nt)
+                ts_ = []
+                for _ in range(2):                   # the first step after a pool resize pays for the new threads
+                    t_s = time.perf_counter()
+                    step_once(None)
+                    ts_.append(time.perf_counter() - t_s)
+                scan[str(nt)] = round(batch / ts_[-1], 3)
+                print(f'[bench] cpu_baseline {kind} batch {batch}: {ts_[-1]:.2f} s on {nt} threads', file=sys.stderr, flush=True)
+            torch.set_num_threads(n)
         timed = times[1:] if len(times) > 1 else times
         dt = float(np.median(timed))
         med = stages[1 + int(np.argsort(timed)[len(timed) // 2])] if len(times) > 1 else stages[0]
         res[batch] = {'clips_per_s': round(batch / dt, 3), 's_per_step': round(dt, 3), 'timed_steps': len(timed),
                       'stage_s': {k: round(v, 3) for k, v in med.items()}}
     main_b = batches[0]
-    what = {'c2': 'FBCRNN', 'deep': "FBCRNN net_config 'deep' width 2"}.get(kind, 'tag-conditioned BiCRNN')
+    what = {'c2': 'FBCRNN', 'deep': "FBCRNN 'deep'"}.get(kind, 'tag-cond. BiCRNN')
     out = {'value': res[main_b]['clips_per_s'], 'unit': 'clips/s', 'cores': n, 'kind': 'port',
-           'sample': f'oracle (stock-PyTorch CPU restatement, fp32) {what} train step incl. STFT, batch {main_b} x 10 s clips, '
-                     f'1 warm-up + {res[main_b]["timed_steps"]} timed steps, median',
+           'sample': f'oracle {what} train step incl. STFT, batch {main_b}, 1 warm-up + {res[main_b]["timed_steps"]} timed steps, median',
            'cpu_model': model_name, 'host_logical_cpus': n_logical, 'affinity_cpus': aff, 'threads_used': n,
            'threads_note': 'intra-op threads capped at min(affinity, 32): the oracle step is many small GRU / conv ops whose CPU time stops falling (and then rises) beyond ~32 threads on this class of host; cores = threads used, not the host total',
            f'batch{main_b}': res[main_b]}
     for bb in batches[1:]:
         out[f'batch{bb}'] = res[bb]
+    if scan is not None:
+        out['threads_scan'] = scan
     if kind == 'c2' and 16 in res:
         out['configs0_stand_in'] = ('BASELINE.json configs[0] (reference plumbing on DESED-weak, batch 16, CPU) is not runnable '
                                     '(padertorch / DESED audio absent): batch16 above is the oracle on synthetic clips')
@@ -773,9 +794,108 @@ def main():
     if rank == 0:
         if rendezvous is not None:
             out['rendezvous'] = rendezvous
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ the contract line
+LINE_LIMIT = 6000           # bytes; tests/test_host_logic.py::test_bench_contract_line_is_compact holds the line to it
+
+
+def _clean(x):
+    """strict JSON: no NaN / Infinity (json.loads of a strict parser refuses them)"""
+    if isinstance(x, float):
+        return x if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _clean(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_clean(v) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+ROOFLINE_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_kind', 'kernel', 'avg_ms', 'flops_per_launch',
+                 'operands', 'us_per_time_step')
+
+
+def _short_roofline(r):
+    r = _pick(r, ROOFLINE_KEYS)
+    if 'operands' in r:
+        r['operands'] = r['operands'].split(' ')[0]           # 'bf16x3', 'bf16', 'f32'
+    if 'kernel' in r:
+        r['kernel'] = r['kernel'][:96]
+    return r
+
+
+def contract_line(out):
+    """The ONE stdout line the driver parses: the contract keys + compact roofline / cpu_baseline / other_configs objects.
+    Everything else of `out` (notes, per-entry-point tables, sub-config details) goes to stderr and gpurun_out/bench_detail.json."""
+    line = _pick(out, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                       'vs_baseline', 'data'))
+    line['dtype'] = str(out.get('dtype', '')).split(' ')[0]
+    cfg = out.get('config', {})
+    line['config'] = _pick(cfg, ('global_batch', 'n_params', 'parallelism', 'clips_per_rank', 'models'))
+    line['config']['workload'] = str(cfg.get('workload', ''))[:160]
+    line['roofline'] = _short_roofline(out.get('roofline'))
+    for key in ('roofline_conv', 'frontend_hbm'):
+        if key in out:
+            line[key] = _short_roofline(out[key])
+    if 'roofline_gru' in out:
+        line['roofline_gru'] = {k: _pick(v, ('ms_per_step', 'achieved', 'frac', 'us_per_time_step', 'polled_bytes_per_launch'))
+                                for k, v in out['roofline_gru'].items() if k in ('forward_scan', 'bptt_scan')}
+    if 'cpu_baseline' in out:
+        cb = out['cpu_baseline']
+        c = _pick(cb, ('value', 'unit', 'cores', 'kind', 'cpu_model', 'host_logical_cpus'))
+        c['sample'] = str(cb.get('sample', ''))[:100]
+        for k, v in cb.items():
+            if k.startswith('batch') and isinstance(v, dict) and 'clips_per_s' in v:
+                c[k + '_clips_per_s'] = v['clips_per_s']
+        if 'threads_scan' in cb:
+            c['threads_scan'] = cb['threads_scan']
+        line['cpu_baseline'] = c
+    if 'sustained' in out:
+        line['sustained'] = _pick(out['sustained'], ('clips_per_s', 'steps'))
+    if 'step_mfma' in out:
+        line['step_mfma'] = _pick(out['step_mfma'], ('algorithmic_tflops_per_gpu', 'frac_algorithmic_of_fp32_mfma_peak',
+                                                     'frac_algorithmic_of_bf16_mfma_peak'))
+    if 'loss' in out:
+        line['loss'] = out['loss']
+    if 'other_configs' in out:
+        oc = {}
+        for k, v in out['other_configs'].items():
+            if 'error' in v:
+                oc[k] = {'error': str(v['error'])[:120]}
+                continue
+            rf = v.get('roofline', {})
+            oc[k] = {'value': v.get('value'), 'ms_per_step': v.get('ms_per_step'), 'dtype': str(v.get('dtype', '')).split(' ')[0],
+                     'roofline_frac': rf.get('frac'), 'kernel': str(rf.get('kernel', ''))[:64]}
+        line['other_configs'] = oc
+    if 'rendezvous' in out:
+        line['rendezvous'] = out['rendezvous']
+    if 'allreduce' in out:
+        line['allreduce'] = _pick(out['allreduce'], ('implementation', 'bytes_per_step', 'exposed_ms_per_step',
+                                                     'busbw_GBs_if_fully_exposed', 'time_at_ring_bound_ms'))
+    line['detail'] = 'gpurun_out/bench_detail.json'
+    return _clean(line)
+
+
+def emit(out):
+    """Full result -> stderr + gpurun_out/bench_detail.json; the compact contract line -> stdout (one line, < LINE_LIMIT bytes)."""
+    detail = json.dumps(_clean(out), allow_nan=False)
+    try:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'), 'w') as f:
+            f.write(detail + '\n')
+    except OSError as e:
+        print(f'[bench] bench_detail.json not written: {e}', file=sys.stderr)
+    print('[bench] detail: ' + detail, file=sys.stderr, flush=True)
+    text = json.dumps(contract_line(out), allow_nan=False, separators=(',', ':'))
+    assert len(text) < LINE_LIMIT and '\n' not in text, len(text)
+    print(text, flush=True)
 
 
 def run_config(args, kind, world, rank, device, sustained_steps=0):

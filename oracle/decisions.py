@@ -112,3 +112,24 @@ def disagreements(dec_a, dec_b, seq_len=None):
             else:
                 out[f'{name}.{k}'] = count(v, w)
     return out
+
+
+def positions(dec, seq_len=None):
+    """Number of decided positions per entry of ``dec`` (same keys as ``disagreements``; inside the sequences when ``seq_len``
+    is given) - the denominator of a bound on how many positions two runs may decide differently."""
+    import numpy as np
+
+    def count(v):
+        if seq_len is not None and v.dim() >= 2 and v.shape[0] == len(seq_len):
+            per_clip = v[0].numel() // v.shape[-1]
+            return int(sum(min(int(n), v.shape[-1]) for n in np.asarray(seq_len)) * per_clip)
+        return int(v.numel())
+
+    out = {}
+    for name, d in dec.items():
+        if torch.is_tensor(d):
+            out[name] = count(d)
+            continue
+        for k, v in d.items():
+            out[f'{name}.{k}'] = sum(count(x) for x in v.values()) if isinstance(v, dict) else count(v)
+    return out

@@ -697,19 +697,39 @@ def check_gru_sync():
             gru_flags_raise(st[0].cpu().numpy())
 
 
-_PINNED = {}            # (shape, dtype) -> list of [pinned host tensor, event of its last use, held by a pending batch]
+_PINNED = {}            # byte size class (power of two) -> list of [view, event of its last use, held, backing uint8 buffer]
+_PINNED_MAX_BYTES = 1 << 30      # page-locked memory the pool may keep; beyond it idle buffers of the largest classes go first
+
+
+def _pinned_trim():
+    total = sum(sl[3].numel() for pool in _PINNED.values() for sl in pool)
+    for cls in sorted(_PINNED, reverse=True):
+        pool = _PINNED[cls]
+        for sl in list(pool):
+            if total <= _PINNED_MAX_BYTES:
+                return
+            if not sl[2] and (sl[1] is None or sl[1].query()):
+                pool.remove(sl)
+                total -= sl[3].numel()
 
 
 def pinned_buffer(shape, dtype, hold=False):
-    """A pinned host buffer out of a per-shape pool (allocating pinned memory costs a driver call): one that no pending
-    batch holds and whose last asynchronous use has completed, else a new one (the pool settles at the few buffers the
-    pipeline depth needs; nothing here waits for the device).  The caller records an event behind its copy with
-    ``pinned_buffer_used``; ``hold`` keeps the buffer out of circulation until its reader clears slot[2]."""
-    pool = _PINNED.setdefault((tuple(shape), dtype), [])
+    """A pinned host buffer out of a pool keyed by BYTE SIZE CLASS (next power of two, >= 256 B): one that no pending batch
+    holds and whose last asynchronous use has completed, else a new one (allocating pinned memory costs a driver call; the
+    pool settles at the few buffers the pipeline depth needs and variable-length batches share classes instead of pinning a
+    buffer per distinct shape; nothing here waits for the device).  slot[0] is a view of the requested shape / dtype.  The
+    caller records an event behind its copy with ``pinned_buffer_used``; ``hold`` keeps the buffer out of circulation until
+    its reader clears slot[2]."""
+    shape = tuple(int(d) for d in shape)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dtype).element_size()
+    cls = max(256, 1 << max(nbytes - 1, 0).bit_length())
+    pool = _PINNED.setdefault(cls, [])
     slot = next((sl for sl in pool if not sl[2] and (sl[1] is None or sl[1].query())), None)
     if slot is None:
-        slot = [torch.empty(tuple(shape), dtype=dtype, pin_memory=True), None, False]
+        slot = [None, None, False, torch.empty(cls, dtype=torch.uint8, pin_memory=True)]
         pool.append(slot)
+        _pinned_trim()
+    slot[0] = slot[3][:nbytes].view(dtype).view(shape)
     slot[2] = hold
     return slot
 
@@ -751,6 +771,7 @@ def gru_flags_snapshot():
 
 def gru_flags_check(snapshot):
     for slot in snapshot:
+        slot[1].synchronize()              # the copy's own event: the caller may only have waited for an earlier one
         words = slot[0].numpy().copy()
         slot[2] = False
         gru_flags_raise(words)

@@ -101,14 +101,43 @@ class LibraryGradSync:
             rank = dist.get_rank() if world > 1 else 0
         self.world, self.rank = world, rank
         self._comm = _LibraryComm(flat_grad.device) if comm is None else comm
+        # Both stages are agreed on COLLECTIVELY when a process group is up: every rank issues the same control
+        # collectives in the same order whatever fails locally (a raise on rank 0 before the broadcast would leave the
+        # other ranks waiting in it; a communicator that comes up on some ranks only would leave the groups diverged).
+        grouped = world > 1 and dist.is_available() and dist.is_initialized()
+        err = None
         if unique_id is None:
-            box = [self._comm.unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(box, src=0)
+            box = [None]
+            if rank == 0:
+                try:
+                    box[0] = self._comm.unique_id()
+                except (RuntimeError, OSError) as ex:
+                    err = ex
+            if grouped:
+                dist.broadcast_object_list(box, src=0)              # None = rank 0 could not make one
             unique_id = box[0]
+            if unique_id is None:
+                raise RuntimeError(f'library communicator: no unique id from rank 0 ({err})')
         assert len(unique_id) == self._comm.id_bytes()
-        self._comm.create(unique_id, rank, world)
+        try:
+            self._comm.create(unique_id, rank, world)
+        except (RuntimeError, OSError) as ex:
+            err = ex
+        if grouped and not self._agree(err is None):
+            if err is None:                                         # up here, not everywhere: take it down again
+                self._comm.destroy()
+            raise RuntimeError(f'library communicator not created on every rank ({err or "another rank failed"})')
+        if err is not None:
+            raise err
         self._done = set()
+
+    def _agree(self, ok):
+        """MIN over the torch process group of a local success flag (control plane, once at construction)."""
+        backend = dist.get_backend()
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                            device=self.flat_grad.device if backend == 'nccl' else 'cpu')
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
 
     def bucket_ready(self, i):
         if i in self._done:
@@ -137,7 +166,7 @@ def make_grad_sync(flat_grad, buckets, allreduce=None):
     communicator (LibraryGradSync - the path include/pbsed.h describes: RCCL on a library-owned stream, event fences, no
     torch call on the data path); 'torch' (torch.distributed.all_reduce on the initialised group, backend "nccl" = RCCL)
     otherwise - a single process, CPU tensors (gloo tests), or when the library's communicator cannot be created (a warning
-    says so; every rank takes the same branch because ncclCommInitRank fails or succeeds collectively)."""
+    says so; LibraryGradSync agrees on success over the process group after each stage, so every rank takes the same branch)."""
     import os
     import warnings
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -148,9 +177,8 @@ def make_grad_sync(flat_grad, buckets, allreduce=None):
         except (RuntimeError, OSError) as ex:
             if allreduce == 'library' or not multi:
                 raise
+            # LibraryGradSync agreed on the failure over the process group: every rank is here
             warnings.warn(f'library communicator unavailable ({ex}); falling back to torch.distributed.all_reduce')
-            ok = torch.ones((), device=flat_grad.device)
-            dist.all_reduce(ok)                          # keep the ranks in step before the first bucket
     return GradSync(flat_grad, buckets), 'torch'
 
 
@@ -251,10 +279,20 @@ class Trainer:
         self.last_enqueue_s = 0.            # host time of the last step up to (not including) the wait for its summary
         self.measure_sync, self.sync_events = False, None   # bench.py: event pairs around the wait for the collectives
         self.snapshot_statistics()
+        # the baseline must be the state the replicas share when training (re)starts: a checkpoint loaded into the model
+        # after this constructor would otherwise count as 'tracked since the last merge' on every rank (its history summed
+        # world times).  Re-snapshot after every load_state_dict and once more at the first step.
+        self._stepped = False
+        self._watch_loads()
+
+    def _watch_loads(self):
+        if hasattr(self.model, 'register_load_state_dict_post_hook'):
+            self.model.register_load_state_dict_post_hook(lambda module, incompatible: self.snapshot_statistics())
 
     def snapshot_statistics(self):
         """Record the cumulative statistics (modules with a ``num_tracked_values`` counter) as the state all replicas share
-        - the baseline of the first sync_buffers() merge.  Called by __init__; call it again after loading a checkpoint."""
+        - the baseline of the first sync_buffers() merge.  Called by __init__, after every ``model.load_state_dict`` (post
+        hook) and at the first step(); call it yourself after writing the buffers any other way mid-training."""
         buffers = dict(self.model.named_buffers())
         self._synced_stats, self._synced_verified = {}, set()
         for name in buffers:
@@ -338,6 +376,9 @@ class Trainer:
     def step(self, batch):
         """One optimisation step.  Returns the review dict (loss is a device scalar, no host sync)."""
         t_start = time.perf_counter()
+        if not self._stepped:
+            self._stepped = True
+            self.snapshot_statistics()               # whatever was loaded since __init__ (load_init_checkpoint, copy_) is shared state
         self.model.train()
         self.flat_grad.zero_()
         flags = ops.gru_flags(self.flat_param.device) if self.flat_param.is_cuda else None

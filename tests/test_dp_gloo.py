@@ -152,6 +152,27 @@ def _equal_count_worker(rank, world, port, out_dir):
         ok = ok and all(torch.equal(g_, gathered[0]) for g_ in gathered)        # the replicas AGREE afterwards
         t.sync_buffers()                              # ... and stay put
         ok = ok and fe.num_tracked_values.item() == tot and torch.allclose(fe.running_mean, got[0], atol=1e-7)
+    # a checkpoint loaded into every replica AFTER the Trainer was built (snapshot at count 0) is shared
+    # state, not 'tracked since the last merge': its 1000 frames must be counted once, not once per rank
+    m = M()
+    fe = m.feature_extractor
+    t = Trainer.__new__(Trainer)
+    t.model = m
+    t.snapshot_statistics()
+    t._watch_loads()
+    ckpt = M()
+    with torch.no_grad():
+        ckpt.feature_extractor.running_mean.fill_(2.), ckpt.feature_extractor.running_power.fill_(7.)
+        ckpt.feature_extractor.num_tracked_values.fill_(1000.)
+    m.load_state_dict(ckpt.state_dict())
+    with torch.no_grad():
+        fe.running_mean.copy_((fe.running_mean * 1000. + (rank + 1.) * 100.) / 1100.)
+        fe.running_power.copy_((fe.running_power * 1000. + 10. * (rank + 1.) * 100.) / 1100.)
+        fe.num_tracked_values.fill_(1100.)
+    t.sync_buffers()
+    ok = ok and fe.num_tracked_values.item() == 1200.
+    ok = ok and torch.allclose(fe.running_mean, torch.full((8,), (2. * 1000. + 300.) / 1200.), atol=1e-6)
+    ok = ok and torch.allclose(fe.running_power, torch.full((8,), (7. * 1000. + 3000.) / 1200.), atol=1e-5)
     with open(os.path.join(out_dir, f'eq{rank}'), 'w') as f:
         f.write(str(bool(ok)))
     dist.destroy_process_group()
@@ -243,6 +264,72 @@ def test_library_gradsync_bucket_logic_with_a_stand_in_communicator_world2(tmp_p
     mp.spawn(_library_sync_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert open(tmp_path / f'lib{r}').read() == 'True'
+
+
+class _FailingComm(_RecordingComm):
+    def __init__(self, flat, fail_id=False, fail_create=False):
+        super().__init__(flat)
+        self.fail_id, self.fail_create = fail_id, fail_create
+
+    def unique_id(self):
+        if self.fail_id:
+            raise RuntimeError('ncclGetUniqueId failed (test)')
+        return super().unique_id()
+
+    def create(self, unique_id, rank, world):
+        if self.fail_create:
+            raise RuntimeError('ncclCommInitRank failed (test)')
+        super().create(unique_id, rank, world)
+
+
+def _library_failure_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pb_sed_amd import trainer
+    g = torch.ones(100) * (rank + 1)
+    ok = True
+    # (1) rank 0 cannot make the unique id; (2) the communicator comes up on rank 0 only: in both cases EVERY rank must
+    # raise (same control collectives everywhere), and the one that came up is taken down again
+    for fail_id, fail_create in ((rank == 0, False), (False, rank == 1)):
+        comm = _FailingComm(g, fail_id, fail_create)
+        try:
+            trainer.LibraryGradSync(g, [(0, 100)], comm=comm)
+            ok = False
+        except RuntimeError:
+            pass
+        if not fail_id and not fail_create and any(c[0] == 'create' for c in comm.calls):
+            ok = ok and comm.calls[-1] == ('destroy',)
+    # the process group is still in step: a plain collective goes through on both ranks
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    ok = ok and t.item() == 3.0
+    # make_grad_sync falls back to torch.distributed on every rank together
+    import warnings
+    real = trainer._LibraryComm
+    trainer._LibraryComm = lambda device: _FailingComm(g, fail_id=(rank == 0))
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            sync, name = trainer.make_grad_sync(g, [(0, 100)], allreduce=None)
+    finally:
+        trainer._LibraryComm = real
+    ok = ok and name == 'torch' and isinstance(sync, trainer.GradSync)
+    sync.bucket_ready(0)
+    sync.finish()
+    ok = ok and torch.equal(g, torch.full((100,), 3.))
+    with open(os.path.join(out_dir, f'fail{rank}'), 'w') as f:
+        f.write(str(bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_library_gradsync_failures_are_agreed_on_by_all_ranks(tmp_path, monkeypatch):
+    """a failure of unique_id() on rank 0 or of create() on some ranks must not leave the ranks in
+    different collectives - every rank raises / falls back together and the process group stays usable."""
+    monkeypatch.setenv('PBSED_ALLREDUCE', 'library')           # CPU tensors would pick 'torch' by default
+    mp.spawn(_library_failure_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f'fail{r}').read() == 'True'
 
 
 def test_make_grad_sync_defaults():

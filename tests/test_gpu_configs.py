@@ -131,6 +131,13 @@ def _grad_table(grads, ref64, ref32, dec, rerun64, tol=2e-4, tag=None, seq_len=N
     for err, name, err_free, err32 in rows[:8]:
         print(f'  {name:40s} err {err:.2e}   vs the free float64 run {err_free:.2e}   fp32 CPU oracle vs free float64 {err32:.2e}')
     n_flip = sum(flips.values())
+    # the imposed decisions are the HIP run's own: bound how many of them the free float64 run takes differently, entry by
+    # entry (a kernel that decided pool rows / ReLU signs / the selector wrongly at more than rounding-level ties would pass
+    # the gradient gate on its own branch).  Measured: <= 36 of 4.1e6 positions (9e-6) on the worst entry.
+    sizes = od.positions(dec, seq_len)
+    for key, nf in flips.items():
+        if nf > max(4, 1e-4 * sizes.get(key, 0)):
+            bad.append(f'{key}: the free float64 run decides {nf} of {sizes.get(key)} positions differently (> 1e-4)')
     print(f'  {sum(1 for r in rows if r[0] <= tol)} of {len(rows)} tensors within {tol:g}; {n_imposed} decision tensors imposed, '
           f'{n_flip} positions decided differently by the free float64 run')
     if tag is None:
@@ -139,6 +146,7 @@ def _grad_table(grads, ref64, ref32, dec, rerun64, tol=2e-4, tag=None, seq_len=N
     _record(tag, kind='per-tensor gradient error vs the float64 oracle with the HIP run\'s decisions imposed (max-abs / tensor max)',
             tol=tol, tensors=len(rows), within_tol_outright=sum(1 for r in rows if r[0] <= tol), failed=len(bad),
             decision_tensors_imposed=n_imposed, positions_the_free_float64_run_decides_differently=n_flip,
+            decided_positions=sum(sizes.get(k, 0) for k in flips),
             differing_positions={k: v for k, v in flips.items() if v},
             worst=[dict(name=n, err=e, err_vs_free_float64_run=ef, fp32_cpu_oracle_vs_free_float64=e32) for e, n, ef, e32 in rows[:12]])
     return bad

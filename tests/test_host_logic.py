@@ -370,3 +370,49 @@ def test_device_prefetcher_passes_batches_through_in_order():
         assert batch['seq_len'] == [3, 2]
     assert seen == [0, 1, 2, 3] and pulled == [0, 1, 2, 3]
     assert list(DevicePrefetcher([], 'cpu')) == []
+
+
+def _strict_loads(text):
+    def refuse(tok):
+        raise ValueError(f'non-strict JSON constant {tok}')
+    return json.loads(text, parse_constant=refuse)
+
+
+@pytest.mark.parametrize('canned', ['r04_bench_c2.json', 'r04_bench_c3.json', 'r04_bench_c5.json', 'r04_bench_deep.json'])
+def test_bench_contract_line_is_compact(canned, capsys, tmp_path, monkeypatch):
+    """bench.py's stdout is ONE short strict-JSON line with the contract keys, `roofline` and `cpu_baseline` (round 4's
+    23.7 KB line was not parsed by the driver); the full result goes to stderr / gpurun_out/bench_detail.json."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    full = json.load(open(os.path.join(root, 'profiles', canned)))
+    full['roofline']['achieved'] = float('nan')                        # a stray NaN must not reach the line
+    if canned.endswith('c2.json'):
+        assert 'other_configs' in full and 'cpu_baseline' in full
+        full['rendezvous'] = {'backend': 'nccl (RCCL)', 'ranks_seen': 8, 'allreduce_check': 36.0}
+        full['allreduce'] = {'implementation': 'pbsed_allreduce', 'bytes_per_step': 13972752, 'exposed_ms_per_step': 0.05,
+                             'busbw_GBs_if_fully_exposed': 400.0, 'time_at_ring_bound_ms': 0.16, 'note': 'x' * 500, 'buckets': ['a'] * 40}
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    bench.emit(full)
+    cap = capsys.readouterr()
+    lines = [l for l in cap.out.split('\n') if l]
+    assert len(lines) == 1
+    assert len(lines[0]) < 6000, len(lines[0])
+    line = _strict_loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert key in line, key
+    assert line['dtype'] in ('f32', 'bf16', 'bf16x3')
+    assert 'workload' in line['config']
+    assert 'frac' in line['roofline'] and 'traffic' in line['roofline'] and 'note' not in line['roofline']
+    assert line['roofline']['achieved'] is None
+    if 'cpu_baseline' in full:
+        assert line['cpu_baseline']['value'] == full['cpu_baseline']['value']
+        assert len(line['cpu_baseline']['sample']) <= 100
+    if canned.endswith('c2.json'):
+        assert set(line['other_configs']) == {'c3', 'c5', 'deep'}
+        assert line['rendezvous']['ranks_seen'] == 8 and line['allreduce']['exposed_ms_per_step'] == 0.05
+        assert 'note' not in line['allreduce']
+    detail = _strict_loads(open(tmp_path / 'gpurun_out' / 'bench_detail.json').read())
+    assert detail['metric'] == full['metric']

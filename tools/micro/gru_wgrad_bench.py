@@ -1,10 +1,10 @@
-"""Time the batched GRU weight-gradient launch of the headline step (8 GEMMs [768 x 256] over 16000 rows) with the fp32-MFMA
-kernel, the bf16x3 kernel (default of pbsed_gru_wgrad) and plain bf16 operands.  gpurun: python tools/micro/gru_wgrad_bench.py"""
+"""Time the batched GRU weight-gradient launch of the headline step (8 GEMMs [768 x 256] over 16000 rows) with the bf16x3
+kernel (fp32 path of pbsed_gru_wgrad) and plain bf16 operands.  gpurun: python tools/micro/gru_wgrad_bench.py"""
 import os, sys, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 if len(sys.argv) == 1:
-    for env, prec in (('0', 'f32'), ('1', 'f32'), ('1', 'bf16')):
-        subprocess.run([sys.executable, __file__, prec], env=dict(os.environ, PBSED_GRU_WGRAD_X3=env))
+    for prec in ('f32', 'bf16'):
+        subprocess.run([sys.executable, __file__, prec])
     sys.exit(0)
 import torch
 from pb_sed_amd import ops
@@ -26,4 +26,4 @@ for k, n in ((256, 8), (512, 4), (256, 2), (512, 2)):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
-    print(f'X3={os.environ.get("PBSED_GRU_WGRAD_X3")} {prec:5s} {n} x [{g} x {k}] x {t * b}: {ms:.3f} ms  {2 * n * t * b * g * k / ms / 1e9:.1f} TFLOP/s')
+    print(f'{prec:5s} {n} x [{g} x {k}] x {t * b}: {ms:.3f} ms  {2 * n * t * b * g * k / ms / 1e9:.1f} TFLOP/s')
