@@ -196,7 +196,7 @@ def cpu_train_baseline(kind, batches=(32, 16), steps=3):
             print(f'[bench] cpu_baseline {kind} batch {batch} step {i}: {times[-1]:.2f} s on {n} threads', file=sys.stderr, flush=True)
             if sum(times) > 60.:                     # bounded sample: stop early on a slow host
                 break
-        if kind == 'c2' and batch == batches[0] and aff >= 64 and sum(times) < 60.:
+        if kind == 'c2' and batch == batches[-1] and aff >= 64 and sum(times) < 60.:
             # SURVEY.md 8(d) says "all host cores": one step each at 64 / 128 intra-op threads shows why the baseline stops at 32
             scan = {}
             for nt in (64, 128):
@@ -208,7 +208,7 @@ def cpu_train_baseline(kind, batches=(32, 16), steps=3):
                     t_s = time.perf_counter()
                     step_once(None)
                     ts_.append(time.perf_counter() - t_s)
-                scan[str(nt)] = round(batch / ts_[-1], 3)
+                scan[f'batch{batch}_clips_per_s_at_{nt}_threads'] = round(batch / ts_[-1], 3)
                 print(f'[bench] cpu_baseline {kind} batch {batch}: {ts_[-1]:.2f} s on {nt} threads', file=sys.stderr, flush=True)
             torch.set_num_threads(n)
         timed = times[1:] if len(times) > 1 else times
