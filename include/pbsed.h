@@ -139,6 +139,17 @@ int pbsed_conv_bwd_data(const float* g, const float* wd_packed, const unsigned c
 int pbsed_conv_bwd_weight(const float* x, const float* scale, const float* shift, int relu,
                           const int* seq_len, const float* g, const unsigned char* unpool_idx, float* dw,
                           float* db, int B, int Cin, int Cout, int F, int T, int KH, int KW, void* stream);
+/* pbsed_conv_bwd_weight with the batch-norm backward of the NEXT layer's input norm (padertorch Normalization behind
+ * pb_sed/experiments/weak_label_crnn/training.py:218-242) applied while dY is staged: dz = that norm's masked ReLU-backward
+ * gradient (output of pbsed_conv_bwd_data), gx = this conv's raw output, coef [3][Cout * (per_cf ? Fo : 1)] from
+ * pbsed_bn_bwd_coef, gseq = the norm's sequence lengths; dY = k1 dz + k2 gx + k3 is also written to gout for the data
+ * gradient.  Replaces pbsed_bn_bwd + pbsed_conv_bwd_weight.  PBSED_E_UNSUPPORTED where no kernel has the loader
+ * (pbsed_conv_bwd_weight_bng_supported returns 1 / 0). */
+int pbsed_conv_bwd_weight_bng(const float* x, const float* scale, const float* shift, int relu, const int* seq_len,
+                              const float* dz, const float* gx, const float* coef, int per_cf, const int* gseq, float* gout,
+                              const unsigned char* unpool_idx, float* dw, float* db, int B, int Cin, int Cout, int F, int T,
+                              int KH, int KW, void* stream);
+int pbsed_conv_bwd_weight_bng_supported(int KH, int KW, int Cin, int Cout, int F, int T, int per_cf);
 /* bf16-MFMA operands (rounded while staged), fp32 accumulation / gradients; < 32 channels: the fp32 kernels. */
 int pbsed_conv_bwd_weight_bf16(const float* x, const float* scale, const float* shift, int relu,
                           const int* seq_len, const float* g, const unsigned char* unpool_idx, float* dw,
@@ -249,6 +260,9 @@ int pbsed_bn_bwd(float* dz, const float* x, const double* sums, double count, co
                  void* stream);
 int pbsed_bn_bwd_finalize(const double* sums, double count, float* dgamma, float* dbeta, float* m1, float* m2,
                           int C, void* stream);
+/* sums -> dgamma, dbeta (+=) and coef [3][C]: dx = coef[0][c] dz + coef[1][c] x + coef[2][c] (pbsed_conv_bwd_weight_bng). */
+int pbsed_bn_bwd_coef(const double* sums, double count, const float* mean, const float* invstd, const float* scale,
+                      float* dgamma, float* dbeta, float* coef, int C, void* stream);
 int pbsed_bn_bwd_apply(float* dz, const float* x, const float* mean, const float* invstd, const float* scale,
                        const float* m1, const float* m2, const int* seq_len, int B, int C, int S, int T,
                        void* stream);

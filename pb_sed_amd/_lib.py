@@ -57,6 +57,9 @@ SIGNATURES = {
     'pbsed_conv_bwd_data_bf16': [_v, _v, _v, _v, _v, _v, _v, _v, _v, _v, I, _v, I, I, I, I, I, I, I, I, _v],
     'pbsed_conv_bwd_weight': [_v, _v, _v, I, _v, _v, _v, _v, _v, I, I, I, I, I, I, I, _v],
     'pbsed_conv_bwd_weight_bf16': [_v, _v, _v, I, _v, _v, _v, _v, _v, I, I, I, I, I, I, I, _v],
+    'pbsed_conv_bwd_weight_bng': [_v, _v, _v, I, _v, _v, _v, _v, I, _v, _v, _v, _v, _v, I, I, I, I, I, I, I, _v],
+    'pbsed_conv_bwd_weight_bng_supported': [I, I, I, I, I, I, I],
+    'pbsed_bn_bwd_coef': [_v, F64, _v, _v, _v, _v, _v, _v, I, _v],
     'pbsed_bn_finalize': [_v, F64, _v, _v, F32, F32, _v, _v, _v, _v, _v, _v, I, _v],
     'pbsed_bn_eval_params': [_v, _v, F32, _v, _v, _v, _v, _v, _v, I, _v],
     'pbsed_bn_bwd': [_v, _v, _v, F64, _v, _v, _v, _v, _v, _v, I, I, I, I, _v],
@@ -109,7 +112,7 @@ SIGNATURES = {
     'pbsed_allreduce_begin': [_v, _v, SZ, _v],
     'pbsed_allreduce_finish': [_v, _v],
 }
-_NON_STATUS = {'pbsed_gru_granule_capacity': C.c_int, 'pbsed_scratch_bytes': C.c_size_t, 'pbsed_last_error': C.c_char_p, 'pbsed_version': C.c_int, 'pbsed_comm_id_bytes': C.c_int, 'pbsed_conv_pack_dims': None,
+_NON_STATUS = {'pbsed_gru_granule_capacity': C.c_int, 'pbsed_conv_bwd_weight_bng_supported': C.c_int, 'pbsed_scratch_bytes': C.c_size_t, 'pbsed_last_error': C.c_char_p, 'pbsed_version': C.c_int, 'pbsed_comm_id_bytes': C.c_int, 'pbsed_conv_pack_dims': None,
                'pbsed_conv_pack_dims_bf16': None, 'pbsed_conv_pack_dims_wino': None, 'pbsed_conv_pack_dims_winox3': None, 'pbsed_conv_pack_dims_s16': None,
                'pbsed_conv1d_pack_dims_x3': None}
 

@@ -203,6 +203,29 @@ int pbsed_conv_bwd_weight(const float* x, const float* scale, const float* shift
     return conv_wgrad_launch(a, KH, KW, (hipStream_t)stream);
 }
 
+// pbsed_conv_bwd_weight with the BN backward of the NEXT layer's input norm folded into the dY loader: `dz` is that norm's
+// masked ReLU-backward gradient (what pbsed_conv_bwd_data wrote), `gx` the raw output of this conv (the norm's input), `coef`
+// [3][Cout * (per_cf ? Fo : 1)] from pbsed_bn_bwd_coef, `gseq` the sequence lengths the norm masks with (null = T).  The
+// kernel multiplies with dY = k1 dz + k2 gx + k3 (0 beyond the sequence) and writes it to `gout` (same shape as dz) for the
+// layer's data gradient - the stand-alone pbsed_bn_bwd pass over the tensor is not needed.  Shapes without such a kernel
+// return PBSED_E_UNSUPPORTED (ask pbsed_conv_bwd_weight_bng_supported first).
+int pbsed_conv_bwd_weight_bng(const float* x, const float* scale, const float* shift, int relu, const int* seq_len,
+                              const float* dz, const float* gx, const float* coef, int per_cf, const int* gseq, float* gout,
+                              const unsigned char* unpool_idx, float* dw, float* db, int B, int Cin, int Cout, int F, int T,
+                              int KH, int KW, void* stream) {
+    if (!dz || !gx || !coef || !gout) { set_error("conv_bwd_weight_bng: dz, gx, coef and gout are required"); return PBSED_E_ARG; }
+    ConvWgradArgs a{};
+    a.x = x; a.scale = scale; a.shift = shift; a.relu = relu; a.seq_len = seq_len; a.g = dz;
+    a.unpool_idx = unpool_idx; a.dw = dw; a.db = db;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.F = F; a.T = T;
+    a.gx = gx; a.gcoef = coef; a.gseq = gseq; a.gout = gout; a.g_cf = per_cf;
+    return conv_wgrad_launch(a, KH, KW, (hipStream_t)stream);
+}
+
+int pbsed_conv_bwd_weight_bng_supported(int KH, int KW, int Cin, int Cout, int F, int T, int per_cf) {
+    return conv_wgrad_bng_supported(KH, KW, Cin, Cout, F, T, 0, per_cf) ? 1 : 0;
+}
+
 // Same contract with bf16-MFMA operands (x after its prologue and dY are rounded to bf16 while staged; products are
 // accumulated, reduced and returned in fp32).  Layers with fewer than 32 input or output channels run the fp32 kernels.
 int pbsed_conv_bwd_weight_bf16(const float* x, const float* scale, const float* shift, int relu,

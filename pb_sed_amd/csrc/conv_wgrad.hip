@@ -922,7 +922,7 @@ __global__ __launch_bounds__(MH * 128) void conv_wgrad_bf16_kernel(ConvWgradArgs
 // Consumer waves: WM x WN wave tiles of (MTL x 16 cout) x (NTL x 16 cin), times KS waves that SPLIT THE STEP'S TIME RANGE (wave
 // ks contracts over t = 32 ks .. + 31 of a 32 KS wide step; the partial sums meet in the final LDS reduction): the layers with
 // 16 / 32 channels have one or two MFMA tiles per side, and four waves only find work along t.  WM * WN * KS = 4.
-template <int WM, int WN, int KS = 1, int MTL = 2, int NTL = 2>
+template <int WM, int WN, int KS = 1, int MTL = 2, int NTL = 2, bool GT = false>
 struct WgradPcCfg {
     static_assert(WM * WN * KS == 4, "four consumer waves");
     static constexpr bool COLUMNS = true;                                // launch_wgrad_cfg: the split is over (clip, column) units
@@ -935,7 +935,9 @@ struct WgradPcCfg {
     static constexpr int YB_CH = (NJ + 1) * 4, YB_PART = COUT_T * YB_CH; // boundary words: per cout row NJ dwords {dY[8j - 1], dY[8j + 8]} (+ 1 pad:
     static constexpr int DY_STAGE = 3 * (DY_PART + YB_PART), X_SLOT = 3 * X_PART;   // odd dword stride = conflict-free 4-byte reads)
     static constexpr int X_BASE = 2 * DY_STAGE;                         // LDS: dY stage 0, dY stage 1, x slots 0..3, zero slot
-    static constexpr int LDS_MAIN = X_BASE + 5 * X_SLOT;
+    // GT (the BN-backward loader, BNG kernels): two fp32 tiles [cout][TT t] of the formed dY on their way to global memory
+    static constexpr int G_BASE = X_BASE + 5 * X_SLOT, G_STAGE = COUT_T * TT * 4;
+    static constexpr int LDS_MAIN = G_BASE + (GT ? 2 * G_STAGE : 0);
     static constexpr int XQ = TT / 4, YQ = TT / 4 + 2;                   // 4-element quads per x row / per dY row (one more on either side)
     static constexpr int DY_ITEMS = COUT_T * YQ, X_ITEMS = CIN_T * XQ;
     static constexpr int DY_PER_T = (DY_ITEMS + 255) / 256, X_PER_T = (X_ITEMS + 255) / 256;
@@ -947,9 +949,13 @@ struct WgradPcCfg {
     static_assert(YB_CH / 4 % 2 == 1 && (XCH / 16) % 2 == 1, "odd strides");
 };
 
-template <int WM, int WN, int KS = 1, int MTL = 2, int NTL = 2>
+// BNG: the dY loader applies the BN backward of the next layer's input norm (ConvWgradArgs::gx / gcoef / gseq / gout): one more
+// 16-byte load and three coefficient loads per dY quad, two FMAs per element, and - in the blocks of the first cin tile - a
+// 16-byte store of dY for the layer's data gradient; the stand-alone elementwise pass over the tensor disappears.
+// (BNG = 1: coefficients per channel, per-thread constants; 2: per (channel, output row), loaded with every step.)
+template <int WM, int WN, int KS = 1, int MTL = 2, int NTL = 2, int BNG = 0>
 __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
-    using C = WgradPcCfg<WM, WN, KS, MTL, NTL>;
+    using C = WgradPcCfg<WM, WN, KS, MTL, NTL, BNG != 0>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
 
@@ -970,7 +976,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
     int nColMine = 0;
     if ((int)blockIdx.x < nCols) nColMine = (nCols - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
     const int nSteps = nColMine * a.F;
-    constexpr int NBU = WgradPcCfg<WM, WN, KS, MTL, NTL>::NB;
+    constexpr int NBU = C::NB;
     const int nStepsR = (nSteps + NBU - 1) / NBU * NBU;                  // the producers' loop body covers NB steps without conditions
 
     f32x4 acc[MTL][NTL][9], accb[MTL];
@@ -1013,6 +1019,29 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
             y_valid[i] = y_item[i] & (cout0 + cl < a.Cout);
             y_base[i] = (cout0 + cl) * Fg * a.T + 4 * y_q[i];
         }
+        // BNG: coefficient row of the item's channel and whether this thread writes the item's dY (inner quads, first cin tile)
+        const int cfS = BNG == 2 ? Fg : 1;
+        const unsigned nCoef = (unsigned)(a.Cout * cfS);
+        const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.gcoef), 0, BNG ? 3u * nCoef * 4u : 0u, 0x00020000);
+        unsigned y_c[BNG ? C::DY_PER_T : 1];
+        int y_wr[BNG ? C::DY_PER_T : 1];
+        unsigned y_g[BNG ? C::DY_PER_T : 1];
+        float y_k[BNG == 1 ? C::DY_PER_T : 1][3];
+        if constexpr (BNG != 0) {
+#pragma unroll
+            for (int i = 0; i < C::DY_PER_T; ++i) {
+                const int it = pt + i * 256, cl = it / C::YQ;
+                y_c[i] = (unsigned)((cout0 + cl) * cfS);
+                y_wr[i] = y_item[i] & (y_q[i] >= 0) & (y_q[i] < C::TT / 4);      // an inner quad: has a place in the fp32 tile
+                y_g[i] = (unsigned)(cl * C::TT * 4 + (y_q[i] & (C::TT / 4 - 1)) * 16);
+                if constexpr (BNG == 1) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        y_k[i][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_k, y_valid[i] ? y_c[i] * 4u : 0x80000000u, k * nCoef * 4u, 0));
+                }
+            }
+        }
         int x_q[C::X_PER_T], x_valid[C::X_PER_T], x_item[C::X_PER_T];
         unsigned x_lds[C::X_PER_T];
         int x_base[C::X_PER_T];
@@ -1035,6 +1064,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
         u32x4_t ry[NB][C::DY_PER_T], rx[NB][C::X_PER_T];
         unsigned ryi[NB][C::DY_PER_T];
         int ry_n[NB][C::DY_PER_T], rx_n[NB][C::X_PER_T], r_par[NB];
+        u32x4_t rgx[BNG ? NB : 1][C::DY_PER_T];                 // BNG: the raw conv output under the norm, the item's three
+        unsigned rk[BNG == 2 ? NB : 1][C::DY_PER_T][3];         // coefficients (per step when they depend on the row)
 
         // step S of the block = (column S / F of its list, row S % F).  Raw set S % 2 holds what is staged DURING step S - 1 ..
         // the dY tile of step S and the x row of step S + 1 (x row g lives in ring slot g % 4; rows 0 and 1 of the stream are
@@ -1053,7 +1084,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
             const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
                 unpool ? const_cast<uint8_t*>(a.unpool_idx) + (size_t)b * gclip : nullptr, 0, unpool ? gclip : 0u, 0x00020000);
             r_par[BUF] = f & 1;
-            const unsigned y_row = (unsigned)((unpool ? (f >> 1) : f) * a.T + t0);
+            const int fg = unpool ? (f >> 1) : f;
+            const unsigned y_row = (unsigned)(fg * a.T + t0);
+            int tlim_g = a.T;
+            __amdgpu_buffer_rsrc_t rs_gx = rs_g;
+            if constexpr (BNG != 0) {
+                const int bc = min(b, a.B - 1);
+                tlim_g = a.gseq ? min(a.gseq[bc], a.T) : a.T;
+                rs_gx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gx) + (size_t)b * gclip, 0, gclip * 4u, 0x00020000);
+            }
 #pragma unroll
             for (int i = 0; i < C::DY_PER_T; ++i) {
                 const int tq = t0 + 4 * y_q[i];
@@ -1062,7 +1101,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
                 const unsigned off = ((unsigned)(y_base[i] + (int)y_row) & ok) | (OOB & ~ok);
                 ry[BUF][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, off * 4u, 0, 0);
                 if (unpool) ryi[BUF][i] = __builtin_amdgcn_raw_buffer_load_b32(rs_i, off, 0, 0);
-                ry_n[BUF][i] = (int)((unsigned)min(a.T - tq, 4) & ok);
+                if constexpr (BNG != 0) {
+                    rgx[BUF][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_gx, off * 4u, 0, 0);
+                    if constexpr (BNG == 2) {
+                        const unsigned coff = (((y_c[i] + (unsigned)fg) * 4u) & ok) | (0x80000000u & ~ok);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) rk[BUF][i][k] = __builtin_amdgcn_raw_buffer_load_b32(rs_k, coff, k * nCoef * 4u, 0);
+                    }
+                    ry_n[BUF][i] = (int)((unsigned)min(max(tlim_g - tq, 0), 4) & ok);
+                } else {
+                    ry_n[BUF][i] = (int)((unsigned)min(a.T - tq, 4) & ok);
+                }
             }
         };
         auto load_x = [&](int S, auto buf_c) __attribute__((always_inline)) {       // the x row of step S (its centre row f)
@@ -1096,11 +1145,29 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
         auto store_dy = [&](int stage, auto buf_c) __attribute__((always_inline)) {
             constexpr int BUF = decltype(buf_c)::value;
             unsigned char* dy_s = lds + stage * C::DY_STAGE;
+            unsigned char* g_s = lds + C::G_BASE + stage * C::G_STAGE;
 #pragma unroll
             for (int i = 0; i < C::DY_PER_T; ++i) {
                 if (y_item[i]) {
                     const u32x4_t r = ry[BUF][i];
                     float v[4] = {__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+                    if constexpr (BNG != 0) {
+                        const u32x4_t gr = rgx[BUF][i];
+                        const float gxv[4] = {__uint_as_float(gr.x), __uint_as_float(gr.y), __uint_as_float(gr.z), __uint_as_float(gr.w)};
+                        constexpr int KB = BNG == 2 ? BUF : 0, KI = BNG == 1 ? 1 : 0;
+                        const float k1 = BNG == 2 ? __uint_as_float(rk[KB][i][0]) : y_k[i * KI][0], k2 = BNG == 2 ? __uint_as_float(rk[KB][i][1]) : y_k[i * KI][1],
+                                    k3 = BNG == 2 ? __uint_as_float(rk[KB][i][2]) : y_k[i * KI][2];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = e < ry_n[BUF][i] ? fmaf(v[e], k1, fmaf(gxv[e], k2, k3)) : 0.f;
+                        const u32x4_t q4 = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+#if !(WGPC_DBG & 64)
+                        // dY leaves through LDS: the CONSUMER waves copy the step's fp32 tile to global memory.  A buffer store in
+                        // this (loading) wave turns every later wait for a load into s_waitcnt vmcnt(0) - on gfx9 loads and stores
+                        // share the counter but return out of order against each other - and the two-step load prefetch
+                        // collapses (measured: +30 % on the launch, also with the store hidden in inline assembly).
+                        if (y_wr[i]) *reinterpret_cast<u32x4_t*>(g_s + y_g[i]) = q4;
+#endif
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         bool keep = e < ry_n[BUF][i];
@@ -1200,9 +1267,30 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
         const unsigned a_lane = (unsigned)(wks * C::COUT_T * 64 + lr * 64 + (((lq ^ ((-(lr >> 2)) & 3)) & 3) * 16));
         const unsigned bnd_lane = (unsigned)(lr * C::YB_CH + (wks * 4 + lq) * 4);
         const unsigned b_lane = (unsigned)(lr * C::XCH + (wks * 4 + lq) * 16);
+        const bool g_writer = BNG != 0 && blockIdx.y == 0 && a.gout != nullptr;     // the first cin tile's blocks write dY out
         auto step = [&](int S) __attribute__((always_inline)) {
             const int f = S % a.F;
             const unsigned char* dy_s = lds + (S & 1) * C::DY_STAGE;
+            if constexpr (BNG != 0) {
+                // the fp32 tile of the formed dY of this step (staged by the producers) -> global memory; a pooled row is staged
+                // in two steps (both parities), written in the even one
+                if (g_writer && (!unpool || !(f & 1))) {
+                    const int col = (int)blockIdx.x + (S / a.F) * (int)gridDim.x;
+                    const int b = col / nTt, t0 = (col % nTt) * C::TT, fg = unpool ? (f >> 1) : f;
+                    const unsigned gclip = (unsigned)(a.Cout * Fg * a.T);
+                    const __amdgpu_buffer_rsrc_t rs_go = __builtin_amdgcn_make_buffer_rsrc(a.gout + (size_t)b * gclip, 0, gclip * 4u, 0x00020000);
+                    const unsigned char* g_s = lds + C::G_BASE + (S & 1) * C::G_STAGE;
+#pragma unroll
+                    for (int k = 0; k < C::COUT_T * C::TT / 4 / 256; ++k) {
+                        const int ch = wave * (C::COUT_T * C::TT / 4 / 4) + k * 64 + lane;        // 16-byte chunk of the tile
+                        const int row = ch / (C::TT / 4), tq = t0 + 4 * (ch % (C::TT / 4));
+                        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(g_s + ch * 16);
+                        const bool ok = cout0 + row < a.Cout && tq < a.T;
+                        const unsigned off = ok ? (unsigned)(((cout0 + row) * Fg + fg) * a.T + tq) * 4u : 0x80000000u;
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_go, off, 0, 0);
+                    }
+                }
+            }
             // x rows f - 1, f, f + 1 of this column: ring slots (S - 1, S, S + 1) % 4, the zero slot outside the plane
             unsigned xoff[3];
             xoff[0] = (unsigned)(C::X_BASE + (f > 0 ? ((S - 1) & 3) : 4) * C::X_SLOT);
@@ -1654,12 +1742,23 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_pc_kernel(ConvWgradArgs a) {
     }
 }
 
+// shapes whose weight-gradient kernel has the BN-backward dY loader (ConvWgradArgs::gx): the dispatch below must agree
+bool conv_wgrad_bng_supported(int KH, int KW, int Cin, int Cout, int F, int T, int bf16, int per_cf) {
+    (void)F;
+    if (bf16 || KH != 3 || KW != 3 || (T & 3)) return false;
+    return (Cin >= 64 && Cout >= 64) || (Cin == 32 && Cout == 32 && !per_cf);      // (the 32->32 form with per-row coefficients spills)
+}
+
 int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     if (a.unpool_idx && (a.F % 2)) { set_error("conv_wgrad: unpool needs even F"); return PBSED_E_ARG; }
     // the loaders address one clip with 32-bit element offsets (buffer loads; 2^29 elements marks "out of range")
     if ((size_t)a.Cin * a.F * a.T >= (1ull << 28) || (size_t)a.Cout * a.F * a.T >= (1ull << 28)) {
         set_error("conv_wgrad: one clip of x / dy must stay below 1 GiB (Cin=%d Cout=%d F=%d T=%d)", a.Cin, a.Cout, a.F, a.T);
         return PBSED_E_ARG;
+    }
+    if (a.gx && !conv_wgrad_bng_supported(KH, KW, a.Cin, a.Cout, a.F, a.T, a.bf16, a.g_cf)) {
+        set_error("conv_wgrad: no kernel with the BN-backward dY loader for %dx%d %d->%d (pbsed_conv_bwd_weight_bng_supported)", KH, KW, a.Cin, a.Cout);
+        return PBSED_E_UNSUPPORTED;
     }
     if (wgrad_s16_takes(a, KH, KW)) return launch_wgrad_s16(a, s);      // 16-channel inputs: register-resident column walk
     // Conv1d layers of the fp32 path (F = 1 rows): exact three-way operand splits on the bf16 MFMA - fp32-class gradients - in
@@ -1691,9 +1790,16 @@ int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s) {
     // and 32->64 - with one or two MFMA tiles per wave and step nothing covers the LDS round trip and the shift arithmetic of
     // the next fragment, and 16->16 has 128 columns for 256 CUs
     if (!a.bf16 && KH == 3 && KW == 3 && (a.T & 3) == 0) {
-        if (a.Cin >= 64 && a.Cout >= 64) return launch_wgrad_cfg<WgradPcCfg<2, 2>>(conv_wgrad_pc_kernel<2, 2>, a, s);
-        if (a.Cin == 32 && a.Cout == 32) return launch_wgrad_cfg<WgradPcCfg<1, 2, 2, 2, 1>>(conv_wgrad_pc_kernel<1, 2, 2, 2, 1>, a, s);
+        if (a.Cin >= 64 && a.Cout >= 64)
+            return !a.gx ? launch_wgrad_cfg<WgradPcCfg<2, 2>>(conv_wgrad_pc_kernel<2, 2>, a, s)
+                 : a.g_cf ? launch_wgrad_cfg<WgradPcCfg<2, 2, 1, 2, 2, true>>(conv_wgrad_pc_kernel<2, 2, 1, 2, 2, 2>, a, s)
+                          : launch_wgrad_cfg<WgradPcCfg<2, 2, 1, 2, 2, true>>(conv_wgrad_pc_kernel<2, 2, 1, 2, 2, 1>, a, s);
+        // (32->64 as a time-sliced 64 x 32 block, WgradPcCfg<2, 1, 2, 2, 2>: 0.162 ms against 0.149 of the fp32 Winograd form - not taken)
+        if (a.Cin == 32 && a.Cout == 32)
+            return !a.gx ? launch_wgrad_cfg<WgradPcCfg<1, 2, 2, 2, 1>>(conv_wgrad_pc_kernel<1, 2, 2, 2, 1>, a, s)
+                         : launch_wgrad_cfg<WgradPcCfg<1, 2, 2, 2, 1, true>>(conv_wgrad_pc_kernel<1, 2, 2, 2, 1, 1>, a, s);
     }
+    if (a.gx) { set_error("conv_wgrad: no kernel with the BN-backward dY loader for this shape (ask pbsed_conv_bwd_weight_bng_supported)"); return PBSED_E_UNSUPPORTED; }
     if (a.bf16 && a.Cin >= 32 && a.Cout >= 32) {       // bf16-MFMA operands (config 3); few-channel layers stay on the fp32 kernels
         if (KH == 3 && KW == 3) {
             if (a.Cout > 64) return launch_wgrad_cfg<WgradB16Cfg<3, 3, 4>>(conv_wgrad_bf16_kernel<3, 3, 4>, a, s);

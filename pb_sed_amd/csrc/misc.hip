@@ -157,6 +157,24 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double c
     m2[c] = (float)(s2 / count);
 }
 
+// BN backward as a dY prologue of the consumers (pbsed_conv_bwd_weight_bng): sums -> dgamma, dbeta (+=) and, per channel,
+// the three coefficients of  dx = gamma*invstd * (dz - m1 - xhat*m2) = k1 * dz + k2 * x + k3:
+//   k1 = scale,  k2 = -scale * invstd * m2,  k3 = -scale * (m1 - mean * invstd * m2);     coef = [3][C].
+__global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, double count, const float* mean, const float* invstd,
+                                   const float* scale, float* dgamma, float* dbeta, float* coef, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < PBSED_STAT_SLOTS; ++k) { s1 += sums[((size_t)k * C + c) * 2]; s2 += sums[((size_t)k * C + c) * 2 + 1]; }
+    if (dbeta) dbeta[c] += (float)s1;
+    if (dgamma) dgamma[c] += (float)s2;
+    const float m1 = (float)(s1 / count), m2 = (float)(s2 / count);
+    const float sc = scale[c], is = invstd[c], mu = mean[c];
+    coef[c] = sc;
+    coef[C + c] = -sc * is * m2;
+    coef[2 * C + c] = -sc * (m1 - mu * is * m2);
+}
+
 // in place: dz -> dx = gamma*invstd * (dz - m1 - xhat*m2) on masked positions (0 elsewhere).
 // tensors [B, C, S, T] with S = inner rows per channel (F for 2-D, 1 for 1-D).  VEC: 4 frames per thread.
 template <bool VEC>
@@ -233,6 +251,53 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(float* __restrict__ d
         }
     } else {
         for (int i = tid; i < S * T; i += 256) {
+            const int t = i % T;
+            dz[base + i] = (t < sl) ? sc * (dz[base + i] - a1 - (x[base + i] - mu) * is * a2) : 0.f;
+        }
+    }
+}
+
+// The same for SHORT slabs (S * T below 2 048 elements: the Conv1d layers, 500 frames per (clip, channel)): a 256-thread block
+// per slab leaves most lanes idle and pays the slot reduction + barrier per 2 KB of data (2048 channels: 90 us for a tensor
+// the long-slab form moves in 47).  Here a block takes four channels, one per wave; the wave reduces its channel's slots
+// itself, no LDS, no barrier.
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_fused_wave_kernel(float* __restrict__ dz, const float* __restrict__ x,
+                                                                const double* __restrict__ sums, double count,
+                                                                const float* mean, const float* invstd, const float* scale,
+                                                                float* dgamma, float* dbeta, const int* seq_len, int C, int S,
+                                                                int T) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (c >= C) return;
+    const int which = lane >> 5, k = lane & 31;
+    double v = (k < PBSED_STAT_SLOTS) ? sums[((size_t)k * C + c) * 2 + which] : 0.0;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o);
+    if (k == 0 && b == 0) {
+        if (which == 0 && dbeta) dbeta[c] += (float)v;
+        if (which == 1 && dgamma) dgamma[c] += (float)v;
+    }
+    const float m = (float)(v / count);
+    const float a1 = __shfl(m, 0), a2 = __shfl(m, 32);
+    const float mu = mean[c], is = invstd[c], sc = scale[c];
+    const int sl = seq_len ? seq_len[b] : T;
+    const size_t base = ((size_t)b * C + c) * S * T;
+    if (VEC) {
+        const int Tq = T / 4, n = S * Tq;
+        float4* d4 = reinterpret_cast<float4*>(dz + base);
+        const float4* x4 = reinterpret_cast<const float4*>(x + base);
+        for (int i = lane; i < n; i += 64) {
+            const int t = (i % Tq) * 4;
+            float4 d = d4[i];
+            const float4 xv = x4[i];
+            d.x = (t + 0 < sl) ? sc * (d.x - a1 - (xv.x - mu) * is * a2) : 0.f;
+            d.y = (t + 1 < sl) ? sc * (d.y - a1 - (xv.y - mu) * is * a2) : 0.f;
+            d.z = (t + 2 < sl) ? sc * (d.z - a1 - (xv.z - mu) * is * a2) : 0.f;
+            d.w = (t + 3 < sl) ? sc * (d.w - a1 - (xv.w - mu) * is * a2) : 0.f;
+            d4[i] = d;
+        }
+    } else {
+        for (int i = lane; i < S * T; i += 64) {
             const int t = i % T;
             dz[base + i] = (t < sl) ? sc * (dz[base + i] - a1 - (x[base + i] - mu) * is * a2) : 0.f;
         }
@@ -772,6 +837,13 @@ int pbsed_bn_bwd_finalize(const double* sums, double count, float* dgamma, float
     return check_launch("bn_bwd_finalize");
 }
 
+int pbsed_bn_bwd_coef(const double* sums, double count, const float* mean, const float* invstd, const float* scale,
+                      float* dgamma, float* dbeta, float* coef, int C, void* stream) {
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, mean, invstd,
+                       scale, dgamma, dbeta, coef, C);
+    return check_launch("bn_bwd_coef");
+}
+
 int pbsed_bn_bwd_apply(float* dz, const float* x, const float* mean, const float* invstd, const float* scale,
                        const float* m1, const float* m2, const int* seq_len, int B, int C, int S, int T,
                        void* stream) {
@@ -790,6 +862,15 @@ int pbsed_bn_bwd(float* dz, const float* x, const double* sums, double count, co
                  void* stream) {
     static_assert(PBSED_STAT_SLOTS <= 32, "one wave half sums the slots");
     if (B > 65535) { set_error("bn_bwd: batch %d over the grid limit", B); return PBSED_E_ARG; }
+    if ((size_t)S * T < 2048) {                       // short slabs: a wave per (clip, channel), four channels per block
+        if (T % 4 == 0)
+            hipLaunchKernelGGL(bn_bwd_fused_wave_kernel<true>, dim3((C + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, dz, x, sums,
+                               count, mean, invstd, scale, dgamma, dbeta, seq_len, C, S, T);
+        else
+            hipLaunchKernelGGL(bn_bwd_fused_wave_kernel<false>, dim3((C + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, dz, x, sums,
+                               count, mean, invstd, scale, dgamma, dbeta, seq_len, C, S, T);
+        return check_launch("bn_bwd");
+    }
     if (T % 4 == 0)
         hipLaunchKernelGGL(bn_bwd_fused_kernel<true>, dim3(C, B), dim3(256), 0, (hipStream_t)stream, dz, x, sums, count, mean,
                            invstd, scale, dgamma, dbeta, seq_len, C, S, T);

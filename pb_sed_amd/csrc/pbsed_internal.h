@@ -43,10 +43,21 @@ struct ConvWgradArgs {
     int bf16;               // bf16-MFMA operands (fp32 accumulation and gradients) where the shape allows
     int nslots;             // > 1: dw/db point at nslots partial copies (stride slot_w / slot_b floats), block x -> x % nslots
     int slot_w, slot_b;
+    // BN backward of the NEXT layer's input norm applied in the dY loader (pbsed_conv_bwd_weight_bng): g is that norm's dz
+    // (the masked ReLU-backward gradient, same shape as the conv output), the gradient the kernel multiplies with is
+    //   dY = k1[c] * dz + k2[c] * gx + k3[c]   for t < gseq[b], 0 beyond      (gx = the raw conv output the norm was applied to),
+    // k = gcoef [3][Cout * (g_cf ? Fg : 1)] (pbsed_bn_bwd_coef); the blocks of the first cin tile also WRITE dY to gout
+    // (same shape) for the layer's data gradient.  All null: g is dY itself.
+    const float* gx;
+    const float* gcoef;
+    const int* gseq;
+    float* gout;
+    int g_cf;               // coefficients per (cout, output row) instead of per cout
 };
 
 void conv_fwd_tile_dims(int KH, int KW, int Cin, int Cout, int* ck, int* cout_t);
 int conv_fwd_launch(const ConvFwdArgs& a, int KH, int KW, int pool, int dgrad, hipStream_t s);
 int conv_wgrad_launch(const ConvWgradArgs& a, int KH, int KW, hipStream_t s);
+bool conv_wgrad_bng_supported(int KH, int KW, int Cin, int Cout, int F, int T, int bf16, int per_cf);
 
 }  // namespace pbsed

@@ -127,6 +127,10 @@ def describe_stack(cnns):
 # oracle is run with (oracle/decisions.py).
 DECISION_TAP = None
 
+# BN backward formed in the dY loader of the weight-gradient kernels that have one (ops.LazyBNGrad) instead of a stand-alone
+# elementwise pass per norm; PBSED_FUSE_BN_BWD=0 restores the stand-alone passes everywhere (A/B measurements, tests).
+FUSE_BN_BWD = os.environ.get('PBSED_FUSE_BN_BWD', '0') != '0'
+
 
 def _count(seq_host, t, rows):
     return float(np.minimum(np.asarray(seq_host), t).sum() * rows)
@@ -296,10 +300,26 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
         count = float('inf') if frozen_f else _count(seq_host, x_raw.shape[-1], rows)
         g = ops.bn_backward(dz, x_raw, st_f, stats_f, count, _grad(norm_f.gamma), _grad(norm_f.beta), seq_dev)
     pending = {}                                 # source layer -> gradient arriving over residual connections
+    deferred_done = None                         # layer whose on_layer_done waits for its norm gradients (LazyBNGrad)
     for j in reversed(range(len(layers))):
         L = layers[j]
         c = L.conv
         x, st_in, pc, idx, pr, frozen, skip_ctx = ctx[j]
+        dw, db = _grad(c.conv.weight), _grad(c.conv.bias)
+        wprec = 'bf16' if pr == 'bf16' else 'f32'
+        lazy = g if isinstance(g, ops.LazyBNGrad) else None
+        if lazy is not None:
+            # g = the BN backward of layer j + 1's input norm, not formed yet: this conv's weight-gradient kernel forms it in its
+            # dY loader (and writes it for the data gradient) where it has that loader; everything else takes the stand-alone pass
+            nxt_1d = j + 1 < len(layers) and layers[j + 1].conv.ndim == 1
+            per_cf = bool(c.ndim == 2 and nxt_1d)
+            fuse = (FUSE_BN_BWD and dw is not None and not skip_ctx and DECISION_TAP is None and not (j < lowest and not need_input_grad)
+                    and ops.conv_bwd_weight_bng_supported(pc, x.shape[1], x.shape[2] if x.dim() == 4 else 1, x.shape[-1], per_cf, wprec))
+            if not fuse:
+                g, lazy = lazy.materialize(), None
+                if deferred_done is not None:
+                    on_layer_done(deferred_done)
+                    deferred_done = None
         # g = dL/d(output of conv j) = dL/d(input of layer j+1): the residuals summed into it take the same gradient
         for src, skip_conv, sctx in skip_ctx:
             gs = _skip_backward(ctx, src, skip_conv, sctx, g.contiguous())
@@ -308,15 +328,23 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
             if on_layer_done is not None:
                 on_layer_done(0)
             return None
-        g = g.contiguous()
+        if lazy is None:
+            g = g.contiguous()
         if DECISION_TAP is not None:
             DECISION_TAP.append(('grad', c, g))                   # gradient wrt this conv's (pooled) output
-        dw, db = _grad(c.conv.weight), _grad(c.conv.bias)
-        if dw is not None:
+        if lazy is not None:
+            g = ops.conv_bwd_weight(x, None, pc, dw, db,
+                                    scale=None if st_in is None else st_in.scale,
+                                    shift=None if st_in is None else st_in.shift,
+                                    relu=True, seq_len=seq_dev, unpool_idx=idx, precision=wprec, bng=lazy, per_cf=per_cf)
+            if deferred_done is not None:        # the norm gradients of layer j + 1 were written by this launch's coefficient pass
+                on_layer_done(deferred_done)
+                deferred_done = None
+        elif dw is not None:
             ops.conv_bwd_weight(x, g, pc, dw, db,
                                 scale=None if st_in is None else st_in.scale,
                                 shift=None if st_in is None else st_in.shift,
-                                relu=True, seq_len=seq_dev, unpool_idx=idx, precision='bf16' if pr == 'bf16' else 'f32')
+                                relu=True, seq_len=seq_dev, unpool_idx=idx, precision=wprec)
         norm0 = L.in_norm if (j == 0 and st_in is not None) else None
         norm0_grads = norm0 is not None and any(p.requires_grad for p in norm0.parameters())
         if j == 0 and not need_input_grad and not norm0_grads:
@@ -332,13 +360,17 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
             norm = L.in_norm
             # frozen statistics are constants: no mean / variance terms in the input gradient (count = inf drops them)
             count = float('inf') if frozen else _count(seq_host, x.shape[-1], rows)
-            g = ops.bn_backward(dz, x, st_in, stats, count, _grad(norm.gamma), _grad(norm.beta), seq_dev)
+            g = ops.LazyBNGrad(dz, x, st_in, stats, count, _grad(norm.gamma), _grad(norm.beta), seq_dev)
+            if j == 0 or j in pending:
+                g = g.materialize()              # no conv below to form it / a residual joins
         else:
             g, _ = ops.conv_bwd_data(g, pc, wd, x.shape, idx, None, precision=pr)
         if j in pending:                         # x_j also feeds a residual connection
             g = ops.add_inplace(g, pending.pop(j))
-        if on_layer_done is not None:
+        if on_layer_done is not None and not isinstance(g, ops.LazyBNGrad):
             on_layer_done(j)        # layer j's in_norm belongs to it or to j-1's tail: both done now
+        elif on_layer_done is not None:
+            deferred_done = j       # dgamma / dbeta of layer j's norm are written by the next layer's launch
     if DECISION_TAP is not None:
         DECISION_TAP.append(('grad_in', layers[0].conv, g))      # gradient wrt the stack input
     return g

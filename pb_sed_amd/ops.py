@@ -416,11 +416,20 @@ def ensure_scratch(device):
 
 
 def conv_bwd_weight(x, g, pc, dw, db=None, scale=None, shift=None, relu=True, seq_len=None,
-                    unpool_idx=None, precision='f32'):
+                    unpool_idx=None, precision='f32', bng=None, per_cf=False):
     """dw (+=), db (+=): gradients of the conv parameters (buffers must be pre-zeroed/accumulating).  ``precision``
-    'bf16': bf16-MFMA operands, fp32 accumulation (layers with >= 32 input and output channels)."""
+    'bf16': bf16-MFMA operands, fp32 accumulation (layers with >= 32 input and output channels).
+    ``bng``: a LazyBNGrad instead of ``g`` (conv_bwd_weight_bng_supported must hold): the kernel forms dY from (dz, x, coef)
+    in its loader and the formed gradient is RETURNED (same shape as dz) for the layer's data gradient."""
     ensure_scratch(x.device)
     b, cin, f, t = _dims4(x)
+    if bng is not None:
+        coef = bng.coefficients()
+        gout = torch.empty_like(bng.dz)
+        call('pbsed_conv_bwd_weight_bng', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(bng.dz), ptr(bng.x), ptr(coef),
+             int(per_cf), ptr(bng.seq_len), ptr(gout), ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream(),
+             tag=_conv_tag(b, cin, pc, f, t) + ' x3pc', flops=_conv_flops(b, cin, pc, f, t))
+        return gout
     if precision == 'bf16' and cin >= 32 and pc.cout >= 32:
         call('pbsed_conv_bwd_weight_bf16', ptr(x), ptr(scale), ptr(shift), int(relu), ptr(seq_len), ptr(g),
              ptr(unpool_idx), ptr(dw), ptr(db), b, cin, pc.cout, f, t, pc.kh, pc.kw, stream(),
@@ -540,6 +549,35 @@ def bn_backward(dz, x, st, stats, count, dgamma, dbeta, seq_len):
     call('pbsed_bn_bwd', ptr(dz), ptr(x), ptr(stats), float(count), ptr(st.mean), ptr(st.invstd), ptr(st.scale),
          ptr(dgamma), ptr(dbeta), ptr(seq_len), b, c, s, t, stream())
     return dz
+
+
+class LazyBNGrad:
+    """The gradient wrt a norm's input, not yet formed: dx = k1[c] dz + k2[c] x + k3[c] inside the sequences.  The weight-gradient
+    kernel of the conv that PRODUCED x forms it while it stages dY (conv_bwd_weight(bng=...), which also writes it out for the
+    data gradient); ``materialize`` is the stand-alone pass (pbsed_bn_bwd) for consumers without that loader."""
+
+    def __init__(self, dz, x, st, stats, count, dgamma, dbeta, seq_len):
+        self.dz, self.x, self.st, self.stats, self.count = dz, x, st, stats, count
+        self.dgamma, self.dbeta, self.seq_len = dgamma, dbeta, seq_len
+        self.shape = dz.shape
+
+    def coefficients(self):
+        """dgamma / dbeta (+=) and the coefficient table [3, C] (pbsed_bn_bwd_coef); once."""
+        c = self.st.c
+        coef = torch.empty((3, c), device=self.dz.device, dtype=torch.float32)
+        call('pbsed_bn_bwd_coef', ptr(self.stats), float(self.count), ptr(self.st.mean), ptr(self.st.invstd), ptr(self.st.scale),
+             ptr(self.dgamma), ptr(self.dbeta), ptr(coef), c, stream())
+        return coef
+
+    def materialize(self):
+        return bn_backward(self.dz, self.x, self.st, self.stats, self.count, self.dgamma, self.dbeta, self.seq_len)
+
+
+def conv_bwd_weight_bng_supported(pc, cin, f, t, per_cf, precision='f32'):
+    """Whether the weight-gradient kernel of this layer has the BN-backward dY loader (pbsed_conv_bwd_weight_bng_supported)."""
+    if precision == 'bf16' and cin >= 32 and pc.cout >= 32:
+        return False
+    return bool(_lib.lib().pbsed_conv_bwd_weight_bng_supported(pc.kh, pc.kw, cin, pc.cout, f, t, int(per_cf)))
 
 
 def augment_logmel(x, masks, seq_len, noise=None, noise_scale=None, mean=None, inv_std=None, clamp=None):

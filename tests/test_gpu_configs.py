@@ -241,6 +241,16 @@ def _bicrnn_inputs(wav, seq, weak, strong, device=None, dtype=torch.float32):
 
 @pytest.mark.parametrize('precision', ['f32', 'bf16'])
 def test_c3_bicrnn_shallow_b8(precision):
+    _c3_parity(precision, REAL_B)
+
+
+def test_c3_bicrnn_shallow_b32():
+    """The fp32 leg of the same comparison at the batch the benchmark is quoted on (BASELINE.json configs[2]: 32 clips), as
+    test_c2_fbcrnn_shallow_b32_logits_loss_grads has it for configs[1]."""
+    _c3_parity('f32', 32)
+
+
+def _c3_parity(precision, batch):
     """BASELINE configs[2] network at its real width, B = 8 (the CPU oracle passes take seconds with 32 intra-op threads, conftest.py).  fp32: the
     fp32 bars (logits 1e-4, scores 2.5e-5, loss 2e-5, per-tensor gradients 2e-3 against the float64 oracle on the HIP run's branch,
     see _grad_table).  bf16 (the config's dtype: bf16 MFMA operands, fp32 accumulation / BN / GRU state): against the
@@ -253,7 +263,7 @@ def test_c3_bicrnn_shallow_b8(precision):
     model.keep_logits = True
     ref64 = copy.deepcopy(ref).double().train()
     # (the bf16 variant runs four oracle passes on the CPU - fp32, float64 free, bf16-operand float64 / float32)
-    wav, seq, weak, strong, t = _sorted_batch(REAL_B, 160000, seed=31)
+    wav, seq, weak, strong, t = _sorted_batch(batch, 160000, seed=31)
     cap, cap64 = _Capture(ref.rnn), _Capture(ref64.rnn)
     ref.train()
     inp_ref = _bicrnn_inputs(wav, seq, weak, strong)
@@ -282,7 +292,7 @@ def test_c3_bicrnn_shallow_b8(precision):
     e_g = ((g - g64).norm() / g64.norm()).item()
     print(f'{precision}: logits {e_logit:.2e} (|cpu32-cpu64| {((cap.out.double() - logit64) * m).abs().max():.2e}) '
           f'scores {e_score:.2e} loss {e_loss:.2e} grad(L2) {e_g:.2e}')
-    _record(f'test_c3_bicrnn_shallow_b8[{precision}]', kind=f'full-width tag-conditioned BiCRNN, B = {len(seq)}, vs the CPU oracle',
+    _record(f'test_c3_bicrnn_shallow_b{len(seq)}[{precision}]', kind=f'full-width tag-conditioned BiCRNN, B = {len(seq)}, vs the CPU oracle',
             logits_max_abs=e_logit, cpu32_vs_cpu64_logits=((cap.out.double() - logit64) * m).abs().max().item(),
             scores_max_abs=e_score, loss_rel=e_loss, grad_rel_l2=e_g)
     if precision == 'f32':
@@ -473,6 +483,26 @@ def test_c5_ensemble_batch64():
     ts = np.round(np.arange(0, 100000) * .02, 6)
     events = inf.scores_to_event_list({a: s[0] for a, s in sed.items()}, .5, classes, ts, device=DEV)
     assert set(events) == set(ids)
+    # (d) the event lists of the ensemble's OWN output, tuple by tuple (pb_sed/experiments/strong_label_crnn/inference.py:
+    # 147-150): the frame indices of the HIP chain's scores against the oracle's change-point arithmetic on the same scores -
+    # exact for all 64 clips; and against the oracle CHAIN's scores for the 17 clips it ran, wherever no oracle score lies
+    # within 1e-4 of the threshold (the scores agree to 5e-5: a closer one may fall on either side)
+    n_events = 0
+    for a in ids:
+        want = opp.scores_to_event_list(sed[a][0], ts, .5, classes)
+        assert events[a] == want, (a, events[a][:3], want[:3])
+        n_events += len(want)
+    assert n_events > 0
+    n_exact = 0
+    for j, i in enumerate(pick):
+        sl = int(seq[i])
+        s = mean[j] * (np.arange(mean.shape[-1]) < sl)
+        w0 = np.stack([opp.medfilt(s[k], int(n)) for k, n in enumerate(medfilt[0])])[:, :sl].T * np.maximum(tags[ids[i]], 0.)[None]
+        if np.abs(w0 - .5).min() <= 1e-4:
+            continue
+        assert events[ids[i]] == opp.scores_to_event_list(w0, ts, .5, classes), ids[i]
+        n_exact += 1
+    assert n_exact >= 12, n_exact
 
 
 # ------------------------------------------------------------------------------------------------ front-end contracts

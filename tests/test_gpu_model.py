@@ -628,3 +628,53 @@ def test_device_prefetcher_hands_over_identical_batches_one_ahead():
         assert torch.equal(ya, yb)
         n += 1
     assert n == 4
+
+
+@pytest.mark.parametrize('kind', ['fbcrnn', 'bicrnn_tag'])
+def test_bn_backward_in_the_weight_gradient_loaders_gives_the_gradients_of_the_standalone_passes(kind):
+    """One train step of the real-width nets with the BN backward formed inside the weight-gradient kernels' dY loaders
+    (engine.FUSE_BN_BWD, the default) and with the stand-alone pbsed_bn_bwd passes: same loss, every gradient tensor within
+    2e-5 of its max (what differs is the rounding of k1 dz + k2 x + k3 against gamma/sigma (dz - m1 - xhat m2) and the order
+    of the atomics).  Ragged sequences; pooled, un-pooled and per-(channel, row) layer boundaries are all in the net."""
+    from pb_sed_amd import engine
+    from pb_sed_amd.models import strong_label, weak_label
+    torch.manual_seed(3)
+    b, n = 3, 16000 * 4
+    wav, seq, weak, bnd, t = synth_batch(b, n, 10, seed=5)
+    if kind == 'fbcrnn':
+        model = weak_label.CRNN.build(num_events=10).to(DEV).train()
+        inputs = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV), 'boundary_targets': bnd.to(DEV)}
+    else:
+        model = strong_label.CRNN.build(tag_conditioning=True).to(DEV).train()
+        hard = (weak > .75).float()
+        inputs = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': hard.to(DEV),
+                  'strong_targets': (bnd > .75).float().to(DEV), 'tag_condition': hard.to(DEV)}
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith('gamma'):
+                p.uniform_(.7, 1.3)
+            elif name.endswith('beta'):
+                p.normal_(0, .1)
+    _, flat_grad = model.flat_parameters()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    res = {}
+    calls = {}
+    from pb_sed_amd import _lib
+    for fuse in (True, False):
+        model.load_state_dict(state)
+        engine.FUSE_BN_BWD = fuse
+        try:
+            flat_grad.zero_()
+            _lib.timing, _lib.timing_filter = [], (lambda name: name == 'pbsed_conv_bwd_weight_bng')
+            rev = model.review(inputs, model(dict(inputs)))
+            rev['loss'].backward()
+            torch.cuda.synchronize()
+            calls[fuse] = len(_lib.timing)
+        finally:
+            engine.FUSE_BN_BWD = True
+            _lib.timing, _lib.timing_filter = None, None
+        res[fuse] = (rev['loss'].item(), {k: p.grad.clone() for k, p in model.named_parameters()})
+    assert res[True][0] == pytest.approx(res[False][0], rel=1e-6)
+    assert calls[True] >= 4 and calls[False] == 0, calls          # the fused launches were really taken / really off
+    for name, g in res[True][1].items():
+        rel_close(g, res[False][1][name], 2e-5, name)

@@ -1051,3 +1051,66 @@ def test_weight_gradients_on_two_streams_with_caller_owned_scratch():
     for k in range(2):
         close(out[k][0], ref[k][0], atol=2e-3, rtol=1e-4, name=f'dw stream {k}')
         close(out[k][1], ref[k][1], atol=2e-3, rtol=1e-4, name=f'db stream {k}')
+
+
+# ------------------------------------------------------------------------------------------ BN backward in the dY loaders
+@pytest.mark.parametrize('cin,cout,f,t,b,pool,per_cf,pro', [
+    (64, 64, 8, 96, 3, False, False, True),          # conv_wgrad_pc_kernel<2,2>, per-channel coefficients
+    (64, 128, 8, 100, 3, True, False, True),         # ... through a (2,1) pool (dz / gx are the pooled tensors), two cout tiles
+    (128, 256, 4, 64, 2, False, True, True),         # ... coefficients per (channel, row): the last conv2d in front of the conv1d stack
+    (32, 32, 8, 200, 3, True, False, True),          # conv_wgrad_pc_kernel<1,2,2,2,1> (time-sliced consumer waves, NB = 4)
+    (32, 32, 6, 68, 2, False, False, False),         # ... no prologue on x
+    (16, 16, 8, 96, 3, True, False, True),           # conv_wgrad_s16
+    (16, 32, 8, 100, 3, False, False, True),
+    (11, 16, 8, 64, 2, False, False, False),
+    (32, 64, 8, 96, 3, False, False, True),          # conv_wgrad_wino_kernel
+    (32, 64, 8, 100, 2, True, False, True),
+    (1, 16, 8, 96, 3, False, False, False),          # the direct kernel (first layer)
+])
+def test_bn_backward_in_the_weight_gradient_loader_matches_the_standalone_pass(cin, cout, f, t, b, pool, per_cf, pro):
+    """pbsed_conv_bwd_weight_bng (dY = k1 dz + k2 gx + k3 formed while dY is staged, written out for the data gradient) against
+    pbsed_bn_bwd followed by pbsed_conv_bwd_weight on the same tensors: the formed gradient, dW, db, dgamma, dbeta.  Ragged
+    sequence lengths (dY is zero beyond them), pooled and un-pooled layers, per-channel and per-(channel, row) norms."""
+    from pb_sed_amd import ops
+    torch.manual_seed(cin * 7 + cout + t)
+    w = torch.randn(cout, cin, 3, 3, device=DEV) * .1
+    pc = ops.PackedConv(w)
+    if not ops.conv_bwd_weight_bng_supported(pc, cin, f, t, per_cf):
+        pytest.skip('no weight-gradient kernel with the BN-backward loader for this shape (the engine takes the stand-alone pass)')
+    seq = np.array(([t, max(t - 29, 1), max(t // 2 - 3, 1)] * 2)[:b])
+    seq_dev = torch.as_tensor(seq, dtype=torch.int32).to(DEV)
+    fo = f // 2 if pool else f
+    x = torch.randn(b, cin, f, t, device=DEV)
+    gx = torch.randn(b, cout, fo, t, device=DEV) * 1.5 + .3           # the conv's raw output = the next norm's input
+    inside = (torch.arange(t, device=DEV)[None] < seq_dev[:, None])[:, None, None, :]
+    dz = torch.randn(b, cout, fo, t, device=DEV) * (torch.rand(b, cout, fo, t, device=DEV) > .4) * inside     # ReLU-masked, zero beyond seq
+    idx = (torch.rand(b, cout, fo, t, device=DEV) > .5).to(torch.uint8) if pool else None
+    c_n = cout * fo if per_cf else cout                                # channels of the norm
+    st = ops.BNState(c_n, DEV)
+    st.mean.normal_(0, .3), st.invstd.uniform_(.5, 2.), st.scale.uniform_(.3, 1.7), st.shift.normal_(0, .2)
+    # the (sum dz, sum dz * xhat) partial sums as the data-gradient epilogue leaves them (spread over the slots)
+    xs = gx.reshape(b, c_n, -1, t) if per_cf else gx
+    dzs = dz.reshape(b, c_n, -1, t) if per_cf else dz
+    xhat = (xs - st.mean[None, :, None, None]) * st.invstd[None, :, None, None]
+    stats = torch.zeros(ops.STAT_SLOTS, c_n, 2, device=DEV, dtype=torch.float64)
+    stats[3, :, 0] = dzs.double().sum((0, 2, 3))
+    stats[5, :, 1] = (dzs.double() * xhat.double()).sum((0, 2, 3))
+    count = float(seq.sum() * (1 if per_cf else fo))
+    xsc, xsh = (torch.rand(cin, device=DEV) + .5, torch.randn(cin, device=DEV) * .3) if pro else (None, None)
+
+    dgamma_r, dbeta_r = torch.zeros(c_n, device=DEV), torch.zeros(c_n, device=DEV)
+    g_ref = ops.bn_backward(dzs.clone().contiguous(), xs.contiguous(), st, stats.clone(), count, dgamma_r, dbeta_r, seq_dev)
+    dw_r, db_r = torch.zeros_like(w), torch.zeros(cout, device=DEV)
+    ops.conv_bwd_weight(x, g_ref.reshape(gx.shape), pc, dw_r, db_r, scale=xsc, shift=xsh, relu=True, seq_len=seq_dev, unpool_idx=idx)
+
+    dgamma, dbeta = torch.zeros(c_n, device=DEV), torch.zeros(c_n, device=DEV)
+    lazy = ops.LazyBNGrad(dzs.clone().contiguous(), xs.contiguous(), st, stats.clone(), count, dgamma, dbeta, seq_dev)
+    dw, db = torch.zeros_like(w), torch.zeros(cout, device=DEV)
+    g = ops.conv_bwd_weight(x, None, pc, dw, db, scale=xsc, shift=xsh, relu=True, seq_len=seq_dev, unpool_idx=idx, bng=lazy, per_cf=per_cf)
+    torch.cuda.synchronize()
+    assert torch.equal(dgamma, dgamma_r) and torch.equal(dbeta, dbeta_r)
+    scale = g_ref.abs().max().item()
+    assert (g.reshape(g_ref.shape) - g_ref).abs().max().item() <= 2e-6 * scale, ((g.reshape(g_ref.shape) - g_ref).abs().max().item(), scale)
+    assert (g.reshape(g_ref.shape)[~inside.expand_as(dz).reshape(g_ref.shape)] == 0).all()      # written as zeros beyond the sequences
+    close(dw, dw_r, atol=3e-6 * dw_r.abs().max().item(), rtol=0, name='dW')
+    close(db, db_r, atol=3e-6 * db_r.abs().max().item(), rtol=0, name='db')
