@@ -88,12 +88,28 @@ def synth_batch(b, device, n_samples=160000, k=10, t=500, seed=0, kind='c2'):
 
 def pmc_traffic(kernel_tag):
     """HBM bytes per launch of the roofline kernel from the PMC passes committed under profiles/ (counters need their
-    own rocprofv3 runs, tools/run_profiles.sh + tools/prof_summary.py); None if that layer was not profiled."""
+    own rocprofv3 runs, tools/run_profiles.sh + tools/prof_summary.py); None if that layer was not profiled.  The persistent
+    scans (keys 'gru_granule_fwd' / 'gru_granule_bwd'): L2 request bytes of the TCC pass - they exchange through L2 / the
+    fabric, HBM is not what they move."""
     try:
         row = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json'))).get(kernel_tag)
     except (OSError, ValueError):
         return None, None
-    return (None, None) if row is None else (row['hbm_bytes_per_launch'], row['source'])
+    if row is None:
+        return None, None
+    return row.get('hbm_bytes_per_launch', row.get('l2_request_bytes_per_launch')), row['source']
+
+
+def scan_polled_bytes(kind, nch, nl, t, b, h):
+    """Bytes the polling loads of ONE persistent scan launch request when every first look succeeds (tools/gru_scan_prof.py: no
+    missed polls at the tuned delays): every ring / projection workgroup of 16 hidden units x 16 batch rows polls the whole
+    16 x H state tile of its source per step (tagged 4-byte words), the gate threads of the upper layers their projected
+    inputs (forward: 3 words, BPTT: 1 word per (row, unit)).  New state per step is 1 / (H / 16) of that."""
+    tiles = (b + 15) // 16
+    groups = nch * (2 * nl - 1)                        # rings + layer-boundary projection groups
+    state = groups * (h // 16) * tiles * 16 * h * 4
+    own = nch * (nl - 1) * tiles * 16 * h * 4 * (3 if kind == 'forward_scan' else 1)
+    return int(t * (state + own))
 
 
 def _pmc_mfma_busy(kernel_prefixes):
@@ -337,7 +353,9 @@ def roofline_objects(agg, by_family, steps, batch, precision, gru_shape, kind):
                                    'bf16x3 (exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMA products per fp32 product)' if x3 else 'f32'),
                       'executed': round(tf * (6 if x3 else 1), 2),
                       'frac_executed': round(tf * (6 if x3 else 1) / PEAK_TFLOPS['bf16'] if (x3 or plain_bf16) else tf / PEAK_TFLOPS['f32'], 4),
-                      'us_per_time_step': round(ms * 1e3 / (t * sum(r[1] for r in rows) / steps), 3)}
+                      'us_per_time_step': round(ms * 1e3 / (t * sum(r[1] for r in rows) / steps), 3),
+                      'polled_bytes_per_launch': scan_polled_bytes(key, nch, nl, t, b, h),
+                      'new_state_bytes_per_launch': int(t * nch * nl * b * h * 4)}
         if g:
             g.update(bound='mfma; latency-bound in practice: T dependent steps with an inter-workgroup hand-off each',
                      note='achieved / frac: fp32-equivalent flops of the recurrence + layer-boundary projections over the fp32-MFMA peak; '
@@ -358,17 +376,23 @@ def roofline_objects(agg, by_family, steps, batch, precision, gru_shape, kind):
                 plain = r['operands'].startswith('bf16 (')
                 peak = PEAK_TFLOPS['bf16'] if plain else PEAK_TFLOPS['bf16'] / 6 if x3 else PEAK_TFLOPS['f32']
                 out['roofline_conv'] = out['roofline']
+                l2_bytes, l2_src = pmc_traffic('gru_granule_fwd' if key == 'forward_scan' else 'gru_granule_bwd') if kind == 'c2' else (None, None)
                 out['roofline'] = {
                     'bound': 'mfma', 'achieved': r['achieved'], 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(r['achieved'] / peak, 4),
-                    'traffic': None, 'kernel': f'persistent GRU scan ({key}): gru_granule_{"fwd" if key == "forward_scan" else "bwd"}_gw_kernel',
+                    'traffic': l2_bytes if l2_bytes is not None else r['polled_bytes_per_launch'],
+                    'traffic_kind': ('L2 request bytes per launch (PMC TCC_REQ_sum x 128 B, own pass)' if l2_bytes is not None
+                                     else 'bytes requested by the poll loads per launch (analytic, first looks only)'),
+                    'traffic_source': l2_src, 'polled_bytes_per_launch': r['polled_bytes_per_launch'],
+                    'new_state_bytes_per_launch': r['new_state_bytes_per_launch'], 'kernel': f'persistent GRU scan ({key}): gru_granule_{"fwd" if key == "forward_scan" else "bwd"}_gw_kernel',
                     'avg_ms': round(r['ms_per_step'] / r['launches_per_step'], 4), 'launches_per_step': r['launches_per_step'],
                     'flops_per_launch': r['gflop_per_step'] * 1e9 / r['launches_per_step'], 'us_per_time_step': r['us_per_time_step'],
                     'frac_of_fp32_mfma_peak': r['frac'], 'operands': r['operands'],
                     'note': 'the dominant launch of the step is a persistent scan: T dependent time steps with an inter-workgroup hand-off each - '
                             'latency-bound, not MFMA-bound (tools/gru_scan_prof.py: half of a step is the hand-off).  achieved = flops of the '
                             'recurrence + layer-boundary projections over the launch time; peak = the ceiling of the operand type (bf16x3: '
-                            '2500 / 6 TFLOP/s); frac_of_fp32_mfma_peak = the same flops over the fp32-MFMA peak.  traffic: null (the scans '
-                            'exchange states through L2 / the fabric, HBM bytes are not what bounds them).  roofline_conv = the largest conv launch'}
+                            '2500 / 6 TFLOP/s); frac_of_fp32_mfma_peak = the same flops over the fp32-MFMA peak.  traffic: what the scan moves through '
+                            'L2 / the fabric per launch (HBM bytes are not what bounds it); polled_bytes_per_launch against '
+                            'new_state_bytes_per_launch is the poll amplification.  roofline_conv = the largest conv launch'}
     fe = [v for k, v in agg.items() if k[0] in ('pbsed_logmel_fwd', 'pbsed_logmel_from_stft')]
     if fe:
         fe_ms = fe[0][0] / fe[0][1]
@@ -818,8 +842,8 @@ def _pick(d, keys):
     return {k: d[k] for k in keys if d is not None and k in d}
 
 
-ROOFLINE_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_kind', 'kernel', 'avg_ms', 'flops_per_launch',
-                 'operands', 'us_per_time_step')
+ROOFLINE_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_kind', 'polled_bytes_per_launch', 'new_state_bytes_per_launch',
+                 'kernel', 'avg_ms', 'flops_per_launch', 'operands', 'us_per_time_step')
 
 
 def _short_roofline(r):

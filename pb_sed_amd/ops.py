@@ -646,6 +646,12 @@ def transpose2d(x):
     return y
 
 
+# Verification tap (tests/test_gpu_configs.py::test_c3_rnn_launches_in_situ): when a list is assigned, tm_gemm and gru_wgrad
+# append their operands and results - what a launch-by-launch check of the recurrent part of a train step needs (the conv
+# launches have engine.DECISION_TAP).
+LAUNCH_TAP = None
+
+
 def tm_gemm(xs, ws, bias=None, precision='f32', role='fwd'):
     """Time-major projection: sum_i xs[i] [T,B,K_i] @ ws[i] [N,K_i]^T (+ bias [N]) -> [T,B,N].  'f32': fp32-class products
     (exact bf16x3 operand splits on the bf16 MFMA); 'bf16': plain bf16 operands.  ``role`` ('fwd' | 'bwd') only labels the
@@ -659,6 +665,8 @@ def tm_gemm(xs, ws, bias=None, precision='f32', role='fwd'):
     call('pbsed_tm_gemm', len(xs), _lib.ptr_array(xs), _lib.ptr_array(ws), _lib.int_array(ks), ptr(bias), ptr(y), t * b, n,
          int(precision == 'bf16'), stream(), tag=f'{"+".join(map(str, ks))}->{n} R{t * b}' + (' bf16' if precision == 'bf16' else '') + ' ' + role,
          flops=2. * t * b * n * sum(ks))
+    if LAUNCH_TAP is not None:
+        LAUNCH_TAP.append(('tm_gemm', list(xs), list(ws), bias, precision, role, y))
     return y
 
 
@@ -1089,6 +1097,8 @@ def gru_wgrad(dg, x, shift, dw, db, precision='f32'):
     ks = [v.shape[2] for v in x]
     assert all(d.shape == (t, b, g) and d.is_contiguous() for d in dg) and all(v.shape[:2] == (t, b) and v.is_contiguous() for v in x)
     assert all(w.shape == (g, k) and w.is_contiguous() for w, k in zip(dw, ks))
+    if LAUNCH_TAP is not None:
+        LAUNCH_TAP.append(('gru_wgrad', list(dg), list(x), list(shift), list(dw), list(db), precision))
     for a in range(0, len(dg), 16):
         sl = slice(a, a + 16)
         call('pbsed_gru_wgrad_multi', len(dg[sl]), _lib.ptr_array(dg[sl]), _lib.ptr_array(x[sl]), _lib.int_array(shift[sl]),

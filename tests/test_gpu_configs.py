@@ -493,16 +493,23 @@ def test_c5_ensemble_batch64():
         assert events[a] == want, (a, events[a][:3], want[:3])
         n_events += len(want)
     assert n_events > 0
-    n_exact = 0
+    n_safe = n_all = n_exact = 0
     for j, i in enumerate(pick):
         sl = int(seq[i])
         s = mean[j] * (np.arange(mean.shape[-1]) < sl)
         w0 = np.stack([opp.medfilt(s[k], int(n)) for k, n in enumerate(medfilt[0])])[:, :sl].T * np.maximum(tags[ids[i]], 0.)[None]
-        if np.abs(w0 - .5).min() <= 1e-4:
-            continue
-        assert events[ids[i]] == opp.scores_to_event_list(w0, ts, .5, classes), ids[i]
-        n_exact += 1
-    assert n_exact >= 12, n_exact
+        safe = np.abs(w0 - .5) > 1e-4
+        # frame by frame: the HIP chain's decision equals the oracle chain's wherever the oracle score is not within 1e-4 of the
+        # threshold (random-init detectors hover around 0.5: a few per cent of the frames are that close)
+        assert ((sed[ids[i]][0] > .5) == (w0 > .5))[safe].all(), ids[i]
+        n_safe += int(safe.sum())
+        n_all += safe.size
+        if safe.all():                      # no frame near the threshold: the whole event list, tuple by tuple
+            assert events[ids[i]] == opp.scores_to_event_list(w0, ts, .5, classes), ids[i]
+            n_exact += 1
+    assert n_safe > .9 * n_all, (n_safe, n_all)
+    print(f'c5 event lists: {n_events} events of 64 clips equal the oracle arithmetic on the HIP scores; oracle chain: {n_safe} of {n_all} '
+          f'frame decisions compared (all equal), {n_exact} of {len(pick)} clips with no score near the threshold compared as whole lists')
 
 
 # ------------------------------------------------------------------------------------------------ front-end contracts
@@ -988,6 +995,80 @@ class _LaunchTap:
 
 def _rbf(x):
     return x.float().to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_c3_rnn_launches_in_situ(precision):
+    """The launches of the RECURRENT part of one BASELINE configs[2] train step that test_c3_conv_launches_in_situ does not see
+    (VERDICT r4 item 6): every time-major projection (pbsed_tm_gemm: the GRU input projections and their data gradients) and
+    the batched GRU weight-gradient launch (pbsed_gru_wgrad_multi), each checked ON ITS OWN against a float64 restatement fed
+    with the HIP run's own operands (ops.LAUNCH_TAP):
+
+      projection   y = sum_i R(x_i) R(W_i)^T + b
+      gradients    dW = sum_{t,b} R(dG[t,b]) (x) R(X[t + shift, b]),   db = sum_{t,b} dG[t,b]
+
+    with R = round-to-nearest-even bf16 in the launches of the bf16 mode, the identity otherwise.  Gates: 1e-4 (max-abs / max)
+    in bf16 mode (fp32 accumulation of rounded operands), 2e-5 in fp32 mode (exact bf16x3 products).  The scans themselves have
+    their own oracle gate (tests/test_gpu_ops.py::test_gru_scans_with_bf16_operands_stay_close_to_the_fp32_scans), the heads are
+    the second stack of test_c3_conv_launches_in_situ."""
+    from pb_sed_amd import ops
+    ref, model = _bicrnn_pair(seed=3)
+    model.conv_precision = precision
+    model.train()
+    b = 4
+    wav, seq, weak, strong, t = _sorted_batch(b, 160000, seed=33)
+    inp = _bicrnn_inputs(wav, seq, weak, strong, DEV)
+    ops.LAUNCH_TAP = []
+    try:
+        _, _, grads = _train_step(model, inp)
+        rows = ops.LAUNCH_TAP
+    finally:
+        ops.LAUNCH_TAP = None
+    gemms = [r for r in rows if r[0] == 'tm_gemm']
+    wgrads = [r for r in rows if r[0] == 'gru_wgrad']
+    assert len(gemms) >= 6 and len(wgrads) == 1, (len(gemms), len(wgrads))       # 2 layers x 2 directions forward + data gradients
+    tol = 1e-4 if precision == 'bf16' else 2e-5
+    worst = {}
+    n_bf16 = 0
+    for n, (_, xs, ws, bias, prec, role, y) in enumerate(gemms):
+        rnd = _rbf if prec == 'bf16' else (lambda v: v.double())
+        n_bf16 += prec == 'bf16'
+        if precision == 'bf16':
+            assert prec == 'bf16', (n, prec)
+        want = sum(rnd(x.cpu()).reshape(-1, x.shape[2]) @ rnd(w.cpu()).T for x, w in zip(xs, ws))
+        if bias is not None:
+            want = want + bias.cpu().double()
+        e = (y.cpu().double().reshape(want.shape) - want).abs().max().item() / want.abs().max().item()
+        worst[f'tm_gemm {n} {role} {"+".join(str(x.shape[2]) for x in xs)}->{ws[0].shape[0]}'] = e
+        assert e < tol, (n, role, e)
+    _, dgs, xs, shifts, dws, dbs, prec = wgrads[0]
+    assert prec == ('bf16' if precision == 'bf16' else 'f32') and len(dgs) == 8       # W_ih, W_hh of 2 layers x 2 directions
+    rnd = _rbf if prec == 'bf16' else (lambda v: v.double())
+    for n, (dg, x, sh, dw, db) in enumerate(zip(dgs, xs, shifts, dws, dbs)):
+        xc = x.cpu()
+        xsft = torch.zeros_like(xc)
+        if sh == 0:
+            xsft = xc
+        elif sh < 0:
+            xsft[-sh:] = xc[:sh]
+        else:
+            xsft[:-sh] = xc[sh:]
+        dgr, xr = rnd(dg.cpu()).reshape(-1, dg.shape[2]), rnd(xsft).reshape(-1, x.shape[2])
+        want = dgr.T @ xr
+        e = (dw.cpu().double() - want).abs().max().item() / want.abs().max().item()
+        worst[f'gru_wgrad {n} dW [{dg.shape[2]} x {x.shape[2]}] shift {sh}'] = e
+        assert e < tol, (n, sh, e)
+        if db is not None:
+            d64 = dg.cpu().double().reshape(-1, dg.shape[2])
+            e_db = (db.cpu().double() - d64.sum(0)).abs().max().item() / d64.abs().sum(0).max().item()
+            worst[f'gru_wgrad {n} db (/ sum |dG|)'] = e_db
+            assert e_db < 1e-5, (n, e_db)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])
+    print(f'{precision}: {len(worst)} quantities of {len(gemms)} projections ({n_bf16} with bf16 operands) + {len(dgs)} weight gradients; worst: '
+          + ', '.join(f'{k} {v:.1e}' for k, v in top[:4]))
+    _record(f'test_c3_rnn_launches_in_situ[{precision}]', kind='every time-major projection and GRU weight gradient of a configs[2] train '
+            'step against float64 on the launch\'s own (rounded) operands', quantities=len(worst), tol=tol,
+            worst=[dict(name=k, err=v) for k, v in top[:8]])
 
 
 @pytest.mark.parametrize('precision', ['bf16', 'f32'])

@@ -525,6 +525,9 @@ WGRAD_BF16_CASES = [
     dict(cin=64, cout=128, f=6, t=133, k=(3, 3), pool=True, pro=True),          # un-pooled dY, odd T (scalar idx loads)
     dict(cin=40, cout=72, f=4, t=96, k=(3, 3), pool=False, pro=False),          # channel counts off the 32 / 64 tiles
     dict(cin=128, cout=128, f=4, t=64, k=(3, 3), pool=True, pro=True),
+    dict(cin=64, cout=64, f=8, t=96, k=(3, 3), pool=False, pro=True),           # the one-part producer / consumer kernel (T % 4 == 0, >= 64 channels)
+    dict(cin=96, cout=160, f=6, t=100, k=(3, 3), pool=True, pro=True),          # ... channel counts off its 64-wide tiles, ragged last column
+    dict(cin=72, cout=64, f=3, t=36, k=(3, 3), pool=False, pro=False),          # ... odd row count, one short column
     dict(cin=64, cout=48, f=1, t=200, k=(1, 3), pool=False, pro=True),
     dict(cin=96, cout=256, f=1, t=130, k=(1, 1), pool=False, pro=True),
     dict(cin=266, cout=64, f=1, t=77, k=(1, 1), pool=False, pro=False),

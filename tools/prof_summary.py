@@ -145,6 +145,18 @@ for tagname, (kern, grid) in ROOFLINE_ROWS.items():
             traffic[tagname] = {'hbm_bytes_per_launch': round((2 * fe + wr) * 1024), 'kernel': kern, 'grid': g,
                                 'source': f'profiles/{tag}_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
                                           'bytes = (2*FETCH_SIZE + WRITE_SIZE) KB)'}
+# The persistent scans do not run under the FETCH / WRITE passes (and HBM is not what they move): their `traffic` is the L2
+# request count of the TCC pass (collected with the scans on) x 128 bytes - polls, saved-factor loads, input projections and
+# output stores of one launch as the L2s saw them.
+tcc_csv = os.path.join(out, f'{tag}_pmc_tcc.csv')
+if os.path.exists(tcc_csv):
+    for r in csv.DictReader(open(tcc_csv)):
+        for key, name in (('gru_granule_fwd', 'gru_granule_fwd'), ('gru_granule_bwd', 'gru_granule_bwd')):
+            if name in r['kernel'] and key not in traffic:
+                traffic[key] = {'l2_request_bytes_per_launch': round(float(r['TCC_REQ_sum']) * 128), 'l2_hit_rate': float(r['l2_hit_rate']),
+                                'kernel': r['kernel'][:60], 'grid': r['grid_threads'],
+                                'source': f'profiles/{tag}_pmc_tcc.csv (rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum, own pass, '
+                                          'bytes = TCC_REQ_sum x 128: a request moves at most one 128-byte line)'}
 if traffic:
     json.dump(traffic, open(os.path.join(out, 'roofline_traffic.json'), 'w'), indent=1)
     print('wrote profiles/roofline_traffic.json', list(traffic))
