@@ -173,8 +173,9 @@ def test_inference_driver_keeps_a_batch_in_flight_without_changing_results():
         assert np.array_equal(together[a], one_by_one[a]), a
     from pb_sed_amd import ops
     assert not any(slot[2] for pool in ops._PINNED.values() for slot in pool), 'a pinned buffer is still held'
-    big = {k: len(v) for k, v in ops._PINNED.items() if int(np.prod(k[0])) >= 1000}
+    big = {k: len(v) for k, v in ops._PINNED.items() if k >= 4096}          # pool keys = byte size classes (powers of two)
     assert big and max(big.values()) <= 3, big                    # score buffers: the pipeline depth, not one per batch
+    assert len(ops._PINNED) <= 8, sorted(ops._PINNED)             # ... and the two score shapes share size classes, not one pool per shape
 
 
 @pytest.mark.parametrize('hidden,batch', [(64, 5), (256, 40)])
