@@ -113,10 +113,10 @@ def scan_polled_bytes(kind, nch, nl, t, b, h):
 
 
 def _pmc_mfma_busy(kernel_prefixes):
-    """MFMA-pipe busy share of kernels of the headline step from the committed counter pass (profiles/r04_pmc_mfma.csv:
+    """MFMA-pipe busy share of kernels of the headline step from the committed counter pass (profiles/r05_pmc_mfma.csv:
     SQ_VALU_MFMA_BUSY_CYCLES per SIMD over the kernel's clocks, tools/run_profiles.sh step 5); {} if the file is not there."""
     import csv
-    path = os.path.join(ROOT, 'profiles', 'r04_pmc_mfma.csv')
+    path = os.path.join(ROOT, 'profiles', 'r05_pmc_mfma.csv')
     out = {}
     try:
         for r in csv.DictReader(open(path)):
@@ -127,7 +127,7 @@ def _pmc_mfma_busy(kernel_prefixes):
     except (OSError, ValueError, IndexError, KeyError):
         return {}
     if out:
-        out['source'] = 'profiles/r04_pmc_mfma.csv (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ..., own pass)'
+        out['source'] = 'profiles/r05_pmc_mfma.csv (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ..., own pass)'
     return out
 
 

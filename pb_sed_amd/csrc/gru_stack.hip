@@ -42,6 +42,9 @@ struct GruStackArgs {
     int B, T, nchains, nlayers, launch;
     int poll_delay, poll_delay_gate;   // granule kernels: first-poll delays (PollPacer) of the non-gate / gate waves
     int ring_xcd, nby;    // granule kernels: ring_xcd = H/16 > 0 selects the 1-D XCD-aware role mapping (granule_role)
+    int local;            // 1 (BPTT with the ring-per-XCD mapping): the LAST ring in scan order - no projection group reads it, its
+                          // only readers are its own blocks on its own XCD, whose L2 is their coherence point - publishes its state
+                          // with a PLAIN store and looks at it first with a PLAIN load; only retries bypass the L1 (sc1)
     unsigned long long* prof;   // diagnostics (pbsed_gru_set_prof): shader-clock stamps of block `prof_block`, steps 200..231
     int prof_block;
 };
@@ -297,6 +300,11 @@ __device__ __forceinline__ float tag_clear(float v) { return __uint_as_float(__f
 __device__ __forceinline__ void publish(gu32* p, float v_cleared, unsigned parity) {
     __hip_atomic_store(p, __float_as_uint(v_cleared) | parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// XCD-local form (GruStackArgs::local): a plain store - it reaches the XCD's L2 (the L1 is write-through), which is where
+// every reader of this word looks; no write-through to the fabric, whose completion is what a racing sc1 poll waits for.
+__device__ __forceinline__ void publish_local(gu32* p, float v_cleared, unsigned parity) {
+    __hip_atomic_store(p, __float_as_uint(v_cleared) | parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // First-poll pacing.  Polls that come before the data only add fabric traffic and slow everybody's hand-off down (two
 // batches in flight per wave: 2x slower scans), and a missed first poll costs a full round trip.  The waves that do
@@ -318,7 +326,7 @@ struct PollPacer {
 // before any tag is looked at (one fabric round trip per step); out[n] = the four (tag-cleared) values.
 template <int NL, int STEP = 1024>
 __device__ __forceinline__ int poll_batch(float4 (&out)[NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned parity,
-                                          bool valid, unsigned* err_flag) {
+                                          bool valid, unsigned* err_flag, bool local = false) {
     u32x4_t q[NL];
 #pragma unroll
     for (int n = 0; n < NL; ++n) q[n] = u32x4_t{0u, 0u, 0u, 0u};
@@ -327,8 +335,16 @@ __device__ __forceinline__ int poll_batch(float4 (&out)[NL], __amdgpu_buffer_rsr
         bool ok = true;
         asm volatile("" ::: "memory");                  // the load builtins are not volatile: every attempt loads again
         if (valid) {
+            // local: every word has its own location, written once per call - the FIRST look may be a plain load (the L1 was
+            // invalidated at the launch and cannot hold a line it never read; inside an XCD the L2 is the coherence point);
+            // a look that came too early leaves the stale line in the L1, so every retry bypasses it (sc1)
+            if (local && spin == 0) {
 #pragma unroll
-            for (int n = 0; n < NL; ++n) q[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + n * STEP, 0, /*aux = sc1*/ 16);
+                for (int n = 0; n < NL; ++n) q[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + n * STEP, 0, 0);
+            } else {
+#pragma unroll
+                for (int n = 0; n < NL; ++n) q[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + n * STEP, 0, /*aux = sc1*/ 16);
+            }
             unsigned all1 = 1u, any1 = 0u;
 #pragma unroll
             for (int n = 0; n < NL; ++n) {
@@ -424,7 +440,7 @@ __device__ __forceinline__ void wait_own_granules(unsigned (&q)[NQ], const gu32*
 // co-resident blocks and stay one launch; a block's two tiles share the W fragments, their polls are issued together).
 template <int NL, int NB>
 __device__ __forceinline__ int poll_tiles(float4 (&out)[NB][NL], __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned tile_stride,
-                                           unsigned parity, const bool (&valid)[NB], unsigned* err_flag) {
+                                           unsigned parity, const bool (&valid)[NB], unsigned* err_flag, bool local = false) {
     u32x4_t q[NB][NL];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -437,9 +453,15 @@ __device__ __forceinline__ int poll_tiles(float4 (&out)[NB][NL], __amdgpu_buffer
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
             if (valid[nb]) {
+                if (local && spin == 0) {                 // see poll_batch
 #pragma unroll
-                for (int n = 0; n < NL; ++n)
-                    q[nb][n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + nb * tile_stride + n * 1024, 0, /*aux = sc1*/ 16);
+                    for (int n = 0; n < NL; ++n)
+                        q[nb][n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + nb * tile_stride + n * 1024, 0, 0);
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NL; ++n)
+                        q[nb][n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + nb * tile_stride + n * 1024, 0, /*aux = sc1*/ 16);
+                }
             }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -588,7 +610,7 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
                 if (prof_now && prof_c && p0) prof_stamp(pslot + 1);
                 const bool v1[1] = {rowv[nb]};
                 const int spins = poll_tiles<NL, 1>(x, rsrc, voff0 + (unsigned)(is_proj ? t : tp) * step_t + nb * tile_bytes, tile_bytes,
-                                                    parity, v1, err_flag);
+                                                    parity, v1, err_flag, false);
                 if (prof_now && prof_c && p0) { prof_stamp(pslot + 2); pslot[5] = (unsigned long long)spins; }
             }
             // requests issued behind the poll (loads return in order, anything older would hold the poll back):
@@ -708,6 +730,7 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
     const int chain = role.chain, top = a.nlayers - 1;
     const bool is_proj = role.gid & 1;
     const int layer = top - ((role.gid + 1) >> 1);    // ring: its layer; projection: the layer it produces dy for
+    const bool ring_local = a.local && !is_proj && layer == 0;      // the bottom layer's ring: nobody else reads its dh
     const GruStackLayer& L = a.lc[chain][layer];
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) - GWV, lq = lane >> 4, lr = lane & 15;
     const bool is_mfma = wave >= 0;
@@ -814,7 +837,7 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         if (contract) {
             pacer.wait();
             if (prof_now && prof_c) prof_stamp(pslot + 1);
-            const int spins = poll_batch<NL>(dh4, rsrc, voff0 + (unsigned)(is_proj ? t : tn) * step_t, parity, rowv, err_flag);
+            const int spins = poll_batch<NL>(dh4, rsrc, voff0 + (unsigned)(is_proj ? t : tn) * step_t, parity, rowv, err_flag, ring_local);
             if (prof_now && prof_c) { prof_stamp(pslot + 2); pslot[5] = (unsigned long long)spins; }
         }
         unsigned qd[1] = {0};                         // behind the poll: loads return in order
@@ -883,7 +906,8 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
                     dhzv = dh * z;
                 }
                 dhz_prev = dhzv;
-                publish(g_own + (size_t)t * Bp * H + (tid & 255), dh, parity);
+                if (ring_local) publish_local(g_own + (size_t)t * Bp * H + (tid & 255), dh, parity);
+                else publish(g_own + (size_t)t * Bp * H + (tid & 255), dh, parity);
                 if (prof_now && prof_g) prof_stamp(pslot + 11);
                 float* dgi = L.dgi + tb * G;
                 float* dgh = L.dgh + tb * G;
@@ -960,7 +984,7 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
 // blocks of that XCD out (found by tests/sweeps/fuzz_gru.py: H = 512, B = 16).  The caller then keeps the 3-D grid, whose
 // blocks spread evenly over the XCDs.
 // nb: 16-row batch tiles per block
-static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid, int nb = 1) {
+static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid, int nb = 1, bool bwd = false) {
     const int cus_per_xcd = device_cus() / 8;           // per device ordinal (common.h)
     const int nby = (a.B + 16 * nb - 1) / (16 * nb), nj = H / 16;
     const int R = a.nchains * a.nlayers * nby, P = a.nchains * (a.nlayers - 1) * nby;
@@ -969,6 +993,13 @@ static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid, int nb = 1) {
     a.nby = nby;
     a.ring_xcd = nj;
     *grid = dim3(8 * slots, 1, 1);
+    // BPTT: the last ring in scan order exchanges its states through its XCD's L2 only (GruStackArgs::local).  Measured on
+    // MI355X, B 32, H 256, T 500: two-layer BPTT 1.346 -> 1.30 ms with every ring local (co-located groups), one-layer BiGRU BPTT
+    // 2.376 -> 2.273 ms per two launches; the FORWARD scans do not gain (0.937 -> 0.943, 1.550 -> 1.577: an early sc1 poll is
+    // parked at the L2 until the write-through store it raced completes and returns at once - a plain look cannot be parked,
+    // it returns the stale line and pays a retry) and keep the sc1 exchange.
+    static const bool local_off = getenv("PBSED_GRU_XCD_LOCAL") && getenv("PBSED_GRU_XCD_LOCAL")[0] == '0';
+    a.local = (bwd && !local_off) ? 1 : 0;
     return true;
 }
 
@@ -1130,7 +1161,7 @@ static int gru_stack_bwd_granule_impl(int nchains, int nlayers, const float* con
                   grid.x * grid.y * grid.z, granule_capacity(true, H, bf16, 1));
         return PBSED_E_UNSUPPORTED;
     }
-    granule_xcd_grid(a, H, &grid);
+    granule_xcd_grid(a, H, &grid, 1, true);
     unsigned* gran_dy = granules + (size_t)nchains * nlayers * T * Bp * H;
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \

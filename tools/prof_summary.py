@@ -126,8 +126,8 @@ for cfg in ('c3', 'c5', 'deep'):
 # `roofline.traffic`); keyed by bench.py's "<entry point> <layer tag>", matched to (kernel template, 3-D grid).
 import json
 ROOFLINE_ROWS = {
-    'pbsed_conv_bwd_weight 128->128 k3x3 B32 F16 T500 x3pc': ('conv_wgrad_pc_kernel<2, 2, 1, 2, 2>', 'x2x2'),      # grid (split, cin tiles, cout tiles)
-    'pbsed_conv_bwd_weight 128->256 k3x3 B32 F8 T500 x3pc': ('conv_wgrad_pc_kernel<2, 2, 1, 2, 2>', 'x2x4'),
+    'pbsed_conv_bwd_weight 128->128 k3x3 B32 F16 T500 x3pc': ('conv_wgrad_pc_kernel<2, 2, 1, 2, 2', 'x2x2'),      # grid (split, cin tiles, cout tiles)
+    'pbsed_conv_bwd_weight 128->256 k3x3 B32 F8 T500 x3pc': ('conv_wgrad_pc_kernel<2, 2, 1, 2, 2', 'x2x4'),
     'pbsed_conv_bwd_data_winox3 128->128 k3x3 B32 F16 T500 winox3': ('conv_winox3_kernel<false, true, true, 64>', None),
     'pbsed_conv_fwd_winox3 128->128 k3x3 B32 F16 T500 winox3': ('conv_winox3_kernel<true, false, false, 64>', None),
     'pbsed_conv_bwd_weight 128->128 k3x3 B32 F16 T500 wino': ('conv_wgrad_wino_kernel', None),
