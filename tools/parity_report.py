@@ -24,7 +24,7 @@ def main(src, dst):
                              f"{w.get('fp32_cpu_oracle_vs_free_float64', float('nan')):.2e}); "
                              f"{r.get('positions_the_free_float64_run_decides_differently', '?')} positions decided differently")
         elif 'quantities' in r:
-            summary[name] = (f"{r['quantities']} quantities ({r['launches_with_bf16_operands']} launches with bf16 operands) within "
+            summary[name] = (f"{r['quantities']} quantities ({r.get('launches_with_bf16_operands', '-')} launches with bf16 operands) within "
                              f"{r['tol']:g}; worst {r['worst'][0]['name']} {r['worst'][0]['err']:.2e}")
         else:
             summary[name] = ', '.join(f'{k} {v:.2e}' for k, v in r.items() if isinstance(v, float))
