@@ -653,6 +653,11 @@ WINO_CASES = [c for c in CONV_CASES if c['k'] == (3, 3) and c['cin'] >= 16] + [
     dict(cin=64, cout=64, f=8, t=70, k=(3, 3), pool=False, pro=False),
     dict(cin=32, cout=64, f=6, t=500, k=(3, 3), pool=True, pro=True),
     dict(cin=40, cout=72, f=5, t=131, k=(3, 3), pool=False, pro=False),
+    # wider layers (two to four 64-cout tiles per spatial tile); odd row counts, a ragged last column
+    dict(cin=64, cout=128, f=6, t=132, k=(3, 3), pool=True, pro=True),
+    dict(cin=128, cout=256, f=5, t=100, k=(3, 3), pool=False, pro=True),
+    dict(cin=128, cout=128, f=8, t=64, k=(3, 3), pool=True, pro=False),
+    dict(cin=128, cout=64, f=3, t=36, k=(3, 3), pool=False, pro=False),
 ]
 
 
@@ -810,7 +815,8 @@ def test_conv1d_producer_consumer_x3_vs_torch(cin, cout, kw, t, b, pro):
 
 
 @pytest.mark.parametrize('cin,cout,f,t,pool', [(64, 64, 8, 150, True), (32, 96, 6, 65, False), (128, 64, 4, 500, True),
-                                              (32, 48, 6, 64, True), (32, 32, 8, 132, False)])      # <= 32 channels produced: 32-cout blocks
+                                              (32, 48, 6, 64, True), (32, 32, 8, 132, False),      # <= 32 channels produced: 32-cout blocks
+                                              (128, 256, 5, 68, False), (256, 128, 6, 100, True)])      # two / four cout tiles
 def test_conv_winograd_dgrad_bn_epilogue_matches_direct(cin, cout, f, t, pool):
     """Data gradient with the fused BN-ReLU-mask backward epilogue (and un-pooling): Winograd vs direct kernel on
     the same inputs - dz, and the (sum dz, sum dz*xhat) statistics BN backward needs."""
