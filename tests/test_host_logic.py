@@ -416,3 +416,22 @@ def test_bench_contract_line_is_compact(canned, capsys, tmp_path, monkeypatch):
         assert 'note' not in line['allreduce']
     detail = _strict_loads(open(tmp_path / 'gpurun_out' / 'bench_detail.json').read())
     assert detail['metric'] == full['metric']
+
+
+def test_bench_scan_poll_volume_model():
+    """bench.scan_polled_bytes: the poll volume of one persistent scan launch as DESIGN.md section 3 counts it - every ring /
+    projection workgroup (16 units x 16 rows) polls its source's whole 16 x H state tile per step, upper-layer gate threads
+    their projected inputs (3 words forward, 1 word BPTT)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    # configs[1]: 2 chains x 2 layers, T 500, B 32, H 256: (8 rings + 4 projection groups) x 16 blocks... = 192 blocks x 16 KB per step
+    fwd = bench.scan_polled_bytes('forward_scan', 2, 2, 500, 32, 256)
+    assert fwd == 500 * (192 * 16 * 256 * 4 + 2 * 2 * 16 * 256 * 4 * 3)
+    bwd = bench.scan_polled_bytes('bptt_scan', 2, 2, 500, 32, 256)
+    assert bwd == 500 * (192 * 16 * 256 * 4 + 2 * 2 * 16 * 256 * 4 * 1)
+    # one-layer BiGRU scans (configs[2]): rings only
+    assert bench.scan_polled_bytes('forward_scan', 2, 1, 500, 32, 256) == 500 * 64 * 16 * 256 * 4
+    new_state = 500 * 2 * 2 * 32 * 256 * 4
+    assert 24 < fwd / new_state < 27                      # 16 ring blocks + 16 projection blocks each read the whole state tile
