@@ -429,3 +429,59 @@ class Trainer:
         """Look at the scan error words of the steps whose check is still pending (flag_check_lag > 0): call it before the
         results of the last steps are used - at the end of an epoch, before a checkpoint or a validation pass."""
         self._check_flags(0)
+
+    # ------------------------------------------------------------------------------------------ checkpoints
+    def state_dict(self):
+        """What a resume needs, in the layout of a padertorch trainer checkpoint (``{'model', 'iteration', 'epoch',
+        'optimizer'}``; pb_sed/experiments/weak_label_crnn/inference.py:407-413 reads ``ckpt['model']`` through
+        ``Model.from_storage_dir``): the model's state_dict under the reference's parameter / buffer names and Adam's state
+        as a ``torch.optim.Adam`` state_dict over ``model.parameters()`` in order (exp_avg / exp_avg_sq views of the flat moment
+        buffers, ``step`` = the iteration), so that the reference's trainer - or ``torch.optim.Adam.load_state_dict`` - can take it."""
+        self.finish()
+        params = list(self.model.parameters())
+        state = {i: {'step': torch.tensor(float(self.iteration)),
+                     'exp_avg': self.m[p._pbsed_off:p._pbsed_off + p.numel()].view(p.shape).detach().clone().cpu(),
+                     'exp_avg_sq': self.v[p._pbsed_off:p._pbsed_off + p.numel()].view(p.shape).detach().clone().cpu()}
+                 for i, p in enumerate(params)}
+        group = {'lr': self.lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': 0, 'amsgrad': False,
+                 'params': list(range(len(params)))}
+        return {'model': {k: v.detach().clone().cpu() for k, v in self.model.state_dict().items()},
+                'iteration': self.iteration, 'epoch': getattr(self, 'epoch', 0),
+                'optimizer': {'state': state if self.iteration else {}, 'param_groups': [group]}}
+
+    def load_state_dict(self, ckpt):
+        """Resume from ``state_dict()`` output or from a padertorch trainer checkpoint of the same model (Adam state keyed by
+        parameter index; a checkpoint without optimizer state restarts the moments at zero)."""
+        self.model.load_state_dict(ckpt['model'])                    # (the post hook re-snapshots the cumulative statistics)
+        self.iteration = int(ckpt.get('iteration', 0))
+        if 'epoch' in ckpt:
+            self.epoch = ckpt['epoch']
+        self.m.zero_(), self.v.zero_()
+        opt = ckpt.get('optimizer') or {}
+        params = list(self.model.parameters())
+        for i, st in (opt.get('state') or {}).items():
+            p = params[int(i)]
+            sl = slice(p._pbsed_off, p._pbsed_off + p.numel())
+            self.m[sl].copy_(st['exp_avg'].reshape(-1))
+            self.v[sl].copy_(st['exp_avg_sq'].reshape(-1))
+            self.iteration = max(self.iteration, int(float(st.get('step', self.iteration))))
+        for g in opt.get('param_groups') or []:
+            self.lr, self.betas, self.eps = g.get('lr', self.lr), tuple(g.get('betas', self.betas)), g.get('eps', self.eps)
+        if self.flat_param.is_cuda:
+            ops.invalidate_packed()
+            ops.refresh_packs()
+        self._stepped = False
+
+    def save_checkpoint(self, storage_dir, name=None):
+        """``<storage_dir>/checkpoints/ckpt_<iteration>.pth`` (padertorch's naming), after sync_buffers() in a data-parallel run;
+        rank 0 writes.  Returns the path."""
+        import os
+        self.sync_buffers()
+        path = os.path.join(storage_dir, 'checkpoints', name or f'ckpt_{self.iteration}.pth')
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            torch.save(self.state_dict(), path)
+        return path
+
+    def load_checkpoint(self, path, map_location='cpu'):
+        self.load_state_dict(torch.load(path, map_location=map_location, weights_only=False))

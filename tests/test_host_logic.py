@@ -435,3 +435,49 @@ def test_bench_scan_poll_volume_model():
     assert bench.scan_polled_bytes('forward_scan', 2, 1, 500, 32, 256) == 500 * 64 * 16 * 256 * 4
     new_state = 500 * 2 * 2 * 32 * 256 * 4
     assert 24 < fwd / new_state < 27                      # 16 ring blocks + 16 projection blocks each read the whole state tile
+
+
+def test_trainer_checkpoint_round_trip_in_padertorch_layout(tmp_path):
+    """Trainer.save_checkpoint / load_checkpoint (checkpoint / resume): the file is a padertorch-style
+    trainer checkpoint - ``ckpt['model']`` is what ``CRNN.from_storage_dir`` loads (experiments/weak_label_crnn/inference.py:
+    407-413), ``ckpt['optimizer']`` is a ``torch.optim.Adam`` state_dict over ``model.parameters()`` - and a second Trainer
+    resumes from it with identical parameters, Adam moments and iteration count."""
+    from pb_sed_amd.models import weak_label
+    from pb_sed_amd.trainer import Trainer
+    net = dict(out_channels_2d=[16, 16, 32], pool_sizes_2d=[1, (2, 1), (2, 1)], kernel_size_2d=3, out_channels_1d=[64, 64],
+               kernel_size_1d=[1, 3])
+    kw = dict(num_events=10, hidden_size=64, num_layers=2, net=net)
+    torch.manual_seed(1)
+    model = weak_label.CRNN.build(**kw)
+    tr = Trainer(model, lr=3e-4, betas=(.8, .99))
+    with torch.no_grad():                         # as after 17 steps
+        tr.m.normal_(0, 1e-3), tr.v.uniform_(0, 1e-5)
+        model.feature_extractor.running_mean.normal_(-6, 1), model.feature_extractor.num_tracked_values.fill_(4242.)
+    tr.iteration = 17
+    path = tr.save_checkpoint(str(tmp_path))
+    assert path.endswith(os.path.join('checkpoints', 'ckpt_17.pth')) and os.path.exists(path)
+    ckpt = torch.load(path, weights_only=False)
+    assert set(ckpt) >= {'model', 'iteration', 'optimizer'} and ckpt['iteration'] == 17
+    # the optimizer part is a torch.optim.Adam state_dict over model.parameters()
+    ref_model = weak_label.CRNN.build(**kw)
+    adam = torch.optim.Adam(ref_model.parameters(), lr=1.)
+    adam.load_state_dict(ckpt['optimizer'])
+    assert adam.param_groups[0]['lr'] == 3e-4 and tuple(adam.param_groups[0]['betas']) == (.8, .99)
+    p0 = next(iter(ref_model.parameters()))
+    assert torch.equal(adam.state[p0]['exp_avg'], tr.m[:p0.numel()].view(p0.shape)) and float(adam.state[p0]['step']) == 17.
+    # a fresh Trainer resumes from it
+    torch.manual_seed(2)
+    model2 = weak_label.CRNN.build(**kw)
+    tr2 = Trainer(model2)
+    tr2.load_checkpoint(path)
+    assert tr2.iteration == 17 and tr2.lr == 3e-4 and tuple(tr2.betas) == (.8, .99)
+    assert torch.equal(tr2.flat_param, tr.flat_param) and torch.equal(tr2.m, tr.m) and torch.equal(tr2.v, tr.v)
+    for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.equal(a, b), k
+    # ... and its cumulative-statistics baseline is the loaded state (ADVICE r4: not the constructor's)
+    base_n, _ = tr2._synced_stats['feature_extractor.']
+    assert base_n.item() == 4242.
+    # a checkpoint without optimizer state (e.g. a model-only file) restarts the moments
+    torch.save({'model': ckpt['model'], 'iteration': 3}, tmp_path / 'model_only.pth')
+    tr2.load_checkpoint(str(tmp_path / 'model_only.pth'))
+    assert tr2.iteration == 3 and not tr2.m.any() and not tr2.v.any()
