@@ -1,13 +1,12 @@
 #!/bin/bash
-# A/B of two builds of the library on the headline step (same box, alternating):
-#   tools/ab_lib.sh NAME_A=path/a.so NAME_B=path/b.so [config ...]    (path "-" = the in-tree library)
-# prints value / ms_per_step per run; the contract lines go to gpurun_out/ablib_<name>_<cfg>_<rep>.json
-A=$1; B=$2; shift 2
-CFGS=${@:-c2}
+# A/B/... of builds of the library on the headline step (same box, alternating, two rounds):
+#   tools/ab_lib.sh "c2 c5" NAME=path.so [NAME=path.so ...]        (path "-" = the in-tree library)
+# prints value / ms_per_step per run; contract lines + per-entry-point tables go to gpurun_out/ablib_<name>_<cfg>_<rep>.{json,err}
+CFGS=$1; shift
 mkdir -p gpurun_out
 for cfg in $CFGS; do
   for rep in 1 2; do
-    for spec in "$A" "$B"; do
+    for spec in "$@"; do
       name=${spec%%=*}; lib=${spec#*=}
       if [ "$lib" = "-" ]; then unset PBSED_LIB; else export PBSED_LIB=$(realpath $lib); fi
       out=gpurun_out/ablib_${name}_${cfg}_$rep

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Builds of the library with the parked patches of tools/micro/attic applied, for tools/ab_lib.sh (PBSED_LIB):
+#   tools/variants/libpbsed_base.so          the tree as it is
+#   tools/variants/libpbsed_scalar.so        + scalar_tile_loads.patch
+#   tools/variants/libpbsed_scalar_hoist.so  + epilogue_hoist.patch on top
+# (the .so files are git-ignored and travel to the GPU box with the snapshot)
+set -e
+cd "$(dirname "$0")/.."
+ROOT=$(pwd)
+mkdir -p tools/variants
+W=$(mktemp -d)
+mkdir -p $W/pb_sed_amd
+cp -r pb_sed_amd/csrc $W/pb_sed_amd/csrc
+rm -rf $W/pb_sed_amd/csrc/build
+build() { (cd $W/pb_sed_amd/csrc && bash build.sh 2>&1 | grep "^built\|error:" || true); cp $W/pb_sed_amd/libpbsed_mi355.so $ROOT/tools/variants/$1; }
+build libpbsed_base.so
+(cd $W && patch -s -p1 < $ROOT/tools/micro/attic/scalar_tile_loads.patch)
+build libpbsed_scalar.so
+(cd $W && patch -s -p1 < $ROOT/tools/micro/attic/epilogue_hoist.patch)
+build libpbsed_scalar_hoist.so
+rm -rf $W
+md5sum tools/variants/*.so
