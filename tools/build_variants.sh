@@ -3,6 +3,7 @@
 #   tools/variants/libpbsed_base.so          the tree as it is
 #   tools/variants/libpbsed_scalar.so        + scalar_tile_loads.patch
 #   tools/variants/libpbsed_scalar_hoist.so  + epilogue_hoist.patch on top
+#   tools/variants/libpbsed_all.so           + s16_branch_free_loads.patch on top
 # (the .so files are git-ignored and travel to the GPU box with the snapshot)
 set -e
 cd "$(dirname "$0")/.."
@@ -18,5 +19,7 @@ build libpbsed_base.so
 build libpbsed_scalar.so
 (cd $W && patch -s -p1 < $ROOT/tools/micro/attic/epilogue_hoist.patch)
 build libpbsed_scalar_hoist.so
+(cd $W && patch -s -p1 < $ROOT/tools/micro/attic/s16_branch_free_loads.patch)
+build libpbsed_all.so
 rm -rf $W
 md5sum tools/variants/*.so
