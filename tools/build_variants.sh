@@ -5,7 +5,8 @@
 #   tools/variants/libpbsed_scalar_hoist.so  + epilogue_hoist.patch on top
 #   tools/variants/libpbsed_s16.so           + s16_branch_free_loads.patch on top
 #   tools/variants/libpbsed_res.so           + residual_group_loads.patch on top
-#   tools/variants/libpbsed_all.so           + s16_constants_once.patch on top
+#   tools/variants/libpbsed_s16c.so          + s16_constants_once.patch on top
+#   tools/variants/libpbsed_all.so           + logmel_setup_one_round_trip.patch on top
 # (the .so files are git-ignored and travel to the GPU box with the snapshot)
 set -e
 cd "$(dirname "$0")/.."
@@ -26,6 +27,8 @@ build libpbsed_s16.so
 (cd $W && patch -s -p1 < $ROOT/tools/micro/attic/residual_group_loads.patch)
 build libpbsed_res.so
 (cd $W && patch -s -p1 < $ROOT/tools/micro/attic/s16_constants_once.patch)
+build libpbsed_s16c.so
+(cd $W && patch -s -p1 < $ROOT/tools/micro/attic/logmel_setup_one_round_trip.patch)
 build libpbsed_all.so
 rm -rf $W
 md5sum tools/variants/*.so
