@@ -7,7 +7,8 @@
 #   tools/variants/libpbsed_res.so           + residual_group_loads.patch on top
 #   tools/variants/libpbsed_s16c.so          + s16_constants_once.patch on top
 #   tools/variants/libpbsed_lm.so            + logmel_setup_one_round_trip.patch on top
-#   tools/variants/libpbsed_all.so           + winox3_dgrad_epilogue_pipeline.patch on top
+#   tools/variants/libpbsed_wxe.so           + winox3_dgrad_epilogue_pipeline.patch on top
+#   tools/variants/libpbsed_all.so           + epilogue_requests_ahead.patch on top
 # (the .so files are git-ignored and travel to the GPU box with the snapshot)
 set -e
 cd "$(dirname "$0")/.."
@@ -32,6 +33,8 @@ build libpbsed_s16c.so
 (cd $W && patch -s -p1 < $ROOT/tools/micro/attic/logmel_setup_one_round_trip.patch)
 build libpbsed_lm.so
 (cd $W && patch -s -p1 < $ROOT/tools/micro/attic/winox3_dgrad_epilogue_pipeline.patch)
+build libpbsed_wxe.so
+(cd $W && patch -s -p1 < $ROOT/tools/micro/attic/epilogue_requests_ahead.patch)
 build libpbsed_all.so
 rm -rf $W
 md5sum tools/variants/*.so
