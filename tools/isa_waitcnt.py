@@ -1,6 +1,7 @@
 """Static look at a kernel file's ISA for the gfx9 load/store counter hazard: loads and stores of a
-wave share `vmcnt` but complete out of order against each other, so the compiler waits for a load that has stores between its
-issue and its use with `s_waitcnt vmcnt(0)` - which also sits out the acknowledgement of every store in flight.  For every kernel
+wave count on ONE `vmcnt`, in issue order (no separate store counter before gfx10), so the wait for a load that has stores in
+front of it also sits out the acknowledgement of those stores - and where the compiler cannot count them (branches, loop
+headers) the wait is `s_waitcnt vmcnt(0)`.  For every kernel
 of a .hip file: the number of VMEM loads / stores / MFMAs and the `vmcnt(0)` waits that have a store within the preceding
 `--window` instructions (a store right in front of the wait: the wait pays its round trip).  CPU only (cross-compiles).
 
