@@ -8,7 +8,8 @@ mkdir -p build
 pids=()
 for f in api conv conv_bf16 conv_wino conv_winox3 conv_s16 conv1d_pc conv_wgrad gru gru_stack gru_wgrad tm_gemm misc logmel postproc collective; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || \
-     [ pbsed_internal.h -nt build/$f.o ] || [ fft512.h -nt build/$f.o ] || [ conv_epilogue.h -nt build/$f.o ] || [ pack_elems.h -nt build/$f.o ] || [ conv_wgrad_s16.h -nt build/$f.o ]; then
+     [ pbsed_internal.h -nt build/$f.o ] || [ fft512.h -nt build/$f.o ] || [ conv_epilogue.h -nt build/$f.o ] || [ pack_elems.h -nt build/$f.o ] || [ conv_wgrad_s16.h -nt build/$f.o ] || \
+     [ gru_granule_map.h -nt build/$f.o ] || [ gru_granule_role.inc -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi

@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "gru_granule_map.h"
 #include "pbsed_internal.h"
 
 namespace pbsed {
@@ -385,26 +386,7 @@ __device__ __forceinline__ GranuleRole granule_role(const GruStackArgs& a) {
     if (a.ring_xcd) {
         // 1-D grid, XCD = block id % 8: ring units (chain, layer, batch tile) one per XCD so that the recurrence's
         // hand-off stays inside one L2; the projection blocks (no recurrence) are dealt round-robin over all XCDs
-        const int nj = a.ring_xcd, x = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int R = a.nchains * a.nlayers * a.nby, P = a.nchains * (a.nlayers - 1) * a.nby;
-        const int ring_slots = (R + 7) / 8 * nj;
-        int unit, m;
-        if (slot < ring_slots) {
-            unit = (slot / nj) * 8 + x;
-            r.bx = slot % nj;
-            r.idle = unit >= R;
-            r.by = unit % a.nby; unit /= a.nby;
-            m = unit % a.nlayers; r.chain = unit / a.nlayers;
-            r.gid = 2 * m;
-        } else {
-            const int pidx = (slot - ring_slots) * 8 + x;
-            unit = pidx / nj;
-            r.bx = pidx % nj;
-            r.idle = unit >= P;
-            r.by = unit % a.nby; unit /= a.nby;
-            m = unit % (a.nlayers > 1 ? a.nlayers - 1 : 1); r.chain = unit / (a.nlayers > 1 ? a.nlayers - 1 : 1);
-            r.gid = 2 * m + 1;
-        }
+#include "gru_granule_role.inc"
     } else {
         r.bx = blockIdx.x; r.by = blockIdx.y;
         r.chain = blockIdx.z % a.nchains; r.gid = blockIdx.z / a.nchains;
@@ -509,7 +491,7 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
         __builtin_amdgcn_make_buffer_rsrc(gran_h_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 4), 0x00020000);
     const unsigned parity = epoch & 1u;
     // ring: h_t, tile-major; this block's first tile of step t starts at g_own + t * Bp * H, the next one H * 16 words on
-    gu32* g_own = (gu32*)gran_h_ + (size_t)(chain * a.nlayers + layer) * per_cl + ((size_t)role.by * NB * (H / 16) + role.bx) * 256;
+    gu32* g_own = (gu32*)gran_h_ + PBSED_GM_RING_BASE(chain, a.nlayers, layer, per_cl, role.by * NB, H, role.bx);
     gu32* g_gi = (gu32*)gran_gi_ + (size_t)(chain * (a.nlayers - 1) + (layer > 0 ? layer - 1 : 0)) * per_cl_b * 3;  // [T][B][3][H]
     // gate thread -> (batch row, unit) row-major: a wave's global stores / loads are whole 64-byte row segments and a producer's
     // 1 KB exchange tile is [16 rows][16 units].  The partial sums a gate thread adds sit in the MFMA D layout (lane (u >> 2) *
@@ -556,7 +538,7 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
     }
     // a projection reads h_t of the layer below, a ring its own h_{t-1}
     const unsigned cl_src = chain * a.nlayers + (is_proj ? layer - 1 : layer);
-    const unsigned voff0 = (unsigned)(((size_t)cl_src * per_cl + (size_t)role.by * NB * 16 * H + (k0 / 16) * 256 + lr * 16 + lq * 4) * 4);
+    const unsigned voff0 = PBSED_GM_POLL_OFFSET0(cl_src, per_cl, role.by * NB, H, k0, lr, lq);
     const unsigned step_t = (unsigned)(Bp * H * 4);           // bytes per time step of one (chain, layer)
     constexpr unsigned tile_bytes = 16u * H * 4u;            // one batch tile of one step
     float h_reg[NB];
@@ -689,7 +671,7 @@ __device__ __forceinline__ void gru_granule_fwd_body(const GruStackArgs& a, unsi
                     const float hp = h_reg[nb];
                     const float h = tag_clear((t < sl[nb]) ? (1.f - z) * n + z * hp : 0.f);    // the state IS the truncated value
                     h_reg[nb] = h;
-                    publish(g_own + (size_t)t * Bp * H + (size_t)nb * (H / 16) * 256 + (tid & 255), h, parity);
+                    publish(g_own + PBSED_GM_RING_WORD_NB(t, Bp, H, nb, tid), h, parity);
                     if (prof_now && prof_g && p0) prof_stamp(pslot + 11);
                     L.hs[tb * H + j] = h;
                     if (L.save) {
@@ -741,7 +723,7 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(gran_dh_, 0, (unsigned)(per_cl * a.nchains * a.nlayers * 4), 0x00020000);
     const unsigned parity = epoch & 1u;
-    gu32* g_own = (gu32*)gran_dh_ + (size_t)(chain * a.nlayers + layer) * per_cl + ((size_t)role.by * (H / 16) + role.bx) * 256;
+    gu32* g_own = (gu32*)gran_dh_ + PBSED_GM_RING_BASE(chain, a.nlayers, layer, per_cl, role.by, H, role.bx);
     gu32* g_dy = (gu32*)gran_dy_ + (size_t)(chain * (a.nlayers - 1) + (layer < top ? layer : 0)) * per_cl_b;
     const int u = tid & 15, bb = (tid >> 4) & 15, b = b0 + bb, j = j0 + u;     // see gru_granule_fwd_body
     const int red_w = lq * 80 + lr * 4, red_r = (u >> 2) * 80 + bb * 4 + (u & 3);
@@ -773,7 +755,7 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
         }
     }
     const unsigned cl_src = chain * a.nlayers + (is_proj ? layer + 1 : layer);
-    const unsigned voff0 = (unsigned)(((size_t)cl_src * per_cl + (size_t)role.by * 16 * H + (k0 / 16) * 256 + lr * 16 + lq * 4) * 4);
+    const unsigned voff0 = PBSED_GM_POLL_OFFSET0(cl_src, per_cl, role.by, H, k0, lr, lq);
     const unsigned step_t = (unsigned)(Bp * H * 4);
     float dhz_prev = 0.f;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -906,8 +888,8 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
                     dhzv = dh * z;
                 }
                 dhz_prev = dhzv;
-                if (ring_local) publish_local(g_own + (size_t)t * Bp * H + (tid & 255), dh, parity);
-                else publish(g_own + (size_t)t * Bp * H + (tid & 255), dh, parity);
+                if (ring_local) publish_local(g_own + PBSED_GM_RING_WORD(t, Bp, H, tid), dh, parity);
+                else publish(g_own + PBSED_GM_RING_WORD(t, Bp, H, tid), dh, parity);
                 if (prof_now && prof_g) prof_stamp(pslot + 11);
                 float* dgi = L.dgi + tb * G;
                 float* dgh = L.dgh + tb * G;
