@@ -8,7 +8,8 @@
 #   tools/variants/libpbsed_s16c.so          + s16_constants_once.patch on top
 #   tools/variants/libpbsed_lm.so            + logmel_setup_one_round_trip.patch on top
 #   tools/variants/libpbsed_wxe.so           + winox3_dgrad_epilogue_pipeline.patch on top
-#   tools/variants/libpbsed_all.so           + epilogue_requests_ahead.patch on top
+#   tools/variants/libpbsed_era.so           + epilogue_requests_ahead.patch on top
+#   tools/variants/libpbsed_all.so           + winox3_seq_len_once_per_tile.patch on top
 # (the .so files are git-ignored and travel to the GPU box with the snapshot)
 set -e
 cd "$(dirname "$0")/.."
@@ -35,6 +36,8 @@ build libpbsed_lm.so
 (cd $W && patch -s -p1 < $ROOT/tools/micro/attic/winox3_dgrad_epilogue_pipeline.patch)
 build libpbsed_wxe.so
 (cd $W && patch -s -p1 < $ROOT/tools/micro/attic/epilogue_requests_ahead.patch)
+build libpbsed_era.so
+(cd $W && patch -s -p1 < $ROOT/tools/micro/attic/winox3_seq_len_once_per_tile.patch)
 build libpbsed_all.so
 rm -rf $W
 md5sum tools/variants/*.so
