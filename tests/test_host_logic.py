@@ -481,3 +481,25 @@ def test_trainer_checkpoint_round_trip_in_padertorch_layout(tmp_path):
     torch.save({'model': ckpt['model'], 'iteration': 3}, tmp_path / 'model_only.pth')
     tr2.load_checkpoint(str(tmp_path / 'model_only.pth'))
     assert tr2.iteration == 3 and not tr2.m.any() and not tr2.v.any()
+
+
+def test_parked_kernel_patches_still_apply_in_stack_order(tmp_path):
+    """tools/micro/attic holds kernel patches that wait for a GPU measurement; they are stacked in the order
+    tools/build_variants.sh applies them.  A tree edit that makes one of them rot should fail here, not on the GPU box."""
+    import re
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = open(os.path.join(root, 'tools', 'build_variants.sh')).read()
+    patches = re.findall(r'attic/(\w+\.patch)\)', script)
+    assert len(patches) >= 9 and patches[0] == 'scalar_tile_loads.patch'
+    work = tmp_path / 'pb_sed_amd'
+    work.mkdir()
+    shutil.copytree(os.path.join(root, 'pb_sed_amd', 'csrc'), work / 'csrc', ignore=shutil.ignore_patterns('build'))
+    for p in patches:
+        r = subprocess.run(['patch', '-s', '-p1', '-i', os.path.join(root, 'tools', 'micro', 'attic', p)], cwd=tmp_path,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (p, r.stdout[-500:], r.stderr[-500:])
+    # every patch listed in the attic README is in the stack, and nothing else is parked silently
+    parked = sorted(f for f in os.listdir(os.path.join(root, 'tools', 'micro', 'attic')) if f.endswith('.patch'))
+    assert parked == sorted(patches)
