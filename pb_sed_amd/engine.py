@@ -130,6 +130,38 @@ DECISION_TAP = None
 # BN backward formed in the dY loader of the weight-gradient kernels that have one (ops.LazyBNGrad) instead of a stand-alone
 # elementwise pass per norm; PBSED_FUSE_BN_BWD=0 restores the stand-alone passes everywhere (A/B measurements, tests).
 FUSE_BN_BWD = os.environ.get('PBSED_FUSE_BN_BWD', '0') != '0'
+# PBSED_SIDE_WGRAD=1 (off by default: prepared while the GPU pool was closed to the build, NOT measured yet - DESIGN.md section 8):
+# the weight gradients of the output heads run on a second stream NEXT TO the persistent BPTT scan instead of in front of it.  The
+# scan occupies 192 of the 256 CUs and is latency-bound (7 % MFMA-pipe busy); the heads' weight gradients are leaves of the
+# backward graph (nothing downstream reads them before the gradient norm), 0.12 - 0.2 ms per FBCRNN step.  The scan is enqueued
+# first, the deferred launches behind an event recorded in front of it; the main stream joins the side stream at the end of
+# the recurrent backward (before anything can read the gradients).  The library's slot scratch is per (device, stream).
+SIDE_WGRAD = os.environ.get('PBSED_SIDE_WGRAD', '0') == '1'
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _SIDE_STREAMS:
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return _SIDE_STREAMS[idx]
+
+
+class _DeferredLaunches(list):
+    """Weight-gradient launches collected during a stack_backward (closures over live tensors: they keep their operands alive
+    until ``run`` has enqueued them and the main stream has joined the side stream)."""
+
+    def run_beside(self, ready_event, device):
+        """Enqueue the collected launches on the side stream behind ``ready_event`` (recorded on the main stream when their
+        operands were final); returns the stream to join."""
+        side = _side_stream(device)
+        if self:
+            with torch.cuda.stream(side):
+                side.wait_event(ready_event)
+                for job in self:
+                    job()
+        return side
 
 
 def _count(seq_host, t, rows):
@@ -281,10 +313,11 @@ def _skip_backward(ctx, src, skip_conv, sctx, g):
     return g
 
 
-def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_done=None, g_tbc=None):
+def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_done=None, g_tbc=None, defer=None):
     """Backward of stack_forward; accumulates parameter grads, returns grad wrt the stack input.
     ``on_layer_done(j)`` fires once every gradient owned by layers >= j is final.  ``g_tbc``: the output gradient in the
-    time-major layout [T,B,C] (instead of ``g``)."""
+    time-major layout [T,B,C] (instead of ``g``).  ``defer``: a _DeferredLaunches that takes the weight-gradient launches instead
+    of running them (SIDE_WGRAD; the caller runs them on a side stream and joins it)."""
     def trainable(j):
         mods = [layers[j].conv.conv] + ([layers[j].in_norm] if layers[j].in_norm is not None else [])
         return any(p.requires_grad for m in mods for p in m.parameters())
@@ -341,10 +374,15 @@ def stack_backward(layers, ctx, g, seq_dev, seq_host, need_input_grad, on_layer_
                 on_layer_done(deferred_done)
                 deferred_done = None
         elif dw is not None:
-            ops.conv_bwd_weight(x, g, pc, dw, db,
-                                scale=None if st_in is None else st_in.scale,
-                                shift=None if st_in is None else st_in.shift,
-                                relu=True, seq_len=seq_dev, unpool_idx=idx, precision=wprec)
+            def wgrad(x=x, g=g, pc=pc, dw=dw, db=db, st_in=st_in, idx=idx, wprec=wprec):
+                ops.conv_bwd_weight(x, g, pc, dw, db,
+                                    scale=None if st_in is None else st_in.scale,
+                                    shift=None if st_in is None else st_in.shift,
+                                    relu=True, seq_len=seq_dev, unpool_idx=idx, precision=wprec)
+            if defer is not None:
+                defer.append(wgrad)
+            else:
+                wgrad()
         norm0 = L.in_norm if (j == 0 and st_in is not None) else None
         norm0_grads = norm0 is not None and any(p.requires_grad for p in norm0.parameters())
         if j == 0 and not need_input_grad and not norm0_grads:
@@ -452,15 +490,20 @@ def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     _, chains, (h, pcs0, hs, save, precision, h_tbc), head_ctx = ctx
     nl = wrappers[0].num_layers
     dy_top = []
+    defer = _DeferredLaunches() if (SIDE_WGRAD and DECISION_TAP is None and dlogits[0].is_cuda) else None
     for wi, w in enumerate(wrappers):
         layers, c = head_ctx[wi]
-        d = stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True)
+        d = stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True, defer=defer)
         dy_top.append(ops.bct_to_tbc(d))
     idx = [(ch, l) for ch in chains for l in range(nl)]
     w_hh_t = [ops.transposed(ch.p('weight_hh', l)) for ch, l in idx]
     w_ih_up_t = [ops.transposed(ch.p('weight_ih', l + 1)) if l + 1 < nl else None for ch, l in idx]
+    if defer is not None:
+        heads_done = torch.cuda.Event()
+        heads_done.record()                      # the heads' gradients wrt their outputs are final on the main stream here
     dgi, dgh = ops.gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, [ch.reverse for ch in chains], seq_dev, nl,
                                  precision='bf16' if precision == 'bf16' else 'f32')
+    side = defer.run_beside(heads_done, dlogits[0].device) if defer is not None else None     # the scan is enqueued: now its neighbours
     dh = None
     jobs = ([], [], [], [], [])                  # all weight gradients of the stacks: one launch
     for ci, ch in enumerate(chains):
@@ -483,6 +526,9 @@ def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
         dh = ops.tbc_to_bct(ops.tm_gemm([dgi[ci * nl] for ci in range(len(chains))], w_t, None, _gemm_prec(precision, w_t[0].shape[1]), role='bwd'))
     if jobs[0]:
         ops.gru_wgrad(*jobs, precision='bf16' if precision == 'bf16' else 'f32')
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)      # nothing behind this point may run before the heads' gradients are final
+        defer.clear()
     return dh
 
 

@@ -486,6 +486,46 @@ def test_fbcrnn_forward_is_reproducible():
         assert ((grad2 - grad).norm() / grad.norm()).item() < 2e-5
 
 
+def test_head_weight_gradients_beside_the_bptt_scan_match_the_serial_order(monkeypatch):
+    """engine.SIDE_WGRAD (PBSED_SIDE_WGRAD=1, off by default): the output heads' weight gradients are enqueued on a second stream
+    behind the persistent BPTT scan's launch and joined at the end of the recurrent backward.  Same batch, same state: the flat
+    gradient has to agree with the serial order to fp32-atomics noise, run after run (a missing event / join would show as
+    run-to-run differences or zeros in the heads' gradients)."""
+    from pb_sed_amd import engine
+    from pb_sed_amd.models import weak_label
+    torch.manual_seed(0)
+    model = weak_label.CRNN.build(num_events=10).to(DEV).train()
+    model.feature_extractor.freeze_stats = True
+    wav, seq, weak, bnd, t = synth_batch(16, 160000, 10, ragged=True)
+    order = np.argsort(-seq, kind='stable')
+    wav, seq, weak, bnd = wav[order], seq[order], weak[order], bnd[order]
+    inputs = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV),
+              'boundary_targets': bnd.to(DEV)}
+
+    def run():
+        _, flat_grad = model.flat_parameters()
+        flat_grad.zero_()
+        for m_ in model.modules():
+            if hasattr(m_, 'running_mean') and m_ is not model.feature_extractor:
+                m_.running_mean.zero_(), m_.running_power.fill_(1.)
+        out = model(dict(inputs))
+        model.review(inputs, out)['loss'].backward()
+        torch.cuda.synchronize()
+        return flat_grad.detach().clone()
+
+    monkeypatch.setattr(engine, 'SIDE_WGRAD', False)
+    ref = run()
+    head_names = [n for n, _ in model.named_parameters() if 'output_net' in n and n.endswith('weight')]
+    assert head_names, 'the FBCRNN has output heads'
+    monkeypatch.setattr(engine, 'SIDE_WGRAD', True)
+    for _ in range(5):
+        g = run()
+        assert ((g - ref).norm() / ref.norm()).item() < 2e-5
+        for n, p_ in model.named_parameters():
+            if n in head_names:
+                assert p_.grad.abs().max().item() > 0, n
+
+
 def test_fbcrnn_finetuning_with_frozen_layers_and_norm_statistics():
     """The reference's fine-tuning path (pb_sed/experiments/weak_label_crnn/training.py:343-350):
     ``model.cnn.cnn_2d.freeze(n, freeze_norm_stats=True)`` and ``cnn_1d.freeze(1)`` - frozen layers normalise with their
