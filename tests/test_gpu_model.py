@@ -486,6 +486,9 @@ def test_fbcrnn_forward_is_reproducible():
         assert ((grad2 - grad).norm() / grad.norm()).item() < 2e-5
 
 
+@pytest.mark.skipif(__import__('os').environ.get('PBSED_TEST_UNMEASURED') != '1',
+                    reason='engine.SIDE_WGRAD was written while the GPU pool was closed to the build: tools/r05_queue.sh runs this test '
+                           '(PBSED_TEST_UNMEASURED=1) together with its A/B; it joins the default suite once it has run on hardware')
 def test_head_weight_gradients_beside_the_bptt_scan_match_the_serial_order(monkeypatch):
     """engine.SIDE_WGRAD (PBSED_SIDE_WGRAD=1, off by default): the output heads' weight gradients are enqueued on a second stream
     behind the persistent BPTT scan's launch and joined at the end of the recurrent backward.  Same batch, same state: the flat
