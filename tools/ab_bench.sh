@@ -3,7 +3,7 @@
 VAR=$1; CFG=${2:-c2}
 mkdir -p gpurun_out
 for v in 1 0; do
-  env $VAR=$v PBSED_BENCH_TABLE=1 python bench.py --config $CFG --headline-only --no-cpu-baseline --steps 50 --warmup 10 \
+  env $VAR=$v PBSED_BENCH_TABLE=1 timeout 300 python bench.py --config $CFG --headline-only --no-cpu-baseline --steps 50 --warmup 10 \
       > gpurun_out/ab_${VAR}_$v.json 2> gpurun_out/ab_${VAR}_$v.err
   python - <<PY
 import json

@@ -10,7 +10,7 @@ for cfg in $CFGS; do
       name=${spec%%=*}; lib=${spec#*=}
       if [ "$lib" = "-" ]; then unset PBSED_LIB; else export PBSED_LIB=$(realpath $lib); fi
       out=gpurun_out/ablib_${name}_${cfg}_$rep
-      PBSED_BENCH_TABLE=1 python bench.py --config $cfg --headline-only --no-cpu-baseline --steps 50 --warmup 10 > $out.json 2> $out.err
+      PBSED_BENCH_TABLE=1 timeout 300 python bench.py --config $cfg --headline-only --no-cpu-baseline --steps 50 --warmup 10 > $out.json 2> $out.err || echo "$cfg $name rep$rep: bench failed or timed out (see $out.err)"
       python - <<PY
 import json
 d = json.load(open('$out.json'))
