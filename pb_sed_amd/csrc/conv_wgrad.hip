@@ -1162,9 +1162,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
                         const u32x4_t q4 = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
 #if !(WGPC_DBG & 64)
                         // dY leaves through LDS: the CONSUMER waves copy the step's fp32 tile to global memory.  A buffer store in
-                        // this (loading) wave turns every later wait for a load into s_waitcnt vmcnt(0) - on gfx9 loads and stores
-                        // share the counter but return out of order against each other - and the two-step load prefetch
-                        // collapses (measured: +30 % on the launch, also with the store hidden in inline assembly).
+                        // this (loading) wave turns every later wait for a load into s_waitcnt vmcnt(0) - on gfx9 a wave's loads and
+                        // stores count on ONE vmcnt, in issue order: a load behind a store waits for the store - and the two-step
+                        // load prefetch collapses (measured: +30 % on the launch, also with the store hidden in inline assembly).
                         if (y_wr[i]) *reinterpret_cast<u32x4_t*>(g_s + y_g[i]) = q4;
 #endif
                     }

@@ -38,6 +38,7 @@ build libpbsed_wxe.so
 (cd $W && patch -s -p1 < $ROOT/tools/micro/attic/epilogue_requests_ahead.patch)
 build libpbsed_era.so
 (cd $W && patch -s -p1 < $ROOT/tools/micro/attic/winox3_seq_len_once_per_tile.patch)
+(cd $W && patch -s -p1 < $ROOT/tools/micro/attic/comment_wording.patch)      # comments only
 build libpbsed_all.so
 rm -rf $W
 md5sum tools/variants/*.so
