@@ -618,20 +618,36 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     hid = wrappers[0].hidden_size
     of_w = [[i for i, ch in enumerate(chains) if ch.widx == wi] for wi in range(len(wrappers))]
     dy = [None] * len(chains)                    # per chain: grad wrt its top-layer output, time-major [T,B,H]
+    # SIDE_WGRAD: leaves of the backward graph run on a second stream beside the NEXT persistent scan (a one-layer BiGRU scan
+    # occupies 64 of the 256 CUs): the heads' weight gradients beside the top layer's scan, a layer's GRU weight gradients
+    # beside the scan of the layer below; the bottom layer's follow on the main stream as before
+    beside = SIDE_WGRAD and DECISION_TAP is None and dlogits[0].is_cuda and _scan_as_stack(wrappers)
+    defer = _DeferredLaunches() if beside else None
+    side, held = None, []
     for wi, w in enumerate(wrappers):
         layers, c = head_ctx[wi]
-        d_out = stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True)       # [B, H*dirs, T]
+        d_out = stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True, defer=defer)       # [B, H*dirs, T]
         for k, i in enumerate(of_w[wi]):
             dy[i] = ops.bct_to_tbc(d_out[:, k * hid:(k + 1) * hid].contiguous())
     dh_in = None
     jobs = ([], [], [], [], [])                  # weight gradients of ALL layers: one launch after the last scan
     padded = []                                  # (gradient of a zero-padded W_ih, the parameter's gradient)
     for l in reversed(range(num_layers)):
+        if beside:
+            ready = torch.cuda.Event()
+            ready.record()                       # what the deferred launches read is final on the main stream here
         src, pcs, hs, save = layer_ctx[l]
         w_hh_t = [ops.transposed(ch.p('weight_hh', l)) for ch in chains]
         if _scan_as_stack(wrappers):
             dgi, dgh = ops.gru_stack_bwd(w_hh_t, [None] * len(chains), hs, save, dy, [ch.reverse for ch in chains],
                                          seq_dev, 1, precision='bf16' if precision == 'bf16' else 'f32')
+            if beside:                           # this layer's scan is enqueued: the launches collected so far run beside it
+                if jobs[0]:                      # (the GRU weight gradients of the layer above)
+                    defer.append(lambda j=jobs: ops.gru_wgrad(*j, precision='bf16' if precision == 'bf16' else 'f32'))
+                    jobs = ([], [], [], [], [])
+                side = defer.run_beside(ready, dlogits[0].device)
+                held.extend(defer)               # the closures keep their operands alive until the join
+                del defer[:]
         else:
             dgi, dgh = ops.gru_scan_bwd(w_hh_t, hs, save, dy, [ch.reverse for ch in chains], seq_dev)
         x_cat = {}                                 # the layer input once per wrapper, time-major, for the weight gradients
@@ -683,6 +699,9 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
         dy = new_dy
     if jobs[0]:
         ops.gru_wgrad(*jobs, precision='bf16' if precision == 'bf16' else 'f32')
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)      # nothing behind this point may run before the deferred gradients are final
+        del held[:]
     for dw_pad, dw in padded:
         dw.add_(dw_pad[:, :dw.shape[1]])
     return dh_in

@@ -489,44 +489,46 @@ def test_fbcrnn_forward_is_reproducible():
 @pytest.mark.skipif(__import__('os').environ.get('PBSED_TEST_UNMEASURED') != '1',
                     reason='engine.SIDE_WGRAD was written while the GPU pool was closed to the build: tools/r05_queue.sh runs this test '
                            '(PBSED_TEST_UNMEASURED=1) together with its A/B; it joins the default suite once it has run on hardware')
-def test_head_weight_gradients_beside_the_bptt_scan_match_the_serial_order(monkeypatch):
-    """engine.SIDE_WGRAD (PBSED_SIDE_WGRAD=1, off by default): the output heads' weight gradients are enqueued on a second stream
-    behind the persistent BPTT scan's launch and joined at the end of the recurrent backward.  Same batch, same state: the flat
-    gradient has to agree with the serial order to fp32-atomics noise, run after run (a missing event / join would show as
-    run-to-run differences or zeros in the heads' gradients)."""
+@pytest.mark.parametrize('kind', ['fbcrnn', 'bicrnn_tag'])
+def test_weight_gradients_beside_the_bptt_scans_match_the_serial_order(monkeypatch, kind):
+    """engine.SIDE_WGRAD (PBSED_SIDE_WGRAD=1, off by default): leaves of the backward graph - the output heads' weight gradients,
+    in the BiCRNN also the upper GRU layer's - are enqueued on a second stream behind the launch of the next persistent BPTT scan
+    and joined at the end of the recurrent backward.  Same batch, same state: every gradient tensor has to agree with the serial
+    order to fp32-atomics noise, run after run (a missing event / join would show as run-to-run differences or as zeros)."""
     from pb_sed_amd import engine
-    from pb_sed_amd.models import weak_label
-    torch.manual_seed(0)
-    model = weak_label.CRNN.build(num_events=10).to(DEV).train()
+    from pb_sed_amd.models import strong_label, weak_label
+    torch.manual_seed(3)
+    wav, seq, weak, bnd, t = synth_batch(8, 16000 * 6, 10, seed=5)
+    if kind == 'fbcrnn':
+        model = weak_label.CRNN.build(num_events=10).to(DEV).train()
+        inputs = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV), 'boundary_targets': bnd.to(DEV)}
+    else:
+        model = strong_label.CRNN.build(tag_conditioning=True).to(DEV).train()
+        hard = (weak > .75).float()
+        inputs = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': hard.to(DEV),
+                  'strong_targets': (bnd > .75).float().to(DEV), 'tag_condition': hard.to(DEV)}
     model.feature_extractor.freeze_stats = True
-    wav, seq, weak, bnd, t = synth_batch(16, 160000, 10, ragged=True)
-    order = np.argsort(-seq, kind='stable')
-    wav, seq, weak, bnd = wav[order], seq[order], weak[order], bnd[order]
-    inputs = {'audio_data': wav.to(DEV), 'seq_len': seq.tolist(), 'weak_targets': weak.to(DEV),
-              'boundary_targets': bnd.to(DEV)}
+    _, flat_grad = model.flat_parameters()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
 
     def run():
-        _, flat_grad = model.flat_parameters()
+        model.load_state_dict(state)
         flat_grad.zero_()
-        for m_ in model.modules():
-            if hasattr(m_, 'running_mean') and m_ is not model.feature_extractor:
-                m_.running_mean.zero_(), m_.running_power.fill_(1.)
-        out = model(dict(inputs))
-        model.review(inputs, out)['loss'].backward()
+        model.review(inputs, model(dict(inputs)))['loss'].backward()
         torch.cuda.synchronize()
-        return flat_grad.detach().clone()
+        return {k: p.grad.clone() for k, p in model.named_parameters()}
 
     monkeypatch.setattr(engine, 'SIDE_WGRAD', False)
     ref = run()
-    head_names = [n for n, _ in model.named_parameters() if 'output_net' in n and n.endswith('weight')]
-    assert head_names, 'the FBCRNN has output heads'
     monkeypatch.setattr(engine, 'SIDE_WGRAD', True)
+    leaves = [n for n in ref if ('output_net' in n or 'rnn' in n) and n.endswith('weight') or 'weight_hh' in n or 'weight_ih' in n]
+    assert leaves
     for _ in range(5):
-        g = run()
-        assert ((g - ref).norm() / ref.norm()).item() < 2e-5
-        for n, p_ in model.named_parameters():
-            if n in head_names:
-                assert p_.grad.abs().max().item() > 0, n
+        got = run()
+        for name, g in got.items():
+            rel_close(g, ref[name], 2e-5, name)
+        for name in leaves:
+            assert got[name].abs().max().item() > 0, name
 
 
 def test_fbcrnn_finetuning_with_frozen_layers_and_norm_statistics():
