@@ -81,3 +81,17 @@ def test_oversized_clip_is_refused_before_any_launch(libpath):
     # x, g, unpool_idx, ..., see include/pbsed.h: B, Cin, Cout, F, T, KH, KW
     rc = L.pbsed_conv_bwd_weight(None, None, None, 1, None, None, None, None, None, 1, 4096, 64, 512, 100000, 3, 3, None)
     assert rc != 0 and b'clip' in L.pbsed_last_error()
+
+
+def test_host_side_of_the_library_is_clean_under_address_sanitizer(tmp_path):
+    """SURVEY.md section 5 (sanitizers): an AddressSanitizer build of the HOST side of the library (device code untouched), every
+    one of its entry points driven through its argument checks, argument structs, pointer tables, tile lists and error strings
+    with host-valid arguments (tools/asan_host_check.sh, tools/asan_host_drive.py; no GPU needed: the launchers reject the
+    shape or stop at their first HIP call).  ~30 s."""
+    import subprocess
+    r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'asan_host_check.sh'), str(tmp_path)], capture_output=True, text=True,
+                       timeout=900)
+    if r.returncode == 77:
+        pytest.skip('no AddressSanitizer runtime in this image')
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
+    assert 'DONE 9' in r.stdout or 'DONE 1' in r.stdout, r.stdout[-500:]          # DONE <n entry points>; ...
