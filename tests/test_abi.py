@@ -83,13 +83,15 @@ def test_oversized_clip_is_refused_before_any_launch(libpath):
     assert rc != 0 and b'clip' in L.pbsed_last_error()
 
 
-def test_host_side_of_the_library_is_clean_under_address_sanitizer(tmp_path):
-    """SURVEY.md section 5 (sanitizers): an AddressSanitizer build of the HOST side of the library (device code untouched), every
-    one of its entry points driven through its argument checks, argument structs, pointer tables, tile lists and error strings
-    with host-valid arguments (tools/asan_host_check.sh, tools/asan_host_drive.py; no GPU needed: the launchers reject the
-    shape or stop at their first HIP call).  ~30 s."""
+@pytest.mark.parametrize('mode', ['asan', 'tsan'])
+def test_host_side_of_the_library_is_clean_under_the_sanitizers(tmp_path, mode):
+    """SURVEY.md section 5 (sanitizers): a sanitizer build of the HOST side of the library (device code untouched), every one
+    of its entry points driven through its argument checks, argument structs, pointer tables, tile lists and error strings with
+    host-valid arguments (tools/asan_host_check.sh, tools/asan_host_drive.py; no GPU needed: the launchers reject the shape or
+    stop at their first HIP call).  'asan': AddressSanitizer + UndefinedBehaviorSanitizer, one thread; 'tsan': ThreadSanitizer, four
+    threads sweeping concurrently (the prefetch thread of the trainer calls into the library beside the main thread).  ~30 s each."""
     import subprocess
-    r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'asan_host_check.sh'), str(tmp_path)], capture_output=True, text=True,
+    r = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'asan_host_check.sh'), str(tmp_path), mode], capture_output=True, text=True,
                        timeout=900)
     if r.returncode == 77:
         pytest.skip('no AddressSanitizer runtime in this image')

@@ -3,7 +3,9 @@ the HOST side of the library (tools/asan_host_check.sh; SURVEY.md section 5: san
 writes on the host (int / float / double / byte arrays, tables of device pointers) get real 4 096-element buffers, device pointers
 are NULL, every integer parameter is set to one value per sweep (0, 1, 4, 17, 1000, -3): the launchers must reject the shape, or
 get as far as their first HIP call and report the missing device - and on the way fill their argument structs, pointer tables,
-tile lists and error strings, which is what the sanitizer watches.  Prints DONE and the tally of return codes.
+tile lists and error strings, which is what the sanitizer watches.  PBSED_DRIVE_THREADS=4: four threads sweep concurrently (the
+ThreadSanitizer pass: per-device tables, the scratch registry, one-time attribute settings are shared host state; the error
+string is thread-local).  Prints DONE and the tally of return codes.
 
     LD_PRELOAD=<libclang_rt.asan> PBSED_LIB=<asan build> python tools/asan_host_drive.py
 """
@@ -35,10 +37,24 @@ def argument(t, ival):
 
 
 tally = collections.Counter()
-for name in sorted(_lib.SIGNATURES):
-    fn = getattr(lib, name)
-    for ival in (0, 1, 4, 17, 1000, -3):
-        print('CALL', name, ival, flush=True)        # (the last line before a sanitizer report names the culprit)
-        r = fn(*[argument(t, ival) for t in _lib.SIGNATURES[name]])
-        tally[r if isinstance(r, int) and r <= 0 else 'value'] += 1
+THREADS = int(os.environ.get('PBSED_DRIVE_THREADS', '1'))     # > 1: the ThreadSanitizer pass (ctypes releases the GIL in the calls)
+
+
+def sweep(quiet):
+    for name in sorted(_lib.SIGNATURES):
+        fn = getattr(lib, name)
+        for ival in (0, 1, 4, 17, 1000, -3):
+            if not quiet:
+                print('CALL', name, ival, flush=True)    # (the last line before a sanitizer report names the culprit)
+            r = fn(*[argument(t, ival) for t in _lib.SIGNATURES[name]])
+            tally[r if isinstance(r, int) and r <= 0 else 'value'] += 1
+
+
+if THREADS > 1:
+    import threading
+    ts = [threading.Thread(target=lambda: [sweep(True) for _ in range(2)]) for _ in range(THREADS)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+else:
+    sweep(False)
 print('DONE', len(_lib.SIGNATURES), 'entry points;', dict(tally))
