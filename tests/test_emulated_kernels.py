@@ -1,0 +1,198 @@
+"""Kernel translation units EXECUTED ON THE CPU (no GPU needed): ``tests/emu/shim/hip/hip_runtime.h`` stands in for the HIP runtime -
+every HIP thread of a block is a fiber, cross-lane instructions (MFMA, DPP, shuffles, readfirstlane) and ``__syncthreads`` are
+rendezvous points, the amdgcn builtins are ordinary functions - so a ``csrc/*.hip`` file compiles for x86 as it is and its
+``extern "C"`` entry points run on host pointers.  Two uses:
+
+* the kernels of the TREE against a plain float64 restatement of the op (a CPU-side sanity check of the device code itself:
+  index maps, masks, fragment layouts, the bf16x3 arithmetic);
+* the tree + the PARKED PATCHES of ``tools/micro/attic`` (re-orderings / equivalent re-writings of loads that wait
+  for a GPU measurement) against the tree: the same emulator, the same inputs - outputs, pool indices and statistics must be
+  BIT-IDENTICAL.  That is the functional half of "the patch changes nothing but the waits"; the timing half needs hardware.
+
+Reference op sites: the few-channel 3x3 layers of pb_sed/experiments/weak_label_crnn/training.py:161-168.
+"""
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, 'tests', 'emu')
+CLANG = '/opt/rocm/lib/llvm/bin/clang++'
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason='needs the ROCm clang++ (ext_vector_type, __bf16)')
+
+
+def _compile(unit, csrc, out):
+    subprocess.run([CLANG, '-x', 'c++', '-std=c++20', '-O1', '-fPIC', '-shared', '-Wno-unused-value', '-Wno-deprecated-declarations',
+                    '-I', os.path.join(EMU, 'shim'), '-I', csrc, os.path.join(EMU, unit), os.path.join(EMU, 'hipemu_runtime.cpp'),
+                    '-o', out], check=True)
+    return C.CDLL(out)
+
+
+@pytest.fixture(scope='module')
+def patched_csrc(tmp_path_factory):
+    """csrc of the tree with the whole parked patch stack applied (the order of tools/build_variants.sh)."""
+    work = tmp_path_factory.mktemp('patched')
+    (work / 'pb_sed_amd').mkdir()
+    shutil.copytree(os.path.join(ROOT, 'pb_sed_amd', 'csrc'), work / 'pb_sed_amd' / 'csrc', ignore=shutil.ignore_patterns('build'))
+    script = open(os.path.join(ROOT, 'tools', 'build_variants.sh')).read()
+    for p in re.findall(r'attic/(\w+\.patch)\)', script):
+        subprocess.run(['patch', '-s', '-p1', '-i', os.path.join(ROOT, 'tools', 'micro', 'attic', p)], cwd=work, check=True)
+    return str(work / 'pb_sed_amd' / 'csrc')
+
+
+@pytest.fixture(scope='module')
+def s16_libs(tmp_path_factory, patched_csrc):
+    d = tmp_path_factory.mktemp('emu_s16')
+    return (_compile('emu_conv_s16.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so')),
+            _compile('emu_conv_s16.cpp', patched_csrc, str(d / 'patched.so')))
+
+
+def P(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _bits(a):
+    return a.view(np.uint32 if a.dtype == np.float32 else np.uint64 if a.dtype == np.float64 else a.dtype)
+
+
+def _conv3x3_f64(x, w):
+    b, cin, f, t = x.shape
+    xp = np.pad(x, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    y = np.zeros((b, w.shape[0], f, t))
+    for kh in range(3):
+        for kw in range(3):
+            y += np.einsum('oc,bcft->boft', w[:, :, kh, kw], xp[:, :, kh:kh + f, kw:kw + t])
+    return y
+
+
+def _pack(lib, w, dgrad):
+    cout, cin = w.shape[:2]
+    outp = 16 if (cin if dgrad else cout) <= 16 else 32
+    up = np.zeros(5 * 3 * (outp // 16) * 512, np.uint16)
+    assert lib.pbsed_pack_conv_weights_s16(P(w), P(up), cout, cin, dgrad, None) == 0
+    return up
+
+
+S16_FWD = [  # (B, Cin, Cout, F, T, pool, prologue, per_cf)
+    (2, 16, 16, 8, 128, 0, True, 0),          # layer 2 of 'shallow' in small
+    (2, 16, 16, 8, 100, 1, True, 0),          # + (2,1) pool, T no multiple of the 64-wide tile, ragged lengths
+    (1, 16, 32, 6, 68, 0, True, 1),           # 32 output channels (2 x 2 waves), F no multiple of the 4-row tile, per-(channel, row) statistics
+    (2, 11, 16, 4, 64, 0, False, 0),          # the tag-conditioned first layer of the BiCRNN: 11 input channels, no prologue
+]
+
+
+@pytest.mark.parametrize('case', S16_FWD, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv_s16_forward_on_the_cpu_tree_vs_float64_and_patched_vs_tree(s16_libs, case):
+    b, cin, cout, f, t, pool, pro, per_cf = case
+    rng = np.random.RandomState(sum(case))
+    x = rng.randn(b, cin, f, t).astype(np.float32)
+    w = (rng.randn(cout, cin, 3, 3) * .1).astype(np.float32)
+    bias = rng.randn(cout).astype(np.float32)
+    scale = (rng.rand(cin) + .5).astype(np.float32) if pro else None
+    shift = (rng.randn(cin) * .1).astype(np.float32) if pro else None
+    seq = np.array([t] + [int(t * .7)] * (b - 1), np.int32)
+    fo = f // 2 if pool else f
+    outs = []
+    for lib in s16_libs:
+        up = _pack(lib, w, 0)
+        y = np.full((b, cout, fo, t), np.nan, np.float32)
+        idx = np.full((b, cout, fo, t), 7, np.uint8) if pool else None
+        stats = np.zeros((32, cout * (fo if per_cf else 1), 2), np.float64)
+        rc = lib.pbsed_conv_fwd_s16(P(x), P(up), P(bias), P(scale), P(shift), 1, P(seq), P(y), P(idx), P(stats), per_cf, b, cin, cout,
+                                    f, t, pool, None)
+        assert rc == 0, lib.emu_last_error()
+        outs.append((y, idx, stats))
+    (y, idx, stats), (y2, idx2, stats2) = outs
+    # --- tree vs float64
+    xa = x.astype(np.float64)
+    if pro:
+        xa = np.maximum(xa * scale[None, :, None, None] + shift[None, :, None, None], 0)
+        for i in range(b):
+            xa[i, :, :, seq[i]:] = 0                             # Normalization re-masks its output; zero padding is post-activation
+    ref = _conv3x3_f64(xa, w.astype(np.float64)) + bias[None, :, None, None]
+    if pool:
+        pair = ref.reshape(b, cout, fo, 2, t)
+        ref_idx = (pair[:, :, :, 1] > pair[:, :, :, 0]).astype(np.uint8)
+        ref = pair.max(3)
+        near_tie = np.abs(pair[:, :, :, 1] - pair[:, :, :, 0]) < 1e-5
+        assert np.array_equal(idx[~near_tie], ref_idx[~near_tie])
+    assert not np.isnan(y).any()
+    assert np.abs(y - ref).max() < 2e-5 * max(1., np.abs(ref).max())
+    masked = ref.copy()
+    for i in range(b):
+        masked[i, :, :, seq[i]:] = 0
+    s_ref = masked.sum((0, 3)) if per_cf else masked.sum((0, 2, 3))
+    s_got = stats.sum(0)[:, 0].reshape(s_ref.shape)
+    assert np.abs(s_got - s_ref).max() < 1e-3 * max(1., np.abs(s_ref).max())
+    # --- patched vs tree: bit for bit
+    assert np.array_equal(_bits(y2), _bits(y))
+    assert np.array_equal(_bits(stats2), _bits(stats))
+    if pool:
+        assert np.array_equal(idx2, idx)
+
+
+S16_BWD = [  # (B, Cin (produced), Cout (contracted), F, T, unpool, bn)
+    (2, 16, 16, 8, 128, False, True),         # data gradient through a norm + ReLU
+    (2, 16, 16, 8, 100, True, True),          # ... of a pooled layer (un-pooling through the argmax bytes)
+    (1, 32, 16, 4, 64, False, True),          # 32 produced channels: the variant that keeps its constants in the channel loop
+    (2, 11, 16, 4, 64, False, False),         # plain store (the first layer: no norm below)
+]
+
+
+@pytest.mark.parametrize('case', S16_BWD, ids=lambda c: 'x'.join(str(int(v)) for v in c))
+def test_conv_s16_data_gradient_on_the_cpu_tree_vs_float64_and_patched_vs_tree(s16_libs, case):
+    b, cin, cout, f, t, unpool, bn = case
+    rng = np.random.RandomState(sum(int(v) for v in case) + 1)
+    w = (rng.randn(cout, cin, 3, 3) * .1).astype(np.float32)
+    fg = f // 2 if unpool else f
+    g = rng.randn(b, cout, fg, t).astype(np.float32)
+    uidx = (rng.rand(b, cout, fg, t) < .5).astype(np.uint8) if unpool else None
+    seq = np.array([t] + [int(t * .8)] * (b - 1), np.int32)
+    bx = rng.randn(b, cin, f, t).astype(np.float32) if bn else None
+    bmean = (rng.randn(cin) * .1).astype(np.float32) if bn else None
+    binv = (rng.rand(cin) + .5).astype(np.float32) if bn else None
+    bscale = (rng.rand(cin) + .5).astype(np.float32) if bn else None
+    bshift = (rng.randn(cin) * .1).astype(np.float32) if bn else None
+    outs = []
+    for lib in s16_libs:
+        up = _pack(lib, w, 1)
+        dz = np.full((b, cin, f, t), np.nan, np.float32)
+        stats = np.zeros((32, cin, 2), np.float64)
+        rc = lib.pbsed_conv_bwd_data_s16(P(g), P(up), P(uidx), P(seq), P(dz), P(bx), P(bmean), P(binv), P(bscale), P(bshift), 1, P(stats),
+                                         b, cin, cout, f, t, None)
+        assert rc == 0, lib.emu_last_error()
+        outs.append((dz, stats))
+    (dz, stats), (dz2, stats2) = outs
+    # --- tree vs float64: dx = conv_transpose(g_unpooled, w) = conv3x3 with flipped, transposed weights
+    gu = g.astype(np.float64)
+    if unpool:
+        full = np.zeros((b, cout, f, t))
+        full[:, :, 0::2] = np.where(uidx == 0, gu, 0)
+        full[:, :, 1::2] = np.where(uidx == 1, gu, 0)
+        gu = full
+    wt = np.flip(w.astype(np.float64), (2, 3)).transpose(1, 0, 2, 3)
+    ref = _conv3x3_f64(gu, wt)
+    if bn:
+        z = bx.astype(np.float64) * bscale[None, :, None, None] + bshift[None, :, None, None]
+        keep = z > 0
+        for i in range(b):
+            keep[i, :, :, seq[i]:] = False
+        near = np.abs(z) < 1e-6
+        ref = np.where(keep, ref, 0)
+        ok = ~near
+        assert np.abs(dz - ref)[ok].max() < 2e-5 * max(1., np.abs(ref).max())
+        xhat = (bx.astype(np.float64) - bmean[None, :, None, None]) * binv[None, :, None, None]
+        s1, s2 = ref.sum((0, 2, 3)), (ref * xhat).sum((0, 2, 3))
+        got = stats.sum(0)
+        assert np.abs(got[:, 0] - s1).max() < 1e-3 * max(1., np.abs(s1).max())
+        assert np.abs(got[:, 1] - s2).max() < 1e-3 * max(1., np.abs(s2).max())
+    else:
+        assert np.abs(dz - ref).max() < 2e-5 * max(1., np.abs(ref).max())
+    # --- patched vs tree: bit for bit
+    assert np.array_equal(_bits(dz2), _bits(dz))
+    assert np.array_equal(_bits(stats2), _bits(stats))
