@@ -8,6 +8,8 @@ void trampoline() {
     Runtime& r = rt();
     r.body();
     r.done[r.cur] = true;
+    --r.active;                                   // a returned thread no longer takes part in the block's barriers (producer waves leave early)
+    if (r.active > 0 && r.blk_arrived >= r.active) { r.blk_arrived = 0; ++r.blk_gen; }
     swapcontext(&r.ctx[r.cur], &r.sched);
 }
 void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
@@ -25,6 +27,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) {
                 r.blk_arrived = 0;
+                r.active = n;
                 for (auto& w : r.wave) w.arrived = 0;
                 for (int i = 0; i < n; ++i) {
                     getcontext(&r.ctx[i]);

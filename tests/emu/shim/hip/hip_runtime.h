@@ -61,7 +61,7 @@ struct Runtime {
     ucontext_t ctx[MAX_THREADS];
     char* stack[MAX_THREADS] = {nullptr};
     bool done[MAX_THREADS];
-    int cur = 0, nthreads = 0;
+    int cur = 0, nthreads = 0, active = 0;   // active: fibers of the block that have not returned (s_barrier counts live waves only)
     int blk_arrived = 0;
     unsigned blk_gen = 0;
     Wave wave[MAX_THREADS / WAVE];
@@ -86,7 +86,7 @@ inline void wave_sync() {
 inline void block_sync() {
     Runtime& r = rt();
     const unsigned g = r.blk_gen;
-    if (++r.blk_arrived == r.nthreads) { r.blk_arrived = 0; ++r.blk_gen; return; }
+    if (++r.blk_arrived >= r.active) { r.blk_arrived = 0; ++r.blk_gen; return; }
     while (r.blk_gen == g) yield();
 }
 inline int lane() { return rt().cur % WAVE; }

@@ -196,3 +196,128 @@ def test_conv_s16_data_gradient_on_the_cpu_tree_vs_float64_and_patched_vs_tree(s
     # --- patched vs tree: bit for bit
     assert np.array_equal(_bits(dz2), _bits(dz))
     assert np.array_equal(_bits(stats2), _bits(stats))
+
+
+# ------------------------------------------------------------------------------------------------ conv_winox3 (Winograd F(4,3), bf16x3)
+@pytest.fixture(scope='module')
+def wx_libs(tmp_path_factory, patched_csrc):
+    d = tmp_path_factory.mktemp('emu_wx')
+    return (_compile('emu_conv_winox3.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so')),
+            _compile('emu_conv_winox3.cpp', patched_csrc, str(d / 'patched.so')))
+
+
+def _pack_wx(lib, w, dgrad):
+    cout, cin = w.shape[:2]
+    inp, outp = C.c_int(), C.c_int()
+    lib.pbsed_conv_pack_dims_winox3(cin, cout, dgrad, C.byref(inp), C.byref(outp))
+    up = np.zeros(18 * inp.value * outp.value * 3, np.uint16)
+    assert lib.pbsed_pack_conv_weights_winox3(P(w), P(up), cout, cin, dgrad, None) == 0
+    return up
+
+
+WX_FWD = [  # (B, Cin, Cout, F, T, pool, per_cf)
+    (1, 32, 64, 4, 64, 0, 0),                 # one chunk, one cout tile
+    (2, 64, 64, 8, 100, 1, 0),                # two chunks, (2,1) pool, ragged, T no multiple of the tile
+    (1, 32, 32, 6, 68, 0, 1),                 # 32-cout blocks (two waves per cout tile), F no multiple of 4, per-(channel, row) statistics
+    (1, 64, 128, 4, 64, 0, 0),                # two cout tiles per spatial tile: the item walk of the persistent blocks
+]
+
+
+@pytest.mark.parametrize('case', WX_FWD, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv_winox3_forward_on_the_cpu_tree_vs_float64_and_patched_vs_tree(wx_libs, case):
+    b, cin, cout, f, t, pool, per_cf = case
+    rng = np.random.RandomState(sum(case) + 7)
+    x = rng.randn(b, cin, f, t).astype(np.float32)
+    w = (rng.randn(cout, cin, 3, 3) * .1).astype(np.float32)
+    bias = rng.randn(cout).astype(np.float32)
+    scale = (rng.rand(cin) + .5).astype(np.float32)
+    shift = (rng.randn(cin) * .1).astype(np.float32)
+    seq = np.array([t] + [int(t * .7)] * (b - 1), np.int32)
+    fo = f // 2 if pool else f
+    outs = []
+    for lib in wx_libs:
+        up = _pack_wx(lib, w, 0)
+        y = np.full((b, cout, fo, t), np.nan, np.float32)
+        idx = np.full((b, cout, fo, t), 7, np.uint8) if pool else None
+        stats = np.zeros((32, cout * (fo if per_cf else 1), 2), np.float64)
+        rc = lib.pbsed_conv_fwd_winox3(P(x), P(up), P(bias), P(scale), P(shift), 1, P(seq), P(y), P(idx), P(stats), per_cf, b, cin, cout,
+                                       f, t, pool, None)
+        assert rc == 0
+        outs.append((y, idx, stats))
+    (y, idx, stats), (y2, idx2, stats2) = outs
+    xa = np.maximum(x.astype(np.float64) * scale[None, :, None, None] + shift[None, :, None, None], 0)
+    for i in range(b):
+        xa[i, :, :, seq[i]:] = 0
+    ref = _conv3x3_f64(xa, w.astype(np.float64)) + bias[None, :, None, None]
+    if pool:
+        pair = ref.reshape(b, cout, fo, 2, t)
+        ref_idx = (pair[:, :, :, 1] > pair[:, :, :, 0]).astype(np.uint8)
+        ref = pair.max(3)
+        near_tie = np.abs(pair[:, :, :, 1] - pair[:, :, :, 0]) < 1e-4
+        assert np.array_equal(idx[~near_tie], ref_idx[~near_tie])
+    assert not np.isnan(y).any()
+    assert np.abs(y - ref).max() < 5e-5 * max(1., np.abs(ref).max())          # Winograd F(4,3) in fp32-class arithmetic
+    masked = ref.copy()
+    for i in range(b):
+        masked[i, :, :, seq[i]:] = 0
+    s_ref = masked.sum((0, 3)) if per_cf else masked.sum((0, 2, 3))
+    s_got = stats.sum(0)[:, 0].reshape(s_ref.shape)
+    assert np.abs(s_got - s_ref).max() < 2e-3 * max(1., np.abs(s_ref).max())
+    assert np.array_equal(_bits(y2), _bits(y))
+    assert np.array_equal(_bits(stats2), _bits(stats))
+    if pool:
+        assert np.array_equal(idx2, idx)
+
+
+WX_BWD = [  # (B, Cin (produced), Cout (contracted), F, T, unpool)
+    (1, 64, 64, 4, 64, False),                # data gradient through a norm + ReLU (the re-load of the layer input, one pair ahead)
+    (2, 64, 32, 8, 100, True),                # ... of a pooled layer, ragged
+    (1, 32, 64, 4, 68, False),                # 32 produced channels: the 32-cout block form
+]
+
+
+@pytest.mark.parametrize('case', WX_BWD, ids=lambda c: 'x'.join(str(int(v)) for v in c))
+def test_conv_winox3_data_gradient_on_the_cpu_tree_vs_float64_and_patched_vs_tree(wx_libs, case):
+    b, cin, cout, f, t, unpool = case
+    rng = np.random.RandomState(sum(int(v) for v in case) + 11)
+    w = (rng.randn(cout, cin, 3, 3) * .1).astype(np.float32)
+    fg = f // 2 if unpool else f
+    g = rng.randn(b, cout, fg, t).astype(np.float32)
+    uidx = (rng.rand(b, cout, fg, t) < .5).astype(np.uint8) if unpool else None
+    seq = np.array([t] + [int(t * .8)] * (b - 1), np.int32)
+    bx = rng.randn(b, cin, f, t).astype(np.float32)
+    bmean = (rng.randn(cin) * .1).astype(np.float32)
+    binv = (rng.rand(cin) + .5).astype(np.float32)
+    bscale = (rng.rand(cin) + .5).astype(np.float32)
+    bshift = (rng.randn(cin) * .1).astype(np.float32)
+    outs = []
+    for lib in wx_libs:
+        up = _pack_wx(lib, w, 1)
+        dz = np.full((b, cin, f, t), np.nan, np.float32)
+        stats = np.zeros((32, cin, 2), np.float64)
+        rc = lib.pbsed_conv_bwd_data_winox3(P(g), P(up), P(uidx), P(seq), P(dz), P(bx), P(bmean), P(binv), P(bscale), P(bshift), 1,
+                                            P(stats), b, cin, cout, f, t, None)
+        assert rc == 0
+        outs.append((dz, stats))
+    (dz, stats), (dz2, stats2) = outs
+    gu = g.astype(np.float64)
+    if unpool:
+        full = np.zeros((b, cout, f, t))
+        full[:, :, 0::2] = np.where(uidx == 0, gu, 0)
+        full[:, :, 1::2] = np.where(uidx == 1, gu, 0)
+        gu = full
+    ref = _conv3x3_f64(gu, np.flip(w.astype(np.float64), (2, 3)).transpose(1, 0, 2, 3))
+    z = bx.astype(np.float64) * bscale[None, :, None, None] + bshift[None, :, None, None]
+    keep = z > 0
+    for i in range(b):
+        keep[i, :, :, seq[i]:] = False
+    ref = np.where(keep, ref, 0)
+    ok = np.abs(z) > 1e-6
+    assert not np.isnan(dz).any()
+    assert np.abs(dz - ref)[ok].max() < 5e-5 * max(1., np.abs(ref).max())
+    xhat = (bx.astype(np.float64) - bmean[None, :, None, None]) * binv[None, :, None, None]
+    got = stats.sum(0)
+    assert np.abs(got[:, 0] - ref.sum((0, 2, 3))).max() < 2e-3 * max(1., np.abs(ref.sum((0, 2, 3))).max())
+    assert np.abs(got[:, 1] - (ref * xhat).sum((0, 2, 3))).max() < 2e-3 * max(1., np.abs((ref * xhat).sum((0, 2, 3))).max())
+    assert np.array_equal(_bits(dz2), _bits(dz))
+    assert np.array_equal(_bits(stats2), _bits(stats))
