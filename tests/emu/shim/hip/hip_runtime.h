@@ -243,6 +243,9 @@ static inline unsigned char __builtin_amdgcn_raw_buffer_load_b8(__amdgpu_buffer_
 static inline void __builtin_amdgcn_raw_buffer_store_b128(hipemu_u32x4 x, __amdgpu_buffer_rsrc_t r, unsigned v, unsigned s, int) { hipemu_buf_store(x, r, v, s); }
 static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned x, __amdgpu_buffer_rsrc_t r, unsigned v, unsigned s, int) { hipemu_buf_store(x, r, v, s); }
 static inline void __builtin_amdgcn_raw_buffer_store_b8(unsigned char x, __amdgpu_buffer_rsrc_t r, unsigned v, unsigned s, int) { hipemu_buf_store(x, r, v, s); }
+static inline void __builtin_amdgcn_fence(int, const char*) {}
+static inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_sync(); }     // (the lanes of a wave run one after the other here: the kernels'
+                                                                                 // "all lanes read, then all lanes write" points are real rendezvous)
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}

@@ -321,3 +321,69 @@ def test_conv_winox3_data_gradient_on_the_cpu_tree_vs_float64_and_patched_vs_tre
     assert np.abs(got[:, 1] - (ref * xhat).sum((0, 2, 3))).max() < 2e-3 * max(1., np.abs((ref * xhat).sum((0, 2, 3))).max())
     assert np.array_equal(_bits(dz2), _bits(dz))
     assert np.array_equal(_bits(stats2), _bits(stats))
+
+
+# ------------------------------------------------------------------------------------------------ logmel (the fused front-end)
+@pytest.fixture(scope='module')
+def lm_libs(tmp_path_factory, patched_csrc):
+    d = tmp_path_factory.mktemp('emu_lm')
+    return (_compile('emu_logmel.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so')),
+            _compile('emu_logmel.cpp', patched_csrc, str(d / 'patched.so')))
+
+
+def _logmel_tables(fb):
+    """pb_sed_amd/ops.py::LogMelTables on the host (window, twiddles, packed sparse filterbank)."""
+    fb = np.asarray(fb, np.float32)
+    nz = fb > 0
+    start = np.array([int(np.argmax(r)) if r.any() else 0 for r in nz], np.int32)
+    end = np.array([len(r) - int(np.argmax(r[::-1])) if r.any() else 0 for r in nz], np.int32)
+    length = (end - start).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.int32)
+    w = np.concatenate([fb[m, start[m]:end[m]] for m in range(fb.shape[0])]).astype(np.float32)
+    k = np.arange(960, dtype=np.float64)
+    win = (0.42 - 0.5 * np.cos(2 * np.pi * k / 960) + 0.08 * np.cos(4 * np.pi * k / 960)).astype(np.float32)
+    q = np.arange(1024, dtype=np.float64)
+    tw = np.stack([np.cos(-2 * np.pi * q / 1024), np.sin(-2 * np.pi * q / 1024)], -1).astype(np.float32)
+    return win, tw, start, length, off, w
+
+
+@pytest.mark.parametrize('warped', [False, True], ids=['static_filterbank', 'warped_mel'])
+def test_logmel_front_end_on_the_cpu_tree_vs_oracle_and_patched_vs_tree(lm_libs, warped):
+    """The fused STFT -> power -> mel -> log -> norm -> clamp -> mask launch (two clips, 23 frames: one full 16-frame tile and a
+    ragged one), with the statistics sums of a training step, against oracle/frontend.py in float64; then the patched kernel
+    (one request group in the set-up, split descriptor load / finish, template on WARPED) bit for bit against the tree's."""
+    import torch
+    from oracle import frontend as ofe
+    rng = np.random.RandomState(3 + warped)
+    b, n = 2, 320 * 22 + 1
+    t = ofe.num_frames(n)
+    wav = rng.randn(b, n).astype(np.float32)
+    seq = np.array([t, t - 5], np.int32)
+    fe = ofe.LogMelExtractor().double().eval()
+    f = fe.number_of_filters
+    win, tw, start, length, off, w = _logmel_tables(fe.fbanks.numpy())
+    mean = (rng.randn(f) * .1 - 3).astype(np.float32)
+    inv_std = (rng.rand(f) * .2 + .4).astype(np.float32)
+    pts = None
+    if warped:                                   # per-clip filter edges: monotone fractional bin positions
+        base = np.linspace(2., 500., f + 2)
+        pts = np.stack([base * s for s in (1., .93)]).astype(np.float32)
+    outs = []
+    for lib in lm_libs:
+        out = np.full((b, 1, f, t), np.nan, np.float32)
+        stats = np.zeros((32, f, 2), np.float64)
+        rc = lib.pbsed_logmel_fwd(P(wav), b, n, t, P(seq), P(win), P(tw), P(start), P(length), P(off), P(w), len(w), f, P(mean), P(inv_std),
+                                  C.c_float(1e-18), C.c_float(6.), P(out), P(stats), 320, P(pts), None)
+        assert rc == 0
+        outs.append((out, stats))
+    (out, stats), (out2, stats2) = outs
+    fe.mean.copy_(torch.from_numpy(mean).double())
+    fe.inv_std.copy_(torch.from_numpy(inv_std).double())
+    ref = fe(ofe.stft(torch.from_numpy(wav).double()), seq_len=torch.from_numpy(seq.astype(np.int64)),
+             mel_points=None if pts is None else pts.astype(np.float64))[0].numpy()
+    assert not np.isnan(out).any()
+    assert np.abs(out - ref).max() < 2e-4                         # the bound of tests/test_gpu_ops.py::test_logmel_vs_oracle
+    got = stats.sum(0)
+    assert np.abs(got[:, 0] - ref.sum((0, 1, 3))).max() < 1e-2
+    assert np.array_equal(_bits(out2), _bits(out))
+    assert np.array_equal(_bits(stats2), _bits(stats))
