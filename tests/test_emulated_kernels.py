@@ -387,3 +387,134 @@ def test_logmel_front_end_on_the_cpu_tree_vs_oracle_and_patched_vs_tree(lm_libs,
     assert np.abs(got[:, 0] - ref.sum((0, 1, 3))).max() < 1e-2
     assert np.array_equal(_bits(out2), _bits(out))
     assert np.array_equal(_bits(stats2), _bits(stats))
+
+
+# ------------------------------------------------------------------------------------------------ conv_bf16 (configs[2]; the 1x1 layers of 'deep')
+@pytest.fixture(scope='module')
+def b16_libs(tmp_path_factory, patched_csrc):
+    d = tmp_path_factory.mktemp('emu_b16')
+    return (_compile('emu_conv_bf16.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so')),
+            _compile('emu_conv_bf16.cpp', patched_csrc, str(d / 'patched.so')))
+
+
+def _pack_b16(lib, w, dgrad, nsplit):
+    cout, cin, kh, kw = w.shape
+    inp, outp = C.c_int(), C.c_int()
+    lib.pbsed_conv_pack_dims_bf16(cin, cout, dgrad, C.byref(inp), C.byref(outp))
+    up = np.zeros(nsplit * kh * kw * outp.value * inp.value, np.uint16)
+    assert lib.pbsed_pack_conv_weights_bf16(P(w), P(up), cout, cin, kh, kw, dgrad, nsplit, None) == 0
+    return up
+
+
+def _conv_f64(x, w):
+    kh, kw = w.shape[2:]
+    b, cin, f, t = x.shape
+    xp = np.pad(x, ((0, 0), (0, 0), (kh // 2, kh // 2), (kw // 2, kw // 2)))
+    y = np.zeros((b, w.shape[0], f, t))
+    for i in range(kh):
+        for j in range(kw):
+            y += np.einsum('oc,bcft->boft', w[:, :, i, j], xp[:, :, i:i + f, j:j + t])
+    return y
+
+
+B16_FWD = [  # (B, Cin, Cout, F, T, K, pool, nsplit, residual)
+    (1, 64, 128, 4, 128, 1, 0, 3, True),      # a 1x1 layer of 'deep' with a residual connection ending at it (bf16x3: fp32-class)
+    (2, 64, 128, 4, 100, 1, 1, 3, True),      # ... under a (2,1) pool, ragged
+    (1, 64, 64, 4, 64, 3, 0, 1, False),       # configs[2]: 3x3, plain bf16 operands
+    (1, 32, 64, 4, 68, 3, 1, 1, False),       # ... with a pool
+]
+
+
+@pytest.mark.parametrize('case', B16_FWD, ids=lambda c: 'x'.join(str(int(v)) for v in c))
+def test_conv_bf16_forward_on_the_cpu_tree_vs_float64_and_patched_vs_tree(b16_libs, case):
+    b, cin, cout, f, t, k, pool, nsplit, with_res = case
+    rng = np.random.RandomState(sum(int(v) for v in case) + 21)
+    x = rng.randn(b, cin, f, t).astype(np.float32)
+    w = (rng.randn(cout, cin, k, k) * .1).astype(np.float32)
+    bias = rng.randn(cout).astype(np.float32)
+    scale = (rng.rand(cin) + .5).astype(np.float32)
+    shift = (rng.randn(cin) * .1).astype(np.float32)
+    seq = np.array([t] + [int(t * .7)] * (b - 1), np.int32)
+    fo = f // 2 if pool else f
+    res = rng.randn(b, cout, fo, t).astype(np.float32) if with_res else None
+    outs = []
+    for lib in b16_libs:
+        up = _pack_b16(lib, w, 0, nsplit)
+        y = np.full((b, cout, fo, t), np.nan, np.float32)
+        idx = np.full((b, cout, fo, t), 7, np.uint8) if pool else None
+        stats = np.zeros((32, cout, 2), np.float64)
+        if with_res:
+            rc = lib.pbsed_conv_fwd_bf16_res(P(x), P(up), P(bias), P(scale), P(shift), 1, P(seq), P(y), P(idx), P(stats), 0, b, cin, cout,
+                                             f, t, k, k, pool, nsplit, P(res), None)
+        else:
+            rc = lib.pbsed_conv_fwd_bf16(P(x), P(up), P(bias), P(scale), P(shift), 1, P(seq), P(y), P(idx), P(stats), 0, b, cin, cout,
+                                         f, t, k, k, pool, nsplit, None)
+        assert rc == 0, lib.emu_last_error()
+        outs.append((y, idx, stats))
+    (y, idx, stats), (y2, idx2, stats2) = outs
+    xa = np.maximum(x.astype(np.float64) * scale[None, :, None, None] + shift[None, :, None, None], 0)
+    for i in range(b):
+        xa[i, :, :, seq[i]:] = 0
+    ref = _conv_f64(xa, w.astype(np.float64)) + bias[None, :, None, None]
+    if pool:
+        ref = ref.reshape(b, cout, fo, 2, t).max(3)
+    if with_res:
+        ref = ref + res
+    tol = 2e-5 if nsplit == 3 else 3e-2                           # bf16x3 is fp32-class; plain bf16 operands round to 8 bits
+    assert not np.isnan(y).any()
+    assert np.abs(y - ref).max() < tol * max(1., np.abs(ref).max())
+    assert np.array_equal(_bits(y2), _bits(y))
+    assert np.array_equal(_bits(stats2), _bits(stats))
+    if pool:
+        assert np.array_equal(idx2, idx)
+
+
+B16_BWD = [  # (B, Cin (produced), Cout (contracted), F, T, K, unpool, nsplit)
+    (1, 64, 64, 4, 64, 3, False, 1),          # configs[2]'s data gradient through a norm + ReLU
+    (2, 64, 32, 8, 100, 3, True, 1),          # ... of a pooled layer, ragged
+    (1, 128, 64, 4, 128, 1, False, 3),        # a 1x1 layer of 'deep' (bf16x3)
+]
+
+
+@pytest.mark.parametrize('case', B16_BWD, ids=lambda c: 'x'.join(str(int(v)) for v in c))
+def test_conv_bf16_data_gradient_on_the_cpu_tree_vs_float64_and_patched_vs_tree(b16_libs, case):
+    b, cin, cout, f, t, k, unpool, nsplit = case
+    rng = np.random.RandomState(sum(int(v) for v in case) + 23)
+    w = (rng.randn(cout, cin, k, k) * .1).astype(np.float32)
+    fg = f // 2 if unpool else f
+    g = rng.randn(b, cout, fg, t).astype(np.float32)
+    uidx = (rng.rand(b, cout, fg, t) < .5).astype(np.uint8) if unpool else None
+    seq = np.array([t] + [int(t * .8)] * (b - 1), np.int32)
+    bx = rng.randn(b, cin, f, t).astype(np.float32)
+    bmean = (rng.randn(cin) * .1).astype(np.float32)
+    binv = (rng.rand(cin) + .5).astype(np.float32)
+    bscale = (rng.rand(cin) + .5).astype(np.float32)
+    bshift = (rng.randn(cin) * .1).astype(np.float32)
+    outs = []
+    for lib in b16_libs:
+        up = _pack_b16(lib, w, 1, nsplit)
+        dz = np.full((b, cin, f, t), np.nan, np.float32)
+        stats = np.zeros((32, cin, 2), np.float64)
+        rc = lib.pbsed_conv_bwd_data_bf16(P(g), P(up), P(uidx), P(seq), P(dz), P(bx), P(bmean), P(binv), P(bscale), P(bshift), 1, P(stats),
+                                          b, cin, cout, f, t, k, k, nsplit, None)
+        assert rc == 0, lib.emu_last_error()
+        outs.append((dz, stats))
+    (dz, stats), (dz2, stats2) = outs
+    gu = g.astype(np.float64)
+    if unpool:
+        full = np.zeros((b, cout, f, t))
+        full[:, :, 0::2] = np.where(uidx == 0, gu, 0)
+        full[:, :, 1::2] = np.where(uidx == 1, gu, 0)
+        gu = full
+    ref = _conv_f64(gu, np.flip(w.astype(np.float64), (2, 3)).transpose(1, 0, 2, 3))
+    z = bx.astype(np.float64) * bscale[None, :, None, None] + bshift[None, :, None, None]
+    keep = z > 0
+    for i in range(b):
+        keep[i, :, :, seq[i]:] = False
+    ref = np.where(keep, ref, 0)
+    ok = np.abs(z) > 1e-6
+    tol = 2e-5 if nsplit == 3 else 3e-2
+    assert not np.isnan(dz).any()
+    assert np.abs(dz - ref)[ok].max() < tol * max(1., np.abs(ref).max())
+    assert np.array_equal(_bits(dz2), _bits(dz))
+    assert np.array_equal(_bits(stats2), _bits(stats))
