@@ -137,6 +137,7 @@ static inline bool __all(bool p) {
     return a;
 }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0); }
+static inline int __builtin_amdgcn_readlane(int v, int l) { return __shfl(v, l); }
 // v_mov_b32_dpp: the controls the kernels use (quad_perm, row_shl / row_shr, row_mirror, row_half_mirror), bound_ctrl -> 0 / old
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     hipemu::Wave& w = hipemu::my_wave();

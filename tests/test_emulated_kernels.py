@@ -518,3 +518,71 @@ def test_conv_bf16_data_gradient_on_the_cpu_tree_vs_float64_and_patched_vs_tree(
     assert np.abs(dz - ref)[ok].max() < tol * max(1., np.abs(ref).max())
     assert np.array_equal(_bits(dz2), _bits(dz))
     assert np.array_equal(_bits(stats2), _bits(stats))
+
+
+# ------------------------------------------------------------------------------------------------ conv1d_pc (Conv1d k = 1 / 3, bf16x3, producer / consumer)
+@pytest.fixture(scope='module')
+def c1_libs(tmp_path_factory, patched_csrc):
+    d = tmp_path_factory.mktemp('emu_c1')
+    return (_compile('emu_conv1d_pc.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so')),
+            _compile('emu_conv1d_pc.cpp', patched_csrc, str(d / 'patched.so')))
+
+
+def _pack_c1(lib, w, dgrad):
+    cout, cin, kw = w.shape
+    inp, outp = C.c_int(), C.c_int()
+    lib.pbsed_conv1d_pack_dims_x3(cin, cout, dgrad, C.byref(inp), C.byref(outp))
+    up = np.zeros(kw * inp.value * outp.value * 3, np.uint16)
+    assert lib.pbsed_pack_conv1d_weights_x3(P(w), P(up), cout, cin, kw, dgrad, None) == 0
+    return up
+
+
+def _conv1d_f64(x, w):
+    kw = w.shape[2]
+    xp = np.pad(x, ((0, 0), (0, 0), (kw // 2, kw // 2)))
+    return sum(np.einsum('oc,bct->bot', w[:, :, j], xp[:, :, j:j + x.shape[2]]) for j in range(kw))
+
+
+@pytest.mark.parametrize('case', [(2, 64, 128, 200, 3), (2, 96, 256, 132, 1)], ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv1d_pc_on_the_cpu_tree_vs_float64_and_patched_vs_tree(c1_libs, case):
+    """Forward (BN-apply + ReLU + mask prologue, bias, statistics) and the data gradient through the layer's norm + ReLU of the
+    Conv1d kernels (CNN1d, the output nets): ragged lengths, T no multiple of the 128-wide tile, Cin no multiple of 64."""
+    b, cin, cout, t, kw = case
+    rng = np.random.RandomState(sum(case) + 31)
+    x = rng.randn(b, cin, t).astype(np.float32)
+    w = (rng.randn(cout, cin, kw) * .1).astype(np.float32)
+    bias = rng.randn(cout).astype(np.float32)
+    scale = (rng.rand(cin) + .5).astype(np.float32)
+    shift = (rng.randn(cin) * .1).astype(np.float32)
+    seq = np.array([t, int(t * .7)], np.int32)
+    g = rng.randn(b, cout, t).astype(np.float32)
+    bmean = (rng.randn(cin) * .1).astype(np.float32)
+    binv = (rng.rand(cin) + .5).astype(np.float32)
+    outs = []
+    for lib in c1_libs:
+        y = np.full((b, cout, t), np.nan, np.float32)
+        stats = np.zeros((32, cout, 2), np.float64)
+        rc = lib.pbsed_conv1d_fwd_x3(P(x), P(_pack_c1(lib, w, 0)), P(bias), P(scale), P(shift), 1, P(seq), P(y), P(stats), b, cin, cout, t,
+                                     kw, None)
+        assert rc == 0, lib.emu_last_error()
+        dz = np.full((b, cin, t), np.nan, np.float32)
+        dstats = np.zeros((32, cin, 2), np.float64)
+        rc = lib.pbsed_conv1d_bwd_data_x3(P(g), P(_pack_c1(lib, w, 1)), P(seq), P(dz), P(x), P(bmean), P(binv), P(scale), P(shift), 1,
+                                          P(dstats), b, cin, cout, t, kw, None)
+        assert rc == 0, lib.emu_last_error()
+        outs.append((y, stats, dz, dstats))
+    (y, stats, dz, dstats), (y2, stats2, dz2, dstats2) = outs
+    z = x.astype(np.float64) * scale[None, :, None] + shift[None, :, None]
+    xa = np.maximum(z, 0)
+    keep = z > 0
+    for i in range(b):
+        xa[i, :, seq[i]:] = 0
+        keep[i, :, seq[i]:] = False
+    ref = _conv1d_f64(xa, w.astype(np.float64)) + bias[None, :, None]
+    assert not np.isnan(y).any() and not np.isnan(dz).any()
+    assert np.abs(y - ref).max() < 2e-5 * max(1., np.abs(ref).max())
+    dref = np.where(keep, _conv1d_f64(g.astype(np.float64), np.flip(w.astype(np.float64), 2).transpose(1, 0, 2)), 0)
+    ok = np.abs(z) > 1e-6
+    assert np.abs(dz - dref)[ok].max() < 2e-5 * max(1., np.abs(dref).max())
+    for a_, b_ in ((y2, y), (stats2, stats), (dz2, dz), (dstats2, dstats)):
+        assert np.array_equal(_bits(a_), _bits(b_))
