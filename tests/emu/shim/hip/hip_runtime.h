@@ -167,6 +167,9 @@ static inline unsigned __builtin_amdgcn_perm(unsigned a, unsigned b, unsigned se
     }
     return r;
 }
+static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) {   // v_alignbit_b32: ({hi, lo} >> sh)[31:0]
+    return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31));
+}
 typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
 // v_mfma_f32_16x16x32_bf16: A[i = lane & 15][k = 8 (lane >> 4) + e], B[k = 8 (lane >> 4) + e][j = lane & 15],

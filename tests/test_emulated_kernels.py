@@ -27,7 +27,8 @@ pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason='needs the ROC
 
 
 def _compile(unit, csrc, out):
-    subprocess.run([CLANG, '-x', 'c++', '-std=c++20', '-O1', '-fPIC', '-shared', '-Wno-unused-value', '-Wno-deprecated-declarations',
+    # -O0: these translation units are template-heavy (28 s at -O1, 2 s at -O0) and the emulated launches are tiny
+    subprocess.run([CLANG, '-x', 'c++', '-std=c++20', '-O0', '-fPIC', '-shared', '-w',
                     '-I', os.path.join(EMU, 'shim'), '-I', csrc, os.path.join(EMU, unit), os.path.join(EMU, 'hipemu_runtime.cpp'),
                     '-o', out], check=True)
     return C.CDLL(out)
@@ -586,3 +587,61 @@ def test_conv1d_pc_on_the_cpu_tree_vs_float64_and_patched_vs_tree(c1_libs, case)
     assert np.abs(dz - dref)[ok].max() < 2e-5 * max(1., np.abs(dref).max())
     for a_, b_ in ((y2, y), (stats2, stats), (dz2, dz), (dstats2, dstats)):
         assert np.array_equal(_bits(a_), _bits(b_))
+
+
+# ------------------------------------------------------------------------------------------------ conv_wgrad (every conv weight-gradient kernel)
+@pytest.fixture(scope='module')
+def wg_libs(tmp_path_factory, patched_csrc):
+    d = tmp_path_factory.mktemp('emu_wg')
+    return (_compile('emu_conv_wgrad.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so')),
+            _compile('emu_conv_wgrad.cpp', patched_csrc, str(d / 'patched.so')))
+
+
+WGRAD = [  # (B, Cin, Cout, F, T, KH, KW, unpool, bf16) -> the kernel conv_wgrad_launch picks
+    (1, 64, 64, 4, 64, 3, 3, False, 0),       # conv_wgrad_pc_kernel (bf16x3, producer / consumer, column walk): the largest item of a step
+    (2, 16, 16, 8, 100, 3, 3, True, 0),       # conv_wgrad_s16_kernel under a pool, ragged
+    (1, 32, 64, 4, 64, 3, 3, False, 0),       # conv_wgrad_wino_kernel (fp32 MFMA, Winograd domain)
+    (2, 64, 64, 4, 68, 3, 3, True, 1),        # conv_wgrad_bf16_kernel<3,3,..> (configs[2]; its loader reads seq_len: scalar_tile_loads.patch)
+    (2, 64, 64, 1, 200, 1, 3, False, 0),      # conv1d_wgrad_pc_kernel<3> (Conv1d k = 3)
+    (2, 96, 64, 1, 132, 1, 1, False, 0),      # conv_wgrad_bf16_kernel<1,1,2,3> (Conv1d k = 1 below 512 inputs, bf16x3)
+]
+
+
+@pytest.mark.parametrize('case', WGRAD, ids=lambda c: 'x'.join(str(int(v)) for v in c))
+def test_conv_weight_gradients_on_the_cpu_tree_vs_float64_and_patched_vs_tree(wg_libs, case):
+    b, cin, cout, f, t, kh, kw, unpool, bf16 = case
+    rng = np.random.RandomState(sum(int(v) for v in case) + 41)
+    x = rng.randn(b, cin, f, t).astype(np.float32)
+    scale = (rng.rand(cin) + .5).astype(np.float32)
+    shift = (rng.randn(cin) * .1).astype(np.float32)
+    seq = np.array([t] + [int(t * .7)] * (b - 1), np.int32)
+    fg = f // 2 if unpool else f
+    g = rng.randn(b, cout, fg, t).astype(np.float32)
+    uidx = (rng.rand(b, cout, fg, t) < .5).astype(np.uint8) if unpool else None
+    outs = []
+    for lib in wg_libs:
+        dw = np.zeros((cout, cin, kh, kw), np.float32)
+        db = np.zeros(cout, np.float32)
+        rc = lib.emu_conv_bwd_weight(P(x), P(scale), P(shift), 1, P(seq), P(g), P(uidx), P(dw), P(db), b, cin, cout, f, t, kh, kw, bf16)
+        assert rc == 0, lib.emu_last_error()
+        outs.append((dw, db))
+    (dw, db), (dw2, db2) = outs
+    xa = np.maximum(x.astype(np.float64) * scale[None, :, None, None] + shift[None, :, None, None], 0)
+    for i in range(b):
+        xa[i, :, :, seq[i]:] = 0
+    gu = g.astype(np.float64)
+    if unpool:
+        full = np.zeros((b, cout, f, t))
+        full[:, :, 0::2] = np.where(uidx == 0, gu, 0)
+        full[:, :, 1::2] = np.where(uidx == 1, gu, 0)
+        gu = full
+    xp = np.pad(xa, ((0, 0), (0, 0), (kh // 2, kh // 2), (kw // 2, kw // 2)))
+    ref = np.zeros((cout, cin, kh, kw))
+    for i in range(kh):
+        for j in range(kw):
+            ref[:, :, i, j] = np.einsum('boft,bcft->oc', gu, xp[:, :, i:i + f, j:j + t])
+    tol = 3e-2 if bf16 else 3e-5
+    assert np.abs(dw - ref).max() < tol * max(1., np.abs(ref).max())
+    assert np.abs(db - gu.sum((0, 2, 3))).max() < tol * max(1., np.abs(gu.sum((0, 2, 3))).max())
+    assert np.array_equal(_bits(dw2), _bits(dw))
+    assert np.array_equal(_bits(db2), _bits(db))
