@@ -4,7 +4,7 @@
 #include <cstdarg>
 
 namespace pbsed {
-alignas(16) unsigned char smem_raw[160 * 1024];          // the kernels' `extern __shared__ unsigned char smem_raw[]` (one block at a time)
+alignas(16) thread_local unsigned char smem_raw[160 * 1024];          // the kernels' `extern __shared__ unsigned char smem_raw[]` (one block at a time)
 }
 #include "conv_bf16.hip"
 

@@ -7,7 +7,7 @@
 #include <cstring>
 
 namespace pbsed {
-alignas(16) float smem[40 * 1024];
+alignas(16) thread_local float smem[40 * 1024];
 }
 #include "conv_wgrad.hip"
 

@@ -4,7 +4,7 @@
 #include <cstdarg>
 
 namespace pbsed {
-alignas(16) unsigned char smem_raw[160 * 1024];
+alignas(16) thread_local unsigned char smem_raw[160 * 1024];
 }
 #include "conv_winox3.hip"
 

@@ -4,7 +4,7 @@
 #include <cstdarg>
 
 namespace pbsed {
-alignas(16) float smem[40 * 1024];                        // the kernels' `extern __shared__ float smem[]`
+alignas(16) thread_local float smem[40 * 1024];                        // the kernels' `extern __shared__ float smem[]`
 }
 #include "logmel.hip"
 

@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sched.h>
 #include <ucontext.h>
 
 #include <algorithm>
@@ -21,7 +22,7 @@
 #define __global__
 #define __device__
 #define __host__
-#define __shared__
+#define __shared__ thread_local      /* one instance per OS thread = per block (the fibers of a block share their thread) */
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define HIP_EMU 1
@@ -67,10 +68,14 @@ struct Runtime {
     Wave wave[MAX_THREADS / WAVE];
     std::function<void()> body;
 };
-inline Runtime& rt() { static Runtime r; return r; }
+extern thread_local Runtime* tls_rt;
+inline Runtime& rt() {
+    if (!tls_rt) tls_rt = new Runtime();
+    return *tls_rt;
+}
 struct Idx { unsigned x, y, z; };
 }  // namespace hipemu
-extern hipemu::Idx threadIdx, blockIdx, blockDim, gridDim;
+extern thread_local hipemu::Idx threadIdx, blockIdx, blockDim, gridDim;
 
 namespace hipemu {
 inline void yield() { Runtime& r = rt(); swapcontext(&r.ctx[r.cur], &r.sched); }
@@ -92,8 +97,11 @@ inline void block_sync() {
 inline int lane() { return rt().cur % WAVE; }
 inline Wave& my_wave() { Runtime& r = rt(); return r.wave[r.cur / WAVE]; }
 void trampoline();
-// run `body` for every thread of every block of the grid (blocks sequentially, threads as fibers)
+// run `body` for every thread of every block of the grid: threads as fibers; blocks one after the other on the calling thread, or -
+// hipemu_set_concurrent(1), for PERSISTENT kernels whose blocks talk to each other through memory - every block on an OS thread of
+// its own, all at once (grids of at most 256 blocks)
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+extern int g_concurrent;
 }  // namespace hipemu
 
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) hipemu::launch((grid), (block), [=]() { kern(__VA_ARGS__); })
@@ -250,7 +258,16 @@ static inline void __builtin_amdgcn_raw_buffer_store_b8(unsigned char x, __amdgp
 static inline void __builtin_amdgcn_fence(int, const char*) {}
 static inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_sync(); }     // (the lanes of a wave run one after the other here: the kernels'
                                                                                  // "all lanes read, then all lanes write" points are real rendezvous)
-static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline void __builtin_amdgcn_s_sleep(int) { hipemu::yield(); if (hipemu::g_concurrent) sched_yield(); }     // a spin loop must let the producers run
 static inline void __builtin_amdgcn_s_setprio(int) {}
+#ifndef __HIP_MEMORY_SCOPE_AGENT          /* (__hip_atomic_load / _store are clang builtins on every target; the scope names are HIP-mode macros) */
+#define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#endif
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.f / x; }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
