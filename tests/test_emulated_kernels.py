@@ -645,3 +645,117 @@ def test_conv_weight_gradients_on_the_cpu_tree_vs_float64_and_patched_vs_tree(wg
     assert np.abs(db - gu.sum((0, 2, 3))).max() < tol * max(1., np.abs(gu.sum((0, 2, 3))).max())
     assert np.array_equal(_bits(dw2), _bits(dw))
     assert np.array_equal(_bits(db2), _bits(db))
+
+
+# ------------------------------------------------------------------------------------------------ gru_stack (the persistent scans, blocks concurrent)
+@pytest.fixture(scope='module')
+def gru_lib(tmp_path_factory):
+    lib = _compile('emu_gru_stack.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(tmp_path_factory.mktemp('emu_gru') / 'tree.so'))
+    lib.hipemu_set_concurrent(1)                 # every workgroup an OS thread: the rings and projection groups hand words to each other
+    return lib
+
+
+def _table(arrs):
+    return (C.c_void_p * len(arrs))(*[P(a) for a in arrs])
+
+
+def _gru_reference(gi0, w_ih, b_ih, w_hh, b_hh, rev, seq, dy_top):
+    """float64 forward + BPTT of nchains unidirectional stacks with the scans' masking (state and output 0 from seq_len on)."""
+    nch, nl = len(w_hh), len(w_hh[0])
+    t_, b_, h3 = gi0[0].shape
+    h_ = h3 // 3
+    sig = lambda v: 1 / (1 + np.exp(-v))
+    hs = [[None] * nl for _ in range(nch)]
+    keep = [[None] * nl for _ in range(nch)]
+    for c in range(nch):
+        below = None
+        for l in range(nl):
+            whh, bhh = w_hh[c][l].astype(np.float64), b_hh[c][l].astype(np.float64)
+            h = np.zeros((b_, h_))
+            out = np.zeros((t_, b_, h_))
+            rec = {}
+            for s in range(t_):
+                t = t_ - 1 - s if rev[c] else s
+                gi = gi0[c][t].astype(np.float64) if l == 0 else below[t] @ w_ih[c][l].astype(np.float64).T + b_ih[c][l]
+                gh = h @ whh.T + bhh
+                r, z = sig(gi[:, :h_] + gh[:, :h_]), sig(gi[:, h_:2 * h_] + gh[:, h_:2 * h_])
+                n = np.tanh(gi[:, 2 * h_:] + r * gh[:, 2 * h_:])
+                live = (t < seq)[:, None]
+                rec[t] = (r, z, n, gh[:, 2 * h_:], h, live)
+                h = np.where(live, (1 - z) * n + z * h, 0.)
+                out[t] = h
+            hs[c][l], keep[c][l], below = out, rec, out
+    dgi = [[None] * nl for _ in range(nch)]
+    dgh = [[None] * nl for _ in range(nch)]
+    for c in range(nch):
+        dy = dy_top[c].astype(np.float64)
+        for l in reversed(range(nl)):
+            whh = w_hh[c][l].astype(np.float64)
+            gi_g, gh_g = np.zeros((t_, b_, 3 * h_)), np.zeros((t_, b_, 3 * h_))
+            carry = np.zeros((b_, h_))
+            for s in reversed(range(t_)):
+                t = t_ - 1 - s if rev[c] else s
+                r, z, n, ghn, hp, live = keep[c][l][t]
+                dh = np.where(live, dy[t] + carry, 0.)
+                dn = dh * (1 - z) * (1 - n * n)
+                dz = dh * (hp - n) * z * (1 - z)
+                dr = dn * ghn * r * (1 - r)
+                gi_g[t] = np.concatenate([dr, dz, dn], 1)
+                gh_g[t] = np.concatenate([dr, dz, dn * r], 1)
+                carry = gh_g[t] @ whh + dh * z
+            dgi[c][l], dgh[c][l] = gi_g, gh_g
+            if l > 0:
+                dy = gi_g @ w_ih[c][l].astype(np.float64)
+    return hs, dgi, dgh
+
+
+@pytest.mark.parametrize('case', [(2, 2, 5, 64, 10), (2, 1, 20, 64, 9)], ids=['two_2layer_stacks_ragged', 'bigru_layer_two_batch_tiles'])
+def test_persistent_scans_on_the_cpu_forward_and_bptt_vs_float64(gru_lib, case):
+    """The persistent forward scan and BPTT of csrc/gru_stack.hip with every workgroup on its own OS thread (rings + projection
+    groups: 40 resp. 32 workgroups of 512 fibers): the tagged-word exchange - publish, paced polls, parity, time-out word - runs for
+    real.  Two forward calls on ONE workspace (the parity flips: the first call's words must never satisfy the second call's
+    polls), then BPTT from the second call's saved factors, against a float64 GRU.  (The host's memory model is stronger than the
+    GPU's: this checks the protocol's logic and the arithmetic; the index maps are enumerated exhaustively by test_scan_protocol.)"""
+    nch, nl, b, h, t = case
+    rng = np.random.RandomState(sum(case))
+    seq = np.sort(rng.randint(max(t - 5, 1), t + 1, b))[::-1].astype(np.int32).copy()
+    seq[0] = t
+    rev = np.array([c & 1 for c in range(nch)], np.int32)
+    k = 1 / np.sqrt(h)
+    u = lambda *s: rng.uniform(-k, k, s).astype(np.float32)
+    w_ih = [[None if l == 0 else u(3 * h, h) for l in range(nl)] for _ in range(nch)]
+    b_ih = [[None if l == 0 else u(3 * h) for l in range(nl)] for _ in range(nch)]
+    w_hh = [[u(3 * h, h) for _ in range(nl)] for _ in range(nch)]
+    b_hh = [[u(3 * h) for _ in range(nl)] for _ in range(nch)]
+    flat = lambda m: [m[c][l] for c in range(nch) for l in range(nl)]
+    bp = (b + 15) // 16 * 16
+    gran = np.zeros(nch * t * bp * h * (nl + 3 * (nl - 1)), np.uint32)
+    err = np.zeros(1, np.uint32)
+    for epoch in (1, 2):                         # odd on the first use of a workspace, then alternating
+        gi0 = [(rng.randn(t, b, 3 * h) * .5).astype(np.float32) for _ in range(nch)]
+        hs = [[np.full((t, b, h), np.nan, np.float32) for _ in range(nl)] for _ in range(nch)]
+        save = [[np.full((t, b, 5 * h), np.nan, np.float32) for _ in range(nl)] for _ in range(nch)]
+        rc = gru_lib.pbsed_gru_stack_fwd_granule(nch, nl, _table(gi0), _table(flat(w_ih)), _table(flat(b_ih)), _table(flat(w_hh)),
+                                                 _table(flat(b_hh)), _table(flat(hs)), _table(flat(save)), P(rev), P(seq), b, h, t,
+                                                 P(gran), epoch, P(err), None)
+        assert rc == 0 and err[0] == 0, (rc, err[0])
+        dy_top = [rng.randn(t, b, h).astype(np.float32) for _ in range(nch)]
+        ref_hs, ref_dgi, ref_dgh = _gru_reference(gi0, w_ih, b_ih, w_hh, b_hh, rev, seq, dy_top)
+        for c in range(nch):
+            for l in range(nl):
+                assert np.abs(hs[c][l] - ref_hs[c][l]).max() < 2e-6, (epoch, c, l)
+    # BPTT from the second call's saved factors
+    w_hh_t = [[np.ascontiguousarray(w_hh[c][l].T) for l in range(nl)] for c in range(nch)]
+    w_ih_up_t = [[np.ascontiguousarray(w_ih[c][l + 1].T) if l + 1 < nl else None for l in range(nl)] for c in range(nch)]
+    dgi = [[np.full((t, b, 3 * h), np.nan, np.float32) for _ in range(nl)] for _ in range(nch)]
+    dgh = [[np.full((t, b, 3 * h), np.nan, np.float32) for _ in range(nl)] for _ in range(nch)]
+    gran_b = np.zeros(nch * t * bp * h * (2 * nl - 1), np.uint32)
+    rc = gru_lib.pbsed_gru_stack_bwd_granule(nch, nl, _table(flat(w_hh_t)), _table(flat(w_ih_up_t)), _table(flat(hs)), _table(flat(save)),
+                                             _table(dy_top), _table(flat(dgi)), _table(flat(dgh)), P(rev), P(seq), b, h, t, P(gran_b), 1,
+                                             P(err), None)
+    assert rc == 0 and err[0] == 0, (rc, err[0])
+    for c in range(nch):
+        for l in range(nl):
+            scale = max(1., np.abs(ref_dgi[c][l]).max())
+            assert np.abs(dgi[c][l] - ref_dgi[c][l]).max() < 1e-5 * scale, (c, l)
+            assert np.abs(dgh[c][l] - ref_dgh[c][l]).max() < 1e-5 * scale, (c, l)
