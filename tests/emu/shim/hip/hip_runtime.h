@@ -123,6 +123,7 @@ static inline float min(float a, float b) { return fminf(a, b); }
 static inline float max(float a, float b) { return fmaxf(a, b); }
 static inline double atomicAdd(double* p, double v) { const double o = *p; *p = o + v; return o; }      // (one OS thread: fibers)
 static inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
+static inline float unsafeAtomicAdd(float* p, float v) { return atomicAdd(p, v); }
 
 // ------------------------------------------------------------------------------------------------ cross-lane operations
 template <class T> static inline T __shfl(T v, int src) {

@@ -759,3 +759,49 @@ def test_persistent_scans_on_the_cpu_forward_and_bptt_vs_float64(gru_lib, case):
             scale = max(1., np.abs(ref_dgi[c][l]).max())
             assert np.abs(dgi[c][l] - ref_dgi[c][l]).max() < 1e-5 * scale, (c, l)
             assert np.abs(dgh[c][l] - ref_dgh[c][l]).max() < 1e-5 * scale, (c, l)
+
+
+# ------------------------------------------------------------------------------------------------ tm_gemm / gru_wgrad (the products around the scans)
+@pytest.fixture(scope='module')
+def rg_lib(tmp_path_factory):
+    return _compile('emu_rnn_gemms.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(tmp_path_factory.mktemp('emu_rg') / 'tree.so'))
+
+
+@pytest.mark.parametrize('bf16', [0, 1], ids=['bf16x3', 'bf16'])
+def test_time_major_projection_on_the_cpu_vs_float64(rg_lib, bf16):
+    """pbsed_tm_gemm: y [R, N] = bias + sum_i x_i [R, k_i] w_i [N, k_i]^T - the input projection of a BiGRU layer from both directions
+    of the layer below (two sources, nothing concatenated), R no multiple of the 128-row block, N no multiple of 128."""
+    rng = np.random.RandomState(5 + bf16)
+    r, n, ks = 200, 192, [64, 96]
+    xs = [rng.randn(r, k).astype(np.float32) for k in ks]
+    ws = [(rng.randn(n, k) * .1).astype(np.float32) for k in ks]
+    bias = rng.randn(n).astype(np.float32)
+    y = np.full((r, n), np.nan, np.float32)
+    rc = rg_lib.pbsed_tm_gemm(2, _table(xs), _table(ws), P(np.array(ks, np.int32)), P(bias), P(y), r, n, bf16, None)
+    assert rc == 0, rg_lib.emu_last_error()
+    ref = bias[None] + sum(x.astype(np.float64) @ w.astype(np.float64).T for x, w in zip(xs, ws))
+    assert np.abs(y - ref).max() < (3e-2 if bf16 else 2e-5) * max(1., np.abs(ref).max())
+
+
+def test_gru_weight_gradients_on_the_cpu_vs_float64(rg_lib):
+    """pbsed_gru_wgrad_multi: dW_hh (x = the layer's own states one step back: shift -1 forward chain, +1 reversed chain, rows outside
+    [0, T) zero), dW_ih (shift 0, another input width in the same launch), db - straight from time-major buffers."""
+    rng = np.random.RandomState(9)
+    t, b, h, kin = 12, 5, 64, 96
+    g3 = 3 * h
+    dg = [(rng.randn(t, b, g3) * .3).astype(np.float32) for _ in range(3)]
+    xs = [rng.randn(t, b, h).astype(np.float32), rng.randn(t, b, h).astype(np.float32), rng.randn(t, b, kin).astype(np.float32)]
+    shift = np.array([-1, 1, 0], np.int32)
+    ks = np.array([h, h, kin], np.int32)
+    dws = [np.zeros((g3, k), np.float32) for k in ks]
+    dbs = [np.zeros(g3, np.float32) for _ in ks]
+    rc = rg_lib.pbsed_gru_wgrad_multi(3, _table(dg), _table(xs), P(shift), _table(dws), _table(dbs), t, b, g3, P(ks), 0, None)
+    assert rc == 0, rg_lib.emu_last_error()
+    for i in range(3):
+        xsft = np.zeros_like(xs[i], dtype=np.float64)
+        for tt in range(t):
+            if 0 <= tt + shift[i] < t:
+                xsft[tt] = xs[i][tt + shift[i]]
+        ref = np.einsum('tbg,tbk->gk', dg[i].astype(np.float64), xsft)
+        assert np.abs(dws[i] - ref).max() < 3e-5 * max(1., np.abs(ref).max()), i
+        assert np.abs(dbs[i] - dg[i].astype(np.float64).sum((0, 1))).max() < 3e-5 * max(1., np.abs(dg[i].sum((0, 1))).max()), i
