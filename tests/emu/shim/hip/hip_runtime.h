@@ -47,6 +47,8 @@ static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s_, size_t n, int, hipStream_t) { memcpy(d, s_, n); return hipSuccess; }
 template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 1; return hipSuccess; }
 
 // ------------------------------------------------------------------------------------------------ the fiber runtime
@@ -113,6 +115,8 @@ static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); re
 static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
 static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
 #define __expf(x) expf(x)
+static inline float rsqrtf(float x) { return 1.f / sqrtf(x); }
+static inline double rsqrt(double x) { return 1. / sqrt(x); }
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }

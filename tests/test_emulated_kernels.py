@@ -805,3 +805,153 @@ def test_gru_weight_gradients_on_the_cpu_vs_float64(rg_lib):
         ref = np.einsum('tbg,tbk->gk', dg[i].astype(np.float64), xsft)
         assert np.abs(dws[i] - ref).max() < 3e-5 * max(1., np.abs(ref).max()), i
         assert np.abs(dbs[i] - dg[i].astype(np.float64).sum((0, 1))).max() < 3e-5 * max(1., np.abs(dg[i].sum((0, 1))).max()), i
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# misc.hip (losses, optimiser) and postproc.hip (filters, event extraction): the reference-pinned golden vectors of the GPU tests
+# (tests/test_gpu_ops.py, tests/test_gpu_postproc.py), through the same kernels, on the CPU.  Reference: pb_sed/models/weak_label/
+# crnn.py:214-300 (fwd_bwd loss), pb_sed/models/strong_label/crnn.py:94-112, pb_sed/models/base/inference.py:229-283 (filters).
+@pytest.fixture(scope='module')
+def misc_lib(tmp_path_factory):
+    d = tmp_path_factory.mktemp('emu_misc')
+    return _compile('emu_misc.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so'))
+
+
+@pytest.fixture(scope='module')
+def pp_lib(tmp_path_factory):
+    d = tmp_path_factory.mktemp('emu_pp')
+    return _compile('emu_postproc.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so'))
+
+
+F = C.c_float
+
+
+@pytest.mark.parametrize('name', ['ragged_strong', 'full_len', 'no_bwd', 'slat', 'weak_only', 'half_weight_smooth', 'class_weights'])
+def test_fbcrnn_loss_kernel_on_the_cpu_vs_reference_golden(misc_lib, golden, name):
+    import ast
+    g = golden('ref_fbcrnn_loss.npz')
+    kw = ast.literal_eval(str(g[f'{name}/kw']))
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    yf = f32(g[f'{name}/y_fwd'])
+    yb = f32(g[f'{name}/y_bwd']) if f'{name}/y_bwd' in g else None
+    weak, bnd = f32(g[f'{name}/weak_targets']), f32(g[f'{name}/boundary_targets'])
+    cw = f32(kw['class_weights']) if 'class_weights' in kw else None
+    seq = np.ascontiguousarray(g[f'{name}/seq_len'], dtype=np.int32)
+    b, k, t = yf.shape
+    o_f, o_b, d_f, d_b = (np.full_like(yf, np.nan) for _ in range(4))
+    loss = np.full(1, np.nan, np.float32)
+    summary = np.full(3 * b * k + 1, np.nan, np.float32)
+    rc = misc_lib.pbsed_fbcrnn_loss(P(yf), P(yb), P(weak), P(bnd), P(cw), P(seq), P(o_f), P(o_b if yb is not None else None),
+                                    P(d_f), P(d_b if yb is not None else None), P(loss), b, k, t, F(1e-5),
+                                    F(kw.get('strong_fwd_bwd_loss_weight', 1.)), int(kw.get('slat', False)),
+                                    F(kw.get('label_smoothing', 0.)), 1, P(summary), None)
+    assert rc == 0
+    assert loss[0] == pytest.approx(float(g[f'{name}/loss']), rel=2e-5)
+    np.testing.assert_allclose(d_f, g[f'{name}/grad_y_fwd'], atol=1e-6, rtol=2e-4)
+    if yb is not None:
+        np.testing.assert_allclose(d_b, g[f'{name}/grad_y_bwd'], atol=1e-6, rtol=2e-4)
+    assert np.isfinite(summary).all()
+
+
+@pytest.mark.parametrize('name', ['a', 'b'])
+def test_bicrnn_loss_kernel_on_the_cpu_vs_reference_golden(misc_lib, golden, name):
+    g = golden('ref_bicrnn_loss.npz')
+    y = np.ascontiguousarray(g[f'{name}/y'], dtype=np.float32)
+    tg = np.ascontiguousarray(g[f'{name}/strong_targets'], dtype=np.float32)
+    seq = np.ascontiguousarray(g[f'{name}/seq_len'], dtype=np.int32)
+    b, k, t = y.shape
+    o, d = np.full_like(y, np.nan), np.full_like(y, np.nan)
+    loss, scratch = np.full(1, np.nan, np.float32), np.zeros(1, np.float64)
+    assert misc_lib.pbsed_bicrnn_loss(P(y), P(tg), P(seq), P(o), P(d), P(loss), P(scratch), b, k, t, 1, None) == 0
+    assert loss[0] == pytest.approx(float(g[f'{name}/loss']), rel=2e-5)
+    np.testing.assert_allclose(d, g[f'{name}/grad_y'], atol=1e-7, rtol=2e-4)
+
+
+def test_adam_and_the_gradient_norm_on_the_cpu_vs_float64(misc_lib):
+    """padertorch's Adam(lr, gradient_clipping) (pb_sed/experiments/weak_label_crnn/training.py:264-269) restated in float64:
+    clip by the global norm, then torch.optim.Adam's update; three steps, an odd length (tail lanes), a skip flag at the end."""
+    rng = np.random.default_rng(3)
+    n = 10007
+    p = rng.standard_normal(n).astype(np.float32)
+    m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    pr, mr, vr = p.astype(np.float64), np.zeros(n), np.zeros(n)
+    lr, b1, b2, eps, max_norm = 5e-4, .9, .999, 1e-8, 5.
+    ss, norm = np.zeros(1, np.float64), np.zeros(1, np.float32)
+    for step, s in enumerate((1., .1, 3.), 1):
+        g = (rng.standard_normal(n) * s).astype(np.float32)
+        ref_norm = np.sqrt((g.astype(np.float64) ** 2).sum())
+        gc = g.astype(np.float64) * min(1., max_norm / (ref_norm + 1e-6))
+        mr = b1 * mr + (1 - b1) * gc
+        vr = b2 * vr + (1 - b2) * gc * gc
+        pr = pr - lr / (1 - b1 ** step) * mr / (np.sqrt(vr / (1 - b2 ** step)) + eps)
+        ss[0] = 0.
+        assert misc_lib.pbsed_grad_sumsq(P(g), C.c_size_t(n), P(ss), None) == 0
+        assert ss[0] == pytest.approx(ref_norm ** 2, rel=1e-12)
+        assert misc_lib.pbsed_adam_step(P(p), P(g), P(m), P(v), C.c_size_t(n), F(lr), F(b1), F(b2), F(eps), step, F(1.), F(max_norm),
+                                        P(ss), P(norm), None, 0, None) == 0
+        assert norm[0] == pytest.approx(ref_norm, rel=1e-6)
+    np.testing.assert_allclose(p, pr, atol=1e-6, rtol=1e-5)
+    before = p.copy(), m.copy(), v.copy()
+    flags = np.array([0, 3], np.int32)                                   # a scan of this step raised its error word
+    assert misc_lib.pbsed_adam_step(P(p), P(g), P(m), P(v), C.c_size_t(n), F(lr), F(b1), F(b2), F(eps), 4, F(1.), F(max_norm),
+                                    P(ss), P(norm), P(flags), 2, None) == 0
+    for a, bfr in zip((p, m, v), before):
+        np.testing.assert_array_equal(a, bfr)
+
+
+def _rows_n(x, per_row):
+    return np.ascontiguousarray(np.broadcast_to(np.asarray(per_row), x.shape[:-1]).reshape(-1), dtype=np.int32)
+
+
+def _medfilt(lib, x, n):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.full_like(x, np.nan)
+    nr = _rows_n(x, n)
+    assert lib.pbsed_medfilt(P(x), P(out), P(nr), nr.size, x.shape[-1], None) == 0
+    return out
+
+
+def test_median_filters_on_the_cpu_bit_exact_vs_reference_golden(pp_lib, golden):
+    """scipy.signal.medfilt as the reference calls it (pb_sed/models/base/inference.py:229-251), incl. per-row lengths and the
+    long filters of the tuning range (bisection-select kernel)."""
+    g = golden('ref_filters.npz')
+    for n in (1, 3, 5, 11, 41, 101):
+        np.testing.assert_array_equal(_medfilt(pp_lib, g['x'], n), g[f'medfilt_{n}'])
+    np.testing.assert_array_equal(_medfilt(pp_lib, g['x'], g['len_1d']), g['filtering_med_1d'])
+    for n in (5, 151, 301):
+        np.testing.assert_array_equal(_medfilt(pp_lib, g['x_long'], n), g[f'medfilt_long_{n}'])
+
+
+def test_boundaries_filter_on_the_cpu_vs_reference_golden(pp_lib, golden):
+    g = golden('ref_filters.npz')
+    x = np.ascontiguousarray(g['x'], dtype=np.float32)
+
+    def run(n, f64):
+        out, out64 = np.full_like(x, np.nan), np.full(x.shape, np.nan)
+        nr = _rows_n(x, n)
+        assert pp_lib.pbsed_boundariesfilt(P(x), P(out), P(out64 if f64 else None), P(nr), nr.size, x.shape[-1], None) == 0
+        return out64 if f64 else out
+    np.testing.assert_array_equal(run(0, False), g['boundariesfilt_0'])
+    for n in (2, 6, 20):
+        np.testing.assert_allclose(run(n, True), g[f'boundariesfilt_{n}'], rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(run(g['steplen_1d'], False), g['filtering_bnd_1d'])
+
+
+def test_event_frames_on_the_cpu_vs_a_plain_scan(pp_lib):
+    """Onsets / offsets of (score > threshold) per class row (pb_sed/models/base/inference.py scores_to_event_list via
+    sed_scores_eval's thresholding): events running to the row's end, empty rows, single frames, rows shorter than T."""
+    rng = np.random.default_rng(5)
+    r, t = 9, 70
+    x = rng.random((r, t)).astype(np.float32)
+    x[6] = 1.
+    x[7] = 0.
+    thr = np.array([.5, .3, .9, .1, .7, .5, .5, .5, .99], np.float32)
+    ln = np.array([70, 37, 1, 64, 70, 2, 20, 20, 70], np.int32)
+    mx = t // 2 + 1
+    ev, cnt = np.zeros((r, mx, 2), np.int32), np.zeros(r, np.int32)
+    assert pp_lib.pbsed_event_frames(P(x), P(thr), P(ln), P(ev), P(cnt), r, t, mx, None) == 0
+    for i in range(r):
+        act = np.concatenate([[False], x[i, :ln[i]] > thr[i], [False]])
+        on, off = np.flatnonzero(act[1:] & ~act[:-1]), np.flatnonzero(~act[1:] & act[:-1])
+        assert cnt[i] == len(on), i
+        np.testing.assert_array_equal(ev[i, :len(on)], np.stack([on, off], 1).reshape(-1, 2))
