@@ -5,6 +5,34 @@
 
 thread_local hipemu::Idx threadIdx, blockIdx, blockDim, gridDim;
 
+#if !defined(__x86_64__)
+#error "hipemu_switch is written for x86-64 (System V)"
+#endif
+// rbx, rbp, r12-r15 and the return address live on the stack being left; a new fiber's stack is laid out as if it had called this
+asm(R"(
+    .text
+    .globl hipemu_switch
+    .hidden hipemu_switch
+    .type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch, .-hipemu_switch
+)");
+
 namespace hipemu {
 thread_local Runtime* tls_rt = nullptr;
 int g_concurrent = 0;
@@ -15,7 +43,8 @@ void trampoline() {
     r.done[r.cur] = true;
     --r.active;                                   // a returned thread no longer takes part in the block's barriers (producer waves leave early)
     if (r.active > 0 && r.blk_arrived >= r.active) { r.blk_arrived = 0; ++r.blk_gen; }
-    swapcontext(&r.ctx[r.cur], &r.sched);
+    hipemu_switch(&r.sp[r.cur], r.sched_sp);       // for good: a finished fiber is never switched to again
+    abort();
 }
 
 // all threads of ONE block as fibers of the calling OS thread
@@ -32,11 +61,11 @@ static void run_block(dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned 
     r.active = n;
     for (auto& w : r.wave) w.arrived = 0;
     for (int i = 0; i < n; ++i) {
-        getcontext(&r.ctx[i]);
-        r.ctx[i].uc_stack.ss_sp = r.stack[i];
-        r.ctx[i].uc_stack.ss_size = stack_bytes;
-        r.ctx[i].uc_link = &r.sched;
-        makecontext(&r.ctx[i], (void (*)())trampoline, 0);
+        void** top = (void**)(((uintptr_t)r.stack[i] + stack_bytes) & ~(uintptr_t)15);
+        top[-1] = nullptr;                            // (where trampoline's caller would have left its return address: rsp = 8 mod 16 on entry)
+        top[-2] = (void*)&trampoline;                 // hipemu_switch's `ret`
+        for (int k = 3; k <= 8; ++k) top[-k] = nullptr;        // rbp, rbx, r12-r15
+        r.sp[i] = (void*)(top - 8);
         r.done[i] = false;
     }
     int left = n;
@@ -46,7 +75,7 @@ static void run_block(dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned 
             r.cur = i;
             blockIdx = Idx{bx, by, bz};
             threadIdx = Idx{(unsigned)i % block.x, ((unsigned)i / block.x) % block.y, (unsigned)i / (block.x * block.y)};
-            swapcontext(&r.sched, &r.ctx[i]);
+            hipemu_switch(&r.sched_sp, r.sp[i]);
             if (r.done[i]) --left;
         }
     }

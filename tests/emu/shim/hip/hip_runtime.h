@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE: a minimal HOST stand-in for <hip/hip_runtime.h> that lets a kernel translation unit of pb_sed_amd/csrc be compiled
 // for x86 and EXECUTED on the CPU, lane by lane (tests/test_emulated_kernels.py).  Every HIP thread of a block is a fiber
-// (ucontext) of one OS thread; cross-lane instructions (MFMA, DPP, shuffles, readfirstlane) and __syncthreads are rendezvous
+// (a stack each, switched by hipemu_switch) of one OS thread; cross-lane instructions (MFMA, DPP, shuffles, readfirstlane) and __syncthreads are rendezvous
 // points of the wave's / the block's fibers, so the semantics are those of the hardware as long as cross-lane operations sit in
 // wave-uniform control flow (they do in these kernels).  Blocks run one after the other.  The amdgcn builtins the kernels call
 // are ordinary functions here.  What this is for: functional equivalence of kernel CHANGES without a GPU (same emulator, two
@@ -13,7 +13,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sched.h>
-#include <ucontext.h>
 
 #include <algorithm>
 #include <functional>
@@ -49,6 +48,14 @@ static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s_, size_t n, int, hipStream_t) { memcpy(d, s_, n); return hipSuccess; }
+#ifndef HIPEMU_CUS
+#define HIPEMU_CUS 8
+#endif
+struct hipDeviceProp_t { int multiProcessorCount = HIPEMU_CUS; };
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t{}; return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)malloc(n); return *p ? hipSuccess : 2; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 1; return hipSuccess; }
 
 // ------------------------------------------------------------------------------------------------ the fiber runtime
@@ -60,8 +67,8 @@ struct Wave {
     alignas(16) unsigned char slot[WAVE][64];       // exchange area: up to 64 bytes per lane and rendezvous
 };
 struct Runtime {
-    ucontext_t sched;
-    ucontext_t ctx[MAX_THREADS];
+    void* sched_sp = nullptr;                        // saved stack pointers (hipemu_switch): the scheduler's and one per fiber
+    void* sp[MAX_THREADS];
     char* stack[MAX_THREADS] = {nullptr};
     bool done[MAX_THREADS];
     int cur = 0, nthreads = 0, active = 0;   // active: fibers of the block that have not returned (s_barrier counts live waves only)
@@ -80,7 +87,12 @@ struct Idx { unsigned x, y, z; };
 extern thread_local hipemu::Idx threadIdx, blockIdx, blockDim, gridDim;
 
 namespace hipemu {
-inline void yield() { Runtime& r = rt(); swapcontext(&r.ctx[r.cur], &r.sched); }
+}  // namespace hipemu
+// the context switch (hipemu_runtime.cpp): callee-saved registers onto the current stack, its pointer to *save, continue on `load`.
+// (swapcontext costs a sigprocmask system call per switch - the emulator spent nearly all of its time there.)
+extern "C" void hipemu_switch(void** save, void* load);
+namespace hipemu {
+inline void yield() { Runtime& r = rt(); hipemu_switch(&r.sp[r.cur], r.sched_sp); }
 // rendezvous of the 64 lanes of the calling fiber's wave (every lane of a wave must call it: wave-uniform control flow)
 inline void wave_sync() {
     Runtime& r = rt();
