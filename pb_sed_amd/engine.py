@@ -148,6 +148,10 @@ def _side_stream(device):
     return _SIDE_STREAMS[idx]
 
 
+def _has_streams(t):
+    return t.is_cuda
+
+
 class _DeferredLaunches(list):
     """Weight-gradient launches collected during a stack_backward (closures over live tensors: they keep their operands alive
     until ``run`` has enqueued them and the main stream has joined the side stream)."""
@@ -490,7 +494,7 @@ def _stack_rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     _, chains, (h, pcs0, hs, save, precision, h_tbc), head_ctx = ctx
     nl = wrappers[0].num_layers
     dy_top = []
-    defer = _DeferredLaunches() if (SIDE_WGRAD and DECISION_TAP is None and dlogits[0].is_cuda) else None
+    defer = _DeferredLaunches() if (SIDE_WGRAD and DECISION_TAP is None and _has_streams(dlogits[0])) else None
     for wi, w in enumerate(wrappers):
         layers, c = head_ctx[wi]
         d = stack_backward(layers, c, dlogits[wi], seq_dev, seq_host, True, defer=defer)
@@ -621,7 +625,7 @@ def rnn_backward(wrappers, ctx, dlogits, seq_dev, seq_host):
     # SIDE_WGRAD: leaves of the backward graph run on a second stream beside the NEXT persistent scan (a one-layer BiGRU scan
     # occupies 64 of the 256 CUs): the heads' weight gradients beside the top layer's scan, a layer's GRU weight gradients
     # beside the scan of the layer below; the bottom layer's follow on the main stream as before
-    beside = SIDE_WGRAD and DECISION_TAP is None and dlogits[0].is_cuda and _scan_as_stack(wrappers)
+    beside = SIDE_WGRAD and DECISION_TAP is None and _has_streams(dlogits[0]) and _scan_as_stack(wrappers)
     defer = _DeferredLaunches() if beside else None
     side, held = None, []
     for wi, w in enumerate(wrappers):

@@ -23,12 +23,13 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CLANG = '/opt/rocm/lib/llvm/bin/clang++'
+OPT = os.environ.get('PBSED_EMU_OPT', '-O0').split()
 UNITS = ('api', 'conv_s16', 'conv_winox3', 'conv_wino', 'conv_bf16', 'conv1d_pc', 'logmel', 'gru', 'gru_stack', 'rnn_gemms', 'postproc')
 
 
 def compile_unit(unit, csrc, out, defines=()):
     # -O0: the units are template-heavy (tens of seconds each at -O1, seconds at -O0) and the emulated launches are small
-    subprocess.run([CLANG, '-x', 'c++', '-std=c++20', '-O0', '-fPIC', '-shared', '-w', *[f'-D{d}' for d in defines],
+    subprocess.run([CLANG, '-x', 'c++', '-std=c++20', *OPT, '-fPIC', '-shared', '-w', *[f'-D{d}' for d in defines],
                     '-I', os.path.join(HERE, 'shim'), '-I', csrc, os.path.join(HERE, f'emu_{unit}.cpp'),
                     os.path.join(HERE, 'hipemu_runtime.cpp'), '-o', out], check=True)
     return out

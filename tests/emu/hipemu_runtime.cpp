@@ -67,11 +67,13 @@ static void run_block(dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned 
         for (int k = 3; k <= 8; ++k) top[-k] = nullptr;        // rbp, rbx, r12-r15
         r.sp[i] = (void*)(top - 8);
         r.done[i] = false;
+        r.wait_word[i] = nullptr;
     }
     int left = n;
     while (left > 0) {
         for (int i = 0; i < n; ++i) {
             if (r.done[i]) continue;
+            if (r.wait_word[i] && *r.wait_word[i] == r.wait_val[i]) continue;
             r.cur = i;
             blockIdx = Idx{bx, by, bz};
             threadIdx = Idx{(unsigned)i % block.x, ((unsigned)i / block.x) % block.y, (unsigned)i / (block.x * block.y)};

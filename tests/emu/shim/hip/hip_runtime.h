@@ -69,6 +69,10 @@ struct Wave {
 struct Runtime {
     void* sched_sp = nullptr;                        // saved stack pointers (hipemu_switch): the scheduler's and one per fiber
     void* sp[MAX_THREADS];
+    // a fiber parked at a rendezvous names the generation word it waits on: the scheduler passes it over until that word moves
+    // (instead of switching to it only for it to look and yield again)
+    const volatile unsigned* wait_word[MAX_THREADS] = {nullptr};
+    unsigned wait_val[MAX_THREADS];
     char* stack[MAX_THREADS] = {nullptr};
     bool done[MAX_THREADS];
     int cur = 0, nthreads = 0, active = 0;   // active: fibers of the block that have not returned (s_barrier counts live waves only)
@@ -93,6 +97,14 @@ namespace hipemu {
 extern "C" void hipemu_switch(void** save, void* load);
 namespace hipemu {
 inline void yield() { Runtime& r = rt(); hipemu_switch(&r.sp[r.cur], r.sched_sp); }
+inline void park(const volatile unsigned* word, unsigned val) {
+    Runtime& r = rt();
+    const int me = r.cur;
+    r.wait_word[me] = word;
+    r.wait_val[me] = val;
+    while (*word == val) hipemu_switch(&r.sp[me], r.sched_sp);
+    r.wait_word[me] = nullptr;
+}
 // rendezvous of the 64 lanes of the calling fiber's wave (every lane of a wave must call it: wave-uniform control flow)
 inline void wave_sync() {
     Runtime& r = rt();
@@ -100,13 +112,13 @@ inline void wave_sync() {
     const int lanes = std::min(WAVE, r.nthreads - (r.cur / WAVE) * WAVE);
     const unsigned g = w.gen;
     if (++w.arrived == lanes) { w.arrived = 0; ++w.gen; return; }
-    while (w.gen == g) yield();
+    park(&w.gen, g);
 }
 inline void block_sync() {
     Runtime& r = rt();
     const unsigned g = r.blk_gen;
     if (++r.blk_arrived >= r.active) { r.blk_arrived = 0; ++r.blk_gen; return; }
-    while (r.blk_gen == g) yield();
+    park(&r.blk_gen, g);
 }
 inline int lane() { return rt().cur % WAVE; }
 inline Wave& my_wave() { Runtime& r = rt(); return r.wave[r.cur / WAVE]; }

@@ -1,0 +1,202 @@
+"""The WHOLE product path on the CPU: pb_sed_amd's models, engine and trainer - unchanged - over the C-ABI, with every kernel of
+``csrc/`` executed by the emulator of tests/emu (tests/emu/cpu_device.py: HIP threads as fibers, MFMA / DPP / barriers as rendezvous
+points, the persistent scans' workgroups as OS threads).  These are the GPU parity tests of tests/test_gpu_model.py in miniature
+(same oracle, same tolerances), run where no GPU is: they pin the arithmetic of the device code and the launch sequence of the host
+side, not timing and not the GPU's memory model.
+
+Reference path: pb_sed/models/weak_label/crnn.py:80-300 (FBCRNN forward / review), pb_sed/models/strong_label/crnn.py:60-136.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.emu import cpu_device
+from tests.test_gpu_model import TINY, _copy_weights, rel_close, synth_batch
+
+pytestmark = pytest.mark.skipif(not os.path.exists(cpu_device.CLANG), reason='needs the ROCm clang++ (ext_vector_type, __bf16)')
+
+
+@pytest.fixture(scope='module')
+def library(tmp_path_factory):
+    return cpu_device.EmulatedLibrary(tmp_path_factory.mktemp('emu_whole'))
+
+
+@pytest.fixture
+def device(monkeypatch, library):
+    with cpu_device.emulated_device(monkeypatch, library):
+        library.calls.clear()
+        yield library
+
+
+def _nontrivial_norms(ref):
+    with torch.no_grad():
+        for name, p in ref.named_parameters():
+            if name.endswith('gamma'):
+                p.uniform_(.7, 1.3)
+            elif name.endswith('beta') or name.endswith('conv.bias'):
+                p.normal_(0, .1)
+        ref.feature_extractor.mean.fill_(-7.)
+        ref.feature_extractor.inv_std.fill_(.4)
+
+
+def test_fbcrnn_train_step_on_the_cpu_follows_the_oracle(device):
+    """tests/test_gpu_model.py::test_fbcrnn_train_step_parity[tiny_ragged] at B = 3, 0.5 s clips, 64 mel bands: features, both directions' scores,
+    the loss, the review summary, every parameter gradient (against the float64 oracle, bar = the fp32 oracle's own error) and the
+    running statistics."""
+    from oracle import frontend as ofe, models as om
+    from pb_sed_amd.models import weak_label
+    torch.manual_seed(0)
+    kw = dict(num_events=10, number_of_filters=64, hidden_size=64, num_layers=2, net=dict(TINY))
+    ref = om.FBCRNN.build(**kw)
+    _nontrivial_norms(ref)
+    model = weak_label.CRNN.build(**kw)
+    _copy_weights(model, ref)
+    wav, seq, weak, bnd, t = synth_batch(3, 8000, 10)
+    ref.train()
+    inputs_ref = {'stft': ofe.stft(wav), 'seq_len': seq.tolist(), 'weak_targets': weak, 'boundary_targets': bnd}
+    out_ref = ref(inputs_ref)
+    rev_ref = ref.review(inputs_ref, out_ref)
+    rev_ref['loss'].backward()
+    ref64 = copy.deepcopy(ref).double()
+    for m_ in ref64.modules():
+        if hasattr(m_, 'running_mean'):
+            m_.running_mean.zero_(), m_.running_power.fill_(1.)
+    in64 = {'stft': ofe.stft(wav).double(), 'seq_len': seq.tolist(), 'weak_targets': weak.double(), 'boundary_targets': bnd.double()}
+    ref64.review(in64, ref64(in64))['loss'].backward()
+
+    model.train()
+    inputs = {'audio_data': wav, 'seq_len': seq.tolist(), 'weak_targets': weak, 'boundary_targets': bnd}
+    model.flat_parameters()[1].zero_()
+    out = model(dict(inputs))
+    rev = model.review(inputs, out)
+    rev['loss'].backward()
+
+    rel_close(out[3], out_ref[3], 1e-4, 'features')
+    assert (out[0] - out_ref[0]).abs().max() < 1e-4 and (out[1] - out_ref[1]).abs().max() < 1e-4
+    assert rev['loss'].item() == pytest.approx(rev_ref['loss'].item(), rel=1e-4)
+    np.testing.assert_allclose(rev['buffers']['y_weak'], rev_ref['buffers']['y_weak'], atol=1e-4)
+    np.testing.assert_array_equal(rev['buffers']['targets_weak'], np.asarray(rev_ref['buffers']['targets_weak']))
+    refp, refp32 = dict(ref64.named_parameters()), dict(ref.named_parameters())
+    bad = []
+    for name, p in model.named_parameters():
+        g64 = refp[name].grad
+        err32 = (refp32[name].grad.double() - g64).abs().max().item() / (g64.abs().max().item() + 1e-12)
+        try:
+            rel_close(p.grad, g64, max(2e-3, 3 * err32), name)
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, '\n'.join(bad)
+    refb = dict(ref.named_buffers())
+    for name, buf in model.named_buffers():
+        if 'running' in name:
+            rel_close(buf, refb[name], 1e-4, name)
+    # the launches of a training step really went through the emulated kernels
+    ran = set(device.calls)
+    assert {'pbsed_logmel_fwd', 'pbsed_gru_stack_fwd_granule', 'pbsed_gru_stack_bwd_granule', 'pbsed_fbcrnn_loss', 'pbsed_conv_bwd_weight',
+            'pbsed_gru_wgrad_multi', 'pbsed_tm_gemm'} <= ran, ' '.join(sorted(ran))
+
+
+def _bicrnn_step(seed=2):
+    """One tag-conditioned BiCRNN training step in the default fp32-class mode on 16-byte aligned rows: engine._prec then picks the
+    bf16x3 kernels of the bench configurations - few-channel MFMA (conv_s16.hip), Winograd-domain 3x3 (conv_winox3.hip), producer /
+    consumer 1-D (conv1d_pc.hip), pipelined bf16-MFMA with three-way splits (conv_bf16.hip); returns (scores, loss, gradients)."""
+    from pb_sed_amd.models import strong_label
+    from oracle import models as om
+    torch.manual_seed(seed)
+    net = dict(out_channels_2d=[16, 16, 32, 32], pool_sizes_2d=[1, (2, 1), 1, (2, 1)], kernel_size_2d=3,
+               out_channels_1d=[128, 128, 64], kernel_size_1d=[1, 3, 1])
+    kw = dict(num_events=10, number_of_filters=32, hidden_size=64, num_layers=2, net=net, tag_conditioning=True)
+    ref = om.BiCRNN.build(**kw)
+    _nontrivial_norms(ref)
+    model = strong_label.CRNN.build(**kw)
+    _copy_weights(model, ref)
+    wav, seq, weak, strong, t = synth_batch(2, 8800, 10, seed=5)          # 28 frames: 16-byte aligned rows, the bf16x3 kernels' form
+    tag = (weak > .99).float()
+    model.train()
+    inp = {'audio_data': wav, 'seq_len': seq.tolist(), 'weak_targets': weak, 'strong_targets': strong, 'tag_condition': tag}
+    model.flat_parameters()[1].zero_()
+    out = model(dict(inp))
+    loss = model.review(inp, out)['loss']
+    loss.backward()
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+    return ref, dict(inp, seq=seq, wav=wav), out[0].detach().clone(), loss.item(), grads
+
+
+@pytest.fixture(scope='module')
+def bicrnn_on_the_tree(library):
+    mp = pytest.MonkeyPatch()
+    try:
+        with cpu_device.emulated_device(mp, library):
+            library.calls.clear()
+            res = _bicrnn_step()
+            return res + (set(library.calls),)
+    finally:
+        mp.undo()
+
+
+def test_bicrnn_train_step_through_the_bf16x3_kernels_on_the_cpu_follows_the_oracle(bicrnn_on_the_tree):
+    """tests/test_gpu_model.py::test_bicrnn_train_step_parity in miniature."""
+    from oracle import frontend as ofe
+    ref, inp, y, loss, grads, ran = bicrnn_on_the_tree
+    ref.train()
+    inp_ref = {'stft': ofe.stft(inp['wav']), 'seq_len': inp['seq'].tolist(), 'weak_targets': inp['weak_targets'],
+               'strong_targets': inp['strong_targets'], 'tag_condition': inp['tag_condition']}
+    out_ref = ref(inp_ref)
+    loss_ref = ref.review(inp_ref, out_ref)['loss']
+    loss_ref.backward()
+    assert (y - out_ref[0]).abs().max() < 1e-4
+    assert loss == pytest.approx(loss_ref.item(), rel=1e-4)
+    bad = []
+    for name, p in ref.named_parameters():
+        try:
+            rel_close(grads[name], p.grad, 2e-3, name)
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, '\n'.join(bad)
+    assert {'pbsed_conv_fwd_s16', 'pbsed_conv_bwd_data_s16', 'pbsed_conv_fwd_winox3', 'pbsed_conv_bwd_data_winox3', 'pbsed_conv1d_fwd_x3',
+            'pbsed_conv1d_bwd_data_x3', 'pbsed_bicrnn_loss'} <= ran, ' '.join(sorted(ran))
+
+
+def test_weight_gradients_beside_the_scans_change_nothing_on_the_cpu(monkeypatch, device, bicrnn_on_the_tree):
+    """engine.SIDE_WGRAD (the heads' and the upper GRU layer's weight gradients deferred to a second stream beside
+    the next persistent scan - parked behind PBSED_SIDE_WGRAD=1 until it is measured): the deferred launches write buffers nothing in
+    between reads, so the step's gradients must be those of the serial order BIT FOR BIT.  (Streams run in program order here: this
+    pins the bookkeeping - what is deferred, that everything deferred runs, joins before the consumers - not the overlap.)"""
+    from pb_sed_amd import engine
+    monkeypatch.setattr(engine, 'SIDE_WGRAD', True)
+    monkeypatch.setattr(engine, '_has_streams', lambda t: True)
+    deferred = []
+    run_beside = engine._DeferredLaunches.run_beside
+    monkeypatch.setattr(engine._DeferredLaunches, 'run_beside', lambda self, *a, **k: (deferred.append(len(self)), run_beside(self, *a, **k))[1])
+    _, _, y, loss, grads = _bicrnn_step()
+    assert sum(deferred) > 0, 'nothing was deferred'
+    _, _, y0, loss0, grads0, _ = bicrnn_on_the_tree
+    assert torch.equal(y, y0) and loss == loss0
+    for name, g in grads0.items():
+        assert torch.equal(grads[name], g), name
+
+
+def test_parked_kernel_patches_change_no_bit_of_a_training_step(monkeypatch, tmp_path, bicrnn_on_the_tree):
+    """The whole patch stack of tools/micro/attic (loads re-ordered around the in-order vmcnt, awaiting a GPU
+    measurement) built as a library of its own: scores, loss and every gradient of the step identical to the tree's."""
+    import re
+    import shutil
+    import subprocess
+    work = tmp_path / 'patched'
+    (work / 'pb_sed_amd').mkdir(parents=True)
+    shutil.copytree(os.path.join(cpu_device.ROOT, 'pb_sed_amd', 'csrc'), work / 'pb_sed_amd' / 'csrc', ignore=shutil.ignore_patterns('build'))
+    script = open(os.path.join(cpu_device.ROOT, 'tools', 'build_variants.sh')).read()
+    patches = re.findall(r'attic/(\w+\.patch)\)', script)
+    assert patches
+    for p in patches:
+        subprocess.run(['patch', '-s', '-p1', '-i', os.path.join(cpu_device.ROOT, 'tools', 'micro', 'attic', p)], cwd=work, check=True)
+    patched = cpu_device.EmulatedLibrary(tmp_path, csrc=str(work / 'pb_sed_amd' / 'csrc'))
+    with cpu_device.emulated_device(monkeypatch, patched):
+        _, _, y, loss, grads = _bicrnn_step()
+    _, _, y0, loss0, grads0, _ = bicrnn_on_the_tree
+    assert torch.equal(y, y0) and loss == loss0
+    for name, g in grads0.items():
+        assert torch.equal(grads[name], g), name
