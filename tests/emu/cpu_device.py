@@ -119,8 +119,10 @@ class _Event:
 
 
 @contextlib.contextmanager
-def emulated_device(monkeypatch, library):
-    """Inside: pb_sed_amd runs on CPU tensors through ``library``.  Everything patched is restored by ``monkeypatch``."""
+def emulated_device(monkeypatch, library, to_copies=False):
+    """Inside: pb_sed_amd runs on CPU tensors through ``library``.  Everything patched is restored by ``monkeypatch``.
+    ``to_copies``: ``tensor.to('cpu')`` hands back a COPY, as ``.to('cuda:0')`` of a host tensor does (the GPU tests keep the host
+    original as their reference while a launch updates the device copy in place)."""
     from pb_sed_amd import _lib, ops
     stream = _Stream()
     monkeypatch.setattr(ops, 'ensure_scratch', lambda device: None)      # the library's own (shim-malloc'ed) scratch serves the launches
@@ -134,4 +136,12 @@ def emulated_device(monkeypatch, library):
     empty = torch.empty
     monkeypatch.setattr(torch, 'empty', lambda *a, pin_memory=False, **k: empty(*a, **k))
     monkeypatch.setattr(torch.Tensor, 'pin_memory', lambda self, *a, **k: self)
+    if to_copies:
+        to = torch.Tensor.to
+
+        def to_device(self, *a, **k):
+            out = to(self, *a, **k)
+            first = a[0] if a else k.get('device')
+            return out.clone() if out is self and isinstance(first, (str, torch.device)) and str(first) == 'cpu' else out
+        monkeypatch.setattr(torch.Tensor, 'to', to_device)
     yield library
