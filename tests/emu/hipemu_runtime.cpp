@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <thread>
+#include <vector>
 
 thread_local hipemu::Idx threadIdx, blockIdx, blockDim, gridDim;
 
@@ -69,9 +70,25 @@ static void run_block(dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned 
         r.done[i] = false;
         r.wait_word[i] = nullptr;
     }
+    // HIPEMU_SCHEDULE: the order in which the scheduler visits the block's fibers - 0 (default) ascending, 1 descending, >= 2 a
+    // seeded shuffle drawn anew on every pass.  Every order is a legal execution (threads of a block are unordered between
+    // barriers; lanes of a wave meet at every cross-lane instruction), so results may differ between orders only in the
+    // rounding of floating-point atomics - a kernel that reads LDS or global memory another wave writes WITHOUT a barrier in
+    // between gives different (wrong) results under some order: tools/emu_schedules.sh runs the emulated tests under each.
+    const char* sched_env = getenv("HIPEMU_SCHEDULE");
+    const unsigned sched = sched_env ? (unsigned)atoi(sched_env) : 0u;
+    unsigned long long lcg = 0x9E3779B97F4A7C15ull * (sched + 1u) + bx + 131u * by;
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = sched == 1 ? n - 1 - i : i;
     int left = n;
     while (left > 0) {
-        for (int i = 0; i < n; ++i) {
+        if (sched >= 2)
+            for (int i = n - 1; i > 0; --i) {
+                lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+                std::swap(order[i], order[(int)((lcg >> 33) % (unsigned)(i + 1))]);
+            }
+        for (int oi = 0; oi < n; ++oi) {
+            const int i = order[oi];
             if (r.done[i]) continue;
             if (r.wait_word[i] && *r.wait_word[i] == r.wait_val[i]) continue;
             r.cur = i;

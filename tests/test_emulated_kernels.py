@@ -981,3 +981,43 @@ def test_address_sanitizer_sees_a_kernel_leave_its_tensor(tmp_path):
     short = subprocess.run([sys.executable, '-c', drive, '64'], env=env, capture_output=True, text=True)
     assert short.returncode != 0 and 'heap-buffer-overflow' in short.stderr and 'medfilt_kernel' in short.stderr, short.stderr[-2000:]
     assert re.search(r'postproc\.hip:\d+', short.stderr)
+
+
+def test_other_fiber_schedules_expose_a_missing_barrier(tmp_path):
+    """tools/emu_schedules.sh: HIPEMU_SCHEDULE = 1 (descending thread order) / >= 2 (seeded shuffles) are other legal executions of
+    a block.  The detector detects: a purpose-written kernel in which thread t reads the LDS word thread t - 1 wrote, WITHOUT a
+    barrier, happens to be right in ascending order and is wrong in the others; with the barrier every order agrees."""
+    src = tmp_path / 'race.cpp'
+    src.write_text('''
+#include <hip/hip_runtime.h>
+static thread_local int lds[256];
+template <bool BARRIER> static void k(int* out) {
+    const int t = threadIdx.x;
+    lds[t] = 1000 + t;
+    if (BARRIER) __syncthreads();
+    out[t] = t ? lds[t - 1] : -1;
+    __syncthreads();
+    lds[t] = 0;
+}
+extern "C" void run(int* out, int barrier) {
+    if (barrier) hipLaunchKernelGGL(k<true>, dim3(1), dim3(256), 0, nullptr, out);
+    else hipLaunchKernelGGL(k<false>, dim3(1), dim3(256), 0, nullptr, out);
+}
+''')
+    so = str(tmp_path / 'race.so')
+    subprocess.run([CLANG, '-x', 'c++', '-std=c++20', '-O0', '-fPIC', '-shared', '-w', '-I', os.path.join(EMU, 'shim'), str(src),
+                    os.path.join(EMU, 'hipemu_runtime.cpp'), '-o', so], check=True)
+    lib = C.CDLL(so)
+    want = np.concatenate([[-1], 1000 + np.arange(255)]).astype(np.int32)
+    got = {}
+    try:
+        for sched in ('0', '1', '2', '3'):
+            os.environ['HIPEMU_SCHEDULE'] = sched
+            for barrier in (0, 1):
+                out = np.zeros(256, np.int32)
+                lib.run(P(out), barrier)
+                got[sched, barrier] = np.array_equal(out, want)
+    finally:
+        del os.environ['HIPEMU_SCHEDULE']
+    assert all(got[s, 1] for s in '0123'), got
+    assert got['0', 0] and not got['1', 0] and not got['2', 0] and not got['3', 0], got
