@@ -175,8 +175,14 @@ def test_weight_gradients_beside_the_scans_change_nothing_on_the_cpu(monkeypatch
     assert sum(deferred) > 0, 'nothing was deferred'
     _, _, y0, loss0, grads0, _ = bicrnn_on_the_tree
     assert torch.equal(y, y0) and loss == loss0
+    # the deferred jobs are grouped into other launches; under a SHUFFLED fiber schedule (tools/emu_schedules.sh, seeded per block
+    # index) the fp32 atomics of the bias gradients then add in another order - as they do from run to run on the GPU
+    shuffled = int(os.environ.get('HIPEMU_SCHEDULE', '0')) >= 2
     for name, g in grads0.items():
-        assert torch.equal(grads[name], g), name
+        if shuffled:
+            torch.testing.assert_close(grads[name], g, rtol=1e-5, atol=1e-7 * g.abs().max().item(), msg=name)
+        else:
+            assert torch.equal(grads[name], g), name
 
 
 def test_parked_kernel_patches_change_no_bit_of_a_training_step(monkeypatch, tmp_path, bicrnn_on_the_tree):
