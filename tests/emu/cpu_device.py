@@ -133,8 +133,20 @@ def emulated_device(monkeypatch, library, to_copies=False):
                       ('stream', lambda s: contextlib.nullcontext()), ('device', lambda d: contextlib.nullcontext()),
                       ('current_device', lambda: 0), ('synchronize', lambda device=None: None)):
         monkeypatch.setattr(torch.cuda, name, obj)
-    empty = torch.empty
-    monkeypatch.setattr(torch, 'empty', lambda *a, pin_memory=False, **k: empty(*a, **k))
+    # uninitialised memory is POISON here (NaN in floating-point tensors, 0xAA.. in integer ones): a launch that leaves part of its
+    # output unwritten, or a consumer that reads what no launch wrote, shows up in the results instead of hiding behind the zeros of
+    # a fresh allocation
+    def poisoned(t):
+        if t.numel():
+            if t.dtype.is_floating_point:
+                t.fill_(float('nan'))
+            elif t.dtype in (torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64):
+                t.fill_({torch.uint8: 0xAA, torch.int8: -86, torch.int16: -21846, torch.int32: -1431655766}.get(t.dtype, -6148914691236517206))
+        return t
+    empty, empty_like, new_empty = torch.empty, torch.empty_like, torch.Tensor.new_empty
+    monkeypatch.setattr(torch, 'empty', lambda *a, pin_memory=False, **k: poisoned(empty(*a, **k)))
+    monkeypatch.setattr(torch, 'empty_like', lambda *a, pin_memory=False, **k: poisoned(empty_like(*a, **k)))
+    monkeypatch.setattr(torch.Tensor, 'new_empty', lambda self, *a, pin_memory=False, **k: poisoned(new_empty(self, *a, **k)))
     monkeypatch.setattr(torch.Tensor, 'pin_memory', lambda self, *a, **k: self)
     if to_copies:
         to = torch.Tensor.to
