@@ -26,7 +26,7 @@ EMULATE = os.environ.get('PBSED_EMULATE') == '1'
 def _emulated_device(tmp_path_factory):
     from tests.emu import cpu_device
     mp = pytest.MonkeyPatch()
-    with cpu_device.emulated_device(mp, cpu_device.EmulatedLibrary(tmp_path_factory.mktemp('emu_whole')), to_copies=True) as library:
+    with cpu_device.emulated_device(mp, cpu_device.EmulatedLibrary(tmp_path_factory.mktemp('emu_whole'))) as library:
         yield library
     mp.undo()
 

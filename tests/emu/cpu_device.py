@@ -119,10 +119,11 @@ class _Event:
 
 
 @contextlib.contextmanager
-def emulated_device(monkeypatch, library, to_copies=False):
+def emulated_device(monkeypatch, library, to_copies=True):
     """Inside: pb_sed_amd runs on CPU tensors through ``library``.  Everything patched is restored by ``monkeypatch``.
-    ``to_copies``: ``tensor.to('cpu')`` hands back a COPY, as ``.to('cuda:0')`` of a host tensor does (the GPU tests keep the host
-    original as their reference while a launch updates the device copy in place)."""
+    ``to_copies``: ``tensor.to('cpu')`` hands back a COPY, as ``.to('cuda:0')`` of a host tensor does (ops.host_to_device stages through pooled
+    pinned buffers that are re-used after the copy; the GPU tests keep host originals as references while a launch updates the device
+    copy in place)."""
     from pb_sed_amd import _lib, ops
     stream = _Stream()
     monkeypatch.setattr(ops, 'ensure_scratch', lambda device: None)      # the library's own (shim-malloc'ed) scratch serves the launches
@@ -137,7 +138,7 @@ def emulated_device(monkeypatch, library, to_copies=False):
     # output unwritten, or a consumer that reads what no launch wrote, shows up in the results instead of hiding behind the zeros of
     # a fresh allocation
     def poisoned(t):
-        if t.numel():
+        if t.numel() and os.environ.get('PBSED_EMU_POISON', '1') == '1':
             if t.dtype.is_floating_point:
                 t.fill_(float('nan'))
             elif t.dtype in (torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64):

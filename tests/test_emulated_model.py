@@ -206,3 +206,55 @@ def test_parked_kernel_patches_change_no_bit_of_a_training_step(monkeypatch, tmp
     assert torch.equal(y, y0) and loss == loss0
     for name, g in grads0.items():
         assert torch.equal(grads[name], g), name
+
+
+def test_inference_driver_on_the_cpu_follows_the_oracle(device):
+    """tests/test_gpu_postproc.py::test_inference_driver_end_to_end_vs_oracle in miniature (BASELINE config 5's shape: taggers ->
+    tags -> tag-conditioned detectors sharing their scan launches -> ensemble mean, per-class median filters, masking, event
+    lists): pb_sed/models/base/inference.py:121-283 restated in oracle/postproc.py."""
+    from oracle import frontend as ofe, models as om, postproc as pp
+    from pb_sed_amd import inference as inf
+    from pb_sed_amd.models import strong_label, weak_label
+    torch.manual_seed(3)
+    kw = dict(num_events=10, number_of_filters=64, hidden_size=64, num_layers=2, net=TINY)
+    pairs_w, pairs_s = [], []
+    for _ in range(2):
+        r = om.FBCRNN.build(**kw).eval()
+        m = weak_label.CRNN.build(**kw)
+        m.load_state_dict(r.state_dict())
+        pairs_w.append((r, m))
+        r = om.BiCRNN.build(tag_conditioning=True, **kw).eval()
+        m = strong_label.CRNN.build(tag_conditioning=True, **kw)
+        m.load_state_dict(r.state_dict())
+        pairs_s.append((r, m))
+    wav, seq, *_ = synth_batch(3, 8800, 10, seed=7)
+    ids = [f'a{i}' for i in range(3)]
+    batch = {'audio_data': wav, 'seq_len': seq.tolist(), 'example_id': ids}
+    stft = ofe.stft(wav)
+    tag_scores = inf.tagging([m for _, m in pairs_w], [dict(batch)], 'cpu')
+    with torch.no_grad():
+        ref = pp.postprocess([r.tagging({'stft': stft, 'seq_len': seq.tolist()})[0].numpy() for r, _ in pairs_w],
+                             np.ones(3, int), ids, tagging=True)
+    for a in ids:
+        np.testing.assert_allclose(tag_scores[a], ref[a], atol=1e-4)
+    tags = {a: (ref[a][0] > .5).astype(np.float32) for a in ids}
+    tag_cond = torch.tensor(np.stack([tags[a] for a in ids]))
+    ml = np.array([[1, 3, 5, 7, 9, 1, 3, 5, 7, 9], [3] * 10])
+    sed = inf.sound_event_detection([m for _, m in pairs_s], [dict(batch, tag_condition=tag_cond)], 'cpu',
+                                    medfilt_length=ml, apply_mask=True, masks=tags)
+    with torch.no_grad():
+        ref = pp.postprocess([r.sound_event_detection({'stft': stft, 'seq_len': seq.tolist(), 'tag_condition': tag_cond})[0].numpy()
+                              for r, _ in pairs_s], seq, ids, medfilt_length=ml, apply_mask=True, masks=tags)
+    for a in ids:
+        assert sed[a].shape == ref[a].shape
+        np.testing.assert_allclose(sed[a], ref[a], atol=1e-4)
+    # thresholds -> event lists (onset, offset, class), bit-exact against the oracle on the build's own scores
+    classes = [f'c{i}' for i in range(10)]
+    ts = np.round(np.arange(0, 100) * .02, 6)
+    thr = np.full(10, .5, np.float32)
+    scores = {a: np.ascontiguousarray(sed[a][0]) for a in ids}              # [T, K]
+    got = inf.scores_to_event_list(scores, thr, classes, ts, device='cpu')
+    for a in ids:
+        assert got[a] == pp.scores_to_event_list(scores[a], ts, thr, classes), a
+    ran = set(device.calls)
+    assert {'pbsed_ensemble_mean_mask', 'pbsed_medfilt', 'pbsed_event_frames', 'pbsed_gru_stack_fwd_granule'} <= ran, ' '.join(sorted(ran))
