@@ -31,6 +31,18 @@ def device(monkeypatch, library):
         yield library
 
 
+def _same_gradients(grads, grads0):
+    """Bit for bit - but: SIDE_WGRAD groups the deferred jobs into other launches, and under a SHUFFLED fiber schedule
+    (tools/emu_schedules.sh, seeded per block index) the fp32 atomics of the bias gradients then add in another order, as they do
+    from run to run on the GPU."""
+    shuffled = int(os.environ.get('HIPEMU_SCHEDULE', '0')) >= 2
+    for name, g in grads0.items():
+        if shuffled:
+            torch.testing.assert_close(grads[name], g, rtol=1e-5, atol=1e-7 * g.abs().max().item(), msg=name)
+        else:
+            assert torch.equal(grads[name], g), name
+
+
 def _nontrivial_norms(ref):
     with torch.no_grad():
         for name, p in ref.named_parameters():
@@ -42,7 +54,7 @@ def _nontrivial_norms(ref):
         ref.feature_extractor.inv_std.fill_(.4)
 
 
-def test_fbcrnn_train_step_on_the_cpu_follows_the_oracle(device):
+def test_fbcrnn_train_step_on_the_cpu_follows_the_oracle(monkeypatch, device):
     """tests/test_gpu_model.py::test_fbcrnn_train_step_parity[tiny_ragged] at B = 3, 0.5 s clips, 64 mel bands: features, both directions' scores,
     the loss, the review summary, every parameter gradient (against the float64 oracle, bar = the fp32 oracle's own error) and the
     running statistics."""
@@ -54,6 +66,7 @@ def test_fbcrnn_train_step_on_the_cpu_follows_the_oracle(device):
     _nontrivial_norms(ref)
     model = weak_label.CRNN.build(**kw)
     _copy_weights(model, ref)
+    state0 = copy.deepcopy(model.state_dict())
     wav, seq, weak, bnd, t = synth_batch(3, 8000, 10)
     ref.train()
     inputs_ref = {'stft': ofe.stft(wav), 'seq_len': seq.tolist(), 'weak_targets': weak, 'boundary_targets': bnd}
@@ -97,6 +110,24 @@ def test_fbcrnn_train_step_on_the_cpu_follows_the_oracle(device):
     ran = set(device.calls)
     assert {'pbsed_logmel_fwd', 'pbsed_gru_stack_fwd_granule', 'pbsed_gru_stack_bwd_granule', 'pbsed_fbcrnn_loss', 'pbsed_conv_bwd_weight',
             'pbsed_gru_wgrad_multi', 'pbsed_tm_gemm'} <= ran, ' '.join(sorted(ran))
+    # the same step with engine.SIDE_WGRAD (the heads' and the upper GRU layers' weight gradients deferred beside the BPTT scans of
+    # both directions' stacks - engine._stack_rnn_backward, the headline configuration's path): the serial order's gradients
+    from pb_sed_amd import engine
+    grads0 = {n: p.grad.clone() for n, p in model.named_parameters()}
+    monkeypatch.setattr(engine, 'SIDE_WGRAD', True)
+    monkeypatch.setattr(engine, '_has_streams', lambda t: True)
+    deferred = []
+    run_beside = engine._DeferredLaunches.run_beside
+    monkeypatch.setattr(engine._DeferredLaunches, 'run_beside', lambda self, *a, **k: (deferred.append(len(self)), run_beside(self, *a, **k))[1])
+    model2 = weak_label.CRNN.build(**kw)           # (a training step moves the feature normalisation's statistics: a fresh copy)
+    model2.load_state_dict(state0)
+    model2.train()
+    model2.flat_parameters()[1].zero_()
+    out2 = model2(dict(inputs))
+    model2.review(inputs, out2)['loss'].backward()
+    assert sum(deferred) > 0, 'nothing was deferred'
+    assert torch.equal(out2[0], out[0]) and torch.equal(out2[1], out[1])
+    _same_gradients({n: p.grad for n, p in model2.named_parameters()}, grads0)
 
 
 def _bicrnn_step(seed=2):
@@ -175,14 +206,7 @@ def test_weight_gradients_beside_the_scans_change_nothing_on_the_cpu(monkeypatch
     assert sum(deferred) > 0, 'nothing was deferred'
     _, _, y0, loss0, grads0, _ = bicrnn_on_the_tree
     assert torch.equal(y, y0) and loss == loss0
-    # the deferred jobs are grouped into other launches; under a SHUFFLED fiber schedule (tools/emu_schedules.sh, seeded per block
-    # index) the fp32 atomics of the bias gradients then add in another order - as they do from run to run on the GPU
-    shuffled = int(os.environ.get('HIPEMU_SCHEDULE', '0')) >= 2
-    for name, g in grads0.items():
-        if shuffled:
-            torch.testing.assert_close(grads[name], g, rtol=1e-5, atol=1e-7 * g.abs().max().item(), msg=name)
-        else:
-            assert torch.equal(grads[name], g), name
+    _same_gradients(grads, grads0)
 
 
 def test_parked_kernel_patches_change_no_bit_of_a_training_step(monkeypatch, tmp_path, bicrnn_on_the_tree):
