@@ -38,10 +38,14 @@ def compile_unit(unit, csrc, out, defines=()):
 class EmulatedLibrary:
     """Attribute access like a ``ctypes.CDLL`` of libpbsed_mi355.so, resolved over the emulated units (argtypes from _lib.SIGNATURES)."""
 
-    def __init__(self, outdir, csrc=None):
+    def __init__(self, outdir, csrc=None, reuse=False):
+        """``reuse``: load the units another EmulatedLibrary has built in ``outdir`` (worker processes of a multi-rank test)."""
         csrc = csrc or os.path.join(ROOT, 'pb_sed_amd', 'csrc')
-        with ThreadPoolExecutor(8) as ex:
-            paths = list(ex.map(lambda u: compile_unit(u, csrc, os.path.join(str(outdir), f'libemu_{u}.so')), UNITS))
+        self.outdir = str(outdir)
+        paths = [os.path.join(self.outdir, f'libemu_{u}.so') for u in UNITS]
+        if not (reuse and all(os.path.exists(p) for p in paths)):
+            with ThreadPoolExecutor(8) as ex:
+                list(ex.map(lambda u: compile_unit(u, csrc, os.path.join(self.outdir, f'libemu_{u}.so')), UNITS))
         self._units = {u: C.CDLL(p) for u, p in zip(UNITS, paths)}
         self._units['gru_stack'].hipemu_set_concurrent(1)      # the persistent scans: every workgroup on an OS thread of its own
         self._fns = {}

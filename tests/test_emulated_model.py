@@ -282,3 +282,73 @@ def test_inference_driver_on_the_cpu_follows_the_oracle(device):
         assert got[a] == pp.scores_to_event_list(scores[a], ts, thr, classes), a
     ran = set(device.calls)
     assert {'pbsed_ensemble_mean_mask', 'pbsed_medfilt', 'pbsed_event_frames', 'pbsed_gru_stack_fwd_granule'} <= ran, ' '.join(sorted(ran))
+
+
+def _dp_batch(b):
+    g = torch.Generator().manual_seed(7)
+    weak = (torch.rand(b, 10, generator=g) < .3).float()
+    weak[:, 0] = 1
+    bnd = torch.zeros(b, 10, 28)
+    bnd[:, 0, 5:15] = 1
+    return {'audio_data': torch.randn(b, 8800, generator=g), 'seq_len': [28] * b, 'weak_targets': weak, 'boundary_targets': bnd}
+
+
+def _dp_model():
+    """Statistics independent of the batch (frozen norm / feature statistics): clips become independent, so the average of the
+    ranks' gradients IS the single-rank gradient (tests/test_gpu_dp.py::test_two_ranks_on_one_gpu[True])."""
+    from pb_sed_amd.models import weak_label
+    from pb_sed_amd.modules import Normalization
+    torch.manual_seed(0)
+    model = weak_label.CRNN.build(num_events=10, number_of_filters=32, hidden_size=64, num_layers=2, net=dict(TINY))
+    model.feature_extractor.freeze_stats = True
+    g = torch.Generator().manual_seed(1)
+    for m in model.modules():
+        if isinstance(m, Normalization):
+            m.freeze_stats = True
+            with torch.no_grad():
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * .1)
+                m.running_power.copy_(torch.rand(m.running_power.shape, generator=g) + .8)
+    return model
+
+
+def _dp_worker(rank, world, port, units_dir, out_dir):
+    import sys
+    sys.path.insert(0, cpu_device.ROOT)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    mp = pytest.MonkeyPatch()
+    with cpu_device.emulated_device(mp, cpu_device.EmulatedLibrary(units_dir, reuse=True)):
+        from pb_sed_amd.trainer import Trainer, shard_batch
+        trainer = Trainer(_dp_model(), lr=1e-3, gradient_clipping=5., allreduce='torch')
+        rev = trainer.step(shard_batch(_dp_batch(4), rank, world))
+        torch.save({'grad': (trainer.flat_grad / world).clone(), 'param': trainer.flat_param.clone(), 'loss': float(rev['loss'].item())},
+                   os.path.join(out_dir, f'rank{rank}.pt'))
+    mp.undo()
+    dist.destroy_process_group()
+
+
+def test_two_data_parallel_ranks_on_the_cpu_reproduce_the_single_rank_step(monkeypatch, tmp_path, library):
+    """SURVEY.md 8(e) with the real kernels and no GPU: two processes (gloo), each with the emulated device and its shard of the
+    batch, one Trainer step (bucketed all-reduce of the flat gradient, averaged Adam through pbsed_adam_step): the ranks end
+    bit-identical, and - statistics frozen - their averaged gradient is the gradient of one rank on the whole batch."""
+    import socket
+    import torch.multiprocessing as tmp_mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    tmp_mp.spawn(_dp_worker, args=(2, port, library.outdir, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f'rank{r}.pt') for r in range(2))
+    assert np.isfinite(r0['loss']) and np.isfinite(r1['loss'])
+    assert torch.equal(r0['grad'], r1['grad']) and torch.equal(r0['param'], r1['param']), 'ranks diverged'
+    with cpu_device.emulated_device(monkeypatch, library):
+        from pb_sed_amd.trainer import Trainer
+        batch = _dp_batch(4)
+        w = ((batch['weak_targets'] < .01) | (batch['weak_targets'] > .99)).float().sum(-1)
+        assert w[:2].sum() == w[2:].sum()          # equal per-rank loss-weight sums: average of the ranks' gradients = global gradient
+        trainer = Trainer(_dp_model(), lr=1e-3, gradient_clipping=5.)
+        trainer.step(batch)
+        single, param = trainer.flat_grad.clone(), trainer.flat_param.clone()
+    rel = ((r0['grad'] - single).norm() / single.norm()).item()
+    assert rel < 2e-5, rel
+    assert (r0['param'] - param).abs().max().item() < 1e-5
