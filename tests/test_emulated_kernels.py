@@ -26,12 +26,13 @@ CLANG = '/opt/rocm/lib/llvm/bin/clang++'
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason='needs the ROCm clang++ (ext_vector_type, __bf16)')
 
 
-def _compile(unit, csrc, out):
+def _build(unit, csrc, out):
     # -O0: these translation units are template-heavy (28 s at -O1, 2 s at -O0) and the emulated launches are tiny
     subprocess.run([CLANG, '-x', 'c++', '-std=c++20', *os.environ.get('PBSED_EMU_OPT', '-O0').split(), '-fPIC', '-shared', '-w',
                     '-I', os.path.join(EMU, 'shim'), '-I', csrc, os.path.join(EMU, unit), os.path.join(EMU, 'hipemu_runtime.cpp'),
                     '-o', out], check=True)
-    return C.CDLL(out)
+    return out
+
 
 
 @pytest.fixture(scope='module')
@@ -46,11 +47,27 @@ def patched_csrc(tmp_path_factory):
     return str(work / 'pb_sed_amd' / 'csrc')
 
 
+_PATCHED_UNITS = ('emu_conv_s16.cpp', 'emu_conv_winox3.cpp', 'emu_logmel.cpp', 'emu_conv_bf16.cpp', 'emu_conv1d_pc.cpp', 'emu_conv_wgrad.cpp')
+_TREE_UNITS = _PATCHED_UNITS + ('emu_gru_stack.cpp', 'emu_rnn_gemms.cpp', 'emu_misc.cpp', 'emu_postproc.cpp')
+
+
 @pytest.fixture(scope='module')
-def s16_libs(tmp_path_factory, patched_csrc):
-    d = tmp_path_factory.mktemp('emu_s16')
-    return (_compile('emu_conv_s16.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so')),
-            _compile('emu_conv_s16.cpp', patched_csrc, str(d / 'patched.so')))
+def built(tmp_path_factory, patched_csrc):
+    """Every emulated unit of this module, from the tree and (where a parked patch touches it) from the patched tree, compiled ONCE
+    and in parallel; built(unit, 'tree' | 'patched') -> CDLL."""
+    from concurrent.futures import ThreadPoolExecutor
+    d = tmp_path_factory.mktemp('emu_units')
+    tree = os.path.join(ROOT, 'pb_sed_amd', 'csrc')
+    jobs = [(u, tree, 'tree') for u in _TREE_UNITS] + [(u, patched_csrc, 'patched') for u in _PATCHED_UNITS]
+    path = lambda u, which: str(d / f'{u[:-4]}_{which}.so')
+    with ThreadPoolExecutor(8) as ex:
+        list(ex.map(lambda j: _build(j[0], j[1], path(j[0], j[2])), jobs))
+    return lambda unit, which='tree': C.CDLL(path(unit, which))
+
+
+@pytest.fixture(scope='module')
+def s16_libs(built):
+    return built('emu_conv_s16.cpp', 'tree'), built('emu_conv_s16.cpp', 'patched')
 
 
 def P(a):
@@ -201,10 +218,8 @@ def test_conv_s16_data_gradient_on_the_cpu_tree_vs_float64_and_patched_vs_tree(s
 
 # ------------------------------------------------------------------------------------------------ conv_winox3 (Winograd F(4,3), bf16x3)
 @pytest.fixture(scope='module')
-def wx_libs(tmp_path_factory, patched_csrc):
-    d = tmp_path_factory.mktemp('emu_wx')
-    return (_compile('emu_conv_winox3.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so')),
-            _compile('emu_conv_winox3.cpp', patched_csrc, str(d / 'patched.so')))
+def wx_libs(built):
+    return built('emu_conv_winox3.cpp', 'tree'), built('emu_conv_winox3.cpp', 'patched')
 
 
 def _pack_wx(lib, w, dgrad):
@@ -326,10 +341,8 @@ def test_conv_winox3_data_gradient_on_the_cpu_tree_vs_float64_and_patched_vs_tre
 
 # ------------------------------------------------------------------------------------------------ logmel (the fused front-end)
 @pytest.fixture(scope='module')
-def lm_libs(tmp_path_factory, patched_csrc):
-    d = tmp_path_factory.mktemp('emu_lm')
-    return (_compile('emu_logmel.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so')),
-            _compile('emu_logmel.cpp', patched_csrc, str(d / 'patched.so')))
+def lm_libs(built):
+    return built('emu_logmel.cpp', 'tree'), built('emu_logmel.cpp', 'patched')
 
 
 def _logmel_tables(fb):
@@ -392,10 +405,8 @@ def test_logmel_front_end_on_the_cpu_tree_vs_oracle_and_patched_vs_tree(lm_libs,
 
 # ------------------------------------------------------------------------------------------------ conv_bf16 (configs[2]; the 1x1 layers of 'deep')
 @pytest.fixture(scope='module')
-def b16_libs(tmp_path_factory, patched_csrc):
-    d = tmp_path_factory.mktemp('emu_b16')
-    return (_compile('emu_conv_bf16.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so')),
-            _compile('emu_conv_bf16.cpp', patched_csrc, str(d / 'patched.so')))
+def b16_libs(built):
+    return built('emu_conv_bf16.cpp', 'tree'), built('emu_conv_bf16.cpp', 'patched')
 
 
 def _pack_b16(lib, w, dgrad, nsplit):
@@ -523,10 +534,8 @@ def test_conv_bf16_data_gradient_on_the_cpu_tree_vs_float64_and_patched_vs_tree(
 
 # ------------------------------------------------------------------------------------------------ conv1d_pc (Conv1d k = 1 / 3, bf16x3, producer / consumer)
 @pytest.fixture(scope='module')
-def c1_libs(tmp_path_factory, patched_csrc):
-    d = tmp_path_factory.mktemp('emu_c1')
-    return (_compile('emu_conv1d_pc.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so')),
-            _compile('emu_conv1d_pc.cpp', patched_csrc, str(d / 'patched.so')))
+def c1_libs(built):
+    return built('emu_conv1d_pc.cpp', 'tree'), built('emu_conv1d_pc.cpp', 'patched')
 
 
 def _pack_c1(lib, w, dgrad):
@@ -591,10 +600,8 @@ def test_conv1d_pc_on_the_cpu_tree_vs_float64_and_patched_vs_tree(c1_libs, case)
 
 # ------------------------------------------------------------------------------------------------ conv_wgrad (every conv weight-gradient kernel)
 @pytest.fixture(scope='module')
-def wg_libs(tmp_path_factory, patched_csrc):
-    d = tmp_path_factory.mktemp('emu_wg')
-    return (_compile('emu_conv_wgrad.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so')),
-            _compile('emu_conv_wgrad.cpp', patched_csrc, str(d / 'patched.so')))
+def wg_libs(built):
+    return built('emu_conv_wgrad.cpp', 'tree'), built('emu_conv_wgrad.cpp', 'patched')
 
 
 WGRAD = [  # (B, Cin, Cout, F, T, KH, KW, unpool, bf16) -> the kernel conv_wgrad_launch picks
@@ -649,8 +656,8 @@ def test_conv_weight_gradients_on_the_cpu_tree_vs_float64_and_patched_vs_tree(wg
 
 # ------------------------------------------------------------------------------------------------ gru_stack (the persistent scans, blocks concurrent)
 @pytest.fixture(scope='module')
-def gru_lib(tmp_path_factory):
-    lib = _compile('emu_gru_stack.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(tmp_path_factory.mktemp('emu_gru') / 'tree.so'))
+def gru_lib(built):
+    lib = built('emu_gru_stack.cpp')
     lib.hipemu_set_concurrent(1)                 # every workgroup an OS thread: the rings and projection groups hand words to each other
     return lib
 
@@ -763,8 +770,8 @@ def test_persistent_scans_on_the_cpu_forward_and_bptt_vs_float64(gru_lib, case):
 
 # ------------------------------------------------------------------------------------------------ tm_gemm / gru_wgrad (the products around the scans)
 @pytest.fixture(scope='module')
-def rg_lib(tmp_path_factory):
-    return _compile('emu_rnn_gemms.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(tmp_path_factory.mktemp('emu_rg') / 'tree.so'))
+def rg_lib(built):
+    return built('emu_rnn_gemms.cpp')
 
 
 @pytest.mark.parametrize('bf16', [0, 1], ids=['bf16x3', 'bf16'])
@@ -812,15 +819,13 @@ def test_gru_weight_gradients_on_the_cpu_vs_float64(rg_lib):
 # (tests/test_gpu_ops.py, tests/test_gpu_postproc.py), through the same kernels, on the CPU.  Reference: pb_sed/models/weak_label/
 # crnn.py:214-300 (fwd_bwd loss), pb_sed/models/strong_label/crnn.py:94-112, pb_sed/models/base/inference.py:229-283 (filters).
 @pytest.fixture(scope='module')
-def misc_lib(tmp_path_factory):
-    d = tmp_path_factory.mktemp('emu_misc')
-    return _compile('emu_misc.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so'))
+def misc_lib(built):
+    return built('emu_misc.cpp')
 
 
 @pytest.fixture(scope='module')
-def pp_lib(tmp_path_factory):
-    d = tmp_path_factory.mktemp('emu_pp')
-    return _compile('emu_postproc.cpp', os.path.join(ROOT, 'pb_sed_amd', 'csrc'), str(d / 'tree.so'))
+def pp_lib(built):
+    return built('emu_postproc.cpp')
 
 
 F = C.c_float
