@@ -22,6 +22,10 @@ path = sys.argv[1] if os.path.exists(sys.argv[1]) else os.path.join(ROOT, 'tests
 src = open(path).read().replace("'cuda:0'", "'cpu'").replace("'cuda'", "'cpu'")
 sys.argv = [path] + sys.argv[2:]
 mp = pytest.MonkeyPatch()
+for name in ('tests.test_gpu_ops', 'tests.test_gpu_model', 'tests.test_gpu_postproc', 'tests.test_gpu_configs'):     # sweeps that re-use a GPU test's body
+    mod = __import__(name, fromlist=['DEV'])
+    if getattr(mod, 'DEV', None) == 'cuda:0':
+        mod.DEV = 'cpu'
 with tempfile.TemporaryDirectory() as d, cpu_device.emulated_device(mp, cpu_device.EmulatedLibrary(d)):
     exec(compile(src, path, 'exec'), {'__name__': '__main__', '__file__': path})
 mp.undo()
