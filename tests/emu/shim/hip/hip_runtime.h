@@ -5,7 +5,7 @@
 // wave-uniform control flow (they do in these kernels).  Blocks run one after the other.  The amdgcn builtins the kernels call
 // are ordinary functions here.  What this is for: functional equivalence of kernel CHANGES without a GPU (same emulator, two
 // versions of a kernel, bit-identical outputs expected) and a sanity check against a plain float64 restatement - not timing, and
-// not the last bits of MFMA accumulation (the emulator sums a product row in k order in fp32).
+// not the last bits of MFMA accumulation (the emulator sums a product row in double and rounds once).
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sched.h>
+#include <time.h>
 
 #include <algorithm>
 #include <functional>
@@ -90,8 +91,6 @@ struct Idx { unsigned x, y, z; };
 }  // namespace hipemu
 extern thread_local hipemu::Idx threadIdx, blockIdx, blockDim, gridDim;
 
-namespace hipemu {
-}  // namespace hipemu
 // the context switch (hipemu_runtime.cpp): callee-saved registers onto the current stack, its pointer to *save, continue on `load`.
 // (swapcontext costs a sigprocmask system call per switch - the emulator spent nearly all of its time there.)
 extern "C" void hipemu_switch(void** save, void* load);
@@ -288,7 +287,15 @@ static inline void __builtin_amdgcn_raw_buffer_store_b8(unsigned char x, __amdgp
 static inline void __builtin_amdgcn_fence(int, const char*) {}
 static inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_sync(); }     // (the lanes of a wave run one after the other here: the kernels'
                                                                                  // "all lanes read, then all lanes write" points are real rendezvous)
-static inline void __builtin_amdgcn_s_sleep(int) { hipemu::yield(); if (hipemu::g_concurrent) sched_yield(); }     // a spin loop must let the producers run
+// a spin loop must let the producers run: the fiber yields; in concurrent mode the OS thread also gives its core away - once per
+// 64 polls (a wave's worth) with a real sleep, so that a hundred polling workgroups do not starve the few that have work
+static inline void __builtin_amdgcn_s_sleep(int) {
+    hipemu::yield();
+    if (hipemu::g_concurrent) {
+        static thread_local unsigned polls = 0;
+        if ((++polls & 63u) == 0) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+    }
+}
 static inline void __builtin_amdgcn_s_setprio(int) {}
 #ifndef __HIP_MEMORY_SCOPE_AGENT          /* (__hip_atomic_load / _store are clang builtins on every target; the scope names are HIP-mode macros) */
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
