@@ -293,7 +293,7 @@ static inline void __builtin_amdgcn_s_sleep(int) {
     hipemu::yield();
     if (hipemu::g_concurrent) {
         static thread_local unsigned polls = 0;
-        if ((++polls & 63u) == 0) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+        if ((++polls & 63u) == 0) { struct timespec ts = {0, 100000}; nanosleep(&ts, nullptr); }
     }
 }
 static inline void __builtin_amdgcn_s_setprio(int) {}
