@@ -299,6 +299,15 @@ int pbsed_gru_granule_capacity(int H, int bwd, int bf16, int tiles_per_block);
  * does at the first scan of every shape) instead of relying on the built-in defaults. */
 int pbsed_gru_get_poll_delays(int kind, int* out4 /*host*/);
 int pbsed_gru_set_poll_delays(int kind, int fwd, int fwd_gate, int bwd, int bwd_gate);
+/* XCD-local exchange of the BPTT scans.  The last ring of a BPTT scan hands its states over through its XCD's L2 alone
+ * (plain stores, a plain first look) - valid only when all workgroups of that ring run on ONE XCD.  The library verifies the
+ * dispatcher's placement once per device with a probe launch (XCC_ID per workgroup; the exchange stays off on any device
+ * where block ids equal mod 8 do not share an XCD, or fewer than 8 XCDs answer), and every workgroup of such a ring
+ * re-checks its own XCC_ID at launch: a mismatch sets bit 1 (value 2) of the scan's err_flag (bit 0 = a hand-off timed
+ * out).  on = 0 switches the exchange off for the process (callers do on seeing bit 1; PBSED_GRU_XCD_LOCAL=0 does the
+ * same from the environment), on = 1 allows it again.  Returns the previous setting.  Replaces nothing in the reference
+ * (torch.nn.GRU has no such knob: pb_sed/models/weak_label/crnn.py:61-67). */
+int pbsed_gru_set_xcd_local(int on);
 /* Diagnostics of the persistent scans: the scans launched after this call write shader-clock stamps of workgroup `block`
  * (1-D index of the launch), scan steps 200..231, to buf[32][16] (device, 4 KB) - slots 0..4: first contraction wave at the top
  * of the step / first poll issued / poll satisfied / partial sums written / past the barrier; 5: poll attempts that missed;

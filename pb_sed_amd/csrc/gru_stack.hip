@@ -12,6 +12,7 @@
 // pb_sed/models/weak_label/crnn.py:61-67,338-340 (config training.py:243-248).
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "common.h"
 #include "gru_granule_map.h"
@@ -46,6 +47,8 @@ struct GruStackArgs {
     int local;            // 1 (BPTT with the ring-per-XCD mapping): the LAST ring in scan order - no projection group reads it, its
                           // only readers are its own blocks on its own XCD, whose L2 is their coherence point - publishes its state
                           // with a PLAIN store and looks at it first with a PLAIN load; only retries bypass the L1 (sc1)
+    unsigned xcc_map;     // local = 1: the XCC_ID the placement probe saw for block ids = r (mod 8), four bits per residue r
+                          // (xcd_placement below); a block of the local ring whose own XCC_ID differs raises error bit 2
     unsigned long long* prof;   // diagnostics (pbsed_gru_set_prof): shader-clock stamps of block `prof_block`, steps 200..231
     int prof_block;
 };
@@ -307,6 +310,15 @@ __device__ __forceinline__ void publish_local(gu32* p, float v_cleared, unsigned
     __hip_atomic_store(p, __float_as_uint(v_cleared) | parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// The XCD this wave runs on: XCC_ID[3:0] of HW_REG_XCC_ID (hardware register 20 on gfx942 / gfx950).
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u; }
+
+// Error word of a scan: bit 0 = a hand-off timed out, bit 1 = a block of an XCD-local ring found itself on another XCD than
+// the placement probe promised (its plain stores then never reach its readers' L2: the time-out that follows has a cause).
+__device__ __forceinline__ void raise_error(unsigned* err_flag, unsigned bit) {
+    __hip_atomic_fetch_or((gu32*)err_flag, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // First-poll pacing.  Polls that come before the data only add fabric traffic and slow everybody's hand-off down (two
 // batches in flight per wave: 2x slower scans), and a missed first poll costs a full round trip.  The waves that do
 // not take part in the gate phase reach the next step's poll a gate phase early, the gate waves one store-to-visible
@@ -356,7 +368,7 @@ __device__ __forceinline__ int poll_batch(float4 (&out)[NL], __amdgpu_buffer_rsr
         }
         if (__all(ok)) break;
         if (spin > (1 << 18)) {                     // bounded: raise the error flag and go on with garbage
-            __hip_atomic_store((gu32*)err_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            raise_error(err_flag, 1u);
             break;
         }
         if (spin > 8) __builtin_amdgcn_s_sleep(1);
@@ -405,7 +417,7 @@ __device__ __forceinline__ void wait_own_granules(unsigned (&q)[NQ], const gu32*
         for (int i = 0; i < NQ; ++i) ok = ok && (q[i] & 1u) == parity;
         if (ok) break;
         if (spin > (1 << 18)) {
-            __hip_atomic_store((gu32*)err_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            raise_error(err_flag, 1u);
             break;
         }
         if (spin > 8) __builtin_amdgcn_s_sleep(1);
@@ -457,7 +469,7 @@ __device__ __forceinline__ int poll_tiles(float4 (&out)[NB][NL], __amdgpu_buffer
         const bool ok = parity ? (all1 & 1u) != 0u : (any1 & 1u) == 0u;
         if (__all(ok)) break;
         if (spin > (1 << 18)) {                     // bounded: raise the error flag and go on with garbage
-            __hip_atomic_store((gu32*)err_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            raise_error(err_flag, 1u);
             break;
         }
         if (spin > 8) __builtin_amdgcn_s_sleep(1);
@@ -713,6 +725,8 @@ __device__ __forceinline__ void gru_granule_bwd_body(const GruStackArgs& a, unsi
     const bool is_proj = role.gid & 1;
     const int layer = top - ((role.gid + 1) >> 1);    // ring: its layer; projection: the layer it produces dy for
     const bool ring_local = a.local && !is_proj && layer == 0;      // the bottom layer's ring: nobody else reads its dh
+    // its plain stores are only seen inside ONE L2: every block of it checks that it runs where the placement probe said
+    if (ring_local && threadIdx.x == 0 && xcc_id() != ((a.xcc_map >> (4 * (blockIdx.x & 7u))) & 15u)) raise_error(err_flag, 2u);
     const GruStackLayer& L = a.lc[chain][layer];
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) - GWV, lq = lane >> 4, lr = lane & 15;
     const bool is_mfma = wave >= 0;
@@ -966,7 +980,49 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
 // blocks of that XCD out (found by tests/sweeps/fuzz_gru.py: H = 512, B = 16).  The caller then keeps the 3-D grid, whose
 // blocks spread evenly over the XCDs.
 // nb: 16-row batch tiles per block
-static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid, int nb = 1, bool bwd = false) {
+//
+// XCD placement probe (once per device): the XCD-local exchange below is only CORRECT when all workgroups of a ring - block
+// ids that are equal mod 8 - run on one XCD.  That is how the dispatcher of an 8-XCD device in SPX mode deals a kernel's
+// workgroups (MI355X_MICROARCH.md), but it is a property of the device configuration (6-XCD parts, CPX / DPX partitions and
+// CU masks differ), so it is observed instead of assumed: one launch of device_cus() single-wave blocks, each recording its
+// XCC_ID; local is enabled only if eight distinct XCDs show up and XCC_ID is a function of block id mod 8.  The map goes to
+// the scan (GruStackArgs::xcc_map), whose local-ring blocks re-check their own placement at every launch (error bit 2).
+__global__ void xcc_probe_kernel(unsigned* out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
+}
+static int g_xcd_local_allowed = 1;                   // pbsed_gru_set_xcd_local
+static int g_xcd_state[64] = {0};                     // per device ordinal: 0 not probed, 1 verified, -1 refused
+static bool xcd_placement(hipStream_t s, unsigned* map) {
+    int (&state)[64] = g_xcd_state;
+    static unsigned maps[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (state[dev] == 0) {
+        state[dev] = -1;
+        const int n = device_cus() < 64 ? 64 : device_cus();
+        unsigned* d = nullptr;
+        std::vector<unsigned> h(n, 0xffu);
+        if (hipMalloc(&d, n * sizeof(unsigned)) == hipSuccess) {
+            hipLaunchKernelGGL(xcc_probe_kernel, dim3(n), dim3(64), 0, s, d);
+            const bool ran = hipMemcpyAsync(h.data(), d, n * sizeof(unsigned), hipMemcpyDeviceToHost, s) == hipSuccess &&
+                             hipStreamSynchronize(s) == hipSuccess;
+            (void)hipFree(d);
+            unsigned seen = 0, m = 0;
+            bool periodic = ran;
+            for (int i = 0; i < n && periodic; ++i) {
+                periodic = h[i] < 16u && h[i] == h[i & 7];
+                seen |= 1u << (h[i] & 15u);
+            }
+            for (int r = 0; r < 8; ++r) m |= (h[r] & 15u) << (4 * r);
+            if (periodic && __builtin_popcount(seen) == 8) { state[dev] = 1; maps[dev] = m; }
+        }
+    }
+    *map = maps[dev];
+    return state[dev] == 1;
+}
+
+static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid, hipStream_t s, int nb = 1, bool bwd = false) {
     const int cus_per_xcd = device_cus() / 8;           // per device ordinal (common.h)
     const int nby = (a.B + 16 * nb - 1) / (16 * nb), nj = H / 16;
     const int R = a.nchains * a.nlayers * nby, P = a.nchains * (a.nlayers - 1) * nby;
@@ -980,8 +1036,9 @@ static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid, int nb = 1, boo
     // 2.376 -> 2.273 ms per two launches; the FORWARD scans do not gain (0.937 -> 0.943, 1.550 -> 1.577: an early sc1 poll is
     // parked at the L2 until the write-through store it raced completes and returns at once - a plain look cannot be parked,
     // it returns the stale line and pays a retry) and keep the sc1 exchange.
+    // Only where the placement probe has SEEN the ring-per-XCD placement on this device (xcd_placement above).
     static const bool local_off = getenv("PBSED_GRU_XCD_LOCAL") && getenv("PBSED_GRU_XCD_LOCAL")[0] == '0';
-    a.local = (bwd && !local_off) ? 1 : 0;
+    a.local = (bwd && !local_off && g_xcd_local_allowed && xcd_placement(s, &a.xcc_map)) ? 1 : 0;
     return true;
 }
 
@@ -1078,7 +1135,7 @@ static int gru_stack_fwd_granule_impl(int nchains, int nlayers, const float* con
                   grid.x * grid.y * grid.z, granule_capacity(false, H, bf16, nb));
         return PBSED_E_UNSUPPORTED;
     }
-    granule_xcd_grid(a, H, &grid, nb);                    // one ring per XCD when every XCD can hold its share (else the 3-D grid)
+    granule_xcd_grid(a, H, &grid, (hipStream_t)stream, nb);                    // one ring per XCD when every XCD can hold its share (else the 3-D grid)
     unsigned* gran_gi = granules + (size_t)nchains * nlayers * T * Bp * H;
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_GW(KB_, NW_, X3_, NB_)                                                                                  \
@@ -1143,7 +1200,7 @@ static int gru_stack_bwd_granule_impl(int nchains, int nlayers, const float* con
                   grid.x * grid.y * grid.z, granule_capacity(true, H, bf16, 1));
         return PBSED_E_UNSUPPORTED;
     }
-    granule_xcd_grid(a, H, &grid, 1, true);
+    granule_xcd_grid(a, H, &grid, (hipStream_t)stream, 1, true);
     unsigned* gran_dy = granules + (size_t)nchains * nlayers * T * Bp * H;
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_GRANULE(KB_, NW_)                                                                                     \
@@ -1240,6 +1297,16 @@ int pbsed_gru_set_prof(unsigned long long* buf, int block) {
     g_prof_buf = buf;
     g_prof_block = block;
     return PBSED_OK;
+}
+
+// The XCD-local exchange of the BPTT scans (GruStackArgs::local): on = 0 switches it off for the process (every ring then
+// exchanges through write-through stores and sc1 loads, correct under any workgroup placement), on = 1 allows it again where
+// the placement probe (run anew) verifies the device.  The caller turns it off when a scan reports error bit 2.  Returns the old value.
+int pbsed_gru_set_xcd_local(int on) {
+    const int old = g_xcd_local_allowed;
+    g_xcd_local_allowed = on != 0;
+    if (on) for (int& st : g_xcd_state) st = 0;       // allowed again: every device is probed anew at its next BPTT scan
+    return old;
 }
 
 int pbsed_gru_get_poll_delays(int kind, int* out4 /*host*/) {

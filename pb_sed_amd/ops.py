@@ -725,11 +725,20 @@ def _gru_err_flag(device):
 def gru_flags_raise(host_words):
     """``host_words``: a host copy of gru_flags()[0].  Drops the scan workspaces (they hold words of mixed parity after
     a time-out) and raises if any word is set."""
-    if np.any(np.asarray(host_words)):
+    words = np.asarray(host_words)
+    if np.any(words):
         _GRANULE_WS.clear()
         for st in _GRU_FLAGS.values():
             st[0].zero_()
             st[1] = 0
+        if np.any(words & 2):
+            # a workgroup of an XCD-local ring ran on another XCD than the library's placement probe saw (include/pbsed.h,
+            # pbsed_gru_set_xcd_local): that exchange is off from here on, the scans use the placement-independent one
+            _lib.lib().pbsed_gru_set_xcd_local(0)
+            raise RuntimeError('persistent GRU scan: a workgroup of an XCD-local ring was dispatched to another XCD than the '
+                               'placement probe observed (partition mode / CU mask changed?); this step\'s results were '
+                               'discarded (the optimiser update was skipped on the device) and the XCD-local exchange is '
+                               'now off for this process (PBSED_GRU_XCD_LOCAL=0 does the same from the start).')
         raise RuntimeError('persistent GRU scan: inter-workgroup hand-off timed out; this step\'s results were discarded '
                            '(the optimiser update was skipped on the device).  PBSED_GRU_PERSIST=0 selects the '
                            'launch-per-step scans.')

@@ -111,22 +111,23 @@ class LibraryGradSync:
             if rank == 0:
                 try:
                     box[0] = self._comm.unique_id()
-                except (RuntimeError, OSError) as ex:
+                except Exception as ex:                             # ANY failure: the broadcast below must still be reached
                     err = ex
             if grouped:
                 dist.broadcast_object_list(box, src=0)              # None = rank 0 could not make one
             unique_id = box[0]
-            if unique_id is None:
+            if unique_id is None:                                   # every rank sees None: every rank raises, nobody waits
                 raise RuntimeError(f'library communicator: no unique id from rank 0 ({err})')
-        assert len(unique_id) == self._comm.id_bytes()
         try:
+            if len(unique_id) != self._comm.id_bytes():
+                raise RuntimeError(f'library communicator: unique id of {len(unique_id)} bytes, expected {self._comm.id_bytes()}')
             self._comm.create(unique_id, rank, world)
-        except (RuntimeError, OSError) as ex:
+        except Exception as ex:                                     # a missing symbol, a bad id, RCCL: all reach the agreement
             err = ex
         if grouped and not self._agree(err is None):
             if err is None:                                         # up here, not everywhere: take it down again
                 self._comm.destroy()
-            raise RuntimeError(f'library communicator not created on every rank ({err or "another rank failed"})')
+            raise RuntimeError(f'library communicator not created on every rank ({err or "another rank failed"})') from err
         if err is not None:
             raise err
         self._done = set()
@@ -436,7 +437,9 @@ class Trainer:
         'optimizer'}``; pb_sed/experiments/weak_label_crnn/inference.py:407-413 reads ``ckpt['model']`` through
         ``Model.from_storage_dir``): the model's state_dict under the reference's parameter / buffer names and Adam's state
         as a ``torch.optim.Adam`` state_dict over ``model.parameters()`` in order (exp_avg / exp_avg_sq views of the flat moment
-        buffers, ``step`` = the iteration), so that the reference's trainer - or ``torch.optim.Adam.load_state_dict`` - can take it."""
+        buffers, ``step`` = the iteration), so that ``torch.optim.Adam.load_state_dict`` can take the 'optimizer' entry as it is.
+        ('hooks', the per-hook state padertorch's trainer also writes, is carried as an empty dict: this trainer has no hooks with
+        state.  Whether padertorch's ``Trainer.load_checkpoint`` accepts the file is NOT verified - padertorch is not installed.)"""
         self.finish()
         params = list(self.model.parameters())
         state = {i: {'step': torch.tensor(float(self.iteration)),
@@ -447,7 +450,7 @@ class Trainer:
                  'params': list(range(len(params)))}
         return {'model': {k: v.detach().clone().cpu() for k, v in self.model.state_dict().items()},
                 'iteration': self.iteration, 'epoch': getattr(self, 'epoch', 0),
-                'optimizer': {'state': state if self.iteration else {}, 'param_groups': [group]}}
+                'optimizer': {'state': state if self.iteration else {}, 'param_groups': [group]}, 'hooks': {}}
 
     def load_state_dict(self, ckpt):
         """Resume from ``state_dict()`` output or from a padertorch trainer checkpoint of the same model (Adam state keyed by
@@ -483,5 +486,9 @@ class Trainer:
             torch.save(self.state_dict(), path)
         return path
 
-    def load_checkpoint(self, path, map_location='cpu'):
-        self.load_state_dict(torch.load(path, map_location=map_location, weights_only=False))
+    def load_checkpoint(self, path, map_location='cpu', trusted_pickle=False):
+        """Resume from a file ``save_checkpoint`` wrote.  Loaded with ``weights_only=True``: ``state_dict()`` holds tensors,
+        numbers, tuples, lists and dicts only, so nothing in such a file needs the unpickler to construct objects - and a file
+        from somewhere else cannot run code here.  ``trusted_pickle=True`` is the explicit opt-out for a legacy padertorch
+        trainer checkpoint that pickled other objects (hook state, numpy scalars): only for files whose origin is known."""
+        self.load_state_dict(torch.load(path, map_location=map_location, weights_only=not trusted_pickle))

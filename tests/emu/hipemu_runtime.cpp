@@ -37,6 +37,7 @@ hipemu_switch:
 namespace hipemu {
 thread_local Runtime* tls_rt = nullptr;
 int g_concurrent = 0;
+int g_xcc_mode = 0;
 
 void trampoline() {
     Runtime& r = rt();
@@ -126,3 +127,4 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 }
 }  // namespace hipemu
 extern "C" void hipemu_set_concurrent(int on) { hipemu::g_concurrent = on; }
+extern "C" void hipemu_set_xcc_mode(int mode) { hipemu::g_xcc_mode = mode; }

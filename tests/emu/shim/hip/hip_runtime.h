@@ -55,6 +55,8 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s_, size_t n, int, 
 struct hipDeviceProp_t { int multiProcessorCount = HIPEMU_CUS; };
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t{}; return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+enum { hipMemcpyDeviceToHost = 2 };
 template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)malloc(n); return *p ? hipSuccess : 2; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 1; return hipSuccess; }
@@ -297,6 +299,14 @@ static inline void __builtin_amdgcn_s_sleep(int) {
     }
 }
 static inline void __builtin_amdgcn_s_setprio(int) {}
+// s_getreg_b32 is only used for HW_REG_XCC_ID (the XCD a wave runs on).  Mode 0: the dispatcher of an 8-XCD device in SPX mode
+// (block id mod 8); 1: one XCD for everybody (a CPX partition); 2: pairs of consecutive blocks share an XCD (a placement that is
+// NOT a function of id mod 8) - hipemu_set_xcc_mode, for the tests of the placement probe and of the scans' own check.
+namespace hipemu { extern int g_xcc_mode; }
+static inline unsigned __builtin_amdgcn_s_getreg(int) {
+    const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    return hipemu::g_xcc_mode == 1 ? 0u : hipemu::g_xcc_mode == 2 ? (id >> 1) & 7u : id & 7u;
+}
 #ifndef __HIP_MEMORY_SCOPE_AGENT          /* (__hip_atomic_load / _store are clang builtins on every target; the scope names are HIP-mode macros) */
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2

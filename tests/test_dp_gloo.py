@@ -267,18 +267,19 @@ def test_library_gradsync_bucket_logic_with_a_stand_in_communicator_world2(tmp_p
 
 
 class _FailingComm(_RecordingComm):
-    def __init__(self, flat, fail_id=False, fail_create=False):
+    def __init__(self, flat, fail_id=False, fail_create=False, exc=RuntimeError, short_id=False):
         super().__init__(flat)
-        self.fail_id, self.fail_create = fail_id, fail_create
+        self.fail_id, self.fail_create, self.exc, self.short_id = fail_id, fail_create, exc, short_id
 
     def unique_id(self):
         if self.fail_id:
-            raise RuntimeError('ncclGetUniqueId failed (test)')
-        return super().unique_id()
+            raise self.exc('ncclGetUniqueId failed (test)')
+        uid = super().unique_id()
+        return uid[:-1] if self.short_id else uid
 
     def create(self, unique_id, rank, world):
         if self.fail_create:
-            raise RuntimeError('ncclCommInitRank failed (test)')
+            raise self.exc('ncclCommInitRank failed (test)')
         super().create(unique_id, rank, world)
 
 
@@ -291,8 +292,12 @@ def _library_failure_worker(rank, world, port, out_dir):
     ok = True
     # (1) rank 0 cannot make the unique id; (2) the communicator comes up on rank 0 only: in both cases EVERY rank must
     # raise (same control collectives everywhere), and the one that came up is taken down again
-    for fail_id, fail_create in ((rank == 0, False), (False, rank == 1)):
-        comm = _FailingComm(g, fail_id, fail_create)
+    # (3) / (4) ADVICE r5: failures that are NOT RuntimeError / OSError - a symbol missing from the library on one rank
+    # (AttributeError from ctypes), an id of the wrong length - reach the same agreement instead of stranding the other rank
+    for fail_id, fail_create, exc, short_id in ((rank == 0, False, RuntimeError, False), (False, rank == 1, RuntimeError, False),
+                                                (rank == 0, False, AttributeError, False), (False, rank == 1, AttributeError, False),
+                                                (False, False, RuntimeError, rank == 0)):
+        comm = _FailingComm(g, fail_id, fail_create, exc, short_id)
         try:
             trainer.LibraryGradSync(g, [(0, 100)], comm=comm)
             ok = False

@@ -768,6 +768,61 @@ def test_persistent_scans_on_the_cpu_forward_and_bptt_vs_float64(gru_lib, case):
             assert np.abs(dgh[c][l] - ref_dgh[c][l]).max() < 1e-5 * scale, (c, l)
 
 
+def test_xcd_local_exchange_is_gated_by_the_placement_probe_and_checked_in_the_kernel(gru_lib):
+    """The XCD-local BPTT exchange (GruStackArgs::local) is correct only if all workgroups of a ring share an XCD.  The library
+    OBSERVES that: a probe launch per device records every workgroup's XCC_ID (here: the shim's placement models,
+    hipemu_set_xcc_mode) and the exchange is enabled only for an 8-XCD placement that is a function of block id mod 8; the ring's
+    workgroups re-check their own XCC_ID at every launch and set bit 1 of the error word when it is not what the probe saw.
+    (i) round-robin placement: local on, no error; (ii) a one-XCD partition: the probe refuses, the scan runs with the
+    placement-independent exchange and gives the SAME bits; (iii) placement changes behind a verified probe: error word 2."""
+    nch, nl, b, h, t = 2, 2, 5, 64, 6
+    rng = np.random.RandomState(11)
+    seq = np.array([6, 6, 5, 4, 3], np.int32)
+    rev = np.array([0, 1], np.int32)
+    k = 1 / np.sqrt(h)
+    u = lambda *s: rng.uniform(-k, k, s).astype(np.float32)
+    flat = lambda m: [m[c][l] for c in range(nch) for l in range(nl)]
+    w_hh_t = [[u(h, 3 * h) for _ in range(nl)] for _ in range(nch)]
+    w_ih_up_t = [[u(h, 3 * h) if l + 1 < nl else None for l in range(nl)] for _ in range(nch)]
+    hs = [[u(t, b, h) for _ in range(nl)] for _ in range(nch)]
+    save = [[u(t, b, 5 * h) for _ in range(nl)] for _ in range(nch)]
+    dy_top = [rng.randn(t, b, h).astype(np.float32) for _ in range(nch)]
+    bp = 16
+
+    def bptt():
+        dgi = [[np.full((t, b, 3 * h), np.nan, np.float32) for _ in range(nl)] for _ in range(nch)]
+        dgh = [[np.full((t, b, 3 * h), np.nan, np.float32) for _ in range(nl)] for _ in range(nch)]
+        gran = np.zeros(nch * t * bp * h * (2 * nl - 1), np.uint32)
+        err = np.zeros(1, np.uint32)
+        rc = gru_lib.pbsed_gru_stack_bwd_granule(nch, nl, _table(flat(w_hh_t)), _table(flat(w_ih_up_t)), _table(flat(hs)),
+                                                 _table(flat(save)), _table(dy_top), _table(flat(dgi)), _table(flat(dgh)), P(rev), P(seq),
+                                                 b, h, t, P(gran), 1, P(err), None)
+        assert rc == 0
+        return int(err[0]), np.stack(flat(dgi) + flat(dgh))
+
+    try:
+        gru_lib.hipemu_set_xcc_mode(0)
+        gru_lib.pbsed_gru_set_xcd_local(1)                # allowed, probed anew at the next BPTT scan
+        e0, r0 = bptt()
+        assert e0 == 0 and np.isfinite(r0).all()
+        gru_lib.hipemu_set_xcc_mode(1)                    # every workgroup reports XCD 0
+        gru_lib.pbsed_gru_set_xcd_local(1)
+        e1, r1 = bptt()
+        assert e1 == 0 and np.array_equal(r0, r1)         # probe refused: sc1 exchange, the same truncated states
+        gru_lib.hipemu_set_xcc_mode(0)
+        gru_lib.pbsed_gru_set_xcd_local(1)
+        assert bptt()[0] == 0                             # verified under the round-robin placement ...
+        gru_lib.hipemu_set_xcc_mode(2)                    # ... which then changes behind the library's back
+        e2, _ = bptt()
+        assert e2 & 2, e2
+        assert gru_lib.pbsed_gru_set_xcd_local(0) == 1    # what ops.gru_flags_raise does on seeing bit 1
+        e3, r3 = bptt()
+        assert e3 == 0 and np.array_equal(r0, r3)
+    finally:
+        gru_lib.hipemu_set_xcc_mode(0)
+        gru_lib.pbsed_gru_set_xcd_local(1)
+
+
 # ------------------------------------------------------------------------------------------------ tm_gemm / gru_wgrad (the products around the scans)
 @pytest.fixture(scope='module')
 def rg_lib(built):
