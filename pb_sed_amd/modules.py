@@ -7,6 +7,7 @@ describe the layer tables; all arithmetic is done by the HIP kernels driven from
 ``pb_sed_amd.engine``.  Reference call sites: pb_sed/models/weak_label/crnn.py:86-100.
 """
 import math
+import re
 
 import numpy as np
 import torch
@@ -272,6 +273,40 @@ def plan_residuals(ndim, residual_connections, in_channels, out_channels, pool_s
     return [None if d is None else (d[0] if isinstance(d, (list, tuple)) else d) for d in residual_connections], skips
 
 
+def canonical_state_dict(state_dict, own):
+    """A flat reference-written ``state_dict`` under THIS build's names and shapes, for code that matches keys itself
+    (trainer.load_init_checkpoint; ``Module.load_state_dict`` does the same through the ``_load_from_state_dict`` overrides):
+    skip convolutions ``residual_skip_convs.<s>-><d>.conv.*`` -> ``skip_convs.<s>_<d>.*`` (_CNN._REF_SKIP), a Normalization's
+    ``scale`` / ``shift`` -> ``gamma`` / ``beta``, tensors padertorch keeps in the broadcast shape of the normalised tensor
+    ([1,C,1,1] / [1,C,1]) flattened to ``own``'s shape.  ``own``: the target's ``state_dict()`` (names and shapes only)."""
+    out = {}
+    for k, v in state_dict.items():
+        m = re.match(r'^(.*\.)?residual_skip_convs\.(\d+)->(\d+)\.conv\.(weight|bias)$', k)
+        if m:
+            k = f'{m.group(1) or ""}skip_convs.{m.group(2)}_{m.group(3)}.{m.group(4)}'
+        elif k.endswith('.norm.scale') and k[:-5] + 'gamma' in own and k[:-5] + 'gamma' not in state_dict:
+            k = k[:-5] + 'gamma'
+        elif k.endswith('.norm.shift') and k[:-5] + 'beta' in own and k[:-5] + 'beta' not in state_dict:
+            k = k[:-5] + 'beta'
+        if k in own and torch.is_tensor(v) and tuple(v.shape) != tuple(own[k].shape) and v.numel() == own[k].numel() \
+                and sorted(d for d in v.shape if d != 1) == sorted(d for d in own[k].shape if d != 1):
+            v = v.reshape(own[k].shape)              # only singleton axes differ
+        out[k] = v
+    return out
+
+
+def reference_state_dict(model):
+    """``model.state_dict()`` under the reference's (padertorch's) parameter names where this build's differ: the skip
+    convolutions of residual stacks (``skip_convs.<src>_<dst>.weight`` -> ``residual_skip_convs.<src>-><dst>.conv.weight``, see
+    _CNN._REF_SKIP).  Everything else already carries the reference's names (``convs.<i>.conv.weight``, ``convs.<i>.norm.gamma``,
+    ``rnn_fwd.rnn.weight_ih_l0`` ...).  The inverse is built into loading: both spellings are accepted."""
+    out = {}
+    for k, v in model.state_dict().items():
+        m = re.match(r'^(.*\.)?skip_convs\.(\d+)_(\d+)\.(weight|bias)$', k)
+        out[f'{m.group(1) or ""}residual_skip_convs.{m.group(2)}->{m.group(3)}.conv.{m.group(4)}' if m else k] = v
+    return out
+
+
 class _CNN(nn.Module):
     ndim = None
 
@@ -313,6 +348,25 @@ class _CNN(nn.Module):
         self.out_norm = Normalization(cin, eps=eps) if final_norm else None
         self.residual_connections, self.skip_convs = plan_residuals(
             self.ndim, residual_connections, in_channels, self.out_channels, ps, pre_activation)
+
+    # padertorch's spelling of the skip convolutions of a stack with residual connections (the 'deep' net_config of
+    # pb_sed/experiments/weak_label_crnn/training.py:170-183): its _CNN keeps them in ``residual_skip_convs``, a ModuleDict
+    # keyed '<src>-><dst>', each a conv block whose convolution is the attribute ``conv`` (as in ``convs.<i>.conv``), so a
+    # reference checkpoint carries ``<stack>.residual_skip_convs.<src>-><dst>.conv.{weight,bias}`` where this build has
+    # ``<stack>.skip_convs.<src>_<dst>.{weight,bias}``.  padertorch is not vendored: the spelling is restated from its
+    # source as remembered (parity unpinned, like the Normalization names above) - both spellings load, reference_state_dict
+    # writes the reference's.
+    _REF_SKIP = re.compile(r'^residual_skip_convs\.(\d+)->(\d+)\.conv\.(weight|bias)$')
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for key in [k for k in state_dict if k.startswith(prefix + 'residual_skip_convs.')]:
+            m = self._REF_SKIP.match(key[len(prefix):])
+            if m is None:
+                continue                                 # (e.g. a norm inside the skip block: left for strict loading to report)
+            ours = f'{prefix}skip_convs.{m.group(1)}_{m.group(2)}.{m.group(3)}'
+            if ours not in state_dict:
+                state_dict[ours] = state_dict.pop(key)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def freeze(self, num_layers=None, freeze_norm_stats=True):
         layers = self.convs if num_layers is None else self.convs[:num_layers]

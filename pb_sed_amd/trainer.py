@@ -221,8 +221,12 @@ def load_init_checkpoint(model, state_dict):
     parameter / buffer names are the reference's (``cnn.cnn_2d.convs.<i>.conv.weight``, ``...norm.gamma|beta|
     running_mean|running_power``, ``rnn_fwd.rnn.weight_ih_l0`` ...), so a ``torch.load(path)['model']`` dict written by
     the reference's trainer is accepted as is.  Buffers the build does not keep are ignored; missing or mis-shaped
-    tensors of the loaded parts raise."""
+    tensors of the loaded parts raise.  A 'deep' reference model's skip convolutions (``residual_skip_convs.<s>-><d>.conv.*``,
+    training.py:170-183) and padertorch's broadcast-shaped normalisation tensors are taken under this build's names / shapes
+    (modules.canonical_state_dict), so `tuning.py:38`-style reuse of a 'deep' checkpoint works too."""
     own = model.state_dict()
+    from .modules import canonical_state_dict
+    state_dict = canonical_state_dict(state_dict, own)
 
     def sub(prefix):
         return {k: v for k, v in state_dict.items() if k.startswith(prefix)}

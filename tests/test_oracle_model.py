@@ -107,6 +107,51 @@ def test_load_init_checkpoint_surgery():
         load_init_checkpoint(dst, broken)
 
 
+def test_deep_reference_checkpoint_names_load():
+    """a reference 'deep' model (residual connections across channel changes,
+    pb_sed/experiments/weak_label_crnn/training.py:170-183) keeps its skip convolutions under padertorch's names -
+    ``<stack>.residual_skip_convs.<src>-><dst>.conv.{weight,bias}`` - and its normalisation tensors in broadcast shape.  A synthetic
+    state_dict under those names loads through ``load_state_dict`` (strict) and through the init-checkpoint surgery of
+    training.py:327-342; ``reference_state_dict`` writes the same names back.  (padertorch is not installed: the spelling is a
+    restatement, see modules._CNN._REF_SKIP.)"""
+    from pb_sed_amd import modules
+    from pb_sed_amd.models import weak_label
+    from pb_sed_amd.trainer import load_init_checkpoint
+    net = dict(out_channels_2d=[8, 8, 16, 16, 16], pool_sizes_2d=[1, (2, 1), 1, (2, 1), 1], kernel_size_2d=[3, 1, 3, 1, 3],
+               residual_connections_2d=[None, 3, None, None, None], out_channels_1d=[32, 48, 48], kernel_size_1d=[1, 3, 1],
+               residual_connections_1d=[None, 2, None])
+    kw = dict(num_events=6, number_of_filters=32, stft_size=512, hidden_size=64, num_layers=1, net=net)
+    torch.manual_seed(3)
+    src = weak_label.CRNN.build(**kw)
+    own_names = src.state_dict()
+    assert {'cnn.cnn_2d.skip_convs.1_3.weight', 'cnn.cnn_1d.skip_convs.1_2.bias'} <= set(own_names)
+    ref = {}
+    for k, v in modules.reference_state_dict(src).items():
+        if '.norm.' in k and v.dim() == 1 and 'feature_extractor' not in k:
+            v = v.reshape((1, -1, 1, 1) if 'cnn_2d' in k else (1, -1, 1))          # padertorch's broadcast shape
+        ref[k] = v.clone()
+    assert 'cnn.cnn_2d.residual_skip_convs.1->3.conv.weight' in ref and not any('.skip_convs.' in k for k in ref)
+    for loader in ('load_state_dict', 'init_checkpoint'):
+        torch.manual_seed(4)
+        dst = weak_label.CRNN.build(**kw)
+        assert not torch.equal(dst.state_dict()['cnn.cnn_2d.skip_convs.1_3.weight'], own_names['cnn.cnn_2d.skip_convs.1_3.weight'])
+        if loader == 'load_state_dict':
+            dst.load_state_dict({k: v.clone() for k, v in ref.items()})           # strict: nothing missing, nothing unexpected
+        else:
+            loaded = load_init_checkpoint(dst, {k: v.clone() for k, v in ref.items()})
+            assert 'cnn.cnn_2d.skip_convs.1_3.weight' in loaded and 'cnn.cnn_1d.skip_convs.1_2.bias' in loaded
+        got = dst.state_dict()
+        for k, v in own_names.items():
+            if loader == 'init_checkpoint' and not k.startswith(('cnn.', 'rnn_fwd.rnn.', 'rnn_bwd.rnn.')):
+                continue
+            assert torch.equal(got[k], v), (loader, k)
+    # an unknown entry inside a skip block is reported by strict loading, not swallowed
+    bad = dict(ref)
+    bad['cnn.cnn_2d.residual_skip_convs.1->3.norm.gamma'] = torch.ones(16)
+    with pytest.raises(RuntimeError):
+        weak_label.CRNN.build(**kw).load_state_dict(bad)
+
+
 def _decision_net():
     net = dict(out_channels_2d=[8, 8, 16, 16], pool_sizes_2d=[1, (2, 1), 1, (2, 1)], kernel_size_2d=3,
                out_channels_1d=[32, 32], kernel_size_1d=[1, 3], residual_connections_2d=[None, 3, None, None],
