@@ -152,10 +152,40 @@ def _cpu_threads():
     return n
 
 
+_ALLOCATOR = None
+
+
+def _tune_host_allocator():
+    """glibc malloc as a CPU training run would set it up (MALLOC_MMAP_MAX_=0, MALLOC_TRIM_THRESHOLD_ / MALLOC_TOP_PAD_ large; here through
+    mallopt, because the process is already running): big tensors are recycled from the heap instead of being mmap'ed, page-faulted
+    and unmapped on every use.  Why it matters for THIS baseline (measured): torch's CPU GRU over a packed
+    sequence runs its recurrence as 500 autograd slices per (layer, direction) and every SliceBackward materialises a zero buffer of
+    the whole [T*B, 3H] gradient - 49 MB at batch 32, 2 000 of them per train step.  glibc's dynamic mmap threshold stops at 32 MB:
+    the 24.5 MB buffers of batch 16 are recycled from the heap, the 49 MB ones of batch 32 are mapped anew each time - 19 M page
+    faults and 70 s of kernel time per step on 8 cores (24.8 s per step against 8.0 s with this setting; batch 16: 5.4 -> 4.5 s).
+    That cliff, not thread oversubscription, made batch 32 cost 4.4x batch 16 per clip in round 5 and the figure move 5x between
+    hosts.  The tuned allocator is the FASTER baseline, i.e. the less flattering one for the GPU."""
+    global _ALLOCATOR
+    if _ALLOCATOR is None:
+        try:
+            import ctypes
+            libc = ctypes.CDLL('libc.so.6')
+            ok = [libc.mallopt(-4, 0),                      # M_MMAP_MAX = 0: no mmap'ed chunks
+                  libc.mallopt(-1, 2 ** 31 - 1),            # M_TRIM_THRESHOLD: the heap top is not given back
+                  libc.mallopt(-2, 256 << 20)]              # M_TOP_PAD: grow the heap 256 MB at a time
+            _ALLOCATOR = 'glibc mallopt(M_MMAP_MAX=0, M_TRIM_THRESHOLD=2^31-1, M_TOP_PAD=256MB)' if all(ok) else 'default (mallopt refused)'
+        except (OSError, AttributeError):
+            _ALLOCATOR = 'default (no glibc mallopt)'
+    return _ALLOCATOR
+
+
 def cpu_train_baseline(kind, batches=(32, 16), steps=3):
-    """Oracle train step (stock PyTorch CPU ops) on this host's cores, per-stage breakdown; the checker timed as baseline."""
+    """Oracle train step (stock PyTorch CPU ops) on this host's cores, per-stage breakdown; the checker timed as baseline.
+    The first batch size is the headline leg: 1 warm-up + `steps` timed steps, no time cap short of a step that takes over a
+    minute; the other legs are bounded samples (60 s)."""
     from oracle import frontend as ofe, models as om
     n = _cpu_threads()
+    allocator = _tune_host_allocator()
     model_name, n_logical, aff = host_cpu()
     res, scan = {}, None
     for batch in batches:
@@ -210,8 +240,9 @@ def cpu_train_baseline(kind, batches=(32, 16), steps=3):
             times.append(step_once(st))
             stages.append(st)
             print(f'[bench] cpu_baseline {kind} batch {batch} step {i}: {times[-1]:.2f} s on {n} threads', file=sys.stderr, flush=True)
-            if sum(times) > 60.:                     # bounded sample: stop early on a slow host
-                break
+            headline = batch == batches[0]
+            if (not headline and sum(times) > 60.) or (headline and times[-1] > 60. and len(times) >= 2):
+                break                                # bounded: side legs by total time; the headline leg only when ONE step takes over a minute
         if kind == 'c2' and batch == batches[-1] and aff >= 64 and sum(times) < 60.:
             # SURVEY.md 8(d) says "all host cores": one step each at 64 / 128 intra-op threads shows why the baseline stops at 32
             scan = {}
@@ -231,12 +262,14 @@ def cpu_train_baseline(kind, batches=(32, 16), steps=3):
         dt = float(np.median(timed))
         med = stages[1 + int(np.argsort(timed)[len(timed) // 2])] if len(times) > 1 else stages[0]
         res[batch] = {'clips_per_s': round(batch / dt, 3), 's_per_step': round(dt, 3), 'timed_steps': len(timed),
+                      'spread': round((max(timed) - min(timed)) / dt, 3),          # (slowest - fastest) / median of the timed steps
                       'stage_s': {k: round(v, 3) for k, v in med.items()}}
     main_b = batches[0]
     what = {'c2': 'FBCRNN', 'deep': "FBCRNN 'deep'"}.get(kind, 'tag-cond. BiCRNN')
     out = {'value': res[main_b]['clips_per_s'], 'unit': 'clips/s', 'cores': n, 'kind': 'port',
            'sample': f'oracle {what} train step incl. STFT, batch {main_b}, 1 warm-up + {res[main_b]["timed_steps"]} timed steps, median',
-           'cpu_model': model_name, 'host_logical_cpus': n_logical, 'affinity_cpus': aff, 'threads_used': n,
+           'cpu_model': model_name, 'host_logical_cpus': n_logical, 'affinity_cpus': aff, 'threads_used': n, 'allocator': allocator,
+           'timed_steps': res[main_b]['timed_steps'], 'spread': res[main_b]['spread'],
            'threads_note': 'intra-op threads capped at min(affinity, 32): the oracle step is many small GRU / conv ops whose CPU time stops falling (and then rises) beyond ~32 threads on this class of host; cores = threads used, not the host total',
            f'batch{main_b}': res[main_b]}
     for bb in batches[1:]:
@@ -253,6 +286,7 @@ def cpu_inference_baseline(clips=8):
     """Oracle ensemble inference (2 FBCRNN + 3 tag-conditioned BiCRNN, median filters, event extraction) on a bounded sample."""
     from oracle import frontend as ofe, models as om, postproc as opp
     n = _cpu_threads()
+    allocator = _tune_host_allocator()
     model_name, n_logical, aff = host_cpu()
     torch.manual_seed(0)
     taggers = [om.FBCRNN.build().eval() for _ in range(2)]
@@ -277,7 +311,7 @@ def cpu_inference_baseline(clips=8):
     return {'value': round(clips / dt, 3), 'unit': 'clips/s', 'cores': n, 'kind': 'port',
             'sample': f'oracle ensemble inference (2 FBCRNN taggers + 3 tag-conditioned BiCRNN detectors, 3 median-filter '
                       f'variants, event extraction) on {clips} x 10 s clips, 1 warm-up + 2 timed passes, median',
-            'cpu_model': model_name, 'host_logical_cpus': n_logical, 'affinity_cpus': aff, 'threads_used': n}
+            'cpu_model': model_name, 'host_logical_cpus': n_logical, 'affinity_cpus': aff, 'threads_used': n, 'allocator': allocator}
 
 
 # ------------------------------------------------------------------------------------------------ per-kernel figures
@@ -873,7 +907,7 @@ def contract_line(out):
                                 for k, v in out['roofline_gru'].items() if k in ('forward_scan', 'bptt_scan')}
     if 'cpu_baseline' in out:
         cb = out['cpu_baseline']
-        c = _pick(cb, ('value', 'unit', 'cores', 'kind', 'cpu_model', 'host_logical_cpus'))
+        c = _pick(cb, ('value', 'unit', 'cores', 'kind', 'cpu_model', 'host_logical_cpus', 'timed_steps', 'spread'))
         c['sample'] = str(cb.get('sample', ''))[:100]
         for k, v in cb.items():
             if k.startswith('batch') and isinstance(v, dict) and 'clips_per_s' in v:
