@@ -984,8 +984,8 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
 // XCD placement probe (once per device): the XCD-local exchange below is only CORRECT when all workgroups of a ring - block
 // ids that are equal mod 8 - run on one XCD.  That is how the dispatcher of an 8-XCD device in SPX mode deals a kernel's
 // workgroups (MI355X_MICROARCH.md), but it is a property of the device configuration (6-XCD parts, CPX / DPX partitions and
-// CU masks differ), so it is observed instead of assumed: one launch of device_cus() single-wave blocks, each recording its
-// XCC_ID; local is enabled only if eight distinct XCDs show up and XCC_ID is a function of block id mod 8.  The map goes to
+// CU masks differ), so it is observed instead of assumed: launches of device_cus() single-wave blocks, each recording its
+// XCC_ID; local is enabled only if eight distinct XCDs show up and XCC_ID is the SAME function of block id mod 8 in every launch.  The map goes to
 // the scan (GruStackArgs::xcc_map), whose local-ring blocks re-check their own placement at every launch (error bit 2).
 __global__ void xcc_probe_kernel(unsigned* out) {
     if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
@@ -1000,20 +1000,25 @@ static bool xcd_placement(hipStream_t s, unsigned* map) {
     dev &= 63;
     if (state[dev] == 0) {
         state[dev] = -1;
+        // three launches: n, n - 5 and n blocks.  The map of the first and the third must agree - a dispatcher that carried its
+        // XCD pointer over from one kernel to the next would still deal ids equal mod 8 to one XCD, but the map the scans check
+        // themselves against would rotate from launch to launch (the odd-sized launch in between shifts it): refused as well
         const int n = device_cus() < 64 ? 64 : device_cus();
         unsigned* d = nullptr;
-        std::vector<unsigned> h(n, 0xffu);
-        if (hipMalloc(&d, n * sizeof(unsigned)) == hipSuccess) {
-            hipLaunchKernelGGL(xcc_probe_kernel, dim3(n), dim3(64), 0, s, d);
-            const bool ran = hipMemcpyAsync(h.data(), d, n * sizeof(unsigned), hipMemcpyDeviceToHost, s) == hipSuccess &&
+        std::vector<unsigned> h(3 * n, 0xffu);
+        if (hipMalloc(&d, 3 * n * sizeof(unsigned)) == hipSuccess) {
+            const int blocks[3] = {n, n - 5, n};
+            for (int k = 0; k < 3; ++k) hipLaunchKernelGGL(xcc_probe_kernel, dim3(blocks[k]), dim3(64), 0, s, d + k * n);
+            const bool ran = hipMemcpyAsync(h.data(), d, 3 * n * sizeof(unsigned), hipMemcpyDeviceToHost, s) == hipSuccess &&
                              hipStreamSynchronize(s) == hipSuccess;
             (void)hipFree(d);
             unsigned seen = 0, m = 0;
             bool periodic = ran;
-            for (int i = 0; i < n && periodic; ++i) {
-                periodic = h[i] < 16u && h[i] == h[i & 7];
-                seen |= 1u << (h[i] & 15u);
-            }
+            for (int k = 0; k < 3 && periodic; ++k)
+                for (int i = 0; i < blocks[k] && periodic; ++i) {
+                    periodic = h[k * n + i] < 16u && h[k * n + i] == h[i & 7];      // every launch: the FIRST launch's map
+                    seen |= 1u << (h[k * n + i] & 15u);
+                }
             for (int r = 0; r < 8; ++r) m |= (h[r] & 15u) << (4 * r);
             if (periodic && __builtin_popcount(seen) == 8) { state[dev] = 1; maps[dev] = m; }
         }

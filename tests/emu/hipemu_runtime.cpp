@@ -38,6 +38,7 @@ namespace hipemu {
 thread_local Runtime* tls_rt = nullptr;
 int g_concurrent = 0;
 int g_xcc_mode = 0;
+unsigned g_xcc_start = 0;       // blocks launched so far (placement model 3, shim/hip/hip_runtime.h)
 
 void trampoline() {
     Runtime& r = rt();
@@ -105,6 +106,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     const int n = (int)(block.x * block.y * block.z);
     if (n > MAX_THREADS) { fprintf(stderr, "hipemu: %d threads per block\n", n); abort(); }
     const unsigned nblocks = grid.x * grid.y * grid.z;
+    struct Advance { unsigned n; ~Advance() { g_xcc_start += n; } } advance{nblocks};
     if (g_concurrent && nblocks > 1) {
         if (nblocks > 256) { fprintf(stderr, "hipemu: %u concurrent blocks\n", nblocks); abort(); }
         std::vector<std::thread> ts;

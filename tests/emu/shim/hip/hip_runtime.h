@@ -302,10 +302,11 @@ static inline void __builtin_amdgcn_s_setprio(int) {}
 // s_getreg_b32 is only used for HW_REG_XCC_ID (the XCD a wave runs on).  Mode 0: the dispatcher of an 8-XCD device in SPX mode
 // (block id mod 8); 1: one XCD for everybody (a CPX partition); 2: pairs of consecutive blocks share an XCD (a placement that is
 // NOT a function of id mod 8) - hipemu_set_xcc_mode, for the tests of the placement probe and of the scans' own check.
-namespace hipemu { extern int g_xcc_mode; }
+// 3: round-robin, but the dispatcher's XCD pointer carries over from launch to launch (g_xcc_start: blocks launched so far).
+namespace hipemu { extern int g_xcc_mode; extern unsigned g_xcc_start; }
 static inline unsigned __builtin_amdgcn_s_getreg(int) {
     const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    return hipemu::g_xcc_mode == 1 ? 0u : hipemu::g_xcc_mode == 2 ? (id >> 1) & 7u : id & 7u;
+    return hipemu::g_xcc_mode == 1 ? 0u : hipemu::g_xcc_mode == 2 ? (id >> 1) & 7u : hipemu::g_xcc_mode == 3 ? (id + hipemu::g_xcc_start) & 7u : id & 7u;
 }
 #ifndef __HIP_MEMORY_SCOPE_AGENT          /* (__hip_atomic_load / _store are clang builtins on every target; the scope names are HIP-mode macros) */
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1

@@ -774,7 +774,9 @@ def test_xcd_local_exchange_is_gated_by_the_placement_probe_and_checked_in_the_k
     hipemu_set_xcc_mode) and the exchange is enabled only for an 8-XCD placement that is a function of block id mod 8; the ring's
     workgroups re-check their own XCC_ID at every launch and set bit 1 of the error word when it is not what the probe saw.
     (i) round-robin placement: local on, no error; (ii) a one-XCD partition: the probe refuses, the scan runs with the
-    placement-independent exchange and gives the SAME bits; (iii) placement changes behind a verified probe: error word 2."""
+    placement-independent exchange and gives the SAME bits; (iii) a dispatcher whose XCD pointer carries over between launches:
+    refused too (the scans' own check needs a map that holds for every launch); (iv) placement changes behind a verified probe:
+    error word 2."""
     nch, nl, b, h, t = 2, 2, 5, 64, 6
     rng = np.random.RandomState(11)
     seq = np.array([6, 6, 5, 4, 3], np.int32)
@@ -809,6 +811,10 @@ def test_xcd_local_exchange_is_gated_by_the_placement_probe_and_checked_in_the_k
         gru_lib.pbsed_gru_set_xcd_local(1)
         e1, r1 = bptt()
         assert e1 == 0 and np.array_equal(r0, r1)         # probe refused: sc1 exchange, the same truncated states
+        gru_lib.hipemu_set_xcc_mode(3)                    # round-robin whose start carries over from launch to launch: every launch
+        gru_lib.pbsed_gru_set_xcd_local(1)                # is periodic, but the map the scans check themselves against would rotate
+        e4, r4 = bptt()
+        assert e4 == 0 and np.array_equal(r0, r4)         # refused by the probe's odd-sized middle launch: no false alarm later
         gru_lib.hipemu_set_xcc_mode(0)
         gru_lib.pbsed_gru_set_xcd_local(1)
         assert bptt()[0] == 0                             # verified under the round-robin placement ...

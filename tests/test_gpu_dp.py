@@ -7,7 +7,8 @@ group is gloo (RCCL refuses two ranks on one device), the tensors are device ten
   statistics) and equal per-rank loss-weight sums the averaged gradient IS the single-rank gradient; with batch
   statistics it is not (per-replica batch norm, a documented semantic of the build - the reference has no DP);
 * the library's own RCCL entry points (pbsed_comm_* / pbsed_allreduce_*) at world size 1: identity, ordered against the
-  compute stream, usable as the Trainer's gradient sync.
+  compute stream, usable as the Trainer's gradient sync;
+* where TWO GPUs are visible (not on the 1-GPU box: skipped there): one rank per GPU over RCCL, both gradient exchanges.
 """
 import os
 import socket
@@ -111,6 +112,63 @@ def test_two_ranks_on_one_gpu(tmp_path, frozen):
         assert rel < 2e-5, 'with batch-independent statistics DP must reproduce the single-rank gradient'
     else:
         assert 1e-4 < rel < .5, 'per-replica batch norm: the DP gradient differs from the single-rank one (documented)'
+
+
+def _rccl_worker(rank, world, port, out_dir, allreduce):
+    """One rank per GPU over RCCL (backend "nccl" IS RCCL on ROCm): the configuration BASELINE.json configs[3] runs, at world 2."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(rank)
+    dev = f'cuda:{rank}'
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+    from pb_sed_amd import ops
+    from pb_sed_amd.trainer import GradSync, LibraryGradSync, Trainer, shard_batch
+    model = _model(True).to(dev)
+    trainer = Trainer(model, lr=1e-3, gradient_clipping=5., allreduce=allreduce)
+    assert isinstance(trainer.sync, LibraryGradSync if allreduce == 'library' else GradSync), type(trainer.sync)
+    mine = shard_batch(_to(_batch(16), dev), rank, world)
+    rows = []
+    for step in range(4):
+        rev = trainer.step(mine)
+        torch.cuda.synchronize()
+        if step == 0:
+            torch.save((trainer.flat_grad / world).cpu(), os.path.join(out_dir, f'rccl_{allreduce}_grad_{rank}.pt'))
+        rows.append((float(rev['loss'].item()), float(trainer.flat_param.double().sum().item()),
+                     float(trainer.flat_param.double().abs().sum().item())))
+    ops.check_gru_sync()                          # the persistent scans ran next to RCCL's kernels: no hand-off may have timed out
+    torch.save({'rows': rows, 'scan_warnings': ops.scan_watch.warned}, os.path.join(out_dir, f'rccl_{allreduce}_rows_{rank}.pt'))
+    if hasattr(trainer.sync, 'close'):
+        trainer.sync.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: one rank per device over RCCL (the 1-GPU test box skips this)')
+@pytest.mark.parametrize('allreduce', ['library', 'torch'])
+def test_two_ranks_on_two_gpus_over_rccl(tmp_path, allreduce):
+    """VERDICT r5 item 8 - runs wherever two MI355X are visible (the driver's multi-GPU node), skipped on the 1-GPU box: one rank per
+    GPU, RCCL, the library's own communicator (LibraryGradSync: pbsed_comm_* / pbsed_allreduce_begin / _finish on the library's
+    stream, issued from inside backward) and torch.distributed's.  Four Trainer steps with batch-independent statistics: the
+    ranks stay bit-identical, the averaged gradient of 2 x 8 clips is the single-rank gradient of the 16 clips, the persistent
+    scans - co-resident with RCCL's kernels - raise no time-out word."""
+    import torch.multiprocessing as mp
+    from pb_sed_amd.trainer import Trainer
+    mp.spawn(_rccl_worker, args=(2, _free_port(), str(tmp_path), allreduce), nprocs=2, join=True)
+    outs = [torch.load(tmp_path / f'rccl_{allreduce}_rows_{r}.pt') for r in range(2)]
+    for step in range(4):
+        (l0, s0, a0), (l1, s1, a1) = outs[0]['rows'][step], outs[1]['rows'][step]
+        assert np.isfinite(l0) and np.isfinite(l1)
+        assert s0 == s1 and a0 == a1, f'step {step}: ranks diverged'
+    g0, g1 = (torch.load(tmp_path / f'rccl_{allreduce}_grad_{r}.pt') for r in range(2))
+    assert torch.equal(g0, g1)
+    model = _model(True)
+    trainer = Trainer(model, lr=1e-3, gradient_clipping=5.)
+    trainer.step(_to(_batch(16), 'cuda:0'))
+    torch.cuda.synchronize()
+    single = trainer.flat_grad.cpu()
+    rel = ((g0 - single).norm() / single.norm()).item()
+    print(f'RCCL world 2 ({allreduce}): |avg of 2x8 - 1x16| / |1x16| = {rel:.2e}')
+    assert rel < 2e-5
 
 
 def test_library_allreduce_world1_and_trainer_sync():
