@@ -322,16 +322,12 @@ static int launch_wgrad_cfg(Kern kern, const ConvWgradArgs& a_in, hipStream_t s)
     const int gz = (a.Cout + C::COUT_T - 1) / C::COUT_T;
     const size_t lds = C::LDS_FLOATS * sizeof(float);
     PBSED_DYN_LDS_ONCE(kern, lds);
-    static int slots_dev[64] = {0};                   // resident block slots of this kernel, per device ordinal
+    static int occ_dev[64] = {0};                     // blocks of this kernel a CU holds, per device ordinal
     int dev = 0;
     PBSED_HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
-    int& slots = slots_dev[dev & 63];
-    if (slots == 0) {
-        int occ = 0;
-        const int n_cu = device_cus();
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, C::NT, lds) != hipSuccess || occ < 1) occ = 2;
-        slots = n_cu * occ;
-    }
+    int& occ = occ_dev[dev & 63];
+    if (occ == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, C::NT, lds) != hipSuccess || occ < 1)) occ = 2;
+    const int slots = device_cus() * occ;             // resident block slots of this kernel
     int split = slots / (gy * gz);
     if (split >= 8) split &= ~7;       // multiple of 8: blocks sharing a spatial chunk share an XCD's L2
     if (split < 1) split = 1;
@@ -345,6 +341,14 @@ static int launch_wgrad_cfg(Kern kern, const ConvWgradArgs& a_in, hipStream_t s)
     if constexpr (wgrad_columns<C>::value) {                          // column-walking kernels split over (clip, column) units
         const int units = a.B * nTt * (C::KK <= 3 ? a.F : 1);       // the Conv1d form takes (clip, row, column) units, the 3x3 form walks the rows
         if (split > units) split = units;
+        // PBSED_WGRAD_XCD_COLS=1 (off by default: built while the GPU pool was closed to the build, NOT measured): block x of the 3x3
+        // column walk takes list position (x % 8) * (split / 8) + x / 8 instead of x, i.e. the blocks of ONE XCD walk split / 8
+        // ADJACENT columns (t ranges of one clip) at the same time.  A column's rows are 128-byte segments (+ 16 bytes either
+        // side for dY) of 2 000-byte tensor rows: every segment straddles cache lines it shares with the neighbouring columns,
+        // which the default map deals to eight different L2s (profiles/r05_pmc_hbm_traffic.csv: 512 MB fetched per 128->128
+        // launch for 213 MB of tensors).
+        const char* xcd_cols = getenv("PBSED_WGRAD_XCD_COLS");          // read per launch: an A/B inside one process
+        a.xcd_cols = (xcd_cols && xcd_cols[0] == '1' && C::KK == 9 && split >= 16 && split % 8 == 0) ? 1 : 0;
     }
     dim3 grid(split, gy, gz);
     float* scratch = (slot_ok && split >= 4 * WGRAD_SLOTS) ? wgrad_slot_scratch(s) : nullptr;
@@ -972,9 +976,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
     // consumer wave -> (cout group, cin group, 32-t slice of the step)
     const int wks = wave % KS, wni = (wave / KS) % WN, wmi = wave / (KS * WN);
     const bool do_bias = (a.db != nullptr) && (blockIdx.y == 0) && wni == 0;
-    // columns of this block: blockIdx.x, + gridDim.x, ..; its steps run through them row by row
+    // columns of this block: bx, + gridDim.x, ..; its steps run through them row by row.  bx = blockIdx.x, or (xcd_cols) the
+    // XCD-contiguous position (x % 8) * (gridDim.x / 8) + x / 8: a permutation of 0 .. gridDim.x - 1 (gridDim.x % 8 == 0)
+    const int bx = a.xcd_cols ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     int nColMine = 0;
-    if ((int)blockIdx.x < nCols) nColMine = (nCols - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+    if (bx < nCols) nColMine = (nCols - 1 - bx) / (int)gridDim.x + 1;
     const int nSteps = nColMine * a.F;
     constexpr int NBU = C::NB;
     const int nStepsR = (nSteps + NBU - 1) / NBU * NBU;                  // the producers' loop body covers NB steps without conditions
@@ -1071,7 +1077,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
         // the dY tile of step S and the x row of step S + 1 (x row g lives in ring slot g % 4; rows 0 and 1 of the stream are
         // staged in the prologue): load_pair(S) issues the loads of {dY of step S, x row of step S + 1}.
         auto locate = [&](int S, int& b, int& f, int& t0) __attribute__((always_inline)) {
-            const int col = (int)blockIdx.x + (S / a.F) * (int)gridDim.x;
+            const int col = bx + (S / a.F) * (int)gridDim.x;
             f = S % a.F; b = col / nTt; t0 = (col % nTt) * C::TT;
         };
         auto load_dy = [&](int S, auto buf_c) __attribute__((always_inline)) {
@@ -1275,7 +1281,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pc_kernel(ConvWgradArgs a) {
                 // the fp32 tile of the formed dY of this step (staged by the producers) -> global memory; a pooled row is staged
                 // in two steps (both parities), written in the even one
                 if (g_writer && (!unpool || !(f & 1))) {
-                    const int col = (int)blockIdx.x + (S / a.F) * (int)gridDim.x;
+                    const int col = bx + (S / a.F) * (int)gridDim.x;
                     const int b = col / nTt, t0 = (col % nTt) * C::TT, fg = unpool ? (f >> 1) : f;
                     const unsigned gclip = (unsigned)(a.Cout * Fg * a.T);
                     const __amdgpu_buffer_rsrc_t rs_go = __builtin_amdgcn_make_buffer_rsrc(a.gout + (size_t)b * gclip, 0, gclip * 4u, 0x00020000);

@@ -53,6 +53,7 @@ struct ConvWgradArgs {
     const int* gseq;
     float* gout;
     int g_cf;               // coefficients per (cout, output row) instead of per cout
+    int xcd_cols;           // conv_wgrad_pc_kernel: XCD-contiguous column positions (launch_wgrad_cfg, PBSED_WGRAD_XCD_COLS)
 };
 
 void conv_fwd_tile_dims(int KH, int KW, int Cin, int Cout, int* ck, int* cout_t);

@@ -20,7 +20,8 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 int check_launch(const char*) { return 0; }
-int device_cus() { return 2; }
+static int g_cus = 2;
+int device_cus() { return g_cus; }                              // emu_set_cus: a larger device = a wider split of the launch
 static float* g_scratch = nullptr;
 static size_t g_scratch_n = 0;
 float* scratch_for(hipStream_t, size_t floats) {                  // zeroed on every growth; the slotted launches keep their front zero
@@ -37,6 +38,7 @@ float* scratch_zeroed_front(hipStream_t s, size_t front, size_t total) {
 }
 }  // namespace pbsed
 extern "C" const char* emu_last_error() { return pbsed::g_err; }
+extern "C" void emu_set_cus(int n) { pbsed::g_cus = n; }
 // api.hip::pbsed_conv_bwd_weight / _bf16 in one: dw (+=), db (+=)
 extern "C" int emu_conv_bwd_weight(const float* x, const float* scale, const float* shift, int relu, const int* seq_len, const float* g,
                                    const unsigned char* unpool_idx, float* dw, float* db, int B, int Cin, int Cout, int F, int T, int KH,

@@ -654,6 +654,45 @@ def test_conv_weight_gradients_on_the_cpu_tree_vs_float64_and_patched_vs_tree(wg
     assert np.array_equal(_bits(db2), _bits(db))
 
 
+def test_wgrad_column_walk_with_xcd_contiguous_positions_gives_the_same_gradient(wg_libs, monkeypatch):
+    """PBSED_WGRAD_XCD_COLS=1 (opt-in, unmeasured): the blocks of conv_wgrad_pc_kernel take XCD-contiguous list positions - a
+    permutation of who walks which (clip, t range) column.  Same columns, same rows, same products: the gradient is that of the
+    default map up to the order of the final atomic adds, and within the float64 bar.  16 blocks over 24 columns (ragged)."""
+    lib = wg_libs[0]
+    b, cin, cout, f, t = 6, 64, 64, 3, 100            # nTt = 4 -> 24 columns; 64 'CUs' / (1 x 1 tiles) -> split = 16 after the column cap
+    rng = np.random.RandomState(77)
+    x = rng.randn(b, cin, f, t).astype(np.float32)
+    scale = (rng.rand(cin) + .5).astype(np.float32)
+    shift = (rng.randn(cin) * .1).astype(np.float32)
+    seq = np.array([t, 90, 81, 70, 64, 33], np.int32)
+    g = rng.randn(b, cout, f, t).astype(np.float32)
+    res = {}
+    lib.emu_set_cus(16)
+    try:
+        for flag in ('0', '1'):
+            monkeypatch.setenv('PBSED_WGRAD_XCD_COLS', flag)
+            dw = np.zeros((cout, cin, 3, 3), np.float32)
+            db = np.zeros(cout, np.float32)
+            rc = lib.emu_conv_bwd_weight(P(x), P(scale), P(shift), 1, P(seq), P(g), None, P(dw), P(db), b, cin, cout, f, t, 3, 3, 0)
+            assert rc == 0, lib.emu_last_error()
+            res[flag] = (dw, db)
+    finally:
+        lib.emu_set_cus(2)
+    xa = np.maximum(x.astype(np.float64) * scale[None, :, None, None] + shift[None, :, None, None], 0)
+    for i in range(b):
+        xa[i, :, :, seq[i]:] = 0
+    xp = np.pad(xa, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    ref = np.zeros((cout, cin, 3, 3))
+    for i in range(3):
+        for j in range(3):
+            ref[:, :, i, j] = np.einsum('boft,bcft->oc', g.astype(np.float64), xp[:, :, i:i + f, j:j + t])
+    for flag in ('0', '1'):
+        assert np.abs(res[flag][0] - ref).max() < 3e-5 * np.abs(ref).max(), flag
+    assert np.abs(res['1'][0] - res['0'][0]).max() < 2e-6 * np.abs(ref).max()        # the order of the atomics only
+    assert np.abs(res['1'][1] - res['0'][1]).max() < 2e-6 * np.abs(res['0'][1]).max()
+    print("bit-identical to the default map:", np.array_equal(res["1"][0], res["0"][0]))
+
+
 # ------------------------------------------------------------------------------------------------ gru_stack (the persistent scans, blocks concurrent)
 @pytest.fixture(scope='module')
 def gru_lib(built):

@@ -487,7 +487,7 @@ def test_fbcrnn_forward_is_reproducible():
 
 
 @pytest.mark.skipif(__import__('os').environ.get('PBSED_TEST_UNMEASURED') != '1',
-                    reason='engine.SIDE_WGRAD was written while the GPU pool was closed to the build: tools/r05_queue.sh runs this test '
+                    reason='engine.SIDE_WGRAD was written while the GPU pool was closed to the build: tools/r06_queue.sh runs this test '
                            '(PBSED_TEST_UNMEASURED=1) together with its A/B; it joins the default suite once it has run on hardware')
 @pytest.mark.parametrize('kind', ['fbcrnn', 'bicrnn_tag'])
 def test_weight_gradients_beside_the_bptt_scans_match_the_serial_order(monkeypatch, kind):
