@@ -40,6 +40,13 @@ int pbsed_version(void);
  * convolution gradients add into them, their reduction pass clears them again): hands off while it is registered. */
 size_t pbsed_scratch_bytes(void);
 int pbsed_set_scratch(void* scratch /*device*/, size_t bytes, void* stream);
+/* CU budget for grid sizing: the weight-gradient entry points (pbsed_conv_bwd_weight*, pbsed_gru_wgrad*) cut their persistent
+ * grids for `cus` compute units instead of the whole device until the budget is changed again (0 = whole device; process-wide,
+ * set and reset around the launches it is meant for).  For launches that are enqueued BESIDE a persistent GRU scan on another
+ * stream (engine.SIDE_WGRAD): the scan holds up to 7/8 of the CUs for its whole duration, and a grid cut for the full device
+ * would leave most of its workgroups waiting for the scan to end.  Returns the previous budget.  Results do not depend on it
+ * beyond the order of the partial sums.  No counterpart in the reference (single stream, library kernels). */
+int pbsed_set_launch_cus(int cus);
 
 /* ---- fused front-end.  Replaces the CPU STFT (pb_sed/data_preparation/provider.py:315-323, called at
  * pb_sed/data_preparation/transform.py:53) + NormalizedLogMelExtractor (pb_sed/models/weak_label/crnn.py:86-90).

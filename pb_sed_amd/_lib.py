@@ -104,6 +104,7 @@ SIGNATURES = {
     'pbsed_gru_set_prof': [_v, I],
     'pbsed_gru_set_xcd_local': [I],
     'pbsed_set_scratch': [_v, SZ, _v],
+    'pbsed_set_launch_cus': [I],
     'pbsed_scratch_bytes': [],
     'pbsed_memset_async': [_v, I, SZ, _v],
     'pbsed_comm_id_bytes': [],
@@ -113,7 +114,7 @@ SIGNATURES = {
     'pbsed_allreduce_begin': [_v, _v, SZ, _v],
     'pbsed_allreduce_finish': [_v, _v],
 }
-_NON_STATUS = {'pbsed_gru_granule_capacity': C.c_int, 'pbsed_gru_set_xcd_local': C.c_int, 'pbsed_conv_bwd_weight_bng_supported': C.c_int, 'pbsed_scratch_bytes': C.c_size_t, 'pbsed_last_error': C.c_char_p, 'pbsed_version': C.c_int, 'pbsed_comm_id_bytes': C.c_int, 'pbsed_conv_pack_dims': None,
+_NON_STATUS = {'pbsed_gru_granule_capacity': C.c_int, 'pbsed_set_launch_cus': C.c_int, 'pbsed_gru_set_xcd_local': C.c_int, 'pbsed_conv_bwd_weight_bng_supported': C.c_int, 'pbsed_scratch_bytes': C.c_size_t, 'pbsed_last_error': C.c_char_p, 'pbsed_version': C.c_int, 'pbsed_comm_id_bytes': C.c_int, 'pbsed_conv_pack_dims': None,
                'pbsed_conv_pack_dims_bf16': None, 'pbsed_conv_pack_dims_wino': None, 'pbsed_conv_pack_dims_winox3': None, 'pbsed_conv_pack_dims_s16': None,
                'pbsed_conv1d_pack_dims_x3': None}
 

@@ -41,6 +41,15 @@ int device_cus() {
     return c;
 }
 
+// Grid-sizing budget of the persistent weight-gradient launchers (pbsed_set_launch_cus): a launch that is meant to run BESIDE a
+// persistent scan must not be cut for the whole device - its grid would be static shares of a device it does not get, and the
+// blocks that find no CU wait for the scan to end (the launch then takes scan + its own time, as if it had not been moved).
+static int g_launch_cus = 0;
+int launch_cus() {
+    const int n = device_cus();
+    return g_launch_cus > 0 && g_launch_cus < n ? g_launch_cus : n;
+}
+
 namespace {
 struct ScratchSlot {
     int dev;
@@ -116,6 +125,13 @@ const char* pbsed_last_error(void) { return g_err; }
 // slots there instead of into the library's per-device buffer, so several streams of one device can run them concurrently.
 // scratch = NULL removes the registration.  pbsed_scratch_bytes() is large enough for every launch of the reference nets.
 size_t pbsed_scratch_bytes(void) { return (size_t)160 << 20; }
+
+// CU budget of the weight-gradient launchers (launch_cus above); 0 = the whole device.  Returns the previous budget.
+int pbsed_set_launch_cus(int cus) {
+    const int old = g_launch_cus;
+    g_launch_cus = cus > 0 ? cus : 0;
+    return old;
+}
 
 int pbsed_set_scratch(void* scratch, size_t bytes, void* stream) {
     int dev = 0;

@@ -115,6 +115,7 @@ __device__ __forceinline__ f32x4 mfma_x3(const Bf3& a, const Bf3& b, f32x4 c) {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 int device_cus();                                             // CUs of the CURRENT device (cached per device ordinal)
+int launch_cus();                                             // ... or the caller's budget for grid sizing (pbsed_set_launch_cus), api.hip
 float* scratch_for(hipStream_t stream, size_t floats);        // partial-sum scratch of (current device, stream); api.hip
 float* scratch_zeroed_front(hipStream_t stream, size_t front, size_t total);     // ... whose first `front` floats are zero and stay so
 constexpr size_t PBSED_SCRATCH_FRONT = (size_t)32 * (16384 + 64);               // the slotted conv weight gradients' part of it

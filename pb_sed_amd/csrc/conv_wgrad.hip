@@ -327,7 +327,7 @@ static int launch_wgrad_cfg(Kern kern, const ConvWgradArgs& a_in, hipStream_t s)
     PBSED_HIP_TRY(hipGetDevice(&dev), "hipGetDevice");
     int& occ = occ_dev[dev & 63];
     if (occ == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, C::NT, lds) != hipSuccess || occ < 1)) occ = 2;
-    const int slots = device_cus() * occ;             // resident block slots of this kernel
+    const int slots = launch_cus() * occ;             // resident block slots of this kernel (on the caller's CU budget, if it set one)
     int split = slots / (gy * gz);
     if (split >= 8) split &= ~7;       // multiple of 8: blocks sharing a spatial chunk share an XCD's L2
     if (split < 1) split = 1;

@@ -219,7 +219,7 @@ static int launch_wgrad_s16_t(const ConvWgradArgs& a_in, hipStream_t s) {
     const int gy = (a.Cin + 15) / 16, gz = a.Cout / (16 * MT);
     // two blocks per CU over all (input tile, output tile) pairs; a multiple of 8 columns keeps the pairs of one unit range on
     // one XCD (block id = x + gx * (y + gy * z), XCD = id % 8): they read the same rows, from one L2
-    int gx = (2 * device_cus()) / (gy * gz) / 8 * 8;
+    int gx = (2 * launch_cus()) / (gy * gz) / 8 * 8;
     if (gx < 8) gx = 8;
     if (gx * 4 > nUnits) gx = (nUnits + 3) / 4;
     const size_t lds = (size_t)16 * MT * 16 * 9 * sizeof(float);

@@ -284,7 +284,7 @@ static int gru_wgrad_launch(int n, const float* const* dg, const float* const* x
     const int K = Ks[0];
     a.TB = T * B; a.G = G; a.K = K;
     hipStream_t s = (hipStream_t)stream;
-    const int n_cu = device_cus();
+    const int n_cu = launch_cus();
     {
         if ((size_t)a.TB * (G > kmax ? G : kmax) * 4 >= (1ull << 31)) { set_error("gru_wgrad: an operand of %d x %d floats exceeds the 2 GiB the loaders address", a.TB, G > kmax ? G : kmax); return PBSED_E_ARG; }
         int ny = 0;

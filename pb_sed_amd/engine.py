@@ -162,7 +162,10 @@ class _DeferredLaunches(list):
         operands were final); returns the stream to join."""
         side = _side_stream(device)
         if self:
-            with torch.cuda.stream(side):
+            # the launches' grids are cut for the CUs the scan leaves free (ops.cus_beside_last_scan): cut for the whole device,
+            # three quarters of their workgroups would wait for the scan to end and the launch would finish no earlier than
+            # it does behind the scan
+            with torch.cuda.stream(side), ops.launch_cus(ops.cus_beside_last_scan(device)):
                 side.wait_event(ready_event)
                 for job in self:
                     job()

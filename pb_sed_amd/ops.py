@@ -697,6 +697,31 @@ def gru_scan_bwd(w_hh_t, hs, save, dy, reverse, seq_len):
     return dgi, dgh
 
 
+last_scan_blocks = 0    # workgroups of the persistent BPTT scan enqueued last (one per CU for the scan's whole duration)
+
+
+class launch_cus:
+    """``with ops.launch_cus(n):`` - the weight-gradient launches enqueued inside size their persistent grids for ``n`` compute
+    units (pbsed_set_launch_cus) instead of the whole device; for launches that run beside a persistent scan on a side stream."""
+
+    def __init__(self, cus):
+        self.cus = int(cus)
+
+    def __enter__(self):
+        self.old = _lib.lib().pbsed_set_launch_cus(self.cus)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().pbsed_set_launch_cus(self.old)
+        return False
+
+
+def cus_beside_last_scan(device):
+    """Compute units the last enqueued persistent BPTT scan leaves free (at least an eighth of the device: the scans keep within 7/8)."""
+    n = max(_granule_capacity(_dev_index(torch.device(device)), 64, True, False, 1), 8)      # = the device's CU count (one scan workgroup per CU)
+    return max(n - last_scan_blocks, n // 8) // 8 * 8
+
+
 _GRANULE_WS = {}        # (device, shape) -> [granule workspace, epoch counter] of the persistent GRU scan
 _GRU_FLAGS = {}         # device -> [int32 flag words, words handed out since the last check]
 GRU_FLAG_WORDS = 64
@@ -1086,6 +1111,8 @@ def gru_stack_bwd(w_hh_t, w_ih_up_t, hs, save, dy_top, reverse, seq_len, nlayers
 
         _tune_poll_delay(dev, 1 if nlayers == 1 else 0, 2, (nch, nlayers, b, h, t, precision), launch)
         watch_end = scan_watch.bracket(('bwd', nch, nlayers, b, h, t)) if scan_watch is not None else None
+        global last_scan_blocks
+        last_scan_blocks = nch * (2 * nlayers - 1) * (h // 16) * ((b + 15) // 16)      # workgroups (= CUs) the scan holds while it runs
         launch()
         if watch_end is not None:
             watch_end.record()

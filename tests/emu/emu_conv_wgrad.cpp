@@ -21,7 +21,8 @@ void set_error(const char* fmt, ...) {
 }
 int check_launch(const char*) { return 0; }
 static int g_cus = 2;
-int device_cus() { return g_cus; }                              // emu_set_cus: a larger device = a wider split of the launch
+int device_cus() { return g_cus; }
+int launch_cus() { return g_cus; }                              // emu_set_cus: a larger device = a wider split of the launch
 static float* g_scratch = nullptr;
 static size_t g_scratch_n = 0;
 float* scratch_for(hipStream_t, size_t floats) {                  // zeroed on every growth; the slotted launches keep their front zero

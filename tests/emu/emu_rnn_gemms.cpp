@@ -23,6 +23,7 @@ void set_error(const char* fmt, ...) {
 }
 int check_launch(const char*) { return 0; }
 int device_cus() { return 4; }
+int launch_cus() { return device_cus(); }
 static float* g_scratch = nullptr;
 static size_t g_scratch_n = 0;
 float* scratch_for(hipStream_t, size_t floats) {
