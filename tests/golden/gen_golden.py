@@ -615,7 +615,45 @@ def gen_summary_metrics():
     print('ref_summary_metrics', len(cases), 'arrays')
 
 
+def gen_pseudo_label():
+    """pb_sed/models/base/pseudo_label.py (pseudo_label, set_onset_offset_times): the hand-off from the ensemble inference to the
+    next training round.  Pure dictionary work: inputs and the reference's outputs go into a JSON fixture."""
+    import json
+    import importlib
+    ref_pl = importlib.import_module('pb_sed.models.base.pseudo_label')      # (the package re-exports the FUNCTION under the module's name)
+    rng = np.random.default_rng(23)
+    classes = ['Alarm_bell_ringing', 'Blender', 'Cat', 'Dishes', 'Dog', 'Speech']
+    dataset, tags, events, boundaries = {}, {}, {}, {}
+    for i in range(14):
+        aid = f'clip{i:02d}'
+        length = float(np.round(rng.uniform(4, 10), 3))
+        present = [c for c in classes if rng.random() < .35]
+        if i == 3:
+            present = []                                             # an untagged clip
+        dataset[aid] = {'audio_path': f'/data/{aid}.wav', 'audio_length': length, 'events': list(present)}
+        tags[aid] = [float(np.round(rng.random() * (.9 if c in present else .6) + (.3 if c in present else 0.), 4)) for c in classes]
+        det = []
+        for c in classes:
+            for _ in range(int(rng.integers(0, 3))):
+                on = float(np.round(rng.uniform(0, length - .5), 2))
+                det.append((on, float(np.round(min(on + rng.uniform(.2, 3.), length), 2)), c))
+        if i == 5:
+            det = []                                                 # tagged, nothing detected: weak labels over the whole clip
+        events[aid] = det
+        boundaries[aid] = [(on, off, c) for on, off, c in det if rng.random() < .6]
+    cases = {}
+    for name, (pt, pb, pe) in {'none': (False, False, False), 'tags': (True, False, False), 'events': (False, False, True),
+                               'boundaries': (False, True, False), 'tags_events': (True, False, True), 'tags_boundaries': (True, True, False)}.items():
+        out = ref_pl.pseudo_label(dataset, classes, pt, pb, pe, tags, boundaries, events)
+        cases[name] = {'flags': [pt, pb, pe], 'same_object': out is dataset, 'dataset': out}
+    fixture = {'event_classes': classes, 'dataset': dataset, 'tags': tags, 'events': events, 'boundaries': boundaries, 'cases': cases}
+    with open(os.path.join(OUT, 'ref_pseudo_label.json'), 'w') as f:
+        json.dump(fixture, f, indent=0, sort_keys=True)
+    print('ref_pseudo_label', len(cases), 'cases')
+
+
 if __name__ == '__main__':
+    gen_pseudo_label()
     gen_fbcrnn_loss()
     gen_bicrnn_loss()
     gen_fbcrnn_heads()

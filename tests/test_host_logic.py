@@ -529,3 +529,42 @@ def test_parked_kernel_patches_still_apply_in_stack_order(tmp_path):
     # every patch listed in the attic README is in the stack, and nothing else is parked silently
     parked = sorted(f for f in os.listdir(os.path.join(root, 'tools', 'micro', 'attic')) if f.endswith('.patch'))
     assert parked == sorted(patches)
+
+
+def _jsonable(x):
+    """tuples -> lists, recursively (the fixture went through JSON)"""
+    if isinstance(x, dict):
+        return {k: _jsonable(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_jsonable(v) for v in x]
+    return x
+
+
+def test_pseudo_label_hand_off_matches_the_reference(tmp_path):
+    """pb_sed_amd.pseudo_label against tests/golden/ref_pseudo_label.json - inputs and outputs of the reference's OWN
+    pb_sed/models/base/pseudo_label.py (six flag combinations over 14 clips incl. an untagged clip, a tagged clip without detections,
+    detections of classes a clip is not tagged with): every relabelled example equal, the input never modified, the untouched
+    dataset handed back as the same object when nothing is asked for; the TSV of
+    pb_sed/experiments/strong_label_crnn/inference.py:393-400 row by row."""
+    import copy
+    from pb_sed_amd import pseudo_label as pl
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = json.load(open(os.path.join(root, 'tests', 'golden', 'ref_pseudo_label.json')))
+    events = {a: [tuple(e) for e in v] for a, v in fx['events'].items()}
+    boundaries = {a: [tuple(e) for e in v] for a, v in fx['boundaries'].items()}
+    assert set(fx['cases']) == {'none', 'tags', 'events', 'boundaries', 'tags_events', 'tags_boundaries'}
+    for name, case in fx['cases'].items():
+        dataset = copy.deepcopy(fx['dataset'])
+        before = copy.deepcopy(dataset)
+        out = pl.pseudo_label(dataset, fx['event_classes'], *case['flags'], fx['tags'], boundaries, events)
+        assert dataset == before, name                                   # relabelling works on a copy
+        assert (out is dataset) == case['same_object'], name
+        assert _jsonable(out) == case['dataset'], name
+    with pytest.raises(AssertionError):
+        pl.pseudo_label(fx['dataset'], fx['event_classes'], False, True, True, fx['tags'], boundaries, events)
+    rates = pl.label_rates(pl.pseudo_label(fx['dataset'], fx['event_classes'], True, True, False, fx['tags'], boundaries, events))
+    assert rates['label_rate'] == pytest.approx(0.7857142857142857) and rates['boundaries'] == pytest.approx(0.5217391304347826)
+    assert rates['weak'] == pytest.approx(0.4782608695652174) and rates['strong'] == 0.      # what the reference printed for 'tags_boundaries'
+    path = tmp_path / 'validation_pseudo_labeled.tsv'
+    pl.write_event_tsv(path, {'a': [(0.5, 1.25, 'Dog'), (2.0, 3.0, 'Cat')], 'b': []})
+    assert open(path).read() == 'filename\tonset\toffset\tevent_label\na.wav\t0.5\t1.25\tDog\na.wav\t2.0\t3.0\tCat\nb.wav\t\t\t\n'
