@@ -245,3 +245,32 @@ class CRNN(SoundEventModel):
         m = (torch.arange(t, device=y.device)[None] <
              engine.seq_to_device(seq_len_y, y.device)[:, None])[:, None, :]
         return y * m, seq_len_y
+
+
+# ---- tuning wrappers (reference pb_sed/models/strong_label/crnn.py:213-262)
+def tune_tagging(crnns, dataset, device, timestamps, event_classes, metrics, minimize=False, storage_dir=None):
+    from .. import inference, tuning
+    print('\nTagging Tuning')
+    tagging_scores = inference.tagging(crnns, dataset, device, timestamps=timestamps, event_classes=event_classes)
+    return tuning.tune_tagging(tagging_scores, medfilt_length_candidates=[1], metrics=metrics, minimize=minimize,
+                               storage_dir=storage_dir, device=device)
+
+
+def tune_boundary_detection(crnns, dataset, device, timestamps, event_classes, tags, metrics, stepfilt_lengths, minimize=False,
+                            tag_masking=True, storage_dir=None):
+    from .. import inference, tuning
+    print('\nBoundaries Detection Tuning')
+    boundaries_scores = inference.boundaries_detection(crnns, dataset, device, stepfilt_length=None, apply_mask=False, masks=tags,
+                                                       timestamps=timestamps, event_classes=event_classes)
+    return tuning.tune_boundaries_detection(boundaries_scores, medfilt_length_candidates=[1], stepfilt_length_candidates=stepfilt_lengths,
+                                            tags=tags, metrics=metrics, minimize=minimize, tag_masking=tag_masking,
+                                            storage_dir=storage_dir, device=device)
+
+
+def tune_sound_event_detection(crnns, dataset, device, timestamps, event_classes, tags, metrics, medfilt_lengths, minimize=False,
+                               tag_masking='?', storage_dir=None):
+    from .. import inference, tuning
+    print('\nSound Event Detection Tuning')
+    detection_scores = inference.sound_event_detection(crnns, dataset, device, timestamps=timestamps, event_classes=event_classes)
+    return tuning.tune_sound_event_detection(detection_scores, medfilt_lengths, tags, metrics=metrics, minimize=minimize,
+                                             tag_masking=tag_masking, storage_dir=storage_dir, device=device)

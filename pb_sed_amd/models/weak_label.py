@@ -276,3 +276,49 @@ class CRNN(SoundEventModel):
         if self.rnn_bwd is not None:
             y = (y + ys[1][..., 0]) / 2
         return y.reshape(n, b, -1).permute(1, 2, 0)
+
+
+# ---- tuning wrappers (reference pb_sed/models/weak_label/crnn.py:343-421): one ensemble inference pass, then the leaderboard search
+# of pb_sed_amd.tuning over the scores (its filters run on the device as well)
+def tune_tagging(crnns, dataset, device, timestamps, event_classes, metrics, minimize=False, storage_dir=None):
+    from .. import inference, tuning
+    print('\nTagging Tuning')
+    tagging_scores = inference.tagging(crnns, dataset, device, timestamps=timestamps, event_classes=event_classes)
+    return tuning.tune_tagging(tagging_scores, medfilt_length_candidates=[1], metrics=metrics, minimize=minimize,
+                               storage_dir=storage_dir, device=device)
+
+
+def tune_boundary_detection(crnns, dataset, device, timestamps, event_classes, tags, metrics, stepfilt_lengths, minimize=False,
+                            tag_masking='?', storage_dir=None):
+    from .. import inference, tuning
+    print('\nBoundaries Detection Tuning')
+    boundaries_scores = inference.boundaries_detection(crnns, dataset, device, stepfilt_length=None, apply_mask=False, masks=tags,
+                                                       timestamps=timestamps, event_classes=event_classes)
+    return tuning.tune_boundaries_detection(boundaries_scores, medfilt_length_candidates=[1], stepfilt_length_candidates=stepfilt_lengths,
+                                            tags=tags, metrics=metrics, minimize=minimize, tag_masking=tag_masking,
+                                            storage_dir=storage_dir, device=device)
+
+
+def tune_sound_event_detection(crnns, dataset, device, timestamps, event_classes, tags, metrics, window_lengths, window_shift,
+                               medfilt_lengths, minimize=False, tag_masking='?', storage_dir=None):
+    """One windowed-SED inference pass per window length, the median-filter / tag-masking search on each, and the best of all
+    window lengths per class and metric (the winner's ``window_length`` / ``window_shift`` recorded with its hyper-parameters)."""
+    from .. import inference, tuning
+    print('\nSound Event Detection Tuning')
+    leaderboard = {}
+    for win_len in window_lengths:
+        print(f'\n### window_length={win_len} ###')
+        detection_scores = inference.sound_event_detection(
+            crnns, dataset, device, model_kwargs={'window_length': win_len, 'window_shift': window_shift},
+            timestamps=timestamps[::window_shift], event_classes=event_classes)
+        for_winlen = tuning.tune_sound_event_detection(detection_scores, medfilt_lengths, tags, metrics=metrics, minimize=minimize,
+                                                       tag_masking=tag_masking, storage_dir=storage_dir, device=device)
+        for metric_name, (metric_values, hyper_params, scores) in for_winlen.items():
+            for event_class in event_classes:
+                hyper_params[event_class]['window_length'] = win_len
+                hyper_params[event_class]['window_shift'] = window_shift
+            leaderboard = tuning.update_leaderboard(leaderboard, metric_name, metric_values, hyper_params, scores, minimize=minimize)
+    print('\nbest overall:')
+    for metric_name in metrics:
+        print(f'\n{metric_name} :\n{leaderboard[metric_name][0]}')
+    return leaderboard

@@ -133,6 +133,20 @@ pt_conv.Pad = onn.Pad
 pb_array.segment_axis = _segment_axis
 pb_segment.segment_axis = _segment_axis
 
+
+def _validate_score_dataframe(scores, timestamps=None, event_classes=None):
+    """sed_scores_eval.utils.scores.validate_score_dataframe restated for what pb_sed/models/base/tuning.py uses of it: the frame
+    boundaries and the class columns of a score DataFrame ('onset', 'offset', then one column per class)."""
+    names = list(scores.columns)
+    assert names[:2] == ['onset', 'offset'], names
+    if event_classes is not None:
+        assert list(event_classes) == names[2:], (event_classes, names)
+    return np.concatenate((scores['onset'].to_numpy(), scores['offset'].to_numpy()[-1:])), names[2:]
+
+
+import sed_scores_eval.utils.scores as sse_scores               # noqa: E402
+sse_scores.validate_score_dataframe = _validate_score_dataframe
+
 sys.path.insert(0, '/root/reference')
 from pb_sed.models.weak_label.crnn import CRNN as RefFBCRNN     # noqa: E402
 from pb_sed.models.strong_label.crnn import CRNN as RefBiCRNN   # noqa: E402
@@ -652,7 +666,67 @@ def gen_pseudo_label():
     print('ref_pseudo_label', len(cases), 'cases')
 
 
+def tuning_inputs():
+    """Synthetic score DataFrames / tags / targets for the tuning drivers: 9 clips (two of them shorter), 3 classes, float32
+    scores with class activity where the target says so.  Shared with tests/test_host_logic.py."""
+    import pandas as pd
+    rng = np.random.default_rng(31)
+    classes = ['Blender', 'Dog', 'Speech']
+    scores, tags, targets = {}, {}, {}
+    for i in range(9):
+        t = 33 if i in (2, 6) else 40
+        tgt = (rng.random(3) < .5).astype(np.float64)
+        x = rng.random((t, 3)) * .45
+        for k in range(3):
+            if tgt[k]:
+                on = int(rng.integers(0, t - 12))
+                x[on:on + int(rng.integers(6, 12)), k] += .5
+            for _ in range(2):                                          # isolated spikes: what a median filter removes
+                x[int(rng.integers(0, t)), k] = rng.random()
+        x = np.clip(x, 0, 1).astype(np.float32)
+        ts = np.round(np.arange(t + 1) * .02, 6)
+        aid = f'clip{i}'
+        scores[aid] = pd.DataFrame(np.concatenate((ts[:-1, None], ts[1:, None], x.astype(np.float64)), axis=1), columns=['onset', 'offset', *classes])
+        noisy = tgt.copy()
+        if i in (1, 5):
+            noisy[i % 3] = 1 - noisy[i % 3]                             # tags that disagree with the targets
+        tags[aid], targets[aid] = noisy, tgt
+    return classes, scores, tags, targets
+
+
+def _board_arrays(prefix, leaderboard, classes, cases):
+    for metric_name, (values, params, scores) in leaderboard.items():
+        cases[f'{prefix}/{metric_name}/values'] = np.array([values[c] for c in classes + ['macro_average']])
+        cases[f'{prefix}/{metric_name}/params'] = np.array(repr({c: dict(sorted(params[c].items())) for c in classes}))
+        for aid in sorted(scores):
+            cases[f'{prefix}/{metric_name}/scores/{aid}'] = scores[aid][classes].to_numpy()
+
+
+def gen_tuning():
+    """pb_sed/models/base/tuning.py: update_leaderboard, tune_tagging, tune_boundaries_detection, tune_sound_event_detection and
+    boundaries_from_events, run on synthetic score DataFrames with two deterministic metric functions (tests/stubs.py)."""
+    import importlib
+    from tests.stubs import make_tuning_metrics
+    ref_tu = importlib.import_module('pb_sed.models.base.tuning')
+    classes, scores, tags, targets = tuning_inputs()
+    metrics = make_tuning_metrics(targets, classes)
+    cases = {'classes': np.array(classes)}
+    for aid in sorted(scores):
+        cases[f'inputs/scores/{aid}'] = scores[aid].to_numpy()
+        cases[f'inputs/tags/{aid}'], cases[f'inputs/targets/{aid}'] = tags[aid], targets[aid]
+    _board_arrays('tagging', ref_tu.tune_tagging(scores, [1, 3, 7], metrics, minimize=['leak']), classes, cases)
+    _board_arrays('boundaries', ref_tu.tune_boundaries_detection(scores, [1, 5], [0, 4, 10], tags, metrics, minimize={'hit_rate': False, 'leak': True},
+                                                                 tag_masking='?'), classes, cases)
+    _board_arrays('sed', ref_tu.tune_sound_event_detection(scores, [1, 5, 11], tags, metrics, minimize=['leak'],
+                                                           tag_masking={'hit_rate': True, 'leak': '?'}), classes, cases)
+    gt = {'a': [(0.5, 1.0, 'Dog'), (2.0, 2.5, 'Dog'), (0.1, 4.0, 'Speech'), (3.0, 3.5, 'Dog')], 'b': [], 'c': [(1.0, 2.0, 'Blender')]}
+    cases['boundaries_from_events'] = np.array(repr(ref_tu.boundaries_from_events(gt)))
+    np.savez_compressed(os.path.join(OUT, 'ref_tuning.npz'), **cases)
+    print('ref_tuning', len(cases), 'arrays')
+
+
 if __name__ == '__main__':
+    gen_tuning()
     gen_pseudo_label()
     gen_fbcrnn_loss()
     gen_bicrnn_loss()

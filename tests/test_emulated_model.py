@@ -352,3 +352,29 @@ def test_two_data_parallel_ranks_on_the_cpu_reproduce_the_single_rank_step(monke
     rel = ((r0['grad'] - single).norm() / single.norm()).item()
     assert rel < 2e-5, rel
     assert (r0['param'] - param).abs().max().item() < 1e-5
+
+
+def test_tuning_drivers_on_the_emulated_device_reproduce_the_reference_leaderboards(device, tmp_path):
+    """pb_sed_amd.tuning (median-filter / step-filter / tag-masking leaderboard search, pb_sed/models/base/tuning.py) with its filters
+    running as the HIP kernels of csrc/postproc.hip on the emulated device: the leaderboards the REFERENCE's drivers produced for the
+    same score DataFrames and metric functions (tests/golden/ref_tuning.npz) - metric values, tuned hyper-parameters per class and
+    the winning score column of every clip, bit for bit; clips of two lengths (one launch per length).  Then the JSON hand-off
+    (`<stage>_hyper_params_<metric>.json`) and the TSV reader behind boundaries_from_events."""
+    import json
+    from tests import tuning_case
+    assert tuning_case.replay('cpu') == 3 * 2 * 9
+    assert {'pbsed_medfilt', 'pbsed_boundariesfilt'} <= set(device.calls)
+    import pandas as pd
+    from pb_sed_amd import tuning
+    ts = np.round(np.arange(11) * .02, 6)
+    x = np.random.RandomState(0).rand(10, 2).astype(np.float32).astype(np.float64)
+    scores = {'c0': pd.DataFrame(np.concatenate((ts[:-1, None], ts[1:, None], x), 1), columns=['onset', 'offset', 'A', 'B'])}
+    metric = {'peak': lambda s: ({'A': float(s['c0']['A'].max()), 'B': float(s['c0']['B'].max()), 'macro_average': 0.}, {'A': {'threshold': .5}})}
+    board = tuning.tune_tagging(scores, [1, 3], metric, storage_dir=tmp_path, device='cpu', verbose=False)
+    stored = json.load(open(tmp_path / 'tagging_hyper_params_peak.json'))
+    assert stored['A'] == {'medfilt_length': board['peak'][1]['A']['medfilt_length'], 'threshold': .5, 'peak': board['peak'][0]['A']}
+    with pytest.raises(ValueError):
+        tuning.tune_tagging({'c0': scores['c0'] * (1 / 3)}, [3], metric, device='cpu', verbose=False)      # not float32 values: refused, not rounded
+    tsv = tmp_path / 'gt.tsv'
+    tsv.write_text('filename\tonset\toffset\tevent_label\na.wav\t0.5\t1.0\tDog\na.wav\t2.0\t2.5\tDog\nb.wav\t\t\t\n')
+    assert tuning.boundaries_from_events(str(tsv)) == {'a': [(0.5, 2.5, 'Dog')], 'b': []}

@@ -354,3 +354,53 @@ def test_target_encoding_bit_exact_vs_the_reference(golden):
         np.testing.assert_array_equal(bnd[i, :, :seq[i]].cpu().numpy(), g[f'targets/{n}/boundary'])
         np.testing.assert_array_equal(strong[i, :, :seq[i]].cpu().numpy(), g[f'targets/{n}/strong'])
         assert not bnd[i, :, seq[i]:].any() and not strong[i, :, seq[i]:].any()
+
+
+def test_tuning_drivers_reproduce_the_reference_leaderboards():
+    """pb_sed_amd.tuning on the GPU against tests/golden/ref_tuning.npz (leaderboards of the reference's own
+    pb_sed/models/base/tuning.py): metric values, tuned hyper-parameters and every winning score column bit for bit."""
+    from tests import tuning_case
+    assert tuning_case.replay(DEV) == 3 * 2 * 9
+
+
+def test_model_level_tuning_wrappers_search_window_and_filter_lengths():
+    """weak_label.tune_tagging / tune_boundary_detection / tune_sound_event_detection (pb_sed/models/weak_label/crnn.py:343-421) on a
+    two-model FBCRNN ensemble in miniature: each equals the inference pass + the leaderboard search done by hand; the windowed
+    search keeps, per class, the best (window length, median filter, tag masking) of all passes."""
+    from pb_sed_amd import inference as inf, tuning
+    from pb_sed_amd.models import weak_label
+    from tests.stubs import make_tuning_metrics
+    from tests.test_gpu_model import TINY, synth_batch
+    torch.manual_seed(5)
+    kw = dict(num_events=4, number_of_filters=128, hidden_size=64, num_layers=2, net=TINY)
+    models = [weak_label.CRNN.build(**kw) for _ in range(2)]
+    wav, seq, *_ = synth_batch(6, 16000 * 2, 4, seed=9)
+    ids = [f'c{i}' for i in range(6)]
+    dataset = [{'audio_data': wav[:3], 'seq_len': seq[:3].tolist(), 'example_id': ids[:3]},
+               {'audio_data': wav[3:], 'seq_len': seq[3:].tolist(), 'example_id': ids[3:]}]
+    classes = ['Blender', 'Cat', 'Dog', 'Speech']
+    timestamps = np.round(np.arange(0, 1000) * .02, 6)
+    rng = np.random.RandomState(1)
+    targets = {a: (rng.rand(4) < .5).astype(np.float64) for a in ids}
+    tags = {a: np.maximum(targets[a], (rng.rand(4) < .2).astype(np.float64)) for a in ids}
+    metrics = make_tuning_metrics(targets, classes)
+    board = weak_label.tune_tagging(models, dataset, DEV, timestamps, classes, metrics, minimize=['leak'])
+    by_hand = tuning.tune_tagging(inf.tagging(models, dataset, DEV, timestamps=timestamps, event_classes=classes), [1], metrics,
+                                  minimize=['leak'], device=DEV, verbose=False)
+    assert board['hit_rate'][0] == by_hand['hit_rate'][0] and board['leak'][1] == by_hand['leak'][1]
+    board = weak_label.tune_boundary_detection(models, dataset, DEV, timestamps, classes, tags, metrics, [0, 4], minimize=['leak'])
+    assert all(p['stepfilt_length'] in (0, 4) and p['tag_masked'] in (False, True) for p in board['leak'][1].values())
+    board = weak_label.tune_sound_event_detection(models, dataset, DEV, timestamps, classes, tags, metrics, window_lengths=[10, 20],
+                                                  window_shift=2, medfilt_lengths=[1, 5], minimize=['leak'], tag_masking='?')
+    per_window = {}
+    for win in (10, 20):
+        scores = inf.sound_event_detection(models, dataset, DEV, model_kwargs={'window_length': win, 'window_shift': 2},
+                                           timestamps=timestamps[::2], event_classes=classes)
+        per_window[win] = tuning.tune_sound_event_detection(scores, [1, 5], tags, metrics, minimize=['leak'], tag_masking='?',
+                                                            device=DEV, verbose=False)
+    for name, sign in (('hit_rate', 1.), ('leak', -1.)):
+        for c in classes:
+            best = max(per_window[w][name][0][c] * sign for w in (10, 20))
+            assert board[name][0][c] * sign == best, (name, c)
+            assert board[name][1][c]['window_length'] in (10, 20) and board[name][1][c]['window_shift'] == 2
+            assert np.isfinite(board[name][0][c])
