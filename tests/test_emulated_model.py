@@ -378,3 +378,35 @@ def test_tuning_drivers_on_the_emulated_device_reproduce_the_reference_leaderboa
     tsv = tmp_path / 'gt.tsv'
     tsv.write_text('filename\tonset\toffset\tevent_label\na.wav\t0.5\t1.0\tDog\na.wav\t2.0\t2.5\tDog\nb.wav\t\t\t\n')
     assert tuning.boundaries_from_events(str(tsv)) == {'a': [(0.5, 2.5, 'Dog')], 'b': []}
+
+
+def test_launch_cu_budget_cuts_the_weight_gradient_grid_not_its_result(library):
+    """pbsed_set_launch_cus (the CU budget SIDE_WGRAD sets around the launches it puts beside a persistent scan): with a budget
+    below the device's CU count the weight-gradient launchers cut their persistent grids for fewer CUs - other shares of the
+    (clip, row, column) units per workgroup, other partial sums - and the gradient is the same to fp32 summation order; the
+    previous budget is handed back, 0 restores the whole device."""
+    import ctypes as C
+    rng = np.random.RandomState(3)
+    b, cin, cout, f, t = 4, 32, 32, 4, 64
+    x = rng.randn(b, cin, f, t).astype(np.float32)
+    g = rng.randn(b, cout, f, t).astype(np.float32)
+    seq = np.array([64, 60, 50, 33], np.int32)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    out = {}
+    assert library.pbsed_set_launch_cus(0) == 0
+    for budget in (0, 2):
+        assert library.pbsed_set_launch_cus(budget) == 0
+        dw, db = np.zeros((cout, cin, 3, 3), np.float32), np.zeros(cout, np.float32)
+        rc = library.pbsed_conv_bwd_weight(P(x), None, None, 0, P(seq), P(g), None, P(dw), P(db), b, cin, cout, f, t, 3, 3, None)
+        assert rc == 0, library.pbsed_last_error()
+        assert library.pbsed_set_launch_cus(0) == budget
+        out[budget] = (dw, db)
+    xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (1, 1), (1, 1)))
+    ref = np.zeros((cout, cin, 3, 3))
+    for i in range(3):
+        for j in range(3):
+            ref[:, :, i, j] = np.einsum('boft,bcft->oc', g.astype(np.float64), xp[:, :, i:i + f, j:j + t])
+    for budget in (0, 2):
+        assert np.abs(out[budget][0] - ref).max() < 3e-5 * np.abs(ref).max(), budget
+    assert np.abs(out[2][0] - out[0][0]).max() < 2e-6 * np.abs(ref).max()
+    assert np.abs(out[2][1] - out[0][1]).max() < 2e-6 * np.abs(out[0][1]).max()

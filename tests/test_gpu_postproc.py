@@ -381,7 +381,7 @@ def test_model_level_tuning_wrappers_search_window_and_filter_lengths():
     classes = ['Blender', 'Cat', 'Dog', 'Speech']
     timestamps = np.round(np.arange(0, 1000) * .02, 6)
     rng = np.random.RandomState(1)
-    targets = {a: (rng.rand(4) < .5).astype(np.float64) for a in ids}
+    targets = {a: np.array([(i + k) % 2 for k in range(4)], np.float64) for i, a in enumerate(ids)}     # every class has both kinds of clips
     tags = {a: np.maximum(targets[a], (rng.rand(4) < .2).astype(np.float64)) for a in ids}
     metrics = make_tuning_metrics(targets, classes)
     board = weak_label.tune_tagging(models, dataset, DEV, timestamps, classes, metrics, minimize=['leak'])
