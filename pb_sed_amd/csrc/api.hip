@@ -1,4 +1,5 @@
 // C-ABI glue: error reporting + convolution entry points (see include/pbsed.h for the contract).
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -44,10 +45,10 @@ int device_cus() {
 // Grid-sizing budget of the persistent weight-gradient launchers (pbsed_set_launch_cus): a launch that is meant to run BESIDE a
 // persistent scan must not be cut for the whole device - its grid would be static shares of a device it does not get, and the
 // blocks that find no CU wait for the scan to end (the launch then takes scan + its own time, as if it had not been moved).
-static int g_launch_cus = 0;
+static std::atomic<int> g_launch_cus{0};
 int launch_cus() {
-    const int n = device_cus();
-    return g_launch_cus > 0 && g_launch_cus < n ? g_launch_cus : n;
+    const int n = device_cus(), budget = g_launch_cus.load(std::memory_order_relaxed);
+    return budget > 0 && budget < n ? budget : n;
 }
 
 namespace {
@@ -128,9 +129,7 @@ size_t pbsed_scratch_bytes(void) { return (size_t)160 << 20; }
 
 // CU budget of the weight-gradient launchers (launch_cus above); 0 = the whole device.  Returns the previous budget.
 int pbsed_set_launch_cus(int cus) {
-    const int old = g_launch_cus;
-    g_launch_cus = cus > 0 ? cus : 0;
-    return old;
+    return g_launch_cus.exchange(cus > 0 ? cus : 0, std::memory_order_relaxed);
 }
 
 int pbsed_set_scratch(void* scratch, size_t bytes, void* stream) {

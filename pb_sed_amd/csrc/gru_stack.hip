@@ -10,8 +10,10 @@
 //
 // Reference op site: torch.nn.GRU(num_layers=2) inside padertorch's GRU wrapper,
 // pb_sed/models/weak_label/crnn.py:61-67,338-340 (config training.py:243-248).
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -990,9 +992,11 @@ int pbsed_gru_stack_fwd(int nchains, int nlayers, const float* const* gi0, const
 __global__ void xcc_probe_kernel(unsigned* out) {
     if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
 }
-static int g_xcd_local_allowed = 1;                   // pbsed_gru_set_xcd_local
+static std::atomic<int> g_xcd_local_allowed{1};       // pbsed_gru_set_xcd_local (any host thread may call it beside a launching one)
+static std::mutex g_xcd_mu;                           // the probe's per-device verdicts below
 static int g_xcd_state[64] = {0};                     // per device ordinal: 0 not probed, 1 verified, -1 refused
 static bool xcd_placement(hipStream_t s, unsigned* map) {
+    std::lock_guard<std::mutex> lock(g_xcd_mu);
     int (&state)[64] = g_xcd_state;
     static unsigned maps[64] = {0};
     int dev = 0;
@@ -1043,7 +1047,7 @@ static bool granule_xcd_grid(GruStackArgs& a, int H, dim3* grid, hipStream_t s, 
     // it returns the stale line and pays a retry) and keep the sc1 exchange.
     // Only where the placement probe has SEEN the ring-per-XCD placement on this device (xcd_placement above).
     static const bool local_off = getenv("PBSED_GRU_XCD_LOCAL") && getenv("PBSED_GRU_XCD_LOCAL")[0] == '0';
-    a.local = (bwd && !local_off && g_xcd_local_allowed && xcd_placement(s, &a.xcc_map)) ? 1 : 0;
+    a.local = (bwd && !local_off && g_xcd_local_allowed.load(std::memory_order_relaxed) && xcd_placement(s, &a.xcc_map)) ? 1 : 0;
     return true;
 }
 
@@ -1308,9 +1312,11 @@ int pbsed_gru_set_prof(unsigned long long* buf, int block) {
 // exchanges through write-through stores and sc1 loads, correct under any workgroup placement), on = 1 allows it again where
 // the placement probe (run anew) verifies the device.  The caller turns it off when a scan reports error bit 2.  Returns the old value.
 int pbsed_gru_set_xcd_local(int on) {
-    const int old = g_xcd_local_allowed;
-    g_xcd_local_allowed = on != 0;
-    if (on) for (int& st : g_xcd_state) st = 0;       // allowed again: every device is probed anew at its next BPTT scan
+    const int old = g_xcd_local_allowed.exchange(on != 0, std::memory_order_relaxed);
+    if (on) {                                         // allowed again: every device is probed anew at its next BPTT scan
+        std::lock_guard<std::mutex> lock(g_xcd_mu);
+        for (int& st : g_xcd_state) st = 0;
+    }
     return old;
 }
 
