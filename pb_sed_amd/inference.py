@@ -250,7 +250,59 @@ def sound_event_detection(models, dataset, device, model_kwargs=None, medfilt_le
                      apply_mask=apply_mask, masks=masks, timestamps=timestamps, event_classes=event_classes, **kw)
 
 
-def shift_and_widen_events(event_lists, pseudo_widening=0., onset_bias=None, offset_bias=None):
+def load_hyper_params(hyper_params_dir, stage, names=('f',)):
+    """The tuned hyper-parameters ``pb_sed_amd.tuning`` (or the reference's tuning scripts) wrote:
+    ``<dir>/<stage>_hyper_params_<name>.json`` for stage 'tagging' / 'boundaries_detection' / 'sed'; one dict
+    ``{event_class: {...}}`` per name (pb_sed/experiments/weak_label_crnn/inference.py:71,147,213-216)."""
+    import json
+    import os
+    names = [names] if isinstance(names, str) else list(names)
+    out = []
+    for name in names:
+        with open(os.path.join(str(hyper_params_dir), f'{stage}_hyper_params_{name}.json')) as f:
+            out.append(json.load(f))
+    return out
+
+
+def sed_hyper_param_arrays(hyper_params, event_classes):
+    """Per-variant, per-class arrays for ONE ensemble pass over several tuned parameter sets
+    (pb_sed/experiments/weak_label_crnn/inference.py:239-262, pb_sed/experiments/strong_label_crnn/inference.py:117-122):
+    ``medfilt_length`` / ``apply_mask`` [n, K] for ``sound_event_detection``; for FBCRNN parameter sets also
+    ``model_kwargs = {'window_length': [n, K], 'window_shift': s}`` (one shift for all, as the reference demands) and the
+    timestamp stride; ``thresholds``: per variant {class: threshold} or None where the metric has none (PSDS)."""
+    hyper_params = [hyper_params] if isinstance(hyper_params, dict) else list(hyper_params)
+    n, k = len(hyper_params), len(event_classes)
+    medfilt, masked = np.zeros((n, k)), np.zeros((n, k))
+    windowed = 'window_length' in hyper_params[0][event_classes[0]]
+    window, shifts = np.zeros((n, k)), set()
+    for i, hp in enumerate(hyper_params):
+        for j, c in enumerate(event_classes):
+            medfilt[i, j], masked[i, j] = hp[c]['medfilt_length'], hp[c]['tag_masked']
+            if windowed:
+                window[i, j] = hp[c]['window_length']
+                shifts.add(hp[c]['window_shift'])
+    out = {'medfilt_length': medfilt, 'apply_mask': masked, 'model_kwargs': None, 'timestamp_stride': 1,
+           'thresholds': [{c: hp[c]['threshold'] for c in event_classes} if 'threshold' in hp[event_classes[0]] else None
+                          for hp in hyper_params]}
+    if windowed:
+        if len(shifts) != 1:
+            raise ValueError('Inference with multiple window shifts is not supported.')
+        shift = int(shifts.pop())
+        out['model_kwargs'] = {'window_length': window, 'window_shift': shift}
+        out['timestamp_stride'] = shift
+    return out
+
+
+def tags_from_scores(tagging_scores, hyper_params, event_classes):
+    """Clip-level tags of the tagging ensemble: score of each class against its tuned threshold
+    (pb_sed/experiments/weak_label_crnn/inference.py:124-135).  ``tagging_scores``: {audio_id: [1, K]} as ``tagging`` returns
+    them.  Returns (tags {audio_id: bool [K]}, scores {audio_id: [K]})."""
+    thresholds = np.array([hyper_params[c]['threshold'] for c in event_classes])
+    scores = {a: np.asarray(s)[0] for a, s in tagging_scores.items()}
+    return {a: s > thresholds for a, s in scores.items()}, scores
+
+
+def shift_and_widen_events(event_lists, pseudo_widening=0., onset_bias=None, offset_bias=None, decimals=None):
     """Boundary correction applied to detected events before they are written out as pseudo labels
     (pb_sed/experiments/strong_label_crnn/inference.py:177-184): onsets move earlier by ``pseudo_widening`` plus the
     class' tuned onset bias (clamped at 0 s), offsets later by ``pseudo_widening`` minus its offset bias; events that
@@ -260,8 +312,11 @@ def shift_and_widen_events(event_lists, pseudo_widening=0., onset_bias=None, off
     for clip_id, events in event_lists.items():
         kept = []
         for onset, offset, label in events:
-            on = max(onset - pseudo_widening - onset_bias.get(label, 0), 0)
+            on = onset - pseudo_widening - onset_bias.get(label, 0)
             off = offset + pseudo_widening - offset_bias.get(label, 0)
+            if decimals is not None:             # the boundaries path rounds to milliseconds (weak_label_crnn/inference.py:190-191)
+                on, off = np.round(on, decimals), np.round(off, decimals)
+            on = max(on, 0)
             if off > on:
                 kept.append((on, off, label))
         out[clip_id] = kept

@@ -568,3 +568,34 @@ def test_pseudo_label_hand_off_matches_the_reference(tmp_path):
     path = tmp_path / 'validation_pseudo_labeled.tsv'
     pl.write_event_tsv(path, {'a': [(0.5, 1.25, 'Dog'), (2.0, 3.0, 'Cat')], 'b': []})
     assert open(path).read() == 'filename\tonset\toffset\tevent_label\na.wav\t0.5\t1.25\tDog\na.wav\t2.0\t3.0\tCat\nb.wav\t\t\t\n'
+
+
+def test_tuned_hyper_params_round_trip_into_the_inference_arguments(tmp_path):
+    """The JSON files the tuning drivers write (`<stage>_hyper_params_<metric>.json`) read back into what ONE ensemble pass over
+    several tuned parameter sets takes (pb_sed/experiments/weak_label_crnn/inference.py:213-262, strong_label_crnn/inference.py:117-122):
+    [variants, classes] arrays of median-filter lengths / tag masking / window lengths, a single window shift (two are refused),
+    thresholds per variant (None for a metric without one); tags from tuned thresholds; the boundaries path's millisecond rounding."""
+    import json
+    from pb_sed_amd import inference as inf
+    classes = ['Cat', 'Dog']
+    f = {'Cat': {'medfilt_length': 5, 'tag_masked': True, 'window_length': 20, 'window_shift': 4, 'threshold': .4, 'f': .7},
+         'Dog': {'medfilt_length': 11, 'tag_masked': False, 'window_length': 40, 'window_shift': 4, 'threshold': .6, 'f': .8}}
+    psds = {c: {'medfilt_length': 1, 'tag_masked': False, 'window_length': 10, 'window_shift': 4, 'psds1': .3} for c in classes}
+    for name, hp in (('f', f), ('psds1', psds)):
+        json.dump(hp, open(tmp_path / f'sed_hyper_params_{name}.json', 'w'))
+    hps = inf.load_hyper_params(tmp_path, 'sed', ['f', 'psds1'])
+    arrs = inf.sed_hyper_param_arrays(hps, classes)
+    assert arrs['medfilt_length'].tolist() == [[5, 11], [1, 1]] and arrs['apply_mask'].tolist() == [[1, 0], [0, 0]]
+    assert arrs['model_kwargs']['window_length'].tolist() == [[20, 40], [10, 10]] and arrs['model_kwargs']['window_shift'] == 4
+    assert arrs['timestamp_stride'] == 4 and arrs['thresholds'] == [{'Cat': .4, 'Dog': .6}, None]
+    psds['Dog']['window_shift'] = 2
+    with pytest.raises(ValueError):
+        inf.sed_hyper_param_arrays([f, psds], classes)
+    plain = inf.sed_hyper_param_arrays({c: {'medfilt_length': 3, 'tag_masked': True, 'threshold': .5} for c in classes}, classes)
+    assert plain['model_kwargs'] is None and plain['timestamp_stride'] == 1 and plain['medfilt_length'].shape == (1, 2)
+    tags, scores = inf.tags_from_scores({'a': np.array([[.5, .5]], np.float32), 'b': np.array([[.3, .9]], np.float32)}, f, classes)
+    assert tags['a'].tolist() == [True, False] and tags['b'].tolist() == [False, True] and scores['b'].shape == (2,)
+    ev = {'a': [(0.1234, 1.0, 'Dog'), (2.0, 2.0004, 'Cat')]}
+    out = inf.shift_and_widen_events(ev, 0., {'Dog': .2}, {'Dog': 0.}, decimals=3)
+    assert out == {'a': [(0.0, 1.0, 'Dog')]}                 # onset clamped at 0; the 0.4 ms event rounds to nothing
+    assert inf.shift_and_widen_events(ev, 0., {'Dog': .02}, None, decimals=3)['a'][0][0] == 0.103
