@@ -3,7 +3,7 @@
 #   gpurun --timeout 1500 -- tools/r06_queue.sh 1     HEAD on the hardware record: the GPU suite, the default bench line, smoke()
 #   gpurun --timeout 2400 -- tools/r06_queue.sh 2     the rocprofv3 set of profiles/ (tools/run_profiles.sh) for HEAD
 #   gpurun --timeout 2700 -- tools/r06_queue.sh 3     A/B of everything parked: the patch stack (tools/micro/attic), SIDE_WGRAD,
-#                                                     PBSED_WGRAD_XCD_COLS, PBSED_GRU_XCD_LOCAL, PBSED_FUSE_BN_BWD
+#                                                     (now with its CU budget), PBSED_WGRAD_XCD_COLS, PBSED_FUSE_BN_BWD
 # Everything lands under gpurun_out/r06_*; copy what is to be judged into profiles/.
 mkdir -p gpurun_out
 stage=${1:-1}
@@ -23,7 +23,6 @@ elif [ "$stage" = 3 ]; then
   tools/ab_bench.sh PBSED_WGRAD_XCD_COLS c2 2>&1 | tee gpurun_out/r06_ab_wgrad_xcd_cols.txt
   tools/ab_bench.sh PBSED_SIDE_WGRAD c2 2>&1 | tee gpurun_out/r06_ab_side_wgrad.txt; tools/ab_bench.sh PBSED_SIDE_WGRAD c3 2>&1 | tee -a gpurun_out/r06_ab_side_wgrad.txt
   tools/ab_bench.sh PBSED_FUSE_BN_BWD c2 2>&1 | tee gpurun_out/r06_ab_fuse_bn_bwd.txt
-  tools/ab_bench.sh PBSED_C5_OVERLAP c5 2>&1 | tee gpurun_out/r06_ab_c5_overlap.txt
   tools/ab_lib.sh "c2 c5 c3" base=- scalar=$V/libpbsed_scalar.so hoist=$V/libpbsed_scalar_hoist.so s16=$V/libpbsed_s16.so s16c=$V/libpbsed_s16c.so lm=$V/libpbsed_lm.so wxe=$V/libpbsed_wxe.so era=$V/libpbsed_era.so all=$V/libpbsed_all.so 2>&1 | tee gpurun_out/r06_ab_patch_stack.txt
   tools/ab_lib.sh "deep" base=- s16=$V/libpbsed_s16.so res=$V/libpbsed_res.so all=$V/libpbsed_all.so 2>&1 | tee gpurun_out/r06_ab_deep.txt
   PBSED_LIB=$(realpath $V/libpbsed_all.so) timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee gpurun_out/r06_variant_gpu_tests.txt
