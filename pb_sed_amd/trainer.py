@@ -42,6 +42,12 @@ class GradSync:
             self._pending.append(dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM,
                                                  group=self.group, async_op=True))
 
+    def extra_sum(self, t):
+        """Sum-all-reduce a small float32 tensor beside the gradient buckets (the scans' error words, Trainer._share_flags);
+        complete after finish() like the buckets."""
+        if self.world > 1:
+            self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def finish(self):
         for i in range(len(self.buckets)):
             self.bucket_ready(i)                    # anything not announced yet
@@ -147,6 +153,11 @@ class LibraryGradSync:
         a, b = self.buckets[i]
         if b > a and self.world > 1:
             self._comm.begin(self.flat_grad.data_ptr() + 4 * a, b - a)
+
+    def extra_sum(self, t):
+        """See GradSync.extra_sum: one more pbsed_allreduce_begin on the library's stream, fenced by the same finish()."""
+        if self.world > 1:
+            self._comm.begin(t.data_ptr(), t.numel())
 
     def finish(self):
         for i in range(len(self.buckets)):
@@ -278,8 +289,16 @@ class Trainer:
         # as the host needs to get going again (0.3 .. 0.5 ms of a 10.8 ms step; 1.4 ms on a box with a slow host).  finish()
         # looks at what is still pending; flag_check_lag=0 restores the check inside the step.
         self.flag_check_lag = flag_check_lag
+        self._flags_on = self.flat_param.is_cuda       # (the emulated-device tests switch it on for CPU tensors)
         self._flags_hosts = [torch.zeros(ops.GRU_FLAG_WORDS, dtype=torch.int32).pin_memory() for _ in range(2)] \
-            if self.flat_param.is_cuda else None
+            if self.flat_param.is_cuda else [torch.zeros(ops.GRU_FLAG_WORDS, dtype=torch.int32) for _ in range(2)]
+        # Data-parallel runs: the words are AGREED ON over the ranks before Adam looks at them (_share_flags) - a hand-off that
+        # timed out on one rank must make every rank skip the update and every rank raise; a rank that skipped alone would
+        # leave the replicas with different parameters, and a rank that raised alone would leave the others waiting in the next
+        # step's collective.
+        self._flags_f32 = torch.zeros(ops.GRU_FLAG_WORDS, dtype=torch.float32, device=self.flat_param.device)
+        self._flags_agreed = torch.zeros(ops.GRU_FLAG_WORDS, dtype=torch.int32, device=self.flat_param.device)
+        self._flags_shared = False
         self._pending_checks = []
         self.last_enqueue_s = 0.            # host time of the last step up to (not including) the wait for its summary
         self.measure_sync, self.sync_events = False, None   # bench.py: event pairs around the wait for the collectives
@@ -310,6 +329,19 @@ class Trainer:
     def _on_grads_ready(self, name):
         if name in self.bucket_names:
             self.sync.bucket_ready(self.bucket_names.index(name))
+            if name == 'rnn':                        # behind the BPTT scans: this step's error words are final in stream order
+                self._share_flags()
+
+    def _share_flags(self):
+        """More than one rank: enqueue the sum over the ranks of this rank's scan error words (bit 0 and bit 1 kept apart:
+        value = bit0 + 1024 bit1, exact in float32 for up to 1023 ranks) beside the gradient buckets - 256 bytes, overlapped
+        with the CNN's backward pass like the 'rnn' bucket it rides behind.  step() decodes it after finish()."""
+        if self._flags_shared or not self._flags_on or getattr(self.sync, 'world', 1) <= 1:
+            return
+        words = ops.gru_flags(self.flat_param.device)[0]
+        self._flags_f32.copy_((words & 1) + 1024 * ((words >> 1) & 1))
+        self.sync.extra_sum(self._flags_f32)
+        self._flags_shared = True
 
     def sync_buffers(self, mode='mean'):
         """Data-parallel replicas keep their own batch-norm / feature running statistics (no SyncBN).  Before a checkpoint
@@ -386,10 +418,13 @@ class Trainer:
             self.snapshot_statistics()               # whatever was loaded since __init__ (load_init_checkpoint, copy_) is shared state
         self.model.train()
         self.flat_grad.zero_()
-        flags = ops.gru_flags(self.flat_param.device) if self.flat_param.is_cuda else None
+        flags = ops.gru_flags(self.flat_param.device) if self._flags_on else None
+        self._flags_shared = False
         outputs = self.model(dict(batch))
         review = self.model.review(batch, outputs, defer_summary=True) if self._defer else self.model.review(batch, outputs)
         review['loss'].backward()
+        if flags is not None:
+            self._share_flags()                      # (if no 'rnn' bucket announced it: frozen recurrent part)
         if self.measure_sync and self.sync_events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -398,18 +433,23 @@ class Trainer:
             self.sync_events.append((e0, e1))
         else:
             scale = self.sync.finish()
+        skip_words = None if flags is None else flags[0]
+        if self._flags_shared:                       # the ranks' words, summed: any rank's bit is every rank's bit
+            f = self._flags_f32
+            self._flags_agreed.copy_((torch.remainder(f, 1024) > 0).to(torch.int32) + 2 * (f >= 1024).to(torch.int32))
+            skip_words = self._flags_agreed
         self.iteration += 1
         ops.grad_sumsq(self.flat_grad, self.sumsq)
         ops.adam_step(self.flat_param, self.flat_grad, self.m, self.v, lr=self.lr, beta1=self.betas[0],
                       beta2=self.betas[1], eps=self.eps, step=self.iteration, grad_scale=scale,
                       max_norm=self.clip, sumsq=self.sumsq, norm_out=self.grad_norm,
-                      skip_flags=None if flags is None else flags[0])     # a timed-out scan: no update on the device
+                      skip_flags=skip_words)     # a timed-out scan (on ANY rank): no update on the device
         ops.invalidate_packed()          # parameters changed in place behind torch's version counters
         ops.refresh_packs()              # ... and every packed copy is rebuilt in one launch
         review['scalars']['grad_norm'] = self.grad_norm
         if flags is not None and flags[1]:
             host_words = self._flags_hosts[self.iteration & 1]
-            host_words.copy_(flags[0], non_blocking=True)
+            host_words.copy_(skip_words, non_blocking=True)
             checked = torch.cuda.Event()
             checked.record()
             flags[1] = 0

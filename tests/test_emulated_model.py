@@ -322,8 +322,26 @@ def _dp_worker(rank, world, port, units_dir, out_dir):
         from pb_sed_amd.trainer import Trainer, shard_batch
         trainer = Trainer(_dp_model(), lr=1e-3, gradient_clipping=5., allreduce='torch')
         rev = trainer.step(shard_batch(_dp_batch(4), rank, world))
-        torch.save({'grad': (trainer.flat_grad / world).clone(), 'param': trainer.flat_param.clone(), 'loss': float(rev['loss'].item())},
-                   os.path.join(out_dir, f'rank{rank}.pt'))
+        out = {'grad': (trainer.flat_grad / world).clone(), 'param': trainer.flat_param.clone(), 'loss': float(rev['loss'].item())}
+        # the scans' error words are agreed on over the ranks (Trainer._share_flags; on a GPU always, here switched on by hand):
+        # (a) nobody flagged -> the step is the step it was; (b) a word raised on rank 1 ONLY (bit 1: a workgroup of an XCD-local ring
+        # on the wrong XCD) -> BOTH ranks skip the update on the device and BOTH raise, naming the cause
+        from pb_sed_amd import ops
+        trainer._flags_on = True
+        trainer.step(shard_batch(_dp_batch(4), rank, world))
+        trainer.finish()
+        out['param_after_clean_step'] = trainer.flat_param.clone()
+        if rank == 1:
+            ops.gru_flags('cpu')[0][7] = 2
+        trainer.step(shard_batch(_dp_batch(4), rank, world))
+        out['param_after_flagged_step'] = trainer.flat_param.clone()
+        out['agreed'] = trainer._flags_agreed.clone()
+        try:
+            trainer.finish()
+            out['raised'] = ''
+        except RuntimeError as ex:
+            out['raised'] = str(ex)
+        torch.save(out, os.path.join(out_dir, f'rank{rank}.pt'))
     mp.undo()
     dist.destroy_process_group()
 
@@ -341,6 +359,12 @@ def test_two_data_parallel_ranks_on_the_cpu_reproduce_the_single_rank_step(monke
     r0, r1 = (torch.load(tmp_path / f'rank{r}.pt') for r in range(2))
     assert np.isfinite(r0['loss']) and np.isfinite(r1['loss'])
     assert torch.equal(r0['grad'], r1['grad']) and torch.equal(r0['param'], r1['param']), 'ranks diverged'
+    for r in (r0, r1):
+        assert not torch.equal(r['param_after_clean_step'], r['param'])                          # a clean step with the words shared: updated
+        assert torch.equal(r['param_after_flagged_step'], r['param_after_clean_step'])           # rank 1's word: no update on EITHER rank
+        assert int(r['agreed'][7]) == 2 and int(r['agreed'].sum()) == 2
+        assert 'XCD' in r['raised'], r['raised']                                                 # both raise, with the cause of bit 1
+    assert torch.equal(r0['param_after_clean_step'], r1['param_after_clean_step'])
     with cpu_device.emulated_device(monkeypatch, library):
         from pb_sed_amd.trainer import Trainer
         batch = _dp_batch(4)
