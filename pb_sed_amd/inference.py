@@ -229,6 +229,40 @@ def inference(model, method, dataset, device, max_segment_length=None, segment_o
     return scores
 
 
+def gather_results(results, dst=None, group=None):
+    """Merge the per-rank result dictionaries of a sharded ``inference(..., rank=r, world_size=n)`` pass ({example_id: scores /
+    DataFrame / event list}; a list of such dictionaries - one per filter variant - is merged position by position).  Clips are
+    independent, so the data path has no collective (config 5); this is the control-plane step behind it, for whatever needs all
+    clips in one place - tuning, evaluation, pseudo labels: host objects through ``torch.distributed.all_gather_object`` (every rank
+    gets the merged dictionary) or, with ``dst``, ``gather_object`` (only that rank; the others get None).  No process group / one
+    rank: the input comes back.  An example_id reported by two ranks is an error (the shards must partition the batches)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return results
+    world = dist.get_world_size(group)
+    if dst is None:
+        parts = [None] * world
+        dist.all_gather_object(parts, results, group=group)
+    else:
+        parts = [None] * world if dist.get_rank(group) == dst else None
+        dist.gather_object(results, parts, dst=dst, group=group)
+        if parts is None:
+            return None
+
+    def merge(dicts):
+        out = {}
+        for d in dicts:
+            twice = out.keys() & d.keys()
+            if twice:
+                raise ValueError(f'gather_results: {sorted(twice)[:3]} reported by more than one rank')
+            out.update(d)
+        return out
+    if isinstance(results, (list, tuple)):
+        assert all(len(p) == len(results) for p in parts), [len(p) for p in parts]
+        return [merge([p[i] for p in parts]) for i in range(len(results))]
+    return merge(parts)
+
+
 def tagging(models, dataset, device, model_kwargs=None, medfilt_length=1, method='tagging', timestamps=None,
             event_classes=None, **kw):
     return inference(models, method, dataset, device, model_kwargs=model_kwargs, medfilt_length=medfilt_length,

@@ -337,6 +337,41 @@ def test_library_gradsync_failures_are_agreed_on_by_all_ranks(tmp_path, monkeypa
         assert open(tmp_path / f'fail{r}').read() == 'True'
 
 
+def _gather_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import numpy as np
+    from pb_sed_amd import inference as inf
+    mine = {f'clip{i}': np.full((3, 2), float(i)) for i in range(5) if i % world == rank}
+    ok = True
+    merged = inf.gather_results(mine)
+    ok = ok and sorted(merged) == [f'clip{i}' for i in range(5)] and all(merged[f'clip{i}'][0, 0] == i for i in range(5))
+    only0 = inf.gather_results(mine, dst=0)
+    ok = ok and ((sorted(only0) == sorted(merged)) if rank == 0 else only0 is None)
+    variants = inf.gather_results([mine, {k: v + 10 for k, v in mine.items()}])
+    ok = ok and len(variants) == 2 and variants[1]['clip3'][0, 0] == 13 and sorted(variants[0]) == sorted(merged)
+    try:
+        inf.gather_results({'same_id': np.zeros(1)})
+        ok = False
+    except ValueError:
+        pass
+    with open(os.path.join(out_dir, f'gather{rank}'), 'w') as f:
+        f.write(str(bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_sharded_inference_results_are_merged_across_ranks(tmp_path):
+    """Config 5 shards the clips over the ranks with no collective on the data path; inference.gather_results is the control-plane
+    step behind it (all ranks / one rank; variant lists position by position; a clip reported twice is refused).  Without a
+    process group the input comes back."""
+    from pb_sed_amd import inference as inf
+    assert inf.gather_results({'a': 1}) == {'a': 1}
+    mp.spawn(_gather_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f'gather{r}').read() == 'True'
+
+
 def test_make_grad_sync_defaults():
     """One process / CPU tensors -> torch.distributed path; the library path is the default only with > 1 rank on GPUs."""
     from pb_sed_amd.trainer import GradSync, LibraryGradSync, make_grad_sync
